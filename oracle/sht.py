@@ -1,0 +1,180 @@
+"""Spherical-harmonic synthesis oracle (test infrastructure only).
+
+Restates what the reference obtains from ``healpy.alm2map(almp, nside)``
+(cora/util/hputil.py:369-391) following the published HEALPix definition
+(SURVEY.md Appendix A).  PARITY UNPINNED against healpy itself (absent here);
+pinned against brute-force ``scipy.special.sph_harm_y`` sums in tests/.
+
+Three implementations, slowest to fastest:
+  * ``alm2map_bruteforce``  - independent: sum a_lm Y_lm via scipy (tiny sizes)
+  * ``alm2map_numpy``       - scaled Legendre recurrence in numpy
+  * ``alm2map``             - same recurrence in C/OpenMP (oracle/sht_ref.c)
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+from . import healpix
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_lib = None
+
+
+def _load():
+    global _lib
+    if _lib is None:
+        so = os.path.join(_HERE, "liboracle.so")
+        if not os.path.exists(so):
+            subprocess.check_call(["make", "-C", _HERE, "-s"])
+        _lib = ctypes.CDLL(so)
+        dp = ctypes.POINTER(ctypes.c_double)
+        _lib.oracle_legendre_synth.argtypes = [ctypes.c_int, ctypes.c_int, dp, dp, dp, dp, dp]
+        _lib.oracle_legendre_synth.restype = None
+        _lib.oracle_lambda_lm.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_double, dp]
+        _lib.oracle_lambda_lm.restype = None
+        _lib.oracle_num_threads.restype = ctypes.c_int
+    return _lib
+
+
+def num_threads():
+    return int(_load().oracle_num_threads())
+
+
+def _dp(a):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+
+
+def alm_index(l, m, lmax):
+    """healpy packed index (cora/util/hputil.py:124-152 ordering)."""
+    return m * (2 * lmax + 1 - m) // 2 + l
+
+
+def lambda_lm(lmax, m, x):
+    """lambda_lm(x) for l = m..lmax via the C recurrence."""
+    out = np.zeros(lmax - m + 1)
+    sth = np.sqrt((1.0 - x) * (1.0 + x))
+    _load().oracle_lambda_lm(lmax, m, float(x), float(sth), _dp(out))
+    return out
+
+
+def _legendre_numpy(lmax, z, sth, alm):
+    """F_m on north rings / mirrored south rings; numpy restatement."""
+    L = lmax + 1
+    npair = len(z)
+    fn = np.zeros((npair, L), dtype=np.complex128)
+    fs = np.zeros((npair, L), dtype=np.complex128)
+    lp = np.empty(L)
+    lp[0] = -0.5 * np.log2(4.0 * np.pi)
+    for m in range(1, L):
+        lp[m] = lp[m - 1] + 0.5 * np.log2((2.0 * m + 1.0) / (2.0 * m))
+    l2s = np.log2(sth)
+    for m in range(L):
+        L2 = lp[m] + m * l2s
+        sc = np.floor(L2).astype(np.int64)
+        lam = np.exp2(L2 - sc) * (-1.0 if (m & 1) else 1.0)
+        lam_prev = np.zeros(npair)
+        inv_alpha_prev = 0.0
+        fe = np.zeros(npair, dtype=np.complex128)
+        fo = np.zeros(npair, dtype=np.complex128)
+        for l in range(m, L):
+            v = np.where(sc > -1000, np.ldexp(lam, np.maximum(sc, -1000)), 0.0)
+            a = alm[alm_index(l, m, lmax)]
+            if ((l - m) & 1) == 0:
+                fe += a * v
+            else:
+                fo += a * v
+            lp1 = l + 1.0
+            alpha = np.sqrt((4.0 * lp1 * lp1 - 1.0) / (lp1 * lp1 - float(m) * m))
+            nxt = alpha * (z * lam - lam_prev * inv_alpha_prev)
+            lam_prev, lam = lam, nxt
+            inv_alpha_prev = 1.0 / alpha
+            big = np.abs(lam) > 2.0**300
+            if big.any():
+                lam = np.where(big, lam * 2.0**-300, lam)
+                lam_prev = np.where(big, lam_prev * 2.0**-300, lam_prev)
+                sc = np.where(big, sc + 300, sc)
+        fn[:, m] = fe + fo
+        fs[:, m] = fe - fo
+    return fn, fs
+
+
+def _legendre_c(lmax, z, sth, alm):
+    L = lmax + 1
+    npair = len(z)
+    a = np.ascontiguousarray(alm, dtype=np.complex128).view(np.float64)
+    fn = np.zeros((npair, L), dtype=np.complex128)
+    fs = np.zeros((npair, L), dtype=np.complex128)
+    zz = np.ascontiguousarray(z, dtype=np.float64)
+    ss = np.ascontiguousarray(sth, dtype=np.float64)
+    _load().oracle_legendre_synth(lmax, npair, _dp(zz), _dp(ss), _dp(a), _dp(fn.view(np.float64)),
+                                  _dp(fs.view(np.float64)))
+    return fn, fs
+
+
+def ring_synthesis(fm, nphi, phi0):
+    """T_j (j < nphi) on one ring from F_m, m = 0..lmax: phase, alias fold, c2r FFT.
+
+    T_j = Re(c_0) + 2 sum_{m>=1} Re(c_m e^{2 pi i j m/nphi}),  c_m = F_m e^{i m phi0}.
+    Each m >= 1 adds c_m to bin (m mod nphi) and conj(c_m) to bin (-m mod nphi) of a
+    Hermitian length-nphi spectrum X; T = nphi * irfft(X[:nphi/2+1]).
+    """
+    L = len(fm)
+    m = np.arange(L)
+    c = fm * np.exp(1j * m * phi0)
+    X = np.zeros(nphi, dtype=np.complex128)
+    X[0] = c[0].real
+    if L > 1:
+        np.add.at(X, m[1:] % nphi, c[1:])
+        np.add.at(X, (-m[1:]) % nphi, np.conj(c[1:]))
+    return np.fft.irfft(X[: nphi // 2 + 1], n=nphi) * nphi
+
+
+def synth_from_fm(fn, fs, nside):
+    """Assemble the RING map from north/south F_m arrays ([2 nside][lmax+1])."""
+    ri = healpix.ring_info(nside)
+    npix = healpix.nside2npix(nside)
+    out = np.empty(npix)
+    nring = 4 * nside - 1
+    npair = 2 * nside
+    for r in range(npair):
+        n, s, p0 = int(ri["nphi"][r]), int(ri["start"][r]), float(ri["phi0"][r])
+        out[s : s + n] = ring_synthesis(fn[r], n, p0)
+        rs = nring - 1 - r
+        if rs != r:
+            n, s, p0 = int(ri["nphi"][rs]), int(ri["start"][rs]), float(ri["phi0"][rs])
+            out[s : s + n] = ring_synthesis(fs[r], n, p0)
+    return out
+
+
+def alm2map(alm, nside, lmax=None, impl="c"):
+    """Packed (healpy-ordered) alm -> RING map, float64."""
+    alm = np.asarray(alm, dtype=np.complex128)
+    if lmax is None:
+        # nalm = (lmax+1)(lmax+2)/2
+        lmax = int(round((-3 + np.sqrt(1 + 8 * alm.size)) / 2))
+    assert alm.size == (lmax + 1) * (lmax + 2) // 2
+    ri = healpix.ring_info(nside)
+    npair = 2 * nside
+    z, sth = ri["z"][:npair], ri["sth"][:npair]
+    fn, fs = (_legendre_c if impl == "c" else _legendre_numpy)(lmax, z, sth, alm)
+    return synth_from_fm(fn, fs, nside)
+
+
+def alm2map_bruteforce(alm, nside, lmax):
+    """Independent definition-level synthesis with scipy.special.sph_harm_y."""
+    from scipy.special import sph_harm_y
+
+    theta, phi = healpix.pix2ang_ring(nside)
+    out = np.zeros(theta.size)
+    for m in range(lmax + 1):
+        cm = 1.0 if m == 0 else 2.0
+        for l in range(m, lmax + 1):
+            a = alm[alm_index(l, m, lmax)]
+            y = sph_harm_y(l, m, theta, phi)
+            if m == 0:
+                out += a.real * y.real
+            else:
+                out += cm * (a * y).real
+    return out

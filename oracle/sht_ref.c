@@ -1,0 +1,117 @@
+/* oracle/sht_ref.c - CPU restatement of the spherical-harmonic synthesis that
+ * the reference delegates to healpy.alm2map (cora/util/hputil.py:388-391).
+ *
+ * TEST INFRASTRUCTURE ONLY (oracle): used by tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg.  Never linked into the product library.
+ *
+ * healpy is a third-party dependency absent from /root/reference, so this
+ * follows the published definition:
+ *   T(theta,phi) = sum_m c_m Re[F_m(theta) e^{i m phi}],  c_0 = 1, c_m = 2,
+ *   F_m(theta)   = sum_{l>=m} a_lm lambda_lm(cos theta),
+ *   lambda_lm    = sqrt((2l+1)/(4pi) (l-m)!/(l+m)!) P_l^m  (Condon-Shortley phase).
+ * This file does the Legendre part (F_m for every ring pair); the per-ring
+ * phase / alias fold / inverse real FFT is done in oracle/sht.py with numpy.
+ *
+ * Recurrence (per m, marching in l), with a power-of-two scale exponent so the
+ * sin^m(theta) seed cannot underflow:
+ *   lambda_mm     = (-1)^m sqrt((2m+1)!!/(4pi (2m)!!)) sin^m(theta)
+ *   lambda_lm     = alpha_lm (x lambda_{l-1,m} - lambda_{l-2,m}/alpha_{l-1,m}),
+ *   alpha_lm      = sqrt((4l^2-1)/(l^2-m^2)).
+ * North/south symmetry lambda_lm(-x) = (-1)^{l+m} lambda_lm(x): even and odd
+ * (l-m) partial sums are accumulated once per ring pair.
+ */
+#include <math.h>
+#include <stdlib.h>
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* alm: packed healpy order idx(l,m) = m(2 lmax+1-m)/2 + l, interleaved (re,im).
+ * z, sth: cos/sin(theta) of the `npair` northern rings (equator included).
+ * fn, fs: [npair][lmax+1][2] outputs (F_m on the north ring, and on its mirror). */
+void oracle_legendre_synth(int lmax, int npair, const double *z, const double *sth,
+                           const double *alm, double *fn, double *fs)
+{
+    const int L = lmax + 1;
+    /* log2 of |lambda_mm| prefactor */
+    double *lp = (double *)malloc(sizeof(double) * L);
+    lp[0] = -0.5 * log2(4.0 * M_PI);
+    for (int m = 1; m < L; m++)
+        lp[m] = lp[m - 1] + 0.5 * log2((2.0 * m + 1.0) / (2.0 * m));
+
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int r = 0; r < npair; r++) {
+        const double x = z[r];
+        const double l2s = log2(sth[r]);
+        for (int m = 0; m < L; m++) {
+            const double *a = alm + 2 * ((long)m * (2 * lmax + 1 - m) / 2);
+            /* a[2*l], a[2*l+1] is a_lm for this m (index offset by +l) */
+            double L2 = lp[m] + m * l2s;
+            int sc = (int)floor(L2);
+            double lam = exp2(L2 - sc);
+            if (m & 1) lam = -lam;
+            double lam_prev = 0.0;
+            double inv_alpha_prev = 0.0; /* 1/alpha_{l,m}; alpha_mm = inf */
+            double fer = 0, fei = 0, f_or = 0, foi = 0;
+            const double m2 = (double)m * m;
+            for (int l = m; l < L; l++) {
+                if (sc > -1000) {
+                    double v = ldexp(lam, sc);
+                    double ar = a[2 * l], ai = a[2 * l + 1];
+                    if (((l - m) & 1) == 0) { fer += ar * v; fei += ai * v; }
+                    else                    { f_or += ar * v; foi += ai * v; }
+                }
+                /* step to l+1 */
+                double lp1 = l + 1.0;
+                double alpha = sqrt((4.0 * lp1 * lp1 - 1.0) / (lp1 * lp1 - m2));
+                double nxt = alpha * (x * lam - lam_prev * inv_alpha_prev);
+                lam_prev = lam;
+                lam = nxt;
+                inv_alpha_prev = 1.0 / alpha;
+                if (fabs(lam) > 0x1p300) {
+                    lam *= 0x1p-300;
+                    lam_prev *= 0x1p-300;
+                    sc += 300;
+                }
+            }
+            long o = 2 * ((long)r * L + m);
+            fn[o] = fer + f_or; fn[o + 1] = fei + foi;
+            fs[o] = fer - f_or; fs[o + 1] = fei - foi;
+        }
+    }
+    free(lp);
+}
+
+/* normalised lambda_lm(x) for one (m, x), l = m..lmax, same recurrence
+ * (used by the tests to check against mpmath / scipy spot values). */
+void oracle_lambda_lm(int lmax, int m, double x, double sthv, double *out)
+{
+    double L2 = -0.5 * log2(4.0 * M_PI);
+    for (int k = 1; k <= m; k++) L2 += 0.5 * log2((2.0 * k + 1.0) / (2.0 * k));
+    L2 += m * log2(sthv);
+    int sc = (int)floor(L2);
+    double lam = exp2(L2 - sc);
+    if (m & 1) lam = -lam;
+    double lam_prev = 0.0, inv_alpha_prev = 0.0;
+    const double m2 = (double)m * m;
+    for (int l = m; l <= lmax; l++) {
+        out[l - m] = (sc > -1070) ? ldexp(lam, sc) : 0.0;
+        double lp1 = l + 1.0;
+        double alpha = sqrt((4.0 * lp1 * lp1 - 1.0) / (lp1 * lp1 - m2));
+        double nxt = alpha * (x * lam - lam_prev * inv_alpha_prev);
+        lam_prev = lam;
+        lam = nxt;
+        inv_alpha_prev = 1.0 / alpha;
+        if (fabs(lam) > 0x1p300) { lam *= 0x1p-300; lam_prev *= 0x1p-300; sc += 300; }
+    }
+}
+
+int oracle_num_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
