@@ -1,0 +1,303 @@
+"""ctypes binding of libcorahip.so (include/corahip.h) + a thin torch-tensor front end.
+
+PyTorch is used for device memory, streams and (elsewhere) torch.distributed only;
+all arithmetic of the hot path runs in the hand-written HIP kernels of the library.
+There is NO CPU fallback: if the library or a gfx950 GPU is missing, the compute
+entry points raise (loudly) instead of computing something else.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcorahip.so")
+
+c_int, c_double, c_void_p, c_size_t = ctypes.c_int, ctypes.c_double, ctypes.c_void_p, ctypes.c_size_t
+c_u64, c_char_p = ctypes.c_uint64, ctypes.c_char_p
+PTR = c_void_p
+
+# name -> (restype, argtypes): every symbol include/corahip.h declares
+SIGNATURES = {
+    "corahip_abi_version": (c_int, []),
+    "corahip_last_error": (c_char_p, []),
+    "corahip_device_count": (c_int, [ctypes.POINTER(c_int)]),
+    "corahip_ctx_create": (c_int, [c_int, ctypes.POINTER(c_void_p)]),
+    "corahip_ctx_destroy": (c_int, [c_void_p]),
+    "corahip_ctx_set_stream": (c_int, [c_void_p, c_void_p]),
+    "corahip_ctx_sync": (c_int, [c_void_p]),
+    "corahip_timer_begin": (c_int, [c_void_p]),
+    "corahip_timer_end": (c_int, [c_void_p, ctypes.POINTER(ctypes.c_float)]),
+    "corahip_profile_enable": (c_int, [c_void_p, c_int]),
+    "corahip_profile_get": (c_int, [c_void_p, c_char_p, ctypes.POINTER(c_double), ctypes.POINTER(c_int)]),
+    "corahip_profile_reset": (c_int, [c_void_p]),
+    "corahip_malloc": (c_int, [c_void_p, c_size_t, ctypes.POINTER(c_void_p)]),
+    "corahip_free": (c_int, [c_void_p, c_void_p]),
+    "corahip_memcpy_h2d": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t]),
+    "corahip_memcpy_d2h": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t]),
+    "corahip_clarray_table21cm": (c_int, [c_void_p, PTR, PTR, PTR, c_int, c_int, c_double, c_double, c_double,
+                                          PTR, PTR, PTR, PTR, c_int, c_int, PTR, PTR, c_int, PTR]),
+    "corahip_aps_table21cm_points": (c_int, [c_void_p, PTR, PTR, PTR, c_int, c_int, c_double, c_double, c_double,
+                                             ctypes.c_long, PTR, PTR, PTR, PTR, PTR, PTR, PTR]),
+    "corahip_clarray_separable": (c_int, [c_void_p, PTR, c_int, PTR, c_int, c_int, PTR, PTR]),
+    "corahip_romb_reduce": (c_int, [c_void_p, PTR, c_int, c_int, c_int, PTR, PTR]),
+    "corahip_factor_batched": (c_int, [c_void_p, PTR, c_int, c_int, c_double, c_double, PTR, PTR]),
+    "corahip_normals_philox": (c_int, [c_void_p, c_u64, c_int, c_int, PTR]),
+    "corahip_draw_alm": (c_int, [c_void_p, PTR, PTR, PTR, c_int, c_int, c_int, c_int, PTR]),
+    "corahip_alm_dev_to_square": (c_int, [c_void_p, PTR, c_int, c_int, PTR]),
+    "corahip_alm_packed_to_dev": (c_int, [c_void_p, PTR, c_int, c_int, PTR]),
+    "corahip_sht_plan_create": (c_int, [c_void_p, c_int, c_int, ctypes.POINTER(c_void_p)]),
+    "corahip_sht_plan_destroy": (c_int, [c_void_p, c_void_p]),
+    "corahip_alm2map_workspace_bytes": (c_int, [c_void_p, c_int, ctypes.POINTER(c_size_t)]),
+    "corahip_alm2map": (c_int, [c_void_p, c_void_p, PTR, c_int, PTR, c_void_p, c_size_t]),
+    "corahip_sht_plan_rings": (c_int, [c_void_p, PTR, PTR, PTR, PTR]),
+    "corahip_sht_lambda": (c_int, [c_void_p, c_void_p, c_int, c_int, PTR]),
+}
+
+
+class CoraHipError(RuntimeError):
+    """An entry point of libcorahip.so returned a non-zero status."""
+
+
+_lib = None
+
+
+def load():
+    """Load libcorahip.so and attach prototypes.  Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "cora_amd: %s not found. Build it with `make -C cora_amd/csrc` (needs hipcc, gfx950). "
+                "There is no CPU fallback for the compute path." % LIB_PATH
+            )
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        if lib.corahip_abi_version() != 1:
+            raise ImportError("cora_amd: ABI version mismatch in %s" % LIB_PATH)
+        _lib = lib
+    return _lib
+
+
+def _check(rc):
+    if rc != 0:
+        msg = load().corahip_last_error()
+        raise CoraHipError("libcorahip status %d: %s" % (rc, msg.decode() if msg else "?"))
+
+
+def _torch():
+    import torch
+
+    return torch
+
+
+class Context:
+    """One context per GPU; wraps the C ABI with torch tensors as device arrays."""
+
+    def __init__(self, device=0):
+        torch = _torch()
+        self.lib = load()
+        if not torch.cuda.is_available():
+            raise CoraHipError(
+                "cora_amd needs an AMD MI355X (gfx950) GPU: torch.cuda.is_available() is False "
+                "and there is no CPU fallback"
+            )
+        self.device = torch.device("cuda", device)
+        torch.cuda.set_device(self.device)
+        h = c_void_p()
+        _check(self.lib.corahip_ctx_create(device, ctypes.byref(h)))
+        self.h = h
+        self._plans = {}
+        self._workspace = None
+        self.use_current_stream()
+
+    # -- plumbing ---------------------------------------------------------------------
+    def use_current_stream(self):
+        torch = _torch()
+        s = torch.cuda.current_stream(self.device).cuda_stream
+        _check(self.lib.corahip_ctx_set_stream(self.h, c_void_p(s)))
+
+    def sync(self):
+        _check(self.lib.corahip_ctx_sync(self.h))
+
+    def timer_begin(self):
+        _check(self.lib.corahip_timer_begin(self.h))
+
+    def timer_end(self):
+        ms = ctypes.c_float()
+        _check(self.lib.corahip_timer_end(self.h, ctypes.byref(ms)))
+        return float(ms.value)
+
+    def profile_enable(self, on=True):
+        _check(self.lib.corahip_profile_enable(self.h, 1 if on else 0))
+
+    def profile_reset(self):
+        _check(self.lib.corahip_profile_reset(self.h))
+
+    def profile_get(self, name):
+        ms, n = c_double(), c_int()
+        _check(self.lib.corahip_profile_get(self.h, name.encode(), ctypes.byref(ms), ctypes.byref(n)))
+        return float(ms.value), int(n.value)
+
+    def empty(self, shape, dtype=None):
+        torch = _torch()
+        return torch.empty(shape, dtype=dtype or torch.float64, device=self.device)
+
+    def to_device(self, a, dtype=np.float64):
+        torch = _torch()
+        a = np.ascontiguousarray(a, dtype=dtype)
+        return torch.from_numpy(a).to(self.device)
+
+    @staticmethod
+    def _p(t):
+        assert t.is_contiguous(), "device array must be contiguous"
+        return c_void_p(t.data_ptr())
+
+    def _f64(self, t):
+        torch = _torch()
+        assert t.dtype == torch.float64 and t.device == self.device
+        return self._p(t)
+
+    # -- K1 ---------------------------------------------------------------------------
+    def clarray_table21cm(self, dd, dv, vv, kperpmin, kperpmax, kparmax, chi, pfd, f, b, F, zint, w, log10l):
+        nl = log10l.numel()
+        out = self.empty((nl, F, F))
+        nkperp, nkpar = dd.shape
+        _check(self.lib.corahip_clarray_table21cm(
+            self.h, self._f64(dd), self._f64(dv), self._f64(vv), nkperp, nkpar, kperpmin, kperpmax, kparmax,
+            self._f64(chi), self._f64(pfd), self._f64(f), self._f64(b), F, zint, self._f64(w), self._f64(log10l),
+            nl, self._f64(out)))
+        return out
+
+    def aps_table21cm_points(self, dd, dv, vv, kperpmin, kperpmax, kparmax, lx, chi1, chi2, cdd, cdv, cvv):
+        n = lx.numel()
+        out = self.empty((n,))
+        nkperp, nkpar = dd.shape
+        _check(self.lib.corahip_aps_table21cm_points(
+            self.h, self._f64(dd), self._f64(dv), self._f64(vv), nkperp, nkpar, kperpmin, kperpmax, kparmax, n,
+            self._f64(lx), self._f64(chi1), self._f64(chi2), self._f64(cdd), self._f64(cdv), self._f64(cvv),
+            self._f64(out)))
+        return out
+
+    def clarray_separable(self, al, bcov, F, zint, w):
+        nl = al.numel()
+        out = self.empty((nl, F, F))
+        _check(self.lib.corahip_clarray_separable(self.h, self._f64(al), nl, self._f64(bcov), F, zint,
+                                                  self._f64(w), self._f64(out)))
+        return out
+
+    def romb_reduce(self, clt, nl, F, zint, w):
+        out = self.empty((nl, F, F))
+        _check(self.lib.corahip_romb_reduce(self.h, self._f64(clt), nl, F, zint, self._f64(w), self._f64(out)))
+        return out
+
+    # -- K2 ---------------------------------------------------------------------------
+    def factor_batched(self, C, jitter_rel=1e-14, eig_thresh=1e-16):
+        torch = _torch()
+        nl, F, F2 = C.shape
+        assert F == F2
+        T = self.empty((nl, F, F))
+        info = torch.empty((nl,), dtype=torch.int32, device=self.device)
+        _check(self.lib.corahip_factor_batched(self.h, self._f64(C), nl, F, jitter_rel, eig_thresh, self._f64(T),
+                                               self._p(info)))
+        return T, info
+
+    # -- K3 ---------------------------------------------------------------------------
+    def normals_philox(self, seed, lmax, F, out=None):
+        n = 2 * F * (lmax + 1) * (lmax + 2) // 2
+        g = out if out is not None else self.empty((n,))
+        assert g.numel() >= n
+        _check(self.lib.corahip_normals_philox(self.h, c_u64(int(seed) & (2**64 - 1)), lmax, F, self._f64(g)))
+        return g
+
+    def draw_alm(self, T, info, g, lmax, F, nu0=0, nnu=None, out=None):
+        nnu = F if nnu is None else nnu
+        nalm = (lmax + 1) * (lmax + 2) // 2
+        G = (nnu + 3) // 4
+        alm = out if out is not None else self.empty((nalm, G, 2, 4))
+        _check(self.lib.corahip_draw_alm(self.h, self._f64(T), self._p(info) if info is not None else None,
+                                         self._f64(g), lmax, F, nu0, nnu, self._f64(alm)))
+        return alm
+
+    def alm_dev_to_square(self, alm, lmax, nnu):
+        torch = _torch()
+        L = lmax + 1
+        sq = torch.empty((nnu, 1, L, L), dtype=torch.complex128, device=self.device)
+        _check(self.lib.corahip_alm_dev_to_square(self.h, self._f64(alm), lmax, nnu, self._p(sq)))
+        return sq
+
+    def alm_packed_to_dev(self, packed, lmax):
+        torch = _torch()
+        assert packed.dtype == torch.complex128
+        nnu, nalm = packed.shape
+        assert nalm == (lmax + 1) * (lmax + 2) // 2
+        alm = self.empty((nalm, (nnu + 3) // 4, 2, 4))
+        _check(self.lib.corahip_alm_packed_to_dev(self.h, self._p(packed), lmax, nnu, self._f64(alm)))
+        return alm
+
+    # -- K4/K5 ------------------------------------------------------------------------
+    def sht_plan(self, nside, lmax):
+        key = (int(nside), int(lmax))
+        if key not in self._plans:
+            h = c_void_p()
+            _check(self.lib.corahip_sht_plan_create(self.h, key[0], key[1], ctypes.byref(h)))
+            self._plans[key] = h
+        return self._plans[key]
+
+    def alm2map_workspace_bytes(self, plan, nnu):
+        b = c_size_t()
+        _check(self.lib.corahip_alm2map_workspace_bytes(plan, nnu, ctypes.byref(b)))
+        return int(b.value)
+
+    def workspace(self, nbytes):
+        torch = _torch()
+        if self._workspace is None or self._workspace.numel() < nbytes:
+            self._workspace = None
+            self._workspace = torch.empty((nbytes,), dtype=torch.uint8, device=self.device)
+        return self._workspace
+
+    def alm2map(self, alm, nside, lmax, nnu, out=None, max_workspace_bytes=None):
+        plan = self.sht_plan(nside, lmax)
+        npix = 12 * nside * nside
+        maps = out if out is not None else self.empty((nnu, npix))
+        need = self.alm2map_workspace_bytes(plan, nnu)
+        if max_workspace_bytes is not None:
+            need = min(need, int(max_workspace_bytes))
+        ws = self.workspace(need)
+        _check(self.lib.corahip_alm2map(self.h, plan, self._f64(alm), nnu, self._f64(maps), self._p(ws), need))
+        return maps
+
+    def sht_rings(self, nside, lmax):
+        plan = self.sht_plan(nside, lmax)
+        nring = 4 * nside - 1
+        start = np.zeros(nring, dtype=np.int64)
+        nphi = np.zeros(nring, dtype=np.int32)
+        z = np.zeros(nring)
+        phi0 = np.zeros(nring)
+        _check(self.lib.corahip_sht_plan_rings(plan, start.ctypes.data_as(c_void_p), nphi.ctypes.data_as(c_void_p),
+                                               z.ctypes.data_as(c_void_p), phi0.ctypes.data_as(c_void_p)))
+        return dict(start=start, nphi=nphi, z=z, phi0=phi0)
+
+    def sht_lambda(self, nside, lmax, m, ring_pair):
+        plan = self.sht_plan(nside, lmax)
+        out = self.empty((lmax - m + 1,))
+        _check(self.lib.corahip_sht_lambda(self.h, plan, m, ring_pair, self._f64(out)))
+        return out
+
+
+_contexts = {}
+
+
+def get_context(device=None):
+    """Cached Context for `device` (default: torch's current CUDA device)."""
+    torch = _torch()
+    if device is None:
+        device = torch.cuda.current_device() if torch.cuda.is_available() else 0
+    if device not in _contexts:
+        _contexts[device] = Context(device)
+    ctx = _contexts[device]
+    ctx.use_current_stream()
+    return ctx

@@ -1,0 +1,204 @@
+"""Counterpart of cora/core/skysim.py: C_l(nu,nu') array + correlated Gaussian sky maps.
+
+Same call surface as the reference (``clarray``, ``mkfullsky``); the work is done by the
+HIP kernels behind ``libcorahip.so``:
+
+  clarray   -> K1  fused table-gather + Romberg channel average (21cm table model),
+                   outer-product kernel (separable foregrounds), or a device Romberg
+                   reduction of host-evaluated samples (any other callable)
+  mkfullsky -> K2  batched jittered Cholesky / eigen root per l
+               K3  correlated draw a = T g on FP64 MFMA (+ device Philox normals)
+               K4  ring-pair Legendre contraction on FP64 MFMA
+               K5  per-ring alias fold + FFT, RING-ordered pixels
+
+``mkconstrained`` (cora/core/skysim.py:139-201) needs the adjoint transform and is out of
+scope of this package.
+"""
+import numpy as np
+import scipy.integrate as si
+
+from .. import _lib
+from ..util import nputil
+from ..util.nputil import DeviceRNG
+
+# l rows evaluated per host call for generic callables (the reference uses chunks of ~5,
+# cora/core/skysim.py:51, purely to bound the [5, F zint, F zint] temporaries)
+_GENERIC_LCHUNK = 8
+
+
+def romberg_weights(zromb):
+    """Normalised weights (sum = 1) of scipy's Romberg rule on 2**zromb + 1 samples.
+
+    Romberg integration is linear in the samples, so ``si.romb(y, dx)/(2 zhalf)`` of
+    cora/core/skysim.py:64-67 is a fixed dot product; the weights are read off scipy itself.
+    """
+    if zromb == 0:
+        return np.ones(1)
+    zint = 2**zromb + 1
+    return si.romb(np.eye(zint), dx=1.0, axis=0) / 2**zromb
+
+
+def _plan_of(aps):
+    obj = getattr(aps, "__self__", None)
+    fn = getattr(obj, "_clarray_plan", None)
+    return fn(aps) if fn is not None else None
+
+
+def clarray_device(aps, lmax, zarray, zromb=3, zwidth=None):
+    """As :func:`clarray` but returns the ``[lmax+1, F, F]`` array as a device tensor."""
+    zarray = np.asarray(zarray, dtype=np.float64)
+    ctx = _lib.get_context()
+    zlen = zarray.size
+    if zromb == 0:
+        zint = 1
+        za = zarray.copy()
+    else:
+        zsort = np.sort(zarray)
+        zhalf = np.abs(zsort[1] - zsort[0]) / 2.0 if zwidth is None else zwidth / 2.0
+        zint = 2**zromb + 1
+        za = (zarray[:, np.newaxis] + np.linspace(-zhalf, zhalf, zint)[np.newaxis, :]).flatten()
+        # the reference splits l into lmax // 5 sections and fails for lmax < 5 (skysim.py:51)
+        np.array_split(np.arange(lmax + 1), lmax // 5)
+    w = ctx.to_device(romberg_weights(zromb))
+    larr = np.arange(lmax + 1, dtype=np.float64)
+
+    plan = _plan_of(aps)
+    if plan is not None and plan["kind"] == "table21cm":
+        p = plan["prepare"](ctx, za)
+        lx = np.log10(np.where(larr == 0.0, 1e-10, larr))
+        return ctx.clarray_table21cm(p["dd"], p["dv"], p["vv"], p["kperpmin"], p["kperpmax"], p["kparmax"],
+                                     ctx.to_device(p["chi"]), ctx.to_device(p["pfd"]), ctx.to_device(p["f"]),
+                                     ctx.to_device(p["b"]), zlen, zint, w, ctx.to_device(lx))
+    if plan is not None and plan["kind"] == "separable":
+        al, bcov = plan["prepare"](larr.copy(), za)
+        return ctx.clarray_separable(ctx.to_device(al), ctx.to_device(bcov), zlen, zint, w)
+
+    # generic callable: evaluate on the host in l-chunks, reduce on the device
+    import torch
+
+    out = ctx.empty((lmax + 1, zlen, zlen))
+    for l0 in range(0, lmax + 1, _GENERIC_LCHUNK):
+        lsec = np.arange(l0, min(l0 + _GENERIC_LCHUNK, lmax + 1))
+        clt = aps(lsec[:, np.newaxis, np.newaxis].astype(np.float64), za[np.newaxis, :, np.newaxis],
+                  za[np.newaxis, np.newaxis, :])
+        clt = np.ascontiguousarray(np.broadcast_to(clt, (len(lsec), za.size, za.size)), dtype=np.float64)
+        out[l0 : l0 + len(lsec)] = ctx.romb_reduce(torch.from_numpy(clt).to(ctx.device), len(lsec), zlen, zint, w)
+    return out
+
+
+def clarray(aps, lmax, zarray, zromb=3, zwidth=None):
+    """Calculate an array of C_l(z, z') (cora/core/skysim.py:10-69).
+
+    Parameters
+    ----------
+    aps : function
+        The angular power spectrum ``aps(l, z1, z2)``, vectorised.
+    lmax : integer
+        Maximum l to calculate up to.
+    zarray : array_like
+        Array of z's (or frequencies) to calculate at.
+    zromb : integer
+        The Romberg order for integrating over frequency samples.
+    zwidth : scalar, optional
+        Width of frequency channel to integrate over. If None (default),
+        calculate from the separation of the first two bins.
+
+    Returns
+    -------
+    aps : np.ndarray[lmax+1, len(zarray), len(zarray)]
+    """
+    return clarray_device(aps, lmax, zarray, zromb=zromb, zwidth=zwidth).cpu().numpy()
+
+
+def _host_normals(numz, maxl, rng):
+    """The reference's draw order (skysim.py:114-120, nputil.py:104-125): for l ascending,
+    F*(l+1) reals then F*(l+1) imaginaries, un-normalised N(0,1)."""
+    nalm = (maxl + 1) * (maxl + 2) // 2
+    g = np.empty(2 * numz * nalm, dtype=np.float64)
+    o = 0
+    sn = np.random.standard_normal if rng is None else rng.standard_normal
+    for l in range(maxl + 1):
+        n = numz * (l + 1)
+        g[o : o + n] = sn((numz, l + 1)).ravel()
+        g[o + n : o + 2 * n] = sn((numz, l + 1)).ravel()
+        o += 2 * n
+    return g
+
+
+def factor_device(corr):
+    """Per-l roots of the jittered covariance blocks (skysim.py:115-119) on the device."""
+    ctx = _lib.get_context()
+    import torch
+
+    if not isinstance(corr, torch.Tensor):
+        corr = ctx.to_device(corr)
+    return ctx.factor_batched(corr, jitter_rel=1e-14, eig_thresh=1e-16)
+
+
+def mkfullsky_device(corr, nside, alms=False, rng=None, factors=None, nu_range=None):
+    """Device-resident :func:`mkfullsky`: returns torch tensors and accepts cached factors.
+
+    corr : ndarray or device tensor [lmax+1, F, F] (ignored when ``factors`` is given)
+    factors : optional (T, info) from :func:`factor_device`
+    nu_range : optional (nu0, nnu): only these channels are synthesised (frequency shard);
+        the normals are always the full global stream so shards are consistent.
+    """
+    import torch
+
+    ctx = _lib.get_context()
+    if factors is None:
+        numz = corr.shape[1]
+        if corr.shape[2] != numz:
+            raise Exception("Correlation matrix is incorrect shape.")
+        T, info = factor_device(corr)
+    else:
+        T, info = factors
+        numz = T.shape[1]
+    maxl = T.shape[0] - 1
+    nu0, nnu = (0, numz) if nu_range is None else nu_range
+
+    if isinstance(rng, DeviceRNG):
+        g = ctx.normals_philox(rng.next_seed(), maxl, numz)
+    else:
+        g = torch.from_numpy(_host_normals(numz, maxl, rng)).to(ctx.device)
+    alm = ctx.draw_alm(T, info, g, maxl, numz, nu0=nu0, nnu=nnu)
+    del g
+    if alms:
+        return ctx.alm_dev_to_square(alm, maxl, nnu)
+    return ctx.alm2map(alm, int(nside), maxl, nnu)
+
+
+def mkfullsky(corr, nside, alms=False, rng=None):
+    """Construct a set of correlated Healpix maps (cora/core/skysim.py:72-136).
+
+    Parameters
+    ----------
+    corr : np.ndarray (lmax+1, numz, numz)
+        The correlation matrix :math:`C_l(z, z')`.
+    nside : integer
+        The resolution of the Healpix maps.
+    alms : boolean, optional
+        If True return the alms ``[numz, 1, lmax+1, lmax+1]`` instead of the sky maps.
+    rng : numpy Generator, :class:`cora_amd.DeviceRNG`, optional
+        Seeded generator.  A numpy Generator (or None = numpy's legacy global state) is
+        consumed on the host in exactly the reference's order, so the same seed gives the
+        same realisation as cora; a ``DeviceRNG`` keeps the draw on the GPU.
+
+    Returns
+    -------
+    hpmaps : np.ndarray (numz, npix)
+    """
+    local = getattr(corr, "local_array", None)
+    if local is not None:  # caput MPIArray: only the single-rank case is supported here
+        if tuple(getattr(corr, "global_shape", local.shape)) != tuple(local.shape):
+            raise NotImplementedError("l-distributed MPIArray input: use cora_amd.parallel.mkfullsky_sharded")
+        corr = np.asarray(local)
+    corr = np.asarray(corr, dtype=np.float64)
+    if corr.shape[2] != corr.shape[1]:
+        raise Exception("Correlation matrix is incorrect shape.")
+    out = mkfullsky_device(corr, nside, alms=alms, rng=rng)
+    return out.cpu().numpy()
+
+
+def mkconstrained(corr, constraints, nside):
+    raise NotImplementedError("mkconstrained (cora/core/skysim.py:139-201) is out of scope of cora_amd")

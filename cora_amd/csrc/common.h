@@ -1,0 +1,82 @@
+// common.h - internals shared by the translation units of libcorahip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/corahip.h"
+
+void corahip_set_error(const char *fmt, ...);
+
+struct corahip_prof_entry {
+    double total_ms = 0.0;
+    int launches = 0;
+};
+
+struct corahip_pending_event {
+    std::string name;
+    hipEvent_t e0, e1;
+};
+
+struct corahip_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    bool profile = false;
+    std::map<std::string, corahip_prof_entry> prof;
+    std::vector<corahip_pending_event> pending;
+    int num_cu = 256;
+};
+
+// RAII: HIP-event pair around the launches of one named stage when profiling is on.
+struct StageTimer {
+    corahip_ctx *ctx;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    const char *name;
+    StageTimer(corahip_ctx *c, const char *n) : ctx(c), name(n) {
+        if (ctx->profile) {
+            (void)hipEventCreate(&e0);
+            (void)hipEventCreate(&e1);
+            (void)hipEventRecord(e0, ctx->stream);
+        }
+    }
+    ~StageTimer() {
+        if (ctx->profile) {
+            (void)hipEventRecord(e1, ctx->stream);
+            ctx->pending.push_back({name, e0, e1});
+        }
+    }
+};
+
+#define HIP_TRY(expr)                                                                       \
+    do {                                                                                    \
+        hipError_t _e = (expr);                                                             \
+        if (_e != hipSuccess) {                                                             \
+            corahip_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e),        \
+                              __FILE__, __LINE__);                                          \
+            return (int)_e;                                                                 \
+        }                                                                                   \
+    } while (0)
+
+#define ARG_CHECK(cond)                                                                     \
+    do {                                                                                    \
+        if (!(cond)) {                                                                      \
+            corahip_set_error("invalid argument: %s (%s:%d)", #cond, __FILE__, __LINE__);   \
+            return CORAHIP_EINVAL;                                                          \
+        }                                                                                   \
+    } while (0)
+
+#define LAUNCH_CHECK() HIP_TRY(hipGetLastError())
+
+static inline long nalm_of(int lmax) { return (long)(lmax + 1) * (lmax + 2) / 2; }
+// healpy packed index (m-major): idx(l,m) = m(2 lmax+1-m)/2 + l
+__host__ __device__ static inline long alm_idx(int l, int m, int lmax) {
+    return (long)m * (2 * lmax + 1 - m) / 2 + l;
+}
+
+typedef double d4_t __attribute__((ext_vector_type(4)));

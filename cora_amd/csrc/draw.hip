@@ -1,0 +1,253 @@
+// draw.hip - correlated Gaussian a_lm draw:  a_lm(nu) = sum_nu' T_l[nu,nu'] g_lm(nu')
+//
+// Replaces nputil.complex_std_normal (cora/util/nputil.py:104-125) in its device
+// (counter-based) form and the np.dot of cora/core/skysim.py:121, writing a_lm in
+// the device layout consumed by the synthesis ([nalm][g][c][v], see sht.hip).
+//
+// K3 is one FP64 MFMA GEMM per l: C[(c,m)][nu] = sum_nu' G[(c,m)][nu'] * T_l[nu][nu'],
+// rows = the 2(l+1) real/imag normal vectors of that l, cols = channels.  T_l is staged
+// k-chunk by k-chunk through LDS (transposed on the fly); the normals are read straight
+// from the stream-ordered buffer (each element is used by exactly one wave).
+#include "common.h"
+
+// ------------------------------------------------------------------------------------
+// Philox4x32-10 counter-based generator -> N(0,1) by Box-Muller, stream order
+// ------------------------------------------------------------------------------------
+__device__ static inline void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
+    const uint64_t p0 = (uint64_t)M0 * c[0];
+    const uint64_t p1 = (uint64_t)M1 * c[2];
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
+    const uint32_t n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+    const uint32_t n3 = (uint32_t)p0;
+    c[0] = n0;
+    c[1] = n1;
+    c[2] = n2;
+    c[3] = n3;
+}
+
+__device__ static inline void philox4x32_10(uint64_t counter, uint64_t key, uint32_t (&out)[4]) {
+    uint32_t c[4] = {(uint32_t)counter, (uint32_t)(counter >> 32), 0u, 0u};
+    uint32_t k0 = (uint32_t)key, k1 = (uint32_t)(key >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        philox_round(c, k0, k1);
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c[0];
+    out[1] = c[1];
+    out[2] = c[2];
+    out[3] = c[3];
+}
+
+// element pair q -> normals at stream positions 2q, 2q+1
+__global__ void normals_kernel(uint64_t seed, long npairs, double *__restrict__ g) {
+    for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < npairs; q += (long)gridDim.x * blockDim.x) {
+        uint32_t r[4];
+        philox4x32_10((uint64_t)q, seed, r);
+        // two uniforms in (0,1) with 53 random bits each
+        const double u1 = ((double)(((uint64_t)r[0] << 21) | (r[1] >> 11)) + 0.5) * 0x1p-53;
+        const double u2 = ((double)(((uint64_t)r[2] << 21) | (r[3] >> 11)) + 0.5) * 0x1p-53;
+        const double rad = sqrt(-2.0 * log(u1));
+        double s, c;
+        sincospi(2.0 * u2, &s, &c);
+        *reinterpret_cast<double2 *>(g + 2 * q) = make_double2(rad * c, rad * s);
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// K3: per-l GEMM on FP64 MFMA
+// ------------------------------------------------------------------------------------
+#define DRAW_KC 32   // nu' per LDS stage
+#define DRAW_ROWS 64 // (c,m) rows per block (4 waves x 16)
+
+// NCT = 16-column tiles per block (block covers 16*NCT channels starting at col0)
+template <int NCT>
+__global__ void __launch_bounds__(256)
+draw_kernel(const double *__restrict__ T, const int32_t *__restrict__ info, const double *__restrict__ g, int lmax,
+            int F, int nu0, int nnu, int Gout, double *__restrict__ alm) {
+    constexpr int NC = 16 * NCT;
+    constexpr int STRIDE = NC + 16;  // doubles; rows k, k+1 differ by 128 B mod 256
+    extern __shared__ __attribute__((aligned(16))) double lds[];  // [DRAW_KC][STRIDE]
+
+    const int l = blockIdx.x;
+    const int nrow = 2 * (l + 1);
+    const int row0 = blockIdx.y * DRAW_ROWS;
+    if (row0 >= nrow) return;
+    const int col0 = blockIdx.z * NC;  // local channel index of first column
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ri = lane & 15, kq = lane >> 4;
+    const int lp1 = l + 1;
+
+    // stream offset of this l: sum_{l'<l} 2 F (l'+1) = F l (l+1)
+    const double *gl = g + (size_t)F * l * (l + 1);
+    const double *Tl = T + (size_t)l * F * F;
+    const bool dense = (info == nullptr) || (info[l] != 0);
+
+    // A operand row of this lane
+    const int rr = row0 + wave * 16 + ri;
+    const bool row_ok = rr < nrow;
+    const int c_of = rr >= lp1 ? 1 : 0;
+    const int m_of = rr - c_of * lp1;
+    const double *grow = gl + (size_t)c_of * F * lp1 + m_of;  // + nu' * lp1
+
+    d4_t acc[NCT];
+#pragma unroll
+    for (int t = 0; t < NCT; t++) acc[t] = (d4_t){0.0, 0.0, 0.0, 0.0};
+
+    // lower-triangular T: columns nu only need nu' <= nu
+    const int kmax = dense ? F : min(F, nu0 + col0 + NC);
+    for (int k0 = 0; k0 < kmax; k0 += DRAW_KC) {
+        __syncthreads();
+        // stage Bs[k][n] = T_l[nu0+col0+n][k0+k]: item (n, 16-byte piece q of the 256-byte k-run)
+        for (int it = tid; it < NC * (DRAW_KC / 2); it += 256) {
+            const int n = it / (DRAW_KC / 2), q = it % (DRAW_KC / 2);
+            const int nu = nu0 + col0 + n;
+            double2 v = make_double2(0.0, 0.0);
+            const int k = k0 + 2 * q;
+            if (col0 + n < nnu && nu < F) {
+                if (k + 1 < F) v = *reinterpret_cast<const double2 *>(Tl + (size_t)nu * F + k);
+                else if (k < F) v.x = Tl[(size_t)nu * F + k];
+            }
+            lds[(2 * q) * STRIDE + n] = v.x;
+            lds[(2 * q + 1) * STRIDE + n] = v.y;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < DRAW_KC / 4; kk++) {
+            const int kbase = k0 + 4 * kk;
+            if (kbase >= kmax) break;
+            const int kp = kbase + kq;
+            double a = 0.0;
+            if (row_ok && kp < F) a = grow[(size_t)kp * lp1];
+            const double *bs = lds + (4 * kk + kq) * STRIDE + ri;
+#pragma unroll
+            for (int t = 0; t < NCT; t++) {
+                // triangular skip: tile t holds channels nu0+col0+16t .. +15
+                if (!dense && kbase > nu0 + col0 + 16 * t + 15) continue;
+                acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bs[16 * t], acc[t], 0, 0, 0);
+            }
+        }
+    }
+
+    // epilogue: 1/sqrt(2) of complex_std_normal, store into [idx][g][c][v]
+    const double sc = 0.70710678118654752440;
+    const long base = alm_idx(l, 0, lmax);  // idx(l,m) = m(2 lmax+1-m)/2 + l
+#pragma unroll
+    for (int t = 0; t < NCT; t++) {
+        const int col = col0 + 16 * t + ri;
+        if (col >= 4 * Gout) continue;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int ro = row0 + wave * 16 + kq + 4 * r;
+            if (ro < nrow) {
+                const int c = ro >= lp1 ? 1 : 0;
+                const int m = ro - c * lp1;
+                const long idx = (long)m * (2 * lmax + 1 - m) / 2 + l;
+                (void)base;
+                alm[((size_t)idx * Gout + (col >> 2)) * 8 + c * 4 + (col & 3)] = acc[t][r] * sc;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// layout converters
+// ------------------------------------------------------------------------------------
+// alm_dev [nalm][G][2][4] -> square [nnu][1][L][L] complex128 (m > l entries zero)
+__global__ void dev_to_square_kernel(const double *__restrict__ alm, int lmax, int nnu, int G,
+                                     double *__restrict__ sq) {
+    const int L = lmax + 1;
+    const long n = (long)nnu * L * L;
+    for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (long)gridDim.x * blockDim.x) {
+        const int m = (int)(q % L);
+        const int l = (int)((q / L) % L);
+        const int nu = (int)(q / ((long)L * L));
+        double2 v = make_double2(0.0, 0.0);
+        if (m <= l) {
+            const long idx = (long)m * (2 * lmax + 1 - m) / 2 + l;
+            const double *cell = alm + ((size_t)idx * G + (nu >> 2)) * 8 + (nu & 3);
+            v = make_double2(cell[0], cell[4]);
+        }
+        *reinterpret_cast<double2 *>(sq + 2 * q) = v;
+    }
+}
+
+// packed [nnu][nalm] complex128 (healpy order) -> alm_dev [nalm][G][2][4]; padding channels zero
+__global__ void packed_to_dev_kernel(const double *__restrict__ packed, long nalm, int nnu, int G,
+                                     double *__restrict__ alm) {
+    const long n = nalm * G * 4;
+    for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (long)gridDim.x * blockDim.x) {
+        const int v = (int)(q & 3);
+        const int gg = (int)((q >> 2) % G);
+        const long idx = q / (4L * G);
+        const int nu = 4 * gg + v;
+        double2 val = make_double2(0.0, 0.0);
+        if (nu < nnu) val = *reinterpret_cast<const double2 *>(packed + 2 * ((size_t)nu * nalm + idx));
+        double *cell = alm + ((size_t)idx * G + gg) * 8 + v;
+        cell[0] = val.x;
+        cell[4] = val.y;
+    }
+}
+
+template <int NCT>
+static int launch_draw(corahip_ctx *ctx, const double *T, const int32_t *info, const double *g, int lmax, int F,
+                       int nu0, int nnu, int Gout, double *alm) {
+    constexpr int NC = 16 * NCT;
+    const size_t shm = sizeof(double) * DRAW_KC * (NC + 16);
+    HIP_TRY(hipFuncSetAttribute((const void *)draw_kernel<NCT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+    dim3 grid(lmax + 1, (2 * (lmax + 1) + DRAW_ROWS - 1) / DRAW_ROWS, (4 * Gout + NC - 1) / NC);
+    draw_kernel<NCT><<<grid, 256, shm, ctx->stream>>>(T, info, g, lmax, F, nu0, nnu, Gout, alm);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" {
+
+int corahip_normals_philox(corahip_ctx *ctx, uint64_t seed, int lmax, int F, double *g) {
+    ARG_CHECK(ctx != nullptr && g != nullptr && lmax >= 0 && F >= 1);
+    StageTimer t(ctx, "normals");
+    const long npairs = (long)F * nalm_of(lmax);  // 2 F nalm doubles
+    const int blocks = (int)std::min<long>((npairs + 255) / 256, 256L * 16);
+    normals_kernel<<<blocks, 256, 0, ctx->stream>>>(seed, npairs, g);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int corahip_draw_alm(corahip_ctx *ctx, const double *T, const int32_t *info, const double *g, int lmax, int F,
+                     int nu0, int nnu, double *alm_dev) {
+    ARG_CHECK(ctx != nullptr && T != nullptr && g != nullptr && alm_dev != nullptr);
+    ARG_CHECK(lmax >= 0 && F >= 1 && nu0 >= 0 && nnu >= 1 && nu0 + nnu <= F);
+    StageTimer t(ctx, "draw");
+    const int Gout = (nnu + 3) / 4;
+    const int ncol = 4 * Gout;
+    if (ncol <= 16) return launch_draw<1>(ctx, T, info, g, lmax, F, nu0, nnu, Gout, alm_dev);
+    if (ncol <= 32) return launch_draw<2>(ctx, T, info, g, lmax, F, nu0, nnu, Gout, alm_dev);
+    if (ncol <= 64) return launch_draw<4>(ctx, T, info, g, lmax, F, nu0, nnu, Gout, alm_dev);
+    if (ncol <= 128) return launch_draw<8>(ctx, T, info, g, lmax, F, nu0, nnu, Gout, alm_dev);
+    return launch_draw<16>(ctx, T, info, g, lmax, F, nu0, nnu, Gout, alm_dev);
+}
+
+int corahip_alm_dev_to_square(corahip_ctx *ctx, const double *alm_dev, int lmax, int nnu, double *square) {
+    ARG_CHECK(ctx != nullptr && alm_dev != nullptr && square != nullptr && lmax >= 0 && nnu >= 1);
+    const long n = (long)nnu * (lmax + 1) * (lmax + 1);
+    const int blocks = (int)std::min<long>((n + 255) / 256, 256L * 16);
+    dev_to_square_kernel<<<blocks, 256, 0, ctx->stream>>>(alm_dev, lmax, nnu, (nnu + 3) / 4, square);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int corahip_alm_packed_to_dev(corahip_ctx *ctx, const double *packed, int lmax, int nnu, double *alm_dev) {
+    ARG_CHECK(ctx != nullptr && alm_dev != nullptr && packed != nullptr && lmax >= 0 && nnu >= 1);
+    const long nalm = nalm_of(lmax);
+    const int G = (nnu + 3) / 4;
+    const long n = nalm * G * 4;
+    const int blocks = (int)std::min<long>((n + 255) / 256, 256L * 16);
+    packed_to_dev_kernel<<<blocks, 256, 0, ctx->stream>>>(packed, nalm, nnu, G, alm_dev);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,351 @@
+// factor.hip - batched per-l matrix root of the nu x nu covariance blocks.
+//
+// Replaces the body of the l-loop of mkfullsky (cora/core/skysim.py:115-119):
+//   cmax  = diag(C_l).max() * 1e-14;  Cm = C_l + I*cmax
+//   T_l   = nputil.matrix_root_manynull(Cm, truncate=False)   (cora/util/nputil.py:51-101)
+// i.e. lower Cholesky; if a pivot is not positive (scipy.linalg.cholesky raising
+// LinAlgError) a symmetric eigen-decomposition with eigenvalues < max*threshold zeroed
+// and root = V sqrt(Lambda).
+//
+// One 256-thread workgroup per matrix.  Blocked right-looking Cholesky (panel width 32)
+// working in place in global memory (the 512 KB block of an F=256 matrix stays in L2):
+// diagonal block factored in LDS, panel solved one row per thread against the LDS
+// block, trailing update in 64x64 tiles with the two row panels staged in LDS.
+// The eigen branch (rare: the all-zero l=0 block of the foreground models, or a truly
+// indefinite block) is a parallel cyclic Jacobi iteration, also one workgroup per matrix.
+#include "common.h"
+
+#include <algorithm>
+#include <vector>
+
+#define CH_NB 32
+
+// lower Cholesky of C + jitter on the diagonal -> T (upper triangle zeroed); info = 1 on failure
+__global__ void __launch_bounds__(256)
+chol_kernel(const double *__restrict__ C, int F, double jitter_rel, double *__restrict__ T,
+            int32_t *__restrict__ info) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    double *D = lds;                      // [32][33] diagonal block
+    double *PA = lds + CH_NB * (CH_NB + 1);  // [64][33] row panel (i tile)
+    double *PB = PA + 64 * (CH_NB + 1);      // [64][33] row panel (j tile)
+    double *red = PB + 64 * (CH_NB + 1);     // [256] reduction scratch
+    int *flag = reinterpret_cast<int *>(red + 256);
+
+    const int tid = threadIdx.x;
+    const size_t off = (size_t)blockIdx.x * F * F;
+    const double *A = C + off;
+    double *Tl = T + off;
+
+    // jitter = max(diag) * jitter_rel
+    double dmax = -INFINITY;
+    for (int i = tid; i < F; i += 256) dmax = fmax(dmax, A[(size_t)i * F + i]);
+    red[tid] = dmax;
+    if (tid == 0) *flag = 0;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) red[tid] = fmax(red[tid], red[tid + s]);
+        __syncthreads();
+    }
+    const double jit = red[0] * jitter_rel;
+    __syncthreads();
+    // copy lower triangle (+jitter), zero the upper
+    for (long q = tid; q < (long)F * F; q += 256) {
+        const int i = (int)(q / F), j = (int)(q % F);
+        double v = 0.0;
+        if (j <= i) v = A[q] + (i == j ? jit : 0.0);
+        Tl[q] = v;
+    }
+    __syncthreads();
+
+    for (int kb = 0; kb < F; kb += CH_NB) {
+        const int nb = min(CH_NB, F - kb);
+        // ---- 1. diagonal block into LDS and factor it
+        for (int q = tid; q < nb * nb; q += 256) {
+            const int i = q / nb, j = q % nb;
+            D[i * (CH_NB + 1) + j] = (j <= i) ? Tl[(size_t)(kb + i) * F + kb + j] : 0.0;
+        }
+        __syncthreads();
+        for (int j = 0; j < nb; j++) {
+            const double d = D[j * (CH_NB + 1) + j];
+            if (!(d > 0.0)) {  // also catches NaN: LAPACK potrf "not positive definite"
+                if (tid == 0) *flag = 1;
+            }
+            __syncthreads();
+            if (*flag) break;
+            const double sj = sqrt(d);
+            // scale column j
+            if (tid > j && tid < nb) D[tid * (CH_NB + 1) + j] /= sj;
+            __syncthreads();
+            if (tid == 0) D[j * (CH_NB + 1) + j] = sj;
+            // rank-1 update of the trailing part of the block
+            for (int q = tid; q < nb * nb; q += 256) {
+                const int i = q / nb, k = q % nb;
+                if (k > j && k <= i) D[i * (CH_NB + 1) + k] -= D[i * (CH_NB + 1) + j] * D[k * (CH_NB + 1) + j];
+            }
+            __syncthreads();
+        }
+        if (*flag) break;
+        for (int q = tid; q < nb * nb; q += 256) {
+            const int i = q / nb, j = q % nb;
+            if (j <= i) Tl[(size_t)(kb + i) * F + kb + j] = D[i * (CH_NB + 1) + j];
+        }
+        const int r0 = kb + nb;
+        if (r0 >= F) break;
+        // ---- 2. panel: rows r0..F-1, X = A21 * L11^{-T}; one row per thread
+        for (int r = r0 + tid; r < F; r += 256) {
+            double x[CH_NB];
+            double *row = Tl + (size_t)r * F + kb;
+#pragma unroll
+            for (int j = 0; j < CH_NB; j++) x[j] = j < nb ? row[j] : 0.0;
+#pragma unroll
+            for (int j = 0; j < CH_NB; j++) {
+                if (j < nb) {
+                    double s = x[j];
+#pragma unroll
+                    for (int p = 0; p < CH_NB; p++)
+                        if (p < j) s -= x[p] * D[j * (CH_NB + 1) + p];
+                    x[j] = s / D[j * (CH_NB + 1) + j];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < CH_NB; j++)
+                if (j < nb) row[j] = x[j];
+        }
+        __syncthreads();  // panel visible to the whole workgroup (same CU, write-through L1)
+        // ---- 3. trailing update A22 -= X X^T (lower triangle), 64x64 tiles, 4x4 per thread
+        const int nt = (F - r0 + 63) / 64;
+        for (int ti = 0; ti < nt; ti++) {
+            for (int tj = 0; tj <= ti; tj++) {
+                const int i0 = r0 + ti * 64, j0 = r0 + tj * 64;
+                for (int q = tid; q < 64 * CH_NB; q += 256) {
+                    const int rr = q / CH_NB, cc = q % CH_NB;
+                    PA[rr * (CH_NB + 1) + cc] = (i0 + rr < F && cc < nb) ? Tl[(size_t)(i0 + rr) * F + kb + cc] : 0.0;
+                    PB[rr * (CH_NB + 1) + cc] = (j0 + rr < F && cc < nb) ? Tl[(size_t)(j0 + rr) * F + kb + cc] : 0.0;
+                }
+                __syncthreads();
+                const int ty = tid >> 4, tx = tid & 15;  // 16 x 16 threads, each a 4x4 micro tile
+                double acc[4][4] = {};
+                for (int p = 0; p < CH_NB; p++) {
+                    double a[4], b[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        a[u] = PA[(ty + 16 * u) * (CH_NB + 1) + p];
+                        b[u] = PB[(tx + 16 * u) * (CH_NB + 1) + p];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; u++)
+#pragma unroll
+                        for (int w = 0; w < 4; w++) acc[u][w] += a[u] * b[w];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+#pragma unroll
+                    for (int w = 0; w < 4; w++) {
+                        const int i = i0 + ty + 16 * u, j = j0 + tx + 16 * w;
+                        if (i < F && j <= i) Tl[(size_t)i * F + j] -= acc[u][w];
+                    }
+                __syncthreads();
+            }
+        }
+    }
+    if (tid == 0) info[blockIdx.x] = *flag;
+}
+
+// ------------------------------------------------------------------------------------
+// eigen branch: parallel cyclic Jacobi on Cm = C + jitter (symmetric), one workgroup per
+// listed matrix.  W = working copy of Cm [F][F], V = eigenvectors [F][F] (global scratch).
+// root = V * sqrt(max(lambda,0) thresholded), columns ordered by ascending eigenvalue
+// (the order scipy.linalg.eigh returns, nputil.py:84-96).
+// ------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+jacobi_root_kernel(const double *__restrict__ C, const int32_t *__restrict__ list, int F, double jitter_rel,
+                   double eig_thresh, double *__restrict__ Wall, double *__restrict__ Vall,
+                   double *__restrict__ T) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    double *cs = lds;                 // [F/2+1][2]
+    double *red = lds + 2 * (F / 2 + 1);  // [256]
+    double *ev = red + 256;           // [F]
+    int *perm = reinterpret_cast<int *>(ev + F);        // [F+1] round-robin player positions
+    int *order = perm + (F + 2);                         // [F]
+    const int tid = threadIdx.x;
+    const int l = list[blockIdx.x];
+    const double *A = C + (size_t)l * F * F;
+    double *W = Wall + (size_t)blockIdx.x * F * F;
+    double *V = Vall + (size_t)blockIdx.x * F * F;
+    double *Tl = T + (size_t)l * F * F;
+
+    double dmax = -INFINITY;
+    for (int i = tid; i < F; i += 256) dmax = fmax(dmax, A[(size_t)i * F + i]);
+    red[tid] = dmax;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) red[tid] = fmax(red[tid], red[tid + s]);
+        __syncthreads();
+    }
+    const double jit = red[0] * jitter_rel;
+    __syncthreads();
+    // symmetrised working copy (use the lower triangle, like LAPACK's default uplo='L')
+    for (long q = tid; q < (long)F * F; q += 256) {
+        const int i = (int)(q / F), j = (int)(q % F);
+        const double v = (j <= i) ? A[(size_t)i * F + j] : A[(size_t)j * F + i];
+        W[q] = v + (i == j ? jit : 0.0);
+        V[q] = (i == j) ? 1.0 : 0.0;
+    }
+    const int np = (F + 1) / 2;      // pairs per round
+    const int nplayers = 2 * np;     // a dummy player F when F is odd
+    for (int i = tid; i < nplayers; i += 256) perm[i] = i;
+    __syncthreads();
+
+    for (int sweep = 0; sweep < 60; sweep++) {
+        // convergence: off-diagonal Frobenius norm vs diagonal
+        double offs = 0.0, dia = 0.0;
+        for (long q = tid; q < (long)F * F; q += 256) {
+            const int i = (int)(q / F), j = (int)(q % F);
+            const double v = W[q];
+            if (i == j) dia += v * v;
+            else offs += v * v;
+        }
+        red[tid] = offs;
+        __syncthreads();
+        for (int s = 128; s > 0; s >>= 1) {
+            if (tid < s) red[tid] += red[tid + s];
+            __syncthreads();
+        }
+        offs = red[0];
+        __syncthreads();
+        red[tid] = dia;
+        __syncthreads();
+        for (int s = 128; s > 0; s >>= 1) {
+            if (tid < s) red[tid] += red[tid + s];
+            __syncthreads();
+        }
+        dia = red[0];
+        __syncthreads();
+        if (offs <= 1e-30 * dia || offs == 0.0) break;
+
+        for (int round = 0; round < nplayers - 1; round++) {
+            // pairs of this round: (perm[k], perm[nplayers-1-k])
+            for (int k = tid; k < np; k += 256) {
+                int p = perm[k], q = perm[nplayers - 1 - k];
+                if (p > q) { int t = p; p = q; q = t; }
+                double c = 1.0, s = 0.0;
+                if (q < F) {
+                    const double apq = W[(size_t)p * F + q];
+                    if (apq != 0.0) {
+                        const double app = W[(size_t)p * F + p], aqq = W[(size_t)q * F + q];
+                        const double tau = (aqq - app) / (2.0 * apq);
+                        const double t = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+                        c = 1.0 / sqrt(1.0 + t * t);
+                        s = t * c;
+                    }
+                }
+                cs[2 * k] = c;
+                cs[2 * k + 1] = s;
+            }
+            __syncthreads();
+            // rows: W <- J^T W
+            for (int it = tid; it < np * F; it += 256) {
+                const int k = it / F, j = it % F;
+                int p = perm[k], q = perm[nplayers - 1 - k];
+                if (p > q) { int t = p; p = q; q = t; }
+                if (q >= F) continue;
+                const double c = cs[2 * k], s = cs[2 * k + 1];
+                const double wp = W[(size_t)p * F + j], wq = W[(size_t)q * F + j];
+                W[(size_t)p * F + j] = c * wp - s * wq;
+                W[(size_t)q * F + j] = s * wp + c * wq;
+            }
+            __syncthreads();
+            // columns: W <- W J, V <- V J
+            for (int it = tid; it < np * F; it += 256) {
+                const int k = it / F, i = it % F;
+                int p = perm[k], q = perm[nplayers - 1 - k];
+                if (p > q) { int t = p; p = q; q = t; }
+                if (q >= F) continue;
+                const double c = cs[2 * k], s = cs[2 * k + 1];
+                const double wp = W[(size_t)i * F + p], wq = W[(size_t)i * F + q];
+                W[(size_t)i * F + p] = c * wp - s * wq;
+                W[(size_t)i * F + q] = s * wp + c * wq;
+                const double vp = V[(size_t)i * F + p], vq = V[(size_t)i * F + q];
+                V[(size_t)i * F + p] = c * vp - s * vq;
+                V[(size_t)i * F + q] = s * vp + c * vq;
+            }
+            __syncthreads();
+            // rotate players 1..nplayers-1 (player at position 0 is fixed)
+            if (tid == 0) {
+                const int last = perm[nplayers - 1];
+                for (int k = nplayers - 1; k > 1; k--) perm[k] = perm[k - 1];
+                perm[1] = last;
+            }
+            __syncthreads();
+        }
+    }
+    // eigenvalues, threshold, ascending order
+    for (int i = tid; i < F; i += 256) ev[i] = W[(size_t)i * F + i];
+    __syncthreads();
+    double emax = -INFINITY;
+    for (int i = tid; i < F; i += 256) emax = fmax(emax, ev[i]);
+    red[tid] = emax;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) red[tid] = fmax(red[tid], red[tid + s]);
+        __syncthreads();
+    }
+    emax = red[0];
+    __syncthreads();
+    // rank of each eigenvalue (stable) -> output column
+    for (int i = tid; i < F; i += 256) {
+        int rank = 0;
+        const double e = ev[i];
+        for (int j = 0; j < F; j++) {
+            const double f = ev[j];
+            if (f < e || (f == e && j < i)) rank++;
+        }
+        order[i] = rank;
+    }
+    __syncthreads();
+    for (long q = tid; q < (long)F * F; q += 256) {
+        const int i = (int)(q / F), j = (int)(q % F);
+        double e = ev[j];
+        if (e < emax * eig_thresh) e = 0.0;  // nputil.py:87 (negative / tiny eigenvalues dropped)
+        Tl[(size_t)i * F + order[j]] = V[q] * sqrt(e);
+    }
+}
+
+extern "C" int corahip_factor_batched(corahip_ctx *ctx, const double *C, int nl, int F, double jitter_rel,
+                                      double eig_thresh, double *T, int32_t *info) {
+    ARG_CHECK(ctx != nullptr && C != nullptr && T != nullptr && info != nullptr);
+    ARG_CHECK(nl >= 1 && F >= 1);
+    StageTimer t(ctx, "factor");
+    {
+        const size_t shm = sizeof(double) * (CH_NB * (CH_NB + 1) + 2 * 64 * (CH_NB + 1) + 256) + 16;
+        chol_kernel<<<nl, 256, shm, ctx->stream>>>(C, F, jitter_rel, T, info);
+        LAUNCH_CHECK();
+    }
+    // eigen branch for the blocks whose Cholesky failed (host round trip: cold path only)
+    std::vector<int32_t> hinfo(nl);
+    HIP_TRY(hipMemcpyAsync(hinfo.data(), info, sizeof(int32_t) * nl, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    std::vector<int32_t> list;
+    for (int l = 0; l < nl; l++)
+        if (hinfo[l] != 0) list.push_back(l);
+    if (list.empty()) return 0;
+    // process in batches bounded by scratch size (2 F^2 doubles per matrix)
+    const size_t per = (size_t)2 * F * F * sizeof(double);
+    const size_t batch = std::max<size_t>(1, std::min<size_t>(list.size(), ((size_t)1 << 31) / per));
+    int32_t *dlist = nullptr;
+    double *scratch = nullptr;
+    HIP_TRY(hipMalloc((void **)&dlist, sizeof(int32_t) * list.size()));
+    HIP_TRY(hipMalloc((void **)&scratch, per * batch));
+    HIP_TRY(hipMemcpyAsync(dlist, list.data(), sizeof(int32_t) * list.size(), hipMemcpyHostToDevice, ctx->stream));
+    const size_t shm = sizeof(double) * (2 * (F / 2 + 1) + 256 + F) + sizeof(int) * (2 * F + 4) + 16;
+    for (size_t b0 = 0; b0 < list.size(); b0 += batch) {
+        const int nb = (int)std::min(batch, list.size() - b0);
+        jacobi_root_kernel<<<nb, 256, shm, ctx->stream>>>(C, dlist + b0, F, jitter_rel, eig_thresh, scratch,
+                                                         scratch + (size_t)nb * F * F, T);
+        LAUNCH_CHECK();
+    }
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    (void)hipFree(dlist);
+    (void)hipFree(scratch);
+    return 0;
+}

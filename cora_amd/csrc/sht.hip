@@ -1,0 +1,846 @@
+// sht.hip - HEALPix spherical-harmonic synthesis (alm -> RING maps) for many channels.
+//
+// Replaces hputil.sphtrans_inv_sky -> healpy.alm2map (cora/util/hputil.py:369-391,500-531).
+// Definition implemented: SURVEY.md Appendix A (HEALPix software conventions).
+//
+// Two kernels per pass over a chunk of channels:
+//   K4 legendre_kernel : F_m(ring) = sum_l a_lm lambda_lm(cos theta_ring) for every ring pair,
+//        as FP64 MFMA (v_mfma_f64_16x16x4_f64): A = lambda (rows = rings, generated in
+//        registers by the three-term recurrence), B = a_lm (LDS-staged rows of the
+//        [nalm][cols] device layout), even/odd (l-m) accumulated separately so the
+//        north ring gets e+o and its southern mirror e-o.
+//   K5 ringfft_kernel  : per ring and channel: phase e^{i m phi0}, alias fold onto nphi
+//        bins, complex-to-real FFT of length nphi (radix-2 in LDS; Bluestein for the
+//        cap rings whose length 4i is not a power of two), pixel store.
+// Intermediate F_m layout: inter[ring][g][m][c*4+v] (g = channel/4, v = channel%4,
+// c = re/im): 64-byte cells, contiguous in m for K5, 64-byte segments for K4's stores.
+#include "common.h"
+
+#include <algorithm>
+#include <cmath>
+
+// ------------------------------------------------------------------------------------
+struct corahip_sht_plan {
+    int nside = 0, lmax = 0, L = 0, npair = 0, nring = 0;
+    long npix = 0, nalm = 0;
+    std::vector<int64_t> h_start;
+    std::vector<int32_t> h_nphi;
+    std::vector<double> h_z, h_sth, h_phi0;
+    // device
+    double *d_z = nullptr, *d_sth = nullptr;              // [npair] (north rings + equator)
+    int32_t *d_nphi = nullptr;                            // [nring]
+    int64_t *d_start = nullptr;                           // [nring]
+    double *d_phi0 = nullptr;                             // [nring]
+    double2 *d_coef = nullptr;                            // [nalm]: (A_l, B_l) at alm_idx(l,m)
+    int32_t *d_lstart = nullptr;                          // [L][npair]
+    double2 *d_seed = nullptr;                            // [L][npair]: (lambda_{lstart-1}, lambda_{lstart})
+    double2 *d_tw = nullptr;                              // e^{+2 pi i k/pmax}, k < pmax/2
+    int pmax = 0, log_pmax = 0;
+    // Bluestein tables, indexed by north-cap ring number i-1 (i = 1..nside-1)
+    int32_t *d_blu_P = nullptr;                           // [nside]: 0 = power-of-two ring
+    int64_t *d_blu_boff = nullptr, *d_blu_foff = nullptr; // offsets into chirp / filter arrays
+    double2 *d_bchirp = nullptr, *d_bfilt = nullptr;
+    int max_fft_len = 0;                                  // largest LDS FFT buffer (complex elems)
+};
+
+static inline int ilog2(int v) {
+    int l = 0;
+    while ((1 << l) < v) l++;
+    return l;
+}
+static inline bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+
+// ------------------------------------------------------------------------------------
+// plan-time kernels
+// ------------------------------------------------------------------------------------
+__device__ static inline void scaled_pow(double s, int n, double &mant, int &ex) {
+    // s^n = mant * 2^ex with mant in [0.5, 1); exponentiation by squaring, renormalised
+    int e;
+    double f = frexp(s, &e);
+    double rm = 1.0;
+    int re = 0;
+    double bm = f;
+    int be = e;
+    while (n) {
+        if (n & 1) {
+            rm *= bm;
+            re += be;
+            int t;
+            rm = frexp(rm, &t);
+            re += t;
+        }
+        bm *= bm;
+        be *= 2;
+        int t;
+        bm = frexp(bm, &t);
+        be += t;
+        n >>= 1;
+    }
+    mant = rm;
+    ex = re;
+}
+
+#define SEED_MIN_EXP (-900)
+
+// lstart[m][r]: first l at which |lambda_lm(ring r)| >= 2^SEED_MIN_EXP, with the two
+// recurrence values there; terms below are < 1e-270 and are dropped (libsharp does the same).
+__global__ void seed_kernel(int lmax, int npair, const double *__restrict__ z, const double *__restrict__ sth,
+                            const double *__restrict__ pref, const double2 *__restrict__ coef,
+                            int32_t *__restrict__ lstart, double2 *__restrict__ seed) {
+    int r = blockIdx.x * blockDim.x + threadIdx.x;
+    int m = blockIdx.y;
+    if (r >= npair) return;
+    double x = z[r];
+    double pm;
+    int pe;
+    scaled_pow(sth[r], m, pm, pe);
+    int t;
+    double mant = frexp(pm * pref[m], &t);
+    int sc = pe + t;
+    if (m & 1) mant = -mant;
+    long o = (long)m * npair + r;
+    if (sc >= SEED_MIN_EXP) {
+        lstart[o] = m;
+        seed[o] = make_double2(0.0, ldexp(mant, sc));
+        return;
+    }
+    const double2 *cf = coef + alm_idx(0, m, lmax);
+    double p0 = 0.0, p1 = mant;  // scaled by 2^sc
+    int found = lmax + 1;
+    double s0 = 0.0, s1 = 0.0;
+    for (int l = m + 1; l <= lmax; l++) {
+        double2 c = cf[l];
+        double v = fma(c.x * x, p1, -(c.y * p0));
+        p0 = p1;
+        p1 = v;
+        if (fabs(p1) > 0x1p100) {
+            p0 *= 0x1p-100;
+            p1 *= 0x1p-100;
+            sc += 100;
+        }
+        if (p1 != 0.0 && sc + ilogb(p1) >= SEED_MIN_EXP) {
+            found = l;
+            s0 = ldexp(p0, sc);
+            s1 = ldexp(p1, sc);
+            break;
+        }
+    }
+    lstart[o] = found;
+    seed[o] = make_double2(s0, s1);
+}
+
+// test hook: lambda_lm for one (m, ring pair), l = m..lmax
+__global__ void lambda_kernel(int lmax, int npair, int m, int r, const double *__restrict__ z,
+                              const double2 *__restrict__ coef, const int32_t *__restrict__ lstart,
+                              const double2 *__restrict__ seed, double *__restrict__ out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double x = z[r];
+    long o = (long)m * npair + r;
+    int ls = lstart[o];
+    double2 sd = seed[o];
+    const double2 *cf = coef + alm_idx(0, m, lmax);
+    double p0 = 0.0, p1 = 0.0;
+    for (int l = m; l <= lmax; l++) {
+        double2 c = cf[l];
+        double v = fma(c.x * x, p1, -(c.y * p0));
+        bool inj = (l == ls);
+        v = inj ? sd.y : v;
+        p0 = inj ? sd.x : p1;
+        p1 = v;
+        out[l - m] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// K4: Legendre contraction on FP64 MFMA
+// ------------------------------------------------------------------------------------
+#define LEG_KT 32      // l rows per LDS stage
+#define LEG_RINGS 64   // ring pairs per block (4 waves x 16)
+
+template <int NT>
+__global__ void __launch_bounds__(256)
+legendre_kernel(int lmax, int npair, int nring, int ncols, const double *__restrict__ z,
+                const double2 *__restrict__ coef, const int32_t *__restrict__ lstart,
+                const double2 *__restrict__ seed, const double *__restrict__ alm,
+                double *__restrict__ inter) {
+    constexpr int TCOLS = 16 * NT;          // columns of this block
+    constexpr int STRIDE = TCOLS + 8;       // LDS row stride (doubles): 2 rows apart = 128 B mod 256
+    constexpr int STAGE = LEG_KT * STRIDE;  // doubles per stage
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    int &s_lmin = *reinterpret_cast<int *>(lds + 2 * STAGE);  // carved after the two stages (G17: no static LDS)
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int ri = lane & 15, kq = lane >> 4;
+    const int m = blockIdx.z;
+    const int cg = blockIdx.y;
+    const int L = lmax + 1;
+    const int G = ncols >> 3;
+    const int ring = blockIdx.x * LEG_RINGS + wave * 16 + ri;
+    const bool ring_ok = ring < npair;
+
+    double x = 0.0;
+    int my_ls = lmax + 1;
+    double2 sd = make_double2(0.0, 0.0);
+    if (ring_ok) {
+        x = z[ring];
+        long o = (long)m * npair + ring;
+        my_ls = lstart[o];
+        sd = seed[o];
+    }
+    if (tid == 0) s_lmin = lmax + 1;
+    __syncthreads();
+    atomicMin(&s_lmin, my_ls);
+    __syncthreads();
+    const int lmin = __builtin_amdgcn_readfirstlane(s_lmin);
+
+    d4_t acce[NT], acco[NT];
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+        acce[t] = (d4_t){0.0, 0.0, 0.0, 0.0};
+        acco[t] = (d4_t){0.0, 0.0, 0.0, 0.0};
+    }
+
+    if (lmin <= lmax) {
+        const int l_begin = m + ((lmin - m) & ~7);
+        const long base_m = alm_idx(0, m, lmax);
+        const double2 *cf = coef + base_m;
+        const double *arow = alm + (size_t)cg * TCOLS;
+        double p0 = 0.0, p1 = 0.0;
+
+        // stage loader: LEG_KT rows x TCOLS doubles = 8*NT*LEG_KT double2 items, NT per thread
+        double2 pre[NT];
+        auto gload = [&](int ls) {
+#pragma unroll
+            for (int j = 0; j < NT; j++) {
+                int q = tid + 256 * j;
+                int row = q / (8 * NT), c2 = q % (8 * NT);
+                int l = ls + row;
+                if (l <= lmax) {
+                    pre[j] = *reinterpret_cast<const double2 *>(arow + (size_t)(base_m + l) * ncols + 2 * c2);
+                } else {
+                    pre[j] = make_double2(0.0, 0.0);
+                }
+            }
+        };
+        auto swrite = [&](int buf) {
+#pragma unroll
+            for (int j = 0; j < NT; j++) {
+                int q = tid + 256 * j;
+                int row = q / (8 * NT), c2 = q % (8 * NT);
+                *reinterpret_cast<double2 *>(lds + buf * STAGE + row * STRIDE + 2 * c2) = pre[j];
+            }
+        };
+
+        gload(l_begin);
+        swrite(0);
+        __syncthreads();
+        int buf = 0;
+        for (int ls = l_begin; ls <= lmax; ls += LEG_KT) {
+            const bool more = (ls + LEG_KT) <= lmax;
+            if (more) gload(ls + LEG_KT);
+            const double *sb = lds + buf * STAGE;
+#pragma unroll 1
+            for (int ms = 0; ms < LEG_KT / 8; ms++) {
+                const int l0 = ls + 8 * ms;
+                if (l0 > lmax) break;
+                // whole wave still below its first contributing l: nothing to do
+                if (__all(my_ls > l0 + 7)) continue;
+                double v[8];
+                const bool inj_here = (my_ls >= l0) && (my_ls < l0 + 8);
+                if (__any(inj_here)) {
+#pragma unroll
+                    for (int j = 0; j < 8; j++) {
+                        const int l = l0 + j;
+                        double2 c = cf[l <= lmax ? l : lmax];
+                        if (l > lmax) c = make_double2(0.0, 0.0);
+                        double vv = fma(c.x * x, p1, -(c.y * p0));
+                        const bool inj = (l == my_ls);
+                        vv = inj ? sd.y : vv;
+                        p0 = inj ? sd.x : p1;
+                        p1 = vv;
+                        v[j] = vv;
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; j++) {
+                        const int l = l0 + j;
+                        double2 c = cf[l <= lmax ? l : lmax];
+                        if (l > lmax) c = make_double2(0.0, 0.0);
+                        double vv = fma(c.x * x, p1, -(c.y * p0));
+                        p0 = p1;
+                        p1 = vv;
+                        v[j] = vv;
+                    }
+                }
+                // MFMA A operand: lane (ring ri, k-slot kq) supplies lambda at l0+2kq (even) / +1 (odd)
+                const double ae = kq == 0 ? v[0] : kq == 1 ? v[2] : kq == 2 ? v[4] : v[6];
+                const double ao = kq == 0 ? v[1] : kq == 1 ? v[3] : kq == 2 ? v[5] : v[7];
+                const double *be = sb + (8 * ms + 2 * kq) * STRIDE + ri;
+                const double *bo = be + STRIDE;
+#pragma unroll
+                for (int t = 0; t < NT; t++) {
+                    acce[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(ae, be[16 * t], acce[t], 0, 0, 0);
+                    acco[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(ao, bo[16 * t], acco[t], 0, 0, 0);
+                }
+            }
+            if (more) swrite(buf ^ 1);
+            __syncthreads();
+            buf ^= 1;
+        }
+    }
+
+    // epilogue: north = even + odd, south mirror = even - odd
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+        const int col = cg * TCOLS + 16 * t + ri;
+        const int g = col >> 3, cv = col & 7;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int ro = blockIdx.x * LEG_RINGS + wave * 16 + kq + 4 * r;
+            if (ro < npair) {
+                const double e = acce[t][r], o = acco[t][r];
+                inter[(((size_t)ro * G + g) * L + m) * 8 + cv] = e + o;
+                const int rs = nring - 1 - ro;
+                if (rs != ro) inter[(((size_t)rs * G + g) * L + m) * 8 + cv] = e - o;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// K5: per-ring phase / fold / FFT
+// ------------------------------------------------------------------------------------
+__device__ static inline double2 cmul(double2 a, double2 b) {
+    return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+__device__ static inline double2 cconj(double2 a) { return make_double2(a.x, -a.y); }
+
+__device__ static inline unsigned bitrev(unsigned v, int bits) { return __brev(v) >> (32 - bits); }
+
+// in-place radix-2 decimation-in-frequency: natural order in -> bit-reversed order out.
+// sign = +1: kernel e^{+2 pi i jk/P};  -1: e^{-2 pi i jk/P}.  tw[k] = e^{+2 pi i k/pmax}.
+__device__ static void fft_dif(double2 *buf, int P, int logP, const double2 *__restrict__ tw, int pmax, int sign) {
+    const int tid = threadIdx.x, nt = blockDim.x;
+    for (int s = 0; s < logP; s++) {
+        const int half = P >> (s + 1);
+        const int twstep = pmax / (2 * half);
+        for (int j = tid; j < (P >> 1); j += nt) {
+            const int grp = j / half, pos = j - grp * half;
+            const int i0 = grp * 2 * half + pos, i1 = i0 + half;
+            const double2 a = buf[i0], b = buf[i1];
+            double2 w = tw[pos * twstep];
+            if (sign < 0) w.y = -w.y;
+            buf[i0] = make_double2(a.x + b.x, a.y + b.y);
+            buf[i1] = cmul(make_double2(a.x - b.x, a.y - b.y), w);
+        }
+        __syncthreads();
+    }
+}
+
+// in-place radix-2 decimation-in-time: bit-reversed order in -> natural order out.
+__device__ static void fft_dit(double2 *buf, int P, int logP, const double2 *__restrict__ tw, int pmax, int sign) {
+    const int tid = threadIdx.x, nt = blockDim.x;
+    for (int s = logP - 1; s >= 0; s--) {
+        const int half = P >> (s + 1);
+        const int twstep = pmax / (2 * half);
+        for (int j = tid; j < (P >> 1); j += nt) {
+            const int grp = j / half, pos = j - grp * half;
+            const int i0 = grp * 2 * half + pos, i1 = i0 + half;
+            double2 w = tw[pos * twstep];
+            if (sign < 0) w.y = -w.y;
+            const double2 a = buf[i0], b = cmul(buf[i1], w);
+            buf[i0] = make_double2(a.x + b.x, a.y + b.y);
+            buf[i1] = make_double2(a.x - b.x, a.y - b.y);
+        }
+        __syncthreads();
+    }
+}
+
+// Bluestein tables for cap ring i (h = 2i not a power of two): chirp b_j = e^{i pi j^2/h}, j < h,
+// and filt = FFT_P(conj chirp wrapped), stored in the bit-reversed order fft_dif produces.
+__global__ void bluestein_table_kernel(const int32_t *__restrict__ blu_P, const int64_t *__restrict__ boff,
+                                       const int64_t *__restrict__ foff, double2 *__restrict__ chirp,
+                                       double2 *__restrict__ filt, const double2 *__restrict__ tw, int pmax) {
+    extern __shared__ __attribute__((aligned(16))) double2 fbuf[];
+    const int i = blockIdx.x + 1;
+    const int P = blu_P[i - 1];
+    if (P == 0) return;
+    const int h = 2 * i;
+    double2 *b = chirp + boff[i - 1];
+    for (int j = threadIdx.x; j < P; j += blockDim.x) fbuf[j] = make_double2(0.0, 0.0);
+    __syncthreads();
+    for (int j = threadIdx.x; j < h; j += blockDim.x) {
+        const long q = ((long)j * j) % (2 * h);
+        double s, c;
+        sincospi((double)q / (double)h, &s, &c);
+        b[j] = make_double2(c, s);
+        fbuf[j] = make_double2(c, -s);
+        if (j > 0) fbuf[P - j] = make_double2(c, -s);
+    }
+    __syncthreads();
+    int logP = 0;
+    while ((1 << logP) < P) logP++;
+    fft_dif(fbuf, P, logP, tw, pmax, -1);
+    double2 *f = filt + foff[i - 1];
+    for (int j = threadIdx.x; j < P; j += blockDim.x) f[j] = fbuf[j];
+}
+
+// one block per (ring, channel group of 4); channels handled one after the other.
+template <bool PHASE_LDS>
+__global__ void __launch_bounds__(256)
+ringfft_kernel(int nside, int lmax, int nring, int G, int nnu, long npix, const int32_t *__restrict__ nphi_a,
+               const int64_t *__restrict__ start_a, const double *__restrict__ phi0_a,
+               const double *__restrict__ inter, double *__restrict__ maps, const double2 *__restrict__ tw,
+               int pmax, const int32_t *__restrict__ blu_P, const int64_t *__restrict__ boff,
+               const int64_t *__restrict__ foff, const double2 *__restrict__ chirp,
+               const double2 *__restrict__ filt, int fft_len_max) {
+    extern __shared__ __attribute__((aligned(16))) double2 sm[];
+    double2 *buf = sm;                   // [max(P, h+1)]
+    double2 *phase = sm + fft_len_max;   // [L] when PHASE_LDS
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int ring = blockIdx.x, g = blockIdx.y;
+    const int L = lmax + 1;
+    const int n = nphi_a[ring];
+    const int h = n >> 1;
+    const long start = start_a[ring];
+    const double phi0 = phi0_a[ring];
+    // cap ring number (1-based, mirrored for the south cap); 0 for belt rings
+    int icap = 0;
+    if (ring + 1 < nside) icap = ring + 1;
+    else if (ring + 1 > 3 * nside) icap = 4 * nside - (ring + 1);
+    const int P = icap ? blu_P[icap - 1] : 0;  // 0 -> direct power-of-two transform of length h
+    const double phi0_over_pi = phi0 / M_PI;
+
+    if (PHASE_LDS) {
+        for (int m = tid; m < L; m += nt) {
+            double s, c;
+            // e^{i m phi0}; phi0/pi is 1/(4i), 1/(4 nside) or 0: reduce m*phi0/pi mod 2 exactly enough
+            sincospi(fmod((double)m * phi0_over_pi, 2.0), &s, &c);
+            phase[m] = make_double2(c, s);
+        }
+    }
+    const double *cell = inter + ((size_t)ring * G + g) * L * 8;
+
+    for (int v = 0; v < 4; v++) {
+        const int nu = 4 * g + v;
+        if (nu >= nnu) break;
+        const int flen = P ? P : (h + 1);
+        for (int j = tid; j < (flen > h + 1 ? flen : h + 1); j += nt) buf[j] = make_double2(0.0, 0.0);
+        __syncthreads();
+        // ---- phase + alias fold onto bins 0..h of the Hermitian length-n spectrum X
+        double *bufd = reinterpret_cast<double *>(buf);
+        for (int m = tid; m < L; m += nt) {
+            double2 f = make_double2(cell[(size_t)m * 8 + v], cell[(size_t)m * 8 + 4 + v]);
+            double2 ph;
+            if (PHASE_LDS) ph = phase[m];
+            else {
+                double s, c;
+                sincospi(fmod((double)m * phi0_over_pi, 2.0), &s, &c);
+                ph = make_double2(c, s);
+            }
+            const double2 c = cmul(f, ph);
+            if (m == 0) {
+                atomicAdd(&bufd[0], c.x);
+            } else {
+                const int k = m % n;
+                const int kc = (n - k) % n;
+                if (k <= h) {
+                    atomicAdd(&bufd[2 * k], c.x);
+                    atomicAdd(&bufd[2 * k + 1], c.y);
+                }
+                if (kc <= h) {
+                    atomicAdd(&bufd[2 * kc], c.x);
+                    atomicAdd(&bufd[2 * kc + 1], -c.y);
+                }
+            }
+        }
+        __syncthreads();
+        // ---- Hermitian -> half-length complex: Z_k = (X_k + conj X_{h-k}) + i w^k (X_k - conj X_{h-k})
+        // pairs (k, h-k) are updated together; w = e^{2 pi i/n}
+        for (int k = tid; k <= h / 2; k += nt) {
+            const int k2 = h - k;
+            const double2 xa = buf[k], xb = buf[k2];
+            double s, c;
+            sincospi(2.0 * (double)k / (double)n, &s, &c);
+            const double2 w = make_double2(c, s);
+            // Z_k
+            double2 sum = make_double2(xa.x + xb.x, xa.y - xb.y);
+            double2 dif = make_double2(xa.x - xb.x, xa.y + xb.y);
+            double2 t = cmul(dif, w);
+            const double2 zk = make_double2(sum.x - t.y, sum.y + t.x);
+            // Z_{h-k}: w^{h-k} = -conj(w^k)
+            sum = make_double2(xb.x + xa.x, xb.y - xa.y);
+            dif = make_double2(xb.x - xa.x, xb.y + xa.y);
+            t = cmul(dif, make_double2(-c, s));
+            const double2 zk2 = make_double2(sum.x - t.y, sum.y + t.x);
+            if (k2 < h) buf[k2] = zk2;
+            if (k < h) buf[k] = zk;
+        }
+        __syncthreads();
+        double *out = maps + (size_t)nu * npix + start;
+        if (P == 0) {
+            // direct: z = IDFT_h(Z) (unnormalised, + sign); h is a power of two
+            int logh = 0;
+            while ((1 << logh) < h) logh++;
+            fft_dif(buf, h, logh, tw, pmax, +1);
+            for (int j = tid; j < h; j += nt) {
+                const double2 zv = buf[logh ? bitrev((unsigned)j, logh) : 0];
+                *reinterpret_cast<double2 *>(out + 2 * j) = zv;
+            }
+        } else {
+            // Bluestein: z_j = b_j * IFFT_P( FFT_P(Z b) * filt )_j
+            const double2 *b = chirp + boff[icap - 1];
+            const double2 *f = filt + foff[icap - 1];
+            int logP = 0;
+            while ((1 << logP) < P) logP++;
+            for (int j = tid; j < P; j += nt) {
+                double2 val = make_double2(0.0, 0.0);
+                if (j < h) val = cmul(buf[j], b[j]);
+                buf[j] = val;
+            }
+            __syncthreads();
+            fft_dif(buf, P, logP, tw, pmax, -1);
+            for (int j = tid; j < P; j += nt) buf[j] = cmul(buf[j], f[j]);
+            __syncthreads();
+            fft_dit(buf, P, logP, tw, pmax, +1);
+            const double invP = 1.0 / (double)P;
+            for (int j = tid; j < h; j += nt) {
+                double2 zv = cmul(buf[j], b[j]);
+                zv.x *= invP;
+                zv.y *= invP;
+                *reinterpret_cast<double2 *>(out + 2 * j) = zv;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------
+template <typename T>
+static int dev_upload(T **dptr, const std::vector<T> &h, hipStream_t s) {
+    HIP_TRY(hipMalloc((void **)dptr, std::max<size_t>(1, h.size()) * sizeof(T)));
+    if (!h.empty()) {
+        HIP_TRY(hipMemcpyAsync(*dptr, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, s));
+        HIP_TRY(hipStreamSynchronize(s));
+    }
+    return 0;
+}
+
+extern "C" {
+
+int corahip_sht_plan_destroy(corahip_ctx *ctx, corahip_sht_plan *p) {
+    if (!p) return 0;
+    (void)hipFree(p->d_z);
+    (void)hipFree(p->d_sth);
+    (void)hipFree(p->d_nphi);
+    (void)hipFree(p->d_start);
+    (void)hipFree(p->d_phi0);
+    (void)hipFree(p->d_coef);
+    (void)hipFree(p->d_lstart);
+    (void)hipFree(p->d_seed);
+    (void)hipFree(p->d_tw);
+    (void)hipFree(p->d_blu_P);
+    (void)hipFree(p->d_blu_boff);
+    (void)hipFree(p->d_blu_foff);
+    (void)hipFree(p->d_bchirp);
+    (void)hipFree(p->d_bfilt);
+    delete p;
+    return 0;
+}
+
+int corahip_sht_plan_create(corahip_ctx *ctx, int nside, int lmax, corahip_sht_plan **out) {
+    ARG_CHECK(ctx != nullptr && out != nullptr);
+    ARG_CHECK(nside >= 1 && is_pow2(nside) && nside <= 8192);
+    ARG_CHECK(lmax >= 0 && lmax <= 16384);
+    HIP_TRY(hipSetDevice(ctx->device));
+    corahip_sht_plan *p = new corahip_sht_plan();
+    p->nside = nside;
+    p->lmax = lmax;
+    p->L = lmax + 1;
+    p->npair = 2 * nside;
+    p->nring = 4 * nside - 1;
+    p->npix = 12L * nside * nside;
+    p->nalm = nalm_of(lmax);
+    const int nring = p->nring;
+    p->h_start.resize(nring);
+    p->h_nphi.resize(nring);
+    p->h_z.resize(nring);
+    p->h_sth.resize(nring);
+    p->h_phi0.resize(nring);
+    // HEALPix RING geometry (pix2ang_ring conventions)
+    const double fact2 = 4.0 / (double)p->npix;       // 1/(3 nside^2)
+    const double fact1 = 2.0 * nside * fact2;         // 2/(3 nside)
+    for (int r = 0; r < nring; r++) {
+        const int i = r + 1;
+        if (i < nside) {
+            const double tmp = (double)i * i * fact2;
+            p->h_z[r] = 1.0 - tmp;
+            p->h_sth[r] = sqrt(tmp * (2.0 - tmp));
+            p->h_nphi[r] = 4 * i;
+            p->h_phi0[r] = M_PI / (4.0 * i);
+            p->h_start[r] = 2L * i * (i - 1);
+        } else if (i <= 3 * nside) {
+            const double zz = (2 * nside - i) * fact1;
+            p->h_z[r] = zz;
+            p->h_sth[r] = sqrt((1.0 - zz) * (1.0 + zz));
+            p->h_nphi[r] = 4 * nside;
+            p->h_phi0[r] = (((i - nside) & 1) == 0) ? M_PI / (4.0 * nside) : 0.0;
+            p->h_start[r] = 2L * nside * (nside - 1) + (long)(i - nside) * 4 * nside;
+        } else {
+            const int ip = 4 * nside - i;
+            const double tmp = (double)ip * ip * fact2;
+            p->h_z[r] = -(1.0 - tmp);
+            p->h_sth[r] = sqrt(tmp * (2.0 - tmp));
+            p->h_nphi[r] = 4 * ip;
+            p->h_phi0[r] = M_PI / (4.0 * ip);
+            p->h_start[r] = p->npix - 2L * ip * (ip + 1);
+        }
+    }
+    hipStream_t s = ctx->stream;
+    int rc;
+    {
+        std::vector<double> zz(p->h_z.begin(), p->h_z.begin() + p->npair);
+        std::vector<double> ss(p->h_sth.begin(), p->h_sth.begin() + p->npair);
+        if ((rc = dev_upload(&p->d_z, zz, s))) return rc;
+        if ((rc = dev_upload(&p->d_sth, ss, s))) return rc;
+    }
+    if ((rc = dev_upload(&p->d_nphi, p->h_nphi, s))) return rc;
+    if ((rc = dev_upload(&p->d_start, p->h_start, s))) return rc;
+    if ((rc = dev_upload(&p->d_phi0, p->h_phi0, s))) return rc;
+
+    // recurrence coefficients: lambda_l = A_l x lambda_{l-1} - B_l lambda_{l-2},
+    // A_l = alpha_lm, B_l = alpha_lm/alpha_{l-1,m}, alpha_lm = sqrt((4l^2-1)/(l^2-m^2))
+    {
+        std::vector<double2> coef(p->nalm);
+        for (int m = 0; m <= lmax; m++) {
+            long double aprev = 0.0L;
+            for (int l = m; l <= lmax; l++) {
+                const long o = alm_idx(l, m, lmax);
+                if (l == m) {
+                    coef[o] = make_double2(0.0, 0.0);
+                    continue;
+                }
+                const long double ll = l, mm = m;
+                const long double al = sqrtl((4.0L * ll * ll - 1.0L) / (ll * ll - mm * mm));
+                coef[o] = make_double2((double)al, l == m + 1 ? 0.0 : (double)(al / aprev));
+                aprev = al;
+            }
+        }
+        if ((rc = dev_upload(&p->d_coef, coef, s))) return rc;
+    }
+    // |lambda_mm| prefactor sqrt((2m+1)!!/(4 pi (2m)!!))
+    double *d_pref = nullptr;
+    {
+        std::vector<double> pref(p->L);
+        long double pr = 1.0L / sqrtl(4.0L * acosl(-1.0L));
+        pref[0] = (double)pr;
+        for (int m = 1; m <= lmax; m++) {
+            pr *= sqrtl((2.0L * m + 1.0L) / (2.0L * m));
+            pref[m] = (double)pr;
+        }
+        if ((rc = dev_upload(&d_pref, pref, s))) return rc;
+    }
+    HIP_TRY(hipMalloc((void **)&p->d_lstart, sizeof(int32_t) * (size_t)p->L * p->npair));
+    HIP_TRY(hipMalloc((void **)&p->d_seed, sizeof(double2) * (size_t)p->L * p->npair));
+    {
+        dim3 grid((p->npair + 63) / 64, p->L);
+        seed_kernel<<<grid, 64, 0, s>>>(lmax, p->npair, p->d_z, p->d_sth, d_pref, p->d_coef, p->d_lstart, p->d_seed);
+        LAUNCH_CHECK();
+    }
+    HIP_TRY(hipStreamSynchronize(s));
+    (void)hipFree(d_pref);
+
+    // FFT twiddles and Bluestein tables
+    p->pmax = std::max(4 * nside, 4);
+    p->log_pmax = ilog2(p->pmax);
+    {
+        std::vector<double2> tw(p->pmax / 2);
+        for (int k = 0; k < p->pmax / 2; k++) {
+            const long double a = 2.0L * acosl(-1.0L) * k / p->pmax;
+            tw[k] = make_double2((double)cosl(a), (double)sinl(a));
+        }
+        if ((rc = dev_upload(&p->d_tw, tw, s))) return rc;
+    }
+    {
+        std::vector<int32_t> bp(nside, 0);
+        std::vector<int64_t> bo(nside, 0), fo(nside, 0);
+        int64_t nb = 0, nf = 0;
+        int maxlen = 2 * nside + 1;  // belt: h + 1
+        for (int i = 1; i < nside; i++) {
+            const int h = 2 * i;
+            if (is_pow2(h)) continue;
+            int P = 1;
+            while (P < 2 * h - 1) P <<= 1;
+            bp[i - 1] = P;
+            bo[i - 1] = nb;
+            fo[i - 1] = nf;
+            nb += h;
+            nf += P;
+            maxlen = std::max(maxlen, P);
+        }
+        p->max_fft_len = maxlen;
+        if ((rc = dev_upload(&p->d_blu_P, bp, s))) return rc;
+        if ((rc = dev_upload(&p->d_blu_boff, bo, s))) return rc;
+        if ((rc = dev_upload(&p->d_blu_foff, fo, s))) return rc;
+        HIP_TRY(hipMalloc((void **)&p->d_bchirp, sizeof(double2) * std::max<int64_t>(1, nb)));
+        HIP_TRY(hipMalloc((void **)&p->d_bfilt, sizeof(double2) * std::max<int64_t>(1, nf)));
+        if (nside > 1) {
+            const size_t shm = sizeof(double2) * (size_t)maxlen;
+            HIP_TRY(hipFuncSetAttribute((const void *)bluestein_table_kernel,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+            bluestein_table_kernel<<<nside - 1, 256, shm, s>>>(p->d_blu_P, p->d_blu_boff, p->d_blu_foff,
+                                                                p->d_bchirp, p->d_bfilt, p->d_tw, p->pmax);
+            LAUNCH_CHECK();
+        }
+    }
+    HIP_TRY(hipStreamSynchronize(s));
+    *out = p;
+    return 0;
+}
+
+int corahip_sht_plan_rings(const corahip_sht_plan *p, int64_t *host_start, int32_t *host_nphi, double *host_z,
+                           double *host_phi0) {
+    ARG_CHECK(p != nullptr);
+    for (int r = 0; r < p->nring; r++) {
+        if (host_start) host_start[r] = p->h_start[r];
+        if (host_nphi) host_nphi[r] = p->h_nphi[r];
+        if (host_z) host_z[r] = p->h_z[r];
+        if (host_phi0) host_phi0[r] = p->h_phi0[r];
+    }
+    return 0;
+}
+
+int corahip_sht_lambda(corahip_ctx *ctx, const corahip_sht_plan *p, int m, int ring_pair, double *out) {
+    ARG_CHECK(ctx != nullptr && p != nullptr && out != nullptr);
+    ARG_CHECK(m >= 0 && m <= p->lmax && ring_pair >= 0 && ring_pair < p->npair);
+    lambda_kernel<<<1, 64, 0, ctx->stream>>>(p->lmax, p->npair, m, ring_pair, p->d_z, p->d_coef, p->d_lstart,
+                                             p->d_seed, out);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+}  // extern "C"
+
+static inline int nnu_pad_of(int nnu) { return (nnu + 7) & ~7; }
+
+extern "C" int corahip_alm2map_workspace_bytes(const corahip_sht_plan *p, int nnu, size_t *bytes) {
+    ARG_CHECK(p != nullptr && bytes != nullptr && nnu >= 1);
+    const size_t G = nnu_pad_of(nnu) / 4;
+    *bytes = (size_t)p->nring * G * p->L * 8 * sizeof(double);
+    // an odd number of 4-channel groups cannot be consumed in place (K4 tiles are 16 columns
+    // = 2 groups wide): the padded copy of the alm block lives in the workspace too
+    if (((nnu + 3) / 4) & 1) *bytes += (size_t)p->nalm * G * 8 * sizeof(double);
+    return 0;
+}
+
+template <int NT>
+static int launch_legendre(corahip_ctx *ctx, const corahip_sht_plan *p, int ncols, const double *alm, double *inter) {
+    constexpr int STRIDE = 16 * NT + 8;
+    const size_t shm = sizeof(double) * 2 * LEG_KT * STRIDE + 16;
+    HIP_TRY(hipFuncSetAttribute((const void *)legendre_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)shm));
+    dim3 grid((p->npair + LEG_RINGS - 1) / LEG_RINGS, ncols / (16 * NT), p->L);
+    legendre_kernel<NT><<<grid, 256, shm, ctx->stream>>>(p->lmax, p->npair, p->nring, ncols, p->d_z, p->d_coef,
+                                                        p->d_lstart, p->d_seed, alm, inter);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+// alm_chunk: [nalm][ncols] with ncols = 2*nnu_pad (multiple of 16)
+static int alm2map_chunk(corahip_ctx *ctx, const corahip_sht_plan *p, const double *alm_chunk, int nnu_chunk_pad,
+                         int nnu_valid, double *maps, double *inter) {
+    const int ncols = 2 * nnu_chunk_pad;
+    const int ntile = ncols / 16;
+    int rc;
+    {
+        StageTimer t(ctx, "legendre");
+        if (ntile % 8 == 0) rc = launch_legendre<8>(ctx, p, ncols, alm_chunk, inter);
+        else if (ntile % 4 == 0) rc = launch_legendre<4>(ctx, p, ncols, alm_chunk, inter);
+        else if (ntile % 2 == 0) rc = launch_legendre<2>(ctx, p, ncols, alm_chunk, inter);
+        else rc = launch_legendre<1>(ctx, p, ncols, alm_chunk, inter);
+        if (rc) return rc;
+    }
+    {
+        StageTimer t(ctx, "ringfft");
+        const int G = nnu_chunk_pad / 4;
+        dim3 grid(p->nring, (nnu_valid + 3) / 4);
+        size_t shm = sizeof(double2) * ((size_t)p->max_fft_len + p->L);
+        if (shm <= 160 * 1024) {
+            HIP_TRY(hipFuncSetAttribute((const void *)ringfft_kernel<true>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+            ringfft_kernel<true><<<grid, 256, shm, ctx->stream>>>(
+                p->nside, p->lmax, p->nring, G, nnu_valid, p->npix, p->d_nphi, p->d_start, p->d_phi0, inter, maps,
+                p->d_tw, p->pmax, p->d_blu_P, p->d_blu_boff, p->d_blu_foff, p->d_bchirp, p->d_bfilt, p->max_fft_len);
+        } else {
+            shm = sizeof(double2) * (size_t)p->max_fft_len;
+            if (shm > 160 * 1024) {
+                corahip_set_error("nside %d needs %zu bytes of LDS for the ring FFT (max 160 KiB)", p->nside, shm);
+                return CORAHIP_ENOMEM;
+            }
+            HIP_TRY(hipFuncSetAttribute((const void *)ringfft_kernel<false>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+            ringfft_kernel<false><<<grid, 256, shm, ctx->stream>>>(
+                p->nside, p->lmax, p->nring, G, nnu_valid, p->npix, p->d_nphi, p->d_start, p->d_phi0, inter, maps,
+                p->d_tw, p->pmax, p->d_blu_P, p->d_blu_boff, p->d_blu_foff, p->d_bchirp, p->d_bfilt, p->max_fft_len);
+        }
+        LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+// gather channel groups [g0, g0+Gc) of alm_dev ([nalm][Gsrc][8]) into a dense [nalm][Gc][8] chunk;
+// groups past the source (padding) are zero-filled
+__global__ void alm_slice_kernel(const double *__restrict__ src, double *__restrict__ dst, long nalm, int Gsrc,
+                                 int g0, int Gc) {
+    const long n = nalm * Gc * 4;  // double2 items (4 per group cell)
+    for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (long)gridDim.x * blockDim.x) {
+        const long idx = q / (Gc * 4);
+        const int w = (int)(q % (Gc * 4));
+        const int gsrc = g0 + (w >> 2);
+        double2 v = make_double2(0.0, 0.0);
+        if (gsrc < Gsrc) v = *reinterpret_cast<const double2 *>(src + ((size_t)idx * Gsrc + g0) * 8 + 2 * w);
+        *reinterpret_cast<double2 *>(dst + (size_t)idx * Gc * 8 + 2 * w) = v;
+    }
+}
+
+extern "C" int corahip_alm2map(corahip_ctx *ctx, const corahip_sht_plan *p, const double *alm_dev, int nnu,
+                               double *maps, void *workspace, size_t workspace_bytes) {
+    ARG_CHECK(ctx != nullptr && p != nullptr && alm_dev != nullptr && maps != nullptr && workspace != nullptr);
+    ARG_CHECK(nnu >= 1);
+    const int nnu_pad4 = (nnu + 3) & ~3;  // alm_dev layout granularity
+    const int Gsrc = nnu_pad4 / 4;
+    const int nnu_pad8 = nnu_pad_of(nnu);
+    size_t need_full;
+    corahip_alm2map_workspace_bytes(p, nnu, &need_full);
+    if (nnu_pad4 == nnu_pad8 && workspace_bytes >= need_full) {
+        // single pass straight from alm_dev
+        return alm2map_chunk(ctx, p, alm_dev, nnu_pad8, nnu, maps, (double *)workspace);
+    }
+    // chunked: workspace holds [inter for chunk][alm slice for chunk]
+    const size_t per8_inter = (size_t)p->nring * 2 * p->L * 8 * sizeof(double);
+    const size_t per8_alm = (size_t)p->nalm * 16 * sizeof(double);
+    int nchunk8 = (int)(workspace_bytes / (per8_inter + per8_alm));
+    if (nchunk8 < 1) {
+        corahip_set_error("alm2map workspace too small: %zu bytes, need at least %zu", workspace_bytes,
+                          per8_inter + per8_alm);
+        return CORAHIP_ENOMEM;
+    }
+    // prefer chunks that are multiples of 64 channels (NT = 8 tiles)
+    if (nchunk8 >= 8) nchunk8 &= ~7;
+    const int chunk = nchunk8 * 8;
+    double *inter = (double *)workspace;
+    double *slice = (double *)((char *)workspace + (size_t)nchunk8 * per8_inter);
+    for (int nu0 = 0; nu0 < nnu; nu0 += chunk) {
+        const int nvalid = std::min(chunk, nnu - nu0);
+        const int cpad8 = nnu_pad_of(nvalid);
+        const int Gc = cpad8 / 4;
+        alm_slice_kernel<<<2048, 256, 0, ctx->stream>>>(alm_dev, slice, p->nalm, Gsrc, nu0 / 4, Gc);
+        LAUNCH_CHECK();
+        int rc = alm2map_chunk(ctx, p, slice, cpad8, nvalid, maps + (size_t)nu0 * p->npix, inter);
+        if (rc) return rc;
+    }
+    return 0;
+}

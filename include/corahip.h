@@ -1,0 +1,159 @@
+/* corahip.h - C ABI of libcorahip.so: the MI355X (gfx950) implementation of cora's
+ * Gaussian-sky hot path (C_l(nu,nu') integration -> per-l factor -> correlated
+ * a_lm draw -> HEALPix synthesis).
+ *
+ * The reference (radiocosmology/cora) has NO FFI on this path: its boundary is the
+ * Python call surface of cora/core/skysim.py, cora/util/nputil.py and
+ * cora/util/hputil.py.  Each entry point below names the reference code it replaces
+ * (file:line relative to the reference root); cora_amd/ mirrors the Python surface
+ * on top of this ABI, and INTEGRATION.md shows the ctypes stub a cora maintainer
+ * would add.
+ *
+ * Conventions
+ *  - every function returns int: 0 = OK, <0 = invalid argument (CORAHIP_E*),
+ *    >0 = hipError_t of the failing runtime call.  Nothing throws across the ABI.
+ *  - corahip_last_error() gives a thread-local human-readable message.
+ *  - all array arguments are DEVICE pointers unless the name says `host_`; they are
+ *    caller-owned (the Python side allocates them as torch tensors; hosts without
+ *    torch can use corahip_malloc/free/memcpy_*).  Arrays are C-contiguous,
+ *    float64 unless stated.
+ *  - work is enqueued on the context's stream (corahip_ctx_set_stream) and is
+ *    asynchronous; corahip_ctx_sync waits for it.
+ *  - one context per GPU/process; a context is not thread-safe.
+ */
+#ifndef CORAHIP_H
+#define CORAHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CORAHIP_ABI_VERSION 1
+
+#define CORAHIP_EINVAL (-1)   /* bad argument / shape */
+#define CORAHIP_ENOMEM (-2)   /* workspace too small / allocation refused */
+#define CORAHIP_ESTATE (-3)   /* object used in the wrong state */
+
+typedef struct corahip_ctx corahip_ctx;
+typedef struct corahip_sht_plan corahip_sht_plan;
+
+/* ---- library / context ------------------------------------------------------------ */
+int corahip_abi_version(void);
+const char *corahip_last_error(void);
+int corahip_device_count(int *count);
+int corahip_ctx_create(int device_id, corahip_ctx **ctx);
+int corahip_ctx_destroy(corahip_ctx *ctx);
+/* hip_stream: a hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL = default stream */
+int corahip_ctx_set_stream(corahip_ctx *ctx, void *hip_stream);
+int corahip_ctx_sync(corahip_ctx *ctx);
+/* HIP-event timing of everything enqueued between begin and end on the ctx stream (bench.py) */
+int corahip_timer_begin(corahip_ctx *ctx);
+int corahip_timer_end(corahip_ctx *ctx, float *elapsed_ms);
+/* per-kernel accumulated HIP-event timings (enable = 1 records an event pair around every
+ * kernel launch of the library; names: "clarray","factor","normals","draw","legendre","ringfft") */
+int corahip_profile_enable(corahip_ctx *ctx, int enable);
+int corahip_profile_get(corahip_ctx *ctx, const char *name, double *total_ms, int *launches);
+int corahip_profile_reset(corahip_ctx *ctx);
+
+/* ---- plain device memory helpers (for hosts without torch) ----------------------- */
+int corahip_malloc(corahip_ctx *ctx, size_t bytes, void **dptr);
+int corahip_free(corahip_ctx *ctx, void *dptr);
+int corahip_memcpy_h2d(corahip_ctx *ctx, void *dst, const void *host_src, size_t bytes);
+int corahip_memcpy_d2h(corahip_ctx *ctx, void *host_dst, const void *src, size_t bytes);
+
+/* ---- K1: C_l(nu,nu') integration --------------------------------------------------
+ * Replaces skysim.clarray (cora/core/skysim.py:10-69) for the two model families
+ * cora ships, plus the bare Romberg reduction for arbitrary host callables.         */
+
+/* 21cm flat-sky table model: RedshiftCorrelation.angular_powerspectrum_fft evaluation
+ * (cora/signal/corr.py:944-982) with bilinearmap.interp (cora/util/bilinearmap.pyx:14-59)
+ * fused with the Romberg channel average of clarray (skysim.py:41-67).
+ *   dd,dv,vv   [nkperp, nkpar] lookup tables (corr.py:936-940)
+ *   chi,pfd,f,b [F*zint]  per sub-sample comoving distance, prefactor*D(z)/D(z_ps),
+ *                         growth rate, bias (corr.py:944-951), sub-sample s of channel i
+ *                         at index i*zint+s (skysim.py:47-49 ordering)
+ *   w          [zint]     normalised Romberg weights (sum = 1); zint = 1, w = {1} is zromb=0
+ *   log10l     [nl]       log10 of the multipoles to evaluate (l = 0 passed as 1e-10, corr.py:957)
+ *   out        [nl, F, F]
+ */
+int corahip_clarray_table21cm(corahip_ctx *ctx, const double *dd, const double *dv, const double *vv,
+                              int nkperp, int nkpar, double kperpmin, double kperpmax, double kparmax,
+                              const double *chi, const double *pfd, const double *f, const double *b,
+                              int F, int zint, const double *w, const double *log10l, int nl,
+                              double *out);
+
+/* the bare aps callable at n independent points (corr.py:953-982): lx = log10(l), chi1, chi2,
+ * and the coefficient triples b1 b2 P, (f1 b2 + f2 b1) P, f1 f2 P with P = D1 D2 pf1 pf2
+ * (the 1/(xc^2 pi) factor is applied by the kernel).  All arrays [n]. */
+int corahip_aps_table21cm_points(corahip_ctx *ctx, const double *dd, const double *dv, const double *vv,
+                                 int nkperp, int nkpar, double kperpmin, double kperpmax, double kparmax,
+                                 long n, const double *lx, const double *chi1, const double *chi2,
+                                 const double *cdd, const double *cdv, const double *cvv, double *out);
+
+/* separable model C_l = A_l * B(nu,nu') (cora/foreground/gaussianfg.py:40-41):
+ *   al [nl], bcov [F*zint, F*zint] (sub-sampled frequency covariance), w [zint] -> out [nl,F,F] */
+int corahip_clarray_separable(corahip_ctx *ctx, const double *al, int nl, const double *bcov, int F,
+                              int zint, const double *w, double *out);
+
+/* Romberg reduction of host-evaluated samples (skysim.py:62-67):
+ *   clt [nl, F, zint, F, zint] -> out [nl, F, F] = sum_ab w_a w_b clt                */
+int corahip_romb_reduce(corahip_ctx *ctx, const double *clt, int nl, int F, int zint, const double *w,
+                        double *out);
+
+/* ---- K2: per-l matrix root ---------------------------------------------------------
+ * Replaces the loop body of mkfullsky (skysim.py:115-119) and
+ * nputil.matrix_root_manynull(truncate=False) (cora/util/nputil.py:51-101):
+ *   Cm = C_l + I * max(diag C_l) * jitter_rel;  T_l = chol_lower(Cm);  if a pivot is
+ *   not positive (LAPACK potrf failure) -> symmetric eigen-decomposition, eigenvalues
+ *   < max * eig_thresh set to 0, T_l = V sqrt(Lambda).
+ *   C [nl,F,F] -> T [nl,F,F];  info [nl] int32: 0 = Cholesky, 1 = eigen branch.      */
+int corahip_factor_batched(corahip_ctx *ctx, const double *C, int nl, int F, double jitter_rel,
+                           double eig_thresh, double *T, int32_t *info);
+
+/* ---- K3: correlated draw -----------------------------------------------------------
+ * Normal stream layout ("stream order"; nputil.py:104-125 called from
+ * skysim.py:120): for l = 0..lmax: F*(l+1) reals [nu'][m] then F*(l+1) imags [nu'][m];
+ * total 2*F*nalm doubles.  The 1/sqrt(2) of complex_std_normal is applied by draw_alm. */
+int corahip_normals_philox(corahip_ctx *ctx, uint64_t seed, int lmax, int F, double *g);
+
+/* a_lm(nu) = sum_nu' T_l[nu,nu'] g_lm(nu')  (skysim.py:121) for channels nu0 <= nu < nu0+nnu.
+ *   T [lmax+1, F, F], info [lmax+1] (from factor_batched; NULL = treat all as dense),
+ *   g stream order (above), alm_dev: device a_lm layout [nalm][nnu_pad/4][2][4]
+ *   (packed healpy index idx = m(2 lmax+1-m)/2 + l; channel nu0+4g+v at [g][c][v], c = re/im;
+ *   nnu_pad = nnu rounded up to a multiple of 4, padding channels are written as 0).  */
+int corahip_draw_alm(corahip_ctx *ctx, const double *T, const int32_t *info, const double *g, int lmax,
+                     int F, int nu0, int nnu, double *alm_dev);
+
+/* layout converters between alm_dev and the reference's arrays:
+ *   square  [nnu, 1, L, L] complex128 as returned by mkfullsky(alms=True) (skysim.py:108-125)
+ *   packed  [nnu, nalm]   complex128 healpy order, as pack_alm produces (hputil.py:124-152)  */
+int corahip_alm_dev_to_square(corahip_ctx *ctx, const double *alm_dev, int lmax, int nnu, double *square);
+int corahip_alm_packed_to_dev(corahip_ctx *ctx, const double *packed, int lmax, int nnu, double *alm_dev);
+
+/* ---- K4/K5: HEALPix synthesis ------------------------------------------------------
+ * Replaces hputil.sphtrans_inv_sky / sphtrans_inv_real -> healpy.alm2map
+ * (cora/util/hputil.py:369-391,500-531) for nnu channels at once.                   */
+int corahip_sht_plan_create(corahip_ctx *ctx, int nside, int lmax, corahip_sht_plan **plan);
+int corahip_sht_plan_destroy(corahip_ctx *ctx, corahip_sht_plan *plan);
+/* bytes of scratch alm2map needs to process `nnu` channels in one pass */
+int corahip_alm2map_workspace_bytes(const corahip_sht_plan *plan, int nnu, size_t *bytes);
+/* alm_dev [nalm][nnu_pad/4][2][4] -> maps [nnu, 12 nside^2] RING order.
+ * workspace: >= corahip_alm2map_workspace_bytes(plan, nnu_chunk) for some nnu_chunk (multiple
+ * of 4) <= nnu_pad; channels are processed in chunks that fit.                        */
+int corahip_alm2map(corahip_ctx *ctx, const corahip_sht_plan *plan, const double *alm_dev, int nnu,
+                    double *maps, void *workspace, size_t workspace_bytes);
+
+/* ring geometry of the plan (host arrays of length 4 nside - 1), for tests */
+int corahip_sht_plan_rings(const corahip_sht_plan *plan, int64_t *host_start, int32_t *host_nphi,
+                           double *host_z, double *host_phi0);
+/* normalised associated Legendre values lambda_lm(cos theta_ring) the synthesis uses
+ * (device recurrence incl. the polar seed table), l = m..lmax -> out [lmax-m+1] (device) */
+int corahip_sht_lambda(corahip_ctx *ctx, const corahip_sht_plan *plan, int m, int ring_pair, double *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CORAHIP_H */

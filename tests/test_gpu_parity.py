@@ -1,0 +1,372 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle.  Run with -m gpu."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    return np.abs(np.asarray(a) - np.asarray(b)).max() / np.abs(b).max()
+
+
+def _rand_alm(rng, nnu, lmax):
+    nalm = (lmax + 1) * (lmax + 2) // 2
+    a = rng.standard_normal((nnu, nalm)) + 1j * rng.standard_normal((nnu, nalm))
+    # realistic red spectrum so that no single l dominates rounding
+    from oracle import sht
+
+    l = np.concatenate([np.arange(m, lmax + 1) for m in range(lmax + 1)])
+    return a / (1.0 + l) ** 1.0
+
+
+# ------------------------------------------------------------------ geometry / Legendre
+@pytest.mark.parametrize("nside", [1, 2, 8, 64])
+def test_ring_geometry(ctx, nside):
+    from oracle import healpix
+
+    ri = healpix.ring_info(nside)
+    dv = ctx.sht_rings(nside, 2 * nside)
+    assert np.array_equal(dv["start"], ri["start"])
+    assert np.array_equal(dv["nphi"], ri["nphi"])
+    assert np.allclose(dv["z"], ri["z"], rtol=0, atol=1e-16)
+    assert np.allclose(dv["phi0"], ri["phi0"], rtol=0, atol=1e-16)
+
+
+@pytest.mark.parametrize("nside,lmax,m,pair", [(8, 16, 0, 3), (8, 16, 5, 0), (64, 128, 100, 2), (64, 128, 128, 127),
+                                              (256, 512, 500, 0), (256, 512, 400, 30), (1024, 2048, 2000, 5),
+                                              (1024, 2048, 1000, 400), (1024, 2048, 2048, 2047)])
+def test_lambda_recurrence(ctx, nside, lmax, m, pair):
+    """Device recurrence incl. polar seed table vs the oracle's scaled recurrence."""
+    from oracle import healpix, sht
+
+    ri = healpix.ring_info(nside)
+    ref = sht.lambda_lm(lmax, m, ri["z"][pair])
+    dev = ctx.sht_lambda(nside, lmax, m, pair).cpu().numpy()
+    scale = max(np.abs(ref).max(), 1e-300)
+    # terms below 2^-900 are dropped on the device by design
+    assert np.abs(dev - ref).max() <= 1e-11 * scale + 1e-260
+
+
+# ------------------------------------------------------------------ K4 + K5
+@pytest.mark.parametrize("nside,lmax,nnu", [(1, 2, 1), (2, 5, 3), (4, 11, 8), (8, 16, 4), (8, 23, 9), (16, 32, 16),
+                                            (32, 95, 5), (64, 128, 24)])
+def test_alm2map_vs_oracle(ctx, nside, lmax, nnu):
+    import torch
+    from oracle import sht
+
+    rng = np.random.default_rng(100 * nside + nnu)
+    alm = _rand_alm(rng, nnu, lmax)
+    ref = np.stack([sht.alm2map(a, nside, lmax) for a in alm])
+    dev = ctx.alm_packed_to_dev(torch.from_numpy(alm).to(ctx.device), lmax)
+    maps = ctx.alm2map(dev, nside, lmax, nnu).cpu().numpy()
+    assert maps.shape == ref.shape
+    err = np.abs(maps - ref).max() / ref.std()
+    assert err < 1e-11, err
+
+
+def test_alm2map_chunked_workspace(ctx):
+    """A workspace too small for all channels forces the chunked path: identical maps."""
+    import torch
+
+    nside, lmax, nnu = 16, 32, 20
+    rng = np.random.default_rng(5)
+    alm = _rand_alm(rng, nnu, lmax)
+    dev = ctx.alm_packed_to_dev(torch.from_numpy(alm).to(ctx.device), lmax)
+    full = ctx.alm2map(dev, nside, lmax, nnu).cpu().numpy()
+    plan = ctx.sht_plan(nside, lmax)
+    small = ctx.alm2map_workspace_bytes(plan, 8) + (lmax + 1) * (lmax + 2) // 2 * 16 * 8
+    part = ctx.alm2map(dev, nside, lmax, nnu, max_workspace_bytes=small).cpu().numpy()
+    assert np.abs(part - full).max() <= 1e-13 * np.abs(full).max()
+
+
+def test_alm2map_single_modes(ctx):
+    """Analytic maps: a_00 -> a/sqrt(4 pi); a_10 -> sqrt(3/4pi) cos(theta); a_11."""
+    import torch
+    from oracle import healpix
+
+    nside, lmax = 8, 4
+    theta, phi = healpix.pix2ang_ring(nside)
+    nalm = (lmax + 1) * (lmax + 2) // 2
+    alm = np.zeros((3, nalm), dtype=np.complex128)
+    alm[0, 0] = 2.5 + 7.0j                      # a_00 (imaginary part must be ignored)
+    alm[1, 1] = -1.25                           # a_10
+    alm[2, (lmax + 1) + 0] = 0.5 - 0.75j        # a_11: idx = m(2 lmax+1-m)/2 + l = lmax + 1
+    dev = ctx.alm_packed_to_dev(torch.from_numpy(alm).to(ctx.device), lmax)
+    maps = ctx.alm2map(dev, nside, lmax, 3).cpu().numpy()
+    assert np.allclose(maps[0], 2.5 / np.sqrt(4 * np.pi), rtol=0, atol=1e-14)
+    assert np.allclose(maps[1], -1.25 * np.sqrt(3 / (4 * np.pi)) * np.cos(theta), rtol=0, atol=1e-14)
+    a = 0.5 - 0.75j
+    ref = -np.sqrt(3 / (8 * np.pi)) * 2 * (a * np.exp(1j * phi)).real * np.sin(theta)
+    assert np.allclose(maps[2], ref, rtol=0, atol=1e-14)
+
+
+# ------------------------------------------------------------------ K2
+def test_factor_cholesky_branch(ctx, golden):
+    from oracle import skysim as osk
+
+    C = golden["cla_21cm_F8_l64_zromb3"]
+    T, info = ctx.factor_batched(ctx.to_device(C))
+    T, info = T.cpu().numpy(), info.cpu().numpy()
+    ref = osk.factors(C)
+    assert np.all(info == 0)
+    for l in range(C.shape[0]):
+        assert np.abs(T[l] - ref[l]).max() <= 1e-12 * np.abs(ref[l]).max()
+        assert np.all(np.triu(T[l], 1) == 0)
+
+
+@pytest.mark.parametrize("F", [5, 33, 70, 256])
+def test_factor_sizes(ctx, F):
+    rng = np.random.default_rng(F)
+    A = rng.standard_normal((3, F, F + 3))
+    C = A @ A.transpose(0, 2, 1) + 0.1 * np.eye(F)
+    T, info = ctx.factor_batched(ctx.to_device(C), jitter_rel=0.0)
+    T = T.cpu().numpy()
+    assert np.all(info.cpu().numpy() == 0)
+    ref = np.linalg.cholesky(C)
+    assert np.abs(T - ref).max() <= 1e-12 * np.abs(ref).max()
+
+
+def test_factor_eigen_branch(ctx, golden):
+    """Cholesky failure -> eigen root: T T^T reproduces the PSD part; zero matrix -> zero."""
+    R = golden["root_rank3_in"]
+    Z = np.zeros_like(R)
+    rng = np.random.default_rng(2)
+    V = rng.standard_normal((6, 6))
+    Ind = V @ np.diag([3.0, 2.0, 1.0, 0.5, -0.2, -1e-3]) @ V.T  # indefinite
+    Ind = 0.5 * (Ind + Ind.T)
+    C = np.stack([R, Z, Ind])
+    T, info = ctx.factor_batched(ctx.to_device(C), jitter_rel=0.0)
+    T, info = T.cpu().numpy(), info.cpu().numpy()
+    assert list(info) == [1, 1, 1]
+    assert np.abs(T[0] @ T[0].T - R).max() <= 1e-13 * np.abs(R).max()
+    assert np.all(T[1] == 0)
+    ev, evec = np.linalg.eigh(Ind)
+    psd = (evec * np.where(ev < ev.max() * 1e-16, 0.0, ev)) @ evec.T
+    assert np.abs(T[2] @ T[2].T - psd).max() <= 1e-13 * np.abs(psd).max()
+
+
+def test_matrix_root_manynull_api(golden):
+    from cora_amd.util import nputil
+
+    r = nputil.matrix_root_manynull(golden["root_well_in"], truncate=False)
+    assert _rel(r, golden["root_well_out"]) < 1e-13
+    rt, npos = nputil.matrix_root_manynull(golden["root_rank3_in"])
+    assert npos == 3 and rt.shape == (6, 3)
+    assert np.abs(rt @ rt.T - golden["root_rank3_in"]).max() < 1e-13 * np.abs(golden["root_rank3_in"]).max()
+    z = nputil.matrix_root_manynull(np.zeros((5, 5)), truncate=False)
+    assert np.array_equal(z, golden["root_zero_out"])
+
+
+# ------------------------------------------------------------------ K3
+@pytest.mark.parametrize("key,cl,seed,nside", [("alm_21cm_F4_l16_seed3", "cla_21cm_F4_l16_zromb1", 3, 8),
+                                               ("alm_21cm_F8_l64_seed4", "cla_21cm_F8_l64_zromb3", 4, 32)])
+def test_mkfullsky_alms_golden(golden, key, cl, seed, nside):
+    """Same seed -> same a_lm as the reference itself (golden captured from cora)."""
+    from cora_amd.core import skysim
+
+    a = skysim.mkfullsky(golden[cl], nside, alms=True, rng=np.random.default_rng(seed))
+    ref = golden[key]
+    assert a.shape == ref.shape and a.dtype == np.complex128
+    assert np.abs(a - ref).max() <= 1e-12 * np.abs(ref).max()
+
+
+def test_mkfullsky_alms_legacy_global_rng(golden):
+    from cora_amd.core import skysim
+
+    np.random.seed(1234)
+    a = skysim.mkfullsky(golden["cla_21cm_F4_l16_zromb1"], 8, alms=True)
+    assert np.abs(a - golden["alm_21cm_F4_l16_legacy1234"]).max() <= 1e-12 * np.abs(a).max()
+
+
+def test_mkfullsky_foreground_near_singular(golden):
+    """cond ~ 1e19 blocks: factor is rounding sensitive: check T T^T = C and
+    a_lm to the looser contract; l = 0 (zero block) must give exactly zero."""
+    from cora_amd.core import skysim
+
+    C = golden["cla_syn_F8_l64_zromb0"]
+    a = skysim.mkfullsky(C, 32, alms=True, rng=np.random.default_rng(5))
+    ref = golden["alm_syn_F8_l64_seed5"]
+    assert np.all(a[:, 0, 0, :] == 0)
+    assert np.abs(a - ref).max() <= 1e-4 * np.abs(ref).std()
+
+
+def test_draw_shard_consistency(ctx, golden):
+    """Frequency-sharded draw (nu0, nnu) equals the matching rows of the full draw."""
+    import torch
+
+    C = golden["cla_21cm_F8_l64_zromb3"]
+    T, info = ctx.factor_batched(ctx.to_device(C))
+    g = ctx.normals_philox(11, 64, 8)
+    full = ctx.alm_dev_to_square(ctx.draw_alm(T, info, g, 64, 8), 64, 8).cpu().numpy()
+    part = ctx.alm_dev_to_square(ctx.draw_alm(T, info, g, 64, 8, nu0=3, nnu=4), 64, 4).cpu().numpy()
+    assert np.array_equal(part, full[3:7])
+
+
+def test_philox_normals_statistics(ctx):
+    g = ctx.normals_philox(7, 200, 16).cpu().numpy()
+    assert abs(g.mean()) < 5 / np.sqrt(g.size)
+    assert abs(g.var() - 1) < 5 * np.sqrt(2 / g.size)
+    assert abs((g**3).mean()) < 5 * np.sqrt(15 / g.size)
+    assert abs((g**4).mean() - 3) < 5 * np.sqrt(96 / g.size)
+    g2 = ctx.normals_philox(7, 200, 16).cpu().numpy()
+    g3 = ctx.normals_philox(8, 200, 16).cpu().numpy()
+    assert np.array_equal(g, g2) and not np.array_equal(g, g3)
+    assert abs(np.corrcoef(g[:-1], g[1:])[0, 1]) < 5 / np.sqrt(g.size)
+
+
+# ------------------------------------------------------------------ K1
+@pytest.mark.parametrize("key,lmax,fkey,zromb,zwidth", [("cla_21cm_F8_l64_zromb0", 64, "f8", 0, None),
+                                                        ("cla_21cm_F8_l64_zromb1", 64, "f8", 1, None),
+                                                        ("cla_21cm_F8_l64_zromb3", 64, "f8", 3, None),
+                                                        ("cla_21cm_F6n_l96_zromb3", 96, "f6", 3, None),
+                                                        ("cla_21cm_F6n_l96_zromb2_zw", 96, "f6", 2, 1.0)])
+def test_clarray_21cm_golden(golden, key, lmax, fkey, zromb, zwidth):
+    from cora_amd.core import skysim
+    from cora_amd.signal import corr21cm
+
+    cr = _shared_corr21cm()
+    cla = skysim.clarray(cr.angular_powerspectrum, lmax, golden[fkey].copy(), zromb=zromb, zwidth=zwidth)
+    ref = golden[key]
+    assert cla.shape == ref.shape
+    assert np.abs(cla - ref).max() <= 1e-11 * np.abs(ref).max()
+
+
+_CR = {}
+
+
+def _shared_corr21cm():
+    from cora_amd.signal import corr21cm
+
+    if "cr" not in _CR:
+        _CR["cr"] = corr21cm.Corr21cm()
+    return _CR["cr"]
+
+
+def test_clarray_21cm_many_channels(model21):
+    """F = 40 channels (3 tiles of 16: exercises tile mirroring) vs the oracle."""
+    from cora_amd.core import skysim
+    from oracle import skysim as osk
+
+    cr = _shared_corr21cm()
+    f = 600.0 + (np.arange(40) + 0.5) * 1.5625
+    cla = skysim.clarray(cr.angular_powerspectrum, 300, f, zromb=1)
+    ref = osk.clarray(model21.angular_powerspectrum, 300, f, zromb=1)
+    assert np.abs(cla - ref).max() <= 1e-11 * np.abs(ref).max()
+    assert np.array_equal(cla, cla.transpose(0, 2, 1))
+
+
+def test_aps_21cm_kat(golden):
+    """The reference's own known-answer test values (tests/test_corr.py:7-32)."""
+    from cora_amd.util.cosmology import Cosmology
+
+    cr = _shared_corr21cm()
+    aps1 = cr.angular_powerspectrum(np.arange(1000), 800.0, 800.0)
+    assert len(aps1) == 1000
+    assert np.allclose(aps1.sum(), golden["sig_kat_default"][0], rtol=1e-10)
+    assert np.allclose(aps1[[0, 1, 2, 10, 100, 500, 999]], golden["sig_aps_800_800"], rtol=1e-10)
+    fa = np.linspace(400.0, 800.0, 64)
+    aps2 = cr.angular_powerspectrum(np.arange(1000)[:, None, None], fa[None, :, None], fa[None, None, :])
+    assert aps2.shape == (1000, 64, 64)
+    sl = aps2[[0, 1, 7, 200, 400, 999]][:, ::9, ::7]
+    # off-diagonal entries are ~1e-12 of the diagonal and come from cancelling table values
+    assert np.abs(sl - golden["sig_aps2_slices"]).max() <= 1e-11 * np.abs(golden["sig_aps2_slices"]).max()
+    # Planck-2013 cosmology reproduces the constants hard-coded in the reference's test
+    old = cr.cosmology
+    cr.cosmology = Cosmology(omega_b=0.0483, omega_c=0.2589, omega_l=0.6914, H0=67.77)
+    try:
+        a1 = cr.angular_powerspectrum(np.arange(1000), 800.0, 800.0)
+        a2 = cr.angular_powerspectrum(np.arange(1000)[:, None, None], fa[None, :, None], fa[None, None, :])
+    finally:
+        cr.cosmology = old
+    assert np.allclose(a1.sum(), 1.5963772205823096e-09, rtol=1e-7)
+    assert np.allclose(a2[400, 40, 40], 8.986790805379046e-13, rtol=1e-7)
+    assert np.allclose(a2[200, 10, 40], 1.1939298801340165e-18, rtol=1e-7)
+
+
+@pytest.mark.parametrize("name,zromb", [("syn", 0), ("syn", 3), ("ups", 0), ("ups", 3)])
+def test_clarray_foreground_golden(golden, name, zromb):
+    from cora_amd.core import skysim
+    from cora_amd.foreground import galaxy, pointsource
+
+    model = galaxy.FullSkySynchrotron() if name == "syn" else pointsource.UnresolvedBackground()
+    cla = skysim.clarray(model.angular_powerspectrum, 64, golden["f8"].copy(), zromb=zromb)
+    ref = golden["cla_%s_F8_l64_zromb%d" % (name, zromb)]
+    assert np.abs(cla - ref).max() <= 1e-13 * np.abs(ref).max()
+
+
+def test_clarray_generic_callable(golden):
+    """A plain Python callable goes through host evaluation + device Romberg reduction."""
+    from cora_amd.core import skysim
+    from oracle import skysim as osk
+
+    def aps(l, z1, z2):
+        return np.exp(-0.5 * (z1 - z2) ** 2) / (1.0 + l) ** 2 * (1 + 0.1 * z1 * z2)
+
+    z = np.linspace(0.5, 2.5, 7)
+    for zr in (0, 2):
+        a = skysim.clarray(aps, 21, z, zromb=zr)
+        b = osk.clarray(aps, 21, z, zromb=zr)
+        assert np.abs(a - b).max() <= 1e-14 * np.abs(b).max()
+
+
+def test_clarray_edge_cases():
+    from cora_amd.core import skysim
+
+    aps = lambda l, a, b: l + a + b
+    with pytest.raises(ValueError):
+        skysim.clarray(aps, 4, np.array([1.0, 2.0]), zromb=1)      # lmax < 5: array_split(.., 0)
+    with pytest.raises(IndexError):
+        skysim.clarray(aps, 8, np.array([1.0]), zromb=1)           # one channel, no zwidth
+
+
+# ------------------------------------------------------------------ end to end
+@pytest.mark.parametrize("model_name,nside,lmax,F,zromb", [("21cm", 16, 32, 4, 1), ("syn", 32, 64, 8, 0)])
+def test_getsky_end_to_end(model21, model_name, nside, lmax, F, zromb):
+    """Sky3d.getsky() == oracle clarray + mkfullsky on the same numpy seed."""
+    from cora_amd.foreground import galaxy
+    from oracle import models
+    from oracle import skysim as osk
+
+    if model_name == "21cm":
+        m, om = _shared_corr21cm(), model21
+    else:
+        m, om = galaxy.FullSkySynchrotron(), models.FullSkySynchrotron()
+    m.nside, m.lmax, m.oversample = nside, lmax, zromb
+    m.frequencies = 500.0 + 20.0 * np.arange(F)
+    try:
+        sky = m.getsky(rng=np.random.default_rng(42))
+    finally:
+        m.lmax, m.frequencies = None, None
+    cla = osk.clarray(om.angular_powerspectrum, lmax, 500.0 + 20.0 * np.arange(F), zromb=zromb)
+    ref = osk.mkfullsky(cla, nside, rng=np.random.default_rng(42))
+    assert sky.shape == (F, 12 * nside * nside)
+    tol = 1e-10 if model_name == "21cm" else 1e-4  # near-singular foreground blocks: SURVEY 8a8
+    assert np.abs(sky - ref).max() <= tol * ref.std()
+
+
+def test_recovered_cl_device_rng(ctx, golden):
+    """Throughput mode (device Philox): recovered power matches C_l (2l+1/2)/(2l+1)
+    (complex a_l0 quirk of the reference) within sampling error."""
+    from cora_amd import DeviceRNG
+    from cora_amd.core import skysim
+    from oracle import skysim as osk
+
+    C = golden["cla_21cm_F8_l64_zromb3"]
+    lmax = 64
+    acc = np.zeros((8, lmax + 1))
+    nrep = 40
+    rng = DeviceRNG(123)
+    for _ in range(nrep):
+        a = skysim.mkfullsky(C, 32, alms=True, rng=rng)[:, 0]
+        for i in range(8):
+            # use only Re(a_l0), as the synthesis does
+            a0 = a[i].copy()
+            a0[:, 0] = a0[:, 0].real
+            acc[i] += osk.sph_ps_from_alm(a0)
+    acc /= nrep
+    l = np.arange(lmax + 1)
+    expect = np.array([C[:, i, i] for i in range(8)]) * (2 * l + 0.5) / (2 * l + 1)
+    sigma = expect * np.sqrt(2.0 / ((2 * l + 1) * nrep))
+    z = (acc - expect)[:, 2:] / sigma[:, 2:]
+    assert np.abs(z).max() < 5.0
+    assert abs(z.mean()) < 0.5
