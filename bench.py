@@ -1,0 +1,313 @@
+#!/usr/bin/env python3
+"""Headline benchmark: sky-maps/s of cora's Gaussian-sky realisation path on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+
+Workload (BASELINE.json configs[2], the config the metric is quoted on): Corr21cm, 256
+channels 400-800 MHz, nside = 1024, lmax = 2048, oversample (Romberg order) 3.
+
+One STEP = one full `Sky3d.getsky()`-equivalent realisation with every input already in
+HBM: K1 C_l(nu,nu') integration -> K2 per-l factor -> device Philox normals -> K3
+correlated draw -> K4 Legendre MFMA contraction -> K5 ring FFT -> 256 RING maps in HBM.
+Nothing is cached between steps except what the reference itself caches per model
+instance (the three DCT lookup tables) and the geometry plan.
+
+N > 1 (frequency sharding, north_star): K1/K2 are l-sharded, the factors are exchanged
+with ONE RCCL all-gather, every rank generates the same global normal stream and
+synthesises F/N channels.  Total work is fixed -> "scaling": "strong".
+
+Prints ONE JSON line (rank 0).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (model, F, nu_lower, nu_upper, nside, lmax, zromb)
+    "cfg3": ("21cm", 256, 400.0, 800.0, 1024, 2048, 3),
+    "cfg2": ("synchrotron", 32, 400.0, 800.0, 256, 512, 3),
+    "tiny": ("21cm", 16, 600.0, 625.0, 64, 128, 1),
+}
+
+FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X vendor spec; profiles/mfma_f64_probe_r01.txt measures 77.4
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md
+
+
+def build_model(name):
+    if name == "21cm":
+        from cora_amd.signal import corr21cm
+
+        return corr21cm.Corr21cm()
+    from cora_amd.foreground import galaxy
+
+    return galaxy.FullSkySynchrotron()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--warm", action="store_true", help="time the warm path only (factors cached)")
+    args = ap.parse_args()
+
+    import torch
+
+    from cora_amd import _lib
+    from cora_amd.core import skysim
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    model_name, F, nu_lo, nu_hi, nside, lmax, zromb = WORKLOADS[args.workload]
+    L = lmax + 1
+    nalm = L * (L + 1) // 2
+    npix = 12 * nside * nside
+    assert F % world == 0
+    nnu = F // world
+    nu0 = rank * nnu
+
+    ctx = _lib.get_context(local_rank)
+    model = build_model(model_name)
+    freq = nu_lo + (np.arange(F) + 0.5) * ((nu_hi - nu_lo) / F)
+
+    # ---- untimed setup: everything the timed region reads is put in HBM ------------------
+    t_setup = time.time()
+    zint = 2**zromb + 1 if zromb else 1
+    zhalf = abs(freq[1] - freq[0]) / 2.0
+    za = (freq[:, None] + np.linspace(-zhalf, zhalf, zint)[None, :]).ravel() if zromb else freq.copy()
+    w = ctx.to_device(skysim.romberg_weights(zromb))
+    plan = model._clarray_plan(model.angular_powerspectrum)
+    # l-shard of K1/K2 (contiguous, padded so all shards are equal for the all-gather)
+    Lpad = (L + world - 1) // world * world
+    lsh = Lpad // world
+    l_lo, l_hi = rank * lsh, min((rank + 1) * lsh, L)
+    larr = np.arange(L, dtype=np.float64)
+    if plan["kind"] == "table21cm":
+        p = plan["prepare"](ctx, za)
+        lx = ctx.to_device(np.log10(np.where(larr == 0.0, 1e-10, larr))[l_lo:l_hi])
+        k1_in = [ctx.to_device(p[k]) for k in ("chi", "pfd", "f", "b")]
+
+        def run_k1():
+            return ctx.clarray_table21cm(p["dd"], p["dv"], p["vv"], p["kperpmin"], p["kperpmax"], p["kparmax"],
+                                         k1_in[0], k1_in[1], k1_in[2], k1_in[3], F, zint, w, lx)
+    else:
+        al, bcov = plan["prepare"](larr.copy(), za)
+        al_d, bcov_d = ctx.to_device(al[l_lo:l_hi]), ctx.to_device(bcov)
+
+        def run_k1():
+            return ctx.clarray_separable(al_d, bcov_d, F, zint, w)
+
+    ctx.sht_plan(nside, lmax)
+    g_buf = ctx.empty((2 * F * nalm,))
+    alm_buf = ctx.empty((nalm, (nnu + 3) // 4, 2, 4))
+    maps_buf = ctx.empty((nnu, npix))
+    T_all = ctx.empty((Lpad, F, F))
+    info_all = torch.zeros((Lpad,), dtype=torch.int32, device=ctx.device)
+    ctx.workspace(ctx.alm2map_workspace_bytes(ctx.sht_plan(nside, lmax), nnu))
+    torch.cuda.synchronize()
+    t_setup = time.time() - t_setup
+
+    seed_box = [1000]
+
+    def cold_factors():
+        C = run_k1()
+        T, info = ctx.factor_batched(C)
+        if world == 1:
+            return T, info
+        T_all[l_lo:l_hi].copy_(T)
+        info_all[l_lo:l_hi].copy_(info)
+        dist.all_gather_into_tensor(T_all, T_all[rank * lsh:(rank + 1) * lsh].clone())
+        dist.all_gather_into_tensor(info_all, info_all[rank * lsh:(rank + 1) * lsh].clone())
+        return T_all[:L], info_all[:L]
+
+    cached = {}
+
+    def step():
+        if args.warm:
+            if "f" not in cached:
+                cached["f"] = cold_factors()
+            T, info = cached["f"]
+        else:
+            T, info = cold_factors()
+        seed_box[0] += 1
+        ctx.normals_philox(seed_box[0], lmax, F, out=g_buf)
+        ctx.draw_alm(T, info, g_buf, lmax, F, nu0=nu0, nnu=nnu, out=alm_buf)
+        ctx.alm2map(alm_buf, nside, lmax, nnu, out=maps_buf)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    ctx.profile_reset()
+    ctx.profile_enable(True)
+    t0 = time.time()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.time() - t0
+    ctx.profile_enable(False)
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device=ctx.device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    stages = {}
+    for name in ("clarray", "factor", "normals", "draw", "legendre", "ringfft"):
+        ms, n = ctx.profile_get(name)
+        if n:
+            stages[name] = {"ms_per_launch": ms / n, "launches": n}
+
+    # sanity: the maps of the last step are finite and have the expected variance scale
+    chk = float(maps_buf[0, ::4097].std().item())
+    assert np.isfinite(chk) and chk > 0
+
+    result = None
+    if rank == 0:
+        ms_step = dt / args.steps * 1e3
+        value = F * args.steps / dt
+        # dominant kernel: K4 Legendre contraction, FP64 MFMA bound
+        leg = stages.get("legendre", {"ms_per_launch": float("nan")})
+        flops_leg = 8.0 * nside * nalm * nnu          # per launch, SURVEY 8(d) / DESIGN.md
+        ach = flops_leg / (leg["ms_per_launch"] * 1e-3) / 1e12
+        alg_bytes = 8.0 * npix * nnu + 32.0 * nalm * nnu + 8.0 * L * F * F   # warm path, SURVEY 8(d)
+        result = {
+            "metric": "sky-maps/sec (nside=%d, lmax=%d, %d freq)" % (nside, lmax, F),
+            "value": value,
+            "unit": "maps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_step,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": "%s: %s, %d channels %g-%g MHz, nside=%d, lmax=%d, zromb=%d, %s path, device Philox normals"
+                            % (args.workload, model_name, F, nu_lo, nu_hi, nside, lmax, zromb,
+                               "warm (cached factors)" if args.warm else "cold (C_l integration + factor + draw + synthesis)"),
+                "parallelism": "freq-shard x%d (l-sharded C_l/factor + 1 RCCL all-gather)" % world if world > 1 else "single GPU",
+                "realisations_per_s": args.steps / dt,
+                "setup_s": t_setup,
+            },
+            "stages_ms": {k: round(v["ms_per_launch"], 3) for k, v in stages.items()},
+            "roofline": {
+                "bound": "mfma",
+                "kernel": "legendre_kernel (K4)",
+                "achieved": ach,
+                "peak": FP64_MFMA_PEAK_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": ach / FP64_MFMA_PEAK_TFLOPS,
+                "traffic": None,
+            },
+            "hbm_roofline_whole_step": {
+                "algorithmic_GB": alg_bytes / 1e9,
+                "achieved_GBs": alg_bytes / 1e9 / (ms_step * 1e-3),
+                "peak_GBs": HBM_PEAK_GBS,
+                "frac": alg_bytes / 1e9 / (ms_step * 1e-3) / HBM_PEAK_GBS,
+            },
+        }
+        if not args.no_cpu_baseline and world == 1:
+            result["cpu_baseline"] = cpu_baseline(model_name, F, freq, nside, lmax, zromb)
+            result["config"]["gpu_over_cpu"] = value / result["cpu_baseline"]["value"]
+        print(json.dumps(result))
+    if dist is not None:
+        dist.destroy_process_group()
+    return result
+
+
+def cpu_baseline(model_name, F, freq, nside, lmax, zromb):
+    """The oracle (a port of the reference's algorithm: numpy/scipy + C/OpenMP SHT) timed on
+    this box's host cores on a bounded sample of the same workload, scaled linearly."""
+    from oracle import models
+    from oracle import sht
+    from oracle import skysim as osk
+
+    ncore = len(os.sched_getaffinity(0))
+    L = lmax + 1
+    rng = np.random.default_rng(0)
+    # K1 sample: 4 l-chunks of 5 (the reference's chunking), all channels
+    if model_name == "21cm":
+        om = models.Corr21cm()
+        t0 = time.time()
+        om.tables()
+        t_tables = time.time() - t0
+    else:
+        om = models.FullSkySynchrotron()
+        t_tables = 0.0
+    zint = 2**zromb + 1
+    zhalf = abs(freq[1] - freq[0]) / 2.0
+    za = (freq[:, None] + np.linspace(-zhalf, zhalf, zint)[None, :]).ravel()
+    import scipy.integrate as si
+
+    nl_s = 4 if F > 64 else 20
+    lsec = np.linspace(1, lmax, nl_s).astype(int).astype(np.float64)
+    t0 = time.time()
+    zspace = 2.0 * zhalf / 2**zromb
+    cl_s = []
+    for l in lsec:
+        clt = om.angular_powerspectrum(np.array([l])[:, None, None], za[None, :, None], za[None, None, :])
+        clt = clt.reshape(-1, F, zint, F, zint)
+        clt = si.romb(si.romb(clt, dx=zspace, axis=4), dx=zspace, axis=2) / (2 * zhalf) ** 2
+        cl_s.append(clt[0])
+    t_k1 = (time.time() - t0) * L / nl_s
+    # K2 + K3 sample: factor + draw for the sampled l
+    t0 = time.time()
+    nd = 0
+    for C, l in zip(cl_s, lsec):
+        l = int(l)
+        cm = C + np.identity(F) * C.diagonal().max() * 1e-14
+        T = osk.matrix_root_manynull(cm, truncate=False)
+        gv = osk.complex_std_normal((F, l + 1), rng=rng)
+        np.dot(T, gv)
+        nd += l + 1
+    t_k23 = (time.time() - t0) * (L * (L + 1) / 2) / nd
+    # K4 + K5 sample: nmap channels through the C/OpenMP synthesis
+    nmap = 2 if nside >= 1024 else 4
+    nalm = L * (L + 1) // 2
+    t0 = time.time()
+    for _ in range(nmap):
+        a = rng.standard_normal(nalm) + 1j * rng.standard_normal(nalm)
+        sht.alm2map(a, nside, lmax)
+    t_sht = (time.time() - t0) * F / nmap
+    t_real = t_k1 + t_k23 + t_sht
+    return {
+        "value": F / t_real,
+        "unit": "maps/s",
+        "cores": ncore,
+        "kind": "port",
+        "sample": "C_l integration on %d of %d l (numpy, as cora/core/skysim.py:51-67), factor+normals+T@g on those l "
+                  "(scipy/numpy, scaled by nalm), C/OpenMP synthesis of %d of %d channels; each leg scaled linearly; "
+                  "per-realisation seconds: clarray %.1f, factor+draw %.1f, synthesis %.1f (one-off 21cm table build %.1f s "
+                  "not counted)" % (nl_s, L, nmap, F, t_k1, t_k23, t_sht, t_tables),
+    }
+
+
+if __name__ == "__main__":
+    main()

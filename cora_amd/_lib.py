@@ -71,6 +71,13 @@ def load():
                 "cora_amd: %s not found. Build it with `make -C cora_amd/csrc` (needs hipcc, gfx950). "
                 "There is no CPU fallback for the compute path." % LIB_PATH
             )
+        # torch bundles its own libamdhip64.so.7; import it FIRST so that libcorahip.so binds to the
+        # same HIP runtime instance (streams and device pointers are shared with torch).  Loading
+        # the library first would pull in /opt/rocm's copy and leave two runtimes in the process.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         lib = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)

@@ -29,50 +29,75 @@
 
 /* alm: packed healpy order idx(l,m) = m(2 lmax+1-m)/2 + l, interleaved (re,im).
  * z, sth: cos/sin(theta) of the `npair` northern rings (equator included).
- * fn, fs: [npair][lmax+1][2] outputs (F_m on the north ring, and on its mirror). */
+ * fn, fs: [npair][lmax+1][2] outputs (F_m on the north ring, and on its mirror).
+ *
+ * Per (ring, m): phase 1 marches the recurrence with a power-of-two scale exponent
+ * (no accumulation) until |lambda| >= 2^-900 - terms below that are < 1e-270 of the
+ * sum and are dropped, as libsharp does; phase 2 is the plain recurrence. */
 void oracle_legendre_synth(int lmax, int npair, const double *z, const double *sth,
                            const double *alm, double *fn, double *fs)
 {
     const int L = lmax + 1;
+    const long nalm = (long)L * (L + 1) / 2;
     /* log2 of |lambda_mm| prefactor */
     double *lp = (double *)malloc(sizeof(double) * L);
     lp[0] = -0.5 * log2(4.0 * M_PI);
     for (int m = 1; m < L; m++)
         lp[m] = lp[m - 1] + 0.5 * log2((2.0 * m + 1.0) / (2.0 * m));
+    /* alpha_lm and 1/alpha_lm at idx(l,m); alpha_mm = inf -> 1/alpha = 0 */
+    double *al = (double *)malloc(sizeof(double) * nalm);
+    double *ial = (double *)malloc(sizeof(double) * nalm);
+#pragma omp parallel for schedule(dynamic, 16)
+    for (int m = 0; m < L; m++) {
+        long base = (long)m * (2 * lmax + 1 - m) / 2;
+        const double m2 = (double)m * m;
+        al[base + m] = 0.0;
+        ial[base + m] = 0.0;
+        for (int l = m + 1; l < L; l++) {
+            double ll = l;
+            double a = sqrt((4.0 * ll * ll - 1.0) / (ll * ll - m2));
+            al[base + l] = a;
+            ial[base + l] = 1.0 / a;
+        }
+    }
 
 #pragma omp parallel for schedule(dynamic, 4)
     for (int r = 0; r < npair; r++) {
         const double x = z[r];
         const double l2s = log2(sth[r]);
         for (int m = 0; m < L; m++) {
-            const double *a = alm + 2 * ((long)m * (2 * lmax + 1 - m) / 2);
-            /* a[2*l], a[2*l+1] is a_lm for this m (index offset by +l) */
+            const long base = (long)m * (2 * lmax + 1 - m) / 2;
+            const double *a = alm + 2 * base; /* a[2*l], a[2*l+1] is a_lm */
+            const double *A = al + base, *IA = ial + base;
             double L2 = lp[m] + m * l2s;
             int sc = (int)floor(L2);
             double lam = exp2(L2 - sc);
             if (m & 1) lam = -lam;
             double lam_prev = 0.0;
-            double inv_alpha_prev = 0.0; /* 1/alpha_{l,m}; alpha_mm = inf */
-            double fer = 0, fei = 0, f_or = 0, foi = 0;
-            const double m2 = (double)m * m;
-            for (int l = m; l < L; l++) {
-                if (sc > -1000) {
-                    double v = ldexp(lam, sc);
-                    double ar = a[2 * l], ai = a[2 * l + 1];
-                    if (((l - m) & 1) == 0) { fer += ar * v; fei += ai * v; }
-                    else                    { f_or += ar * v; foi += ai * v; }
-                }
-                /* step to l+1 */
-                double lp1 = l + 1.0;
-                double alpha = sqrt((4.0 * lp1 * lp1 - 1.0) / (lp1 * lp1 - m2));
-                double nxt = alpha * (x * lam - lam_prev * inv_alpha_prev);
+            int l = m;
+            /* phase 1: scaled, no accumulation */
+            while (l < L && sc + ilogb(lam) < -900) {
+                double nxt = (l + 1 < L) ? A[l + 1] * (x * lam - lam_prev * IA[l]) : 0.0;
                 lam_prev = lam;
                 lam = nxt;
-                inv_alpha_prev = 1.0 / alpha;
-                if (fabs(lam) > 0x1p300) {
-                    lam *= 0x1p-300;
-                    lam_prev *= 0x1p-300;
-                    sc += 300;
+                l++;
+                if (fabs(lam) > 0x1p300) { lam *= 0x1p-300; lam_prev *= 0x1p-300; sc += 300; }
+                if (lam == 0.0) break;
+            }
+            double fer = 0, fei = 0, f_or = 0, foi = 0;
+            if (l < L && lam != 0.0) {
+                lam = ldexp(lam, sc);
+                lam_prev = ldexp(lam_prev, sc);
+                /* phase 2: plain recurrence, even/odd (l-m) sums */
+                for (; l < L; l++) {
+                    double ar = a[2 * l], ai = a[2 * l + 1];
+                    if (((l - m) & 1) == 0) { fer += ar * lam; fei += ai * lam; }
+                    else                    { f_or += ar * lam; foi += ai * lam; }
+                    if (l + 1 < L) {
+                        double nxt = A[l + 1] * (x * lam - lam_prev * IA[l]);
+                        lam_prev = lam;
+                        lam = nxt;
+                    }
                 }
             }
             long o = 2 * ((long)r * L + m);
@@ -80,7 +105,7 @@ void oracle_legendre_synth(int lmax, int npair, const double *z, const double *s
             fs[o] = fer - f_or; fs[o + 1] = fei - foi;
         }
     }
-    free(lp);
+    free(lp); free(al); free(ial);
 }
 
 /* normalised lambda_lm(x) for one (m, x), l = m..lmax, same recurrence
