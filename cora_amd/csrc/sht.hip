@@ -18,6 +18,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <map>
 
 // ------------------------------------------------------------------------------------
 struct corahip_sht_plan {
@@ -41,6 +42,15 @@ struct corahip_sht_plan {
     int64_t *d_blu_boff = nullptr, *d_blu_foff = nullptr; // offsets into chirp / filter arrays
     double2 *d_bchirp = nullptr, *d_bfilt = nullptr;
     int max_fft_len = 0;                                  // largest LDS FFT buffer (complex elems)
+    // K5 launch classes: rings grouped by transform kind/length so each launch sizes its LDS
+    struct ring_class {
+        int P = 0;        // Bluestein length, 0 = direct power-of-two transform
+        int nch = 4;      // channels transformed together per workgroup
+        int bstride = 0;  // complex elements per channel buffer in LDS
+        int count = 0;
+        int32_t *d_list = nullptr;
+    };
+    std::vector<ring_class> classes;
 };
 
 static inline int ilog2(int v) {
@@ -314,54 +324,193 @@ legendre_kernel(int lmax, int npair, int nring, int ncols, const double *__restr
 __device__ static inline double2 cmul(double2 a, double2 b) {
     return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
 }
-__device__ static inline double2 cconj(double2 a) { return make_double2(a.x, -a.y); }
-
-__device__ static inline unsigned bitrev(unsigned v, int bits) { return __brev(v) >> (32 - bits); }
-
-// in-place radix-2 decimation-in-frequency: natural order in -> bit-reversed order out.
-// sign = +1: kernel e^{+2 pi i jk/P};  -1: e^{-2 pi i jk/P}.  tw[k] = e^{+2 pi i k/pmax}.
-__device__ static void fft_dif(double2 *buf, int P, int logP, const double2 *__restrict__ tw, int pmax, int sign) {
-    const int tid = threadIdx.x, nt = blockDim.x;
-    for (int s = 0; s < logP; s++) {
-        const int half = P >> (s + 1);
-        const int twstep = pmax / (2 * half);
-        for (int j = tid; j < (P >> 1); j += nt) {
-            const int grp = j / half, pos = j - grp * half;
-            const int i0 = grp * 2 * half + pos, i1 = i0 + half;
-            const double2 a = buf[i0], b = buf[i1];
-            double2 w = tw[pos * twstep];
-            if (sign < 0) w.y = -w.y;
-            buf[i0] = make_double2(a.x + b.x, a.y + b.y);
-            buf[i1] = cmul(make_double2(a.x - b.x, a.y - b.y), w);
-        }
-        __syncthreads();
-    }
+__device__ static inline double2 cadd(double2 a, double2 b) { return make_double2(a.x + b.x, a.y + b.y); }
+__device__ static inline double2 csub(double2 a, double2 b) { return make_double2(a.x - b.x, a.y - b.y); }
+// multiply by SIGN * i
+template <int SIGN>
+__device__ static inline double2 cmuli(double2 a) {
+    return SIGN > 0 ? make_double2(-a.y, a.x) : make_double2(a.y, -a.x);
 }
 
-// in-place radix-2 decimation-in-time: bit-reversed order in -> natural order out.
-__device__ static void fft_dit(double2 *buf, int P, int logP, const double2 *__restrict__ tw, int pmax, int sign) {
-    const int tid = threadIdx.x, nt = blockDim.x;
-    for (int s = logP - 1; s >= 0; s--) {
-        const int half = P >> (s + 1);
-        const int twstep = pmax / (2 * half);
-        for (int j = tid; j < (P >> 1); j += nt) {
-            const int grp = j / half, pos = j - grp * half;
-            const int i0 = grp * 2 * half + pos, i1 = i0 + half;
-            double2 w = tw[pos * twstep];
-            if (sign < 0) w.y = -w.y;
-            const double2 a = buf[i0], b = cmul(buf[i1], w);
-            buf[i0] = make_double2(a.x + b.x, a.y + b.y);
-            buf[i1] = make_double2(a.x - b.x, a.y - b.y);
-        }
-        __syncthreads();
+// small DFTs in registers, kernel e^{SIGN 2 pi i r p / R}, natural order in and out
+template <int SIGN>
+__device__ static inline void dft2(double2 &a, double2 &b) {
+    const double2 t = a;
+    a = cadd(t, b);
+    b = csub(t, b);
+}
+template <int SIGN>
+__device__ static inline void dft4(double2 &x0, double2 &x1, double2 &x2, double2 &x3) {
+    const double2 s02 = cadd(x0, x2), d02 = csub(x0, x2);
+    const double2 s13 = cadd(x1, x3), d13 = cmuli<SIGN>(csub(x1, x3));
+    x0 = cadd(s02, s13);
+    x2 = csub(s02, s13);
+    x1 = cadd(d02, d13);
+    x3 = csub(d02, d13);
+}
+template <int R, int SIGN>
+struct DftR;
+template <int SIGN>
+struct DftR<2, SIGN> {
+    __device__ static inline void run(double2 (&x)[2]) { dft2<SIGN>(x[0], x[1]); }
+};
+template <int SIGN>
+struct DftR<4, SIGN> {
+    __device__ static inline void run(double2 (&x)[4]) { dft4<SIGN>(x[0], x[1], x[2], x[3]); }
+};
+template <int SIGN>
+struct DftR<8, SIGN> {
+    __device__ static inline void run(double2 (&x)[8]) {
+        // even / odd halves, then radix-2 combine with eighth roots
+        dft4<SIGN>(x[0], x[2], x[4], x[6]);
+        dft4<SIGN>(x[1], x[3], x[5], x[7]);
+        const double h = 0.70710678118654752440;
+        const double2 w1 = make_double2(h, SIGN * h), w3 = make_double2(-h, SIGN * h);
+        const double2 o0 = x[1], o1 = cmul(x[3], w1), o2 = cmuli<SIGN>(x[5]), o3 = cmul(x[7], w3);
+        const double2 e0 = x[0], e1 = x[2], e2 = x[4], e3 = x[6];
+        x[0] = cadd(e0, o0);
+        x[4] = csub(e0, o0);
+        x[1] = cadd(e1, o1);
+        x[5] = csub(e1, o1);
+        x[2] = cadd(e2, o2);
+        x[6] = csub(e2, o2);
+        x[3] = cadd(e3, o3);
+        x[7] = csub(e3, o3);
     }
+};
+template <int SIGN>
+struct DftR<16, SIGN> {
+    __device__ static inline void run(double2 (&x)[16]) {
+        // n = 4a + c, k = k1 + 4 k2: DFT4 over a, twiddle w16^{c k1}, DFT4 over c
+        const double c1 = 0.92387953251128675613, s1 = 0.38268343236508977173;  // cos, sin(pi/8)
+        const double h = 0.70710678118654752440;
+#pragma unroll
+        for (int c = 0; c < 4; c++) dft4<SIGN>(x[c], x[4 + c], x[8 + c], x[12 + c]);
+        // after this x[4 k1 + c] holds t_c[k1]
+        // twiddles w16^{c k1}, c,k1 in 1..3: exponents 1,2,3,2,4,6,3,6,9
+        const double2 w1 = make_double2(c1, SIGN * s1), w2 = make_double2(h, SIGN * h), w3 = make_double2(s1, SIGN * c1);
+        const double2 w6 = make_double2(-h, SIGN * h), w9 = make_double2(-c1, -SIGN * s1);
+        x[4 + 1] = cmul(x[4 + 1], w1);
+        x[4 + 2] = cmul(x[4 + 2], w2);
+        x[4 + 3] = cmul(x[4 + 3], w3);
+        x[8 + 1] = cmul(x[8 + 1], w2);
+        x[8 + 2] = cmuli<SIGN>(x[8 + 2]);
+        x[8 + 3] = cmul(x[8 + 3], w6);
+        x[12 + 1] = cmul(x[12 + 1], w3);
+        x[12 + 2] = cmul(x[12 + 2], w6);
+        x[12 + 3] = cmul(x[12 + 3], w9);
+#pragma unroll
+        for (int k1 = 0; k1 < 4; k1++) dft4<SIGN>(x[4 * k1], x[4 * k1 + 1], x[4 * k1 + 2], x[4 * k1 + 3]);
+        // now x[4 k1 + k2] = X[k1 + 4 k2]: transpose to natural order
+#pragma unroll
+        for (int k1 = 0; k1 < 4; k1++)
+#pragma unroll
+            for (int k2 = k1 + 1; k2 < 4; k2++) {
+                const double2 t = x[4 * k1 + k2];
+                x[4 * k1 + k2] = x[4 * k2 + k1];
+                x[4 * k2 + k1] = t;
+            }
+    }
+};
+
+// e^{SIGN 2 pi i idx/pmax} from the half-circle table tw[k] = e^{+2 pi i k/pmax}, k < pmax/2
+template <int SIGN>
+__device__ static inline double2 tw_get(const double2 *__restrict__ tw, int pmax, int idx) {
+    const int hp = pmax >> 1;
+    double2 w = tw[idx >= hp ? idx - hp : idx];
+    if (idx >= hp) w = make_double2(-w.x, -w.y);
+    if (SIGN < 0) w.y = -w.y;
+    return w;
+}
+
+// One radix-R pass over `nch` channel buffers (channel c at buf + c*bstride), transform
+// length N, current sub-length Ls.  DIT = false: decimation in frequency (DFT then twiddle),
+// true: its transpose (twiddle then DFT).  Ends with a workgroup barrier.
+template <int R, int SIGN, bool DIT>
+__device__ static void fft_pass(double2 *buf, int bstride, int nch, int N, int Ls, const double2 *__restrict__ tw,
+                                int pmax) {
+    const int q = Ls / R;
+    const int nb = N / R;
+    const int total = nch * nb;
+    const int twstep = pmax / Ls;
+    for (int idx = threadIdx.x; idx < total; idx += blockDim.x) {
+        const int ch = idx / nb, t = idx - ch * nb;
+        const int b = t / q, j = t - b * q;
+        double2 *base = buf + (size_t)ch * bstride + b * Ls + j;
+        double2 x[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) x[r] = base[r * q];
+        // w[p] = w_Ls^{SIGN j p}
+        double2 w[R];
+        if (R > 1) {
+            w[1] = tw_get<SIGN>(tw, pmax, j * twstep);
+#pragma unroll
+            for (int pp = 2; pp < R; pp++) w[pp] = (pp & 1) ? cmul(w[pp - 1], w[1]) : cmul(w[pp >> 1], w[pp >> 1]);
+        }
+        if (DIT) {
+#pragma unroll
+            for (int r = 1; r < R; r++) x[r] = cmul(x[r], w[r]);
+        }
+        DftR<R, SIGN>::run(x);
+        if (!DIT) {
+#pragma unroll
+            for (int r = 1; r < R; r++) x[r] = cmul(x[r], w[r]);
+        }
+#pragma unroll
+        for (int r = 0; r < R; r++) base[r * q] = x[r];
+    }
+    __syncthreads();
+}
+
+// pass schedule for N = 2^k: radix 16 while k >= 4, then the remainder
+template <int SIGN>
+__device__ static void fft_dif(double2 *buf, int bstride, int nch, int N, const double2 *__restrict__ tw, int pmax) {
+    int Ls = N;
+    while (Ls >= 16) {
+        fft_pass<16, SIGN, false>(buf, bstride, nch, N, Ls, tw, pmax);
+        Ls >>= 4;
+    }
+    if (Ls == 8) fft_pass<8, SIGN, false>(buf, bstride, nch, N, Ls, tw, pmax);
+    else if (Ls == 4) fft_pass<4, SIGN, false>(buf, bstride, nch, N, Ls, tw, pmax);
+    else if (Ls == 2) fft_pass<2, SIGN, false>(buf, bstride, nch, N, Ls, tw, pmax);
+}
+// transpose of fft_dif: digit-reversed order in -> natural order out
+template <int SIGN>
+__device__ static void fft_dit(double2 *buf, int bstride, int nch, int N, const double2 *__restrict__ tw, int pmax) {
+    int rem = N;
+    while (rem >= 16) rem >>= 4;  // remainder radix handled first (it was last in DIF)
+    int Ls = rem;
+    if (rem == 8) fft_pass<8, SIGN, true>(buf, bstride, nch, N, Ls, tw, pmax);
+    else if (rem == 4) fft_pass<4, SIGN, true>(buf, bstride, nch, N, Ls, tw, pmax);
+    else if (rem == 2) fft_pass<2, SIGN, true>(buf, bstride, nch, N, Ls, tw, pmax);
+    if (rem == 1) Ls = 1;
+    while (Ls < N) {
+        Ls <<= 4;
+        fft_pass<16, SIGN, true>(buf, bstride, nch, N, Ls, tw, pmax);
+    }
+}
+// position of frequency index k in the digit-reversed output of fft_dif
+__device__ static inline int fft_dif_pos(int k, int N) {
+    int pos = 0, len = N, Ls = N;
+    while (Ls >= 16) {
+        len >>= 4;
+        pos += (k & 15) * len;
+        k >>= 4;
+        Ls >>= 4;
+    }
+    if (Ls > 1) {
+        len /= Ls;
+        pos += (k & (Ls - 1)) * len;
+    }
+    return pos;
 }
 
 // Bluestein tables for cap ring i (h = 2i not a power of two): chirp b_j = e^{i pi j^2/h}, j < h,
-// and filt = FFT_P(conj chirp wrapped), stored in the bit-reversed order fft_dif produces.
-__global__ void bluestein_table_kernel(const int32_t *__restrict__ blu_P, const int64_t *__restrict__ boff,
-                                       const int64_t *__restrict__ foff, double2 *__restrict__ chirp,
-                                       double2 *__restrict__ filt, const double2 *__restrict__ tw, int pmax) {
+// and filt = FFT_P(conj chirp wrapped), stored in the digit-reversed order fft_dif produces.
+__global__ void __launch_bounds__(256)
+bluestein_table_kernel(const int32_t *__restrict__ blu_P, const int64_t *__restrict__ boff,
+                       const int64_t *__restrict__ foff, double2 *__restrict__ chirp, double2 *__restrict__ filt,
+                       const double2 *__restrict__ tw, int pmax) {
     extern __shared__ __attribute__((aligned(16))) double2 fbuf[];
     const int i = blockIdx.x + 1;
     const int P = blu_P[i - 1];
@@ -379,140 +528,166 @@ __global__ void bluestein_table_kernel(const int32_t *__restrict__ blu_P, const 
         if (j > 0) fbuf[P - j] = make_double2(c, -s);
     }
     __syncthreads();
-    int logP = 0;
-    while ((1 << logP) < P) logP++;
-    fft_dif(fbuf, P, logP, tw, pmax, -1);
+    fft_dif<-1>(fbuf, 0, 1, P, tw, pmax);
     double2 *f = filt + foff[i - 1];
     for (int j = threadIdx.x; j < P; j += blockDim.x) f[j] = fbuf[j];
 }
 
-// one block per (ring, channel group of 4); channels handled one after the other.
-template <bool PHASE_LDS>
-__global__ void __launch_bounds__(256)
-ringfft_kernel(int nside, int lmax, int nring, int G, int nnu, long npix, const int32_t *__restrict__ nphi_a,
-               const int64_t *__restrict__ start_a, const double *__restrict__ phi0_a,
-               const double *__restrict__ inter, double *__restrict__ maps, const double2 *__restrict__ tw,
-               int pmax, const int32_t *__restrict__ blu_P, const int64_t *__restrict__ boff,
-               const int64_t *__restrict__ foff, const double2 *__restrict__ chirp,
-               const double2 *__restrict__ filt, int fft_len_max) {
-    extern __shared__ __attribute__((aligned(16))) double2 sm[];
-    double2 *buf = sm;                   // [max(P, h+1)]
-    double2 *phase = sm + fft_len_max;   // [L] when PHASE_LDS
+// One workgroup = (ring from `ring_list`, NCH consecutive channels), all NCH channels
+// transformed together.  P > 0: Bluestein of length P; P == 0: h = nphi/2 is a power of two.
+template <int NCH>
+__global__ void __launch_bounds__(512)
+ringfft_kernel(const int32_t *__restrict__ ring_list, int nside, int lmax, int G, int nnu, long npix,
+               const int32_t *__restrict__ nphi_a, const int64_t *__restrict__ start_a,
+               const double *__restrict__ phi0_a, const double *__restrict__ inter, double *__restrict__ maps,
+               const double2 *__restrict__ tw, int pmax, const int32_t *__restrict__ blu_P,
+               const int64_t *__restrict__ boff, const int64_t *__restrict__ foff,
+               const double2 *__restrict__ chirp, const double2 *__restrict__ filt, int bstride) {
+    extern __shared__ __attribute__((aligned(16))) double2 sm[];  // [NCH][bstride]
     const int tid = threadIdx.x, nt = blockDim.x;
-    const int ring = blockIdx.x, g = blockIdx.y;
+    const int ring = ring_list[blockIdx.x];
+    const int ch0 = blockIdx.y * NCH;
+    if (ch0 >= nnu) return;
+    const int g = ch0 >> 2, v0 = ch0 & 3;
     const int L = lmax + 1;
     const int n = nphi_a[ring];
     const int h = n >> 1;
     const long start = start_a[ring];
-    const double phi0 = phi0_a[ring];
-    // cap ring number (1-based, mirrored for the south cap); 0 for belt rings
+    const double phi0_over_pi = phi0_a[ring] / M_PI;
     int icap = 0;
     if (ring + 1 < nside) icap = ring + 1;
     else if (ring + 1 > 3 * nside) icap = 4 * nside - (ring + 1);
-    const int P = icap ? blu_P[icap - 1] : 0;  // 0 -> direct power-of-two transform of length h
-    const double phi0_over_pi = phi0 / M_PI;
+    const int P = icap ? blu_P[icap - 1] : 0;
+    const int flen = P ? P : h + 1;
+    double *smd = reinterpret_cast<double *>(sm);
 
-    if (PHASE_LDS) {
-        for (int m = tid; m < L; m += nt) {
-            double s, c;
-            // e^{i m phi0}; phi0/pi is 1/(4i), 1/(4 nside) or 0: reduce m*phi0/pi mod 2 exactly enough
-            sincospi(fmod((double)m * phi0_over_pi, 2.0), &s, &c);
-            phase[m] = make_double2(c, s);
+    for (int j = tid; j < flen; j += nt)
+#pragma unroll
+        for (int c = 0; c < NCH; c++) sm[(size_t)c * bstride + j] = make_double2(0.0, 0.0);
+    __syncthreads();
+
+    // ---- phase + alias fold onto bins 0..h of the Hermitian length-n spectrum X
+    const double *cell = inter + ((size_t)ring * G + g) * L * 8 + v0;
+    const bool noalias = lmax <= h;
+    for (int m = tid; m < L; m += nt) {
+        double re[NCH], im[NCH];
+        if (NCH == 4) {
+            const double4 a = *reinterpret_cast<const double4 *>(cell + (size_t)m * 8);
+            const double4 b = *reinterpret_cast<const double4 *>(cell + (size_t)m * 8 + 4);
+            re[0] = a.x; re[1 % NCH] = a.y; re[2 % NCH] = a.z; re[3 % NCH] = a.w;
+            im[0] = b.x; im[1 % NCH] = b.y; im[2 % NCH] = b.z; im[3 % NCH] = b.w;
+        } else if (NCH == 2) {
+            const double2 a = *reinterpret_cast<const double2 *>(cell + (size_t)m * 8);
+            const double2 b = *reinterpret_cast<const double2 *>(cell + (size_t)m * 8 + 4);
+            re[0] = a.x; re[1 % NCH] = a.y;
+            im[0] = b.x; im[1 % NCH] = b.y;
+        } else {
+            re[0] = cell[(size_t)m * 8];
+            im[0] = cell[(size_t)m * 8 + 4];
         }
-    }
-    const double *cell = inter + ((size_t)ring * G + g) * L * 8;
-
-    for (int v = 0; v < 4; v++) {
-        const int nu = 4 * g + v;
-        if (nu >= nnu) break;
-        const int flen = P ? P : (h + 1);
-        for (int j = tid; j < (flen > h + 1 ? flen : h + 1); j += nt) buf[j] = make_double2(0.0, 0.0);
-        __syncthreads();
-        // ---- phase + alias fold onto bins 0..h of the Hermitian length-n spectrum X
-        double *bufd = reinterpret_cast<double *>(buf);
-        for (int m = tid; m < L; m += nt) {
-            double2 f = make_double2(cell[(size_t)m * 8 + v], cell[(size_t)m * 8 + 4 + v]);
-            double2 ph;
-            if (PHASE_LDS) ph = phase[m];
-            else {
-                double s, c;
-                sincospi(fmod((double)m * phi0_over_pi, 2.0), &s, &c);
-                ph = make_double2(c, s);
-            }
-            const double2 c = cmul(f, ph);
+        double s, cph;
+        sincospi(fmod((double)m * phi0_over_pi, 2.0), &s, &cph);
+        const double2 ph = make_double2(cph, s);
+        const int k = m % n;
+        const int kc = (n - k) % n;
+#pragma unroll
+        for (int c = 0; c < NCH; c++) {
+            const double2 val = cmul(make_double2(re[c], im[c]), ph);
+            double *bd = smd + (size_t)c * bstride * 2;
             if (m == 0) {
-                atomicAdd(&bufd[0], c.x);
+                if (noalias) bd[0] = val.x;  // Re(c_0) only; no other m reaches bin 0
+                else atomicAdd(&bd[0], val.x);
+            } else if (noalias) {
+                if (m < h) *reinterpret_cast<double2 *>(bd + 2 * m) = val;
+                else bd[2 * h] = 2.0 * val.x;  // m == h: c + conj(c)
             } else {
-                const int k = m % n;
-                const int kc = (n - k) % n;
                 if (k <= h) {
-                    atomicAdd(&bufd[2 * k], c.x);
-                    atomicAdd(&bufd[2 * k + 1], c.y);
+                    atomicAdd(&bd[2 * k], val.x);
+                    atomicAdd(&bd[2 * k + 1], val.y);
                 }
                 if (kc <= h) {
-                    atomicAdd(&bufd[2 * kc], c.x);
-                    atomicAdd(&bufd[2 * kc + 1], -c.y);
+                    atomicAdd(&bd[2 * kc], val.x);
+                    atomicAdd(&bd[2 * kc + 1], -val.y);
                 }
             }
         }
-        __syncthreads();
-        // ---- Hermitian -> half-length complex: Z_k = (X_k + conj X_{h-k}) + i w^k (X_k - conj X_{h-k})
-        // pairs (k, h-k) are updated together; w = e^{2 pi i/n}
-        for (int k = tid; k <= h / 2; k += nt) {
-            const int k2 = h - k;
-            const double2 xa = buf[k], xb = buf[k2];
+    }
+    __syncthreads();
+    // ---- Hermitian -> half-length complex: Z_k = (X_k + conj X_{h-k}) + i w^k (X_k - conj X_{h-k}),
+    //      w = e^{2 pi i/n}; pairs (k, h-k) updated together.  Bluestein: times chirp b_k.
+    const double2 *bch = P ? chirp + boff[icap - 1] : nullptr;
+    const bool n_in_table = (pmax % n) == 0;
+    for (int k = tid; k <= h / 2; k += nt) {
+        const int k2 = h - k;
+        double2 w;
+        if (n_in_table) w = tw_get<1>(tw, pmax, k * (pmax / n));
+        else {
             double s, c;
             sincospi(2.0 * (double)k / (double)n, &s, &c);
-            const double2 w = make_double2(c, s);
-            // Z_k
+            w = make_double2(c, s);
+        }
+        double2 bk = make_double2(1.0, 0.0), bk2 = make_double2(1.0, 0.0);
+        if (P) {
+            if (k < h) bk = bch[k];
+            if (k2 < h) bk2 = bch[k2];
+        }
+#pragma unroll
+        for (int c = 0; c < NCH; c++) {
+            double2 *bc = sm + (size_t)c * bstride;
+            const double2 xa = bc[k], xb = bc[k2];
             double2 sum = make_double2(xa.x + xb.x, xa.y - xb.y);
             double2 dif = make_double2(xa.x - xb.x, xa.y + xb.y);
             double2 t = cmul(dif, w);
-            const double2 zk = make_double2(sum.x - t.y, sum.y + t.x);
-            // Z_{h-k}: w^{h-k} = -conj(w^k)
+            double2 zk = make_double2(sum.x - t.y, sum.y + t.x);
             sum = make_double2(xb.x + xa.x, xb.y - xa.y);
             dif = make_double2(xb.x - xa.x, xb.y + xa.y);
-            t = cmul(dif, make_double2(-c, s));
-            const double2 zk2 = make_double2(sum.x - t.y, sum.y + t.x);
-            if (k2 < h) buf[k2] = zk2;
-            if (k < h) buf[k] = zk;
+            t = cmul(dif, make_double2(-w.x, w.y));  // w^{h-k} = -conj(w^k)
+            double2 zk2 = make_double2(sum.x - t.y, sum.y + t.x);
+            if (P) {
+                zk = cmul(zk, bk);
+                zk2 = cmul(zk2, bk2);
+            }
+            if (k2 < h) bc[k2] = zk2;
+            else if (P) bc[k2] = make_double2(0.0, 0.0);  // slot h is padding for the length-P transform
+            if (k < h) bc[k] = zk;
         }
-        __syncthreads();
-        double *out = maps + (size_t)nu * npix + start;
-        if (P == 0) {
-            // direct: z = IDFT_h(Z) (unnormalised, + sign); h is a power of two
-            int logh = 0;
-            while ((1 << logh) < h) logh++;
-            fft_dif(buf, h, logh, tw, pmax, +1);
-            for (int j = tid; j < h; j += nt) {
-                const double2 zv = buf[logh ? bitrev((unsigned)j, logh) : 0];
-                *reinterpret_cast<double2 *>(out + 2 * j) = zv;
-            }
-        } else {
-            // Bluestein: z_j = b_j * IFFT_P( FFT_P(Z b) * filt )_j
-            const double2 *b = chirp + boff[icap - 1];
-            const double2 *f = filt + foff[icap - 1];
-            int logP = 0;
-            while ((1 << logP) < P) logP++;
-            for (int j = tid; j < P; j += nt) {
-                double2 val = make_double2(0.0, 0.0);
-                if (j < h) val = cmul(buf[j], b[j]);
-                buf[j] = val;
-            }
-            __syncthreads();
-            fft_dif(buf, P, logP, tw, pmax, -1);
-            for (int j = tid; j < P; j += nt) buf[j] = cmul(buf[j], f[j]);
-            __syncthreads();
-            fft_dit(buf, P, logP, tw, pmax, +1);
-            const double invP = 1.0 / (double)P;
-            for (int j = tid; j < h; j += nt) {
-                double2 zv = cmul(buf[j], b[j]);
-                zv.x *= invP;
-                zv.y *= invP;
-                *reinterpret_cast<double2 *>(out + 2 * j) = zv;
+    }
+    __syncthreads();
+
+    if (P == 0) {
+        fft_dif<1>(sm, bstride, NCH, h, tw, pmax);
+        for (int j = tid; j < h; j += nt) {
+            const int pos = fft_dif_pos(j, h);
+#pragma unroll
+            for (int c = 0; c < NCH; c++) {
+                if (ch0 + c < nnu)
+                    *reinterpret_cast<double2 *>(maps + (size_t)(ch0 + c) * npix + start + 2 * j) =
+                        sm[(size_t)c * bstride + pos];
             }
         }
+    } else {
+        const double2 *f = filt + foff[icap - 1];
+        fft_dif<-1>(sm, bstride, NCH, P, tw, pmax);
+        for (int j = tid; j < P; j += nt) {
+            const double2 fj = f[j];
+#pragma unroll
+            for (int c = 0; c < NCH; c++) sm[(size_t)c * bstride + j] = cmul(sm[(size_t)c * bstride + j], fj);
+        }
         __syncthreads();
+        fft_dit<1>(sm, bstride, NCH, P, tw, pmax);
+        const double invP = 1.0 / (double)P;
+        for (int j = tid; j < h; j += nt) {
+            const double2 bj = bch[j];
+#pragma unroll
+            for (int c = 0; c < NCH; c++) {
+                if (ch0 + c < nnu) {
+                    double2 zv = cmul(sm[(size_t)c * bstride + j], bj);
+                    zv.x *= invP;
+                    zv.y *= invP;
+                    *reinterpret_cast<double2 *>(maps + (size_t)(ch0 + c) * npix + start + 2 * j) = zv;
+                }
+            }
+        }
     }
 }
 
@@ -547,6 +722,7 @@ int corahip_sht_plan_destroy(corahip_ctx *ctx, corahip_sht_plan *p) {
     (void)hipFree(p->d_blu_foff);
     (void)hipFree(p->d_bchirp);
     (void)hipFree(p->d_bfilt);
+    for (auto &c : p->classes) (void)hipFree(c.d_list);
     delete p;
     return 0;
 }
@@ -696,6 +872,40 @@ int corahip_sht_plan_create(corahip_ctx *ctx, int nside, int lmax, corahip_sht_p
             LAUNCH_CHECK();
         }
     }
+    // K5 ring classes
+    {
+        std::map<int, std::vector<int32_t>> by_len;
+        for (int r = 0; r < nring; r++) {
+            const int i = r + 1;
+            int icap = 0;
+            if (i < nside) icap = i;
+            else if (i > 3 * nside) icap = 4 * nside - i;
+            int P = 0;
+            if (icap) {
+                const int h = 2 * icap;
+                if (!is_pow2(h)) {
+                    P = 1;
+                    while (P < 2 * h - 1) P <<= 1;
+                }
+            }
+            by_len[P].push_back(r);
+        }
+        const size_t lds_budget = 160 * 1024;
+        for (auto &kv : by_len) {
+            corahip_sht_plan::ring_class c;
+            c.P = kv.first;
+            c.bstride = c.P ? c.P : 2 * nside + 1;
+            c.nch = 4;
+            while (c.nch > 1 && (size_t)c.nch * c.bstride * sizeof(double2) > lds_budget) c.nch >>= 1;
+            if ((size_t)c.nch * c.bstride * sizeof(double2) > lds_budget) {
+                corahip_set_error("nside %d: ring FFT of length %d does not fit in LDS", nside, c.bstride);
+                return CORAHIP_ENOMEM;
+            }
+            c.count = (int)kv.second.size();
+            if ((rc = dev_upload(&c.d_list, kv.second, s))) return rc;
+            p->classes.push_back(c);
+        }
+    }
     HIP_TRY(hipStreamSynchronize(s));
     *out = p;
     return 0;
@@ -766,27 +976,22 @@ static int alm2map_chunk(corahip_ctx *ctx, const corahip_sht_plan *p, const doub
     {
         StageTimer t(ctx, "ringfft");
         const int G = nnu_chunk_pad / 4;
-        dim3 grid(p->nring, (nnu_valid + 3) / 4);
-        size_t shm = sizeof(double2) * ((size_t)p->max_fft_len + p->L);
-        if (shm <= 160 * 1024) {
-            HIP_TRY(hipFuncSetAttribute((const void *)ringfft_kernel<true>,
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-            ringfft_kernel<true><<<grid, 256, shm, ctx->stream>>>(
-                p->nside, p->lmax, p->nring, G, nnu_valid, p->npix, p->d_nphi, p->d_start, p->d_phi0, inter, maps,
-                p->d_tw, p->pmax, p->d_blu_P, p->d_blu_boff, p->d_blu_foff, p->d_bchirp, p->d_bfilt, p->max_fft_len);
-        } else {
-            shm = sizeof(double2) * (size_t)p->max_fft_len;
-            if (shm > 160 * 1024) {
-                corahip_set_error("nside %d needs %zu bytes of LDS for the ring FFT (max 160 KiB)", p->nside, shm);
-                return CORAHIP_ENOMEM;
-            }
-            HIP_TRY(hipFuncSetAttribute((const void *)ringfft_kernel<false>,
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-            ringfft_kernel<false><<<grid, 256, shm, ctx->stream>>>(
-                p->nside, p->lmax, p->nring, G, nnu_valid, p->npix, p->d_nphi, p->d_start, p->d_phi0, inter, maps,
-                p->d_tw, p->pmax, p->d_blu_P, p->d_blu_boff, p->d_blu_foff, p->d_bchirp, p->d_bfilt, p->max_fft_len);
+        for (const auto &c : p->classes) {
+            const size_t shm = sizeof(double2) * (size_t)c.nch * c.bstride;
+            dim3 grid(c.count, (nnu_valid + c.nch - 1) / c.nch);
+#define RINGFFT_LAUNCH(NCH)                                                                                     \
+    HIP_TRY(hipFuncSetAttribute((const void *)ringfft_kernel<NCH>, hipFuncAttributeMaxDynamicSharedMemorySize,  \
+                                160 * 1024));                                                                   \
+    ringfft_kernel<NCH><<<grid, 512, shm, ctx->stream>>>(c.d_list, p->nside, p->lmax, G, nnu_valid, p->npix,     \
+                                                         p->d_nphi, p->d_start, p->d_phi0, inter, maps, p->d_tw, \
+                                                         p->pmax, p->d_blu_P, p->d_blu_boff, p->d_blu_foff,      \
+                                                         p->d_bchirp, p->d_bfilt, c.bstride)
+            if (c.nch == 4) { RINGFFT_LAUNCH(4); }
+            else if (c.nch == 2) { RINGFFT_LAUNCH(2); }
+            else { RINGFFT_LAUNCH(1); }
+#undef RINGFFT_LAUNCH
+            LAUNCH_CHECK();
         }
-        LAUNCH_CHECK();
     }
     return 0;
 }
