@@ -245,6 +245,18 @@ legendre_kernel(int lmax, int npair, int nring, int ncols, const double *__restr
         gload(l_begin);
         swrite(0);
         __syncthreads();
+        // lane-constant select masks for the MFMA A operand (k-slot kq takes lambda at l0+2kq / +1)
+        const unsigned long long mk0 = kq == 0 ? ~0ull : 0ull, mk1 = kq == 1 ? ~0ull : 0ull,
+                                 mk2 = kq == 2 ? ~0ull : 0ull;
+        auto sel = [](unsigned long long mask, double a, double b) {
+            return __longlong_as_double((__double_as_longlong(a) & mask) | (__double_as_longlong(b) & ~mask));
+        };
+        // recurrence coefficients are wave-uniform: fetched 8 at a time (scalar loads), one
+        // macro-step ahead.  Reads past lmax stay inside the (padded) table; the a_lm rows there
+        // are zero so the extra lambdas are never used.
+        double2 ccur[8], cnext[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) ccur[j] = cf[l_begin + j];
         int buf = 0;
         for (int ls = l_begin; ls <= lmax; ls += LEG_KT) {
             const bool more = (ls + LEG_KT) <= lmax;
@@ -254,45 +266,43 @@ legendre_kernel(int lmax, int npair, int nring, int ncols, const double *__restr
             for (int ms = 0; ms < LEG_KT / 8; ms++) {
                 const int l0 = ls + 8 * ms;
                 if (l0 > lmax) break;
+#pragma unroll
+                for (int j = 0; j < 8; j++) cnext[j] = cf[l0 + 8 + j];
                 // whole wave still below its first contributing l: nothing to do
-                if (__all(my_ls > l0 + 7)) continue;
-                double v[8];
-                const bool inj_here = (my_ls >= l0) && (my_ls < l0 + 8);
-                if (__any(inj_here)) {
+                if (!__all(my_ls > l0 + 7)) {
+                    double v[8];
+                    const bool inj_here = (my_ls >= l0) && (my_ls < l0 + 8);
+                    if (__any(inj_here)) {
 #pragma unroll
-                    for (int j = 0; j < 8; j++) {
-                        const int l = l0 + j;
-                        double2 c = cf[l <= lmax ? l : lmax];
-                        if (l > lmax) c = make_double2(0.0, 0.0);
-                        double vv = fma(c.x * x, p1, -(c.y * p0));
-                        const bool inj = (l == my_ls);
-                        vv = inj ? sd.y : vv;
-                        p0 = inj ? sd.x : p1;
-                        p1 = vv;
-                        v[j] = vv;
+                        for (int j = 0; j < 8; j++) {
+                            double vv = fma(ccur[j].x * x, p1, -(ccur[j].y * p0));
+                            const bool inj = (l0 + j == my_ls);
+                            vv = inj ? sd.y : vv;
+                            p0 = inj ? sd.x : p1;
+                            p1 = vv;
+                            v[j] = vv;
+                        }
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 8; j++) {
+                            const double vv = fma(ccur[j].x * x, p1, -(ccur[j].y * p0));
+                            p0 = p1;
+                            p1 = vv;
+                            v[j] = vv;
+                        }
                     }
-                } else {
+                    const double ae = sel(mk0, v[0], sel(mk1, v[2], sel(mk2, v[4], v[6])));
+                    const double ao = sel(mk0, v[1], sel(mk1, v[3], sel(mk2, v[5], v[7])));
+                    const double *be = sb + (8 * ms + 2 * kq) * STRIDE + ri;
+                    const double *bo = be + STRIDE;
 #pragma unroll
-                    for (int j = 0; j < 8; j++) {
-                        const int l = l0 + j;
-                        double2 c = cf[l <= lmax ? l : lmax];
-                        if (l > lmax) c = make_double2(0.0, 0.0);
-                        double vv = fma(c.x * x, p1, -(c.y * p0));
-                        p0 = p1;
-                        p1 = vv;
-                        v[j] = vv;
+                    for (int t = 0; t < NT; t++) {
+                        acce[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(ae, be[16 * t], acce[t], 0, 0, 0);
+                        acco[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(ao, bo[16 * t], acco[t], 0, 0, 0);
                     }
                 }
-                // MFMA A operand: lane (ring ri, k-slot kq) supplies lambda at l0+2kq (even) / +1 (odd)
-                const double ae = kq == 0 ? v[0] : kq == 1 ? v[2] : kq == 2 ? v[4] : v[6];
-                const double ao = kq == 0 ? v[1] : kq == 1 ? v[3] : kq == 2 ? v[5] : v[7];
-                const double *be = sb + (8 * ms + 2 * kq) * STRIDE + ri;
-                const double *bo = be + STRIDE;
 #pragma unroll
-                for (int t = 0; t < NT; t++) {
-                    acce[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(ae, be[16 * t], acce[t], 0, 0, 0);
-                    acco[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(ao, bo[16 * t], acco[t], 0, 0, 0);
-                }
+                for (int j = 0; j < 8; j++) ccur[j] = cnext[j];
             }
             if (more) swrite(buf ^ 1);
             __syncthreads();
@@ -790,7 +800,7 @@ int corahip_sht_plan_create(corahip_ctx *ctx, int nside, int lmax, corahip_sht_p
     // recurrence coefficients: lambda_l = A_l x lambda_{l-1} - B_l lambda_{l-2},
     // A_l = alpha_lm, B_l = alpha_lm/alpha_{l-1,m}, alpha_lm = sqrt((4l^2-1)/(l^2-m^2))
     {
-        std::vector<double2> coef(p->nalm);
+        std::vector<double2> coef(p->nalm + 32, make_double2(0.0, 0.0));  // +32: K4 prefetches past the end
         for (int m = 0; m <= lmax; m++) {
             long double aprev = 0.0L;
             for (int l = m; l <= lmax; l++) {
