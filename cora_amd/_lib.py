@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcorahip.so")
+LIB_PATH = os.environ.get("CORAHIP_LIB", os.path.join(_HERE, "libcorahip.so"))  # override: diagnostics only
 
 c_int, c_double, c_void_p, c_size_t = ctypes.c_int, ctypes.c_double, ctypes.c_void_p, ctypes.c_size_t
 c_u64, c_char_p = ctypes.c_uint64, ctypes.c_char_p

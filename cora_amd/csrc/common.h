@@ -73,7 +73,7 @@ struct StageTimer {
 
 #define LAUNCH_CHECK() HIP_TRY(hipGetLastError())
 
-static inline long nalm_of(int lmax) { return (long)(lmax + 1) * (lmax + 2) / 2; }
+__host__ __device__ static inline long nalm_of(int lmax) { return (long)(lmax + 1) * (lmax + 2) / 2; }
 // healpy packed index (m-major): idx(l,m) = m(2 lmax+1-m)/2 + l
 __host__ __device__ static inline long alm_idx(int l, int m, int lmax) {
     return (long)m * (2 * lmax + 1 - m) / 2 + l;

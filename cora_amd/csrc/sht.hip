@@ -18,6 +18,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <map>
 
 // ------------------------------------------------------------------------------------
@@ -35,6 +36,8 @@ struct corahip_sht_plan {
     double2 *d_coef = nullptr;                            // [nalm]: (A_l, B_l) at alm_idx(l,m)
     int32_t *d_lstart = nullptr;                          // [L][npair]
     double2 *d_seed = nullptr;                            // [L][npair]: (lambda_{lstart-1}, lambda_{lstart})
+    unsigned long long *d_stamps = nullptr;               // diagnostic builds only (LEG_ABLATE == 9)
+    double *d_zeros = nullptr;                            // 4 KiB of zeros (source of padding rows for LDS-DMA)
     double2 *d_tw = nullptr;                              // e^{+2 pi i k/pmax}, k < pmax/2
     int pmax = 0, log_pmax = 0;
     // Bluestein tables, indexed by north-cap ring number i-1 (i = 1..nside-1)
@@ -164,29 +167,75 @@ __global__ void lambda_kernel(int lmax, int npair, int m, int r, const double *_
 // ------------------------------------------------------------------------------------
 // K4: Legendre contraction on FP64 MFMA
 // ------------------------------------------------------------------------------------
+#ifndef LEG_ABLATE
+#define LEG_ABLATE 0  // diagnostic builds only (make ablate): 1 no MFMA, 2 no recurrence, 3 no B reads
+#endif
 #define LEG_KT 32      // l rows per LDS stage
-#define LEG_RINGS 64   // ring pairs per block (4 waves x 16)
+#define LEG_WAVES 8
+#define LEG_RINGS (16 * LEG_WAVES)  // ring pairs per workgroup
+#define LEG_NBUF 4     // LDS stage ring: one being read + three in flight
 
+// LDS-DMA issued from inline asm: hipcc does not count it, so it does not drain the DMA with a
+// vmcnt(0) in front of every later ds_read (which it does for the builtin: the DMA is a pending LDS
+// write it cannot disambiguate).  The kernel waits itself: s_waitcnt vmcnt(0) before the stage barrier.
+// lds_byte_addr must be wave-uniform; lane i's 16 bytes land at lds_byte_addr + 16 i.
+__device__ static inline void glds16(const void *gsrc, unsigned lds_byte_addr) {
+    unsigned keep;
+    const unsigned dst = __builtin_amdgcn_readfirstlane(lds_byte_addr);
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(dst)
+                 : "memory");
+}
+
+// Lane roles (wave = 16 rings x 4 k-slots, the A operand of v_mfma_f64_16x16x4_f64):
+// lane (ri = lane&15, kq = lane>>4) runs the recurrence of ring ri STAGGERED by 2 kq steps, so that
+// at every macro-step (8 consecutive l, base l0) the first two values it produces are exactly the
+// ones its k-slot must feed: lambda at l0+2kq (even l-m -> north+south accumulator) and l0+2kq+1
+// (odd).  No cross-lane movement, no selects; the price is that the recurrence coefficients are
+// no longer wave-uniform (4 distinct rows per step) - they are staged through LDS with the a_lm
+// rows and read with one broadcast ds_read_b128 per step.
 template <int NT>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(512)
 legendre_kernel(int lmax, int npair, int nring, int ncols, const double *__restrict__ z,
                 const double2 *__restrict__ coef, const int32_t *__restrict__ lstart,
                 const double2 *__restrict__ seed, const double *__restrict__ alm,
-                double *__restrict__ inter) {
+                const double *__restrict__ zeros, double *__restrict__ inter, unsigned long long *stamps) {
     constexpr int TCOLS = 16 * NT;          // columns of this block
     constexpr int STRIDE = TCOLS + 8;       // LDS row stride (doubles): 2 rows apart = 128 B mod 256
-    constexpr int STAGE = LEG_KT * STRIDE;  // doubles per stage
+    constexpr int CROWS = LEG_KT + 8;       // coefficient rows per stage (staggered lanes look 6 ahead)
+    constexpr int STAGE = LEG_KT * STRIDE + 2 * CROWS;  // doubles per stage: a_lm rows + (A,B) pairs
+    constexpr int PIECES = LEG_KT / LEG_WAVES + 1;      // LDS-DMA pieces per wave per stage
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    int &s_lmin = *reinterpret_cast<int *>(lds + 2 * STAGE);  // carved after the two stages (G17: no static LDS)
+    int &s_lmin = *reinterpret_cast<int *>(lds + LEG_NBUF * STAGE);  // carved after the stage ring (G17)
 
+#if LEG_ABLATE == 9
+#define STAMP(var) { unsigned long long _t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)::"memory"); var = _t; }
+    unsigned long long T0, Ta, Tb, t_pro = 0, t_wait = 0, t_issue = 0, t_rec = 0, t_mfma = 0, t_epi = 0;
+    STAMP(T0);
+#else
+#define STAMP(var)
+#endif
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int ri = lane & 15, kq = lane >> 4;
-    const int m = blockIdx.z;
-    const int cg = blockIdx.y;
+    // work mapping: consecutive workgroups = the ring tiles of one (m, column-group) a_lm slice; the
+    // dispatcher deals them round-robin over the 8 XCDs.  (Packing a whole slice group onto ONE XCD
+    // was measured 24 % slower: all resident workgroups of the XCD then hammer the same 1-2 L2
+    // channels in lock step.)  Small m (long K loops) first.
+    const int ntile = (npair + LEG_RINGS - 1) / LEG_RINGS;
+    const int ncg = ncols / TCOLS;
+    const int bid = blockIdx.x;
+    const int gidx = bid / ntile;
+    const int rtile = bid - gidx * ntile;
+    if (gidx >= (lmax + 1) * ncg) return;
+    const int m = gidx / ncg;
+    const int cg = gidx % ncg;
     const int L = lmax + 1;
     const int G = ncols >> 3;
-    const int ring = blockIdx.x * LEG_RINGS + wave * 16 + ri;
+    // rings are dealt to the waves interleaved (ring = tile base + 8 ri + wave) so that every wave of
+    // the workgroup has the same mix of first-contributing l and reaches the stage barriers together
+    const int ring = rtile * LEG_RINGS + ri * LEG_WAVES + wave;
     const bool ring_ok = ring < npair;
 
     double x = 0.0;
@@ -213,119 +262,195 @@ legendre_kernel(int lmax, int npair, int nring, int ncols, const double *__restr
 
     if (lmin <= lmax) {
         const int l_begin = m + ((lmin - m) & ~7);
+        const int nstage = (lmax - l_begin) / LEG_KT + 1;
         const long base_m = alm_idx(0, m, lmax);
         const double2 *cf = coef + base_m;
         const double *arow = alm + (size_t)cg * TCOLS;
+        const int d = 2 * kq;
+        const unsigned lds_base_bytes = (unsigned)(size_t)(__attribute__((address_space(3))) double *)lds;
+
+        // ---- stage loader: every wave issues exactly PIECES LDS-DMA pieces per stage (counted waits):
+        //      LEG_KT/LEG_WAVES a_lm rows (zero rows past lmax) + the CROWS coefficient pairs (all waves
+        //      write the same bytes; keeps the per-wave piece count uniform)
+        const int wv = __builtin_amdgcn_readfirstlane(wave);
+        const long last_row = nalm_of(lmax) - 1;
+        auto stage_issue = [&](int st) {
+            const int ls = l_begin + st * LEG_KT;
+            const unsigned sbase = lds_base_bytes + (unsigned)((st % LEG_NBUF) * STAGE * sizeof(double));
+#pragma unroll
+            for (int rr = 0; rr < LEG_KT / LEG_WAVES; rr++) {
+                // rows past lmax are never used (their lambda is 0): read any valid row instead of zeros,
+                // which keeps the source address wave-uniform scalar arithmetic
+                const int row = wv + LEG_WAVES * rr;
+                long rowidx = base_m + ls + row;
+                rowidx = rowidx < last_row ? rowidx : last_row;
+                const double *src = arow + (size_t)rowidx * ncols + 2 * lane;
+                if (lane < 8 * NT) glds16(src, sbase + (unsigned)(row * STRIDE * sizeof(double)));
+            }
+            {
+                const int l = ls + lane;
+                const double *src = (l <= lmax) ? reinterpret_cast<const double *>(cf + l) : zeros;
+                if (lane < CROWS) glds16(src, sbase + (unsigned)(LEG_KT * STRIDE * sizeof(double)));
+            }
+        };
+
+#pragma unroll
+        for (int st = 0; st < LEG_NBUF - 1; st++)
+            if (st < nstage) stage_issue(st);
+
+        // ---- per-lane start state: (lambda_{lf-2}, lambda_{lf-1}) with lf = l_begin + d the first l of
+        //      this lane.  If the ring's first contributing l lies before lf, advance from the seeds.
         double p0 = 0.0, p1 = 0.0;
-
-        // stage loader: LEG_KT rows x TCOLS doubles = 8*NT*LEG_KT double2 items, NT per thread
-        double2 pre[NT];
-        auto gload = [&](int ls) {
-#pragma unroll
-            for (int j = 0; j < NT; j++) {
-                int q = tid + 256 * j;
-                int row = q / (8 * NT), c2 = q % (8 * NT);
-                int l = ls + row;
-                if (l <= lmax) {
-                    pre[j] = *reinterpret_cast<const double2 *>(arow + (size_t)(base_m + l) * ncols + 2 * c2);
-                } else {
-                    pre[j] = make_double2(0.0, 0.0);
+        int inj_l = my_ls;  // l at which the seeds are injected
+        {
+            const int lf = l_begin + d;
+            if (my_ls < lf) {
+                p0 = sd.x;
+                p1 = sd.y;
+                for (int l = my_ls + 1; l < lf; l++) {
+                    const double2 c = (l <= lmax) ? cf[l] : make_double2(0.0, 0.0);
+                    const double vv = fma(c.x * x, p1, -(c.y * p0));
+                    p0 = p1;
+                    p1 = vv;
                 }
+                inj_l = 0x7fffffff;
             }
-        };
-        auto swrite = [&](int buf) {
-#pragma unroll
-            for (int j = 0; j < NT; j++) {
-                int q = tid + 256 * j;
-                int row = q / (8 * NT), c2 = q % (8 * NT);
-                *reinterpret_cast<double2 *>(lds + buf * STAGE + row * STRIDE + 2 * c2) = pre[j];
-            }
-        };
+        }
 
-        gload(l_begin);
-        swrite(0);
-        __syncthreads();
-        // lane-constant select masks for the MFMA A operand (k-slot kq takes lambda at l0+2kq / +1)
-        const unsigned long long mk0 = kq == 0 ? ~0ull : 0ull, mk1 = kq == 1 ? ~0ull : 0ull,
-                                 mk2 = kq == 2 ? ~0ull : 0ull;
-        auto sel = [](unsigned long long mask, double a, double b) {
-            return __longlong_as_double((__double_as_longlong(a) & mask) | (__double_as_longlong(b) & ~mask));
-        };
-        // recurrence coefficients are wave-uniform: fetched 8 at a time (scalar loads), one
-        // macro-step ahead.  Reads past lmax stay inside the (padded) table; the a_lm rows there
-        // are zero so the extra lambdas are never used.
-        double2 ccur[8], cnext[8];
-#pragma unroll
-        for (int j = 0; j < 8; j++) ccur[j] = cf[l_begin + j];
-        int buf = 0;
-        for (int ls = l_begin; ls <= lmax; ls += LEG_KT) {
-            const bool more = (ls + LEG_KT) <= lmax;
-            if (more) gload(ls + LEG_KT);
-            const double *sb = lds + buf * STAGE;
+#if LEG_ABLATE == 9
+        STAMP(Ta); t_pro = Ta - T0;
+#endif
+        for (int st = 0; st < nstage; st++) {
+            STAMP(Ta);
+            // own pieces of stage st have landed when at most the pieces of the (up to LEG_NBUF-2)
+            // younger stages are still in flight
+            if (st + 2 < nstage) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PIECES) : "memory");
+            else if (st + 1 < nstage) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();  // everyone's pieces of stage st landed; everyone is done reading stage st-1
+#if LEG_ABLATE == 9
+            STAMP(Tb); t_wait += Tb - Ta;
+#endif
+            if (st + LEG_NBUF - 1 < nstage) stage_issue(st + LEG_NBUF - 1);
+#if LEG_ABLATE == 9
+            STAMP(Ta); t_issue += Ta - Tb;
+#endif
+            const int ls = l_begin + st * LEG_KT;
+            const double *sb = lds + (st % LEG_NBUF) * STAGE;
+            const double2 *sc = reinterpret_cast<const double2 *>(sb + LEG_KT * STRIDE) + d;
 #pragma unroll 1
             for (int ms = 0; ms < LEG_KT / 8; ms++) {
                 const int l0 = ls + 8 * ms;
                 if (l0 > lmax) break;
+                // nothing of this wave starts before l0+14: skip the macro-step entirely
+                if (__all(my_ls > l0 + 13)) continue;
+                STAMP(Ta);
+#if LEG_ABLATE == 2  // diagnostic: no recurrence
+                double ae = x, ao = x + 1.0;
+                asm volatile("" : "+v"(ae), "+v"(ao));
+#else
+                double2 c[8];
 #pragma unroll
-                for (int j = 0; j < 8; j++) cnext[j] = cf[l0 + 8 + j];
-                // whole wave still below its first contributing l: nothing to do
-                if (!__all(my_ls > l0 + 7)) {
-                    double v[8];
-                    const bool inj_here = (my_ls >= l0) && (my_ls < l0 + 8);
-                    if (__any(inj_here)) {
+                for (int j = 0; j < 8; j++) c[j] = sc[8 * ms + j];
+                double ae, ao;
+                const int lf = l0 + d;
+                if (__any(inj_l >= lf && inj_l < lf + 8)) {
 #pragma unroll
-                        for (int j = 0; j < 8; j++) {
-                            double vv = fma(ccur[j].x * x, p1, -(ccur[j].y * p0));
-                            const bool inj = (l0 + j == my_ls);
-                            vv = inj ? sd.y : vv;
-                            p0 = inj ? sd.x : p1;
-                            p1 = vv;
-                            v[j] = vv;
-                        }
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < 8; j++) {
-                            const double vv = fma(ccur[j].x * x, p1, -(ccur[j].y * p0));
-                            p0 = p1;
-                            p1 = vv;
-                            v[j] = vv;
-                        }
+                    for (int j = 0; j < 8; j++) {
+                        double vv = fma(c[j].x * x, p1, -(c[j].y * p0));
+                        const bool inj = (lf + j == inj_l);
+                        vv = inj ? sd.y : vv;
+                        p0 = inj ? sd.x : p1;
+                        p1 = vv;
+                        if (j == 0) ae = vv;
+                        if (j == 1) ao = vv;
                     }
-                    const double ae = sel(mk0, v[0], sel(mk1, v[2], sel(mk2, v[4], v[6])));
-                    const double ao = sel(mk0, v[1], sel(mk1, v[3], sel(mk2, v[5], v[7])));
-                    const double *be = sb + (8 * ms + 2 * kq) * STRIDE + ri;
-                    const double *bo = be + STRIDE;
+                } else {
 #pragma unroll
-                    for (int t = 0; t < NT; t++) {
-                        acce[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(ae, be[16 * t], acce[t], 0, 0, 0);
-                        acco[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(ao, bo[16 * t], acco[t], 0, 0, 0);
+                    for (int j = 0; j < 8; j++) {
+                        const double vv = fma(c[j].x * x, p1, -(c[j].y * p0));
+                        p0 = p1;
+                        p1 = vv;
+                        if (j == 0) ae = vv;
+                        if (j == 1) ao = vv;
                     }
                 }
+#endif
+#if LEG_ABLATE == 9
+                asm volatile("" : "+v"(ae), "+v"(ao));
+                STAMP(Tb); t_rec += Tb - Ta;
+#endif
+                if (__all(my_ls > l0 + 7)) continue;  // all A operands of this macro-step are zero
+                const double *be = sb + (8 * ms + d) * STRIDE + ri;
+                const double *bo = be + STRIDE;
+#if LEG_ABLATE == 1  // diagnostic: no MFMA (keep the operands alive)
+                asm volatile("" ::"v"(ae), "v"(ao), "v"(be), "v"(bo));
+#elif LEG_ABLATE == 3  // diagnostic: MFMA without LDS B reads
 #pragma unroll
-                for (int j = 0; j < 8; j++) ccur[j] = cnext[j];
+                for (int t = 0; t < NT; t++) {
+                    acce[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(ae, x, acce[t], 0, 0, 0);
+                    acco[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(ao, x, acco[t], 0, 0, 0);
+                }
+#else
+#pragma unroll
+                for (int t = 0; t < NT; t++) {
+                    acce[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(ae, be[16 * t], acce[t], 0, 0, 0);
+                    acco[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(ao, bo[16 * t], acco[t], 0, 0, 0);
+                }
+#endif
+#if LEG_ABLATE == 9
+                asm volatile("" : "+v"(acce[NT - 1]), "+v"(acco[NT - 1]));
+                STAMP(Ta); t_mfma += Ta - Tb;
+#endif
             }
-            if (more) swrite(buf ^ 1);
-            __syncthreads();
-            buf ^= 1;
         }
     }
+#if LEG_ABLATE == 9
+    STAMP(Tb);
+#endif
 
-    // epilogue: north = even + odd, south mirror = even - odd
+    // epilogue: north = even + odd, south mirror = even - odd.  Adjacent lanes (columns n, n+1 of the
+    // same rows) swap one value each so that every lane stores 16 bytes: half the store instructions.
+    const bool odd_lane = lane & 1;
 #pragma unroll
     for (int t = 0; t < NT; t++) {
-        const int col = cg * TCOLS + 16 * t + ri;
+        const int col = cg * TCOLS + 16 * t + (ri & ~1);  // even column of the lane pair
         const int g = col >> 3, cv = col & 7;
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const int ro = blockIdx.x * LEG_RINGS + wave * 16 + kq + 4 * r;
+        for (int rp = 0; rp < 2; rp++) {
+            const int r0 = 2 * rp, r1 = 2 * rp + 1;
+            const double n0 = acce[t][r0] + acco[t][r0], n1 = acce[t][r1] + acco[t][r1];
+            const double s0 = acce[t][r0] - acco[t][r0], s1 = acce[t][r1] - acco[t][r1];
+            // even lane keeps row r0 and sends its r1 value; odd lane keeps row r1 and sends its r0 value
+            const double nrecv = __shfl_xor(odd_lane ? n0 : n1, 1);
+            const double srecv = __shfl_xor(odd_lane ? s0 : s1, 1);
+            const int rr = odd_lane ? r1 : r0;
+            const int ro = rtile * LEG_RINGS + (kq + 4 * rr) * LEG_WAVES + wave;
             if (ro < npair) {
-                const double e = acce[t][r], o = acco[t][r];
-                inter[(((size_t)ro * G + g) * L + m) * 8 + cv] = e + o;
+                const double2 nv = odd_lane ? make_double2(nrecv, n1) : make_double2(n0, nrecv);
+                *reinterpret_cast<double2 *>(inter + (((size_t)ro * G + g) * L + m) * 8 + cv) = nv;
                 const int rs = nring - 1 - ro;
-                if (rs != ro) inter[(((size_t)rs * G + g) * L + m) * 8 + cv] = e - o;
+                if (rs != ro) {
+                    const double2 sv = odd_lane ? make_double2(srecv, s1) : make_double2(s0, srecv);
+                    *reinterpret_cast<double2 *>(inter + (((size_t)rs * G + g) * L + m) * 8 + cv) = sv;
+                }
             }
         }
     }
+#if LEG_ABLATE == 9
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    STAMP(Ta); t_epi = Ta - Tb;
+    if (lane == 0) {
+        atomicAdd(&stamps[0], Ta - T0);
+        atomicAdd(&stamps[1], t_pro);
+        atomicAdd(&stamps[2], t_wait);
+        atomicAdd(&stamps[3], t_issue);
+        atomicAdd(&stamps[4], t_rec);
+        atomicAdd(&stamps[5], t_mfma);
+        atomicAdd(&stamps[6], t_epi);
+        atomicAdd(&stamps[7], 1ull);
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------
@@ -727,6 +852,8 @@ int corahip_sht_plan_destroy(corahip_ctx *ctx, corahip_sht_plan *p) {
     (void)hipFree(p->d_lstart);
     (void)hipFree(p->d_seed);
     (void)hipFree(p->d_tw);
+    (void)hipFree(p->d_zeros);
+    (void)hipFree(p->d_stamps);
     (void)hipFree(p->d_blu_P);
     (void)hipFree(p->d_blu_boff);
     (void)hipFree(p->d_blu_foff);
@@ -839,6 +966,10 @@ int corahip_sht_plan_create(corahip_ctx *ctx, int nside, int lmax, corahip_sht_p
     HIP_TRY(hipStreamSynchronize(s));
     (void)hipFree(d_pref);
 
+    HIP_TRY(hipMalloc((void **)&p->d_stamps, 4096));
+    HIP_TRY(hipMemsetAsync(p->d_stamps, 0, 4096, s));
+    HIP_TRY(hipMalloc((void **)&p->d_zeros, 4096));
+    HIP_TRY(hipMemsetAsync(p->d_zeros, 0, 4096, s));
     // FFT twiddles and Bluestein tables
     p->pmax = std::max(4 * nside, 4);
     p->log_pmax = ilog2(p->pmax);
@@ -959,13 +1090,25 @@ extern "C" int corahip_alm2map_workspace_bytes(const corahip_sht_plan *p, int nn
 template <int NT>
 static int launch_legendre(corahip_ctx *ctx, const corahip_sht_plan *p, int ncols, const double *alm, double *inter) {
     constexpr int STRIDE = 16 * NT + 8;
-    const size_t shm = sizeof(double) * 2 * LEG_KT * STRIDE + 16;
+    const size_t shm = sizeof(double) * LEG_NBUF * (LEG_KT * STRIDE + 2 * (LEG_KT + 8)) + 16;
     HIP_TRY(hipFuncSetAttribute((const void *)legendre_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)shm));
-    dim3 grid((p->npair + LEG_RINGS - 1) / LEG_RINGS, ncols / (16 * NT), p->L);
-    legendre_kernel<NT><<<grid, 256, shm, ctx->stream>>>(p->lmax, p->npair, p->nring, ncols, p->d_z, p->d_coef,
-                                                        p->d_lstart, p->d_seed, alm, inter);
+    const int ntile = (p->npair + LEG_RINGS - 1) / LEG_RINGS;
+    const int ngroup = p->L * (ncols / (16 * NT));
+    dim3 grid(ngroup * ntile);
+    legendre_kernel<NT><<<grid, 64 * LEG_WAVES, shm, ctx->stream>>>(p->lmax, p->npair, p->nring, ncols, p->d_z, p->d_coef,
+                                                        p->d_lstart, p->d_seed, alm, p->d_zeros, inter, p->d_stamps);
     LAUNCH_CHECK();
+#if LEG_ABLATE == 9
+    {
+        unsigned long long h[8];
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        HIP_TRY(hipMemcpy(h, p->d_stamps, sizeof(h), hipMemcpyDeviceToHost));
+        fprintf(stderr, "K4 stamps (wave-cycle sums): total %llu  prologue %llu  wait+barrier %llu  issue %llu  recur %llu  mfma %llu  epilogue %llu waves %llu\n",
+                h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]);
+        HIP_TRY(hipMemset(p->d_stamps, 0, 4096));
+    }
+#endif
     return 0;
 }
 
