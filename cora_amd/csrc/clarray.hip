@@ -17,11 +17,19 @@
 #define CL_TJ 16
 #define CL_MAXZ 17  // zint <= 17 (zromb <= 4)
 
+#define CL_ISPLIT 4
+#define CL_TJH 8    // channels of the j tile whose constants are resident in LDS at a time
+
+// per sub-sample pair (i a, j b): everything that does not depend on l.  The y interpolation
+// weights are folded into the coefficients: value = sum_T (cT0 T[x][y0] + cT1 T[x][y0+1]).
 struct cl_pair_const {
-    double lxc;   // log10(xc * kperpmin)
-    double wy;    // fractional part of clipped y
-    double cdd, cdv, cvv;  // W*b1b2, W*(f1b2+f2b1), W*f1f2; W = w_a w_b pfD_a pfD_b/(xc^2 pi)
-    int y0, pad;
+    double lxcs;             // log10(xc * kperpmin) * xscale
+    double c[6];             // {dd,dv,vv} x {(1-wy), wy} x W x model factor; W = w_a w_b pfD_a pfD_b/(xc^2 pi)
+    unsigned y0, pad;        // floor of the clipped y
+};
+
+struct __attribute__((aligned(8))) cl_d2 {  // two adjacent table entries (8-byte aligned 16-byte load)
+    double a, b;
 };
 
 __global__ void __launch_bounds__(256)
@@ -32,72 +40,97 @@ clarray21_kernel(const double *__restrict__ dd, const double *__restrict__ dv, c
                  const double *__restrict__ log10l, int nl, const int2 *__restrict__ tiles,
                  double *__restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    cl_pair_const *pc = reinterpret_cast<cl_pair_const *>(smem);  // [zint][CL_TJ][zint]
+    cl_pair_const *pc = reinterpret_cast<cl_pair_const *>(smem);  // [zint][CL_TJH][zint]
     const int tid = threadIdx.x;
     const int it = tiles[blockIdx.x].x, jt = tiles[blockIdx.x].y;
     const int li = blockIdx.y * 256 + tid;
     const bool l_ok = li < nl;
-    const double lx = l_ok ? log10l[li] : 0.0;
+    const double lxs = (l_ok ? log10l[li] : 0.0) * xscale;
     const double ux = (double)nkperp - 1e-5, uy = (double)nkpar - 1e-5;
-    const int nsub = zint * CL_TJ * zint;
+    const int nsub = zint * CL_TJH * zint;
+    const unsigned xlast = (unsigned)(nkperp - 1);
 
-    for (int ii = 0; ii < CL_TI; ii++) {
+    // blockIdx.z splits the 16 rows of the tile over CL_ISPLIT workgroups (more, shorter workgroups:
+    // 136 tile pairs x 9 l-chunks alone leave the second wave of workgroups 40 % empty at F = 256)
+    for (int ii = blockIdx.z * (CL_TI / CL_ISPLIT); ii < (blockIdx.z + 1) * (CL_TI / CL_ISPLIT); ii++) {
         const int i = it * CL_TI + ii;
         if (i >= F) break;
-        __syncthreads();
-        // per sub-pair constants for channel i against the 16 channels of the j tile
-        for (int q = tid; q < nsub; q += 256) {
-            const int b = q % zint, jj = (q / zint) % CL_TJ, a = q / (zint * CL_TJ);
-            const int j = jt * CL_TJ + jj;
-            cl_pair_const c;
-            c.lxc = 0.0; c.wy = 0.0; c.cdd = 0.0; c.cdv = 0.0; c.cvv = 0.0; c.y0 = 0; c.pad = 0;
-            if (j < F) {
-                const int za = i * zint + a, zb = j * zint + b;
-                const double x1 = chi[za], x2 = chi[zb];
-                const double xc = 0.5 * (x1 + x2);
-                const double rpar = fabs(x2 - x1);
-                c.lxc = log10(xc * kperpmin);
-                double yy = rpar * yscale;  // rpar / (pi / kparmax)
-                yy = yy < 0.0 ? 0.0 : (yy > uy ? uy : yy);
-                const int y0 = (int)yy;
-                c.y0 = y0;
-                c.wy = yy - (double)y0;
-                const double W = w[a] * w[b] * pfd[za] * pfd[zb] / (xc * xc * M_PI);
-                c.cdd = W * bz[za] * bz[zb];
-                c.cdv = W * (fz[za] * bz[zb] + fz[zb] * bz[za]);
-                c.cvv = W * fz[za] * fz[zb];
-            }
-            pc[q] = c;
-        }
-        __syncthreads();
-        if (l_ok) {
-            double acc[CL_TJ];
+        double acc[CL_TJ];
 #pragma unroll
-            for (int jj = 0; jj < CL_TJ; jj++) acc[jj] = 0.0;
-            for (int a = 0; a < zint; a++) {
+        for (int jj = 0; jj < CL_TJ; jj++) acc[jj] = 0.0;
 #pragma unroll
-                for (int jj = 0; jj < CL_TJ; jj++) {
-                    double s = 0.0;
-                    for (int b = 0; b < zint; b++) {
-                        const cl_pair_const c = pc[(a * CL_TJ + jj) * zint + b];
-                        double xx = (lx - c.lxc) * xscale;
-                        xx = xx < 0.0 ? 0.0 : (xx > ux ? ux : xx);
-                        const int x0 = (int)xx;
-                        const double wx = xx - (double)x0;
-                        const int x1 = min(x0 + 1, nkperp - 1);
-                        const int y1 = min(c.y0 + 1, nkpar - 1);
-                        const size_t o00 = (size_t)x0 * nkpar + c.y0, o01 = (size_t)x0 * nkpar + y1;
-                        const size_t o10 = (size_t)x1 * nkpar + c.y0, o11 = (size_t)x1 * nkpar + y1;
-                        const double wa = (1.0 - wx) * (1.0 - c.wy), wb = (1.0 - wx) * c.wy;
-                        const double wc = wx * (1.0 - c.wy), wd = wx * c.wy;
-                        const double vdd = wa * dd[o00] + wb * dd[o01] + wc * dd[o10] + wd * dd[o11];
-                        const double vdv = wa * dv[o00] + wb * dv[o01] + wc * dv[o10] + wd * dv[o11];
-                        const double vvv = wa * vv[o00] + wb * vv[o01] + wc * vv[o10] + wd * vv[o11];
-                        s += c.cdd * vdd + c.cdv * vdv + c.cvv * vvv;
+        for (int half = 0; half < CL_TJ / CL_TJH; half++) {
+            __syncthreads();
+            // constants of channel i against CL_TJH channels of the j tile
+            for (int q = tid; q < nsub; q += 256) {
+                const int b = q % zint, jj = (q / zint) % CL_TJH, a = q / (zint * CL_TJH);
+                const int j = jt * CL_TJ + half * CL_TJH + jj;
+                cl_pair_const c;
+                c.lxcs = 0.0;
+#pragma unroll
+                for (int u = 0; u < 6; u++) c.c[u] = 0.0;
+                c.y0 = 0;
+                c.pad = 0;
+                if (j < F) {
+                    const int za = i * zint + a, zb = j * zint + b;
+                    const double x1 = chi[za], x2 = chi[zb];
+                    const double xc = 0.5 * (x1 + x2);
+                    const double rpar = fabs(x2 - x1);
+                    c.lxcs = log10(xc * kperpmin) * xscale;
+                    double yy = rpar * yscale;  // rpar / (pi / kparmax)
+                    yy = yy < 0.0 ? 0.0 : (yy > uy ? uy : yy);
+                    unsigned y0 = (unsigned)yy;
+                    double wy = yy - (double)y0;
+                    if (y0 + 1 > (unsigned)(nkpar - 1)) {  // keep the 16-byte pair load in bounds (the
+                        y0 = (unsigned)(nkpar - 2);        // reference reads out of bounds here)
+                        wy = 1.0;
                     }
-                    acc[jj] += s;
+                    c.y0 = y0;
+                    const double W = w[a] * w[b] * pfd[za] * pfd[zb] / (xc * xc * M_PI);
+                    const double cdd = W * bz[za] * bz[zb];
+                    const double cdv = W * (fz[za] * bz[zb] + fz[zb] * bz[za]);
+                    const double cvv = W * fz[za] * fz[zb];
+                    c.c[0] = cdd * (1.0 - wy);
+                    c.c[1] = cdd * wy;
+                    c.c[2] = cdv * (1.0 - wy);
+                    c.c[3] = cdv * wy;
+                    c.c[4] = cvv * (1.0 - wy);
+                    c.c[5] = cvv * wy;
+                }
+                pc[q] = c;
+            }
+            __syncthreads();
+            if (l_ok) {
+                for (int a = 0; a < zint; a++) {
+#pragma unroll
+                    for (int jj = 0; jj < CL_TJH; jj++) {
+                        double s = 0.0;
+                        for (int b = 0; b < zint; b++) {
+                            const cl_pair_const &c = pc[(a * CL_TJH + jj) * zint + b];
+                            double xx = lxs - c.lxcs;
+                            xx = xx < 0.0 ? 0.0 : (xx > ux ? ux : xx);
+                            const unsigned x0 = (unsigned)xx;
+                            const double wx = xx - (double)x0;
+                            const unsigned x1 = x0 + 1 > xlast ? xlast : x0 + 1;
+                            const unsigned o0 = x0 * (unsigned)nkpar + c.y0, o1 = x1 * (unsigned)nkpar + c.y0;
+                            const cl_d2 d0 = *reinterpret_cast<const cl_d2 *>(dd + o0);
+                            const cl_d2 v0 = *reinterpret_cast<const cl_d2 *>(dv + o0);
+                            const cl_d2 q0 = *reinterpret_cast<const cl_d2 *>(vv + o0);
+                            const cl_d2 d1 = *reinterpret_cast<const cl_d2 *>(dd + o1);
+                            const cl_d2 v1 = *reinterpret_cast<const cl_d2 *>(dv + o1);
+                            const cl_d2 q1 = *reinterpret_cast<const cl_d2 *>(vv + o1);
+                            const double s0 = c.c[0] * d0.a + c.c[1] * d0.b + c.c[2] * v0.a + c.c[3] * v0.b +
+                                              c.c[4] * q0.a + c.c[5] * q0.b;
+                            const double s1 = c.c[0] * d1.a + c.c[1] * d1.b + c.c[2] * v1.a + c.c[3] * v1.b +
+                                              c.c[4] * q1.a + c.c[5] * q1.b;
+                            s += s0 + wx * (s1 - s0);
+                        }
+                        acc[half * CL_TJH + jj] += s;
+                    }
                 }
             }
+        }
+        if (l_ok) {
             double *orow = out + ((size_t)li * F + i) * F + (size_t)jt * CL_TJ;
 #pragma unroll
             for (int jj = 0; jj < CL_TJ; jj++)
@@ -203,9 +236,9 @@ int corahip_clarray_table21cm(corahip_ctx *ctx, const double *dd, const double *
     HIP_TRY(hipMemcpyAsync(dtiles, tiles.data(), sizeof(int2) * tiles.size(), hipMemcpyHostToDevice, ctx->stream));
     const double xscale = (double)(nkperp - 1) / log10(kperpmax / kperpmin);
     const double yscale = kparmax / M_PI;
-    const size_t shm = sizeof(cl_pair_const) * (size_t)zint * CL_TJ * zint;
+    const size_t shm = sizeof(cl_pair_const) * (size_t)zint * CL_TJH * zint;
     HIP_TRY(hipFuncSetAttribute((const void *)clarray21_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-    dim3 grid((unsigned)tiles.size(), (nl + 255) / 256);
+    dim3 grid((unsigned)tiles.size(), (nl + 255) / 256, CL_ISPLIT);
     clarray21_kernel<<<grid, 256, shm, ctx->stream>>>(dd, dv, vv, nkperp, nkpar, kperpmin, xscale, yscale, chi, pfd, f,
                                                       b, F, zint, w, log10l, nl, dtiles, out);
     LAUNCH_CHECK();
