@@ -51,6 +51,7 @@ def matrix_root_manynull(mat, threshold=1e-16, truncate=True):
         if truncate:
             # columns are in ascending-eigenvalue order (scipy.linalg.eigh order): keep the last num_pos
             root = root[:, n - num_pos:] if num_pos > 0 else root[:, n:]
+            root = root[np.newaxis]  # the reference returns [1, N, num_pos] here (nputil.py:92-96 quirk)
     if truncate:
         return root, num_pos
     return root

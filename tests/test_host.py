@@ -1,0 +1,242 @@
+"""Host-side logic of cora_amd (no GPU): API surface mirrored from cora, error behaviour,
+the C ABI library loads and exports every symbol of include/corahip.h."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# ------------------------------------------------------------------ C ABI
+def test_library_exports_every_declared_symbol():
+    from cora_amd import _lib
+
+    hdr = open(os.path.join(ROOT, "include", "corahip.h")).read()
+    declared = set(re.findall(r"\b(corahip_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no prototypes found"
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    lib = _lib.load()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.corahip_abi_version() == 1
+    assert isinstance(lib.corahip_last_error(), bytes)
+
+
+def test_no_gpu_fails_loudly():
+    """Without a GPU the compute entry points raise; they never fall back to a CPU path."""
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from cora_amd import CoraHipError
+    from cora_amd.core import skysim
+    from cora_amd.util import hputil, nputil
+
+    with pytest.raises(CoraHipError):
+        skysim.mkfullsky(np.ones((3, 2, 2)), 4)
+    with pytest.raises(CoraHipError):
+        skysim.clarray(lambda l, a, b: l + a + b, 8, np.array([1.0, 2.0]), zromb=0)
+    with pytest.raises(CoraHipError):
+        nputil.matrix_root_manynull(np.eye(3))
+    with pytest.raises(CoraHipError):
+        hputil.sphtrans_inv_real(np.zeros((3, 3), dtype=complex), 2)
+
+
+def test_product_never_imports_oracle():
+    """oracle/ is test infrastructure: no module under cora_amd/ may reference it."""
+    for dp, _, files in os.walk(os.path.join(ROOT, "cora_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                txt = open(os.path.join(dp, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, re.M), os.path.join(dp, f)
+                assert "liboracle" not in txt, os.path.join(dp, f)
+
+
+# ------------------------------------------------------------------ maps / frequencies
+def test_map3d_frequencies(golden):
+    from cora_amd.core import maps
+
+    m = maps.Map3d()
+    assert np.array_equal(m.frequencies, golden["map3d_freq_default"])
+    m.nu_lower, m.nu_upper, m.nu_num = 400.0, 800.0, 32
+    assert np.array_equal(m.frequencies, golden["map3d_freq_400_800_32"])
+    assert m.nu_num == 32 and np.array_equal(m.nu_pixels, m.frequencies)
+    m.frequencies = np.array([500.0, 600.0])
+    assert m.nu_num == 2
+    c = maps.Map3d.like_map(m)
+    assert np.array_equal(c.frequencies, m.frequencies) and c.nu_lower == 400.0
+
+
+def test_nside_setter():
+    from cora_amd.core import maps
+
+    m = maps.Map2d()
+    m.nside = 64
+    assert m.nside == 64
+    with pytest.raises(Exception, match="Not a valid value of nside."):
+        m.nside = 48
+    s = maps.Sky3d()
+    with pytest.raises(Exception, match="Not implemented in base class."):
+        s.angular_powerspectrum(1, 2, 3)
+    assert s.oversample == 3 and s._lmax() == 3 * s.nside - 1
+
+
+# ------------------------------------------------------------------ hputil / nputil host parts
+def test_pack_unpack_alm(golden):
+    from cora_amd.util import hputil
+
+    assert np.array_equal(hputil.pack_alm(golden["pack_in"]), golden["pack_out"])
+    assert np.array_equal(hputil.unpack_alm(golden["pack_out"], 5), golden["unpack_out"])
+    full = hputil.unpack_alm(golden["pack_out"], 5, fullm=True)
+    assert full.shape == (6, 11)
+    assert np.array_equal(hputil.pack_alm(full), golden["pack_out"])
+    for lmax, nside in golden["nside_for_lmax"]:
+        assert hputil.nside_for_lmax(int(lmax)) == nside
+    with pytest.raises(Exception, match="a_lm array wrong shape."):
+        hputil.sphtrans_inv_real(np.zeros((3, 4), dtype=complex), 2)
+
+
+def test_complex_std_normal(golden):
+    from cora_amd.util import nputil
+
+    assert np.array_equal(nputil.complex_std_normal((3, 5), rng=np.random.default_rng(7)), golden["csn_3x5_seed7"])
+    np.random.seed(3)
+    a = nputil.complex_std_normal((2, 2))
+    np.random.seed(3)
+    re, im = np.random.standard_normal((2, 2)), np.random.standard_normal((2, 2))
+    assert np.array_equal(a, (re + 1j * im) / 2**0.5)
+
+
+def test_host_normal_stream_order():
+    """The uploaded stream is exactly the reference's per-l draw sequence."""
+    from cora_amd.core import skysim
+    from oracle import skysim as osk
+
+    F, lmax = 3, 4
+    g = skysim._host_normals(F, lmax, np.random.default_rng(11))
+    rng = np.random.default_rng(11)
+    o = 0
+    for l in range(lmax + 1):
+        v = osk.complex_std_normal((F, l + 1), rng=rng) * 2**0.5
+        n = F * (l + 1)
+        assert np.allclose(g[o : o + n], v.real.ravel(), rtol=4e-16, atol=0)  # (x/sqrt2)*sqrt2 round trip
+        assert np.allclose(g[o + n : o + 2 * n], v.imag.ravel(), rtol=4e-16, atol=0)
+        o += 2 * n
+    assert o == g.size
+
+
+def test_romberg_weights():
+    import scipy.integrate as si
+
+    from cora_amd.core import skysim
+
+    assert np.allclose(skysim.romberg_weights(3) * 2835 * 8, [868, 4096, 1408, 4096, 1744, 4096, 1408, 4096, 868])
+    assert np.allclose(skysim.romberg_weights(2) * 45 * 4, [14, 64, 24, 64, 14])
+    assert np.allclose(skysim.romberg_weights(1) * 3 * 2, [1, 4, 1])
+    assert np.array_equal(skysim.romberg_weights(0), [1.0])
+    y = np.random.default_rng(0).standard_normal(9)
+    assert np.isclose(si.romb(y, dx=0.25) / 2.0, skysim.romberg_weights(3) @ y)
+
+
+# ------------------------------------------------------------------ model classes (host part)
+def test_foreground_models_kat(golden):
+    from cora_amd.foreground import galaxy, gaussianfg, pointsource
+
+    cr = galaxy.FullSkySynchrotron()
+    aps1 = cr.angular_powerspectrum(np.arange(1000), 800.0, 800.0)
+    assert np.allclose(aps1.sum(), 75.47681191093129, rtol=1e-7)
+    fa = np.linspace(400.0, 800.0, 64)
+    aps2 = cr.angular_powerspectrum(np.arange(1000)[:, None, None], fa[None, :, None], fa[None, None, :])
+    assert np.allclose(aps2[400, 40, 40], 9.690708728692975e-06, rtol=1e-7)
+    assert np.allclose(aps2[200, 10, 40], 0.00017630767166797886, rtol=1e-7)
+    ub = pointsource.CombinedPointSources._UnresolvedBackground()
+    assert (ub.A, ub.alpha, ub.beta, ub.zeta, ub.nu_0, ub.l_0, ub.oversample) == (3.55e-5, 2.07, 1.1, 1.0, 408.0, 100.0, 0)
+    assert gaussianfg.Synchrotron.A == 7.00e-4 and galaxy.FullSkyPolarisedSynchrotron.zeta == 0.04
+    plan = cr._clarray_plan(cr.angular_powerspectrum)
+    al, bcov = plan["prepare"](np.arange(5.0), np.array([400.0, 500.0]))
+    assert al[0] == 0.0 and bcov.shape == (2, 2) and np.allclose(bcov, bcov.T)
+
+
+def test_corr21cm_host_quantities(golden):
+    from cora_amd.signal import corr21cm
+    from cora_amd.util import cosmology, cubicspline
+
+    cr = corr21cm.Corr21cm()
+    z = golden["m21_z"]
+    assert np.allclose(cr.T_b(z), golden["m21_Tb"], rtol=1e-15)
+    assert np.allclose(cr.growth_factor(z), golden["m21_D"], rtol=1e-15)
+    assert np.allclose(cr.growth_rate(z), golden["m21_f"], rtol=1e-15)
+    assert np.allclose(cr.ps_vv(golden["ps_k"]), golden["ps_vv"], rtol=1e-13)
+    assert np.allclose(cr.mean_nu(np.array([600.0])), 0.0)
+    c = cosmology.Cosmology()
+    assert np.allclose(c.comoving_distance(golden["cosmo_z"]), golden["cosmo_chi"], rtol=1e-14)
+    assert np.allclose(c.H(golden["cosmo_z"]), golden["cosmo_H"], rtol=1e-15)
+    assert np.isclose(c.comoving_distance(1.0), c.comoving_distance(np.array([1.0]))[0])
+    plan = cr._clarray_plan(cr.angular_powerspectrum)
+    assert plan["kind"] == "table21cm"
+    assert cr._clarray_plan(lambda l, a, b: 0) is None
+
+
+def test_21cm_table_build_matches_reference(golden):
+    """Host table build (P(k) spline grid + DCT-I) against slices of the reference's tables."""
+    from cora_amd.signal import corr21cm
+
+    cr = corr21cm.Corr21cm()
+    cr._build_tables()
+    ix = np.ix_(golden["tab_rows"], golden["tab_cols"])
+    for nm in ("dd", "dv", "vv"):
+        t = getattr(cr, "_aps_" + nm)
+        assert np.abs(t[ix] - golden["tab_" + nm]).max() <= 1e-13 * np.abs(golden["tab_" + nm]).max()
+
+
+# ------------------------------------------------------------------ cubic spline (mirrors tests/test_cubicspline.py)
+def test_cubicspline_usage_errors():
+    from cora_amd.util import cubicspline as cs
+
+    with pytest.raises(cs.InterpolationException):
+        cs.Interpolater(np.zeros((5, 3)))
+    with pytest.raises(cs.InterpolationException):
+        cs.Interpolater(np.zeros((3, 2)))
+    with pytest.raises(cs.InterpolationException):
+        cs.Interpolater(np.array([[0, 1.0], [1, np.nan], [2, 1], [3, 1]]))
+    with pytest.raises(cs.InterpolationException):
+        cs.LogInterpolater(np.array([[0, 1.0], [1, 2], [2, 1], [3, 1]]))
+
+
+def test_cubicspline_accuracy(golden):
+    from cora_amd.util import cubicspline as cs
+
+    x = np.linspace(0, 10, 50)
+    assert np.allclose(cs.Interpolater(x, np.full(50, 3.0))(np.linspace(-2, 12, 31)), 3.0, atol=1e-12)
+    lin = cs.Interpolater(x, 2 * x + 1)
+    assert np.allclose(lin(np.linspace(-2, 12, 31)), 2 * np.linspace(-2, 12, 31) + 1, atol=1e-10)
+    xf = np.linspace(0, 10, 2000)
+    sm = cs.Interpolater(xf, np.sin(xf))
+    xe = np.linspace(0.1, 9.9, 333)
+    assert np.abs(sm(xe) - np.sin(xe)).max() < 1e-7
+    assert np.isclose(sm(2.5), np.sin(2.5), atol=1e-7) and isinstance(sm(2.5), float)
+    sp = cs.Interpolater(golden["spl_xk"], golden["spl_yk"])
+    assert np.abs(sp(golden["spl_xe"]) - golden["spl_ye"]).max() < 1e-13
+    assert np.abs(sp.data()[1] - golden["spl_y2"]).max() < 1e-13
+    lsp = cs.LogInterpolater(np.dstack((golden["spl_xk"] + 0.5, np.exp(golden["spl_yk"])))[0])
+    assert np.abs(lsp(np.abs(golden["spl_xe"]) + 0.25) / golden["lspl_ye"] - 1).max() < 1e-12
+
+
+# ------------------------------------------------------------------ flat-sky API surface
+def test_random_field_api():
+    from cora_amd.core import gaussianfield, maps
+
+    rf = gaussianfield.RandomField(npix=[8, 8, 8], wsize=[1.0, 1.0, 2.0])
+    rf.powerspectrum = lambda k: 1.0 / (1.0 + (k**2).sum(axis=3))
+    np.random.seed(0)
+    f = rf.getfield()
+    assert f.shape == (8, 8, 8) and np.isrealobj(f) and abs(f.mean()) < 1e-12
+    m = maps.Map3d()
+    m.x_num, m.y_num, m.nu_num = 4, 6, 8
+    a2f = gaussianfield.RandomFieldA2F.like_map(m)
+    assert list(a2f._n) == [8, 4, 6]
+    a2 = gaussianfield.RandomFieldA2.like_map(m)
+    assert list(a2._n) == [4, 6]
