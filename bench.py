@@ -83,9 +83,10 @@ def main():
     L = lmax + 1
     nalm = L * (L + 1) // 2
     npix = 12 * nside * nside
-    assert F % world == 0
-    nnu = F // world
-    nu0 = rank * nnu
+    from cora_amd.parallel import allgather_factors, shard_plan
+
+    sp = shard_plan(L, F, rank, world)
+    nnu, nu0 = sp.nnu, sp.nu0
 
     ctx = _lib.get_context(local_rank)
     model = build_model(model_name)
@@ -98,10 +99,8 @@ def main():
     za = (freq[:, None] + np.linspace(-zhalf, zhalf, zint)[None, :]).ravel() if zromb else freq.copy()
     w = ctx.to_device(skysim.romberg_weights(zromb))
     plan = model._clarray_plan(model.angular_powerspectrum)
-    # l-shard of K1/K2 (contiguous, padded so all shards are equal for the all-gather)
-    Lpad = (L + world - 1) // world * world
-    lsh = Lpad // world
-    l_lo, l_hi = rank * lsh, min((rank + 1) * lsh, L)
+    # l-shard of K1/K2 (contiguous; shards are padded to equal length inside the all-gather)
+    l_lo, l_hi = sp.l_lo, sp.l_hi
     larr = np.arange(L, dtype=np.float64)
     if plan["kind"] == "table21cm":
         p = plan["prepare"](ctx, za)
@@ -122,8 +121,6 @@ def main():
     g_buf = ctx.empty((2 * F * nalm,))
     alm_buf = ctx.empty((nalm, (nnu + 3) // 4, 2, 4))
     maps_buf = ctx.empty((nnu, npix))
-    T_all = ctx.empty((Lpad, F, F))
-    info_all = torch.zeros((Lpad,), dtype=torch.int32, device=ctx.device)
     ctx.workspace(ctx.alm2map_workspace_bytes(ctx.sht_plan(nside, lmax), nnu))
     torch.cuda.synchronize()
     t_setup = time.time() - t_setup
@@ -135,11 +132,7 @@ def main():
         T, info = ctx.factor_batched(C)
         if world == 1:
             return T, info
-        T_all[l_lo:l_hi].copy_(T)
-        info_all[l_lo:l_hi].copy_(info)
-        dist.all_gather_into_tensor(T_all, T_all[rank * lsh:(rank + 1) * lsh].clone())
-        dist.all_gather_into_tensor(info_all, info_all[rank * lsh:(rank + 1) * lsh].clone())
-        return T_all[:L], info_all[:L]
+        return allgather_factors(T, info, sp)  # the single exchange step (RCCL all-gather)
 
     cached = {}
 
