@@ -25,6 +25,7 @@ class ShardPlan:
     l_pad: int     # l_shard * world >= L
     nu0: int       # this rank synthesises channels [nu0, nu0 + nnu)
     nnu: int
+    L: int = 0     # total number of multipoles (lmax + 1)
 
 
 def shard_plan(L, F, rank, world):
@@ -35,7 +36,7 @@ def shard_plan(L, F, rank, world):
     base, extra = divmod(F, world)
     nnu = base + (1 if rank < extra else 0)
     nu0 = rank * base + min(rank, extra)
-    return ShardPlan(rank, world, l_lo, l_hi, l_shard, l_shard * world, nu0, nnu)
+    return ShardPlan(rank, world, l_lo, l_hi, l_shard, l_shard * world, nu0, nnu, L)
 
 
 def allgather_factors(T_local, info_local, plan):
@@ -44,7 +45,6 @@ def allgather_factors(T_local, info_local, plan):
     import torch.distributed as dist
 
     F = T_local.shape[1]
-    L = None
     pad_T = torch.zeros((plan.l_shard, F, F), dtype=T_local.dtype, device=T_local.device)
     pad_i = torch.zeros((plan.l_shard,), dtype=info_local.dtype, device=info_local.device)
     n = plan.l_hi - plan.l_lo
@@ -54,9 +54,4 @@ def allgather_factors(T_local, info_local, plan):
     i_all = torch.empty((plan.l_pad,), dtype=info_local.dtype, device=info_local.device)
     dist.all_gather_into_tensor(T_all, pad_T)
     dist.all_gather_into_tensor(i_all, pad_i)
-    # total L = sum of shard lengths; recover it with one tiny all-reduce-free rule: the last
-    # non-empty shard ends at L
-    lens = [None] * plan.world
-    dist.all_gather_object(lens, n)
-    L = sum(lens)
-    return T_all[:L], i_all[:L]
+    return T_all[: plan.L], i_all[: plan.L]
