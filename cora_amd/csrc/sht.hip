@@ -487,15 +487,15 @@ template <int R, int SIGN>
 struct DftR;
 template <int SIGN>
 struct DftR<2, SIGN> {
-    __device__ static inline void run(double2 (&x)[2]) { dft2<SIGN>(x[0], x[1]); }
+    __device__ __forceinline__ static void run(double2 (&x)[2]) { dft2<SIGN>(x[0], x[1]); }
 };
 template <int SIGN>
 struct DftR<4, SIGN> {
-    __device__ static inline void run(double2 (&x)[4]) { dft4<SIGN>(x[0], x[1], x[2], x[3]); }
+    __device__ __forceinline__ static void run(double2 (&x)[4]) { dft4<SIGN>(x[0], x[1], x[2], x[3]); }
 };
 template <int SIGN>
 struct DftR<8, SIGN> {
-    __device__ static inline void run(double2 (&x)[8]) {
+    __device__ __forceinline__ static void run(double2 (&x)[8]) {
         // even / odd halves, then radix-2 combine with eighth roots
         dft4<SIGN>(x[0], x[2], x[4], x[6]);
         dft4<SIGN>(x[1], x[3], x[5], x[7]);
@@ -515,7 +515,7 @@ struct DftR<8, SIGN> {
 };
 template <int SIGN>
 struct DftR<16, SIGN> {
-    __device__ static inline void run(double2 (&x)[16]) {
+    __device__ __forceinline__ static void run(double2 (&x)[16]) {
         // n = 4a + c, k = k1 + 4 k2: DFT4 over a, twiddle w16^{c k1}, DFT4 over c
         const double c1 = 0.92387953251128675613, s1 = 0.38268343236508977173;  // cos, sin(pi/8)
         const double h = 0.70710678118654752440;
@@ -548,6 +548,11 @@ struct DftR<16, SIGN> {
     }
 };
 
+// LDS index padding of the FFT buffers: one spare slot per 8 elements plus 8 per 128.  Makes the
+// unit-stride last pass (lane t owns elements R t .. R t + R-1) and the stride-8/16 middle pass at
+// most 2-way bank conflicted for ds_read/write_b128 instead of 8..16-way.
+__host__ __device__ static inline int fpad(int i) { return i + (i >> 3) + ((i >> 7) << 3); }
+
 // e^{SIGN 2 pi i idx/pmax} from the half-circle table tw[k] = e^{+2 pi i k/pmax}, k < pmax/2
 template <int SIGN>
 __device__ static inline double2 tw_get(const double2 *__restrict__ tw, int pmax, int idx) {
@@ -562,7 +567,7 @@ __device__ static inline double2 tw_get(const double2 *__restrict__ tw, int pmax
 // length N, current sub-length Ls.  DIT = false: decimation in frequency (DFT then twiddle),
 // true: its transpose (twiddle then DFT).  Ends with a workgroup barrier.
 template <int R, int SIGN, bool DIT>
-__device__ static void fft_pass(double2 *buf, int bstride, int nch, int N, int Ls, const double2 *__restrict__ tw,
+__device__ __forceinline__ static void fft_pass(double2 *buf, int bstride, int nch, int N, int Ls, const double2 *__restrict__ tw,
                                 int pmax) {
     const int q = Ls / R;
     const int nb = N / R;
@@ -571,35 +576,37 @@ __device__ static void fft_pass(double2 *buf, int bstride, int nch, int N, int L
     for (int idx = threadIdx.x; idx < total; idx += blockDim.x) {
         const int ch = idx / nb, t = idx - ch * nb;
         const int b = t / q, j = t - b * q;
-        double2 *base = buf + (size_t)ch * bstride + b * Ls + j;
+        double2 *cbuf = buf + (size_t)ch * bstride;
+        const int i0 = b * Ls + j;
         double2 x[R];
 #pragma unroll
-        for (int r = 0; r < R; r++) x[r] = base[r * q];
-        // w[p] = w_Ls^{SIGN j p}
-        double2 w[R];
-        if (R > 1) {
-            w[1] = tw_get<SIGN>(tw, pmax, j * twstep);
+        for (int r = 0; r < R; r++) x[r] = cbuf[fpad(i0 + r * q)];
+        // twiddles w_Ls^{SIGN j r}: only the binary powers w, w^2, w^4, w^8 are kept in registers and
+        // x[r] is multiplied by the ones its index selects (16 VGPRs instead of a 64-VGPR power table)
+        double2 wp[4];
+        wp[0] = tw_get<SIGN>(tw, pmax, j * twstep);
 #pragma unroll
-            for (int pp = 2; pp < R; pp++) w[pp] = (pp & 1) ? cmul(w[pp - 1], w[1]) : cmul(w[pp >> 1], w[pp >> 1]);
-        }
-        if (DIT) {
+        for (int b = 1; b < 4; b++) wp[b] = cmul(wp[b - 1], wp[b - 1]);
+        auto twiddle_all = [&]() {
 #pragma unroll
-            for (int r = 1; r < R; r++) x[r] = cmul(x[r], w[r]);
-        }
+            for (int r = 1; r < R; r++) {
+#pragma unroll
+                for (int b = 0; b < 4; b++)
+                    if (r & (1 << b)) x[r] = cmul(x[r], wp[b]);
+            }
+        };
+        if (DIT) twiddle_all();
         DftR<R, SIGN>::run(x);
-        if (!DIT) {
+        if (!DIT) twiddle_all();
 #pragma unroll
-            for (int r = 1; r < R; r++) x[r] = cmul(x[r], w[r]);
-        }
-#pragma unroll
-        for (int r = 0; r < R; r++) base[r * q] = x[r];
+        for (int r = 0; r < R; r++) cbuf[fpad(i0 + r * q)] = x[r];
     }
     __syncthreads();
 }
 
 // pass schedule for N = 2^k: radix 16 while k >= 4, then the remainder
 template <int SIGN>
-__device__ static void fft_dif(double2 *buf, int bstride, int nch, int N, const double2 *__restrict__ tw, int pmax) {
+__device__ __forceinline__ static void fft_dif(double2 *buf, int bstride, int nch, int N, const double2 *__restrict__ tw, int pmax) {
     int Ls = N;
     while (Ls >= 16) {
         fft_pass<16, SIGN, false>(buf, bstride, nch, N, Ls, tw, pmax);
@@ -611,7 +618,7 @@ __device__ static void fft_dif(double2 *buf, int bstride, int nch, int N, const 
 }
 // transpose of fft_dif: digit-reversed order in -> natural order out
 template <int SIGN>
-__device__ static void fft_dit(double2 *buf, int bstride, int nch, int N, const double2 *__restrict__ tw, int pmax) {
+__device__ __forceinline__ static void fft_dit(double2 *buf, int bstride, int nch, int N, const double2 *__restrict__ tw, int pmax) {
     int rem = N;
     while (rem >= 16) rem >>= 4;  // remainder radix handled first (it was last in DIF)
     int Ls = rem;
@@ -652,27 +659,32 @@ bluestein_table_kernel(const int32_t *__restrict__ blu_P, const int64_t *__restr
     if (P == 0) return;
     const int h = 2 * i;
     double2 *b = chirp + boff[i - 1];
-    for (int j = threadIdx.x; j < P; j += blockDim.x) fbuf[j] = make_double2(0.0, 0.0);
+    for (int j = threadIdx.x; j < fpad(P); j += blockDim.x) fbuf[j] = make_double2(0.0, 0.0);
     __syncthreads();
     for (int j = threadIdx.x; j < h; j += blockDim.x) {
         const long q = ((long)j * j) % (2 * h);
         double s, c;
         sincospi((double)q / (double)h, &s, &c);
         b[j] = make_double2(c, s);
-        fbuf[j] = make_double2(c, -s);
-        if (j > 0) fbuf[P - j] = make_double2(c, -s);
+        fbuf[fpad(j)] = make_double2(c, -s);
+        if (j > 0) fbuf[fpad(P - j)] = make_double2(c, -s);
     }
     __syncthreads();
     fft_dif<-1>(fbuf, 0, 1, P, tw, pmax);
     double2 *f = filt + foff[i - 1];
-    for (int j = threadIdx.x; j < P; j += blockDim.x) f[j] = fbuf[j];
+    for (int j = threadIdx.x; j < P; j += blockDim.x) f[j] = fbuf[fpad(j)];
 }
 
-// One workgroup = (ring from `ring_list`, NCH consecutive channels), all NCH channels
-// transformed together.  P > 0: Bluestein of length P; P == 0: h = nphi/2 is a power of two.
+// Persistent workgroups: each loops over work items (ring of the class, NCH consecutive channels),
+// all NCH channels transformed together in LDS.  The F_m cells of the NEXT item are fetched into
+// registers while the current item is in its FFT passes, so HBM reads overlap the FP64 work and the
+// pixel stores of one item drain during the next.  P > 0: Bluestein of length P; P == 0: h = nphi/2
+// is a power of two.
+#define K5_MC 4  // cells per thread held in registers for the next item (the rest is read in place)
+
 template <int NCH>
 __global__ void __launch_bounds__(512)
-ringfft_kernel(const int32_t *__restrict__ ring_list, int nside, int lmax, int G, int nnu, long npix,
+ringfft_kernel(const int32_t *__restrict__ ring_list, int nlist, int nside, int lmax, int G, int nnu, long npix,
                const int32_t *__restrict__ nphi_a, const int64_t *__restrict__ start_a,
                const double *__restrict__ phi0_a, const double *__restrict__ inter, double *__restrict__ maps,
                const double2 *__restrict__ tw, int pmax, const int32_t *__restrict__ blu_P,
@@ -680,146 +692,180 @@ ringfft_kernel(const int32_t *__restrict__ ring_list, int nside, int lmax, int G
                const double2 *__restrict__ chirp, const double2 *__restrict__ filt, int bstride) {
     extern __shared__ __attribute__((aligned(16))) double2 sm[];  // [NCH][bstride]
     const int tid = threadIdx.x, nt = blockDim.x;
-    const int ring = ring_list[blockIdx.x];
-    const int ch0 = blockIdx.y * NCH;
-    if (ch0 >= nnu) return;
-    const int g = ch0 >> 2, v0 = ch0 & 3;
     const int L = lmax + 1;
-    const int n = nphi_a[ring];
-    const int h = n >> 1;
-    const long start = start_a[ring];
-    const double phi0_over_pi = phi0_a[ring] / M_PI;
-    int icap = 0;
-    if (ring + 1 < nside) icap = ring + 1;
-    else if (ring + 1 > 3 * nside) icap = 4 * nside - (ring + 1);
-    const int P = icap ? blu_P[icap - 1] : 0;
-    const int flen = P ? P : h + 1;
+    const int ngrp = (nnu + NCH - 1) / NCH;
+    const int nitems = nlist * ngrp;
     double *smd = reinterpret_cast<double *>(sm);
 
-    for (int j = tid; j < flen; j += nt)
-#pragma unroll
-        for (int c = 0; c < NCH; c++) sm[(size_t)c * bstride + j] = make_double2(0.0, 0.0);
-    __syncthreads();
-
-    // ---- phase + alias fold onto bins 0..h of the Hermitian length-n spectrum X
-    const double *cell = inter + ((size_t)ring * G + g) * L * 8 + v0;
-    const bool noalias = lmax <= h;
-    for (int m = tid; m < L; m += nt) {
+    // register prefetch of the cells m = tid + k nt, k < K5_MC, of one item
+    struct cell_t {
         double re[NCH], im[NCH];
+    };
+    cell_t pf0, pf1, pf2, pf3;
+    auto cell_ptr = [&](int item) {
+        const int ring = ring_list[item / ngrp];
+        const int ch0 = (item % ngrp) * NCH;
+        return inter + ((size_t)ring * G + (ch0 >> 2)) * L * 8 + (ch0 & 3);
+    };
+    auto load_cell = [&](const double *cell, int m) {
+        cell_t c;
         if (NCH == 4) {
             const double4 a = *reinterpret_cast<const double4 *>(cell + (size_t)m * 8);
             const double4 b = *reinterpret_cast<const double4 *>(cell + (size_t)m * 8 + 4);
-            re[0] = a.x; re[1 % NCH] = a.y; re[2 % NCH] = a.z; re[3 % NCH] = a.w;
-            im[0] = b.x; im[1 % NCH] = b.y; im[2 % NCH] = b.z; im[3 % NCH] = b.w;
+            c.re[0] = a.x; c.re[1 % NCH] = a.y; c.re[2 % NCH] = a.z; c.re[3 % NCH] = a.w;
+            c.im[0] = b.x; c.im[1 % NCH] = b.y; c.im[2 % NCH] = b.z; c.im[3 % NCH] = b.w;
         } else if (NCH == 2) {
             const double2 a = *reinterpret_cast<const double2 *>(cell + (size_t)m * 8);
             const double2 b = *reinterpret_cast<const double2 *>(cell + (size_t)m * 8 + 4);
-            re[0] = a.x; re[1 % NCH] = a.y;
-            im[0] = b.x; im[1 % NCH] = b.y;
+            c.re[0] = a.x; c.re[1 % NCH] = a.y;
+            c.im[0] = b.x; c.im[1 % NCH] = b.y;
         } else {
-            re[0] = cell[(size_t)m * 8];
-            im[0] = cell[(size_t)m * 8 + 4];
+            c.re[0] = cell[(size_t)m * 8];
+            c.im[0] = cell[(size_t)m * 8 + 4];
         }
-        double s, cph;
-        sincospi(fmod((double)m * phi0_over_pi, 2.0), &s, &cph);
-        const double2 ph = make_double2(cph, s);
-        const int k = m % n;
-        const int kc = (n - k) % n;
-#pragma unroll
-        for (int c = 0; c < NCH; c++) {
-            const double2 val = cmul(make_double2(re[c], im[c]), ph);
-            double *bd = smd + (size_t)c * bstride * 2;
-            if (m == 0) {
-                if (noalias) bd[0] = val.x;  // Re(c_0) only; no other m reaches bin 0
-                else atomicAdd(&bd[0], val.x);
-            } else if (noalias) {
-                if (m < h) *reinterpret_cast<double2 *>(bd + 2 * m) = val;
-                else bd[2 * h] = 2.0 * val.x;  // m == h: c + conj(c)
-            } else {
-                if (k <= h) {
-                    atomicAdd(&bd[2 * k], val.x);
-                    atomicAdd(&bd[2 * k + 1], val.y);
-                }
-                if (kc <= h) {
-                    atomicAdd(&bd[2 * kc], val.x);
-                    atomicAdd(&bd[2 * kc + 1], -val.y);
-                }
-            }
-        }
-    }
-    __syncthreads();
-    // ---- Hermitian -> half-length complex: Z_k = (X_k + conj X_{h-k}) + i w^k (X_k - conj X_{h-k}),
-    //      w = e^{2 pi i/n}; pairs (k, h-k) updated together.  Bluestein: times chirp b_k.
-    const double2 *bch = P ? chirp + boff[icap - 1] : nullptr;
-    const bool n_in_table = (pmax % n) == 0;
-    for (int k = tid; k <= h / 2; k += nt) {
-        const int k2 = h - k;
-        double2 w;
-        if (n_in_table) w = tw_get<1>(tw, pmax, k * (pmax / n));
-        else {
-            double s, c;
-            sincospi(2.0 * (double)k / (double)n, &s, &c);
-            w = make_double2(c, s);
-        }
-        double2 bk = make_double2(1.0, 0.0), bk2 = make_double2(1.0, 0.0);
-        if (P) {
-            if (k < h) bk = bch[k];
-            if (k2 < h) bk2 = bch[k2];
-        }
-#pragma unroll
-        for (int c = 0; c < NCH; c++) {
-            double2 *bc = sm + (size_t)c * bstride;
-            const double2 xa = bc[k], xb = bc[k2];
-            double2 sum = make_double2(xa.x + xb.x, xa.y - xb.y);
-            double2 dif = make_double2(xa.x - xb.x, xa.y + xb.y);
-            double2 t = cmul(dif, w);
-            double2 zk = make_double2(sum.x - t.y, sum.y + t.x);
-            sum = make_double2(xb.x + xa.x, xb.y - xa.y);
-            dif = make_double2(xb.x - xa.x, xb.y + xa.y);
-            t = cmul(dif, make_double2(-w.x, w.y));  // w^{h-k} = -conj(w^k)
-            double2 zk2 = make_double2(sum.x - t.y, sum.y + t.x);
-            if (P) {
-                zk = cmul(zk, bk);
-                zk2 = cmul(zk2, bk2);
-            }
-            if (k2 < h) bc[k2] = zk2;
-            else if (P) bc[k2] = make_double2(0.0, 0.0);  // slot h is padding for the length-P transform
-            if (k < h) bc[k] = zk;
-        }
-    }
-    __syncthreads();
+        return c;
+    };
+    auto prefetch = [&](int item) {
+        const double *cell = cell_ptr(item);
+        if (tid < L) pf0 = load_cell(cell, tid);
+        if (tid + nt < L) pf1 = load_cell(cell, tid + nt);
+        if (tid + 2 * nt < L) pf2 = load_cell(cell, tid + 2 * nt);
+        if (tid + 3 * nt < L) pf3 = load_cell(cell, tid + 3 * nt);
+    };
 
-    if (P == 0) {
-        fft_dif<1>(sm, bstride, NCH, h, tw, pmax);
-        for (int j = tid; j < h; j += nt) {
-            const int pos = fft_dif_pos(j, h);
+    int item = blockIdx.x;
+    if (item < nitems) prefetch(item);
+    for (; item < nitems; item += gridDim.x) {
+        const int ring = ring_list[item / ngrp];
+        const int ch0 = (item % ngrp) * NCH;
+        const int n = nphi_a[ring];
+        const int h = n >> 1;
+        const long start = start_a[ring];
+        const double phi0_over_pi = phi0_a[ring] / M_PI;
+        int icap = 0;
+        if (ring + 1 < nside) icap = ring + 1;
+        else if (ring + 1 > 3 * nside) icap = 4 * nside - (ring + 1);
+        const int P = icap ? blu_P[icap - 1] : 0;
+        const int flen = P ? P : h + 1;
+
+        __syncthreads();  // previous item's LDS reads are done
+        for (int j = tid; j < fpad(flen); j += nt)
+#pragma unroll
+            for (int c = 0; c < NCH; c++) sm[(size_t)c * bstride + j] = make_double2(0.0, 0.0);
+        __syncthreads();
+
+        // ---- phase + alias fold onto bins 0..h of the Hermitian length-n spectrum X
+        const double *cell = cell_ptr(item);
+        const bool noalias = lmax <= h;
+        auto fold_one = [&](int m, const cell_t cv) {
+            double s, cph;
+            sincospi(fmod((double)m * phi0_over_pi, 2.0), &s, &cph);
+            const double2 ph = make_double2(cph, s);
+            const int k = m % n;
+            const int kc = (n - k) % n;
 #pragma unroll
             for (int c = 0; c < NCH; c++) {
-                if (ch0 + c < nnu)
-                    *reinterpret_cast<double2 *>(maps + (size_t)(ch0 + c) * npix + start + 2 * j) =
-                        sm[(size_t)c * bstride + pos];
+                const double2 val = cmul(make_double2(cv.re[c], cv.im[c]), ph);
+                double *bd = smd + (size_t)c * bstride * 2;
+                if (m == 0) {
+                    if (noalias) bd[0] = val.x;  // Re(c_0) only; no other m reaches bin 0
+                    else atomicAdd(&bd[0], val.x);
+                } else if (noalias) {
+                    if (m < h) *reinterpret_cast<double2 *>(bd + 2 * fpad(m)) = val;
+                    else bd[2 * fpad(h)] = 2.0 * val.x;  // m == h: c + conj(c)
+                } else {
+                    if (k <= h) {
+                        atomicAdd(&bd[2 * fpad(k)], val.x);
+                        atomicAdd(&bd[2 * fpad(k) + 1], val.y);
+                    }
+                    if (kc <= h) {
+                        atomicAdd(&bd[2 * fpad(kc)], val.x);
+                        atomicAdd(&bd[2 * fpad(kc) + 1], -val.y);
+                    }
+                }
             }
-        }
-    } else {
-        const double2 *f = filt + foff[icap - 1];
-        fft_dif<-1>(sm, bstride, NCH, P, tw, pmax);
-        for (int j = tid; j < P; j += nt) {
-            const double2 fj = f[j];
+        };
+        if (tid < L) fold_one(tid, pf0);
+        if (tid + nt < L) fold_one(tid + nt, pf1);
+        if (tid + 2 * nt < L) fold_one(tid + 2 * nt, pf2);
+        if (tid + 3 * nt < L) fold_one(tid + 3 * nt, pf3);
+        for (int m = tid + K5_MC * nt; m < L; m += nt) fold_one(m, load_cell(cell, m));
+        // the registers are free again: fetch the next item's cells behind the FFT passes
+        if (item + (int)gridDim.x < nitems) prefetch(item + gridDim.x);
+        __syncthreads();
+        // ---- Hermitian -> half-length complex: Z_k = (X_k + conj X_{h-k}) + i w^k (X_k - conj X_{h-k}),
+        //      w = e^{2 pi i/n}; pairs (k, h-k) updated together.  Bluestein: times chirp b_k.
+        const double2 *bch = P ? chirp + boff[icap - 1] : nullptr;
+        const bool n_in_table = (pmax % n) == 0;
+        for (int k = tid; k <= h / 2; k += nt) {
+            const int k2 = h - k;
+            double2 w;
+            if (n_in_table) w = tw_get<1>(tw, pmax, k * (pmax / n));
+            else {
+                double s, c;
+                sincospi(2.0 * (double)k / (double)n, &s, &c);
+                w = make_double2(c, s);
+            }
+            double2 bk = make_double2(1.0, 0.0), bk2 = make_double2(1.0, 0.0);
+            if (P) {
+                if (k < h) bk = bch[k];
+                if (k2 < h) bk2 = bch[k2];
+            }
 #pragma unroll
-            for (int c = 0; c < NCH; c++) sm[(size_t)c * bstride + j] = cmul(sm[(size_t)c * bstride + j], fj);
+            for (int c = 0; c < NCH; c++) {
+                double2 *bc = sm + (size_t)c * bstride;
+                const double2 xa = bc[fpad(k)], xb = bc[fpad(k2)];
+                double2 sum = make_double2(xa.x + xb.x, xa.y - xb.y);
+                double2 dif = make_double2(xa.x - xb.x, xa.y + xb.y);
+                double2 t = cmul(dif, w);
+                double2 zk = make_double2(sum.x - t.y, sum.y + t.x);
+                sum = make_double2(xb.x + xa.x, xb.y - xa.y);
+                dif = make_double2(xb.x - xa.x, xb.y + xa.y);
+                t = cmul(dif, make_double2(-w.x, w.y));  // w^{h-k} = -conj(w^k)
+                double2 zk2 = make_double2(sum.x - t.y, sum.y + t.x);
+                if (P) {
+                    zk = cmul(zk, bk);
+                    zk2 = cmul(zk2, bk2);
+                }
+                if (k2 < h) bc[fpad(k2)] = zk2;
+                else if (P) bc[fpad(k2)] = make_double2(0.0, 0.0);  // slot h is padding for the length-P transform
+                if (k < h) bc[fpad(k)] = zk;
+            }
         }
         __syncthreads();
-        fft_dit<1>(sm, bstride, NCH, P, tw, pmax);
-        const double invP = 1.0 / (double)P;
-        for (int j = tid; j < h; j += nt) {
-            const double2 bj = bch[j];
+
+        if (P == 0) {
+            fft_dif<1>(sm, bstride, NCH, h, tw, pmax);
+            for (int j = tid; j < h; j += nt) {
+                const int pos = fpad(fft_dif_pos(j, h));
 #pragma unroll
-            for (int c = 0; c < NCH; c++) {
-                if (ch0 + c < nnu) {
-                    double2 zv = cmul(sm[(size_t)c * bstride + j], bj);
-                    zv.x *= invP;
-                    zv.y *= invP;
-                    *reinterpret_cast<double2 *>(maps + (size_t)(ch0 + c) * npix + start + 2 * j) = zv;
+                for (int c = 0; c < NCH; c++) {
+                    if (ch0 + c < nnu)
+                        *reinterpret_cast<double2 *>(maps + (size_t)(ch0 + c) * npix + start + 2 * j) =
+                            sm[(size_t)c * bstride + pos];
+                }
+            }
+        } else {
+            const double2 *f = filt + foff[icap - 1];
+            fft_dif<-1>(sm, bstride, NCH, P, tw, pmax);
+            for (int j = tid; j < P; j += nt) {
+                const double2 fj = f[j];
+#pragma unroll
+                for (int c = 0; c < NCH; c++) sm[(size_t)c * bstride + fpad(j)] = cmul(sm[(size_t)c * bstride + fpad(j)], fj);
+            }
+            __syncthreads();
+            fft_dit<1>(sm, bstride, NCH, P, tw, pmax);
+            const double invP = 1.0 / (double)P;
+            for (int j = tid; j < h; j += nt) {
+                const double2 bj = bch[j];
+#pragma unroll
+                for (int c = 0; c < NCH; c++) {
+                    if (ch0 + c < nnu) {
+                        double2 zv = cmul(sm[(size_t)c * bstride + fpad(j)], bj);
+                        zv.x *= invP;
+                        zv.y *= invP;
+                        *reinterpret_cast<double2 *>(maps + (size_t)(ch0 + c) * npix + start + 2 * j) = zv;
+                    }
                 }
             }
         }
@@ -1005,7 +1051,7 @@ int corahip_sht_plan_create(corahip_ctx *ctx, int nside, int lmax, corahip_sht_p
         HIP_TRY(hipMalloc((void **)&p->d_bchirp, sizeof(double2) * std::max<int64_t>(1, nb)));
         HIP_TRY(hipMalloc((void **)&p->d_bfilt, sizeof(double2) * std::max<int64_t>(1, nf)));
         if (nside > 1) {
-            const size_t shm = sizeof(double2) * (size_t)maxlen;
+            const size_t shm = sizeof(double2) * (size_t)(fpad(maxlen) + 1);
             HIP_TRY(hipFuncSetAttribute((const void *)bluestein_table_kernel,
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
             bluestein_table_kernel<<<nside - 1, 256, shm, s>>>(p->d_blu_P, p->d_blu_boff, p->d_blu_foff,
@@ -1031,14 +1077,15 @@ int corahip_sht_plan_create(corahip_ctx *ctx, int nside, int lmax, corahip_sht_p
             }
             by_len[P].push_back(r);
         }
-        const size_t lds_budget = 160 * 1024;
+        size_t lds_budget = 160 * 1024;
+        if (getenv("CORAHIP_K5_LDS_KB")) lds_budget = (size_t)atoi(getenv("CORAHIP_K5_LDS_KB")) * 1024;
         for (auto &kv : by_len) {
             corahip_sht_plan::ring_class c;
             c.P = kv.first;
-            c.bstride = c.P ? c.P : 2 * nside + 1;
+            c.bstride = fpad(c.P ? c.P : 2 * nside + 1) + 1;
             c.nch = 4;
             while (c.nch > 1 && (size_t)c.nch * c.bstride * sizeof(double2) > lds_budget) c.nch >>= 1;
-            if ((size_t)c.nch * c.bstride * sizeof(double2) > lds_budget) {
+            if ((size_t)c.nch * c.bstride * sizeof(double2) > 160 * 1024) {
                 corahip_set_error("nside %d: ring FFT of length %d does not fit in LDS", nside, c.bstride);
                 return CORAHIP_ENOMEM;
             }
@@ -1129,13 +1176,16 @@ static int alm2map_chunk(corahip_ctx *ctx, const corahip_sht_plan *p, const doub
     {
         StageTimer t(ctx, "ringfft");
         const int G = nnu_chunk_pad / 4;
+        const int k5_threads = getenv("CORAHIP_K5_THREADS") ? atoi(getenv("CORAHIP_K5_THREADS")) : 512;
         for (const auto &c : p->classes) {
             const size_t shm = sizeof(double2) * (size_t)c.nch * c.bstride;
-            dim3 grid(c.count, (nnu_valid + c.nch - 1) / c.nch);
+            const long nitems = (long)c.count * ((nnu_valid + c.nch - 1) / c.nch);
+            const int per_cu = std::max<int>(1, (int)((160 * 1024) / std::max<size_t>(shm, 1)));
+            dim3 grid((unsigned)std::min<long>(nitems, (long)ctx->num_cu * std::min(per_cu, 4)));
 #define RINGFFT_LAUNCH(NCH)                                                                                     \
     HIP_TRY(hipFuncSetAttribute((const void *)ringfft_kernel<NCH>, hipFuncAttributeMaxDynamicSharedMemorySize,  \
                                 160 * 1024));                                                                   \
-    ringfft_kernel<NCH><<<grid, 512, shm, ctx->stream>>>(c.d_list, p->nside, p->lmax, G, nnu_valid, p->npix,     \
+    ringfft_kernel<NCH><<<grid, k5_threads, shm, ctx->stream>>>(c.d_list, c.count, p->nside, p->lmax, G, nnu_valid, p->npix,     \
                                                          p->d_nphi, p->d_start, p->d_phi0, inter, maps, p->d_tw, \
                                                          p->pmax, p->d_blu_P, p->d_blu_boff, p->d_blu_foff,      \
                                                          p->d_bchirp, p->d_bfilt, c.bstride)
