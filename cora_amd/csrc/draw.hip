@@ -69,8 +69,8 @@ __global__ void __launch_bounds__(256)
 draw_kernel(const double *__restrict__ T, const int32_t *__restrict__ info, const double *__restrict__ g, int lmax,
             int F, int nu0, int nnu, int Gout, double *__restrict__ alm) {
     constexpr int NC = 16 * NCT;
-    constexpr int STRIDE = NC + 16;  // doubles; rows k, k+1 differ by 128 B mod 256
-    extern __shared__ __attribute__((aligned(16))) double lds[];  // [DRAW_KC][STRIDE]
+    constexpr int STRIDE = DRAW_KC + 2;  // doubles per channel row: 272 B, so 16 consecutive rows hit 16 distinct 16-B slots
+    extern __shared__ __attribute__((aligned(16))) double lds[];  // Bs[n][k] = T_l[nu0+col0+n][k0+k], [NC][STRIDE]
 
     const int l = blockIdx.x;
     const int nrow = 2 * (l + 1);
@@ -101,7 +101,8 @@ draw_kernel(const double *__restrict__ T, const int32_t *__restrict__ info, cons
     const int kmax = dense ? F : min(F, nu0 + col0 + NC);
     for (int k0 = 0; k0 < kmax; k0 += DRAW_KC) {
         __syncthreads();
-        // stage Bs[k][n] = T_l[nu0+col0+n][k0+k]: item (n, 16-byte piece q of the 256-byte k-run)
+        // stage the 256-byte k-run of every channel row: 16 lanes x 16 B per row, coalesced in HBM/L2
+        // and conflict-free in LDS (row stride 272 B)
         for (int it = tid; it < NC * (DRAW_KC / 2); it += 256) {
             const int n = it / (DRAW_KC / 2), q = it % (DRAW_KC / 2);
             const int nu = nu0 + col0 + n;
@@ -111,8 +112,7 @@ draw_kernel(const double *__restrict__ T, const int32_t *__restrict__ info, cons
                 if (k + 1 < F) v = *reinterpret_cast<const double2 *>(Tl + (size_t)nu * F + k);
                 else if (k < F) v.x = Tl[(size_t)nu * F + k];
             }
-            lds[(2 * q) * STRIDE + n] = v.x;
-            lds[(2 * q + 1) * STRIDE + n] = v.y;
+            *reinterpret_cast<double2 *>(lds + n * STRIDE + 2 * q) = v;
         }
         __syncthreads();
 #pragma unroll
@@ -122,12 +122,12 @@ draw_kernel(const double *__restrict__ T, const int32_t *__restrict__ info, cons
             const int kp = kbase + kq;
             double a = 0.0;
             if (row_ok && kp < F) a = grow[(size_t)kp * lp1];
-            const double *bs = lds + (4 * kk + kq) * STRIDE + ri;
+            const double *bs = lds + ri * STRIDE + 4 * kk + kq;
 #pragma unroll
             for (int t = 0; t < NCT; t++) {
                 // triangular skip: tile t holds channels nu0+col0+16t .. +15
                 if (!dense && kbase > nu0 + col0 + 16 * t + 15) continue;
-                acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bs[16 * t], acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bs[16 * t * STRIDE], acc[t], 0, 0, 0);
             }
         }
     }
@@ -196,7 +196,7 @@ template <int NCT>
 static int launch_draw(corahip_ctx *ctx, const double *T, const int32_t *info, const double *g, int lmax, int F,
                        int nu0, int nnu, int Gout, double *alm) {
     constexpr int NC = 16 * NCT;
-    const size_t shm = sizeof(double) * DRAW_KC * (NC + 16);
+    const size_t shm = sizeof(double) * NC * (DRAW_KC + 2);
     HIP_TRY(hipFuncSetAttribute((const void *)draw_kernel<NCT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
     dim3 grid(lmax + 1, (2 * (lmax + 1) + DRAW_ROWS - 1) / DRAW_ROWS, (4 * Gout + NC - 1) / NC);
     draw_kernel<NCT><<<grid, 256, shm, ctx->stream>>>(T, info, g, lmax, F, nu0, nnu, Gout, alm);

@@ -36,7 +36,7 @@ struct corahip_sht_plan {
     double2 *d_coef = nullptr;                            // [nalm]: (A_l, B_l) at alm_idx(l,m)
     int32_t *d_lstart = nullptr;                          // [L][npair]
     double2 *d_seed = nullptr;                            // [L][npair]: (lambda_{lstart-1}, lambda_{lstart})
-    unsigned long long *d_stamps = nullptr;               // diagnostic builds only (LEG_ABLATE == 9)
+    int32_t *d_lmin = nullptr;                            // [L][ntile] first l per (m, ring tile)
     double *d_zeros = nullptr;                            // 4 KiB of zeros (source of padding rows for LDS-DMA)
     double2 *d_tw = nullptr;                              // e^{+2 pi i k/pmax}, k < pmax/2
     int pmax = 0, log_pmax = 0;
@@ -199,258 +199,241 @@ template <int NT>
 __global__ void __launch_bounds__(512)
 legendre_kernel(int lmax, int npair, int nring, int ncols, const double *__restrict__ z,
                 const double2 *__restrict__ coef, const int32_t *__restrict__ lstart,
-                const double2 *__restrict__ seed, const double *__restrict__ alm,
-                const double *__restrict__ zeros, double *__restrict__ inter, unsigned long long *stamps) {
+                const double2 *__restrict__ seed, const int32_t *__restrict__ lmin_tab,
+                const double *__restrict__ alm, const double *__restrict__ zeros, double *__restrict__ inter) {
     constexpr int TCOLS = 16 * NT;          // columns of this block
     constexpr int STRIDE = TCOLS + 8;       // LDS row stride (doubles): 2 rows apart = 128 B mod 256
     constexpr int CROWS = LEG_KT + 8;       // coefficient rows per stage (staggered lanes look 6 ahead)
     constexpr int STAGE = LEG_KT * STRIDE + 2 * CROWS;  // doubles per stage: a_lm rows + (A,B) pairs
-    constexpr int PIECES = LEG_KT / LEG_WAVES + 1;      // LDS-DMA pieces per wave per stage
+    constexpr int RPW = LEG_KT / LEG_WAVES;             // a_lm rows each wave moves per stage
+    constexpr int PIECES = RPW + 1;                     // LDS-DMA pieces per wave per stage (+ coefficients)
+    static_assert(RPW == LEG_KT / 8, "one a_lm piece per macro-step");
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    int &s_lmin = *reinterpret_cast<int *>(lds + LEG_NBUF * STAGE);  // carved after the stage ring (G17)
 
-#if LEG_ABLATE == 9
-#define STAMP(var) { unsigned long long _t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)::"memory"); var = _t; }
-    unsigned long long T0, Ta, Tb, t_pro = 0, t_wait = 0, t_issue = 0, t_rec = 0, t_mfma = 0, t_epi = 0;
-    STAMP(T0);
-#else
-#define STAMP(var)
-#endif
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
     const int ri = lane & 15, kq = lane >> 4;
-    // work mapping: consecutive workgroups = the ring tiles of one (m, column-group) a_lm slice; the
-    // dispatcher deals them round-robin over the 8 XCDs.  (Packing a whole slice group onto ONE XCD
-    // was measured 24 % slower: all resident workgroups of the XCD then hammer the same 1-2 L2
-    // channels in lock step.)  Small m (long K loops) first.
-    const int ntile = (npair + LEG_RINGS - 1) / LEG_RINGS;
-    const int ncg = ncols / TCOLS;
-    const int bid = blockIdx.x;
-    const int gidx = bid / ntile;
-    const int rtile = bid - gidx * ntile;
-    if (gidx >= (lmax + 1) * ncg) return;
-    const int m = gidx / ncg;
-    const int cg = gidx % ncg;
+    const int d = 2 * kq;
     const int L = lmax + 1;
     const int G = ncols >> 3;
-    // rings are dealt to the waves interleaved (ring = tile base + 8 ri + wave) so that every wave of
-    // the workgroup has the same mix of first-contributing l and reaches the stage barriers together
-    const int ring = rtile * LEG_RINGS + ri * LEG_WAVES + wave;
-    const bool ring_ok = ring < npair;
+    const int ntile = (npair + LEG_RINGS - 1) / LEG_RINGS;
+    const int ncg = ncols / TCOLS;
+    const int nitems = L * ncg * ntile;
+    const long last_row = nalm_of(lmax) - 1;
+    const unsigned lds_base_bytes = (unsigned)(size_t)(__attribute__((address_space(3))) double *)lds;
+    const bool odd_lane = lane & 1;
 
-    double x = 0.0;
-    int my_ls = lmax + 1;
-    double2 sd = make_double2(0.0, 0.0);
-    if (ring_ok) {
-        x = z[ring];
-        long o = (long)m * npair + ring;
-        my_ls = lstart[o];
-        sd = seed[o];
-    }
-    if (tid == 0) s_lmin = lmax + 1;
-    __syncthreads();
-    atomicMin(&s_lmin, my_ls);
-    __syncthreads();
-    const int lmin = __builtin_amdgcn_readfirstlane(s_lmin);
-
-    d4_t acce[NT], acco[NT];
+    // Persistent workgroups.  Work item = (m, column group, ring tile); consecutive items are the ring
+    // tiles of one a_lm slice, so the workgroups running at the same time share slices in L2 (they are
+    // dealt over all 8 XCDs; packing a slice group onto ONE XCD was measured 24 % slower: every resident
+    // workgroup of the XCD then hits the same 1-2 L2 channels in lock step).  Small m (long K) first.
+    struct item_t {
+        int m, cg, rtile, l_begin, nstage;
+        long base_m;
+    };
+    auto decode = [&](int it) {
+        item_t w;
+        const int gidx = it / ntile;
+        w.rtile = it - gidx * ntile;
+        w.m = gidx / ncg;
+        w.cg = gidx - w.m * ncg;
+        const int lmin = lmin_tab[w.m * ntile + w.rtile];
+        w.l_begin = w.m + ((lmin - w.m) & ~7);
+        w.nstage = lmin <= lmax ? (lmax - w.l_begin) / LEG_KT + 1 : 0;
+        w.base_m = alm_idx(0, w.m, lmax);
+        return w;
+    };
+    // LDS-DMA pieces: every wave issues exactly PIECES per stage (counted vmcnt): RPW a_lm rows (rows past
+    // lmax are never used - their lambda is 0 - so any valid row is read, keeping the address scalar) and
+    // the CROWS coefficient pairs (all waves write the same bytes).
+    auto issue_row = [&](const item_t &w, int st, int rr) {
+        const int row = wv + LEG_WAVES * rr;
+        long rowidx = w.base_m + w.l_begin + st * LEG_KT + row;
+        rowidx = rowidx < last_row ? rowidx : last_row;
+        const double *src = alm + (size_t)w.cg * TCOLS + (size_t)rowidx * ncols + 2 * lane;
+        const unsigned dst = lds_base_bytes + (unsigned)(((st % LEG_NBUF) * STAGE + row * STRIDE) * sizeof(double));
+        if (lane < 8 * NT) glds16(src, dst);
+    };
+    auto issue_coef = [&](const item_t &w, int st) {
+        const int l = w.l_begin + st * LEG_KT + lane;
+        const double *src = (l <= lmax) ? reinterpret_cast<const double *>(coef + w.base_m + l) : zeros;
+        const unsigned dst = lds_base_bytes + (unsigned)(((st % LEG_NBUF) * STAGE + LEG_KT * STRIDE) * sizeof(double));
+        if (lane < CROWS) glds16(src, dst);
+    };
+    auto issue_stage = [&](const item_t &w, int st) {
+        issue_coef(w, st);
 #pragma unroll
-    for (int t = 0; t < NT; t++) {
-        acce[t] = (d4_t){0.0, 0.0, 0.0, 0.0};
-        acco[t] = (d4_t){0.0, 0.0, 0.0, 0.0};
-    }
+        for (int rr = 0; rr < RPW; rr++) issue_row(w, st, rr);
+    };
 
-    if (lmin <= lmax) {
-        const int l_begin = m + ((lmin - m) & ~7);
-        const int nstage = (lmax - l_begin) / LEG_KT + 1;
-        const long base_m = alm_idx(0, m, lmax);
-        const double2 *cf = coef + base_m;
-        const double *arow = alm + (size_t)cg * TCOLS;
-        const int d = 2 * kq;
-        const unsigned lds_base_bytes = (unsigned)(size_t)(__attribute__((address_space(3))) double *)lds;
-
-        // ---- stage loader: every wave issues exactly PIECES LDS-DMA pieces per stage (counted waits):
-        //      LEG_KT/LEG_WAVES a_lm rows (zero rows past lmax) + the CROWS coefficient pairs (all waves
-        //      write the same bytes; keeps the per-wave piece count uniform)
-        const int wv = __builtin_amdgcn_readfirstlane(wave);
-        const long last_row = nalm_of(lmax) - 1;
-        auto stage_issue = [&](int st) {
-            const int ls = l_begin + st * LEG_KT;
-            const unsigned sbase = lds_base_bytes + (unsigned)((st % LEG_NBUF) * STAGE * sizeof(double));
+    int item = blockIdx.x;
+    if (item >= nitems) return;
+    item_t w = decode(item);
 #pragma unroll
-            for (int rr = 0; rr < LEG_KT / LEG_WAVES; rr++) {
-                // rows past lmax are never used (their lambda is 0): read any valid row instead of zeros,
-                // which keeps the source address wave-uniform scalar arithmetic
-                const int row = wv + LEG_WAVES * rr;
-                long rowidx = base_m + ls + row;
-                rowidx = rowidx < last_row ? rowidx : last_row;
-                const double *src = arow + (size_t)rowidx * ncols + 2 * lane;
-                if (lane < 8 * NT) glds16(src, sbase + (unsigned)(row * STRIDE * sizeof(double)));
-            }
-            {
-                const int l = ls + lane;
-                const double *src = (l <= lmax) ? reinterpret_cast<const double *>(cf + l) : zeros;
-                if (lane < CROWS) glds16(src, sbase + (unsigned)(LEG_KT * STRIDE * sizeof(double)));
-            }
-        };
+    for (int st = 0; st < LEG_NBUF - 1; st++)
+        if (st < w.nstage) issue_stage(w, st);
 
+    for (;;) {
+        const int m = w.m;
+        // rings are dealt to the waves interleaved (ring = tile base + 8 ri + wave) so that every wave of
+        // the workgroup has the same mix of first-contributing l and reaches the stage barriers together
+        const int ring = w.rtile * LEG_RINGS + ri * LEG_WAVES + wave;
+        d4_t acce[NT], acco[NT];
 #pragma unroll
-        for (int st = 0; st < LEG_NBUF - 1; st++)
-            if (st < nstage) stage_issue(st);
-
-        // ---- per-lane start state: (lambda_{lf-2}, lambda_{lf-1}) with lf = l_begin + d the first l of
-        //      this lane.  If the ring's first contributing l lies before lf, advance from the seeds.
-        double p0 = 0.0, p1 = 0.0;
-        int inj_l = my_ls;  // l at which the seeds are injected
-        {
-            const int lf = l_begin + d;
-            if (my_ls < lf) {
-                p0 = sd.x;
-                p1 = sd.y;
-                for (int l = my_ls + 1; l < lf; l++) {
-                    const double2 c = (l <= lmax) ? cf[l] : make_double2(0.0, 0.0);
-                    const double vv = fma(c.x * x, p1, -(c.y * p0));
-                    p0 = p1;
-                    p1 = vv;
-                }
-                inj_l = 0x7fffffff;
-            }
+        for (int t = 0; t < NT; t++) {
+            acce[t] = (d4_t){0.0, 0.0, 0.0, 0.0};
+            acco[t] = (d4_t){0.0, 0.0, 0.0, 0.0};
         }
-
-#if LEG_ABLATE == 9
-        STAMP(Ta); t_pro = Ta - T0;
-#endif
-        for (int st = 0; st < nstage; st++) {
-            STAMP(Ta);
-            // own pieces of stage st have landed when at most the pieces of the (up to LEG_NBUF-2)
-            // younger stages are still in flight
-            if (st + 2 < nstage) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PIECES) : "memory");
-            else if (st + 1 < nstage) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();  // everyone's pieces of stage st landed; everyone is done reading stage st-1
-#if LEG_ABLATE == 9
-            STAMP(Tb); t_wait += Tb - Ta;
-#endif
-            if (st + LEG_NBUF - 1 < nstage) stage_issue(st + LEG_NBUF - 1);
-#if LEG_ABLATE == 9
-            STAMP(Ta); t_issue += Ta - Tb;
-#endif
-            const int ls = l_begin + st * LEG_KT;
-            const double *sb = lds + (st % LEG_NBUF) * STAGE;
-            const double2 *sc = reinterpret_cast<const double2 *>(sb + LEG_KT * STRIDE) + d;
-#pragma unroll 1
-            for (int ms = 0; ms < LEG_KT / 8; ms++) {
-                const int l0 = ls + 8 * ms;
-                if (l0 > lmax) break;
-                // nothing of this wave starts before l0+14: skip the macro-step entirely
-                if (__all(my_ls > l0 + 13)) continue;
-                STAMP(Ta);
-#if LEG_ABLATE == 2  // diagnostic: no recurrence
-                double ae = x, ao = x + 1.0;
-                asm volatile("" : "+v"(ae), "+v"(ao));
-#else
-                double2 c[8];
-#pragma unroll
-                for (int j = 0; j < 8; j++) c[j] = sc[8 * ms + j];
-                double ae, ao;
-                const int lf = l0 + d;
-                if (__any(inj_l >= lf && inj_l < lf + 8)) {
-#pragma unroll
-                    for (int j = 0; j < 8; j++) {
-                        double vv = fma(c[j].x * x, p1, -(c[j].y * p0));
-                        const bool inj = (lf + j == inj_l);
-                        vv = inj ? sd.y : vv;
-                        p0 = inj ? sd.x : p1;
-                        p1 = vv;
-                        if (j == 0) ae = vv;
-                        if (j == 1) ao = vv;
-                    }
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 8; j++) {
-                        const double vv = fma(c[j].x * x, p1, -(c[j].y * p0));
+        if (w.nstage > 0) {
+            double x = 0.0;
+            int my_ls = lmax + 1;
+            double2 sd = make_double2(0.0, 0.0);
+            if (ring < npair) {
+                x = z[ring];
+                const long o = (long)m * npair + ring;
+                my_ls = lstart[o];
+                sd = seed[o];
+            }
+            const double2 *cf = coef + w.base_m;
+            // per-lane start state: (lambda_{lf-2}, lambda_{lf-1}) with lf = l_begin + d the first l of this
+            // lane.  If the ring's first contributing l lies before lf, advance from the seeds.
+            double p0 = 0.0, p1 = 0.0;
+            int inj_l = my_ls;  // l at which the seeds are injected
+            {
+                const int lf = w.l_begin + d;
+                if (my_ls < lf) {
+                    p0 = sd.x;
+                    p1 = sd.y;
+                    for (int l = my_ls + 1; l < lf; l++) {
+                        const double2 c = (l <= lmax) ? cf[l] : make_double2(0.0, 0.0);
+                        const double vv = fma(c.x * x, p1, -(c.y * p0));
                         p0 = p1;
                         p1 = vv;
-                        if (j == 0) ae = vv;
-                        if (j == 1) ao = vv;
                     }
+                    inj_l = 0x7fffffff;
                 }
-#endif
-#if LEG_ABLATE == 9
-                asm volatile("" : "+v"(ae), "+v"(ao));
-                STAMP(Tb); t_rec += Tb - Ta;
-#endif
-                if (__all(my_ls > l0 + 7)) continue;  // all A operands of this macro-step are zero
-                const double *be = sb + (8 * ms + d) * STRIDE + ri;
-                const double *bo = be + STRIDE;
-#if LEG_ABLATE == 1  // diagnostic: no MFMA (keep the operands alive)
-                asm volatile("" ::"v"(ae), "v"(ao), "v"(be), "v"(bo));
-#elif LEG_ABLATE == 3  // diagnostic: MFMA without LDS B reads
+            }
+
+            for (int st = 0; st < w.nstage; st++) {
+                // own pieces of stage st have landed when at most the pieces of the (up to LEG_NBUF-2) younger
+                // stages are still in flight (anything younger than those only makes the wait stricter)
+                if (st + 2 < w.nstage) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PIECES) : "memory");
+                else if (st + 1 < w.nstage) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();  // everyone's pieces of stage st landed; everyone is done reading stage st-1
+                const bool refill = st + LEG_NBUF - 1 < w.nstage;
+                if (refill) issue_coef(w, st + LEG_NBUF - 1);
+                const int ls = w.l_begin + st * LEG_KT;
+                const double *sb = lds + (st % LEG_NBUF) * STAGE;
+                const double2 *sc = reinterpret_cast<const double2 *>(sb + LEG_KT * STRIDE) + d;
+#pragma unroll 1
+                for (int ms = 0; ms < LEG_KT / 8; ms++) {
+                    // one a_lm piece of the stage being refilled per macro-step: spreads the LDS-DMA issue
+                    // over the MFMA work instead of an 8-wave burst behind the barrier (measured 7 % of time)
+                    if (refill) issue_row(w, st + LEG_NBUF - 1, ms);
+                    const int l0 = ls + 8 * ms;
+                    if (l0 > lmax) continue;
+                    // nothing of this wave starts before l0+14: skip the macro-step entirely
+                    if (__all(my_ls > l0 + 13)) continue;
+#if LEG_ABLATE == 2  // diagnostic: no recurrence
+                    double ae = x, ao = x + 1.0;
+                    asm volatile("" : "+v"(ae), "+v"(ao));
+#else
+                    double2 c[8];
 #pragma unroll
-                for (int t = 0; t < NT; t++) {
-                    acce[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(ae, x, acce[t], 0, 0, 0);
-                    acco[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(ao, x, acco[t], 0, 0, 0);
-                }
+                    for (int j = 0; j < 8; j++) c[j] = sc[8 * ms + j];
+                    double ae, ao;
+                    const int lf = l0 + d;
+                    if (__any(inj_l >= lf && inj_l < lf + 8)) {
+#pragma unroll
+                        for (int j = 0; j < 8; j++) {
+                            double vv = fma(c[j].x * x, p1, -(c[j].y * p0));
+                            const bool inj = (lf + j == inj_l);
+                            vv = inj ? sd.y : vv;
+                            p0 = inj ? sd.x : p1;
+                            p1 = vv;
+                            if (j == 0) ae = vv;
+                            if (j == 1) ao = vv;
+                        }
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 8; j++) {
+                            const double vv = fma(c[j].x * x, p1, -(c[j].y * p0));
+                            p0 = p1;
+                            p1 = vv;
+                            if (j == 0) ae = vv;
+                            if (j == 1) ao = vv;
+                        }
+                    }
+#endif
+                    if (__all(my_ls > l0 + 7)) continue;  // all A operands of this macro-step are zero
+                    const double *be = sb + (8 * ms + d) * STRIDE + ri;
+                    const double *bo = be + STRIDE;
+#if LEG_ABLATE == 1  // diagnostic: no MFMA (keep the operands alive)
+                    asm volatile("" ::"v"(ae), "v"(ao), "v"(be), "v"(bo));
 #else
 #pragma unroll
-                for (int t = 0; t < NT; t++) {
-                    acce[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(ae, be[16 * t], acce[t], 0, 0, 0);
-                    acco[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(ao, bo[16 * t], acco[t], 0, 0, 0);
+                    for (int t = 0; t < NT; t++) {
+                        acce[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(ae, be[16 * t], acce[t], 0, 0, 0);
+                        acco[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(ao, bo[16 * t], acco[t], 0, 0, 0);
+                    }
+#endif
                 }
-#endif
-#if LEG_ABLATE == 9
-                asm volatile("" : "+v"(acce[NT - 1]), "+v"(acco[NT - 1]));
-                STAMP(Ta); t_mfma += Ta - Tb;
-#endif
             }
         }
-    }
-#if LEG_ABLATE == 9
-    STAMP(Tb);
-#endif
 
-    // epilogue: north = even + odd, south mirror = even - odd.  Adjacent lanes (columns n, n+1 of the
-    // same rows) swap one value each so that every lane stores 16 bytes: half the store instructions.
-    const bool odd_lane = lane & 1;
+        // ---- next item: start its first stages now, so they land behind this item's epilogue stores
+        const int cur_rtile = w.rtile, cur_cg = w.cg, cur_m = w.m;
+        item += gridDim.x;
+        const bool have_next = item < nitems;
+        __syncthreads();  // all waves are done reading the stage ring
+        if (have_next) {
+            w = decode(item);
 #pragma unroll
-    for (int t = 0; t < NT; t++) {
-        const int col = cg * TCOLS + 16 * t + (ri & ~1);  // even column of the lane pair
-        const int g = col >> 3, cv = col & 7;
+            for (int st = 0; st < LEG_NBUF - 1; st++)
+                if (st < w.nstage) issue_stage(w, st);
+        }
+
+        // ---- epilogue: north = even + odd, south mirror = even - odd.  Adjacent lanes (columns n, n+1 of the
+        //      same rows) swap one value each so that every lane stores 16 bytes: half the store instructions.
 #pragma unroll
-        for (int rp = 0; rp < 2; rp++) {
-            const int r0 = 2 * rp, r1 = 2 * rp + 1;
-            const double n0 = acce[t][r0] + acco[t][r0], n1 = acce[t][r1] + acco[t][r1];
-            const double s0 = acce[t][r0] - acco[t][r0], s1 = acce[t][r1] - acco[t][r1];
-            // even lane keeps row r0 and sends its r1 value; odd lane keeps row r1 and sends its r0 value
-            const double nrecv = __shfl_xor(odd_lane ? n0 : n1, 1);
-            const double srecv = __shfl_xor(odd_lane ? s0 : s1, 1);
-            const int rr = odd_lane ? r1 : r0;
-            const int ro = rtile * LEG_RINGS + (kq + 4 * rr) * LEG_WAVES + wave;
-            if (ro < npair) {
-                const double2 nv = odd_lane ? make_double2(nrecv, n1) : make_double2(n0, nrecv);
-                *reinterpret_cast<double2 *>(inter + (((size_t)ro * G + g) * L + m) * 8 + cv) = nv;
-                const int rs = nring - 1 - ro;
-                if (rs != ro) {
-                    const double2 sv = odd_lane ? make_double2(srecv, s1) : make_double2(s0, srecv);
-                    *reinterpret_cast<double2 *>(inter + (((size_t)rs * G + g) * L + m) * 8 + cv) = sv;
+        for (int t = 0; t < NT; t++) {
+            const int col = cur_cg * TCOLS + 16 * t + (ri & ~1);  // even column of the lane pair
+            const int g = col >> 3, cv = col & 7;
+#pragma unroll
+            for (int rp = 0; rp < 2; rp++) {
+                const int r0 = 2 * rp, r1 = 2 * rp + 1;
+                const double n0 = acce[t][r0] + acco[t][r0], n1 = acce[t][r1] + acco[t][r1];
+                const double s0 = acce[t][r0] - acco[t][r0], s1 = acce[t][r1] - acco[t][r1];
+                // even lane keeps row r0 and sends its r1 value; odd lane keeps row r1 and sends its r0 value
+                const double nrecv = __shfl_xor(odd_lane ? n0 : n1, 1);
+                const double srecv = __shfl_xor(odd_lane ? s0 : s1, 1);
+                const int rr = odd_lane ? r1 : r0;
+                const int ro = cur_rtile * LEG_RINGS + (kq + 4 * rr) * LEG_WAVES + wave;
+                if (ro < npair) {
+                    const double2 nv = odd_lane ? make_double2(nrecv, n1) : make_double2(n0, nrecv);
+                    *reinterpret_cast<double2 *>(inter + (((size_t)ro * G + g) * L + cur_m) * 8 + cv) = nv;
+                    const int rs = nring - 1 - ro;
+                    if (rs != ro) {
+                        const double2 sv = odd_lane ? make_double2(srecv, s1) : make_double2(s0, srecv);
+                        *reinterpret_cast<double2 *>(inter + (((size_t)rs * G + g) * L + cur_m) * 8 + cv) = sv;
+                    }
                 }
             }
         }
+        if (!have_next) break;
     }
-#if LEG_ABLATE == 9
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    STAMP(Ta); t_epi = Ta - Tb;
-    if (lane == 0) {
-        atomicAdd(&stamps[0], Ta - T0);
-        atomicAdd(&stamps[1], t_pro);
-        atomicAdd(&stamps[2], t_wait);
-        atomicAdd(&stamps[3], t_issue);
-        atomicAdd(&stamps[4], t_rec);
-        atomicAdd(&stamps[5], t_mfma);
-        atomicAdd(&stamps[6], t_epi);
-        atomicAdd(&stamps[7], 1ull);
-    }
-#endif
+}
+
+// per (m, ring tile) minimum of lstart: the first l the tile's workgroup has to visit
+__global__ void lmin_kernel(int lmax, int npair, int ntile, const int32_t *__restrict__ lstart,
+                            int32_t *__restrict__ lmin_tab) {
+    const int m = blockIdx.x, t = threadIdx.x;
+    if (t >= ntile) return;
+    int v = lmax + 1;
+    for (int r = t * LEG_RINGS; r < min((t + 1) * LEG_RINGS, npair); r++) v = min(v, lstart[(long)m * npair + r]);
+    lmin_tab[m * ntile + t] = v;
 }
 
 // ------------------------------------------------------------------------------------
@@ -899,7 +882,7 @@ int corahip_sht_plan_destroy(corahip_ctx *ctx, corahip_sht_plan *p) {
     (void)hipFree(p->d_seed);
     (void)hipFree(p->d_tw);
     (void)hipFree(p->d_zeros);
-    (void)hipFree(p->d_stamps);
+    (void)hipFree(p->d_lmin);
     (void)hipFree(p->d_blu_P);
     (void)hipFree(p->d_blu_boff);
     (void)hipFree(p->d_blu_foff);
@@ -1009,11 +992,15 @@ int corahip_sht_plan_create(corahip_ctx *ctx, int nside, int lmax, corahip_sht_p
         seed_kernel<<<grid, 64, 0, s>>>(lmax, p->npair, p->d_z, p->d_sth, d_pref, p->d_coef, p->d_lstart, p->d_seed);
         LAUNCH_CHECK();
     }
+    {
+        const int ntile = (p->npair + LEG_RINGS - 1) / LEG_RINGS;
+        HIP_TRY(hipMalloc((void **)&p->d_lmin, sizeof(int32_t) * (size_t)p->L * ntile));
+        lmin_kernel<<<p->L, 64 * ((ntile + 63) / 64), 0, s>>>(lmax, p->npair, ntile, p->d_lstart, p->d_lmin);
+        LAUNCH_CHECK();
+    }
     HIP_TRY(hipStreamSynchronize(s));
     (void)hipFree(d_pref);
 
-    HIP_TRY(hipMalloc((void **)&p->d_stamps, 4096));
-    HIP_TRY(hipMemsetAsync(p->d_stamps, 0, 4096, s));
     HIP_TRY(hipMalloc((void **)&p->d_zeros, 4096));
     HIP_TRY(hipMemsetAsync(p->d_zeros, 0, 4096, s));
     // FFT twiddles and Bluestein tables
@@ -1141,21 +1128,14 @@ static int launch_legendre(corahip_ctx *ctx, const corahip_sht_plan *p, int ncol
     HIP_TRY(hipFuncSetAttribute((const void *)legendre_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)shm));
     const int ntile = (p->npair + LEG_RINGS - 1) / LEG_RINGS;
-    const int ngroup = p->L * (ncols / (16 * NT));
-    dim3 grid(ngroup * ntile);
-    legendre_kernel<NT><<<grid, 64 * LEG_WAVES, shm, ctx->stream>>>(p->lmax, p->npair, p->nring, ncols, p->d_z, p->d_coef,
-                                                        p->d_lstart, p->d_seed, alm, p->d_zeros, inter, p->d_stamps);
+    const long nitems = (long)p->L * (ncols / (16 * NT)) * ntile;
+    // persistent: as many workgroups as fit (LDS-limited: one per CU for NT = 8)
+    const int per_cu = std::max<int>(1, std::min<int>(2, (int)((160 * 1024) / shm)));
+    dim3 grid((unsigned)std::min<long>(nitems, (long)ctx->num_cu * per_cu));
+    legendre_kernel<NT><<<grid, 64 * LEG_WAVES, shm, ctx->stream>>>(p->lmax, p->npair, p->nring, ncols, p->d_z,
+                                                                   p->d_coef, p->d_lstart, p->d_seed, p->d_lmin, alm,
+                                                                   p->d_zeros, inter);
     LAUNCH_CHECK();
-#if LEG_ABLATE == 9
-    {
-        unsigned long long h[8];
-        HIP_TRY(hipStreamSynchronize(ctx->stream));
-        HIP_TRY(hipMemcpy(h, p->d_stamps, sizeof(h), hipMemcpyDeviceToHost));
-        fprintf(stderr, "K4 stamps (wave-cycle sums): total %llu  prologue %llu  wait+barrier %llu  issue %llu  recur %llu  mfma %llu  epilogue %llu waves %llu\n",
-                h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]);
-        HIP_TRY(hipMemset(p->d_stamps, 0, 4096));
-    }
-#endif
     return 0;
 }
 
