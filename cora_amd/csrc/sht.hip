@@ -37,6 +37,7 @@ struct corahip_sht_plan {
     int32_t *d_lstart = nullptr;                          // [L][npair]
     double2 *d_seed = nullptr;                            // [L][npair]: (lambda_{lstart-1}, lambda_{lstart})
     int32_t *d_lmin = nullptr;                            // [L][ntile] first l per (m, ring tile)
+    unsigned *d_queue = nullptr;                          // K4 work-queue head
     double *d_zeros = nullptr;                            // 4 KiB of zeros (source of padding rows for LDS-DMA)
     double2 *d_tw = nullptr;                              // e^{+2 pi i k/pmax}, k < pmax/2
     int pmax = 0, log_pmax = 0;
@@ -200,7 +201,8 @@ __global__ void __launch_bounds__(512)
 legendre_kernel(int lmax, int npair, int nring, int ncols, const double *__restrict__ z,
                 const double2 *__restrict__ coef, const int32_t *__restrict__ lstart,
                 const double2 *__restrict__ seed, const int32_t *__restrict__ lmin_tab,
-                const double *__restrict__ alm, const double *__restrict__ zeros, double *__restrict__ inter) {
+                const double *__restrict__ alm, const double *__restrict__ zeros, double *__restrict__ inter,
+                unsigned *__restrict__ queue) {
     constexpr int TCOLS = 16 * NT;          // columns of this block
     constexpr int STRIDE = TCOLS + 8;       // LDS row stride (doubles): 2 rows apart = 128 B mod 256
     constexpr int CROWS = LEG_KT + 8;       // coefficient rows per stage (staggered lanes look 6 ahead)
@@ -209,6 +211,7 @@ legendre_kernel(int lmax, int npair, int nring, int ncols, const double *__restr
     constexpr int PIECES = RPW + 1;                     // LDS-DMA pieces per wave per stage (+ coefficients)
     static_assert(RPW == LEG_KT / 8, "one a_lm piece per macro-step");
     extern __shared__ __attribute__((aligned(16))) double lds[];
+    int &s_next = *reinterpret_cast<int *>(lds + LEG_NBUF * STAGE);  // next work item (carved after the ring)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -267,7 +270,9 @@ legendre_kernel(int lmax, int npair, int nring, int ncols, const double *__restr
         for (int rr = 0; rr < RPW; rr++) issue_row(w, st, rr);
     };
 
-    int item = blockIdx.x;
+    // dynamic work queue (one atomic per item, fetched one item ahead): items differ a lot in length
+    // (polar ring tiles start late, large m is short), a static assignment left ~10 % on the table
+    int item = blockIdx.x;  // the first gridDim.x items are pre-assigned; the queue starts behind them
     if (item >= nitems) return;
     item_t w = decode(item);
 #pragma unroll
@@ -276,6 +281,7 @@ legendre_kernel(int lmax, int npair, int nring, int ncols, const double *__restr
 
     for (;;) {
         const int m = w.m;
+        if (tid == 0) s_next = (int)(gridDim.x + atomicAdd(queue, 1u));  // latency hidden behind this item
         // rings are dealt to the waves interleaved (ring = tile base + 8 ri + wave) so that every wave of
         // the workgroup has the same mix of first-contributing l and reaches the stage barriers together
         const int ring = w.rtile * LEG_RINGS + ri * LEG_WAVES + wave;
@@ -385,9 +391,9 @@ legendre_kernel(int lmax, int npair, int nring, int ncols, const double *__restr
 
         // ---- next item: start its first stages now, so they land behind this item's epilogue stores
         const int cur_rtile = w.rtile, cur_cg = w.cg, cur_m = w.m;
-        item += gridDim.x;
+        __syncthreads();  // all waves are done reading the stage ring; s_next is visible
+        item = __builtin_amdgcn_readfirstlane(s_next);
         const bool have_next = item < nitems;
-        __syncthreads();  // all waves are done reading the stage ring
         if (have_next) {
             w = decode(item);
 #pragma unroll
@@ -423,6 +429,7 @@ legendre_kernel(int lmax, int npair, int nring, int ncols, const double *__restr
             }
         }
         if (!have_next) break;
+        __syncthreads();  // everyone has read s_next before thread 0 overwrites it
     }
 }
 
@@ -883,6 +890,7 @@ int corahip_sht_plan_destroy(corahip_ctx *ctx, corahip_sht_plan *p) {
     (void)hipFree(p->d_tw);
     (void)hipFree(p->d_zeros);
     (void)hipFree(p->d_lmin);
+    (void)hipFree(p->d_queue);
     (void)hipFree(p->d_blu_P);
     (void)hipFree(p->d_blu_boff);
     (void)hipFree(p->d_blu_foff);
@@ -994,6 +1002,7 @@ int corahip_sht_plan_create(corahip_ctx *ctx, int nside, int lmax, corahip_sht_p
     }
     {
         const int ntile = (p->npair + LEG_RINGS - 1) / LEG_RINGS;
+        HIP_TRY(hipMalloc((void **)&p->d_queue, 64));
         HIP_TRY(hipMalloc((void **)&p->d_lmin, sizeof(int32_t) * (size_t)p->L * ntile));
         lmin_kernel<<<p->L, 64 * ((ntile + 63) / 64), 0, s>>>(lmax, p->npair, ntile, p->d_lstart, p->d_lmin);
         LAUNCH_CHECK();
@@ -1132,9 +1141,10 @@ static int launch_legendre(corahip_ctx *ctx, const corahip_sht_plan *p, int ncol
     // persistent: as many workgroups as fit (LDS-limited: one per CU for NT = 8)
     const int per_cu = std::max<int>(1, std::min<int>(2, (int)((160 * 1024) / shm)));
     dim3 grid((unsigned)std::min<long>(nitems, (long)ctx->num_cu * per_cu));
+    HIP_TRY(hipMemsetAsync(p->d_queue, 0, 64, ctx->stream));
     legendre_kernel<NT><<<grid, 64 * LEG_WAVES, shm, ctx->stream>>>(p->lmax, p->npair, p->nring, ncols, p->d_z,
                                                                    p->d_coef, p->d_lstart, p->d_seed, p->d_lmin, alm,
-                                                                   p->d_zeros, inter);
+                                                                   p->d_zeros, inter, p->d_queue);
     LAUNCH_CHECK();
     return 0;
 }
