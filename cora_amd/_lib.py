@@ -43,6 +43,7 @@ SIGNATURES = {
     "corahip_romb_reduce": (c_int, [c_void_p, PTR, c_int, c_int, c_int, PTR, PTR]),
     "corahip_factor_batched": (c_int, [c_void_p, PTR, c_int, c_int, c_double, c_double, PTR, PTR]),
     "corahip_normals_philox": (c_int, [c_void_p, c_u64, c_int, c_int, PTR]),
+    "corahip_draw_alm_philox": (c_int, [c_void_p, PTR, PTR, c_u64, c_int, c_int, c_int, c_int, PTR]),
     "corahip_draw_alm": (c_int, [c_void_p, PTR, PTR, PTR, c_int, c_int, c_int, c_int, PTR]),
     "corahip_alm_dev_to_square": (c_int, [c_void_p, PTR, c_int, c_int, PTR]),
     "corahip_alm_packed_to_dev": (c_int, [c_void_p, PTR, c_int, c_int, PTR]),
@@ -227,6 +228,15 @@ class Context:
         alm = out if out is not None else self.empty((nalm, G, 2, 4))
         _check(self.lib.corahip_draw_alm(self.h, self._f64(T), self._p(info) if info is not None else None,
                                          self._f64(g), lmax, F, nu0, nnu, self._f64(alm)))
+        return alm
+
+    def draw_alm_philox(self, T, info, seed, lmax, F, nu0=0, nnu=None, out=None):
+        nnu = F if nnu is None else nnu
+        nalm = (lmax + 1) * (lmax + 2) // 2
+        G = (nnu + 3) // 4
+        alm = out if out is not None else self.empty((nalm, G, 2, 4))
+        _check(self.lib.corahip_draw_alm_philox(self.h, self._f64(T), self._p(info) if info is not None else None,
+                                                c_u64(int(seed) & (2**64 - 1)), lmax, F, nu0, nnu, self._f64(alm)))
         return alm
 
     def alm_dev_to_square(self, alm, lmax, nnu):

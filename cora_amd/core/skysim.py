@@ -158,11 +158,11 @@ def mkfullsky_device(corr, nside, alms=False, rng=None, factors=None, nu_range=N
     nu0, nnu = (0, numz) if nu_range is None else nu_range
 
     if isinstance(rng, DeviceRNG):
-        g = ctx.normals_philox(rng.next_seed(), maxl, numz)
+        alm = ctx.draw_alm_philox(T, info, rng.next_seed(), maxl, numz, nu0=nu0, nnu=nnu)
     else:
         g = torch.from_numpy(_host_normals(numz, maxl, rng)).to(ctx.device)
-    alm = ctx.draw_alm(T, info, g, maxl, numz, nu0=nu0, nnu=nnu)
-    del g
+        alm = ctx.draw_alm(T, info, g, maxl, numz, nu0=nu0, nnu=nnu)
+        del g
     if alms:
         return ctx.alm_dev_to_square(alm, maxl, nnu)
     return ctx.alm2map(alm, int(nside), maxl, nnu)

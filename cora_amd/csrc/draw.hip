@@ -42,18 +42,36 @@ __device__ static inline void philox4x32_10(uint64_t counter, uint64_t key, uint
     out[3] = c[3];
 }
 
-// element pair q -> normals at stream positions 2q, 2q+1
-__global__ void normals_kernel(uint64_t seed, long npairs, double *__restrict__ g) {
-    for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < npairs; q += (long)gridDim.x * blockDim.x) {
-        uint32_t r[4];
-        philox4x32_10((uint64_t)q, seed, r);
-        // two uniforms in (0,1) with 53 random bits each
-        const double u1 = ((double)(((uint64_t)r[0] << 21) | (r[1] >> 11)) + 0.5) * 0x1p-53;
-        const double u2 = ((double)(((uint64_t)r[2] << 21) | (r[3] >> 11)) + 0.5) * 0x1p-53;
-        const double rad = sqrt(-2.0 * log(u1));
-        double s, c;
-        sincospi(2.0 * u2, &s, &c);
-        *reinterpret_cast<double2 *>(g + 2 * q) = make_double2(rad * c, rad * s);
+// The device stream: the normals of (l, c = re/im, nu', m) and (.., m+1), m even, are the two
+// Box-Muller outputs of Philox counter {lo = m/2, hi = l*2F + c*F + nu'} under key = seed.  A value
+// depends only on (seed, l, c, nu', m): the same for any number of GPUs, and the same whether it is
+// materialised in HBM (normals_kernel, stream-order layout) or generated inside K3.
+__device__ static inline double2 philox_normal_pair(uint64_t seed, int l, int F, int c, int nup, int mpair) {
+    uint32_t r[4];
+    const uint64_t ctr = ((uint64_t)((uint32_t)l * 2u * (uint32_t)F + (uint32_t)(c * F + nup)) << 32) | (uint32_t)mpair;
+    philox4x32_10(ctr, seed, r);
+    // two uniforms in (0,1) with 53 random bits each
+    const double u1 = ((double)(((uint64_t)r[0] << 21) | (r[1] >> 11)) + 0.5) * 0x1p-53;
+    const double u2 = ((double)(((uint64_t)r[2] << 21) | (r[3] >> 11)) + 0.5) * 0x1p-53;
+    const double rad = sqrt(-2.0 * log(u1));
+    double sn, cs;
+    sincospi(2.0 * u2, &sn, &cs);
+    return make_double2(rad * cs, rad * sn);
+}
+
+// one thread per (l, c, nu', m-pair): writes the stream-order buffer  g[F l(l+1) + c F(l+1) + nu'(l+1) + m]
+__global__ void normals_kernel(uint64_t seed, int lmax, int F, double *__restrict__ g) {
+    const int l = blockIdx.y;
+    const int lp1 = l + 1, npair = (lp1 + 1) >> 1;
+    const long n = 2L * F * npair;
+    double *gl = g + (size_t)F * l * lp1;
+    for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (long)gridDim.x * blockDim.x) {
+        const int mp = (int)(q % npair);
+        const int cn = (int)(q / npair);  // c*F + nu'
+        const double2 v = philox_normal_pair(seed, l, F, cn / F, cn % F, mp);
+        double *dst = gl + (size_t)cn * lp1 + 2 * mp;
+        dst[0] = v.x;
+        if (2 * mp + 1 < lp1) dst[1] = v.y;
     }
 }
 
@@ -154,6 +172,110 @@ draw_kernel(const double *__restrict__ T, const int32_t *__restrict__ info, cons
 }
 
 // ------------------------------------------------------------------------------------
+// K3 with the normals generated in registers (device-RNG mode): no 8.6 GB normal buffer is written or
+// read.  Wave tile = 32 rows (16 m-pairs of one c: the two Box-Muller outputs feed the even-m and the
+// odd-m row tile) x 16*NCT channels; workgroup = 4 waves = 128 rows.
+// ------------------------------------------------------------------------------------
+template <int NCT>
+__global__ void __launch_bounds__(256)
+draw_rng_kernel(const double *__restrict__ T, const int32_t *__restrict__ info, uint64_t seed, int lmax, int F,
+                int nu0, int nnu, int Gout, double *__restrict__ alm) {
+    constexpr int NC = 16 * NCT;
+    constexpr int STRIDE = DRAW_KC + 2;
+    extern __shared__ __attribute__((aligned(16))) double lds[];  // Bs[n][k] = T_l[nu0+col0+n][k0+k]
+
+    const int l = blockIdx.x;
+    const int lp1 = l + 1;
+    const int nmb = (lp1 + 127) / 128;          // 128-row blocks per c
+    const int c_of = blockIdx.y / nmb, mb = blockIdx.y % nmb;
+    if (c_of > 1) return;
+    const int col0 = blockIdx.z * NC;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ri = lane & 15, kq = lane >> 4;
+    const int m0 = mb * 128 + wave * 32;        // first m of this wave
+    const int mpair = (m0 >> 1) + ri;           // this lane's m-pair: rows m = 2 mpair, 2 mpair + 1
+    const bool pair_ok = 2 * mpair < lp1;
+
+    const double *Tl = T + (size_t)l * F * F;
+    const bool dense = (info == nullptr) || (info[l] != 0);
+
+    d4_t acc0[NCT], acc1[NCT];
+#pragma unroll
+    for (int t = 0; t < NCT; t++) {
+        acc0[t] = (d4_t){0.0, 0.0, 0.0, 0.0};
+        acc1[t] = (d4_t){0.0, 0.0, 0.0, 0.0};
+    }
+    const int kmax = dense ? F : min(F, nu0 + col0 + NC);
+    const bool wave_has_rows = m0 < lp1;
+    for (int k0 = 0; k0 < kmax; k0 += DRAW_KC) {
+        __syncthreads();
+        for (int it = tid; it < NC * (DRAW_KC / 2); it += 256) {
+            const int n = it / (DRAW_KC / 2), q = it % (DRAW_KC / 2);
+            const int nu = nu0 + col0 + n;
+            double2 v = make_double2(0.0, 0.0);
+            const int k = k0 + 2 * q;
+            if (col0 + n < nnu && nu < F) {
+                if (k + 1 < F) v = *reinterpret_cast<const double2 *>(Tl + (size_t)nu * F + k);
+                else if (k < F) v.x = Tl[(size_t)nu * F + k];
+            }
+            *reinterpret_cast<double2 *>(lds + n * STRIDE + 2 * q) = v;
+        }
+        __syncthreads();
+        if (!wave_has_rows) continue;
+#pragma unroll 2
+        for (int kk = 0; kk < DRAW_KC / 4; kk++) {
+            const int kbase = k0 + 4 * kk;
+            if (kbase >= kmax) break;
+            const int kp = kbase + kq;
+            double2 a = make_double2(0.0, 0.0);
+            if (pair_ok && kp < F) a = philox_normal_pair(seed, l, F, c_of, kp, mpair);
+            const double *bs = lds + ri * STRIDE + 4 * kk + kq;
+#pragma unroll
+            for (int t = 0; t < NCT; t++) {
+                if (!dense && kbase > nu0 + col0 + 16 * t + 15) continue;
+                const double b = bs[16 * t * STRIDE];
+                acc0[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, b, acc0[t], 0, 0, 0);
+                acc1[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, b, acc1[t], 0, 0, 0);
+            }
+        }
+    }
+    if (!wave_has_rows) return;
+    // epilogue: C row i of tile0 is m = m0 + 2 i, of tile1 m = m0 + 2 i + 1; 1/sqrt(2) of complex_std_normal
+    const double sc = 0.70710678118654752440;
+#pragma unroll
+    for (int t = 0; t < NCT; t++) {
+        const int col = col0 + 16 * t + ri;
+        if (col >= 4 * Gout) continue;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int i = kq + 4 * r;
+#pragma unroll
+            for (int par = 0; par < 2; par++) {
+                const int m = m0 + 2 * i + par;
+                if (m < lp1) {
+                    const long idx = (long)m * (2 * lmax + 1 - m) / 2 + l;
+                    alm[((size_t)idx * Gout + (col >> 2)) * 8 + c_of * 4 + (col & 3)] =
+                        (par ? acc1[t][r] : acc0[t][r]) * sc;
+                }
+            }
+        }
+    }
+}
+
+template <int NCT>
+static int launch_draw_rng(corahip_ctx *ctx, const double *T, const int32_t *info, uint64_t seed, int lmax, int F,
+                           int nu0, int nnu, int Gout, double *alm) {
+    constexpr int NC = 16 * NCT;
+    const size_t shm = sizeof(double) * NC * (DRAW_KC + 2);
+    HIP_TRY(hipFuncSetAttribute((const void *)draw_rng_kernel<NCT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)shm));
+    dim3 grid(lmax + 1, 2 * ((lmax + 1 + 127) / 128), (4 * Gout + NC - 1) / NC);
+    draw_rng_kernel<NCT><<<grid, 256, shm, ctx->stream>>>(T, info, seed, lmax, F, nu0, nnu, Gout, alm);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------
 // layout converters
 // ------------------------------------------------------------------------------------
 // alm_dev [nalm][G][2][4] -> square [nnu][1][L][L] complex128 (m > l entries zero)
@@ -209,11 +331,23 @@ extern "C" {
 int corahip_normals_philox(corahip_ctx *ctx, uint64_t seed, int lmax, int F, double *g) {
     ARG_CHECK(ctx != nullptr && g != nullptr && lmax >= 0 && F >= 1);
     StageTimer t(ctx, "normals");
-    const long npairs = (long)F * nalm_of(lmax);  // 2 F nalm doubles
-    const int blocks = (int)std::min<long>((npairs + 255) / 256, 256L * 16);
-    normals_kernel<<<blocks, 256, 0, ctx->stream>>>(seed, npairs, g);
+    dim3 grid(std::max(1, std::min(64, (F * (lmax + 2) / 2 + 255) / 256)), lmax + 1);
+    normals_kernel<<<grid, 256, 0, ctx->stream>>>(seed, lmax, F, g);
     LAUNCH_CHECK();
     return 0;
+}
+
+int corahip_draw_alm_philox(corahip_ctx *ctx, const double *T, const int32_t *info, uint64_t seed, int lmax, int F,
+                            int nu0, int nnu, double *alm_dev) {
+    ARG_CHECK(ctx != nullptr && T != nullptr && alm_dev != nullptr);
+    ARG_CHECK(lmax >= 0 && F >= 1 && nu0 >= 0 && nnu >= 1 && nu0 + nnu <= F);
+    StageTimer t(ctx, "draw");
+    const int Gout = (nnu + 3) / 4;
+    const int ncol = 4 * Gout;
+    if (ncol <= 16) return launch_draw_rng<1>(ctx, T, info, seed, lmax, F, nu0, nnu, Gout, alm_dev);
+    if (ncol <= 32) return launch_draw_rng<2>(ctx, T, info, seed, lmax, F, nu0, nnu, Gout, alm_dev);
+    if (ncol <= 64) return launch_draw_rng<4>(ctx, T, info, seed, lmax, F, nu0, nnu, Gout, alm_dev);
+    return launch_draw_rng<8>(ctx, T, info, seed, lmax, F, nu0, nnu, Gout, alm_dev);
 }
 
 int corahip_draw_alm(corahip_ctx *ctx, const double *T, const int32_t *info, const double *g, int lmax, int F,

@@ -116,7 +116,9 @@ int corahip_factor_batched(corahip_ctx *ctx, const double *C, int nl, int F, dou
 /* ---- K3: correlated draw -----------------------------------------------------------
  * Normal stream layout ("stream order"; nputil.py:104-125 called from
  * skysim.py:120): for l = 0..lmax: F*(l+1) reals [nu'][m] then F*(l+1) imags [nu'][m];
- * total 2*F*nalm doubles.  The 1/sqrt(2) of complex_std_normal is applied by draw_alm. */
+ * total 2*F*nalm doubles.  The 1/sqrt(2) of complex_std_normal is applied by draw_alm.
+ * normals_philox fills that buffer with the device stream: element (l, c, nu', m) is a Box-Muller output
+ * of Philox4x32-10 counter {m/2, l*2F + c*F + nu'} under key `seed` (independent of the GPU count). */
 int corahip_normals_philox(corahip_ctx *ctx, uint64_t seed, int lmax, int F, double *g);
 
 /* a_lm(nu) = sum_nu' T_l[nu,nu'] g_lm(nu')  (skysim.py:121) for channels nu0 <= nu < nu0+nnu.
@@ -126,6 +128,11 @@ int corahip_normals_philox(corahip_ctx *ctx, uint64_t seed, int lmax, int F, dou
  *   nnu_pad = nnu rounded up to a multiple of 4, padding channels are written as 0).  */
 int corahip_draw_alm(corahip_ctx *ctx, const double *T, const int32_t *info, const double *g, int lmax,
                      int F, int nu0, int nnu, double *alm_dev);
+
+/* draw_alm with the device stream generated in registers (same values as normals_philox(seed) followed by
+ * draw_alm, without the 16*F*nalm-byte normal buffer) */
+int corahip_draw_alm_philox(corahip_ctx *ctx, const double *T, const int32_t *info, uint64_t seed, int lmax,
+                            int F, int nu0, int nnu, double *alm_dev);
 
 /* layout converters between alm_dev and the reference's arrays:
  *   square  [nnu, 1, L, L] complex128 as returned by mkfullsky(alms=True) (skysim.py:108-125)

@@ -202,6 +202,33 @@ def test_draw_shard_consistency(ctx, golden):
     assert np.array_equal(part, full[3:7])
 
 
+def test_draw_fused_rng_equals_materialised_stream(ctx, golden):
+    """K3 with in-register Philox normals == normals_philox buffer + K3 (same device stream)."""
+    C = golden["cla_21cm_F8_l64_zromb3"]
+    T, info = ctx.factor_batched(ctx.to_device(C))
+    for nu0, nnu in ((0, 8), (2, 5)):
+        g = ctx.normals_philox(321, 64, 8)
+        a = ctx.alm_dev_to_square(ctx.draw_alm(T, info, g, 64, 8, nu0=nu0, nnu=nnu), 64, nnu).cpu().numpy()
+        b = ctx.alm_dev_to_square(ctx.draw_alm_philox(T, info, 321, 64, 8, nu0=nu0, nnu=nnu), 64, nnu).cpu().numpy()
+        assert np.abs(a - b).max() <= 1e-13 * np.abs(a).max()
+    rng = np.random.default_rng(0)
+    A = rng.standard_normal((40, 70, 75))
+    C2 = A @ A.transpose(0, 2, 1)
+    T2, info2 = ctx.factor_batched(ctx.to_device(C2))
+    g = ctx.normals_philox(5, 39, 70)
+    a = ctx.alm_dev_to_square(ctx.draw_alm(T2, info2, g, 39, 70), 39, 70).cpu().numpy()
+    b = ctx.alm_dev_to_square(ctx.draw_alm_philox(T2, info2, 5, 39, 70), 39, 70).cpu().numpy()
+    assert np.abs(a - b).max() <= 1e-13 * np.abs(a).max()
+    # and the draw itself is right: a = T g / sqrt(2) with g in the reference's (nu', m) block order
+    gh = g.cpu().numpy()
+    l, F = 17, 70
+    o = F * l * (l + 1)
+    re = gh[o : o + F * (l + 1)].reshape(F, l + 1)
+    im = gh[o + F * (l + 1) : o + 2 * F * (l + 1)].reshape(F, l + 1)
+    ref = T2[l].cpu().numpy() @ (re + 1j * im) / 2**0.5
+    assert np.abs(a[:, 0, l, : l + 1] - ref).max() <= 1e-12 * np.abs(ref).max()
+
+
 def test_philox_normals_statistics(ctx):
     g = ctx.normals_philox(7, 200, 16).cpu().numpy()
     assert abs(g.mean()) < 5 / np.sqrt(g.size)
