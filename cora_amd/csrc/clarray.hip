@@ -5,149 +5,157 @@
 // and its three bilinearmap.interp calls (cora/util/bilinearmap.pyx:14-59) are fused with
 // the Romberg reduction (skysim.py:62-67): no [l, F*zint, F*zint] intermediate exists.
 //
-// K1 mapping: one workgroup = (16x16 tile of channel pairs with jt >= it, 256 consecutive l).
-// Lanes run over l, so for a given sub-sample pair every lane shares the table columns
-// (y0, y0+1) and touches only the 1-3 adjacent table rows that 64 consecutive l span:
-// gathers are near-broadcast and served from L1/L2 (the per-l working set of the three
-// 131 MB tables is a ~3.5 MB band each).  Per-sub-pair constants (log10(xc kperpmin), y
-// split, prefactors x Romberg weights) are computed once per (i, j-tile) into LDS.
+// K1: for a fixed sub-sample pair (nu_i+a, nu_j+b) the table columns (y0, y0+1) are fixed, so the y
+// interpolation and the dd/dv/vv combination collapse, once per sub-pair, into a 1-D profile along
+// the k_perp axis x; every multipole then costs one linear interpolation of that profile in LDS.
+// The tables are transposed (x contiguous) so the profile is read with coalesced loads: 12x fewer
+// table reads than gathering 4 corners x 3 tables per (l, sub-pair).  One workgroup per channel pair
+// j >= i, results to a [pair][l] scratch, a tiled transpose scatters them into [l][i][j] and its mirror.
 #include "common.h"
 
-#define CL_TI 16
-#define CL_TJ 16
 #define CL_MAXZ 17  // zint <= 17 (zromb <= 4)
 
-#define CL_ISPLIT 4
-#define CL_TJH 8    // channels of the j tile whose constants are resident in LDS at a time
+#define CL_XS 512      // padded row length of the transposed tables (nkperp <= 511)
+#define CL_LPT 9       // multipoles per thread (256 threads x 9 = 2304 >= 2049)
 
-// per sub-sample pair (i a, j b): everything that does not depend on l.  The y interpolation
-// weights are folded into the coefficients: value = sum_T (cT0 T[x][y0] + cT1 T[x][y0+1]).
-struct cl_pair_const {
-    double lxcs;             // log10(xc * kperpmin) * xscale
-    double c[6];             // {dd,dv,vv} x {(1-wy), wy} x W x model factor; W = w_a w_b pfD_a pfD_b/(xc^2 pi)
-    unsigned y0, pad;        // floor of the clipped y
-};
-
-struct __attribute__((aligned(8))) cl_d2 {  // two adjacent table entries (8-byte aligned 16-byte load)
-    double a, b;
-};
-
-__global__ void __launch_bounds__(256)
-clarray21_kernel(const double *__restrict__ dd, const double *__restrict__ dv, const double *__restrict__ vv,
-                 int nkperp, int nkpar, double kperpmin, double xscale, double yscale,
-                 const double *__restrict__ chi, const double *__restrict__ pfd, const double *__restrict__ fz,
-                 const double *__restrict__ bz, int F, int zint, const double *__restrict__ w,
-                 const double *__restrict__ log10l, int nl, const int2 *__restrict__ tiles,
-                 double *__restrict__ out) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    cl_pair_const *pc = reinterpret_cast<cl_pair_const *>(smem);  // [zint][CL_TJH][zint]
-    const int tid = threadIdx.x;
-    const int it = tiles[blockIdx.x].x, jt = tiles[blockIdx.x].y;
-    const int li = blockIdx.y * 256 + tid;
-    const bool l_ok = li < nl;
-    const double lxs = (l_ok ? log10l[li] : 0.0) * xscale;
-    const double ux = (double)nkperp - 1e-5, uy = (double)nkpar - 1e-5;
-    const int nsub = zint * CL_TJH * zint;
-    const unsigned xlast = (unsigned)(nkperp - 1);
-
-    // blockIdx.z splits the 16 rows of the tile over CL_ISPLIT workgroups (more, shorter workgroups:
-    // 136 tile pairs x 9 l-chunks alone leave the second wave of workgroups 40 % empty at F = 256)
-    for (int ii = blockIdx.z * (CL_TI / CL_ISPLIT); ii < (blockIdx.z + 1) * (CL_TI / CL_ISPLIT); ii++) {
-        const int i = it * CL_TI + ii;
-        if (i >= F) break;
-        double acc[CL_TJ];
-#pragma unroll
-        for (int jj = 0; jj < CL_TJ; jj++) acc[jj] = 0.0;
-#pragma unroll
-        for (int half = 0; half < CL_TJ / CL_TJH; half++) {
-            __syncthreads();
-            // constants of channel i against CL_TJH channels of the j tile
-            for (int q = tid; q < nsub; q += 256) {
-                const int b = q % zint, jj = (q / zint) % CL_TJH, a = q / (zint * CL_TJH);
-                const int j = jt * CL_TJ + half * CL_TJH + jj;
-                cl_pair_const c;
-                c.lxcs = 0.0;
-#pragma unroll
-                for (int u = 0; u < 6; u++) c.c[u] = 0.0;
-                c.y0 = 0;
-                c.pad = 0;
-                if (j < F) {
-                    const int za = i * zint + a, zb = j * zint + b;
-                    const double x1 = chi[za], x2 = chi[zb];
-                    const double xc = 0.5 * (x1 + x2);
-                    const double rpar = fabs(x2 - x1);
-                    c.lxcs = log10(xc * kperpmin) * xscale;
-                    double yy = rpar * yscale;  // rpar / (pi / kparmax)
-                    yy = yy < 0.0 ? 0.0 : (yy > uy ? uy : yy);
-                    unsigned y0 = (unsigned)yy;
-                    double wy = yy - (double)y0;
-                    if (y0 + 1 > (unsigned)(nkpar - 1)) {  // keep the 16-byte pair load in bounds (the
-                        y0 = (unsigned)(nkpar - 2);        // reference reads out of bounds here)
-                        wy = 1.0;
-                    }
-                    c.y0 = y0;
-                    const double W = w[a] * w[b] * pfd[za] * pfd[zb] / (xc * xc * M_PI);
-                    const double cdd = W * bz[za] * bz[zb];
-                    const double cdv = W * (fz[za] * bz[zb] + fz[zb] * bz[za]);
-                    const double cvv = W * fz[za] * fz[zb];
-                    c.c[0] = cdd * (1.0 - wy);
-                    c.c[1] = cdd * wy;
-                    c.c[2] = cdv * (1.0 - wy);
-                    c.c[3] = cdv * wy;
-                    c.c[4] = cvv * (1.0 - wy);
-                    c.c[5] = cvv * wy;
-                }
-                pc[q] = c;
-            }
-            __syncthreads();
-            if (l_ok) {
-                for (int a = 0; a < zint; a++) {
-#pragma unroll
-                    for (int jj = 0; jj < CL_TJH; jj++) {
-                        double s = 0.0;
-                        for (int b = 0; b < zint; b++) {
-                            const cl_pair_const &c = pc[(a * CL_TJH + jj) * zint + b];
-                            double xx = lxs - c.lxcs;
-                            xx = xx < 0.0 ? 0.0 : (xx > ux ? ux : xx);
-                            const unsigned x0 = (unsigned)xx;
-                            const double wx = xx - (double)x0;
-                            const unsigned x1 = x0 + 1 > xlast ? xlast : x0 + 1;
-                            const unsigned o0 = x0 * (unsigned)nkpar + c.y0, o1 = x1 * (unsigned)nkpar + c.y0;
-                            const cl_d2 d0 = *reinterpret_cast<const cl_d2 *>(dd + o0);
-                            const cl_d2 v0 = *reinterpret_cast<const cl_d2 *>(dv + o0);
-                            const cl_d2 q0 = *reinterpret_cast<const cl_d2 *>(vv + o0);
-                            const cl_d2 d1 = *reinterpret_cast<const cl_d2 *>(dd + o1);
-                            const cl_d2 v1 = *reinterpret_cast<const cl_d2 *>(dv + o1);
-                            const cl_d2 q1 = *reinterpret_cast<const cl_d2 *>(vv + o1);
-                            const double s0 = c.c[0] * d0.a + c.c[1] * d0.b + c.c[2] * v0.a + c.c[3] * v0.b +
-                                              c.c[4] * q0.a + c.c[5] * q0.b;
-                            const double s1 = c.c[0] * d1.a + c.c[1] * d1.b + c.c[2] * v1.a + c.c[3] * v1.b +
-                                              c.c[4] * q1.a + c.c[5] * q1.b;
-                            s += s0 + wx * (s1 - s0);
-                        }
-                        acc[half * CL_TJH + jj] += s;
-                    }
-                }
-            }
-        }
-        if (l_ok) {
-            double *orow = out + ((size_t)li * F + i) * F + (size_t)jt * CL_TJ;
-#pragma unroll
-            for (int jj = 0; jj < CL_TJ; jj++)
-                if (jt * CL_TJ + jj < F) orow[jj] = acc[jj];
-        }
+// Transposed, x-padded copy of the three tables: Tt[t][y][x], x contiguous.  For a fixed sub-sample
+// pair the y columns (y0, y0+1) are fixed, so the whole l-dependence of the model is a 1-D profile
+// along x; with x contiguous that profile is read with coalesced loads.
+__global__ void cl_transpose_kernel(const double *__restrict__ dd, const double *__restrict__ dv,
+                                    const double *__restrict__ vv, int nkperp, int nkpar, double *__restrict__ tt) {
+    __shared__ double tile[32][33];
+    const double *src = blockIdx.z == 0 ? dd : (blockIdx.z == 1 ? dv : vv);
+    double *dst = tt + (size_t)blockIdx.z * nkpar * CL_XS;
+    const int x0 = blockIdx.y * 32, y0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    for (int r = ty; r < 32; r += 8) {
+        const int x = x0 + r, y = y0 + tx;
+        tile[r][tx] = (x < nkperp && y < nkpar) ? src[(size_t)x * nkpar + y] : 0.0;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int y = y0 + r, x = x0 + tx;
+        if (y < nkpar && x < CL_XS) dst[(size_t)y * CL_XS + x] = (x < nkperp) ? tile[tx][r] : 0.0;
     }
 }
 
-// fill everything below the diagonal from the computed upper part: C[l][i][j] = C[l][j][i], i > j
-// (tiles with jt > it were not computed at all; inside diagonal tiles this makes the block
-// exactly symmetric instead of symmetric to rounding as in the reference).
-__global__ void clarray_mirror_kernel(double *__restrict__ out, int nl, int F) {
-    const long n = (long)nl * F * F;
-    for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (long)gridDim.x * blockDim.x) {
-        const int j = (int)(q % F), i = (int)((q / F) % F);
-        const long l = q / ((long)F * F);
-        if (i > j) out[q] = out[(l * F + j) * F + i];
+// One workgroup = one channel pair (i, j >= i).  For every sub-sample pair (a, b):
+//   profile  s_ab[x] = sum_T (cT0 Tt[T][y0][x] + cT1 Tt[T][y0+1][x])          (x = table row, in LDS)
+//   value    C_l    += (1 - wx) s_ab[x0] + wx s_ab[x0+1],  x = (log10 l - log10(xc kperpmin)) xscale
+// which is the bilinear lookup of the reference (bilinearmap.pyx:41-59) with the y interpolation and
+// the three-table combination (corr.py:980-982) hoisted out of the l loop: 12x fewer table reads.
+// Results go to a [pair][l] scratch (coalesced); cl_finish_kernel scatters them into [l][i][j].
+__global__ void __launch_bounds__(256)
+clarray21_kernel(const double *__restrict__ tt, int nkperp, int nkpar, double kperpmin, double xscale, double yscale,
+                 const double *__restrict__ chi, const double *__restrict__ pfd, const double *__restrict__ fz,
+                 const double *__restrict__ bz, int F, int zint, const double *__restrict__ w,
+                 const double *__restrict__ log10l, int nl, int l_base, const int2 *__restrict__ pairs,
+                 double *__restrict__ scratch, int nl_total) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    double *prof = sm;                       // [zint][CL_XS + 2]
+    double *lxcs_s = sm + zint * (CL_XS + 2);   // [zint]
+    const int PS = CL_XS + 2;
+    const int tid = threadIdx.x;
+    const int i = pairs[blockIdx.x].x, j = pairs[blockIdx.x].y;
+    const double ux = (double)nkperp - 1e-5, uy = (double)nkpar - 1e-5;
+    const size_t tsz = (size_t)nkpar * CL_XS;
+
+    double lxs[CL_LPT], acc[CL_LPT];
+#pragma unroll
+    for (int k = 0; k < CL_LPT; k++) {
+        const int li = l_base + tid + 256 * k;
+        lxs[k] = (li < nl_total ? log10l[li] : 0.0) * xscale;
+        acc[k] = 0.0;
+    }
+    // rows the l range can touch: x <= x(l_max) + 1 (x is monotone in l); log10l is ascending
+    const double lx_hi = log10l[min(nl_total, l_base + 256 * CL_LPT) - 1] * xscale;
+
+    for (int a = 0; a < zint; a++) {
+        const int za = i * zint + a;
+        const double x1 = chi[za];
+        __syncthreads();
+        // ---- profiles of the zint sub-sample pairs (a, b = 0..zint-1)
+        int nx_max = 0;
+        for (int b = 0; b < zint; b++) {
+            const int zb = j * zint + b;
+            const double x2 = chi[zb];
+            const double xc = 0.5 * (x1 + x2);
+            const double lxc = log10(xc * kperpmin) * xscale;
+            double yy = fabs(x2 - x1) * yscale;  // rpar / (pi / kparmax)
+            yy = yy < 0.0 ? 0.0 : (yy > uy ? uy : yy);
+            int y0 = (int)yy;
+            double wy = yy - (double)y0;
+            if (y0 + 1 > nkpar - 1) {  // stay in bounds where the reference reads past the table edge
+                y0 = nkpar - 2;
+                wy = 1.0;
+            }
+            const double W = w[a] * w[b] * pfd[za] * pfd[zb] / (xc * xc * M_PI);
+            const double cdd = W * bz[za] * bz[zb];
+            const double cdv = W * (fz[za] * bz[zb] + fz[zb] * bz[za]);
+            const double cvv = W * fz[za] * fz[zb];
+            const double c0 = cdd * (1.0 - wy), c1 = cdd * wy, c2 = cdv * (1.0 - wy), c3 = cdv * wy;
+            const double c4 = cvv * (1.0 - wy), c5 = cvv * wy;
+            double xhi = lx_hi - lxc;
+            xhi = xhi < 0.0 ? 0.0 : (xhi > ux ? ux : xhi);
+            const int nx = min((int)xhi + 2, nkperp);  // rows 0 .. nx-1 are needed
+            nx_max = max(nx_max, nx);
+            const double *r0 = tt + (size_t)y0 * CL_XS, *r1 = r0 + CL_XS;
+            double *pb = prof + b * PS;
+            for (int x = tid; x < nx; x += 256)
+                pb[x] = c0 * r0[x] + c1 * r1[x] + c2 * r0[tsz + x] + c3 * r1[tsz + x] + c4 * r0[2 * tsz + x] +
+                        c5 * r1[2 * tsz + x];
+            if (tid == 0) {
+                pb[nkperp] = 0.0;  // x1 = x0 + 1 is clamped to the last row below; slot kept finite
+                lxcs_s[b] = lxc;
+            }
+        }
+        __syncthreads();
+        // ---- 1-D interpolation for this thread's multipoles
+#pragma unroll
+        for (int k = 0; k < CL_LPT; k++) {
+            double s = 0.0;
+            for (int b = 0; b < zint; b++) {
+                double xx = lxs[k] - lxcs_s[b];
+                xx = xx < 0.0 ? 0.0 : (xx > ux ? ux : xx);
+                const int x0 = (int)xx;
+                const double wx = xx - (double)x0;
+                const int xb = min(x0 + 1, nkperp - 1);
+                const double s0 = prof[b * PS + x0], s1 = prof[b * PS + xb];
+                s += s0 + wx * (s1 - s0);
+            }
+            acc[k] += s;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < CL_LPT; k++) {
+        const int li = l_base + tid + 256 * k;
+        if (li < nl_total) scratch[(size_t)blockIdx.x * nl_total + li] = acc[k];
+    }
+}
+
+// scratch [pair][l] -> out [l][i][j] and its mirror [l][j][i]
+__global__ void cl_finish_kernel(const double *__restrict__ scratch, const int2 *__restrict__ pairs, long npairs,
+                                 int nl, int F, double *__restrict__ out) {
+    __shared__ double tile[32][33];
+    // tile: 32 pairs x 32 l
+    const long p0 = (long)blockIdx.x * 32;
+    const int l0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8) {
+        const long p = p0 + r;
+        const int l = l0 + tx;
+        tile[r][tx] = (p < npairs && l < nl) ? scratch[(size_t)p * nl + l] : 0.0;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int l = l0 + r;
+        const long p = p0 + tx;
+        if (l < nl && p < npairs) {
+            const int2 ij = pairs[p];
+            const double v = tile[tx][r];
+            out[((size_t)l * F + ij.x) * F + ij.y] = v;
+            out[((size_t)l * F + ij.y) * F + ij.x] = v;
+        }
     }
 }
 
@@ -224,31 +232,45 @@ int corahip_clarray_table21cm(corahip_ctx *ctx, const double *dd, const double *
                               const double *pfd, const double *f, const double *b, int F, int zint, const double *w,
                               const double *log10l, int nl, double *out) {
     ARG_CHECK(ctx != nullptr && dd && dv && vv && chi && pfd && f && b && w && log10l && out);
-    ARG_CHECK(nkperp >= 2 && nkpar >= 2 && F >= 1 && zint >= 1 && zint <= CL_MAXZ && nl >= 1);
+    ARG_CHECK(nkperp >= 2 && nkperp < CL_XS && nkpar >= 2 && F >= 1 && zint >= 1 && zint <= CL_MAXZ && nl >= 1);
     ARG_CHECK(kperpmin > 0 && kperpmax > kperpmin && kparmax > 0);
     StageTimer t(ctx, "clarray");
-    const int nt = (F + CL_TI - 1) / CL_TI;
-    std::vector<int2> tiles;
-    for (int it = 0; it < nt; it++)
-        for (int jt = it; jt < nt; jt++) tiles.push_back(make_int2(it, jt));
-    int2 *dtiles = nullptr;
-    HIP_TRY(hipMalloc((void **)&dtiles, sizeof(int2) * tiles.size()));
-    HIP_TRY(hipMemcpyAsync(dtiles, tiles.data(), sizeof(int2) * tiles.size(), hipMemcpyHostToDevice, ctx->stream));
-    const double xscale = (double)(nkperp - 1) / log10(kperpmax / kperpmin);
-    const double yscale = kparmax / M_PI;
-    const size_t shm = sizeof(cl_pair_const) * (size_t)zint * CL_TJH * zint;
-    HIP_TRY(hipFuncSetAttribute((const void *)clarray21_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-    dim3 grid((unsigned)tiles.size(), (nl + 255) / 256, CL_ISPLIT);
-    clarray21_kernel<<<grid, 256, shm, ctx->stream>>>(dd, dv, vv, nkperp, nkpar, kperpmin, xscale, yscale, chi, pfd, f,
-                                                      b, F, zint, w, log10l, nl, dtiles, out);
-    LAUNCH_CHECK();
-    if (F > 1) {
-        const long n = (long)nl * F * F;
-        clarray_mirror_kernel<<<(int)std::min<long>((n + 255) / 256, 4096), 256, 0, ctx->stream>>>(out, nl, F);
+    // channel pairs j >= i, ordered so that concurrently running workgroups share table columns
+    std::vector<int2> pairs;
+    for (int i = 0; i < F; i++)
+        for (int j = i; j < F; j++) pairs.push_back(make_int2(i, j));
+    const long npairs = (long)pairs.size();
+    // scratch: transposed tables + pair list + [pair][l] results (context-owned, grow-only)
+    const size_t tt_bytes = sizeof(double) * 3 * (size_t)nkpar * CL_XS;
+    const size_t sc_bytes = sizeof(double) * (size_t)npairs * nl;
+    double *tt = nullptr, *scratch = nullptr;
+    int2 *dpairs = nullptr;
+    int rc;
+    if ((rc = corahip_ctx_scratch(ctx, 0, tt_bytes, (void **)&tt))) return rc;
+    if ((rc = corahip_ctx_scratch(ctx, 1, sc_bytes, (void **)&scratch))) return rc;
+    if ((rc = corahip_ctx_scratch(ctx, 2, sizeof(int2) * npairs, (void **)&dpairs))) return rc;
+    HIP_TRY(hipMemcpyAsync(dpairs, pairs.data(), sizeof(int2) * npairs, hipMemcpyHostToDevice, ctx->stream));
+    {
+        dim3 grid((nkpar + 31) / 32, CL_XS / 32, 3);
+        cl_transpose_kernel<<<grid, 256, 0, ctx->stream>>>(dd, dv, vv, nkperp, nkpar, tt);
         LAUNCH_CHECK();
     }
-    HIP_TRY(hipStreamSynchronize(ctx->stream));  // dtiles lifetime (cold path)
-    (void)hipFree(dtiles);
+    const double xscale = (double)(nkperp - 1) / log10(kperpmax / kperpmin);
+    const double yscale = kparmax / M_PI;
+    const size_t shm = sizeof(double) * ((size_t)zint * (CL_XS + 2) + zint);
+    HIP_TRY(hipFuncSetAttribute((const void *)clarray21_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+    for (int l_base = 0; l_base < nl; l_base += 256 * CL_LPT) {
+        clarray21_kernel<<<(unsigned)npairs, 256, shm, ctx->stream>>>(tt, nkperp, nkpar, kperpmin, xscale, yscale, chi, pfd,
+                                                                     f, b, F, zint, w, log10l, nl, l_base, dpairs, scratch,
+                                                                     nl);
+        LAUNCH_CHECK();
+    }
+    {
+        dim3 grid((unsigned)((npairs + 31) / 32), (nl + 31) / 32);
+        cl_finish_kernel<<<grid, 256, 0, ctx->stream>>>(scratch, dpairs, npairs, nl, F, out);
+        LAUNCH_CHECK();
+    }
+    HIP_TRY(hipStreamSynchronize(ctx->stream));  // `pairs` (host) must outlive the async copy
     return 0;
 }
 

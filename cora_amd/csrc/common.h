@@ -31,7 +31,13 @@ struct corahip_ctx {
     std::map<std::string, corahip_prof_entry> prof;
     std::vector<corahip_pending_event> pending;
     int num_cu = 256;
+    // grow-only device scratch slots owned by the context (freed by ctx_destroy)
+    void *scratch[4] = {nullptr, nullptr, nullptr, nullptr};
+    size_t scratch_bytes[4] = {0, 0, 0, 0};
 };
+
+// returns a device buffer of at least `bytes` for `slot`, reallocating only when it must grow
+int corahip_ctx_scratch(corahip_ctx *ctx, int slot, size_t bytes, void **out);
 
 // RAII: HIP-event pair around the launches of one named stage when profiling is on.
 struct StageTimer {

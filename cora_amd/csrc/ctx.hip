@@ -12,6 +12,19 @@ void corahip_set_error(const char *fmt, ...) {
     va_end(ap);
 }
 
+int corahip_ctx_scratch(corahip_ctx *ctx, int slot, size_t bytes, void **out) {
+    if (ctx->scratch_bytes[slot] < bytes) {
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        if (ctx->scratch[slot]) HIP_TRY(hipFree(ctx->scratch[slot]));
+        ctx->scratch[slot] = nullptr;
+        ctx->scratch_bytes[slot] = 0;
+        HIP_TRY(hipMalloc(&ctx->scratch[slot], bytes));
+        ctx->scratch_bytes[slot] = bytes;
+    }
+    *out = ctx->scratch[slot];
+    return 0;
+}
+
 extern "C" {
 
 int corahip_abi_version(void) { return CORAHIP_ABI_VERSION; }
@@ -55,6 +68,8 @@ int corahip_ctx_destroy(corahip_ctx *ctx) {
     }
     (void)hipEventDestroy(ctx->t0);
     (void)hipEventDestroy(ctx->t1);
+    for (int i = 0; i < 4; i++)
+        if (ctx->scratch[i]) (void)hipFree(ctx->scratch[i]);
     delete ctx;
     return 0;
 }
