@@ -558,7 +558,7 @@ __device__ static inline double2 tw_get(const double2 *__restrict__ tw, int pmax
 // true: its transpose (twiddle then DFT).  Ends with a workgroup barrier.
 template <int R, int SIGN, bool DIT>
 __device__ __forceinline__ static void fft_pass(double2 *buf, int bstride, int nch, int N, int Ls, const double2 *__restrict__ tw,
-                                int pmax) {
+                                int pmax, const double2 *__restrict__ postmul = nullptr) {
     const int q = Ls / R;
     const int nb = N / R;
     const int total = nch * nb;
@@ -588,6 +588,10 @@ __device__ __forceinline__ static void fft_pass(double2 *buf, int bstride, int n
         if (DIT) twiddle_all();
         DftR<R, SIGN>::run(x);
         if (!DIT) twiddle_all();
+        if (postmul) {  // pointwise factor indexed by storage position (Bluestein filter, digit-reversed order)
+#pragma unroll
+            for (int r = 0; r < R; r++) x[r] = cmul(x[r], postmul[i0 + r * q]);
+        }
 #pragma unroll
         for (int r = 0; r < R; r++) cbuf[fpad(i0 + r * q)] = x[r];
     }
@@ -595,16 +599,18 @@ __device__ __forceinline__ static void fft_pass(double2 *buf, int bstride, int n
 }
 
 // pass schedule for N = 2^k: radix 16 while k >= 4, then the remainder
+// `postmul` (optional) is multiplied into the output of the LAST pass, indexed by storage position
 template <int SIGN>
-__device__ __forceinline__ static void fft_dif(double2 *buf, int bstride, int nch, int N, const double2 *__restrict__ tw, int pmax) {
+__device__ __forceinline__ static void fft_dif(double2 *buf, int bstride, int nch, int N, const double2 *__restrict__ tw, int pmax,
+                                               const double2 *__restrict__ postmul = nullptr) {
     int Ls = N;
     while (Ls >= 16) {
-        fft_pass<16, SIGN, false>(buf, bstride, nch, N, Ls, tw, pmax);
+        fft_pass<16, SIGN, false>(buf, bstride, nch, N, Ls, tw, pmax, Ls == 16 ? postmul : nullptr);
         Ls >>= 4;
     }
-    if (Ls == 8) fft_pass<8, SIGN, false>(buf, bstride, nch, N, Ls, tw, pmax);
-    else if (Ls == 4) fft_pass<4, SIGN, false>(buf, bstride, nch, N, Ls, tw, pmax);
-    else if (Ls == 2) fft_pass<2, SIGN, false>(buf, bstride, nch, N, Ls, tw, pmax);
+    if (Ls == 8) fft_pass<8, SIGN, false>(buf, bstride, nch, N, Ls, tw, pmax, postmul);
+    else if (Ls == 4) fft_pass<4, SIGN, false>(buf, bstride, nch, N, Ls, tw, pmax, postmul);
+    else if (Ls == 2) fft_pass<2, SIGN, false>(buf, bstride, nch, N, Ls, tw, pmax, postmul);
 }
 // transpose of fft_dif: digit-reversed order in -> natural order out
 template <int SIGN>
@@ -738,19 +744,28 @@ ringfft_kernel(const int32_t *__restrict__ ring_list, int nlist, int nside, int 
         const int P = icap ? blu_P[icap - 1] : 0;
         const int flen = P ? P : h + 1;
 
+        const bool noalias = lmax <= h;
+        const bool need_zero = !(noalias && lmax == h && P == 0);  // direct ring whose bins 0..h are all written
         __syncthreads();  // previous item's LDS reads are done
-        for (int j = tid; j < fpad(flen); j += nt)
+        if (need_zero) {
+            for (int j = tid; j < fpad(flen); j += nt)
 #pragma unroll
-            for (int c = 0; c < NCH; c++) sm[(size_t)c * bstride + j] = make_double2(0.0, 0.0);
-        __syncthreads();
+                for (int c = 0; c < NCH; c++) sm[(size_t)c * bstride + j] = make_double2(0.0, 0.0);
+            __syncthreads();
+        }
 
         // ---- phase + alias fold onto bins 0..h of the Hermitian length-n spectrum X
         const double *cell = cell_ptr(item);
-        const bool noalias = lmax <= h;
+        // e^{i m phi0}: one sincospi for m = tid, then the fixed rotation e^{i nt phi0} per further cell
+        double2 ph, phstep;
+        {
+            double s, c;
+            sincospi(fmod((double)tid * phi0_over_pi, 2.0), &s, &c);
+            ph = make_double2(c, s);
+            sincospi(fmod((double)nt * phi0_over_pi, 2.0), &s, &c);
+            phstep = make_double2(c, s);
+        }
         auto fold_one = [&](int m, const cell_t cv) {
-            double s, cph;
-            sincospi(fmod((double)m * phi0_over_pi, 2.0), &s, &cph);
-            const double2 ph = make_double2(cph, s);
             const int k = m % n;
             const int kc = (n - k) % n;
 #pragma unroll
@@ -758,11 +773,11 @@ ringfft_kernel(const int32_t *__restrict__ ring_list, int nlist, int nside, int 
                 const double2 val = cmul(make_double2(cv.re[c], cv.im[c]), ph);
                 double *bd = smd + (size_t)c * bstride * 2;
                 if (m == 0) {
-                    if (noalias) bd[0] = val.x;  // Re(c_0) only; no other m reaches bin 0
+                    if (noalias) *reinterpret_cast<double2 *>(bd) = make_double2(val.x, 0.0);  // Re(c_0) only
                     else atomicAdd(&bd[0], val.x);
                 } else if (noalias) {
                     if (m < h) *reinterpret_cast<double2 *>(bd + 2 * fpad(m)) = val;
-                    else bd[2 * fpad(h)] = 2.0 * val.x;  // m == h: c + conj(c)
+                    else *reinterpret_cast<double2 *>(bd + 2 * fpad(h)) = make_double2(2.0 * val.x, 0.0);  // m == h: c + conj(c)
                 } else {
                     if (k <= h) {
                         atomicAdd(&bd[2 * fpad(k)], val.x);
@@ -776,10 +791,16 @@ ringfft_kernel(const int32_t *__restrict__ ring_list, int nlist, int nside, int 
             }
         };
         if (tid < L) fold_one(tid, pf0);
+        ph = cmul(ph, phstep);
         if (tid + nt < L) fold_one(tid + nt, pf1);
+        ph = cmul(ph, phstep);
         if (tid + 2 * nt < L) fold_one(tid + 2 * nt, pf2);
+        ph = cmul(ph, phstep);
         if (tid + 3 * nt < L) fold_one(tid + 3 * nt, pf3);
-        for (int m = tid + K5_MC * nt; m < L; m += nt) fold_one(m, load_cell(cell, m));
+        for (int m = tid + K5_MC * nt; m < L; m += nt) {
+            ph = cmul(ph, phstep);
+            fold_one(m, load_cell(cell, m));
+        }
         // the registers are free again: fetch the next item's cells behind the FFT passes
         if (item + (int)gridDim.x < nitems) prefetch(item + gridDim.x);
         __syncthreads();
@@ -837,13 +858,7 @@ ringfft_kernel(const int32_t *__restrict__ ring_list, int nlist, int nside, int 
             }
         } else {
             const double2 *f = filt + foff[icap - 1];
-            fft_dif<-1>(sm, bstride, NCH, P, tw, pmax);
-            for (int j = tid; j < P; j += nt) {
-                const double2 fj = f[j];
-#pragma unroll
-                for (int c = 0; c < NCH; c++) sm[(size_t)c * bstride + fpad(j)] = cmul(sm[(size_t)c * bstride + fpad(j)], fj);
-            }
-            __syncthreads();
+            fft_dif<-1>(sm, bstride, NCH, P, tw, pmax, f);  // filter multiplied in by the last pass
             fft_dit<1>(sm, bstride, NCH, P, tw, pmax);
             const double invP = 1.0 / (double)P;
             for (int j = tid; j < h; j += nt) {
