@@ -38,6 +38,7 @@ struct corahip_sht_plan {
     double2 *d_seed = nullptr;                            // [L][npair]: (lambda_{lstart-1}, lambda_{lstart})
     int32_t *d_lmin = nullptr;                            // [L][ntile] first l per (m, ring tile)
     unsigned *d_queue = nullptr;                          // K4 work-queue head
+    int32_t *d_mcut = nullptr;                            // [nring] number of m with any non-negligible lambda_lm
     double *d_zeros = nullptr;                            // 4 KiB of zeros (source of padding rows for LDS-DMA)
     double2 *d_tw = nullptr;                              // e^{+2 pi i k/pmax}, k < pmax/2
     int pmax = 0, log_pmax = 0;
@@ -390,7 +391,7 @@ legendre_kernel(int lmax, int npair, int nring, int ncols, const double *__restr
         }
 
         // ---- next item: start its first stages now, so they land behind this item's epilogue stores
-        const int cur_rtile = w.rtile, cur_cg = w.cg, cur_m = w.m;
+        const int cur_rtile = w.rtile, cur_cg = w.cg, cur_m = w.m, cur_nstage = w.nstage;
         __syncthreads();  // all waves are done reading the stage ring; s_next is visible
         item = __builtin_amdgcn_readfirstlane(s_next);
         const bool have_next = item < nitems;
@@ -403,6 +404,8 @@ legendre_kernel(int lmax, int npair, int nring, int ncols, const double *__restr
 
         // ---- epilogue: north = even + odd, south mirror = even - odd.  Adjacent lanes (columns n, n+1 of the
         //      same rows) swap one value each so that every lane stores 16 bytes: half the store instructions.
+        //      A tile with no contributing l at all is not written: K5 never reads cells with m >= mcut(ring).
+        if (cur_nstage > 0)
 #pragma unroll
         for (int t = 0; t < NT; t++) {
             const int col = cur_cg * TCOLS + 16 * t + (ri & ~1);  // even column of the lane pair
@@ -431,6 +434,19 @@ legendre_kernel(int lmax, int npair, int nring, int ncols, const double *__restr
         if (!have_next) break;
         __syncthreads();  // everyone has read s_next before thread 0 overwrites it
     }
+}
+
+// per ring: mcut = number of m (from 0) whose lambda_lm reach 2^-900 for some l <= lmax; F_m of the ring
+// is exactly zero beyond (lstart is monotone in m), so K4 need not write and K5 need not read those cells
+__global__ void mcut_kernel(int lmax, int npair, int nring, const int32_t *__restrict__ lstart,
+                            int32_t *__restrict__ mcut) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= npair) return;
+    int c = 0;
+    for (int m = 0; m <= lmax; m++)
+        if (lstart[(long)m * npair + r] <= lmax) c = m + 1;
+    mcut[r] = c;
+    mcut[nring - 1 - r] = c;
 }
 
 // per (m, ring tile) minimum of lstart: the first l the tile's workgroup has to visit
@@ -677,6 +693,15 @@ bluestein_table_kernel(const int32_t *__restrict__ blu_P, const int64_t *__restr
 // pixel stores of one item drain during the next.  P > 0: Bluestein of length P; P == 0: h = nphi/2
 // is a power of two.
 #define K5_MC 4  // cells per thread held in registers for the next item (the rest is read in place)
+#ifndef K5_STAMPS
+#define K5_STAMPS 0  // diagnostic build: s_memtime phase breakdown
+#endif
+#if K5_STAMPS
+__device__ unsigned long long g_k5_stamps[8];
+#define K5STAMP(acc) { unsigned long long _t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)::"memory"); acc += _t - k5_last; k5_last = _t; }
+#else
+#define K5STAMP(acc)
+#endif
 
 template <int NCH>
 __global__ void __launch_bounds__(512)
@@ -685,7 +710,8 @@ ringfft_kernel(const int32_t *__restrict__ ring_list, int nlist, int nside, int 
                const double *__restrict__ phi0_a, const double *__restrict__ inter, double *__restrict__ maps,
                const double2 *__restrict__ tw, int pmax, const int32_t *__restrict__ blu_P,
                const int64_t *__restrict__ boff, const int64_t *__restrict__ foff,
-               const double2 *__restrict__ chirp, const double2 *__restrict__ filt, int bstride) {
+               const double2 *__restrict__ chirp, const double2 *__restrict__ filt, int bstride,
+               const int32_t *__restrict__ mcut) {
     extern __shared__ __attribute__((aligned(16))) double2 sm[];  // [NCH][bstride]
     const int tid = threadIdx.x, nt = blockDim.x;
     const int L = lmax + 1;
@@ -723,12 +749,17 @@ ringfft_kernel(const int32_t *__restrict__ ring_list, int nlist, int nside, int 
     };
     auto prefetch = [&](int item) {
         const double *cell = cell_ptr(item);
-        if (tid < L) pf0 = load_cell(cell, tid);
-        if (tid + nt < L) pf1 = load_cell(cell, tid + nt);
-        if (tid + 2 * nt < L) pf2 = load_cell(cell, tid + 2 * nt);
-        if (tid + 3 * nt < L) pf3 = load_cell(cell, tid + 3 * nt);
+        const int Lr = mcut[ring_list[item / ngrp]];  // cells m >= Lr are exactly zero (and were not written)
+        if (tid < Lr) pf0 = load_cell(cell, tid);
+        if (tid + nt < Lr) pf1 = load_cell(cell, tid + nt);
+        if (tid + 2 * nt < Lr) pf2 = load_cell(cell, tid + 2 * nt);
+        if (tid + 3 * nt < Lr) pf3 = load_cell(cell, tid + 3 * nt);
     };
 
+#if K5_STAMPS
+    unsigned long long k5_last, t_zero = 0, t_fold = 0, t_z = 0, t_fft = 0, t_out = 0, t_pre = 0;
+    { unsigned long long _t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)::"memory"); k5_last = _t; }
+#endif
     int item = blockIdx.x;
     if (item < nitems) prefetch(item);
     for (; item < nitems; item += gridDim.x) {
@@ -743,9 +774,11 @@ ringfft_kernel(const int32_t *__restrict__ ring_list, int nlist, int nside, int 
         else if (ring + 1 > 3 * nside) icap = 4 * nside - (ring + 1);
         const int P = icap ? blu_P[icap - 1] : 0;
         const int flen = P ? P : h + 1;
+        const int Lr = mcut[ring];
 
         const bool noalias = lmax <= h;
-        const bool need_zero = !(noalias && lmax == h && P == 0);  // direct ring whose bins 0..h are all written
+        const bool need_zero = !(noalias && Lr == h + 1 && P == 0);  // direct ring whose bins 0..h are all written
+        K5STAMP(t_pre);
         __syncthreads();  // previous item's LDS reads are done
         if (need_zero) {
             for (int j = tid; j < fpad(flen); j += nt)
@@ -755,6 +788,7 @@ ringfft_kernel(const int32_t *__restrict__ ring_list, int nlist, int nside, int 
         }
 
         // ---- phase + alias fold onto bins 0..h of the Hermitian length-n spectrum X
+        K5STAMP(t_zero);
         const double *cell = cell_ptr(item);
         // e^{i m phi0}: one sincospi for m = tid, then the fixed rotation e^{i nt phi0} per further cell
         double2 ph, phstep;
@@ -790,20 +824,21 @@ ringfft_kernel(const int32_t *__restrict__ ring_list, int nlist, int nside, int 
                 }
             }
         };
-        if (tid < L) fold_one(tid, pf0);
+        if (tid < Lr) fold_one(tid, pf0);
         ph = cmul(ph, phstep);
-        if (tid + nt < L) fold_one(tid + nt, pf1);
+        if (tid + nt < Lr) fold_one(tid + nt, pf1);
         ph = cmul(ph, phstep);
-        if (tid + 2 * nt < L) fold_one(tid + 2 * nt, pf2);
+        if (tid + 2 * nt < Lr) fold_one(tid + 2 * nt, pf2);
         ph = cmul(ph, phstep);
-        if (tid + 3 * nt < L) fold_one(tid + 3 * nt, pf3);
-        for (int m = tid + K5_MC * nt; m < L; m += nt) {
+        if (tid + 3 * nt < Lr) fold_one(tid + 3 * nt, pf3);
+        for (int m = tid + K5_MC * nt; m < Lr; m += nt) {
             ph = cmul(ph, phstep);
             fold_one(m, load_cell(cell, m));
         }
         // the registers are free again: fetch the next item's cells behind the FFT passes
         if (item + (int)gridDim.x < nitems) prefetch(item + gridDim.x);
         __syncthreads();
+        K5STAMP(t_fold);
         // ---- Hermitian -> half-length complex: Z_k = (X_k + conj X_{h-k}) + i w^k (X_k - conj X_{h-k}),
         //      w = e^{2 pi i/n}; pairs (k, h-k) updated together.  Bluestein: times chirp b_k.
         const double2 *bch = P ? chirp + boff[icap - 1] : nullptr;
@@ -844,9 +879,11 @@ ringfft_kernel(const int32_t *__restrict__ ring_list, int nlist, int nside, int 
             }
         }
         __syncthreads();
+        K5STAMP(t_z);
 
         if (P == 0) {
             fft_dif<1>(sm, bstride, NCH, h, tw, pmax);
+            K5STAMP(t_fft);
             for (int j = tid; j < h; j += nt) {
                 const int pos = fpad(fft_dif_pos(j, h));
 #pragma unroll
@@ -860,6 +897,7 @@ ringfft_kernel(const int32_t *__restrict__ ring_list, int nlist, int nside, int 
             const double2 *f = filt + foff[icap - 1];
             fft_dif<-1>(sm, bstride, NCH, P, tw, pmax, f);  // filter multiplied in by the last pass
             fft_dit<1>(sm, bstride, NCH, P, tw, pmax);
+            K5STAMP(t_fft);
             const double invP = 1.0 / (double)P;
             for (int j = tid; j < h; j += nt) {
                 const double2 bj = bch[j];
@@ -874,7 +912,18 @@ ringfft_kernel(const int32_t *__restrict__ ring_list, int nlist, int nside, int 
                 }
             }
         }
+        K5STAMP(t_out);
     }
+#if K5_STAMPS
+    if ((tid & 63) == 0) {
+        atomicAdd(&g_k5_stamps[0], t_pre);
+        atomicAdd(&g_k5_stamps[1], t_zero);
+        atomicAdd(&g_k5_stamps[2], t_fold);
+        atomicAdd(&g_k5_stamps[3], t_z);
+        atomicAdd(&g_k5_stamps[4], t_fft);
+        atomicAdd(&g_k5_stamps[5], t_out);
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------
@@ -906,6 +955,7 @@ int corahip_sht_plan_destroy(corahip_ctx *ctx, corahip_sht_plan *p) {
     (void)hipFree(p->d_zeros);
     (void)hipFree(p->d_lmin);
     (void)hipFree(p->d_queue);
+    (void)hipFree(p->d_mcut);
     (void)hipFree(p->d_blu_P);
     (void)hipFree(p->d_blu_boff);
     (void)hipFree(p->d_blu_foff);
@@ -1018,6 +1068,9 @@ int corahip_sht_plan_create(corahip_ctx *ctx, int nside, int lmax, corahip_sht_p
     {
         const int ntile = (p->npair + LEG_RINGS - 1) / LEG_RINGS;
         HIP_TRY(hipMalloc((void **)&p->d_queue, 64));
+        HIP_TRY(hipMalloc((void **)&p->d_mcut, sizeof(int32_t) * (size_t)p->nring));
+        mcut_kernel<<<(p->npair + 63) / 64, 64, 0, s>>>(lmax, p->npair, p->nring, p->d_lstart, p->d_mcut);
+        LAUNCH_CHECK();
         HIP_TRY(hipMalloc((void **)&p->d_lmin, sizeof(int32_t) * (size_t)p->L * ntile));
         lmin_kernel<<<p->L, 64 * ((ntile + 63) / 64), 0, s>>>(lmax, p->npair, ntile, p->d_lstart, p->d_lmin);
         LAUNCH_CHECK();
@@ -1193,12 +1246,23 @@ static int alm2map_chunk(corahip_ctx *ctx, const corahip_sht_plan *p, const doub
     ringfft_kernel<NCH><<<grid, k5_threads, shm, ctx->stream>>>(c.d_list, c.count, p->nside, p->lmax, G, nnu_valid, p->npix,     \
                                                          p->d_nphi, p->d_start, p->d_phi0, inter, maps, p->d_tw, \
                                                          p->pmax, p->d_blu_P, p->d_blu_boff, p->d_blu_foff,      \
-                                                         p->d_bchirp, p->d_bfilt, c.bstride)
+                                                         p->d_bchirp, p->d_bfilt, c.bstride, p->d_mcut)
             if (c.nch == 4) { RINGFFT_LAUNCH(4); }
             else if (c.nch == 2) { RINGFFT_LAUNCH(2); }
             else { RINGFFT_LAUNCH(1); }
 #undef RINGFFT_LAUNCH
             LAUNCH_CHECK();
+#if K5_STAMPS
+            {
+                unsigned long long hs[8];
+                HIP_TRY(hipStreamSynchronize(ctx->stream));
+                HIP_TRY(hipMemcpyFromSymbol(hs, HIP_SYMBOL(g_k5_stamps), sizeof(hs)));
+                fprintf(stderr, "K5 class P=%d nch=%d rings=%d: pre %llu zero %llu fold %llu z %llu fft %llu out %llu\n", c.P,
+                        c.nch, c.count, hs[0], hs[1], hs[2], hs[3], hs[4], hs[5]);
+                unsigned long long z8[8] = {0};
+                HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_k5_stamps), z8, sizeof(z8)));
+            }
+#endif
         }
     }
     return 0;
