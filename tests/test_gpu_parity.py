@@ -397,3 +397,110 @@ def test_recovered_cl_device_rng(ctx, golden):
     z = (acc - expect)[:, 2:] / sigma[:, 2:]
     assert np.abs(z).max() < 5.0
     assert abs(z.mean()) < 0.5
+
+
+# ------------------------------------------------------------------ BASELINE.json configs
+def test_config1_single_frequency_21cm(model21):
+    """configs[0]: Corr21cm, one frequency, nside=64, lmax=128 (zromb=0: one channel has no width)."""
+    from oracle import skysim as osk
+
+    m = _shared_corr21cm()
+    m.nside, m.lmax, m.oversample = 64, 128, 0
+    m.frequencies = np.array([600.0])
+    try:
+        sky = m.getsky(rng=np.random.default_rng(1))
+    finally:
+        m.lmax, m.frequencies, m.oversample = None, None, 3
+    cla = osk.clarray(model21.angular_powerspectrum, 128, np.array([600.0]), zromb=0)
+    ref = osk.mkfullsky(cla, 64, rng=np.random.default_rng(1))
+    assert sky.shape == (1, 12 * 64 * 64)
+    assert np.abs(sky - ref).max() <= 1e-10 * ref.std()
+
+
+def test_config2_synchrotron_full_size():
+    """configs[1]: FullSkySynchrotron, 32 channels 400-800 MHz, nside=256, lmax=512, oversample 3.
+    C_l vs oracle to 1e-13; maps from host-injected identical a_lm vs the oracle synthesis to 1e-11 rms
+    (the factor of the cond~1e19 blocks is rounding sensitive, SURVEY 8a8, so a_lm are compared at 1e-4)."""
+    import torch
+    from cora_amd import _lib
+    from cora_amd.core import skysim
+    from cora_amd.foreground import galaxy
+    from oracle import models, sht
+    from oracle import skysim as osk
+
+    nside, lmax, F = 256, 512, 32
+    freq = 400.0 + (np.arange(F) + 0.5) * 12.5
+    fg, ofg = galaxy.FullSkySynchrotron(), models.FullSkySynchrotron()
+    cla = skysim.clarray(fg.angular_powerspectrum, lmax, freq, zromb=3)
+    cref = osk.clarray(ofg.angular_powerspectrum, lmax, freq, zromb=3)
+    assert np.abs(cla - cref).max() <= 1e-13 * np.abs(cref).max()
+    a = skysim.mkfullsky(cla, nside, alms=True, rng=np.random.default_rng(2))
+    aref = osk.mkfullsky(cref, nside, alms=True, rng=np.random.default_rng(2))
+    # blocks have cond ~ 7e14 after the 1e-14 jitter: T T^T = C holds to 1e-15 on both sides but T itself
+    # (hence T g) moves by ~1e-7..1e-5 with rounding; compare per l against that l's rms
+    Tg, _ = _lib.get_context().factor_batched(_lib.get_context().to_device(cref[[1, 100, 512]]))
+    for T_l, C_l in zip(Tg.cpu().numpy(), cref[[1, 100, 512]]):
+        Cm = C_l + np.eye(F) * C_l.diagonal().max() * 1e-14
+        assert np.abs(T_l @ T_l.T - Cm).max() <= 1e-14 * Cm.max()
+    for l in range(1, lmax + 1):
+        d = np.abs(a[:, 0, l, : l + 1] - aref[:, 0, l, : l + 1]).max()
+        assert d <= 1e-4 * np.sqrt((np.abs(aref[:, 0, l, : l + 1]) ** 2).mean()), l
+    assert np.all(a[:, 0, 0] == 0)
+    # synthesis at full size on identical a_lm, 4 of the 32 channels checked against the C/OpenMP oracle
+    ctx = _lib.get_context()
+    packed = np.stack([osk.pack_alm(aref[i, 0]) for i in range(F)])
+    dev = ctx.alm_packed_to_dev(torch.from_numpy(packed).to(ctx.device), lmax)
+    maps = ctx.alm2map(dev, nside, lmax, F).cpu().numpy()
+    for i in (0, 7, 18, 31):
+        ref = sht.alm2map(packed[i], nside, lmax)
+        assert np.abs(maps[i] - ref).max() <= 1e-11 * ref.std(), i
+
+
+def test_config3_full_size_properties(ctx):
+    """configs[2] at FULL size (256 channels, nside=1024, lmax=2048), checked on the device through
+    size-independent properties: (1) linearity of the synthesis, (2) Parseval: the pixel variance of every
+    channel equals sum_l (2l+1) C^_l / 4pi of its own a_lm (with only Re a_l0 counted) to quadrature accuracy,
+    (3) north/south mirror: a_lm with only even l+m gives maps symmetric under z -> -z."""
+    import torch
+
+    nside, lmax, F = 1024, 2048, 256
+    L = lmax + 1
+    nalm = L * (L + 1) // 2
+    npix = 12 * nside * nside
+    gen = torch.Generator(device=ctx.device)
+    gen.manual_seed(5)
+    # red spectrum ~ 1/(1+l)^2 so the band limit is well inside the pixelisation
+    idx_l = torch.cat([torch.arange(m, L, device=ctx.device) for m in range(L)])
+    amp = (1.0 / (1.0 + idx_l.double()) ** 1.0)
+    G = F // 4
+    alm = torch.randn((nalm, G, 2, 4), generator=gen, device=ctx.device, dtype=torch.float64) * amp[:, None, None, None]
+    maps = ctx.alm2map(alm, nside, lmax, F)
+    # (2) Parseval per channel
+    pw = (alm[:, :, 0, :] ** 2 + alm[:, :, 1, :] ** 2)           # |a_lm|^2  [nalm, G, 4]
+    m0 = torch.zeros(nalm, device=ctx.device, dtype=torch.float64)
+    m0[:L] = 1.0                                                  # packed index of m = 0 is l
+    tot = (2.0 * pw * (1 - m0)[:, None, None] + (alm[:, :, 0, :] ** 2) * m0[:, None, None]).sum(0)  # [G,4]
+    var_alm = (tot / (4 * np.pi)).reshape(F)
+    mean_sq = (maps**2).mean(dim=1)
+    rel = ((mean_sq - var_alm).abs() / var_alm).max().item()
+    assert rel < 2e-3, rel  # HEALPix quadrature is not exact; 1e-3 level at lmax = 2 nside
+    # (1) linearity on 8 channels
+    a8 = alm[:, :2].contiguous()
+    b8 = torch.randn(a8.shape, generator=gen, device=ctx.device, dtype=torch.float64) * amp[:, None, None, None]
+    ma, mb = ctx.alm2map(a8, nside, lmax, 8).clone(), ctx.alm2map(b8, nside, lmax, 8).clone()
+    mc = ctx.alm2map(2.0 * a8 - 3.0 * b8, nside, lmax, 8)
+    err = (mc - (2.0 * ma - 3.0 * mb)).abs().max().item() / mc.std().item()
+    assert err < 1e-11, err
+    # (3) mirror symmetry: keep only even l+m
+    par = ((idx_l + torch.cat([torch.full((L - m,), m, device=ctx.device) for m in range(L)])) % 2 == 0).double()
+    ms = ctx.alm2map(a8 * par[:, None, None, None], nside, lmax, 8)
+    ri = ctx.sht_rings(nside, lmax)
+    nring = 4 * nside - 1
+    worst = 0.0
+    for r in (0, 5, 511, 1023, 1500, 2046):
+        s, n = int(ri["start"][r]), int(ri["nphi"][r])
+        s2 = int(ri["start"][nring - 1 - r])
+        worst = max(worst, (ms[:, s : s + n] - ms[:, s2 : s2 + n]).abs().max().item())
+    assert worst < 1e-11 * ms.std().item(), worst
+    del maps, alm
+    torch.cuda.empty_cache()
