@@ -187,6 +187,14 @@ def main():
         flops_leg = 8.0 * nside * nalm * nnu          # per launch, SURVEY 8(d) / DESIGN.md
         ach = flops_leg / (leg["ms_per_launch"] * 1e-3) / 1e12
         alg_bytes = 8.0 * npix * nnu + 32.0 * nalm * nnu + 8.0 * L * F * F   # warm path, SURVEY 8(d)
+        # HBM bytes of the dominant kernel from the PMC passes of the same command (collected separately
+        # with rocprofv3 --pmc and committed under profiles/; bench.py cannot read counters itself)
+        traffic = None
+        pmc_file = os.path.join(ROOT, "profiles", "r01_k4_pmc.json")
+        if os.path.exists(pmc_file) and world == 1:
+            pmc = json.load(open(pmc_file))
+            if pmc.get("workload") == args.workload:
+                traffic = pmc["traffic_bytes_per_launch"]
         result = {
             "metric": "sky-maps/sec (nside=%d, lmax=%d, %d freq)" % (nside, lmax, F),
             "value": value,
@@ -216,7 +224,8 @@ def main():
                 "peak": FP64_MFMA_PEAK_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": ach / FP64_MFMA_PEAK_TFLOPS,
-                "traffic": None,
+                "traffic": traffic,
+                "algorithmic_bytes": 16.0 * nalm * nnu + 16.0 * (4 * nside - 1) * L * nnu,
             },
             "hbm_roofline_whole_step": {
                 "algorithmic_GB": alg_bytes / 1e9,
