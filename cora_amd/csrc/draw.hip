@@ -176,13 +176,27 @@ draw_kernel(const double *__restrict__ T, const int32_t *__restrict__ info, cons
 // read.  Wave tile = 32 rows (16 m-pairs of one c: the two Box-Muller outputs feed the even-m and the
 // odd-m row tile) x 16*NCT channels; workgroup = 4 waves = 128 rows.
 // ------------------------------------------------------------------------------------
+// LDS-DMA of 16 bytes per lane from inline asm (see sht.hip: hipcc would drain a builtin DMA with
+// vmcnt(0) before every later ds_read); lane i's bytes land at lds_byte_addr + 16 i.
+__device__ static inline void draw_glds16(const void *gsrc, unsigned lds_byte_addr) {
+    unsigned keep;
+    const unsigned dst = __builtin_amdgcn_readfirstlane(lds_byte_addr);
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(dst)
+                 : "memory");
+}
+
 template <int NCT>
 __global__ void __launch_bounds__(256)
-draw_rng_kernel(const double *__restrict__ T, const int32_t *__restrict__ info, uint64_t seed, int lmax, int F,
-                int nu0, int nnu, int Gout, double *__restrict__ alm) {
+draw_rng_kernel(const double *__restrict__ T, const int32_t *__restrict__ info, const double *__restrict__ zeros,
+                uint64_t seed, int lmax, int F, int nu0, int nnu, int Gout, double *__restrict__ alm) {
     constexpr int NC = 16 * NCT;
-    constexpr int STRIDE = DRAW_KC + 2;
-    extern __shared__ __attribute__((aligned(16))) double lds[];  // Bs[n][k] = T_l[nu0+col0+n][k0+k]
+    constexpr int ROWD = DRAW_KC;            // doubles per channel row in LDS: 256 B, unpadded (DMA is lane-linear)
+    constexpr int BUF = NC * ROWD;           // doubles per stage
+    // Bs[n][slot' = slot ^ (n & 15)][2]: the 16-byte slots of a row are XOR-swizzled with the row number
+    // (applied on the DMA source address), so that 16 rows read at the same k hit 16 distinct slots
+    extern __shared__ __attribute__((aligned(16))) double lds[];  // [2][NC][ROWD]
 
     const int l = blockIdx.x;
     const int lp1 = l + 1;
@@ -198,6 +212,7 @@ draw_rng_kernel(const double *__restrict__ T, const int32_t *__restrict__ info, 
 
     const double *Tl = T + (size_t)l * F * F;
     const bool dense = (info == nullptr) || (info[l] != 0);
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) double *)lds;
 
     d4_t acc0[NCT], acc1[NCT];
 #pragma unroll
@@ -206,22 +221,38 @@ draw_rng_kernel(const double *__restrict__ T, const int32_t *__restrict__ info, 
         acc1[t] = (d4_t){0.0, 0.0, 0.0, 0.0};
     }
     const int kmax = dense ? F : min(F, nu0 + col0 + NC);
+    const int nchunk = (kmax + DRAW_KC - 1) / DRAW_KC;
     const bool wave_has_rows = m0 < lp1;
-    for (int k0 = 0; k0 < kmax; k0 += DRAW_KC) {
-        __syncthreads();
-        for (int it = tid; it < NC * (DRAW_KC / 2); it += 256) {
-            const int n = it / (DRAW_KC / 2), q = it % (DRAW_KC / 2);
+    const bool full_k = (F % DRAW_KC) == 0;      // rows of T_l are whole 256-byte runs
+
+    // stage chunk c of T_l (rows nu0+col0 .. +NC-1, k in [c KC, c KC + KC)) into buffer c & 1:
+    // each wave-instruction moves 4 rows x 16 slots
+    auto stage = [&](int c) {
+        const int k0 = c * DRAW_KC;
+#pragma unroll
+        for (int it = 0; it < NC / 16; it++) {      // NC/4 row-quads over 4 waves
+            const int rq = wave + 4 * it;           // row quad index
+            if (rq >= NC / 4) break;
+            const int n = 4 * rq + (lane >> 4);     // row of this lane
+            const int slot_dst = lane & 15;
+            const int slot_src = slot_dst ^ (n & 15);
             const int nu = nu0 + col0 + n;
-            double2 v = make_double2(0.0, 0.0);
-            const int k = k0 + 2 * q;
-            if (col0 + n < nnu && nu < F) {
-                if (k + 1 < F) v = *reinterpret_cast<const double2 *>(Tl + (size_t)nu * F + k);
-                else if (k < F) v.x = Tl[(size_t)nu * F + k];
-            }
-            *reinterpret_cast<double2 *>(lds + n * STRIDE + 2 * q) = v;
+            const int k = k0 + 2 * slot_src;
+            const double *src = zeros;  // F is even on this path (host wrapper), so k + 1 < F whenever k < F
+            if (col0 + n < nnu && nu < F && k + 1 < F) src = Tl + (size_t)nu * F + k;
+            draw_glds16(src, lds_base + (unsigned)(((c & 1) * BUF + 4 * rq * ROWD) * sizeof(double)));
         }
-        __syncthreads();
+    };
+    (void)full_k;
+
+    stage(0);
+    for (int c = 0; c < nchunk; c++) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                 // chunk c landed; everyone is done with chunk c-1
+        if (c + 1 < nchunk) stage(c + 1);
         if (!wave_has_rows) continue;
+        const double *sb = lds + (c & 1) * BUF;
+        const int k0 = c * DRAW_KC;
 #pragma unroll 2
         for (int kk = 0; kk < DRAW_KC / 4; kk++) {
             const int kbase = k0 + 4 * kk;
@@ -229,11 +260,12 @@ draw_rng_kernel(const double *__restrict__ T, const int32_t *__restrict__ info, 
             const int kp = kbase + kq;
             double2 a = make_double2(0.0, 0.0);
             if (pair_ok && kp < F) a = philox_normal_pair(seed, l, F, c_of, kp, mpair);
-            const double *bs = lds + ri * STRIDE + 4 * kk + kq;
+            const int kl = 4 * kk + kq;          // k within the chunk
 #pragma unroll
             for (int t = 0; t < NCT; t++) {
                 if (!dense && kbase > nu0 + col0 + 16 * t + 15) continue;
-                const double b = bs[16 * t * STRIDE];
+                const int n = 16 * t + ri;
+                const double b = sb[n * ROWD + 2 * ((kl >> 1) ^ (n & 15)) + (kl & 1)];
                 acc0[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, b, acc0[t], 0, 0, 0);
                 acc1[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, b, acc1[t], 0, 0, 0);
             }
@@ -266,11 +298,15 @@ template <int NCT>
 static int launch_draw_rng(corahip_ctx *ctx, const double *T, const int32_t *info, uint64_t seed, int lmax, int F,
                            int nu0, int nnu, int Gout, double *alm) {
     constexpr int NC = 16 * NCT;
-    const size_t shm = sizeof(double) * NC * (DRAW_KC + 2);
+    const size_t shm = sizeof(double) * 2 * NC * DRAW_KC;
     HIP_TRY(hipFuncSetAttribute((const void *)draw_rng_kernel<NCT>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)shm));
+    double *zeros = nullptr;
+    int rc = corahip_ctx_scratch(ctx, 3, 4096, (void **)&zeros);
+    if (rc) return rc;
+    HIP_TRY(hipMemsetAsync(zeros, 0, 4096, ctx->stream));
     dim3 grid(lmax + 1, 2 * ((lmax + 1 + 127) / 128), (4 * Gout + NC - 1) / NC);
-    draw_rng_kernel<NCT><<<grid, 256, shm, ctx->stream>>>(T, info, seed, lmax, F, nu0, nnu, Gout, alm);
+    draw_rng_kernel<NCT><<<grid, 256, shm, ctx->stream>>>(T, info, zeros, seed, lmax, F, nu0, nnu, Gout, alm);
     LAUNCH_CHECK();
     return 0;
 }
@@ -341,6 +377,15 @@ int corahip_draw_alm_philox(corahip_ctx *ctx, const double *T, const int32_t *in
                             int nu0, int nnu, double *alm_dev) {
     ARG_CHECK(ctx != nullptr && T != nullptr && alm_dev != nullptr);
     ARG_CHECK(lmax >= 0 && F >= 1 && nu0 >= 0 && nnu >= 1 && nu0 + nnu <= F);
+    if (F & 1) {
+        // odd F: a 16-byte LDS-DMA piece would straddle the end of a T row; materialise the (identical)
+        // device stream and use the generic kernel instead
+        double *g = nullptr;
+        int rc = corahip_ctx_scratch(ctx, 1, sizeof(double) * 2 * (size_t)F * nalm_of(lmax), (void **)&g);
+        if (rc) return rc;
+        if ((rc = corahip_normals_philox(ctx, seed, lmax, F, g))) return rc;
+        return corahip_draw_alm(ctx, T, info, g, lmax, F, nu0, nnu, alm_dev);
+    }
     StageTimer t(ctx, "draw");
     const int Gout = (nnu + 3) / 4;
     const int ncol = 4 * Gout;

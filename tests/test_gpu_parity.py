@@ -212,6 +212,14 @@ def test_draw_fused_rng_equals_materialised_stream(ctx, golden):
         b = ctx.alm_dev_to_square(ctx.draw_alm_philox(T, info, 321, 64, 8, nu0=nu0, nnu=nnu), 64, nnu).cpu().numpy()
         assert np.abs(a - b).max() <= 1e-13 * np.abs(a).max()
     rng = np.random.default_rng(0)
+    for Fodd in (7, 33):  # odd channel counts take the materialised-stream route inside the library
+        A = rng.standard_normal((20, Fodd, Fodd + 3))
+        Co = A @ A.transpose(0, 2, 1)
+        To, io = ctx.factor_batched(ctx.to_device(Co))
+        g = ctx.normals_philox(9, 19, Fodd)
+        a = ctx.alm_dev_to_square(ctx.draw_alm(To, io, g, 19, Fodd), 19, Fodd).cpu().numpy()
+        b = ctx.alm_dev_to_square(ctx.draw_alm_philox(To, io, 9, 19, Fodd), 19, Fodd).cpu().numpy()
+        assert np.abs(a - b).max() <= 1e-13 * np.abs(a).max()
     A = rng.standard_normal((40, 70, 75))
     C2 = A @ A.transpose(0, 2, 1)
     T2, info2 = ctx.factor_batched(ctx.to_device(C2))
