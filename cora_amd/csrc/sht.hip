@@ -347,6 +347,7 @@ legendre_kernel(int lmax, int npair, int nring, int ncols, const double *__restr
                     double ae = x, ao = x + 1.0;
                     asm volatile("" : "+v"(ae), "+v"(ao));
 #else
+                    __builtin_amdgcn_s_setprio(2);  // experiment: the short recurrence outranks the partner's MFMAs
                     double2 c[8];
 #pragma unroll
                     for (int j = 0; j < 8; j++) c[j] = sc[8 * ms + j];
@@ -373,6 +374,7 @@ legendre_kernel(int lmax, int npair, int nring, int ncols, const double *__restr
                             if (j == 1) ao = vv;
                         }
                     }
+                    __builtin_amdgcn_s_setprio(0);
 #endif
                     if (__all(my_ls > l0 + 7)) continue;  // all A operands of this macro-step are zero
                     const double *be = sb + (8 * ms + d) * STRIDE + ri;
