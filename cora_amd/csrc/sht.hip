@@ -591,15 +591,16 @@ __device__ __forceinline__ static void fft_pass(double2 *buf, int bstride, int n
         for (int r = 0; r < R; r++) x[r] = cbuf[fpad(i0 + r * q)];
         // twiddles w_Ls^{SIGN j r}: only the binary powers w, w^2, w^4, w^8 are kept in registers and
         // x[r] is multiplied by the ones its index selects (16 VGPRs instead of a 64-VGPR power table)
-        double2 wp[4];
+        constexpr int NB = R == 16 ? 4 : (R == 8 ? 3 : (R == 4 ? 2 : 1));
+        double2 wp[NB];
         wp[0] = tw_get<SIGN>(tw, pmax, j * twstep);
 #pragma unroll
-        for (int b = 1; b < 4; b++) wp[b] = cmul(wp[b - 1], wp[b - 1]);
+        for (int b = 1; b < NB; b++) wp[b] = cmul(wp[b - 1], wp[b - 1]);
         auto twiddle_all = [&]() {
 #pragma unroll
             for (int r = 1; r < R; r++) {
 #pragma unroll
-                for (int b = 0; b < 4; b++)
+                for (int b = 0; b < NB; b++)
                     if (r & (1 << b)) x[r] = cmul(x[r], wp[b]);
             }
         };
@@ -616,17 +617,22 @@ __device__ __forceinline__ static void fft_pass(double2 *buf, int bstride, int n
     __syncthreads();
 }
 
-// pass schedule for N = 2^k: radix 16 while k >= 4, then the remainder
+#ifndef K5_RADIX
+#define K5_RADIX 16    // largest butterfly: 16 -> 512-thread workgroups; 8 -> 1024 threads (<= 128 VGPRs: measured 30 % slower, spills)
+#endif
+#define K5_LOGR (K5_RADIX == 16 ? 4 : 3)
+#define K5_THREADS (K5_RADIX == 16 ? 512 : 1024)
+// pass schedule for N = 2^k: radix K5_RADIX while it fits, then the remainder
 // `postmul` (optional) is multiplied into the output of the LAST pass, indexed by storage position
 template <int SIGN>
 __device__ __forceinline__ static void fft_dif(double2 *buf, int bstride, int nch, int N, const double2 *__restrict__ tw, int pmax,
                                                const double2 *__restrict__ postmul = nullptr) {
     int Ls = N;
-    while (Ls >= 16) {
-        fft_pass<16, SIGN, false>(buf, bstride, nch, N, Ls, tw, pmax, Ls == 16 ? postmul : nullptr);
-        Ls >>= 4;
+    while (Ls >= K5_RADIX) {
+        fft_pass<K5_RADIX, SIGN, false>(buf, bstride, nch, N, Ls, tw, pmax, Ls == K5_RADIX ? postmul : nullptr);
+        Ls >>= K5_LOGR;
     }
-    if (Ls == 8) fft_pass<8, SIGN, false>(buf, bstride, nch, N, Ls, tw, pmax, postmul);
+    if (K5_RADIX == 16 && Ls == 8) fft_pass<8, SIGN, false>(buf, bstride, nch, N, Ls, tw, pmax, postmul);
     else if (Ls == 4) fft_pass<4, SIGN, false>(buf, bstride, nch, N, Ls, tw, pmax, postmul);
     else if (Ls == 2) fft_pass<2, SIGN, false>(buf, bstride, nch, N, Ls, tw, pmax, postmul);
 }
@@ -634,25 +640,25 @@ __device__ __forceinline__ static void fft_dif(double2 *buf, int bstride, int nc
 template <int SIGN>
 __device__ __forceinline__ static void fft_dit(double2 *buf, int bstride, int nch, int N, const double2 *__restrict__ tw, int pmax) {
     int rem = N;
-    while (rem >= 16) rem >>= 4;  // remainder radix handled first (it was last in DIF)
+    while (rem >= K5_RADIX) rem >>= K5_LOGR;  // remainder radix handled first (it was last in DIF)
     int Ls = rem;
-    if (rem == 8) fft_pass<8, SIGN, true>(buf, bstride, nch, N, Ls, tw, pmax);
+    if (K5_RADIX == 16 && rem == 8) fft_pass<8, SIGN, true>(buf, bstride, nch, N, Ls, tw, pmax);
     else if (rem == 4) fft_pass<4, SIGN, true>(buf, bstride, nch, N, Ls, tw, pmax);
     else if (rem == 2) fft_pass<2, SIGN, true>(buf, bstride, nch, N, Ls, tw, pmax);
     if (rem == 1) Ls = 1;
     while (Ls < N) {
-        Ls <<= 4;
-        fft_pass<16, SIGN, true>(buf, bstride, nch, N, Ls, tw, pmax);
+        Ls <<= K5_LOGR;
+        fft_pass<K5_RADIX, SIGN, true>(buf, bstride, nch, N, Ls, tw, pmax);
     }
 }
 // position of frequency index k in the digit-reversed output of fft_dif
 __device__ static inline int fft_dif_pos(int k, int N) {
     int pos = 0, len = N, Ls = N;
-    while (Ls >= 16) {
-        len >>= 4;
-        pos += (k & 15) * len;
-        k >>= 4;
-        Ls >>= 4;
+    while (Ls >= K5_RADIX) {
+        len >>= K5_LOGR;
+        pos += (k & (K5_RADIX - 1)) * len;
+        k >>= K5_LOGR;
+        Ls >>= K5_LOGR;
     }
     if (Ls > 1) {
         len /= Ls;
@@ -694,7 +700,7 @@ bluestein_table_kernel(const int32_t *__restrict__ blu_P, const int64_t *__restr
 // registers while the current item is in its FFT passes, so HBM reads overlap the FP64 work and the
 // pixel stores of one item drain during the next.  P > 0: Bluestein of length P; P == 0: h = nphi/2
 // is a power of two.
-#define K5_MC 4  // cells per thread held in registers for the next item (the rest is read in place)
+#define K5_MC (K5_RADIX == 16 ? 4 : 2)  // cells per thread held in registers for the next item (rest read in place)
 #ifndef K5_STAMPS
 #define K5_STAMPS 0  // diagnostic build: s_memtime phase breakdown
 #endif
@@ -706,7 +712,7 @@ __device__ unsigned long long g_k5_stamps[8];
 #endif
 
 template <int NCH>
-__global__ void __launch_bounds__(512)
+__global__ void __launch_bounds__(K5_THREADS)
 ringfft_kernel(const int32_t *__restrict__ ring_list, int nlist, int nside, int lmax, int G, int nnu, long npix,
                const int32_t *__restrict__ nphi_a, const int64_t *__restrict__ start_a,
                const double *__restrict__ phi0_a, const double *__restrict__ inter, double *__restrict__ maps,
@@ -754,8 +760,10 @@ ringfft_kernel(const int32_t *__restrict__ ring_list, int nlist, int nside, int 
         const int Lr = mcut[ring_list[item / ngrp]];  // cells m >= Lr are exactly zero (and were not written)
         if (tid < Lr) pf0 = load_cell(cell, tid);
         if (tid + nt < Lr) pf1 = load_cell(cell, tid + nt);
-        if (tid + 2 * nt < Lr) pf2 = load_cell(cell, tid + 2 * nt);
-        if (tid + 3 * nt < Lr) pf3 = load_cell(cell, tid + 3 * nt);
+        if (K5_MC > 2) {
+            if (tid + 2 * nt < Lr) pf2 = load_cell(cell, tid + 2 * nt);
+            if (tid + 3 * nt < Lr) pf3 = load_cell(cell, tid + 3 * nt);
+        }
     };
 
 #if K5_STAMPS
@@ -829,10 +837,12 @@ ringfft_kernel(const int32_t *__restrict__ ring_list, int nlist, int nside, int 
         if (tid < Lr) fold_one(tid, pf0);
         ph = cmul(ph, phstep);
         if (tid + nt < Lr) fold_one(tid + nt, pf1);
-        ph = cmul(ph, phstep);
-        if (tid + 2 * nt < Lr) fold_one(tid + 2 * nt, pf2);
-        ph = cmul(ph, phstep);
-        if (tid + 3 * nt < Lr) fold_one(tid + 3 * nt, pf3);
+        if (K5_MC > 2) {
+            ph = cmul(ph, phstep);
+            if (tid + 2 * nt < Lr) fold_one(tid + 2 * nt, pf2);
+            ph = cmul(ph, phstep);
+            if (tid + 3 * nt < Lr) fold_one(tid + 3 * nt, pf3);
+        }
         for (int m = tid + K5_MC * nt; m < Lr; m += nt) {
             ph = cmul(ph, phstep);
             fold_one(m, load_cell(cell, m));
@@ -1236,7 +1246,7 @@ static int alm2map_chunk(corahip_ctx *ctx, const corahip_sht_plan *p, const doub
     {
         StageTimer t(ctx, "ringfft");
         const int G = nnu_chunk_pad / 4;
-        const int k5_threads = getenv("CORAHIP_K5_THREADS") ? atoi(getenv("CORAHIP_K5_THREADS")) : 512;
+        const int k5_threads = K5_THREADS;
         for (const auto &c : p->classes) {
             const size_t shm = sizeof(double2) * (size_t)c.nch * c.bstride;
             const long nitems = (long)c.count * ((nnu_valid + c.nch - 1) / c.nch);
