@@ -59,6 +59,10 @@ def main():
     ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--warm", action="store_true", help="time the warm path only (factors cached)")
+    # test hooks (not used by the driver): run N ranks on ONE GPU over gloo and print per-channel checksums
+    ap.add_argument("--dist-backend", default="nccl")
+    ap.add_argument("--same-device", action="store_true")
+    ap.add_argument("--checksum", action="store_true")
     args = ap.parse_args()
 
     import torch
@@ -71,13 +75,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
+    if args.same_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.dist_backend)
 
     model_name, F, nu_lo, nu_hi, nside, lmax, zromb = WORKLOADS[args.workload]
     L = lmax + 1
@@ -177,6 +186,18 @@ def main():
     # sanity: the maps of the last step are finite and have the expected variance scale
     chk = float(maps_buf[0, ::4097].std().item())
     assert os.environ.get("CORAHIP_LIB") or (np.isfinite(chk) and chk > 0)  # (diagnostic builds skip the check)
+
+    if args.checksum:
+        # per-channel (mean, rms) of the last realisation, gathered in channel order: identical for any N
+        st = torch.stack([maps_buf.mean(dim=1), (maps_buf**2).mean(dim=1).sqrt()], dim=1).cpu()
+        if dist is not None:
+            parts = [None] * world
+            dist.all_gather_object(parts, (nu0, st))
+            st = torch.cat([p[1] for p in sorted(parts, key=lambda x: x[0])])
+        if rank == 0:
+            import hashlib
+
+            print("CHECKSUM", hashlib.sha1(st.numpy().round(decimals=14).tobytes()).hexdigest(), float(st[:, 1].sum()), file=sys.stderr)
 
     result = None
     if rank == 0:

@@ -512,3 +512,28 @@ def test_config3_full_size_properties(ctx):
     assert worst < 1e-11 * ms.std().item(), worst
     del maps, alm
     torch.cuda.empty_cache()
+
+
+def test_frequency_sharded_pipeline_matches_single_gpu():
+    """bench.py's N-rank path (l-sharded C_l/factor -> all-gather -> nu-sharded draw + synthesis), run as
+    2 and 4 ranks sharing this one GPU over gloo, gives the same per-channel map statistics as 1 rank."""
+    import os
+    import re
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["--workload", "cfg2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--checksum"]
+
+    def run(cmd):
+        p = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=600)
+        m = re.search(r"CHECKSUM (\w+)", p.stderr)
+        assert m, p.stderr[-2000:]
+        return m.group(1)
+
+    ref = run([sys.executable, "bench.py"] + common)
+    for n, port in ((2, 29631), (4, 29632)):
+        got = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+                   "--master-addr", "127.0.0.1", "--master-port", str(port), "bench.py", "--gpus", str(n),
+                   "--dist-backend", "gloo", "--same-device"] + common)
+        assert got == ref, (n, got, ref)
