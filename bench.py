@@ -63,6 +63,7 @@ def main():
     ap.add_argument("--dist-backend", default="nccl")
     ap.add_argument("--same-device", action="store_true")
     ap.add_argument("--checksum", action="store_true")
+    ap.add_argument("--emulate-shard", type=int, default=0, help="time the work of the LAST rank of an N-rank job, no comm")
     args = ap.parse_args()
 
     import torch
@@ -95,6 +96,11 @@ def main():
     from cora_amd.parallel import allgather_factors, shard_plan
 
     sp = shard_plan(L, F, rank, world)
+    if args.emulate_shard > 1:
+        # worst rank per stage: rank 0 has the widest table range in K1, the last rank the full RNG in K3
+        sp = shard_plan(L, F, args.emulate_shard - 1, args.emulate_shard)
+        sp0 = shard_plan(L, F, 0, args.emulate_shard)
+        sp.l_lo, sp.l_hi = sp0.l_lo, sp0.l_hi
     nnu, nu0 = sp.nnu, sp.nu0
 
     ctx = _lib.get_context(local_rank)
@@ -138,11 +144,19 @@ def main():
     def cold_factors():
         C = run_k1()
         T, info = ctx.factor_batched(C)
+        if args.emulate_shard > 1:
+            return cached_full["f"]
         if world == 1:
             return T, info
         return allgather_factors(T, info, sp)  # the single exchange step (RCCL all-gather)
 
     cached = {}
+    cached_full = {}
+    if args.emulate_shard > 1:
+        Cf = ctx.empty((L, F, F)).normal_()
+        Cf = Cf @ Cf.transpose(1, 2) + 0.1 * torch.eye(F, device=ctx.device, dtype=torch.float64)
+        cached_full["f"] = ctx.factor_batched(Cf)
+        del Cf
 
     def step():
         if args.warm:

@@ -67,8 +67,10 @@ clarray21_kernel(const double *__restrict__ tt, int nkperp, int nkpar, double kp
         lxs[k] = (li < nl_total ? log10l[li] : 0.0) * xscale;
         acc[k] = 0.0;
     }
-    // rows the l range can touch: x <= x(l_max) + 1 (x is monotone in l); log10l is ascending
-    const double lx_hi = log10l[min(nl_total, l_base + 256 * CL_LPT) - 1] * xscale;
+    // rows the l range can touch: x(l_first) <= x <= x(l_last) + 1 (x is monotone in l; log10l ascending)
+    const int l_end = min(nl_total, l_base + 256 * CL_LPT);
+    const double lx_lo = log10l[l_base] * xscale, lx_hi = log10l[l_end - 1] * xscale;
+    const int kmax = (l_end - l_base + 255) / 256;  // multipoles per thread actually present
 
     for (int a = 0; a < zint; a++) {
         const int za = i * zint + a;
@@ -95,13 +97,15 @@ clarray21_kernel(const double *__restrict__ tt, int nkperp, int nkpar, double kp
             const double cvv = W * fz[za] * fz[zb];
             const double c0 = cdd * (1.0 - wy), c1 = cdd * wy, c2 = cdv * (1.0 - wy), c3 = cdv * wy;
             const double c4 = cvv * (1.0 - wy), c5 = cvv * wy;
-            double xhi = lx_hi - lxc;
+            double xhi = lx_hi - lxc, xlo = lx_lo - lxc;
             xhi = xhi < 0.0 ? 0.0 : (xhi > ux ? ux : xhi);
-            const int nx = min((int)xhi + 2, nkperp);  // rows 0 .. nx-1 are needed
+            xlo = xlo < 0.0 ? 0.0 : (xlo > ux ? ux : xlo);
+            const int nx = min((int)xhi + 2, nkperp);  // rows x0 .. nx-1 are needed
+            const int x0r = (int)xlo;
             nx_max = max(nx_max, nx);
             const double *r0 = tt + (size_t)y0 * CL_XS, *r1 = r0 + CL_XS;
             double *pb = prof + b * PS;
-            for (int x = tid; x < nx; x += 256)
+            for (int x = x0r + tid; x < nx; x += 256)
                 pb[x] = c0 * r0[x] + c1 * r1[x] + c2 * r0[tsz + x] + c3 * r1[tsz + x] + c4 * r0[2 * tsz + x] +
                         c5 * r1[2 * tsz + x];
             if (tid == 0) {
@@ -113,6 +117,7 @@ clarray21_kernel(const double *__restrict__ tt, int nkperp, int nkpar, double kp
         // ---- 1-D interpolation for this thread's multipoles
 #pragma unroll
         for (int k = 0; k < CL_LPT; k++) {
+            if (k >= kmax) break;  // uniform: l-sharded callers pass short l ranges
             double s = 0.0;
             for (int b = 0; b < zint; b++) {
                 double xx = lxs[k] - lxcs_s[b];

@@ -188,7 +188,7 @@ __device__ static inline void draw_glds16(const void *gsrc, unsigned lds_byte_ad
 }
 
 template <int NCT>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 2)
 draw_rng_kernel(const double *__restrict__ T, const int32_t *__restrict__ info, const double *__restrict__ zeros,
                 uint64_t seed, int lmax, int F, int nu0, int nnu, int Gout, double *__restrict__ alm) {
     constexpr int NC = 16 * NCT;
@@ -253,7 +253,7 @@ draw_rng_kernel(const double *__restrict__ T, const int32_t *__restrict__ info, 
         if (!wave_has_rows) continue;
         const double *sb = lds + (c & 1) * BUF;
         const int k0 = c * DRAW_KC;
-#pragma unroll 2
+#pragma unroll 1
         for (int kk = 0; kk < DRAW_KC / 4; kk++) {
             const int kbase = k0 + 4 * kk;
             if (kbase >= kmax) break;
