@@ -197,7 +197,10 @@ __device__ static inline void glds16(const void *gsrc, unsigned lds_byte_addr) {
 // (odd).  No cross-lane movement, no selects; the price is that the recurrence coefficients are
 // no longer wave-uniform (4 distinct rows per step) - they are staged through LDS with the a_lm
 // rows and read with one broadcast ds_read_b128 per step.
-template <int NT>
+// NT = 16-column tiles per wave, RT = 16-ring row tiles per wave (RT x NT x 2 parities = 16 accumulator
+// tiles = 128 VGPRs in both shipped shapes: <8,1> for >= 128 columns, <4,2> for 64-column shards, where a
+// second, independent recurrence per lane keeps the recurrence : MFMA ratio of the wide shape).
+template <int NT, int RT>
 __global__ void __launch_bounds__(512)
 legendre_kernel(int lmax, int npair, int nring, int ncols, const double *__restrict__ z,
                 const double2 *__restrict__ coef, const int32_t *__restrict__ lstart,
@@ -210,6 +213,7 @@ legendre_kernel(int lmax, int npair, int nring, int ncols, const double *__restr
     constexpr int STAGE = LEG_KT * STRIDE + 2 * CROWS;  // doubles per stage: a_lm rows + (A,B) pairs
     constexpr int RPW = LEG_KT / LEG_WAVES;             // a_lm rows each wave moves per stage
     constexpr int PIECES = RPW + 1;                     // LDS-DMA pieces per wave per stage (+ coefficients)
+    constexpr int TRINGS = LEG_RINGS * RT;              // ring pairs per workgroup
     static_assert(RPW == LEG_KT / 8, "one a_lm piece per macro-step");
     extern __shared__ __attribute__((aligned(16))) double lds[];
     int &s_next = *reinterpret_cast<int *>(lds + LEG_NBUF * STAGE);  // next work item (carved after the ring)
@@ -221,7 +225,8 @@ legendre_kernel(int lmax, int npair, int nring, int ncols, const double *__restr
     const int d = 2 * kq;
     const int L = lmax + 1;
     const int G = ncols >> 3;
-    const int ntile = (npair + LEG_RINGS - 1) / LEG_RINGS;
+    const int ntile128 = (npair + LEG_RINGS - 1) / LEG_RINGS;   // granularity of lmin_tab
+    const int ntile = (npair + TRINGS - 1) / TRINGS;
     const int ncg = ncols / TCOLS;
     const int nitems = L * ncg * ntile;
     const long last_row = nalm_of(lmax) - 1;
@@ -242,7 +247,12 @@ legendre_kernel(int lmax, int npair, int nring, int ncols, const double *__restr
         w.rtile = it - gidx * ntile;
         w.m = gidx / ncg;
         w.cg = gidx - w.m * ncg;
-        const int lmin = lmin_tab[w.m * ntile + w.rtile];
+        int lmin = lmax + 1;
+#pragma unroll
+        for (int q = 0; q < RT; q++) {
+            const int t128 = w.rtile * RT + q;
+            if (t128 < ntile128) lmin = min(lmin, lmin_tab[w.m * ntile128 + t128]);
+        }
         w.l_begin = w.m + ((lmin - w.m) & ~7);
         w.nstage = lmin <= lmax ? (lmax - w.l_begin) / LEG_KT + 1 : 0;
         w.base_m = alm_idx(0, w.m, lmax);
@@ -283,42 +293,51 @@ legendre_kernel(int lmax, int npair, int nring, int ncols, const double *__restr
     for (;;) {
         const int m = w.m;
         if (tid == 0) s_next = (int)(gridDim.x + atomicAdd(queue, 1u));  // latency hidden behind this item
-        // rings are dealt to the waves interleaved (ring = tile base + 8 ri + wave) so that every wave of
-        // the workgroup has the same mix of first-contributing l and reaches the stage barriers together
-        const int ring = w.rtile * LEG_RINGS + ri * LEG_WAVES + wave;
-        d4_t acce[NT], acco[NT];
+        d4_t acce[RT][NT], acco[RT][NT];
 #pragma unroll
-        for (int t = 0; t < NT; t++) {
-            acce[t] = (d4_t){0.0, 0.0, 0.0, 0.0};
-            acco[t] = (d4_t){0.0, 0.0, 0.0, 0.0};
-        }
-        if (w.nstage > 0) {
-            double x = 0.0;
-            int my_ls = lmax + 1;
-            double2 sd = make_double2(0.0, 0.0);
-            if (ring < npair) {
-                x = z[ring];
-                const long o = (long)m * npair + ring;
-                my_ls = lstart[o];
-                sd = seed[o];
+        for (int q = 0; q < RT; q++)
+#pragma unroll
+            for (int t = 0; t < NT; t++) {
+                acce[q][t] = (d4_t){0.0, 0.0, 0.0, 0.0};
+                acco[q][t] = (d4_t){0.0, 0.0, 0.0, 0.0};
             }
+        if (w.nstage > 0) {
+            // rings are dealt to the waves interleaved (ring = tile base + 8 (ri + 16 q) + wave) so that every
+            // wave of the workgroup has the same mix of first-contributing l and reaches the barriers together
+            double x[RT], p0[RT], p1[RT];
+            double2 sd[RT];
+            int my_ls[RT], inj_l[RT];
             const double2 *cf = coef + w.base_m;
-            // per-lane start state: (lambda_{lf-2}, lambda_{lf-1}) with lf = l_begin + d the first l of this
-            // lane.  If the ring's first contributing l lies before lf, advance from the seeds.
-            double p0 = 0.0, p1 = 0.0;
-            int inj_l = my_ls;  // l at which the seeds are injected
-            {
+            int ls_min = lmax + 1;
+#pragma unroll
+            for (int q = 0; q < RT; q++) {
+                const int ring = w.rtile * TRINGS + (ri + 16 * q) * LEG_WAVES + wave;
+                x[q] = 0.0;
+                my_ls[q] = lmax + 1;
+                sd[q] = make_double2(0.0, 0.0);
+                if (ring < npair) {
+                    x[q] = z[ring];
+                    const long o = (long)m * npair + ring;
+                    my_ls[q] = lstart[o];
+                    sd[q] = seed[o];
+                }
+                ls_min = min(ls_min, my_ls[q]);
+                // per-lane start state: (lambda_{lf-2}, lambda_{lf-1}) with lf = l_begin + d the first l of this
+                // lane.  If the ring's first contributing l lies before lf, advance from the seeds.
+                p0[q] = 0.0;
+                p1[q] = 0.0;
+                inj_l[q] = my_ls[q];  // l at which the seeds are injected
                 const int lf = w.l_begin + d;
-                if (my_ls < lf) {
-                    p0 = sd.x;
-                    p1 = sd.y;
-                    for (int l = my_ls + 1; l < lf; l++) {
+                if (my_ls[q] < lf) {
+                    p0[q] = sd[q].x;
+                    p1[q] = sd[q].y;
+                    for (int l = my_ls[q] + 1; l < lf; l++) {
                         const double2 c = (l <= lmax) ? cf[l] : make_double2(0.0, 0.0);
-                        const double vv = fma(c.x * x, p1, -(c.y * p0));
-                        p0 = p1;
-                        p1 = vv;
+                        const double vv = fma(c.x * x[q], p1[q], -(c.y * p0[q]));
+                        p0[q] = p1[q];
+                        p1[q] = vv;
                     }
-                    inj_l = 0x7fffffff;
+                    inj_l[q] = 0x7fffffff;
                 }
             }
 
@@ -342,50 +361,67 @@ legendre_kernel(int lmax, int npair, int nring, int ncols, const double *__restr
                     const int l0 = ls + 8 * ms;
                     if (l0 > lmax) continue;
                     // nothing of this wave starts before l0+14: skip the macro-step entirely
-                    if (__all(my_ls > l0 + 13)) continue;
+                    if (__all(ls_min > l0 + 13)) continue;
+                    double ae[RT], ao[RT];
 #if LEG_ABLATE == 2  // diagnostic: no recurrence
-                    double ae = x, ao = x + 1.0;
-                    asm volatile("" : "+v"(ae), "+v"(ao));
+#pragma unroll
+                    for (int q = 0; q < RT; q++) {
+                        ae[q] = x[q];
+                        ao[q] = x[q] + 1.0;
+                        asm volatile("" : "+v"(ae[q]), "+v"(ao[q]));
+                    }
 #else
-                    __builtin_amdgcn_s_setprio(2);  // experiment: the short recurrence outranks the partner's MFMAs
+                    __builtin_amdgcn_s_setprio(2);  // the short recurrence outranks the partner wave's MFMAs
                     double2 c[8];
 #pragma unroll
                     for (int j = 0; j < 8; j++) c[j] = sc[8 * ms + j];
-                    double ae, ao;
                     const int lf = l0 + d;
-                    if (__any(inj_l >= lf && inj_l < lf + 8)) {
+                    bool any_inj = false;
 #pragma unroll
-                        for (int j = 0; j < 8; j++) {
-                            double vv = fma(c[j].x * x, p1, -(c[j].y * p0));
-                            const bool inj = (lf + j == inj_l);
-                            vv = inj ? sd.y : vv;
-                            p0 = inj ? sd.x : p1;
-                            p1 = vv;
-                            if (j == 0) ae = vv;
-                            if (j == 1) ao = vv;
+                    for (int q = 0; q < RT; q++) any_inj |= (inj_l[q] >= lf && inj_l[q] < lf + 8);
+                    if (__any(any_inj)) {
+#pragma unroll
+                        for (int q = 0; q < RT; q++) {
+#pragma unroll
+                            for (int j = 0; j < 8; j++) {
+                                double vv = fma(c[j].x * x[q], p1[q], -(c[j].y * p0[q]));
+                                const bool inj = (lf + j == inj_l[q]);
+                                vv = inj ? sd[q].y : vv;
+                                p0[q] = inj ? sd[q].x : p1[q];
+                                p1[q] = vv;
+                                if (j == 0) ae[q] = vv;
+                                if (j == 1) ao[q] = vv;
+                            }
                         }
                     } else {
 #pragma unroll
                         for (int j = 0; j < 8; j++) {
-                            const double vv = fma(c[j].x * x, p1, -(c[j].y * p0));
-                            p0 = p1;
-                            p1 = vv;
-                            if (j == 0) ae = vv;
-                            if (j == 1) ao = vv;
+#pragma unroll
+                            for (int q = 0; q < RT; q++) {
+                                const double vv = fma(c[j].x * x[q], p1[q], -(c[j].y * p0[q]));
+                                p0[q] = p1[q];
+                                p1[q] = vv;
+                                if (j == 0) ae[q] = vv;
+                                if (j == 1) ao[q] = vv;
+                            }
                         }
                     }
                     __builtin_amdgcn_s_setprio(0);
 #endif
-                    if (__all(my_ls > l0 + 7)) continue;  // all A operands of this macro-step are zero
+                    if (__all(ls_min > l0 + 7)) continue;  // all A operands of this macro-step are zero
                     const double *be = sb + (8 * ms + d) * STRIDE + ri;
                     const double *bo = be + STRIDE;
 #if LEG_ABLATE == 1  // diagnostic: no MFMA (keep the operands alive)
-                    asm volatile("" ::"v"(ae), "v"(ao), "v"(be), "v"(bo));
+                    asm volatile("" ::"v"(ae[0]), "v"(ao[0]), "v"(be), "v"(bo));
 #else
 #pragma unroll
                     for (int t = 0; t < NT; t++) {
-                        acce[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(ae, be[16 * t], acce[t], 0, 0, 0);
-                        acco[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(ao, bo[16 * t], acco[t], 0, 0, 0);
+                        const double bev = be[16 * t], bov = bo[16 * t];
+#pragma unroll
+                        for (int q = 0; q < RT; q++) {
+                            acce[q][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(ae[q], bev, acce[q][t], 0, 0, 0);
+                            acco[q][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(ao[q], bov, acco[q][t], 0, 0, 0);
+                        }
                     }
 #endif
                 }
@@ -407,31 +443,34 @@ legendre_kernel(int lmax, int npair, int nring, int ncols, const double *__restr
         // ---- epilogue: north = even + odd, south mirror = even - odd.  Adjacent lanes (columns n, n+1 of the
         //      same rows) swap one value each so that every lane stores 16 bytes: half the store instructions.
         //      A tile with no contributing l at all is not written: K5 never reads cells with m >= mcut(ring).
-        if (cur_nstage > 0)
+        if (cur_nstage > 0) {
 #pragma unroll
-        for (int t = 0; t < NT; t++) {
-            const int col = cur_cg * TCOLS + 16 * t + (ri & ~1);  // even column of the lane pair
-            const int g = col >> 3, cv = col & 7;
+            for (int q = 0; q < RT; q++)
 #pragma unroll
-            for (int rp = 0; rp < 2; rp++) {
-                const int r0 = 2 * rp, r1 = 2 * rp + 1;
-                const double n0 = acce[t][r0] + acco[t][r0], n1 = acce[t][r1] + acco[t][r1];
-                const double s0 = acce[t][r0] - acco[t][r0], s1 = acce[t][r1] - acco[t][r1];
-                // even lane keeps row r0 and sends its r1 value; odd lane keeps row r1 and sends its r0 value
-                const double nrecv = __shfl_xor(odd_lane ? n0 : n1, 1);
-                const double srecv = __shfl_xor(odd_lane ? s0 : s1, 1);
-                const int rr = odd_lane ? r1 : r0;
-                const int ro = cur_rtile * LEG_RINGS + (kq + 4 * rr) * LEG_WAVES + wave;
-                if (ro < npair) {
-                    const double2 nv = odd_lane ? make_double2(nrecv, n1) : make_double2(n0, nrecv);
-                    *reinterpret_cast<double2 *>(inter + (((size_t)ro * G + g) * L + cur_m) * 8 + cv) = nv;
-                    const int rs = nring - 1 - ro;
-                    if (rs != ro) {
-                        const double2 sv = odd_lane ? make_double2(srecv, s1) : make_double2(s0, srecv);
-                        *reinterpret_cast<double2 *>(inter + (((size_t)rs * G + g) * L + cur_m) * 8 + cv) = sv;
+                for (int t = 0; t < NT; t++) {
+                    const int col = cur_cg * TCOLS + 16 * t + (ri & ~1);  // even column of the lane pair
+                    const int g = col >> 3, cv = col & 7;
+#pragma unroll
+                    for (int rp = 0; rp < 2; rp++) {
+                        const int r0 = 2 * rp, r1 = 2 * rp + 1;
+                        const double n0 = acce[q][t][r0] + acco[q][t][r0], n1 = acce[q][t][r1] + acco[q][t][r1];
+                        const double s0 = acce[q][t][r0] - acco[q][t][r0], s1 = acce[q][t][r1] - acco[q][t][r1];
+                        // even lane keeps row r0 and sends its r1 value; odd lane keeps row r1 and sends its r0 value
+                        const double nrecv = __shfl_xor(odd_lane ? n0 : n1, 1);
+                        const double srecv = __shfl_xor(odd_lane ? s0 : s1, 1);
+                        const int rr = odd_lane ? r1 : r0;
+                        const int ro = cur_rtile * TRINGS + (kq + 4 * rr + 16 * q) * LEG_WAVES + wave;
+                        if (ro < npair) {
+                            const double2 nv = odd_lane ? make_double2(nrecv, n1) : make_double2(n0, nrecv);
+                            *reinterpret_cast<double2 *>(inter + (((size_t)ro * G + g) * L + cur_m) * 8 + cv) = nv;
+                            const int rs = nring - 1 - ro;
+                            if (rs != ro) {
+                                const double2 sv = odd_lane ? make_double2(srecv, s1) : make_double2(s0, srecv);
+                                *reinterpret_cast<double2 *>(inter + (((size_t)rs * G + g) * L + cur_m) * 8 + cv) = sv;
+                            }
+                        }
                     }
                 }
-            }
         }
         if (!have_next) break;
         __syncthreads();  // everyone has read s_next before thread 0 overwrites it
@@ -1210,21 +1249,21 @@ extern "C" int corahip_alm2map_workspace_bytes(const corahip_sht_plan *p, int nn
     return 0;
 }
 
-template <int NT>
+template <int NT, int RT>
 static int launch_legendre(corahip_ctx *ctx, const corahip_sht_plan *p, int ncols, const double *alm, double *inter) {
     constexpr int STRIDE = 16 * NT + 8;
     const size_t shm = sizeof(double) * LEG_NBUF * (LEG_KT * STRIDE + 2 * (LEG_KT + 8)) + 16;
-    HIP_TRY(hipFuncSetAttribute((const void *)legendre_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    HIP_TRY(hipFuncSetAttribute((const void *)legendre_kernel<NT, RT>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)shm));
-    const int ntile = (p->npair + LEG_RINGS - 1) / LEG_RINGS;
+    const int ntile = (p->npair + LEG_RINGS * RT - 1) / (LEG_RINGS * RT);
     const long nitems = (long)p->L * (ncols / (16 * NT)) * ntile;
     // persistent: as many workgroups as fit (LDS-limited: one per CU for NT = 8)
     const int per_cu = std::max<int>(1, std::min<int>(2, (int)((160 * 1024) / shm)));
     dim3 grid((unsigned)std::min<long>(nitems, (long)ctx->num_cu * per_cu));
     HIP_TRY(hipMemsetAsync(p->d_queue, 0, 64, ctx->stream));
-    legendre_kernel<NT><<<grid, 64 * LEG_WAVES, shm, ctx->stream>>>(p->lmax, p->npair, p->nring, ncols, p->d_z,
-                                                                   p->d_coef, p->d_lstart, p->d_seed, p->d_lmin, alm,
-                                                                   p->d_zeros, inter, p->d_queue);
+    legendre_kernel<NT, RT><<<grid, 64 * LEG_WAVES, shm, ctx->stream>>>(p->lmax, p->npair, p->nring, ncols, p->d_z,
+                                                                       p->d_coef, p->d_lstart, p->d_seed, p->d_lmin,
+                                                                       alm, p->d_zeros, inter, p->d_queue);
     LAUNCH_CHECK();
     return 0;
 }
@@ -1237,10 +1276,10 @@ static int alm2map_chunk(corahip_ctx *ctx, const corahip_sht_plan *p, const doub
     int rc;
     {
         StageTimer t(ctx, "legendre");
-        if (ntile % 8 == 0) rc = launch_legendre<8>(ctx, p, ncols, alm_chunk, inter);
-        else if (ntile % 4 == 0) rc = launch_legendre<4>(ctx, p, ncols, alm_chunk, inter);
-        else if (ntile % 2 == 0) rc = launch_legendre<2>(ctx, p, ncols, alm_chunk, inter);
-        else rc = launch_legendre<1>(ctx, p, ncols, alm_chunk, inter);
+        if (ntile % 8 == 0) rc = launch_legendre<8, 1>(ctx, p, ncols, alm_chunk, inter);
+        else if (ntile % 4 == 0) rc = launch_legendre<4, 2>(ctx, p, ncols, alm_chunk, inter);
+        else if (ntile % 2 == 0) rc = launch_legendre<2, 2>(ctx, p, ncols, alm_chunk, inter);
+        else rc = launch_legendre<1, 2>(ctx, p, ncols, alm_chunk, inter);
         if (rc) return rc;
     }
     {
