@@ -706,6 +706,97 @@ __device__ static inline int fft_dif_pos(int k, int N) {
     return pos;
 }
 
+// ---- Bluestein convolution with the middle and the end kept in registers ----------------------
+// forward DIF: every pass but the last
+template <int SIGN>
+__device__ __forceinline__ static int fft_dif_head(double2 *buf, int bstride, int nch, int N, const double2 *__restrict__ tw, int pmax) {
+    int Ls = N;
+    while (Ls > K5_RADIX) {   // stop with the final sub-length (<= K5_RADIX) left
+        fft_pass<K5_RADIX, SIGN, false>(buf, bstride, nch, N, Ls, tw, pmax);
+        Ls >>= K5_LOGR;
+    }
+    return Ls;  // radix of the last forward pass == radix of the first inverse pass (stride 1)
+}
+// last forward pass (DFT_R, sign -), pointwise filter, first inverse pass (DFT_R, sign +): both act on the
+// same R consecutive storage positions and their twiddles are 1, so the data never leaves the registers
+template <int R>
+__device__ __forceinline__ static void fft_mid_fused(double2 *buf, int bstride, int nch, int N,
+                                                     const double2 *__restrict__ filt) {
+    const int nb = N / R;
+    const int total = nch * nb;
+    for (int idx = threadIdx.x; idx < total; idx += blockDim.x) {
+        const int ch = idx / nb, b = idx - ch * nb;
+        double2 *cbuf = buf + (size_t)ch * bstride;
+        const int i0 = b * R;
+        double2 x[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) x[r] = cbuf[fpad(i0 + r)];
+        DftR<R, -1>::run(x);
+#pragma unroll
+        for (int r = 0; r < R; r++) x[r] = cmul(x[r], filt[i0 + r]);
+        DftR<R, 1>::run(x);
+#pragma unroll
+        for (int r = 0; r < R; r++) cbuf[fpad(i0 + r)] = x[r];
+    }
+    __syncthreads();
+}
+// inverse DIT passes after the first one, except the last (Ls == N), which is fft_dit_last_out
+template <int SIGN>
+__device__ __forceinline__ static void fft_dit_middle(double2 *buf, int bstride, int nch, int N, int Ls_first,
+                                                      const double2 *__restrict__ tw, int pmax) {
+    int Ls = Ls_first;
+    while ((Ls << K5_LOGR) < N) {
+        Ls <<= K5_LOGR;
+        fft_pass<K5_RADIX, SIGN, true>(buf, bstride, nch, N, Ls, tw, pmax);
+    }
+}
+// last inverse pass (radix K5_RADIX, Ls = N): results are natural-order j = j0 + r N/R; multiply by the
+// chirp b_j / P and store the pixel pair (2j, 2j+1) of every channel straight to HBM (consecutive lanes ->
+// consecutive j: coalesced 16-byte stores), j < h only.
+template <int SIGN>
+__device__ __forceinline__ static void fft_dit_last_out(const double2 *buf, int bstride, int nch, int N,
+                                                        const double2 *__restrict__ tw, int pmax,
+                                                        const double2 *__restrict__ chirpb, double invP, int h,
+                                                        double *__restrict__ maps, long npix, long start, int ch0,
+                                                        int nnu) {
+    constexpr int R = K5_RADIX;
+    const int q = N / R;
+    const int total = nch * q;
+    const int twstep = pmax / N;
+    for (int idx = threadIdx.x; idx < total; idx += blockDim.x) {
+        const int ch = idx / q, j = idx - ch * q;
+        const double2 *cbuf = buf + (size_t)ch * bstride;
+        double2 x[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) x[r] = cbuf[fpad(j + r * q)];
+        constexpr int NB = R == 16 ? 4 : 3;
+        double2 wp[NB];
+        wp[0] = tw_get<SIGN>(tw, pmax, j * twstep);
+#pragma unroll
+        for (int b = 1; b < NB; b++) wp[b] = cmul(wp[b - 1], wp[b - 1]);
+#pragma unroll
+        for (int r = 1; r < R; r++) {
+#pragma unroll
+            for (int b = 0; b < NB; b++)
+                if (r & (1 << b)) x[r] = cmul(x[r], wp[b]);
+        }
+        DftR<R, SIGN>::run(x);
+        if (ch0 + ch < nnu) {
+            double *out = maps + (size_t)(ch0 + ch) * npix + start;
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const int jj = j + r * q;
+                if (jj < h) {
+                    double2 zv = cmul(x[r], chirpb[jj]);
+                    zv.x *= invP;
+                    zv.y *= invP;
+                    *reinterpret_cast<double2 *>(out + 2 * jj) = zv;
+                }
+            }
+        }
+    }
+}
+
 // Bluestein tables for cap ring i (h = 2i not a power of two): chirp b_j = e^{i pi j^2/h}, j < h,
 // and filt = FFT_P(conj chirp wrapped), stored in the digit-reversed order fft_dif produces.
 __global__ void __launch_bounds__(256)
@@ -946,10 +1037,22 @@ ringfft_kernel(const int32_t *__restrict__ ring_list, int nlist, int nside, int 
             }
         } else {
             const double2 *f = filt + foff[icap - 1];
+            const double invP = 1.0 / (double)P;
+            if (P >= K5_RADIX * K5_RADIX) {
+                // >= 3 passes each way: the filter step and the final chirp/store are fused into the passes
+                const int rl = fft_dif_head<-1>(sm, bstride, NCH, P, tw, pmax);
+                if (rl == 16) fft_mid_fused<16>(sm, bstride, NCH, P, f);
+                else if (rl == 8) fft_mid_fused<8>(sm, bstride, NCH, P, f);
+                else if (rl == 4) fft_mid_fused<4>(sm, bstride, NCH, P, f);
+                else fft_mid_fused<2>(sm, bstride, NCH, P, f);
+                fft_dit_middle<1>(sm, bstride, NCH, P, rl, tw, pmax);
+                fft_dit_last_out<1>(sm, bstride, NCH, P, tw, pmax, bch, invP, h, maps, npix, start, ch0, nnu);
+                K5STAMP(t_fft);
+                continue;
+            }
             fft_dif<-1>(sm, bstride, NCH, P, tw, pmax, f);  // filter multiplied in by the last pass
             fft_dit<1>(sm, bstride, NCH, P, tw, pmax);
             K5STAMP(t_fft);
-            const double invP = 1.0 / (double)P;
             for (int j = tid; j < h; j += nt) {
                 const double2 bj = bch[j];
 #pragma unroll
