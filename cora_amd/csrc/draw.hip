@@ -42,20 +42,96 @@ __device__ static inline void philox4x32_10(uint64_t counter, uint64_t key, uint
     out[3] = c[3];
 }
 
+// Box-Muller in FP64 with short, branch-free kernels (the generic libm log/sincospi cost ~130 DP instructions
+// per pair and made the RNG, not the MFMAs, the bound of K3): every step is accurate to ~1e-16.
+//   ln x   : x = 2^e m, m in [1/sqrt2, sqrt2); c = round(64 m)/64; r = m (1/c) - 1 (one fma, |r| <= 0.0111);
+//            ln x = e ln2 - ln(1/c) + log1p(r), log1p by its degree-8 Taylor polynomial (remainder 3e-17 r).
+//            c = 1 is a centre, so x -> 1 keeps full RELATIVE accuracy (the radius there is sqrt(-2 ln x)).
+//   sqrt t : v_rsq_f64 seed + two Goldschmidt steps + one residual correction.
+//   sin/cos(2 pi u): octant from the top three bits of u (exact), argument in [0, pi/4], the classic
+//            degree-13/14 minimax kernels (Sun fdlibm k_sin/k_cos coefficients; max error 1.1e-16).
+__device__ static const double2 LOG_TAB[47] = {
+#include "log_tab.inc"
+};
+
+__device__ static inline double fast_log01(double x) {  // x in (0, 1]
+    double m = __builtin_amdgcn_frexp_mant(x);           // [0.5, 1)
+    int e = __builtin_amdgcn_frexp_exp(x);
+    const bool lo = m < 0.70710678118654752440;
+    m = lo ? m + m : m;                                  // [1/sqrt2, sqrt2)
+    e = lo ? e - 1 : e;
+    const int i = (int)__builtin_rint(m * 64.0);         // 45 .. 91
+    const double2 tc = LOG_TAB[i - 45];
+    const double r = fma(m, tc.x, -1.0);
+    double p = -1.0 / 8.0;
+    p = fma(p, r, 1.0 / 7.0);
+    p = fma(p, r, -1.0 / 6.0);
+    p = fma(p, r, 1.0 / 5.0);
+    p = fma(p, r, -1.0 / 4.0);
+    p = fma(p, r, 1.0 / 3.0);
+    p = fma(p, r, -1.0 / 2.0);
+    p = fma(p * r, r, r);                                // log1p(r)
+    return fma((double)e, 0.69314718055994530942, tc.y + p);
+}
+
+__device__ static inline double fast_sqrt_pos(double t) {  // t in [0, ~80]
+    const double y = __builtin_amdgcn_rsq(t);
+    double g = t * y, h = 0.5 * y;
+    double r = fma(-h, g, 0.5);
+    g = fma(g, r, g);
+    h = fma(h, r, h);
+    r = fma(-h, g, 0.5);
+    g = fma(g, r, g);
+    h = fma(h, r, h);
+    const double dd = fma(-g, g, t);
+    g = fma(dd, h, g);
+    return t > 0.0 ? g : 0.0;
+}
+
+// cos(2 pi u), sin(2 pi u) for u in (0, 1)
+__device__ static inline void fast_sincos2pi(double u, double &sn, double &cs) {
+    const double a = 8.0 * u;                 // exact
+    const int q = (int)a;                     // octant 0..7 (a < 8 always: u <= 1 - 2^-54 rounds to at most 1.0 ...)
+    const double f = a - (double)q;           // exact, [0, 1)
+    const double g = (q & 1) ? 1.0 - f : f;   // reflect odd octants
+    const double x = g * 0.78539816339744830962;
+    const double z = x * x;
+    double ps = 1.58969099521155010221e-10;
+    ps = fma(ps, z, -2.50507602534068634195e-08);
+    ps = fma(ps, z, 2.75573137070700676789e-06);
+    ps = fma(ps, z, -1.98412698298579493134e-04);
+    ps = fma(ps, z, 8.33333333332248946124e-03);
+    ps = fma(ps, z, -1.66666666666666324348e-01);
+    const double s = fma(x * z, ps, x);
+    double pc = -1.13596475577881948265e-11;
+    pc = fma(pc, z, 2.08757232129817482790e-09);
+    pc = fma(pc, z, -2.75573143513906633035e-07);
+    pc = fma(pc, z, 2.48015872894767294178e-05);
+    pc = fma(pc, z, -1.38888888888741095749e-03);
+    pc = fma(pc, z, 4.16666666666666019037e-02);
+    const double c = fma(z * z, pc, fma(-0.5, z, 1.0));
+    const bool swap = ((q + 1) >> 1) & 1;     // octants 1,2,5,6
+    const double cc = swap ? s : c, ss = swap ? c : s;
+    cs = (((q + 2) >> 2) & 1) ? -cc : cc;     // octants 2..5
+    sn = (q & 4) ? -ss : ss;                  // octants 4..7
+}
+
 // The device stream: the normals of (l, c = re/im, nu', m) and (.., m+1), m even, are the two
-// Box-Muller outputs of Philox counter {lo = m/2, hi = l*2F + c*F + nu'} under key = seed.  A value
-// depends only on (seed, l, c, nu', m): the same for any number of GPUs, and the same whether it is
-// materialised in HBM (normals_kernel, stream-order layout) or generated inside K3.
+// Box-Muller outputs of Philox counter {lo = m/2, hi = l*2F + c*F + nu'} under key = seed:
+//   u1 = (k1 + 0.5) 2^-53, u2 = (k2 + 0.5) 2^-53 with k1 = r0 << 21 | r1 >> 11, k2 = r2 << 21 | r3 >> 11;
+//   (sqrt(-2 ln u1) cos(2 pi u2), sqrt(-2 ln u1) sin(2 pi u2)).
+// A value depends only on (seed, l, c, nu', m): the same for any number of GPUs, and the same whether it is
+// materialised in HBM (normals_kernel, stream-order layout) or generated inside K3.  oracle/philox.py
+// restates the stream in numpy.
 __device__ static inline double2 philox_normal_pair(uint64_t seed, int l, int F, int c, int nup, int mpair) {
     uint32_t r[4];
     const uint64_t ctr = ((uint64_t)((uint32_t)l * 2u * (uint32_t)F + (uint32_t)(c * F + nup)) << 32) | (uint32_t)mpair;
     philox4x32_10(ctr, seed, r);
-    // two uniforms in (0,1) with 53 random bits each
     const double u1 = ((double)(((uint64_t)r[0] << 21) | (r[1] >> 11)) + 0.5) * 0x1p-53;
     const double u2 = ((double)(((uint64_t)r[2] << 21) | (r[3] >> 11)) + 0.5) * 0x1p-53;
-    const double rad = sqrt(-2.0 * log(u1));
+    const double rad = fast_sqrt_pos(-2.0 * fast_log01(u1));
     double sn, cs;
-    sincospi(2.0 * u2, &sn, &cs);
+    fast_sincos2pi(u2, sn, cs);
     return make_double2(rad * cs, rad * sn);
 }
 

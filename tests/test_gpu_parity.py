@@ -237,6 +237,16 @@ def test_draw_fused_rng_equals_materialised_stream(ctx, golden):
     assert np.abs(a[:, 0, l, : l + 1] - ref).max() <= 1e-12 * np.abs(ref).max()
 
 
+def test_philox_normals_match_stream_oracle(ctx):
+    """normals_philox (fast in-kernel log / sqrt / sincos) == numpy restatement of the device stream."""
+    from oracle import philox
+
+    for seed, lmax, F in ((7, 48, 8), (2**40 + 12345, 33, 5)):
+        g = ctx.normals_philox(seed, lmax, F).cpu().numpy()
+        ref = philox.device_normals(seed, lmax, F)
+        assert np.abs(g - ref).max() <= 4e-15 * max(1.0, np.abs(ref).max()), np.abs(g - ref).max()
+
+
 def test_philox_normals_statistics(ctx):
     g = ctx.normals_philox(7, 200, 16).cpu().numpy()
     assert abs(g.mean()) < 5 / np.sqrt(g.size)

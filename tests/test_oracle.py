@@ -257,3 +257,30 @@ def test_alm2map_linearity_and_m0_imag():
     a2 = a.copy()
     a2[: lmax + 1] = a2[: lmax + 1].real  # imaginary part of a_l0 never contributes
     assert np.abs(sht.alm2map(a2, nside, lmax) - ma).max() < 1e-13 * ma.std()
+
+
+def test_philox4x32_10_known_answers():
+    """Random123 kat_vectors for philox4x32 with 10 rounds (Salmon et al. SC'11) pin the device-stream oracle."""
+    from oracle import philox
+
+    kats = [
+        ((0, 0, 0, 0), (0, 0), "6627e8d5 e169c58d bc57ac4c 9b00dbd8"),
+        ((0xFFFFFFFF,) * 4, (0xFFFFFFFF,) * 2, "408f276d 41c83b0e a20bc7c6 6d5451fd"),
+        ((0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344), (0xA4093822, 0x299F31D0), "d16cfe09 94fdcceb 5001e420 24126ea1"),
+    ]
+    for ctr, key, want in kats:
+        r = philox.philox4x32_10(*[np.array([c]) for c in ctr], *key)
+        assert " ".join("%08x" % int(v[0]) for v in r) == want
+
+
+def test_device_stream_oracle_layout_and_moments():
+    from oracle import philox
+
+    F, lmax = 6, 30
+    g = philox.device_normals(12345, lmax, F)
+    assert g.size == 2 * F * (lmax + 1) * (lmax + 2) // 2
+    # element (l, c, nu', m) sits at F l (l+1) + c F (l+1) + nu' (l+1) + m
+    l, c, nu, m = 17, 1, 4, 9
+    a, b = philox.normal_pairs(12345, l, F, c, nu, m // 2)
+    assert g[F * l * (l + 1) + c * F * (l + 1) + nu * (l + 1) + m] == (b if m & 1 else a)
+    assert abs(g.mean()) < 5 / np.sqrt(g.size) and abs(g.var() - 1) < 5 * np.sqrt(2 / g.size)
