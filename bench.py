@@ -12,8 +12,9 @@ draw with device Philox normals generated in registers -> K4 Legendre MFMA contr
 Nothing is cached between steps except what the reference itself caches per model
 instance (the three DCT lookup tables) and the geometry plan.
 
-N > 1 (frequency sharding, north_star): K1/K2 are l-sharded, the factors are exchanged
-with ONE RCCL all-gather, every rank generates the same global normal stream and
+N > 1 (frequency sharding, north_star): K1 is sharded over channel pairs, one small RCCL
+all-to-all turns pair shards into l shards for K2, a second all-to-all hands every rank the
+factor rows of its own channels; every rank generates the same global normal stream and
 synthesises F/N channels.  Total work is fixed -> "scaling": "strong".
 
 Prints ONE JSON line (rank 0).
@@ -63,8 +64,15 @@ def main():
     ap.add_argument("--dist-backend", default="nccl")
     ap.add_argument("--same-device", action="store_true")
     ap.add_argument("--checksum", action="store_true")
+    ap.add_argument("--force-dist", action="store_true", help="take the multi-rank code path (process group, exchanges) even with 1 rank")
     ap.add_argument("--emulate-shard", type=int, default=0, help="time the work of the LAST rank of an N-rank job, no comm")
     args = ap.parse_args()
+
+    # stdout carries exactly ONE line (the JSON): native libraries print banners there (RCCL's version block
+    # at communicator creation), so fd 1 is pointed at stderr for the run and the result goes to the saved fd
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
 
     import torch
 
@@ -80,10 +88,14 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    multi = world > 1 or args.force_dist
+    if multi:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29655")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if args.dist_backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
@@ -93,7 +105,7 @@ def main():
     L = lmax + 1
     nalm = L * (L + 1) // 2
     npix = 12 * nside * nside
-    from cora_amd.parallel import allgather_factors, shard_plan
+    from cora_amd.parallel import allgather_factors, exchange_factor_rows, exchange_pair_slabs, shard_plan
 
     sp = shard_plan(L, F, rank, world)
     if args.emulate_shard > 1:
@@ -117,14 +129,21 @@ def main():
     # l-shard of K1/K2 (contiguous; shards are padded to equal length inside the all-gather)
     l_lo, l_hi = sp.l_lo, sp.l_hi
     larr = np.arange(L, dtype=np.float64)
+    pair_sharded = plan["kind"] == "table21cm" and (multi or args.emulate_shard > 1) and F % max(world, args.emulate_shard, 1) == 0
     if plan["kind"] == "table21cm":
         p = plan["prepare"](ctx, za)
-        lx = ctx.to_device(np.log10(np.where(larr == 0.0, 1e-10, larr))[l_lo:l_hi])
+        lx_full = np.log10(np.where(larr == 0.0, 1e-10, larr))
+        lx = ctx.to_device(lx_full if pair_sharded else lx_full[l_lo:l_hi])
         k1_in = [ctx.to_device(p[k]) for k in ("chi", "pfd", "f", "b")]
+        tabs = (p["dd"], p["dv"], p["vv"], p["kperpmin"], p["kperpmax"], p["kparmax"])
 
         def run_k1():
-            return ctx.clarray_table21cm(p["dd"], p["dv"], p["vv"], p["kperpmin"], p["kperpmax"], p["kparmax"],
-                                         k1_in[0], k1_in[1], k1_in[2], k1_in[3], F, zint, w, lx)
+            return ctx.clarray_table21cm(*tabs, k1_in[0], k1_in[1], k1_in[2], k1_in[3], F, zint, w, lx)
+
+        def run_k1_pairs(first, step):
+            # this rank's channel pairs at ALL multipoles, laid out as one slab per destination rank
+            return ctx.clarray_table21cm_pairs(*tabs, k1_in[0], k1_in[1], k1_in[2], k1_in[3], F, zint, w, lx,
+                                               first, step, sp.l_shard)
     else:
         al, bcov = plan["prepare"](larr.copy(), za)
         al_d, bcov_d = ctx.to_device(al[l_lo:l_hi]), ctx.to_device(bcov)
@@ -142,32 +161,53 @@ def main():
     seed_box = [1000]
 
     def cold_factors():
+        if args.emulate_shard > 1:
+            # the work of one rank of an N-rank job, without the exchanges
+            N = args.emulate_shard
+            if pair_sharded:
+                slab = run_k1_pairs(N - 1, N)
+                C = ctx.clarray_pairs_finish(slab.new_zeros((N,) + tuple(slab.shape[1:])), F, sp.l_hi - sp.l_lo)
+            else:
+                C = run_k1()
+            ctx.factor_batched(C)
+            return cached_full["f"]
+        if not multi:
+            C = run_k1()
+            T, info = ctx.factor_batched(C)
+            return T, info, False
+        if pair_sharded:
+            mine = exchange_pair_slabs(run_k1_pairs(rank, world), sp)     # all-to-all #1 (67 MB per rank at cfg3)
+            C = ctx.clarray_pairs_finish(mine, F, sp.l_hi - sp.l_lo)
+            T, info = ctx.factor_batched(C)
+            Tr, ia = exchange_factor_rows(T, info, sp)                   # all-to-all #2 (row blocks)
+            return Tr, ia, True
         C = run_k1()
         T, info = ctx.factor_batched(C)
-        if args.emulate_shard > 1:
-            return cached_full["f"]
-        if world == 1:
-            return T, info
-        return allgather_factors(T, info, sp)  # the single exchange step (RCCL all-gather)
+        Ta, ia = allgather_factors(T, info, sp)
+        return Ta, ia, False
 
     cached = {}
     cached_full = {}
     if args.emulate_shard > 1:
         Cf = ctx.empty((L, F, F)).normal_()
         Cf = Cf @ Cf.transpose(1, 2) + 0.1 * torch.eye(F, device=ctx.device, dtype=torch.float64)
-        cached_full["f"] = ctx.factor_batched(Cf)
-        del Cf
+        Tf, inf = ctx.factor_batched(Cf)
+        cached_full["f"] = (Tf[:, nu0:nu0 + nnu, :].contiguous(), inf, True) if pair_sharded else (Tf, inf, False)
+        del Cf, Tf
 
     def step():
         if args.warm:
             if "f" not in cached:
                 cached["f"] = cold_factors()
-            T, info = cached["f"]
+            T, info, rows = cached["f"]
         else:
-            T, info = cold_factors()
+            T, info, rows = cold_factors()
         seed_box[0] += 1
         # device Philox normals are generated inside the draw kernel (no 8.6 GB normal buffer)
-        ctx.draw_alm_philox(T, info, seed_box[0], lmax, F, nu0=nu0, nnu=nnu, out=alm_buf)
+        if rows:
+            ctx.draw_alm_philox_rows(T, info, seed_box[0], lmax, F, nu0, nnu, out=alm_buf)
+        else:
+            ctx.draw_alm_philox(T, info, seed_box[0], lmax, F, nu0=nu0, nnu=nnu, out=alm_buf)
         ctx.alm2map(alm_buf, nside, lmax, nnu, out=maps_buf)
 
     def barrier():
@@ -195,7 +235,7 @@ def main():
     for name in ("clarray", "factor", "normals", "draw", "legendre", "ringfft"):
         ms, n = ctx.profile_get(name)
         if n:
-            stages[name] = {"ms_per_launch": ms / n, "launches": n}
+            stages[name] = {"ms_per_launch": ms / n, "launches": n, "ms_per_step": ms / args.steps}
 
     # sanity: the maps of the last step are finite and have the expected variance scale
     chk = float(maps_buf[0, ::4097].std().item())
@@ -247,11 +287,11 @@ def main():
                 "workload": "%s: %s, %d channels %g-%g MHz, nside=%d, lmax=%d, zromb=%d, %s path, device Philox normals"
                             % (args.workload, model_name, F, nu_lo, nu_hi, nside, lmax, zromb,
                                "warm (cached factors)" if args.warm else "cold (C_l integration + factor + draw + synthesis)"),
-                "parallelism": "freq-shard x%d (l-sharded C_l/factor + 1 RCCL all-gather)" % world if world > 1 else "single GPU",
+                "parallelism": "freq-shard x%d (pair-sharded C_l -> all-to-all -> l-sharded factor -> all-to-all of factor row blocks)" % world if world > 1 else "single GPU",
                 "realisations_per_s": args.steps / dt,
                 "setup_s": t_setup,
             },
-            "stages_ms": {k: round(v["ms_per_launch"], 3) for k, v in stages.items()},
+            "stages_ms": {k: round(v["ms_per_step"], 3) for k, v in stages.items()},
             "roofline": {
                 "bound": "mfma",
                 "kernel": "legendre_kernel (K4)",
@@ -272,7 +312,8 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             result["cpu_baseline"] = cpu_baseline(model_name, F, freq, nside, lmax, zromb)
             result["config"]["gpu_over_cpu"] = value / result["cpu_baseline"]["value"]
-        print(json.dumps(result))
+        os.write(json_fd, (json.dumps(result) + "\n").encode())
+    os.close(json_fd)
     if dist is not None:
         dist.destroy_process_group()
     return result

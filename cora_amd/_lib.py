@@ -37,6 +37,10 @@ SIGNATURES = {
     "corahip_memcpy_d2h": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t]),
     "corahip_clarray_table21cm": (c_int, [c_void_p, PTR, PTR, PTR, c_int, c_int, c_double, c_double, c_double,
                                           PTR, PTR, PTR, PTR, c_int, c_int, PTR, PTR, c_int, PTR]),
+    "corahip_clarray_table21cm_pairs": (c_int, [c_void_p, PTR, PTR, PTR, c_int, c_int, c_double, c_double, c_double,
+                                                PTR, PTR, PTR, PTR, c_int, c_int, PTR, PTR, c_int, c_int, c_int, c_int,
+                                                PTR]),
+    "corahip_clarray_pairs_finish": (c_int, [c_void_p, PTR, c_int, c_int, c_int, c_int, PTR]),
     "corahip_aps_table21cm_points": (c_int, [c_void_p, PTR, PTR, PTR, c_int, c_int, c_double, c_double, c_double,
                                              ctypes.c_long, PTR, PTR, PTR, PTR, PTR, PTR, PTR]),
     "corahip_clarray_separable": (c_int, [c_void_p, PTR, c_int, PTR, c_int, c_int, PTR, PTR]),
@@ -44,6 +48,7 @@ SIGNATURES = {
     "corahip_factor_batched": (c_int, [c_void_p, PTR, c_int, c_int, c_double, c_double, PTR, PTR]),
     "corahip_normals_philox": (c_int, [c_void_p, c_u64, c_int, c_int, PTR]),
     "corahip_draw_alm_philox": (c_int, [c_void_p, PTR, PTR, c_u64, c_int, c_int, c_int, c_int, PTR]),
+    "corahip_draw_alm_philox_rows": (c_int, [c_void_p, PTR, PTR, c_u64, c_int, c_int, c_int, c_int, PTR]),
     "corahip_draw_alm": (c_int, [c_void_p, PTR, PTR, PTR, c_int, c_int, c_int, c_int, PTR]),
     "corahip_alm_dev_to_square": (c_int, [c_void_p, PTR, c_int, c_int, PTR]),
     "corahip_alm_packed_to_dev": (c_int, [c_void_p, PTR, c_int, c_int, PTR]),
@@ -180,6 +185,29 @@ class Context:
             nl, self._f64(out)))
         return out
 
+    def clarray_table21cm_pairs(self, dd, dv, vv, kperpmin, kperpmax, kparmax, chi, pfd, f, b, F, zint, w, log10l,
+                                pair_first, pair_step, l_block):
+        """Pair shard of the integration: [ceil(nl / l_block), npl, l_block] slabs (see include/corahip.h)."""
+        torch = _torch()
+        nl = log10l.numel()
+        npl = (F * (F + 1) // 2 + pair_step - 1) // pair_step
+        nblk = (nl + l_block - 1) // l_block
+        out = torch.zeros((nblk, npl, l_block), dtype=torch.float64, device=self.device)
+        nkperp, nkpar = dd.shape
+        _check(self.lib.corahip_clarray_table21cm_pairs(
+            self.h, self._f64(dd), self._f64(dv), self._f64(vv), nkperp, nkpar, kperpmin, kperpmax, kparmax,
+            self._f64(chi), self._f64(pfd), self._f64(f), self._f64(b), F, zint, self._f64(w), self._f64(log10l),
+            nl, pair_first, pair_step, l_block, self._f64(out)))
+        return out
+
+    def clarray_pairs_finish(self, slabs, F, nl):
+        """[nranks, npl, l_stride] pair slabs (slab r integrated by rank r) -> C [nl, F, F]."""
+        nranks, npl, l_stride = slabs.shape
+        assert npl == (F * (F + 1) // 2 + nranks - 1) // nranks and nl <= l_stride
+        out = self.empty((nl, F, F))
+        _check(self.lib.corahip_clarray_pairs_finish(self.h, self._f64(slabs), F, nranks, l_stride, nl, self._f64(out)))
+        return out
+
     def aps_table21cm_points(self, dd, dv, vv, kperpmin, kperpmax, kparmax, lx, chi1, chi2, cdd, cdv, cvv):
         n = lx.numel()
         out = self.empty((n,))
@@ -237,6 +265,16 @@ class Context:
         alm = out if out is not None else self.empty((nalm, G, 2, 4))
         _check(self.lib.corahip_draw_alm_philox(self.h, self._f64(T), self._p(info) if info is not None else None,
                                                 c_u64(int(seed) & (2**64 - 1)), lmax, F, nu0, nnu, self._f64(alm)))
+        return alm
+
+    def draw_alm_philox_rows(self, T_rows, info, seed, lmax, F, nu0, nnu, out=None):
+        """draw_alm_philox with T_rows [lmax+1, nnu, F] = rows nu0..nu0+nnu-1 of every factor."""
+        assert tuple(T_rows.shape) == (lmax + 1, nnu, F), T_rows.shape
+        nalm = (lmax + 1) * (lmax + 2) // 2
+        G = (nnu + 3) // 4
+        alm = out if out is not None else self.empty((nalm, G, 2, 4))
+        _check(self.lib.corahip_draw_alm_philox_rows(self.h, self._f64(T_rows), self._p(info) if info is not None else None,
+                                                     c_u64(int(seed) & (2**64 - 1)), lmax, F, nu0, nnu, self._f64(alm)))
         return alm
 
     def alm_dev_to_square(self, alm, lmax, nnu):

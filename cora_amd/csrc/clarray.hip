@@ -13,6 +13,8 @@
 // j >= i, results to a [pair][l] scratch, a tiled transpose scatters them into [l][i][j] and its mirror.
 #include "common.h"
 
+#include <cstring>
+
 #define CL_MAXZ 17  // zint <= 17 (zromb <= 4)
 
 #define CL_XS 512      // padded row length of the transposed tables (nkperp <= 511)
@@ -45,18 +47,20 @@ __global__ void cl_transpose_kernel(const double *__restrict__ dd, const double 
 // which is the bilinear lookup of the reference (bilinearmap.pyx:41-59) with the y interpolation and
 // the three-table combination (corr.py:980-982) hoisted out of the l loop: 12x fewer table reads.
 // Results go to a [pair][l] scratch (coalesced); cl_finish_kernel scatters them into [l][i][j].
+// Pairs with i < 0 (padding of a multi-GPU pair shard) are skipped.
 __global__ void __launch_bounds__(256)
 clarray21_kernel(const double *__restrict__ tt, int nkperp, int nkpar, double kperpmin, double xscale, double yscale,
                  const double *__restrict__ chi, const double *__restrict__ pfd, const double *__restrict__ fz,
                  const double *__restrict__ bz, int F, int zint, const double *__restrict__ w,
                  const double *__restrict__ log10l, int nl, int l_base, const int2 *__restrict__ pairs,
-                 double *__restrict__ scratch, int nl_total) {
+                 double *__restrict__ scratch, int nl_total, int l_block) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     double *prof = sm;                       // [zint][CL_XS + 2]
     double *lxcs_s = sm + zint * (CL_XS + 2);   // [zint]
     const int PS = CL_XS + 2;
     const int tid = threadIdx.x;
     const int i = pairs[blockIdx.x].x, j = pairs[blockIdx.x].y;
+    if (i < 0) return;
     const double ux = (double)nkperp - 1e-5, uy = (double)nkpar - 1e-5;
     const size_t tsz = (size_t)nkpar * CL_XS;
 
@@ -134,29 +138,46 @@ clarray21_kernel(const double *__restrict__ tt, int nkperp, int nkpar, double kp
 #pragma unroll
     for (int k = 0; k < CL_LPT; k++) {
         const int li = l_base + tid + 256 * k;
-        if (li < nl_total) scratch[(size_t)blockIdx.x * nl_total + li] = acc[k];
+        // results: [l / l_block][pair][l % l_block] (l_block = nl: plain [pair][l]; l_block = the l-shard
+        // length of a multi-GPU run: one contiguous slab per destination rank of the all-to-all)
+        if (li < nl_total)
+            scratch[((size_t)(li / l_block) * gridDim.x + blockIdx.x) * l_block + li % l_block] = acc[k];
     }
 }
 
-// scratch [pair][l] -> out [l][i][j] and its mirror [l][j][i]
-__global__ void cl_finish_kernel(const double *__restrict__ scratch, const int2 *__restrict__ pairs, long npairs,
-                                 int nl, int F, double *__restrict__ out) {
+// scratch [slot][l] -> out [l][i][j] and its mirror [l][j][i].  Slot s holds canonical pair
+// p = (s % npl) * W + s / npl of the (i, j >= i) enumeration: W = 1, npl = npairs for a single GPU;
+// after the all-to-all of a W-rank run slab r = s / npl came from rank r, which integrated pairs r, r + W, ...
+__device__ static inline int2 pair_of_index(long p, int F) {
+    // p = i F - i (i - 1) / 2 + (j - i), row i found from the quadratic, fixed up for rounding
+    int i = (int)(((2.0 * F + 1.0) - sqrt((2.0 * F + 1.0) * (2.0 * F + 1.0) - 8.0 * (double)p)) * 0.5);
+    i = max(0, min(i, F - 1));
+    while (i > 0 && (long)i * F - (long)i * (i - 1) / 2 > p) i--;
+    while ((long)(i + 1) * F - (long)(i + 1) * i / 2 <= p) i++;
+    return make_int2(i, i + (int)(p - ((long)i * F - (long)i * (i - 1) / 2)));
+}
+
+__global__ void cl_finish_kernel(const double *__restrict__ scratch, long npairs, int W, long npl, int lstride, int nl,
+                                 int F, double *__restrict__ out) {
     __shared__ double tile[32][33];
-    // tile: 32 pairs x 32 l
-    const long p0 = (long)blockIdx.x * 32;
+    // tile: 32 slots x 32 l
+    const long s0 = (long)blockIdx.x * 32;
     const int l0 = blockIdx.y * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const long nslot = npl * W;
     for (int r = ty; r < 32; r += 8) {
-        const long p = p0 + r;
+        const long sl = s0 + r;
         const int l = l0 + tx;
-        tile[r][tx] = (p < npairs && l < nl) ? scratch[(size_t)p * nl + l] : 0.0;
+        tile[r][tx] = (sl < nslot && l < nl) ? scratch[(size_t)sl * lstride + l] : 0.0;
     }
     __syncthreads();
+    const long sl = s0 + tx;
+    const long p = sl < nslot ? (sl % npl) * W + sl / npl : npairs;
+    if (p >= npairs) return;
+    const int2 ij = pair_of_index(p, F);
     for (int r = ty; r < 32; r += 8) {
         const int l = l0 + r;
-        const long p = p0 + tx;
-        if (l < nl && p < npairs) {
-            const int2 ij = pairs[p];
+        if (l < nl) {
             const double v = tile[tx][r];
             out[((size_t)l * F + ij.x) * F + ij.y] = v;
             out[((size_t)l * F + ij.y) * F + ij.x] = v;
@@ -232,29 +253,32 @@ __global__ void aps21_points_kernel(const double *__restrict__ dd, const double 
 
 extern "C" {
 
-int corahip_clarray_table21cm(corahip_ctx *ctx, const double *dd, const double *dv, const double *vv, int nkperp,
-                              int nkpar, double kperpmin, double kperpmax, double kparmax, const double *chi,
-                              const double *pfd, const double *f, const double *b, int F, int zint, const double *w,
-                              const double *log10l, int nl, double *out) {
-    ARG_CHECK(ctx != nullptr && dd && dv && vv && chi && pfd && f && b && w && log10l && out);
-    ARG_CHECK(nkperp >= 2 && nkperp < CL_XS && nkpar >= 2 && F >= 1 && zint >= 1 && zint <= CL_MAXZ && nl >= 1);
-    ARG_CHECK(kperpmin > 0 && kperpmax > kperpmin && kparmax > 0);
-    StageTimer t(ctx, "clarray");
-    // channel pairs j >= i, ordered so that concurrently running workgroups share table columns
-    std::vector<int2> pairs;
-    for (int i = 0; i < F; i++)
-        for (int j = i; j < F; j++) pairs.push_back(make_int2(i, j));
-    const long npairs = (long)pairs.size();
-    // scratch: transposed tables + pair list + [pair][l] results (context-owned, grow-only)
+// pairs pair_first, pair_first + pair_step, ... of the canonical (i, j >= i) enumeration -> out_pairs in the
+// [l / l_block][k][l % l_block] layout (npl = ceil((npairs - pair_first) / pair_step) slots, padded to npl_pad)
+static int clarray21_pairs(corahip_ctx *ctx, const double *dd, const double *dv, const double *vv, int nkperp,
+                           int nkpar, double kperpmin, double kperpmax, double kparmax, const double *chi,
+                           const double *pfd, const double *f, const double *b, int F, int zint, const double *w,
+                           const double *log10l, int nl, int pair_first, int pair_step, long npl_pad, int l_block,
+                           double *out_pairs) {
     const size_t tt_bytes = sizeof(double) * 3 * (size_t)nkpar * CL_XS;
-    const size_t sc_bytes = sizeof(double) * (size_t)npairs * nl;
-    double *tt = nullptr, *scratch = nullptr;
+    double *tt = nullptr;
     int2 *dpairs = nullptr;
     int rc;
     if ((rc = corahip_ctx_scratch(ctx, 0, tt_bytes, (void **)&tt))) return rc;
-    if ((rc = corahip_ctx_scratch(ctx, 1, sc_bytes, (void **)&scratch))) return rc;
-    if ((rc = corahip_ctx_scratch(ctx, 2, sizeof(int2) * npairs, (void **)&dpairs))) return rc;
-    HIP_TRY(hipMemcpyAsync(dpairs, pairs.data(), sizeof(int2) * npairs, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = corahip_ctx_scratch(ctx, 2, sizeof(int2) * npl_pad, (void **)&dpairs))) return rc;
+    const long key[4] = {F, pair_first, pair_step, npl_pad};
+    if (ctx->pairs_ptr != (void *)dpairs || memcmp(key, ctx->pairs_key, sizeof(key)) != 0) {
+        // (re)build the pair list of this shard; it stays resident for the following calls
+        std::vector<int2> pairs((size_t)npl_pad, make_int2(-1, -1));
+        long p = 0, k = 0;
+        for (int i = 0; i < F; i++)
+            for (int j = i; j < F; j++, p++)
+                if (p >= pair_first && (p - pair_first) % pair_step == 0) pairs[(size_t)k++] = make_int2(i, j);
+        HIP_TRY(hipMemcpyAsync(dpairs, pairs.data(), sizeof(int2) * npl_pad, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));  // `pairs` (host) must outlive the async copy
+        memcpy(ctx->pairs_key, key, sizeof(key));
+        ctx->pairs_ptr = (void *)dpairs;
+    }
     {
         dim3 grid((nkpar + 31) / 32, CL_XS / 32, 3);
         cl_transpose_kernel<<<grid, 256, 0, ctx->stream>>>(dd, dv, vv, nkperp, nkpar, tt);
@@ -265,17 +289,60 @@ int corahip_clarray_table21cm(corahip_ctx *ctx, const double *dd, const double *
     const size_t shm = sizeof(double) * ((size_t)zint * (CL_XS + 2) + zint);
     HIP_TRY(hipFuncSetAttribute((const void *)clarray21_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
     for (int l_base = 0; l_base < nl; l_base += 256 * CL_LPT) {
-        clarray21_kernel<<<(unsigned)npairs, 256, shm, ctx->stream>>>(tt, nkperp, nkpar, kperpmin, xscale, yscale, chi, pfd,
-                                                                     f, b, F, zint, w, log10l, nl, l_base, dpairs, scratch,
-                                                                     nl);
+        clarray21_kernel<<<(unsigned)npl_pad, 256, shm, ctx->stream>>>(tt, nkperp, nkpar, kperpmin, xscale, yscale, chi, pfd,
+                                                                      f, b, F, zint, w, log10l, nl, l_base, dpairs,
+                                                                      out_pairs, nl, l_block);
         LAUNCH_CHECK();
     }
-    {
-        dim3 grid((unsigned)((npairs + 31) / 32), (nl + 31) / 32);
-        cl_finish_kernel<<<grid, 256, 0, ctx->stream>>>(scratch, dpairs, npairs, nl, F, out);
-        LAUNCH_CHECK();
-    }
-    HIP_TRY(hipStreamSynchronize(ctx->stream));  // `pairs` (host) must outlive the async copy
+    return 0;
+}
+
+int corahip_clarray_table21cm(corahip_ctx *ctx, const double *dd, const double *dv, const double *vv, int nkperp,
+                              int nkpar, double kperpmin, double kperpmax, double kparmax, const double *chi,
+                              const double *pfd, const double *f, const double *b, int F, int zint, const double *w,
+                              const double *log10l, int nl, double *out) {
+    ARG_CHECK(ctx != nullptr && dd && dv && vv && chi && pfd && f && b && w && log10l && out);
+    ARG_CHECK(nkperp >= 2 && nkperp < CL_XS && nkpar >= 2 && F >= 1 && zint >= 1 && zint <= CL_MAXZ && nl >= 1);
+    ARG_CHECK(kperpmin > 0 && kperpmax > kperpmin && kparmax > 0);
+    StageTimer t(ctx, "clarray");
+    const long npairs = (long)F * (F + 1) / 2;
+    double *scratch = nullptr;
+    int rc;
+    if ((rc = corahip_ctx_scratch(ctx, 1, sizeof(double) * (size_t)npairs * nl, (void **)&scratch))) return rc;
+    if ((rc = clarray21_pairs(ctx, dd, dv, vv, nkperp, nkpar, kperpmin, kperpmax, kparmax, chi, pfd, f, b, F, zint, w,
+                              log10l, nl, 0, 1, npairs, nl, scratch)))
+        return rc;
+    dim3 grid((unsigned)((npairs + 31) / 32), (nl + 31) / 32);
+    cl_finish_kernel<<<grid, 256, 0, ctx->stream>>>(scratch, npairs, 1, npairs, nl, nl, F, out);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int corahip_clarray_table21cm_pairs(corahip_ctx *ctx, const double *dd, const double *dv, const double *vv, int nkperp,
+                                    int nkpar, double kperpmin, double kperpmax, double kparmax, const double *chi,
+                                    const double *pfd, const double *f, const double *b, int F, int zint,
+                                    const double *w, const double *log10l, int nl, int pair_first, int pair_step,
+                                    int l_block, double *out_pairs) {
+    ARG_CHECK(ctx != nullptr && dd && dv && vv && chi && pfd && f && b && w && log10l && out_pairs);
+    ARG_CHECK(nkperp >= 2 && nkperp < CL_XS && nkpar >= 2 && F >= 1 && zint >= 1 && zint <= CL_MAXZ && nl >= 1);
+    ARG_CHECK(kperpmin > 0 && kperpmax > kperpmin && kparmax > 0);
+    ARG_CHECK(pair_step >= 1 && pair_first >= 0 && pair_first < pair_step && l_block >= 1);
+    StageTimer t(ctx, "clarray");
+    const long npairs = (long)F * (F + 1) / 2;
+    const long npl = (npairs + pair_step - 1) / pair_step;  // slots per rank, equal on all ranks (padded)
+    return clarray21_pairs(ctx, dd, dv, vv, nkperp, nkpar, kperpmin, kperpmax, kparmax, chi, pfd, f, b, F, zint, w,
+                           log10l, nl, pair_first, pair_step, npl, l_block, out_pairs);
+}
+
+int corahip_clarray_pairs_finish(corahip_ctx *ctx, const double *pairs_in, int F, int nranks, int l_stride, int nl,
+                                 double *out) {
+    ARG_CHECK(ctx != nullptr && pairs_in && out && F >= 1 && nranks >= 1 && nl >= 1 && l_stride >= nl);
+    StageTimer t(ctx, "clarray");
+    const long npairs = (long)F * (F + 1) / 2;
+    const long npl = (npairs + nranks - 1) / nranks;
+    dim3 grid((unsigned)((npl * nranks + 31) / 32), (nl + 31) / 32);
+    cl_finish_kernel<<<grid, 256, 0, ctx->stream>>>(pairs_in, npairs, nranks, npl, l_stride, nl, F, out);
+    LAUNCH_CHECK();
     return 0;
 }
 

@@ -34,6 +34,9 @@ struct corahip_ctx {
     // grow-only device scratch slots owned by the context (freed by ctx_destroy)
     void *scratch[4] = {nullptr, nullptr, nullptr, nullptr};
     size_t scratch_bytes[4] = {0, 0, 0, 0};
+    // K1 pair list resident in scratch slot 2: (F, first, step, slots, device pointer it was written to)
+    long pairs_key[4] = {-1, -1, -1, -1};
+    void *pairs_ptr = nullptr;
 };
 
 // returns a device buffer of at least `bytes` for `slot`, reallocating only when it must grow

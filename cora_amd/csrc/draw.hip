@@ -160,8 +160,8 @@ __global__ void normals_kernel(uint64_t seed, int lmax, int F, double *__restric
 // NCT = 16-column tiles per block (block covers 16*NCT channels starting at col0)
 template <int NCT>
 __global__ void __launch_bounds__(256)
-draw_kernel(const double *__restrict__ T, const int32_t *__restrict__ info, const double *__restrict__ g, int lmax,
-            int F, int nu0, int nnu, int Gout, double *__restrict__ alm) {
+draw_kernel(const double *__restrict__ T, size_t t_ldl, int t_row0, const int32_t *__restrict__ info,
+            const double *__restrict__ g, int lmax, int F, int nu0, int nnu, int Gout, double *__restrict__ alm) {
     constexpr int NC = 16 * NCT;
     constexpr int STRIDE = DRAW_KC + 2;  // doubles per channel row: 272 B, so 16 consecutive rows hit 16 distinct 16-B slots
     extern __shared__ __attribute__((aligned(16))) double lds[];  // Bs[n][k] = T_l[nu0+col0+n][k0+k], [NC][STRIDE]
@@ -177,7 +177,7 @@ draw_kernel(const double *__restrict__ T, const int32_t *__restrict__ info, cons
 
     // stream offset of this l: sum_{l'<l} 2 F (l'+1) = F l (l+1)
     const double *gl = g + (size_t)F * l * (l + 1);
-    const double *Tl = T + (size_t)l * F * F;
+    const double *Tl = T + (size_t)l * t_ldl - (size_t)t_row0 * F;  // row nu of T_l at Tl + nu F (rows < t_row0 never read)
     const bool dense = (info == nullptr) || (info[l] != 0);
 
     // A operand row of this lane
@@ -265,8 +265,9 @@ __device__ static inline void draw_glds16(const void *gsrc, unsigned lds_byte_ad
 
 template <int NCT>
 __global__ void __launch_bounds__(256, 2)
-draw_rng_kernel(const double *__restrict__ T, const int32_t *__restrict__ info, const double *__restrict__ zeros,
-                uint64_t seed, int lmax, int F, int nu0, int nnu, int Gout, double *__restrict__ alm) {
+draw_rng_kernel(const double *__restrict__ T, size_t t_ldl, int t_row0, const int32_t *__restrict__ info,
+                const double *__restrict__ zeros, uint64_t seed, int lmax, int F, int nu0, int nnu, int Gout,
+                double *__restrict__ alm) {
     constexpr int NC = 16 * NCT;
     constexpr int ROWD = DRAW_KC;            // doubles per channel row in LDS: 256 B, unpadded (DMA is lane-linear)
     constexpr int BUF = NC * ROWD;           // doubles per stage
@@ -286,7 +287,7 @@ draw_rng_kernel(const double *__restrict__ T, const int32_t *__restrict__ info, 
     const int mpair = (m0 >> 1) + ri;           // this lane's m-pair: rows m = 2 mpair, 2 mpair + 1
     const bool pair_ok = 2 * mpair < lp1;
 
-    const double *Tl = T + (size_t)l * F * F;
+    const double *Tl = T + (size_t)l * t_ldl - (size_t)t_row0 * F;  // row nu of T_l at Tl + nu F (rows < t_row0 never read)
     const bool dense = (info == nullptr) || (info[l] != 0);
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) double *)lds;
 
@@ -371,8 +372,8 @@ draw_rng_kernel(const double *__restrict__ T, const int32_t *__restrict__ info, 
 }
 
 template <int NCT>
-static int launch_draw_rng(corahip_ctx *ctx, const double *T, const int32_t *info, uint64_t seed, int lmax, int F,
-                           int nu0, int nnu, int Gout, double *alm) {
+static int launch_draw_rng(corahip_ctx *ctx, const double *T, size_t t_ldl, int t_row0, const int32_t *info,
+                           uint64_t seed, int lmax, int F, int nu0, int nnu, int Gout, double *alm) {
     constexpr int NC = 16 * NCT;
     const size_t shm = sizeof(double) * 2 * NC * DRAW_KC;
     HIP_TRY(hipFuncSetAttribute((const void *)draw_rng_kernel<NCT>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -382,7 +383,8 @@ static int launch_draw_rng(corahip_ctx *ctx, const double *T, const int32_t *inf
     if (rc) return rc;
     HIP_TRY(hipMemsetAsync(zeros, 0, 4096, ctx->stream));
     dim3 grid(lmax + 1, 2 * ((lmax + 1 + 127) / 128), (4 * Gout + NC - 1) / NC);
-    draw_rng_kernel<NCT><<<grid, 256, shm, ctx->stream>>>(T, info, zeros, seed, lmax, F, nu0, nnu, Gout, alm);
+    draw_rng_kernel<NCT><<<grid, 256, shm, ctx->stream>>>(T, t_ldl, t_row0, info, zeros, seed, lmax, F, nu0, nnu, Gout,
+                                                          alm);
     LAUNCH_CHECK();
     return 0;
 }
@@ -427,13 +429,13 @@ __global__ void packed_to_dev_kernel(const double *__restrict__ packed, long nal
 }
 
 template <int NCT>
-static int launch_draw(corahip_ctx *ctx, const double *T, const int32_t *info, const double *g, int lmax, int F,
-                       int nu0, int nnu, int Gout, double *alm) {
+static int launch_draw(corahip_ctx *ctx, const double *T, size_t t_ldl, int t_row0, const int32_t *info,
+                       const double *g, int lmax, int F, int nu0, int nnu, int Gout, double *alm) {
     constexpr int NC = 16 * NCT;
     const size_t shm = sizeof(double) * NC * (DRAW_KC + 2);
     HIP_TRY(hipFuncSetAttribute((const void *)draw_kernel<NCT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
     dim3 grid(lmax + 1, (2 * (lmax + 1) + DRAW_ROWS - 1) / DRAW_ROWS, (4 * Gout + NC - 1) / NC);
-    draw_kernel<NCT><<<grid, 256, shm, ctx->stream>>>(T, info, g, lmax, F, nu0, nnu, Gout, alm);
+    draw_kernel<NCT><<<grid, 256, shm, ctx->stream>>>(T, t_ldl, t_row0, info, g, lmax, F, nu0, nnu, Gout, alm);
     LAUNCH_CHECK();
     return 0;
 }
@@ -449,10 +451,20 @@ int corahip_normals_philox(corahip_ctx *ctx, uint64_t seed, int lmax, int F, dou
     return 0;
 }
 
-int corahip_draw_alm_philox(corahip_ctx *ctx, const double *T, const int32_t *info, uint64_t seed, int lmax, int F,
-                            int nu0, int nnu, double *alm_dev) {
-    ARG_CHECK(ctx != nullptr && T != nullptr && alm_dev != nullptr);
-    ARG_CHECK(lmax >= 0 && F >= 1 && nu0 >= 0 && nnu >= 1 && nu0 + nnu <= F);
+static int draw_host_stream(corahip_ctx *ctx, const double *T, size_t t_ldl, int t_row0, const int32_t *info,
+                            const double *g, int lmax, int F, int nu0, int nnu, double *alm_dev) {
+    StageTimer t(ctx, "draw");
+    const int Gout = (nnu + 3) / 4;
+    const int ncol = 4 * Gout;
+    if (ncol <= 16) return launch_draw<1>(ctx, T, t_ldl, t_row0, info, g, lmax, F, nu0, nnu, Gout, alm_dev);
+    if (ncol <= 32) return launch_draw<2>(ctx, T, t_ldl, t_row0, info, g, lmax, F, nu0, nnu, Gout, alm_dev);
+    if (ncol <= 64) return launch_draw<4>(ctx, T, t_ldl, t_row0, info, g, lmax, F, nu0, nnu, Gout, alm_dev);
+    if (ncol <= 128) return launch_draw<8>(ctx, T, t_ldl, t_row0, info, g, lmax, F, nu0, nnu, Gout, alm_dev);
+    return launch_draw<16>(ctx, T, t_ldl, t_row0, info, g, lmax, F, nu0, nnu, Gout, alm_dev);
+}
+
+static int draw_philox(corahip_ctx *ctx, const double *T, size_t t_ldl, int t_row0, const int32_t *info,
+                       uint64_t seed, int lmax, int F, int nu0, int nnu, double *alm_dev) {
     if (F & 1) {
         // odd F: a 16-byte LDS-DMA piece would straddle the end of a T row; materialise the (identical)
         // device stream and use the generic kernel instead
@@ -460,29 +472,36 @@ int corahip_draw_alm_philox(corahip_ctx *ctx, const double *T, const int32_t *in
         int rc = corahip_ctx_scratch(ctx, 1, sizeof(double) * 2 * (size_t)F * nalm_of(lmax), (void **)&g);
         if (rc) return rc;
         if ((rc = corahip_normals_philox(ctx, seed, lmax, F, g))) return rc;
-        return corahip_draw_alm(ctx, T, info, g, lmax, F, nu0, nnu, alm_dev);
+        return draw_host_stream(ctx, T, t_ldl, t_row0, info, g, lmax, F, nu0, nnu, alm_dev);
     }
     StageTimer t(ctx, "draw");
     const int Gout = (nnu + 3) / 4;
     const int ncol = 4 * Gout;
-    if (ncol <= 16) return launch_draw_rng<1>(ctx, T, info, seed, lmax, F, nu0, nnu, Gout, alm_dev);
-    if (ncol <= 32) return launch_draw_rng<2>(ctx, T, info, seed, lmax, F, nu0, nnu, Gout, alm_dev);
-    if (ncol <= 64) return launch_draw_rng<4>(ctx, T, info, seed, lmax, F, nu0, nnu, Gout, alm_dev);
-    return launch_draw_rng<8>(ctx, T, info, seed, lmax, F, nu0, nnu, Gout, alm_dev);
+    if (ncol <= 16) return launch_draw_rng<1>(ctx, T, t_ldl, t_row0, info, seed, lmax, F, nu0, nnu, Gout, alm_dev);
+    if (ncol <= 32) return launch_draw_rng<2>(ctx, T, t_ldl, t_row0, info, seed, lmax, F, nu0, nnu, Gout, alm_dev);
+    if (ncol <= 64) return launch_draw_rng<4>(ctx, T, t_ldl, t_row0, info, seed, lmax, F, nu0, nnu, Gout, alm_dev);
+    return launch_draw_rng<8>(ctx, T, t_ldl, t_row0, info, seed, lmax, F, nu0, nnu, Gout, alm_dev);
+}
+
+int corahip_draw_alm_philox(corahip_ctx *ctx, const double *T, const int32_t *info, uint64_t seed, int lmax, int F,
+                            int nu0, int nnu, double *alm_dev) {
+    ARG_CHECK(ctx != nullptr && T != nullptr && alm_dev != nullptr);
+    ARG_CHECK(lmax >= 0 && F >= 1 && nu0 >= 0 && nnu >= 1 && nu0 + nnu <= F);
+    return draw_philox(ctx, T, (size_t)F * F, 0, info, seed, lmax, F, nu0, nnu, alm_dev);
+}
+
+int corahip_draw_alm_philox_rows(corahip_ctx *ctx, const double *T_rows, const int32_t *info, uint64_t seed, int lmax,
+                                 int F, int nu0, int nnu, double *alm_dev) {
+    ARG_CHECK(ctx != nullptr && T_rows != nullptr && alm_dev != nullptr);
+    ARG_CHECK(lmax >= 0 && F >= 1 && nu0 >= 0 && nnu >= 1 && nu0 + nnu <= F);
+    return draw_philox(ctx, T_rows, (size_t)nnu * F, nu0, info, seed, lmax, F, nu0, nnu, alm_dev);
 }
 
 int corahip_draw_alm(corahip_ctx *ctx, const double *T, const int32_t *info, const double *g, int lmax, int F,
                      int nu0, int nnu, double *alm_dev) {
     ARG_CHECK(ctx != nullptr && T != nullptr && g != nullptr && alm_dev != nullptr);
     ARG_CHECK(lmax >= 0 && F >= 1 && nu0 >= 0 && nnu >= 1 && nu0 + nnu <= F);
-    StageTimer t(ctx, "draw");
-    const int Gout = (nnu + 3) / 4;
-    const int ncol = 4 * Gout;
-    if (ncol <= 16) return launch_draw<1>(ctx, T, info, g, lmax, F, nu0, nnu, Gout, alm_dev);
-    if (ncol <= 32) return launch_draw<2>(ctx, T, info, g, lmax, F, nu0, nnu, Gout, alm_dev);
-    if (ncol <= 64) return launch_draw<4>(ctx, T, info, g, lmax, F, nu0, nnu, Gout, alm_dev);
-    if (ncol <= 128) return launch_draw<8>(ctx, T, info, g, lmax, F, nu0, nnu, Gout, alm_dev);
-    return launch_draw<16>(ctx, T, info, g, lmax, F, nu0, nnu, Gout, alm_dev);
+    return draw_host_stream(ctx, T, (size_t)F * F, 0, info, g, lmax, F, nu0, nnu, alm_dev);
 }
 
 int corahip_alm_dev_to_square(corahip_ctx *ctx, const double *alm_dev, int lmax, int nnu, double *square) {

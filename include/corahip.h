@@ -85,6 +85,22 @@ int corahip_clarray_table21cm(corahip_ctx *ctx, const double *dd, const double *
                               int F, int zint, const double *w, const double *log10l, int nl,
                               double *out);
 
+/* Multi-GPU form of the same integration (the reference shards clarray's output over l with
+ * caput.mpiarray, skysim.py:97-103; the table lookups of a channel pair are shared by all l, so here
+ * the PAIRS are sharded instead and the l-shards are assembled by one all-to-all):
+ *   table21cm_pairs integrates, for all nl multipoles, the channel pairs p = pair_first + k pair_step
+ *   (k = 0 .. npl-1, npl = ceil(F(F+1)/2 / pair_step); p enumerates (i, j >= i) row-major) and writes
+ *   out_pairs [ceil(nl / l_block)][npl][l_block]: slab q is what the rank owning l in [q l_block, (q+1) l_block)
+ *   receives.  pairs_finish takes the received slabs [nranks][npl][l_stride] (slab r from rank r) and
+ *   scatters them into out [nl, F, F] and its mirror.                                              */
+int corahip_clarray_table21cm_pairs(corahip_ctx *ctx, const double *dd, const double *dv, const double *vv,
+                                    int nkperp, int nkpar, double kperpmin, double kperpmax, double kparmax,
+                                    const double *chi, const double *pfd, const double *f, const double *b,
+                                    int F, int zint, const double *w, const double *log10l, int nl,
+                                    int pair_first, int pair_step, int l_block, double *out_pairs);
+int corahip_clarray_pairs_finish(corahip_ctx *ctx, const double *pairs_in, int F, int nranks, int l_stride,
+                                 int nl, double *out);
+
 /* the bare aps callable at n independent points (corr.py:953-982): lx = log10(l), chi1, chi2,
  * and the coefficient triples b1 b2 P, (f1 b2 + f2 b1) P, f1 f2 P with P = D1 D2 pf1 pf2
  * (the 1/(xc^2 pi) factor is applied by the kernel).  All arrays [n]. */
@@ -133,6 +149,12 @@ int corahip_draw_alm(corahip_ctx *ctx, const double *T, const int32_t *info, con
  * draw_alm, without the 16*F*nalm-byte normal buffer) */
 int corahip_draw_alm_philox(corahip_ctx *ctx, const double *T, const int32_t *info, uint64_t seed, int lmax,
                             int F, int nu0, int nnu, double *alm_dev);
+
+/* draw_alm_philox with only the rank's rows of the factors resident: T_rows [lmax+1, nnu, F] holds rows
+ * nu0 .. nu0+nnu-1 of every T_l (what a frequency-sharded rank receives from the all-to-all of the
+ * l-sharded factor stack: 1/N of the all-gather traffic and memory).                                */
+int corahip_draw_alm_philox_rows(corahip_ctx *ctx, const double *T_rows, const int32_t *info, uint64_t seed,
+                                 int lmax, int F, int nu0, int nnu, double *alm_dev);
 
 /* layout converters between alm_dev and the reference's arrays:
  *   square  [nnu, 1, L, L] complex128 as returned by mkfullsky(alms=True) (skysim.py:108-125)

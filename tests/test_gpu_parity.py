@@ -525,15 +525,16 @@ def test_config3_full_size_properties(ctx):
 
 
 def test_frequency_sharded_pipeline_matches_single_gpu():
-    """bench.py's N-rank path (l-sharded C_l/factor -> all-gather -> nu-sharded draw + synthesis), run as
-    2 and 4 ranks sharing this one GPU over gloo, gives the same per-channel map statistics as 1 rank."""
+    """bench.py's N-rank paths, run as 2 and 4 ranks sharing this one GPU over gloo, give the same per-channel
+    map statistics as 1 rank: cfg2 (separable model: l-sharded C_l/factor -> all-gather) and a small 21cm
+    case (pair-sharded C_l -> all-to-all -> l-sharded factor -> all-to-all of factor rows).  The RCCL
+    calls themselves are exercised with a 1-rank nccl group (--force-dist)."""
     import os
     import re
     import subprocess
     import sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    common = ["--workload", "cfg2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--checksum"]
 
     def run(cmd):
         p = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=600)
@@ -541,9 +542,57 @@ def test_frequency_sharded_pipeline_matches_single_gpu():
         assert m, p.stderr[-2000:]
         return m.group(1)
 
-    ref = run([sys.executable, "bench.py"] + common)
-    for n, port in ((2, 29631), (4, 29632)):
-        got = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
-                   "--master-addr", "127.0.0.1", "--master-port", str(port), "bench.py", "--gpus", str(n),
-                   "--dist-backend", "gloo", "--same-device"] + common)
-        assert got == ref, (n, got, ref)
+    port = 29631
+    for workload in ("cfg2", "tiny"):
+        common = ["--workload", workload, "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--checksum"]
+        ref = run([sys.executable, "bench.py"] + common)
+        for n in (2, 4):
+            port += 1
+            got = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+                       "--master-addr", "127.0.0.1", "--master-port", str(port), "bench.py", "--gpus", str(n),
+                       "--dist-backend", "gloo", "--same-device"] + common)
+            assert got == ref, (workload, n, got, ref)
+        port += 1
+        env_port = ["--master-port", str(port)]
+        got = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                   "--master-addr", "127.0.0.1"] + env_port + ["bench.py", "--gpus", "1", "--force-dist"] + common)
+        assert got == ref, (workload, "nccl x1", got, ref)
+
+
+def test_pair_sharded_clarray_and_row_sliced_draw(ctx, golden):
+    """The multi-GPU building blocks against their single-GPU forms, in one process: K1 pair shards of 3
+    'ranks' assembled by hand == clarray_table21cm; draw from factor row blocks == draw from full factors."""
+    import torch
+    from cora_amd.core import skysim
+    from cora_amd.signal import corr21cm
+
+    cr = corr21cm.Corr21cm()
+    F, lmax, zromb = 12, 70, 2
+    L = lmax + 1
+    freq = np.linspace(500.0, 530.0, F)
+    zint = 2**zromb + 1
+    zh = abs(freq[1] - freq[0]) / 2
+    za = (freq[:, None] + np.linspace(-zh, zh, zint)[None, :]).ravel()
+    plan = cr._clarray_plan(cr.angular_powerspectrum)
+    p = plan["prepare"](ctx, za)
+    w = ctx.to_device(skysim.romberg_weights(zromb))
+    larr = np.arange(L, dtype=np.float64)
+    lx = ctx.to_device(np.log10(np.where(larr == 0, 1e-10, larr)))
+    k1 = [ctx.to_device(p[k]) for k in ("chi", "pfd", "f", "b")]
+    tabs = (p["dd"], p["dv"], p["vv"], p["kperpmin"], p["kperpmax"], p["kparmax"])
+    C = ctx.clarray_table21cm(*tabs, *k1, F, zint, w, lx)
+    W = 3
+    lsh = (L + W - 1) // W
+    slabs = [ctx.clarray_table21cm_pairs(*tabs, *k1, F, zint, w, lx, r, W, lsh) for r in range(W)]   # [W][npl][lsh] each
+    for q in range(W):
+        mine = torch.stack([slabs[r][q] for r in range(W)])          # what the all-to-all hands rank q
+        nl = min(L, (q + 1) * lsh) - q * lsh
+        Cq = ctx.clarray_pairs_finish(mine, F, nl)
+        assert torch.equal(Cq, C[q * lsh : q * lsh + nl])
+    T, info = ctx.factor_batched(C)
+    full = ctx.draw_alm_philox(T, info, 99, lmax, F)
+    fsq = ctx.alm_dev_to_square(full, lmax, F)
+    for nu0, nnu in ((0, 4), (4, 4), (8, 4), (2, 7)):
+        rows = T[:, nu0 : nu0 + nnu, :].contiguous()
+        part = ctx.alm_dev_to_square(ctx.draw_alm_philox_rows(rows, info, 99, lmax, F, nu0, nnu), lmax, nnu)
+        assert torch.equal(part, fsq[nu0 : nu0 + nnu])

@@ -55,3 +55,51 @@ def test_allgather_factors_gloo_world2():
     for p in procs:
         p.join(timeout=60)
     assert sorted(res) == [(0, True), (1, True)]
+
+
+def _worker_a2a(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+
+    sys.path.insert(0, ROOT)
+    from cora_amd.parallel import exchange_factor_rows, exchange_pair_slabs, shard_plan
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    L, F = 11, 4
+    p = shard_plan(L, F, rank, world)
+    # factor rows: rank r must end up with T_l[nu in its channels, :] for every l
+    full = torch.arange(L * F * F, dtype=torch.float64).reshape(L, F, F)
+    info_full = (torch.arange(L) % 2).to(torch.int32)
+    Tr, info = exchange_factor_rows(full[p.l_lo:p.l_hi].clone(), info_full[p.l_lo:p.l_hi].clone(), p)
+    ok = bool(torch.equal(Tr, full[:, p.nu0:p.nu0 + p.nnu, :]) and torch.equal(info, info_full))
+    # pair slabs: value encodes (source rank, destination rank, slot, l): slab q of rank r -> slab r of rank q
+    npl = 5
+    send = torch.empty((world, npl, p.l_shard), dtype=torch.float64)
+    for dst in range(world):
+        for k in range(npl):
+            send[dst, k] = 1000 * rank + 100 * dst + 10 * k + torch.arange(p.l_shard, dtype=torch.float64) / 100
+    recv = exchange_pair_slabs(send, p)
+    for src in range(world):
+        for k in range(npl):
+            want = 1000 * src + 100 * rank + 10 * k + torch.arange(p.l_shard, dtype=torch.float64) / 100
+            ok = ok and bool(torch.equal(recv[src, k], want))
+    q.put((rank, ok))
+    dist.destroy_process_group()
+
+
+def test_all_to_all_exchanges_gloo_world2():
+    """pair-shard -> l-shard all-to-all of K1 and the factor row-block all-to-all (21cm multi-GPU path)."""
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker_a2a, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, True), (1, True)]
