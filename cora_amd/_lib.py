@@ -56,6 +56,8 @@ SIGNATURES = {
     "corahip_sht_plan_destroy": (c_int, [c_void_p, c_void_p]),
     "corahip_alm2map_workspace_bytes": (c_int, [c_void_p, c_int, ctypes.POINTER(c_size_t)]),
     "corahip_alm2map": (c_int, [c_void_p, c_void_p, PTR, c_int, PTR, c_void_p, c_size_t]),
+    "corahip_map2alm_workspace_bytes": (c_int, [c_void_p, c_int, ctypes.POINTER(c_size_t)]),
+    "corahip_map2alm": (c_int, [c_void_p, c_void_p, PTR, c_int, PTR, PTR, c_void_p, c_size_t]),
     "corahip_sht_plan_rings": (c_int, [c_void_p, PTR, PTR, PTR, PTR]),
     "corahip_sht_lambda": (c_int, [c_void_p, c_void_p, c_int, c_int, PTR]),
 }
@@ -324,6 +326,42 @@ class Context:
         ws = self.workspace(need)
         _check(self.lib.corahip_alm2map(self.h, plan, self._f64(alm), nnu, self._f64(maps), self._p(ws), need))
         return maps
+
+    def map2alm_workspace_bytes(self, plan, nnu):
+        b = c_size_t()
+        _check(self.lib.corahip_map2alm_workspace_bytes(plan, nnu, ctypes.byref(b)))
+        return int(b.value)
+
+    def map2alm(self, maps, nside, lmax, ring_w=None, chunk=None):
+        """One weighted quadrature pass maps [nnu, npix] -> alm_dev [nalm, ceil(nnu/4), 2, 4] (K5^T + K4^T).
+
+        ring_w: device [2 nside] north-ring weights or None.  Channels go through in chunks of `chunk`
+        (a multiple of 8; default: as many as a 96 GB workspace holds)."""
+        torch = _torch()
+        plan = self.sht_plan(nside, lmax)
+        nnu, npix = maps.shape
+        assert npix == 12 * nside * nside
+        nalm = (lmax + 1) * (lmax + 2) // 2
+        G4 = (nnu + 3) // 4
+        if chunk is None:
+            per8 = self.map2alm_workspace_bytes(plan, 8)
+            chunk = max(8, min((int(96e9 // per8)) * 8, (nnu + 7) // 8 * 8))
+        assert chunk % 8 == 0
+        out = self.empty((nalm, G4, 2, 4))
+        for c0 in range(0, nnu, chunk):
+            n = min(chunk, nnu - c0)
+            G8 = (n + 7) // 8 * 2
+            need = self.map2alm_workspace_bytes(plan, n)
+            ws = self.workspace(need)
+            part = out if (c0 == 0 and n == nnu and G8 == G4) else self.empty((nalm, G8, 2, 4))
+            _check(self.lib.corahip_map2alm(self.h, plan, self._f64(maps[c0:c0 + n]), n,
+                                            self._f64(ring_w) if ring_w is not None else None, self._f64(part),
+                                            self._p(ws), need))
+            if part is not out:
+                g0 = c0 // 4
+                gn = min(G8, G4 - g0)
+                out[:, g0:g0 + gn].copy_(part[:, :gn])
+        return out
 
     def sht_rings(self, nside, lmax):
         plan = self.sht_plan(nside, lmax)

@@ -1081,6 +1081,287 @@ ringfft_kernel(const int32_t *__restrict__ ring_list, int nlist, int nside, int 
 }
 
 // ------------------------------------------------------------------------------------
+// Analysis (adjoint of K5 and K4): healpy.map2alm as the reference reaches it through
+// hputil.sphtrans_real / sphtrans_sky / sph_ps (cora/util/hputil.py:195-234,460-497,607-619)
+// ------------------------------------------------------------------------------------
+// K5^T  ringana_kernel: per ring, G_m = w_ring (4 pi / npix) e^{-i m phi0} sum_j x_j e^{-2 pi i j m / n},
+//       m < mcut(ring), for NCH channels at once, written in the `inter` cell layout K4 writes and K5 reads.
+//       The n real pixels are packed as h = n/2 complex numbers z_j = x_2j + i x_2j+1; a complex transform of
+//       length h (radix-16 LDS passes; Bluestein with the synthesis' chirp/filter tables for the cap rings,
+//       run on conj(z) so that the same e^{+...} machinery serves) and the split
+//           X_k = 1/2 [(Z_k + conj Z_{h-k}) - i e^{-2 pi i k/n} (Z_k - conj Z_{h-k})]
+//       give bins 0..h; m >= n aliases back (k = m mod n, conjugate above h).
+template <int NCH>
+__global__ void __launch_bounds__(K5_THREADS)
+ringana_kernel(const int32_t *__restrict__ ring_list, int nlist, int nside, int lmax, int G, int nnu, long npix,
+               const int32_t *__restrict__ nphi_a, const int64_t *__restrict__ start_a,
+               const double *__restrict__ phi0_a, const double *__restrict__ maps, double *__restrict__ inter,
+               const double2 *__restrict__ tw, int pmax, const int32_t *__restrict__ blu_P,
+               const int64_t *__restrict__ boff, const int64_t *__restrict__ foff,
+               const double2 *__restrict__ chirp, const double2 *__restrict__ filt, int bstride,
+               const int32_t *__restrict__ mcut, const double *__restrict__ ring_w, int nvalid) {
+    // nnu: channels incl. padding (every cell K4^T reads gets written); nvalid: channels present in `maps`
+    extern __shared__ __attribute__((aligned(16))) double2 sm[];  // [NCH][bstride]
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int L = lmax + 1;
+    const int ngrp = (nnu + NCH - 1) / NCH;
+    const int nitems = nlist * ngrp;
+    const int nring = 4 * nside - 1;
+    for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+        const int ring = ring_list[item / ngrp];
+        const int ch0 = (item % ngrp) * NCH;
+        const int n = nphi_a[ring];
+        const int h = n >> 1;
+        const long start = start_a[ring];
+        const double phi0_over_pi = phi0_a[ring] / M_PI;
+        int icap = 0;
+        if (ring + 1 < nside) icap = ring + 1;
+        else if (ring + 1 > 3 * nside) icap = 4 * nside - (ring + 1);
+        const int P = icap ? blu_P[icap - 1] : 0;
+        const int Lr = mcut[ring];
+        const double wr = (ring_w ? ring_w[min(ring, nring - 1 - ring)] : 1.0) * (4.0 * M_PI / (double)npix);
+        const double2 *bch = P ? chirp + boff[icap - 1] : nullptr;
+        __syncthreads();  // previous item's LDS reads are done
+        if (P) {
+            for (int j = h + tid; j < P; j += nt)
+#pragma unroll
+                for (int c = 0; c < NCH; c++) sm[(size_t)c * bstride + fpad(j)] = make_double2(0.0, 0.0);
+        }
+        // ---- pixels -> packed complex (conjugated and chirped for the Bluestein path)
+        for (int j = tid; j < h; j += nt) {
+            const double2 bj = P ? bch[j] : make_double2(1.0, 0.0);
+#pragma unroll
+            for (int c = 0; c < NCH; c++) {
+                double2 zv = make_double2(0.0, 0.0);
+                if (ch0 + c < nvalid) zv = *reinterpret_cast<const double2 *>(maps + (size_t)(ch0 + c) * npix + start + 2 * j);
+                if (P) zv = cmul(make_double2(zv.x, -zv.y), bj);
+                sm[(size_t)c * bstride + fpad(j)] = zv;
+            }
+        }
+        __syncthreads();
+        double scaleZ = 1.0;
+        if (P == 0) {
+            fft_dif<-1>(sm, bstride, NCH, h, tw, pmax);          // Z_k at fft_dif_pos(k)
+        } else {
+            const double2 *f = filt + foff[icap - 1];
+            fft_dif<-1>(sm, bstride, NCH, P, tw, pmax, f);
+            fft_dit<1>(sm, bstride, NCH, P, tw, pmax);           // W'_k natural order; Z_k = conj(W'_k b_k / P)
+            scaleZ = 1.0 / (double)P;
+        }
+        auto getZ = [&](const double2 *bc, int k) {  // k in [0, h)
+            if (P == 0) return bc[fpad(fft_dif_pos(k, h))];
+            const double2 v = cmul(bc[fpad(k)], bch[k]);
+            return make_double2(v.x * scaleZ, -v.y * scaleZ);
+        };
+        // ---- bins -> G_m cells
+        const bool n_in_table = (pmax % n) == 0;
+        double *cell0 = inter + ((size_t)ring * G + (ch0 >> 2)) * L * 8 + (ch0 & 3);
+        for (int m = tid; m < Lr; m += nt) {
+            const int k = m % n;
+            const bool cj = k > h;
+            const int kk = cj ? n - k : k;            // 0..h
+            const int ka = kk == h ? 0 : kk;          // Z_h := Z_0
+            const int kb = kk == 0 ? 0 : h - kk;      // partner h - kk (kk = 0 -> Z_h = Z_0)
+            double2 w;                                // e^{-2 pi i kk / n}
+            if (n_in_table) w = tw_get<-1>(tw, pmax, kk * (pmax / n));
+            else {
+                double sv, cv;
+                sincospi(2.0 * (double)kk / (double)n, &sv, &cv);
+                w = make_double2(cv, -sv);
+            }
+            double sp, cp;
+            sincospi(fmod((double)m * phi0_over_pi, 2.0), &sp, &cp);
+            const double2 ph = make_double2(cp * wr, -sp * wr);   // w_ring area e^{-i m phi0}
+            double re[NCH], im[NCH];
+#pragma unroll
+            for (int c = 0; c < NCH; c++) {
+                const double2 *bc = sm + (size_t)c * bstride;
+                const double2 za = getZ(bc, ka), zb = getZ(bc, kb);
+                const double2 sum = make_double2(za.x + zb.x, za.y - zb.y);   // Z_k + conj Z_{h-k}
+                const double2 dif = make_double2(za.x - zb.x, za.y + zb.y);   // Z_k - conj Z_{h-k}
+                const double2 t = cmul(dif, w);
+                // X = 1/2 [sum - i t]
+                double2 X = make_double2(0.5 * (sum.x + t.y), 0.5 * (sum.y - t.x));
+                if (cj) X.y = -X.y;
+                const double2 g = cmul(X, ph);
+                re[c] = g.x;
+                im[c] = g.y;
+            }
+            double *cell = cell0 + (size_t)m * 8;
+            if (NCH == 4) {
+                *reinterpret_cast<double4 *>(cell) = make_double4(re[0], re[1 % NCH], re[2 % NCH], re[3 % NCH]);
+                *reinterpret_cast<double4 *>(cell + 4) = make_double4(im[0], im[1 % NCH], im[2 % NCH], im[3 % NCH]);
+            } else if (NCH == 2) {
+                *reinterpret_cast<double2 *>(cell) = make_double2(re[0], re[1 % NCH]);
+                *reinterpret_cast<double2 *>(cell + 4) = make_double2(im[0], im[1 % NCH]);
+            } else {
+                cell[0] = re[0];
+                cell[4] = im[0];
+            }
+        }
+    }
+}
+
+// K4^T  legendre_adj_kernel: a_lm(col) = sum_rings lambda_lm(ring) [G_m(north) + (-1)^{l+m} G_m(south)](col)
+// on FP64 MFMA with M = l, K = ring pairs, N = columns (channel re/im).  Work item = (m, 16 NCT columns,
+// tile of 512 ring pairs).  A wave owns 64 ring pairs: lane = ring steps the recurrence once per l (no
+// redundancy), the 32 lambda values of an l-block go through a wave-private LDS transpose into the A-operand
+// layout (16 same-parity l x 4 rings), and the wave's G tile (64 rings x 16 NCT columns, even = N+S and
+// odd = N-S combinations) stays in REGISTERS as the B operand for the whole item.  The eight waves hold
+// different rings, so their [32 l x 16 NCT] partial sums are added through LDS once per l-block; the four
+// ring tiles of an (m, column group) go to separate partial buffers summed by alm_reduce_kernel
+// (deterministic - no atomics).
+template <int NCT>
+__global__ void __launch_bounds__(512)
+legendre_adj_kernel(int lmax, int npair, int nring, int ncols, const double *__restrict__ z,
+                    const double2 *__restrict__ coef, const int32_t *__restrict__ lstart,
+                    const double2 *__restrict__ seed, const int32_t *__restrict__ lmin_tab,
+                    const int32_t *__restrict__ mcut, const double *__restrict__ inter, double *__restrict__ part,
+                    unsigned *__restrict__ queue) {
+    constexpr int TCOLS = 16 * NCT;
+    constexpr int TRINGS = 64 * LEG_WAVES;     // 512 ring pairs per workgroup
+    constexpr int LB = 32;                     // l per block: 16 even + 16 odd (l - m)
+    constexpr int LSTR = LB + 1;               // LDS row stride of the transpose: conflict-free both ways
+    constexpr int WREG = 64 * LSTR;            // doubles per wave
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    int &s_next = *reinterpret_cast<int *>(lds + LEG_WAVES * WREG);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int ri = lane & 15, kq = lane >> 4;
+    const int L = lmax + 1;
+    const int G = ncols >> 3;
+    const long nalm = nalm_of(lmax);
+    const int ntile128 = (npair + LEG_RINGS - 1) / LEG_RINGS;
+    const int ntile = (npair + TRINGS - 1) / TRINGS;
+    const int ncg = ncols / TCOLS;
+    const int nitems = L * ncg * ntile;
+    double *lamw = lds + wave * WREG;
+
+    int item = blockIdx.x;
+    while (item < nitems) {
+        if (tid == 0) s_next = (int)(gridDim.x + atomicAdd(queue, 1u));
+        const int gidx = item / ntile;
+        const int rtile = item - gidx * ntile;
+        const int m = gidx / ncg;
+        const int cg = gidx - m * ncg;
+        int lmin = lmax + 1;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int t128 = rtile * 4 + q;
+            if (t128 < ntile128) lmin = min(lmin, lmin_tab[m * ntile128 + t128]);
+        }
+        const long base_m = alm_idx(0, m, lmax);
+        const int lb0 = lmin <= lmax ? m + ((lmin - m) & ~(LB - 1)) : lmax + 1;
+        double *pout = part + ((size_t)rtile * nalm + base_m) * ncols + (size_t)cg * TCOLS;
+        // multipoles this tile cannot reach contribute zero
+        for (int e = tid; e < (lb0 - m) * TCOLS; e += 512) pout[(size_t)(m + e / TCOLS) * ncols + e % TCOLS] = 0.0;
+
+        if (lb0 <= lmax) {
+            // ---- this wave's G tile -> registers (B operand): k-step s covers rings 4s..4s+3 of the wave
+            double ge[16][NCT], go[16][NCT];
+#pragma unroll
+            for (int s = 0; s < 16; s++) {
+                const int ro = rtile * TRINGS + (4 * s + kq) * LEG_WAVES + wave;
+                const bool ok = ro < npair && m < mcut[min(ro, npair - 1)];
+                const int rs = nring - 1 - ro;
+#pragma unroll
+                for (int t = 0; t < NCT; t++) {
+                    const int col = cg * TCOLS + 16 * t + ri;
+                    const size_t off = ((size_t)(col >> 3) * L + m) * 8 + (col & 7);
+                    double gn = 0.0, gsv = 0.0;
+                    if (ok) {
+                        gn = inter[(size_t)ro * G * L * 8 + off];
+                        if (rs != ro) gsv = inter[(size_t)rs * G * L * 8 + off];
+                    }
+                    ge[s][t] = gn + gsv;
+                    go[s][t] = gn - gsv;
+                }
+            }
+            // ---- recurrence state of this lane's ring
+            const int ring = rtile * TRINGS + lane * LEG_WAVES + wave;
+            double x = 0.0, p0 = 0.0, p1 = 0.0;
+            double2 sd = make_double2(0.0, 0.0);
+            int my_ls = lmax + 1;
+            if (ring < npair) {
+                x = z[ring];
+                const long o = (long)m * npair + ring;
+                my_ls = lstart[o];
+                sd = seed[o];
+            }
+            // first l of each group of 4 lanes (= one MFMA k-step): lets whole k-steps be skipped
+            int ls4 = min(my_ls, __shfl_xor(my_ls, 1));
+            ls4 = min(ls4, __shfl_xor(ls4, 2));
+            const double2 *cf = coef + base_m;
+
+            for (int lb = lb0; lb <= lmax; lb += LB) {
+                const unsigned long long act = __ballot(ls4 <= lb + LB - 1);   // bit 4s: k-step s has a started ring
+                // lambda_{lb .. lb+31} of this lane's ring -> transpose buffer [ring][l - lb]
+#pragma unroll 8
+                for (int j = 0; j < LB; j++) {
+                    const int l = lb + j;
+                    const double2 c = (l <= lmax) ? cf[l] : make_double2(0.0, 0.0);
+                    double vv = fma(c.x * x, p1, -(c.y * p0));
+                    const bool inj = (l == my_ls);
+                    vv = inj ? sd.y : vv;
+                    p0 = inj ? sd.x : p1;
+                    p1 = vv;
+                    lamw[lane * LSTR + j] = vv;
+                }
+                d4_t acc[2][NCT];
+#pragma unroll
+                for (int par = 0; par < 2; par++)
+#pragma unroll
+                    for (int t = 0; t < NCT; t++) acc[par][t] = (d4_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int s = 0; s < 16; s++) {
+                    if (!((act >> (4 * s)) & 1ull)) continue;
+                    const double ae = lamw[(4 * s + kq) * LSTR + 2 * ri];
+                    const double ao = lamw[(4 * s + kq) * LSTR + 2 * ri + 1];
+#pragma unroll
+                    for (int t = 0; t < NCT; t++) {
+                        acc[0][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(ae, ge[s][t], acc[0][t], 0, 0, 0);
+                        acc[1][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(ao, go[s][t], acc[1][t], 0, 0, 0);
+                    }
+                }
+                // ---- add the eight waves' partial tiles through LDS (the wave's transpose buffer is free now:
+                //      LDS operations of one wave are ordered)
+#pragma unroll
+                for (int par = 0; par < 2; par++)
+#pragma unroll
+                    for (int t = 0; t < NCT; t++)
+#pragma unroll
+                        for (int r = 0; r < 4; r++) lamw[((par * NCT + t) * 4 + r) * 64 + lane] = acc[par][t][r];
+                __syncthreads();
+#pragma unroll
+                for (int u = 0; u < NCT; u++) {
+                    const int e = tid + 512 * u;          // element (par, t, r, lane) of the reduced tile
+                    double sum = 0.0;
+#pragma unroll
+                    for (int w = 0; w < LEG_WAVES; w++) sum += lds[w * WREG + e];
+                    const int el = e & 63, r = (e >> 6) & 3, t = (e >> 8) % NCT, par = (e >> 8) / NCT;
+                    const int l = lb + 2 * ((el >> 4) + 4 * r) + par;
+                    if (l <= lmax) pout[(size_t)l * ncols + 16 * t + (el & 15)] = sum;
+                }
+                __syncthreads();
+            }
+        }
+        __syncthreads();
+        item = __builtin_amdgcn_readfirstlane(s_next);
+        __syncthreads();
+    }
+}
+
+// alm_dev[idx][col] = sum over ring tiles of part[rt][idx][col]
+__global__ void alm_reduce_kernel(const double *__restrict__ part, long n, int ntile, double *__restrict__ alm) {
+    for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (long)gridDim.x * blockDim.x) {
+        double s = 0.0;
+        for (int t = 0; t < ntile; t++) s += part[(size_t)t * n + q];
+        alm[q] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------
 template <typename T>
@@ -1472,6 +1753,90 @@ extern "C" int corahip_alm2map(corahip_ctx *ctx, const corahip_sht_plan *p, cons
         LAUNCH_CHECK();
         int rc = alm2map_chunk(ctx, p, slice, cpad8, nvalid, maps + (size_t)nu0 * p->npix, inter);
         if (rc) return rc;
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------
+// analysis host side
+// ------------------------------------------------------------------------------------
+extern "C" int corahip_map2alm_workspace_bytes(const corahip_sht_plan *p, int nnu, size_t *bytes) {
+    ARG_CHECK(p != nullptr && bytes != nullptr && nnu >= 1);
+    const size_t G = nnu_pad_of(nnu) / 4;
+    const int ntile = (p->npair + 64 * LEG_WAVES - 1) / (64 * LEG_WAVES);
+    *bytes = (size_t)p->nring * G * p->L * 8 * sizeof(double)            // G_m cells (the `inter` layout)
+             + (size_t)ntile * p->nalm * G * 8 * sizeof(double);         // per-ring-tile partial a_lm
+    return 0;
+}
+
+template <int NCT>
+static int launch_legendre_adj(corahip_ctx *ctx, const corahip_sht_plan *p, int ncols, const double *inter,
+                               double *part) {
+    const size_t shm = sizeof(double) * (size_t)LEG_WAVES * 64 * 33 + 16;
+    HIP_TRY(hipFuncSetAttribute((const void *)legendre_adj_kernel<NCT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)shm));
+    const int ntile = (p->npair + 64 * LEG_WAVES - 1) / (64 * LEG_WAVES);
+    const long nitems = (long)p->L * (ncols / (16 * NCT)) * ntile;
+    dim3 grid((unsigned)std::min<long>(nitems, (long)ctx->num_cu));
+    HIP_TRY(hipMemsetAsync(p->d_queue, 0, 64, ctx->stream));
+    legendre_adj_kernel<NCT><<<grid, 512, shm, ctx->stream>>>(p->lmax, p->npair, p->nring, ncols, p->d_z, p->d_coef,
+                                                             p->d_lstart, p->d_seed, p->d_lmin, p->d_mcut, inter, part,
+                                                             p->d_queue);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+// maps [nnu][npix] RING -> alm_dev [nalm][nnu_pad8/4][2][4]: ONE weighted quadrature pass (no iteration),
+//   a_lm = sum_pix w_ring(pix) (4 pi / npix) map(pix) conj(Y_lm(pix)).
+// ring_w: device [2 nside] weights of the north rings incl. equator (mirrored to the south), or NULL = 1.
+extern "C" int corahip_map2alm(corahip_ctx *ctx, const corahip_sht_plan *p, const double *maps, int nnu,
+                               const double *ring_w, double *alm_dev, void *workspace, size_t workspace_bytes) {
+    ARG_CHECK(ctx != nullptr && p != nullptr && maps != nullptr && alm_dev != nullptr && workspace != nullptr);
+    ARG_CHECK(nnu >= 1);
+    size_t need;
+    corahip_map2alm_workspace_bytes(p, nnu, &need);
+    if (workspace_bytes < need) {
+        corahip_set_error("map2alm workspace too small: %zu bytes, need %zu (process fewer channels per call)",
+                          workspace_bytes, need);
+        return CORAHIP_ENOMEM;
+    }
+    const int nnu_pad8 = nnu_pad_of(nnu);
+    const int G = nnu_pad8 / 4;
+    const int ncols = 2 * nnu_pad8;
+    double *inter = (double *)workspace;
+    double *part = inter + (size_t)p->nring * G * p->L * 8;
+    {
+        StageTimer t(ctx, "ringana");
+        const int k5_threads = K5_THREADS;
+        for (const auto &c : p->classes) {
+            const size_t shm = sizeof(double2) * (size_t)c.nch * c.bstride;
+            const long nitems = (long)c.count * ((nnu_pad8 + c.nch - 1) / c.nch);
+            dim3 grid((unsigned)std::min<long>(nitems, (long)ctx->num_cu * 4));
+#define RINGANA_LAUNCH(NCH)                                                                                      \
+    HIP_TRY(hipFuncSetAttribute((const void *)ringana_kernel<NCH>, hipFuncAttributeMaxDynamicSharedMemorySize,   \
+                                160 * 1024));                                                                    \
+    ringana_kernel<NCH><<<grid, k5_threads, shm, ctx->stream>>>(c.d_list, c.count, p->nside, p->lmax, G, nnu_pad8, p->npix,  \
+                                                         p->d_nphi, p->d_start, p->d_phi0, maps, inter, p->d_tw,    \
+                                                         p->pmax, p->d_blu_P, p->d_blu_boff, p->d_blu_foff,         \
+                                                         p->d_bchirp, p->d_bfilt, c.bstride, p->d_mcut, ring_w, nnu)
+            if (c.nch == 4) { RINGANA_LAUNCH(4); }
+            else if (c.nch == 2) { RINGANA_LAUNCH(2); }
+            else { RINGANA_LAUNCH(1); }
+#undef RINGANA_LAUNCH
+            LAUNCH_CHECK();
+        }
+    }
+    {
+        StageTimer t(ctx, "legendre_adj");
+        const int nt16 = ncols / 16;
+        int rc;
+        if (nt16 % 2 == 0) rc = launch_legendre_adj<2>(ctx, p, ncols, inter, part);
+        else rc = launch_legendre_adj<1>(ctx, p, ncols, inter, part);
+        if (rc) return rc;
+        const int ntile = (p->npair + 64 * LEG_WAVES - 1) / (64 * LEG_WAVES);
+        const long n = p->nalm * (long)ncols;
+        alm_reduce_kernel<<<(int)std::min<long>((n + 255) / 256, 8192), 256, 0, ctx->stream>>>(part, n, ntile, alm_dev);
+        LAUNCH_CHECK();
     }
     return 0;
 }

@@ -3,6 +3,8 @@
 ``sphtrans_inv_real`` / ``sphtrans_inv_sky`` call the library's HEALPix synthesis
 (K4 Legendre MFMA contraction + K5 ring FFT) where the reference calls
 ``healpy.alm2map`` (cora/util/hputil.py:388-391); all channels go through in one batch.
+``sphtrans_real`` / ``sphtrans_sky`` / ``sph_ps`` call the adjoint kernels where the reference
+calls ``healpy.map2alm(use_weights=True, iter=2)`` (cora/util/hputil.py:46-47,195-234,460-497,607-619).
 """
 import numpy as np
 
@@ -81,3 +83,116 @@ def sphtrans_inv_sky(alm, nside):
     for p in range(npol):
         sky[:, p] = _synth(np.asarray(alm[:, p]), nside)
     return sky
+
+
+# ------------------------------------------------------------------------------------
+# analysis: healpy.map2alm(use_weights=_weight, iter=_iter) as the reference configures it
+# ------------------------------------------------------------------------------------
+_weight = True   # cora/util/hputil.py:46
+_iter = 2        # cora/util/hputil.py:47
+_ring_weight_cache = {}
+
+
+def ring_weights(nside, lmax_exact=None):
+    """Quadrature weights of the 2 nside north rings (equator included).
+
+    healpy reads these from the HEALPix data file weight_ring_n<nside>.fits; that file is data of a
+    dependency which is not available to this package, so the defining property is used: the
+    minimum-norm correction to uniform weights that integrates the zonal P_l(z), even l <= lmax_exact
+    (default 3 nside), exactly.  Host numpy, once per nside (cached)."""
+    key = (int(nside), lmax_exact)
+    if key not in _ring_weight_cache:
+        nside = int(nside)
+        npair = 2 * nside
+        npix = nside2npix(nside)
+        i = np.arange(1, npair + 1, dtype=np.float64)
+        cap = i < nside
+        z = np.where(cap, 1.0 - i * i / (3.0 * nside * nside), 4.0 / 3.0 - 2.0 * i / (3.0 * nside))
+        cnt = np.where(cap, 4.0 * i, 4.0 * nside) * 2.0
+        cnt[-1] = 4.0 * nside                       # the equator ring has no mirror
+        lx = 3 * nside if lmax_exact is None else int(lmax_exact)
+        P = np.empty((lx + 1, npair))
+        P[0] = 1.0
+        if lx >= 1:
+            P[1] = z
+        for l in range(2, lx + 1):
+            P[l] = ((2 * l - 1) * z * P[l - 1] - (l - 1) * P[l - 2]) / l
+        M = P[0::2] * (cnt * 4.0 * np.pi / npix)[None, :]
+        rhs = np.zeros(M.shape[0])
+        rhs[0] = 4.0 * np.pi
+        _ring_weight_cache[key] = 1.0 + np.linalg.lstsq(M, rhs - M.sum(axis=1), rcond=None)[0]
+    return _ring_weight_cache[key]
+
+
+def map2alm_device(maps, nside, lmax, use_weights=None, niter=None):
+    """Device maps [n, npix] -> alm_dev: quadrature pass + `niter` Jacobi refinements
+    alm <- alm + A(map - S alm), i.e. healpy.map2alm(..., use_weights, iter) for all maps at once."""
+    ctx = _lib.get_context()
+    use_weights = _weight if use_weights is None else use_weights
+    niter = _iter if niter is None else niter
+    w = ctx.to_device(ring_weights(nside)) if use_weights else None
+    n = maps.shape[0]
+    alm = ctx.map2alm(maps, int(nside), int(lmax), w)
+    for _ in range(niter):
+        resid = maps - ctx.alm2map(alm, int(nside), int(lmax), n)
+        alm = alm + ctx.map2alm(resid, int(nside), int(lmax), w)
+        del resid
+    return alm
+
+
+def _analyse(hpmaps, lmax):
+    """[n, npix] host maps -> [n, lmax+1, lmax+1] complex alm[l, m] (m > l entries zero)."""
+    import torch
+
+    hpmaps = np.ascontiguousarray(hpmaps, dtype=np.float64)
+    n, npix = hpmaps.shape
+    nside = int(round(np.sqrt(npix / 12.0)))
+    if 12 * nside * nside != npix:
+        raise ValueError("Wrong pixel number (it is not 12*nside**2)")   # healpy.npix2nside
+    ctx = _lib.get_context()
+    alm = map2alm_device(torch.from_numpy(hpmaps).to(ctx.device), nside, lmax)
+    return ctx.alm_dev_to_square(alm, lmax, n).cpu().numpy()[:, 0]
+
+
+def sphtrans_real(hpmap, lmax=None, lside=None):
+    """Spherical harmonic transform of a real map -> alm[l, m], m >= 0 (cora/util/hputil.py:195-234)."""
+    hpmap = np.asarray(hpmap)
+    if lmax is None:
+        lmax = 3 * int(round(np.sqrt(hpmap.size / 12.0))) - 1
+    if lside is None or lside < lmax:
+        lside = lmax
+    alm = np.zeros([lside + 1, lside + 1], dtype=np.complex128)
+    alm[: lmax + 1, : lmax + 1] = _analyse(hpmap.reshape(1, -1), lmax)[0]
+    return alm
+
+
+def sphtrans_sky(skymap, lmax=None):
+    """[freq, npix] (or [freq, 1|2, npix]) sky -> alm [freq, (pol,) l, m] (cora/util/hputil.py:460-497).
+    All frequency slices go through the GPU in one batch; the polarised branch (3 or 4 components) is
+    outside this package's scope."""
+    skymap = np.asarray(skymap)
+    if skymap.ndim == 3 and skymap.shape[1] >= 3:
+        raise NotImplementedError("polarised analysis (hputil.py:265-330) is out of scope of cora_amd")
+    if lmax is None:
+        lmax = 3 * int(round(np.sqrt(skymap.shape[-1] / 12.0))) - 1
+    flat = skymap.reshape(-1, skymap.shape[-1]).astype(np.float64)
+    alm = _analyse(flat, lmax)
+    return alm.reshape(skymap.shape[:-1] + (lmax + 1, lmax + 1))
+
+
+def sph_ps(map1, map2=None, lmax=None):
+    """Angular (cross) power spectrum of maps (cora/util/hputil.py:607-619).
+
+    The reference's test ``if map is not None`` looks at the builtin ``map`` and is always true, so its
+    auto-spectrum branch never runs and ``map2=None`` fails inside healpy; here ``map2=None`` means the
+    auto spectrum, which is what the signature documents."""
+    map1 = np.asarray(map1)
+    lmax = lmax if lmax is not None else (3 * int(round(np.sqrt(map1.size / 12.0))) - 1)
+    if map2 is None:
+        alm1 = alm2 = sphtrans_real(map1, lmax)
+    else:
+        both = _analyse(np.stack([map1, np.asarray(map2)]), lmax)
+        alm1, alm2 = both[0], both[1]
+    prod = alm1 * alm2.conj()
+    s = prod[:, 0] + 2 * prod[:, 1:].sum(axis=1).real
+    return s / (2.0 * np.arange(lmax + 1) + 1.0)

@@ -175,6 +175,18 @@ int corahip_alm2map_workspace_bytes(const corahip_sht_plan *plan, int nnu, size_
 int corahip_alm2map(corahip_ctx *ctx, const corahip_sht_plan *plan, const double *alm_dev, int nnu,
                     double *maps, void *workspace, size_t workspace_bytes);
 
+/* ---- analysis: the quadrature pass of healpy.map2alm --------------------
+ * Replaces what hputil.sphtrans_real / sphtrans_sky / sph_ps obtain from healpy.map2alm
+ * (cora/util/hputil.py:195-234,460-497,607-619) for nnu channels at once:
+ *   a_lm = sum_pix w_ring(pix) (4 pi / npix) map(pix) conj(Y_lm(pix))
+ * maps [nnu, 12 nside^2] RING -> alm_dev [nalm][nnu_pad/4][2][4] (nnu_pad = nnu rounded up to 8).
+ * ring_w: device [2 nside] quadrature weights of the north rings incl. the equator (the south mirrors
+ * them; what healpy reads from weight_ring_n*.fits for use_weights=True), NULL = uniform.
+ * healpy's iter=N refinement alm += A(map - S alm) is composed by the caller from alm2map/map2alm. */
+int corahip_map2alm_workspace_bytes(const corahip_sht_plan *plan, int nnu, size_t *bytes);
+int corahip_map2alm(corahip_ctx *ctx, const corahip_sht_plan *plan, const double *maps, int nnu,
+                    const double *ring_w, double *alm_dev, void *workspace, size_t workspace_bytes);
+
 /* ring geometry of the plan (host arrays of length 4 nside - 1), for tests */
 int corahip_sht_plan_rings(const corahip_sht_plan *plan, int64_t *host_start, int32_t *host_nphi,
                            double *host_z, double *host_phi0);

@@ -32,6 +32,8 @@ def _load():
         dp = ctypes.POINTER(ctypes.c_double)
         _lib.oracle_legendre_synth.argtypes = [ctypes.c_int, ctypes.c_int, dp, dp, dp, dp, dp]
         _lib.oracle_legendre_synth.restype = None
+        _lib.oracle_legendre_anal.argtypes = [ctypes.c_int, ctypes.c_int, dp, dp, dp, dp, dp]
+        _lib.oracle_legendre_anal.restype = None
         _lib.oracle_lambda_lm.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_double, dp]
         _lib.oracle_lambda_lm.restype = None
         _lib.oracle_num_threads.restype = ctypes.c_int
@@ -178,3 +180,112 @@ def alm2map_bruteforce(alm, nside, lmax):
             else:
                 out += cm * (a * y).real
     return out
+
+
+# ------------------------------------------------------------------------------------
+# analysis (healpy.map2alm as the reference calls it: use_weights=True, iter=2;
+# cora/util/hputil.py:46-47,195-234) - "next" row n1 of SURVEY 8(f)
+# ------------------------------------------------------------------------------------
+def ring_weights(nside, lmax_exact=None):
+    """Ring quadrature weights w_r (north rings, equator included; the south mirrors them).
+
+    healpy's use_weights=True multiplies every ring by (1 + w) read from the HEALPix data file
+    weight_ring_n<nside>.fits - DATA that is absent here (healpy is not installed), so parity with
+    those files is UNPINNED.  The defining property of ring weights is restated instead: the
+    minimum-norm correction to uniform weights that integrates the zonal Legendre polynomials
+    P_l(z), even l <= lmax_exact (default 3 nside, rounded down to even), exactly:
+        sum_rings w_r n_r (4 pi / npix) P_l(z_r) = 4 pi delta_l0.
+    """
+    from numpy.polynomial import legendre as npleg
+
+    ri = healpix.ring_info(nside)
+    npair = 2 * nside
+    z = ri["z"][:npair]
+    cnt = ri["nphi"][:npair].astype(np.float64) * 2.0
+    cnt[npair - 1] = ri["nphi"][npair - 1]        # the equator ring has no mirror
+    if lmax_exact is None:
+        lmax_exact = 3 * nside
+    ls = np.arange(0, lmax_exact + 1, 2)
+    # P_l(z_r) for the even l by the three-term recurrence
+    P = np.empty((lmax_exact + 1, npair))
+    P[0] = 1.0
+    if lmax_exact >= 1:
+        P[1] = z
+    for l in range(2, lmax_exact + 1):
+        P[l] = ((2 * l - 1) * z * P[l - 1] - (l - 1) * P[l - 2]) / l
+    M = P[ls] * (cnt * 4.0 * np.pi / healpix.nside2npix(nside))[None, :]
+    rhs = np.zeros(len(ls))
+    rhs[0] = 4.0 * np.pi
+    dw = np.linalg.lstsq(M, rhs - M @ np.ones(npair), rcond=None)[0]   # minimum-norm solution
+    del npleg
+    return 1.0 + dw
+
+
+def ring_analysis(x, nphi, phi0, L):
+    """G_m = sum_j x_j e^{-i m phi_j}, m = 0..L-1, phi_j = phi0 + 2 pi j / nphi (adjoint of ring_synthesis)."""
+    X = np.fft.fft(x)
+    m = np.arange(L)
+    return X[m % nphi] * np.exp(-1j * m * phi0)
+
+
+def anal_to_gm(hpmap, nside, lmax, ring_w=None):
+    """Weighted ring spectra (gn, gs) [2 nside][lmax+1] of a RING map."""
+    ri = healpix.ring_info(nside)
+    nring = 4 * nside - 1
+    npair = 2 * nside
+    L = lmax + 1
+    area = 4.0 * np.pi / healpix.nside2npix(nside)
+    gn = np.zeros((npair, L), dtype=np.complex128)
+    gs = np.zeros((npair, L), dtype=np.complex128)
+    for r in range(npair):
+        wr = area * (1.0 if ring_w is None else ring_w[r])
+        n, s, p0 = int(ri["nphi"][r]), int(ri["start"][r]), float(ri["phi0"][r])
+        gn[r] = wr * ring_analysis(hpmap[s : s + n], n, p0, L)
+        rs = nring - 1 - r
+        if rs != r:
+            n, s, p0 = int(ri["nphi"][rs]), int(ri["start"][rs]), float(ri["phi0"][rs])
+            gs[r] = wr * ring_analysis(hpmap[s : s + n], n, p0, L)
+    return gn, gs
+
+
+def map2alm_adjoint(hpmap, nside, lmax, ring_w=None):
+    """One quadrature pass: a_lm = sum_pix w_ring(pix) (4 pi / npix) map(pix) conj(Y_lm(pix)), packed order."""
+    ri = healpix.ring_info(nside)
+    npair = 2 * nside
+    gn, gs = anal_to_gm(np.asarray(hpmap, dtype=np.float64), nside, lmax, ring_w)
+    alm = np.zeros((lmax + 1) * (lmax + 2) // 2, dtype=np.complex128)
+    z = np.ascontiguousarray(ri["z"][:npair])
+    sth = np.ascontiguousarray(ri["sth"][:npair])
+    _load().oracle_legendre_anal(lmax, npair, _dp(z), _dp(sth), _dp(np.ascontiguousarray(gn).view(np.float64)),
+                                 _dp(np.ascontiguousarray(gs).view(np.float64)), _dp(alm.view(np.float64)))
+    return alm
+
+
+def map2alm(hpmap, nside, lmax, use_weights=True, niter=2):
+    """healpy.map2alm(map, lmax=lmax, use_weights=..., iter=niter): quadrature + Jacobi refinement
+    alm <- alm + A(map - S alm)."""
+    w = ring_weights(nside) if use_weights else None
+    alm = map2alm_adjoint(hpmap, nside, lmax, w)
+    for _ in range(niter):
+        alm = alm + map2alm_adjoint(hpmap - alm2map(alm, nside, lmax), nside, lmax, w)
+    return alm
+
+
+def map2alm_bruteforce(hpmap, nside, lmax, ring_w=None):
+    """Independent definition-level quadrature with scipy.special.sph_harm_y (tiny sizes)."""
+    from scipy.special import sph_harm_y
+
+    theta, phi = healpix.pix2ang_ring(nside)
+    ri = healpix.ring_info(nside)
+    nring = 4 * nside - 1
+    wpix = np.empty(theta.size)
+    for r in range(nring):
+        n, s = int(ri["nphi"][r]), int(ri["start"][r])
+        rr = min(r, nring - 1 - r)
+        wpix[s : s + n] = 1.0 if ring_w is None else ring_w[rr]
+    wpix *= 4.0 * np.pi / theta.size
+    alm = np.zeros((lmax + 1) * (lmax + 2) // 2, dtype=np.complex128)
+    for m in range(lmax + 1):
+        for l in range(m, lmax + 1):
+            alm[alm_index(l, m, lmax)] = np.sum(wpix * hpmap * np.conj(sph_harm_y(l, m, theta, phi)))
+    return alm

@@ -108,6 +108,72 @@ void oracle_legendre_synth(int lmax, int npair, const double *z, const double *s
     free(lp); free(al); free(ial);
 }
 
+
+/* Adjoint of oracle_legendre_synth (the Legendre part of healpy.map2alm, which the reference
+ * reaches through hputil.sphtrans_real, cora/util/hputil.py:195-234):
+ *   a_lm = sum_rings lambda_lm(z_r) [G_m(north r) + (-1)^{l+m} G_m(south mirror of r)]
+ * gn, gs: [npair][lmax+1][2] weighted ring spectra (gs of an unpaired equator ring = 0).
+ * alm out: packed healpy order, interleaved (re,im).  Same two-phase recurrence as above. */
+void oracle_legendre_anal(int lmax, int npair, const double *z, const double *sth,
+                          const double *gn, const double *gs, double *alm)
+{
+    const int L = lmax + 1;
+    double *lp = (double *)malloc(sizeof(double) * L);
+    lp[0] = -0.5 * log2(4.0 * M_PI);
+    for (int m = 1; m < L; m++)
+        lp[m] = lp[m - 1] + 0.5 * log2((2.0 * m + 1.0) / (2.0 * m));
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int m = 0; m < L; m++) {
+        const long base = (long)m * (2 * lmax + 1 - m) / 2;
+        const double m2 = (double)m * m;
+        double *A = (double *)malloc(sizeof(double) * (L + 1));
+        double *IA = (double *)malloc(sizeof(double) * (L + 1));
+        A[m] = 0.0; IA[m] = 0.0;
+        for (int l = m + 1; l < L; l++) {
+            double ll = l;
+            A[l] = sqrt((4.0 * ll * ll - 1.0) / (ll * ll - m2));
+            IA[l] = 1.0 / A[l];
+        }
+        double *out = alm + 2 * base;
+        for (int l = m; l < L; l++) { out[2 * l] = 0.0; out[2 * l + 1] = 0.0; }
+        for (int r = 0; r < npair; r++) {
+            const double x = z[r];
+            const long o = 2 * ((long)r * L + m);
+            const double er = gn[o] + gs[o], ei = gn[o + 1] + gs[o + 1];       /* even l-m */
+            const double orr = gn[o] - gs[o], oi = gn[o + 1] - gs[o + 1];      /* odd l-m  */
+            double L2 = lp[m] + m * log2(sth[r]);
+            int sc = (int)floor(L2);
+            double lam = exp2(L2 - sc);
+            if (m & 1) lam = -lam;
+            double lam_prev = 0.0;
+            int l = m;
+            while (l < L && sc + ilogb(lam) < -900) {
+                double nxt = (l + 1 < L) ? A[l + 1] * (x * lam - lam_prev * IA[l]) : 0.0;
+                lam_prev = lam;
+                lam = nxt;
+                l++;
+                if (fabs(lam) > 0x1p300) { lam *= 0x1p-300; lam_prev *= 0x1p-300; sc += 300; }
+                if (lam == 0.0) break;
+            }
+            if (l < L && lam != 0.0) {
+                lam = ldexp(lam, sc);
+                lam_prev = ldexp(lam_prev, sc);
+                for (; l < L; l++) {
+                    if (((l - m) & 1) == 0) { out[2 * l] += er * lam;  out[2 * l + 1] += ei * lam; }
+                    else                    { out[2 * l] += orr * lam; out[2 * l + 1] += oi * lam; }
+                    if (l + 1 < L) {
+                        double nxt = A[l + 1] * (x * lam - lam_prev * IA[l]);
+                        lam_prev = lam;
+                        lam = nxt;
+                    }
+                }
+            }
+        }
+        free(A); free(IA);
+    }
+    free(lp);
+}
+
 /* normalised lambda_lm(x) for one (m, x), l = m..lmax, same recurrence
  * (used by the tests to check against mpmath / scipy spot values). */
 void oracle_lambda_lm(int lmax, int m, double x, double sthv, double *out)

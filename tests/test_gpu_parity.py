@@ -596,3 +596,102 @@ def test_pair_sharded_clarray_and_row_sliced_draw(ctx, golden):
         rows = T[:, nu0 : nu0 + nnu, :].contiguous()
         part = ctx.alm_dev_to_square(ctx.draw_alm_philox_rows(rows, info, 99, lmax, F, nu0, nnu), lmax, nnu)
         assert torch.equal(part, fsq[nu0 : nu0 + nnu])
+
+
+# ------------------------------------------------------------------ n1: analysis (map2alm, sph_ps)
+@pytest.mark.parametrize("nside,lmax,nnu", [(8, 16, 3), (16, 47, 8), (64, 128, 5), (32, 40, 17)])
+def test_map2alm_quadrature_vs_oracle(ctx, nside, lmax, nnu):
+    """K5^T + K4^T (one weighted quadrature pass) against the CPU oracle, through the C ABI."""
+    import torch
+    from cora_amd.util import hputil
+    from oracle import sht
+
+    rng = np.random.default_rng(nside + lmax)
+    maps = rng.standard_normal((nnu, 12 * nside * nside))
+    w = hputil.ring_weights(nside)
+    alm = ctx.map2alm(torch.from_numpy(maps).to(ctx.device), nside, lmax, ctx.to_device(w))
+    got = ctx.alm_dev_to_square(alm, lmax, nnu).cpu().numpy()[:, 0]
+    for k in range(nnu):
+        ref = hputil.unpack_alm(sht.map2alm_adjoint(maps[k], nside, lmax, sht.ring_weights(nside)), lmax)
+        assert np.abs(got[k] - ref).max() <= 2e-13 * np.abs(ref).max(), (k, np.abs(got[k] - ref).max())
+    # unweighted pass, chunked over channels
+    alm_u = ctx.map2alm(torch.from_numpy(maps).to(ctx.device), nside, lmax, None, chunk=8)
+    got_u = ctx.alm_dev_to_square(alm_u, lmax, nnu).cpu().numpy()[:, 0]
+    ref_u = hputil.unpack_alm(sht.map2alm_adjoint(maps[nnu - 1], nside, lmax, None), lmax)
+    assert np.abs(got_u[nnu - 1] - ref_u).max() <= 2e-13 * np.abs(ref_u).max()
+
+
+def test_map2alm_iterated_matches_oracle_and_round_trips(ctx):
+    """healpy.map2alm(use_weights=True, iter=2) semantics: GPU == oracle, and a band-limited sky comes back."""
+    import torch
+    from cora_amd.util import hputil
+    from oracle import sht
+
+    nside, lmax, nnu = 32, 48, 4
+    rng = np.random.default_rng(5)
+    n = (lmax + 1) * (lmax + 2) // 2
+    a = rng.standard_normal((nnu, n)) + 1j * rng.standard_normal((nnu, n))
+    a[:, : lmax + 1] = a[:, : lmax + 1].real
+    maps = ctx.alm2map(ctx.alm_packed_to_dev(torch.from_numpy(a).to(ctx.device), lmax), nside, lmax, nnu)
+    alm = hputil.map2alm_device(maps, nside, lmax)                    # weights + 2 iterations
+    got = ctx.alm_dev_to_square(alm, lmax, nnu).cpu().numpy()[:, 0]
+    mh = maps.cpu().numpy()
+    for k in range(nnu):
+        ref = hputil.unpack_alm(sht.map2alm(mh[k], nside, lmax, True, 2), lmax)
+        assert np.abs(got[k] - ref).max() <= 1e-11 * np.abs(ref).max()
+        assert np.abs(got[k] - hputil.unpack_alm(a[k], lmax)).max() < 1e-4
+
+
+def test_sphtrans_and_sph_ps_api(ctx):
+    """hputil.sphtrans_real / sphtrans_sky / sph_ps shapes and values (cora/util/hputil.py:195-234,460-497,607-619)."""
+    from cora_amd.util import hputil
+    from oracle import sht
+
+    nside, lmax = 16, 24
+    rng = np.random.default_rng(8)
+    n = (lmax + 1) * (lmax + 2) // 2
+    a = rng.standard_normal((2, n)) + 1j * rng.standard_normal((2, n))
+    a[:, : lmax + 1] = a[:, : lmax + 1].real
+    m0, m1 = sht.alm2map(a[0], nside, lmax), sht.alm2map(a[1], nside, lmax)
+    r = hputil.sphtrans_real(m0, lmax, lside=30)
+    assert r.shape == (31, 31) and np.all(r[lmax + 1 :] == 0) and np.all(r[:, lmax + 1 :] == 0)
+    assert np.abs(r[: lmax + 1, : lmax + 1] - hputil.unpack_alm(a[0], lmax)).max() < 1e-5   # lmax = 1.5 nside, 2 iterations
+    assert hputil.sphtrans_real(m0).shape == (3 * nside, 3 * nside)
+    sky = hputil.sphtrans_sky(np.stack([m0, m1]), lmax)
+    assert sky.shape == (2, lmax + 1, lmax + 1)
+    assert np.abs(sky[0] - r[: lmax + 1, : lmax + 1]).max() < 1e-13
+    sky3 = hputil.sphtrans_sky(np.stack([m0, m1])[:, None, :], lmax)
+    assert sky3.shape == (2, 1, lmax + 1, lmax + 1) and np.array_equal(sky3[:, 0], sky)
+    with pytest.raises(NotImplementedError):
+        hputil.sphtrans_sky(np.zeros((2, 3, 12 * nside * nside)), lmax)
+    al0, al1 = hputil.unpack_alm(a[0], lmax), hputil.unpack_alm(a[1], lmax)
+    ll = 2.0 * np.arange(lmax + 1) + 1.0
+    auto = (np.abs(al0[:, 0]) ** 2 + 2 * (np.abs(al0[:, 1:]) ** 2).sum(axis=1)) / ll
+    cross = ((al0 * al1.conj())[:, 0] + 2 * (al0 * al1.conj())[:, 1:].sum(axis=1).real) / ll
+    assert np.abs(hputil.sph_ps(m0, lmax=lmax) - auto).max() < 1e-5 * auto.max()
+    assert np.abs(hputil.sph_ps(m0, m1, lmax=lmax) - cross).max() < 1e-5 * auto.max()
+
+
+def test_map2alm_full_size_adjointness(ctx):
+    """At BASELINE cfg-3 geometry (nside 1024, lmax 2048): <S a, x> 4 pi / npix == <a, A x> for random a, x -
+    the size-independent property tying the analysis kernels to the synthesis ones."""
+    import torch
+
+    nside, lmax, nnu = 1024, 2048, 8
+    L = lmax + 1
+    nalm = L * (L + 1) // 2
+    npix = 12 * nside * nside
+    gen = torch.Generator(device=ctx.device).manual_seed(3)
+    a = torch.randn((nalm, 2, 2, 4), generator=gen, device=ctx.device, dtype=torch.float64)
+    a[:L, :, 1, :] = 0.0                     # imaginary parts of a_l0 do not enter a real map
+    x = torch.randn((nnu, npix), generator=gen, device=ctx.device, dtype=torch.float64)
+    Sa = ctx.alm2map(a, nside, lmax, nnu)
+    Ax = ctx.map2alm(x, nside, lmax, None)
+    wgt = torch.full((nalm, 1, 1, 1), 2.0, device=ctx.device, dtype=torch.float64)
+    wgt[:L] = 1.0
+    lhs = (Sa * x).sum(dim=1) * (4 * np.pi / npix)                      # per channel
+    rhs = (wgt * a * Ax).sum(dim=(0, 2)).reshape(-1)[:nnu]               # [G,4] -> channel order
+    scale = (Sa.abs() * x.abs()).sum(dim=1) * (4 * np.pi / npix)
+    assert ((lhs - rhs).abs() / scale).max().item() < 1e-12
+    del a, x, Sa, Ax
+    torch.cuda.empty_cache()

@@ -284,3 +284,36 @@ def test_device_stream_oracle_layout_and_moments():
     a, b = philox.normal_pairs(12345, l, F, c, nu, m // 2)
     assert g[F * l * (l + 1) + c * F * (l + 1) + nu * (l + 1) + m] == (b if m & 1 else a)
     assert abs(g.mean()) < 5 / np.sqrt(g.size) and abs(g.var() - 1) < 5 * np.sqrt(2 / g.size)
+
+
+def test_map2alm_oracle_against_bruteforce_and_adjointness():
+    """The analysis oracle (n1: healpy.map2alm restated) vs an independent scipy Y_lm quadrature,
+    <S a, x> = <a, A x> adjointness with the synthesis oracle, and convergence of the Jacobi iterations."""
+    nside, lmax = 8, 16
+    rng = np.random.default_rng(11)
+    n = (lmax + 1) * (lmax + 2) // 2
+    a = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+    a[: lmax + 1] = a[: lmax + 1].real
+    m = sht.alm2map(a, nside, lmax)
+    w = sht.ring_weights(nside)
+    # weights integrate the monopole exactly and are symmetric small corrections
+    ri = healpix.ring_info(nside)
+    cnt = ri["nphi"][: 2 * nside].astype(float) * 2
+    cnt[-1] /= 2
+    assert abs((w * cnt).sum() * 4 * np.pi / (12 * nside**2) - 4 * np.pi) < 1e-12
+    assert np.abs(w - 1).max() < 0.2
+    b = sht.map2alm_adjoint(m, nside, lmax, w)
+    assert np.abs(b - sht.map2alm_bruteforce(m, nside, lmax, w)).max() < 1e-13
+    x = rng.standard_normal(m.size)
+    Ax = sht.map2alm_adjoint(x, nside, lmax, None)
+    mm = np.concatenate([np.full(lmax + 1 - k, k) for k in range(lmax + 1)])
+    wgt = np.where(mm == 0, 1.0, 2.0)
+    assert abs(np.dot(m, x) * 4 * np.pi / m.size - np.sum(wgt * (a.conj() * Ax).real)) < 1e-12 * np.abs(m).sum()
+    errs = [np.abs(sht.map2alm(m, nside, lmax, True, it) - a).max() for it in (0, 1, 2, 3)]
+    assert all(e1 < 0.2 * e0 for e0, e1 in zip(errs, errs[1:])) and errs[2] < 1e-3
+    # band limit well inside the grid: two iterations are already at the 1e-9 level
+    lmax2 = 8
+    n2 = (lmax2 + 1) * (lmax2 + 2) // 2
+    a2 = rng.standard_normal(n2) + 1j * rng.standard_normal(n2)
+    a2[: lmax2 + 1] = a2[: lmax2 + 1].real
+    assert np.abs(sht.map2alm(sht.alm2map(a2, nside, lmax2), nside, lmax2) - a2).max() < 1e-8
