@@ -201,4 +201,41 @@ def mkfullsky(corr, nside, alms=False, rng=None):
 
 
 def mkconstrained(corr, constraints, nside):
-    raise NotImplementedError("mkconstrained (cora/core/skysim.py:139-201) is out of scope of cora_amd")
+    """Maps satisfying given constraints on some frequency slices, built from the lowest eigenmodes
+    (cora/core/skysim.py:139-205).
+
+    corr [lmax+1, numz, numz]; constraints = [[frequency_index, healpix map], ...]; returns [numz, npix].
+    The per-l symmetric eigenproblems and the nmodes x nmodes solves stay on the host (scipy, as the
+    reference); the two transforms the reference takes from healpy - ``map2alm(cons, lmax=maxl)`` with
+    healpy's defaults (iter=3, no ring weights) and ``alm2map`` of every channel - run on the GPU in
+    one batch each."""
+    import scipy.linalg as la
+    import torch
+
+    from ..util import hputil
+
+    numz = corr.shape[1]
+    maxl = corr.shape[0] - 1
+    L = maxl + 1
+    nmodes = len(constraints)
+    f_ind = [c[0] for c in constraints]
+    if corr.shape[2] != numz:
+        raise Exception("Correlation matrix is incorrect shape.")
+
+    trans = np.zeros((corr.shape[0], nmodes, corr.shape[2]))
+    tmat = np.zeros((corr.shape[0], nmodes, nmodes))
+    for i in range(L):
+        trans[i] = la.eigh(corr[i])[1][:, -nmodes:].T
+        tmat[i] = trans[i][:, f_ind]
+
+    ctx = _lib.get_context()
+    cons = np.ascontiguousarray(np.stack([np.asarray(c[1], dtype=np.float64) for c in constraints]))
+    ns_c = int(round(np.sqrt(cons.shape[1] / 12.0)))
+    calm = hputil.map2alm_device(torch.from_numpy(cons).to(ctx.device), ns_c, maxl, use_weights=False, niter=3)
+    cmap = ctx.alm_dev_to_square(calm, maxl, nmodes).cpu().numpy()[:, 0]      # [nmodes, l, m]
+
+    cv = np.zeros((numz, L, L), dtype=np.complex128)
+    for l in range(1, L):                                                     # l = 0 stays zero (:193-194)
+        amp = la.solve(tmat[l].T, cmap[:, l, : l + 1])                        # [nmodes, m]
+        cv[:, l, : l + 1] = np.dot(trans[l].T, amp)
+    return hputil._synth(cv, nside)

@@ -15,6 +15,41 @@ def nside2npix(nside):
     return 12 * int(nside) * int(nside)
 
 
+def ang2pix(nside, theta, phi, lonlat=False):
+    """RING pixel index of a direction (what the reference takes from ``healpy.ang2pix`` in
+    scripts/makesky.py:412-420): colatitude/longitude in radians, or (lon, lat) in degrees with
+    ``lonlat=True``.  Standard HEALPix geometry (Gorski et al. 2005, eqs. 2-9)."""
+    nside = int(nside)
+    theta = np.asarray(theta, dtype=np.float64)
+    phi = np.asarray(phi, dtype=np.float64)
+    if lonlat:
+        theta, phi = np.pi / 2.0 - np.radians(phi), np.radians(theta)
+    z = np.cos(theta)
+    za = np.abs(z)
+    tt = np.mod(phi, 2.0 * np.pi) / (np.pi / 2.0)          # [0, 4)
+    npix = 12 * nside * nside
+    ncap = 2 * nside * (nside - 1)
+    # equatorial belt
+    t1 = nside * (0.5 + tt)
+    t2 = nside * z * 0.75
+    jp = np.floor(t1 - t2).astype(np.int64)
+    jm = np.floor(t1 + t2).astype(np.int64)
+    ir = nside + 1 + jp - jm
+    kshift = 1 - (ir & 1)
+    ip = np.mod((jp + jm - nside + kshift + 1) // 2, 4 * nside)
+    belt = ncap + (ir - 1) * 4 * nside + ip
+    # polar caps
+    tp = tt - np.floor(tt)
+    tmp = nside * np.sqrt(3.0 * (1.0 - za))
+    jp = np.floor(tp * tmp).astype(np.int64)
+    jm = np.floor((1.0 - tp) * tmp).astype(np.int64)
+    irc = jp + jm + 1
+    ipc = np.mod(np.floor(tt * irc).astype(np.int64), 4 * irc)
+    cap = np.where(z > 0, 2 * irc * (irc - 1) + ipc, npix - 2 * irc * (irc + 1) + ipc)
+    out = np.where(za <= 2.0 / 3.0, belt, cap)
+    return out if out.ndim else int(out)
+
+
 def nside_for_lmax(lmax, accuracy_boost=1):
     """cora/util/hputil.py:76-90."""
     return int(2 ** (accuracy_boost + np.ceil(np.log((lmax + 1) / 3.0) / np.log(2.0))))

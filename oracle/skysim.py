@@ -128,3 +128,34 @@ def sph_ps_from_alm(alm2d):
     prod = alm2d * alm2d.conj()
     s = prod[:, 0] + 2 * prod[:, 1:].sum(axis=1).real
     return (s / (2.0 * np.arange(alm2d.shape[0]) + 1.0)).real
+
+
+def mkconstrained(corr, constraints, nside):
+    """cora/core/skysim.py:139-205 with the oracle transforms standing in for healpy
+    (map2alm with healpy's defaults iter=3 / no weights; alm2map)."""
+    numz = corr.shape[1]
+    maxl = corr.shape[0] - 1
+    larr = np.concatenate([np.arange(m, maxl + 1) for m in range(maxl + 1)])     # healpy.Alm.getlm order
+    nmodes = len(constraints)
+    f_ind = [c[0] for c in constraints]
+    if corr.shape[2] != numz:
+        raise Exception("Correlation matrix is incorrect shape.")
+    trans = np.zeros((corr.shape[0], nmodes, corr.shape[2]))
+    tmat = np.zeros((corr.shape[0], nmodes, nmodes))
+    cmap = np.zeros(larr.shape + (nmodes,), dtype=np.complex128)
+    cv = np.zeros((numz,) + larr.shape, dtype=np.complex128)
+    for i in range(maxl + 1):
+        trans[i] = la.eigh(corr[i])[1][:, -nmodes:].T
+        tmat[i] = trans[i][:, f_ind]
+    for i, cons in enumerate(constraints):
+        ns_c = int(round(np.sqrt(np.asarray(cons[1]).size / 12.0)))
+        cmap[:, i] = sht.map2alm(np.asarray(cons[1], dtype=np.float64), ns_c, maxl, use_weights=False, niter=3)
+    for i, l in enumerate(larr):
+        if l == 0:
+            cv[:, i] = 0.0
+        else:
+            cv[:, i] = np.dot(trans[l].T, la.solve(tmat[l].T, cmap[i]))
+    hpmaps = np.empty((numz, healpix.nside2npix(nside)))
+    for i in range(numz):
+        hpmaps[i] = sht.alm2map(cv[i], nside, maxl)
+    return hpmaps

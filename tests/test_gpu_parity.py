@@ -695,3 +695,64 @@ def test_map2alm_full_size_adjointness(ctx):
     assert ((lhs - rhs).abs() / scale).max().item() < 1e-12
     del a, x, Sa, Ax
     torch.cuda.empty_cache()
+
+
+def test_mkconstrained_vs_oracle(golden):
+    """skysim.mkconstrained (cora/core/skysim.py:139-205): constrained channels reproduce their constraint
+    maps (up to the l = 0 mode the reference zeroes) and the whole stack matches the CPU oracle."""
+    from cora_amd.core import skysim
+    from oracle import sht
+    from oracle import skysim as osk
+
+    cl = golden["cla_21cm_F8_l64_zromb3"][:33]                 # [33, 8, 8], well conditioned
+    nside, lmax = 16, 32
+    rng = np.random.default_rng(4)
+    n = (lmax + 1) * (lmax + 2) // 2
+    cons = []
+    for fi in (1, 5):
+        a = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+        a[: lmax + 1] = a[: lmax + 1].real
+        a[0] = 0.0                                              # no monopole: mkconstrained drops l = 0
+        cons.append([fi, sht.alm2map(a, nside, lmax)])
+    got = skysim.mkconstrained(cl, cons, nside)
+    ref = osk.mkconstrained(cl, cons, nside)
+    assert got.shape == (8, 12 * nside * nside)
+    assert np.abs(got - ref).max() <= 1e-9 * np.abs(ref).max()
+    for fi, cm in cons:
+        assert np.abs(got[fi] - cm).max() < 1e-3 * np.abs(cm).max()
+    with pytest.raises(Exception, match="incorrect shape"):
+        skysim.mkconstrained(np.zeros((5, 3, 4)), cons, nside)
+
+
+def test_makesky_cli_21cm_and_gaussianfg(tmp_path):
+    """cora-makesky commands on the GPU path (scripts/makesky.py:313-390): same-seed maps equal the module API."""
+    from click.testing import CliRunner
+
+    from cora_amd.foreground import galaxy
+    from cora_amd.scripts import makesky
+    from cora_amd.signal import corr21cm
+
+    out = str(tmp_path / "m21.h5")
+    r = CliRunner().invoke(makesky.cli, ["21cm", "--nside", "16", "--freq", "600", "640", "4", "--freq-mode", "edge",
+                                         "--pol", "zero", "--oversample", "1", "--seed", "3", "--filename", out])
+    assert r.exit_code == 0, r.output
+    f = np.load(out + ".npz")
+    assert f["map"].shape == (4, 4, 12 * 16 * 16) and np.all(f["map"][:, 1:] == 0)
+    cr = corr21cm.Corr21cm()
+    cr.nside = 16
+    cr.frequencies = np.array([605.0, 615.0, 625.0, 635.0])
+    cr.oversample = 1
+    assert np.array_equal(f["map"][:, 0], cr.getsky(rng=np.random.default_rng(3)))
+    assert np.array_equal(f["index_map__freq"]["centre"], cr.frequencies) and np.all(f["index_map__freq"]["width"] == 10.0)
+
+    out2 = str(tmp_path / "fg.h5")
+    r = CliRunner().invoke(makesky.cli, ["gaussianfg", "--nside", "8", "--freq", "400", "800", "3", "--freq-mode", "edge",
+                                         "--pol", "none", "--seed", "5", "--filename", out2])
+    assert r.exit_code == 0, r.output
+    g = np.load(out2 + ".npz")
+    assert g["map"].shape == (3, 1, 768) and np.isfinite(g["map"]).all() and g["map"].std() > 0
+    # brighter at low frequency (synchrotron spectral index -2.8)
+    assert g["map"][0].std() > g["map"][2].std()
+    r = CliRunner().invoke(makesky.cli, ["gaussianfg", "--nside", "8", "--pol", "full"])
+    assert r.exit_code != 0 and "spin-2" in r.output
+    del galaxy

@@ -240,3 +240,65 @@ def test_random_field_api():
     assert list(a2f._n) == [8, 4, 6]
     a2 = gaussianfield.RandomFieldA2.like_map(m)
     assert list(a2._n) == [4, 6]
+
+
+def test_makesky_freqstate_matches_reference_vectors():
+    """FreqState (cora/scripts/makesky.py:44-92) against outputs of the reference's own class
+    (tests/golden/make_golden_makesky.py) in every channelisation mode."""
+    import json
+
+    from cora_amd.scripts import makesky
+
+    g = np.load(os.path.join(ROOT, "tests", "golden", "makesky_vectors.npz"))
+    cases = json.loads(str(g["cases_json"]))
+    assert len(cases) >= 7
+    for name, kw in cases.items():
+        fs = makesky.FreqState()
+        for k, v in kw.items():
+            setattr(fs, k, tuple(v) if k in ("freq", "channel_range") else v)
+        assert np.array_equal(fs.frequencies, g[name + "__frequencies"]), name
+        assert np.array_equal(np.asarray(fs.freq_width), g[name + "__freq_width"]), name
+
+
+def test_makesky_cli_surface_and_map_container(tmp_path):
+    """Option parsing, the single-source map (no GPU needed) and the container layout of write_map."""
+    from click.testing import CliRunner
+
+    from cora_amd.scripts import makesky
+    from cora_amd.util import hputil
+    from oracle import healpix
+
+    assert set(makesky.cli.commands) == {"foreground", "galaxy", "pointsource", "21cm", "gaussianfg", "singlesource"}
+    out = str(tmp_path / "src.h5")
+    r = CliRunner().invoke(makesky.cli, ["singlesource", "--nside", "8", "--freq", "400", "800", "4", "--freq-mode", "edge",
+                                         "--pol", "none", "--ra", "33.0", "--dec", "-12.5", "--channel-list", "[0, 2]",
+                                         "--filename", out])
+    assert r.exit_code == 0, r.output
+    path = out if os.path.exists(out) else out + ".npz"
+    assert path.endswith(".npz")          # h5py is not installed in this image
+    f = np.load(path)
+    assert f["map"].shape == (2, 1, 768) and f["map"].sum() == 2.0
+    pix = int(np.argmax(f["map"][0, 0]))
+    th, ph = healpix.pix2ang_ring(8)
+    assert pix == hputil.ang2pix(8, 33.0, -12.5, lonlat=True)
+    assert abs(np.degrees(ph[pix]) - 33.0) < 8 and abs(90 - np.degrees(th[pix]) + 12.5) < 8
+    assert np.array_equal(f["index_map__freq"]["centre"], [450.0, 650.0]) and np.all(f["index_map__freq"]["width"] == 100.0)
+    # a 3-D input always gets the four-entry pol index, even with one Stokes plane (scripts/makesky.py:419-420)
+    assert list(f["index_map__pol"]) == ["I", "Q", "U", "V"] and np.array_equal(f["index_map__pixel"], np.arange(768))
+    assert list(makesky.map_container(np.ones((3, 48)), np.array([1.0, 2.0, 3.0]), include_pol=False)["index_map/pol"]) == ["I"]
+    c = makesky.map_container(np.ones((3, 48)), np.array([1.0, 2.0, 3.0]))
+    assert c["map"].shape == (3, 4, 48) and np.all(c["map"][:, 1:] == 0) and list(c["index_map/pol"]) == ["I", "Q", "U", "V"]
+    assert np.all(c["index_map/freq"]["width"] == 1.0)
+    r = CliRunner().invoke(makesky.cli, ["galaxy", "--nside", "8"])
+    assert r.exit_code != 0 and "not part of cora_amd" in r.output
+    r = CliRunner().invoke(makesky.cli, ["singlesource", "--channel-list", "[0, 'a']"])
+    assert r.exit_code != 0
+
+
+def test_ang2pix_inverts_pix2ang():
+    from cora_amd.util import hputil
+    from oracle import healpix
+
+    for ns in (1, 2, 8, 32):
+        th, ph = healpix.pix2ang_ring(ns)
+        assert np.array_equal(hputil.ang2pix(ns, th, ph), np.arange(12 * ns * ns))
