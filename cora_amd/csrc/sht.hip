@@ -600,12 +600,42 @@ struct DftR<16, SIGN> {
 // most 2-way bank conflicted for ds_read/write_b128 instead of 8..16-way.
 __host__ __device__ static inline int fpad(int i) { return i + (i >> 3) + ((i >> 7) << 3); }
 
-// e^{SIGN 2 pi i idx/pmax} from the half-circle table tw[k] = e^{+2 pi i k/pmax}, k < pmax/2
-template <int SIGN>
-__device__ static inline double2 tw_get(const double2 *__restrict__ tw, int pmax, int idx) {
+// e^{+2 pi i idx/pmax} from the half-circle table in HBM, tw[k] = e^{+2 pi i k/pmax}, k < pmax/2
+__device__ static inline double2 tw_global(const double2 *__restrict__ tw, int pmax, int idx) {
     const int hp = pmax >> 1;
     double2 w = tw[idx >= hp ? idx - hp : idx];
     if (idx >= hp) w = make_double2(-w.x, -w.y);
+    return w;
+}
+// The kernels look twiddles up in a two-level LDS table instead: tl[lo] = e^{2 pi i lo/pmax}, lo < 64, and
+// tl[64 + hi] = e^{2 pi i 64 hi/pmax}; e^{2 pi i idx/pmax} = tl[idx & 63] * tl[64 + (idx >> 6)].  A twiddle
+// fetched from HBM inside an FFT pass made every pass wait (vmcnt is in-order) for the register prefetch of
+// the NEXT ring's cells issued just before it - the whole HBM latency was exposed once per ring.
+// Measured at cfg 3: the extra LDS reads + complex multiply and the higher register pressure cost more
+// (belt class 13.2 -> 15.8 ms) than the exposed latency they remove, so the switch is OFF; kept for the record.
+#ifndef K5_LDS_TW
+#define K5_LDS_TW 0
+#endif
+#if K5_LDS_TW
+#define TWL_ENTRIES(pmax) (64 + ((pmax) >= 64 ? (pmax) / 64 : 1))
+#else
+#define TWL_ENTRIES(pmax) 0
+#endif
+__device__ static inline void twl_fill(double2 *tl, const double2 *__restrict__ tw, int pmax) {
+    const int nhi = pmax >= 64 ? pmax / 64 : 1;
+    for (int i = threadIdx.x; i < 64 + nhi; i += blockDim.x) {
+        const int idx = i < 64 ? (i < pmax ? i : 0) : 64 * (i - 64);
+        tl[i] = tw_global(tw, pmax, idx);
+    }
+    __syncthreads();
+}
+template <int SIGN>
+__device__ static inline double2 tw_get(const double2 *tl, int pmax, int idx) {
+#if K5_LDS_TW
+    double2 w = cmul(tl[idx & 63], tl[64 + (idx >> 6)]);
+#else
+    double2 w = tw_global(tl, pmax, idx);
+#endif
     if (SIGN < 0) w.y = -w.y;
     return w;
 }
@@ -781,6 +811,9 @@ __device__ __forceinline__ static void fft_dit_last_out(const double2 *buf, int 
                 if (r & (1 << b)) x[r] = cmul(x[r], wp[b]);
         }
         DftR<R, SIGN>::run(x);
+#if K5_ABLATE == 2
+        if (x[0].x == 1.2345e300)
+#endif
         if (ch0 + ch < nnu) {
             double *out = maps + (size_t)(ch0 + ch) * npix + start;
 #pragma unroll
@@ -802,11 +835,17 @@ __device__ __forceinline__ static void fft_dit_last_out(const double2 *buf, int 
 __global__ void __launch_bounds__(256)
 bluestein_table_kernel(const int32_t *__restrict__ blu_P, const int64_t *__restrict__ boff,
                        const int64_t *__restrict__ foff, double2 *__restrict__ chirp, double2 *__restrict__ filt,
-                       const double2 *__restrict__ tw, int pmax) {
-    extern __shared__ __attribute__((aligned(16))) double2 fbuf[];
+                       const double2 *__restrict__ tw, int pmax, int tl_off) {
+    extern __shared__ __attribute__((aligned(16))) double2 fbuf[];   // [fpad(maxlen) + 1] then the twiddle table
     const int i = blockIdx.x + 1;
     const int P = blu_P[i - 1];
     if (P == 0) return;
+#if K5_LDS_TW
+    double2 *tl = fbuf + tl_off;
+    twl_fill(tl, tw, pmax);
+#else
+    const double2 *tl = tw;
+#endif
     const int h = 2 * i;
     double2 *b = chirp + boff[i - 1];
     for (int j = threadIdx.x; j < fpad(P); j += blockDim.x) fbuf[j] = make_double2(0.0, 0.0);
@@ -820,7 +859,7 @@ bluestein_table_kernel(const int32_t *__restrict__ blu_P, const int64_t *__restr
         if (j > 0) fbuf[fpad(P - j)] = make_double2(c, -s);
     }
     __syncthreads();
-    fft_dif<-1>(fbuf, 0, 1, P, tw, pmax);
+    fft_dif<-1>(fbuf, 0, 1, P, tl, pmax);
     double2 *f = filt + foff[i - 1];
     for (int j = threadIdx.x; j < P; j += blockDim.x) f[j] = fbuf[fpad(j)];
 }
@@ -834,6 +873,9 @@ bluestein_table_kernel(const int32_t *__restrict__ blu_P, const int64_t *__restr
 #ifndef K5_STAMPS
 #define K5_STAMPS 0  // diagnostic build: s_memtime phase breakdown
 #endif
+#ifndef K5_ABLATE
+#define K5_ABLATE 0  // diagnostic builds (make k5ablate; wrong results, timing only): 1 no FFT, 2 no pixel stores, 3 no cell loads
+#endif
 #if K5_STAMPS
 __device__ unsigned long long g_k5_stamps[8];
 #define K5STAMP(acc) { unsigned long long _t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)::"memory"); acc += _t - k5_last; k5_last = _t; }
@@ -841,23 +883,34 @@ __device__ unsigned long long g_k5_stamps[8];
 #define K5STAMP(acc)
 #endif
 
-template <int NCH>
+// BLU = false: class of power-of-two rings only (the belt); the Bluestein code and its registers are compiled out
+template <int NCH, bool BLU>
 __global__ void __launch_bounds__(K5_THREADS)
 ringfft_kernel(const int32_t *__restrict__ ring_list, int nlist, int nside, int lmax, int G, int nnu, long npix,
                const int32_t *__restrict__ nphi_a, const int64_t *__restrict__ start_a,
                const double *__restrict__ phi0_a, const double *__restrict__ inter, double *__restrict__ maps,
-               const double2 *__restrict__ tw, int pmax, const int32_t *__restrict__ blu_P,
+               const double2 *__restrict__ tw_hbm, int pmax, const int32_t *__restrict__ blu_P,
                const int64_t *__restrict__ boff, const int64_t *__restrict__ foff,
                const double2 *__restrict__ chirp, const double2 *__restrict__ filt, int bstride,
                const int32_t *__restrict__ mcut) {
-    extern __shared__ __attribute__((aligned(16))) double2 sm[];  // [NCH][bstride]
+    // cells per thread prefetched into registers for the next item (the rest are read in place): the Bluestein
+    // instantiations need the registers for the fused filter pass (4 cells made them spill 66 VGPRs)
+    constexpr int MC = BLU ? (K5_MC > 2 ? 2 : K5_MC) : K5_MC;
+    extern __shared__ __attribute__((aligned(16))) double2 sm[];  // [NCH][bstride], then the twiddle table
     const int tid = threadIdx.x, nt = blockDim.x;
     const int L = lmax + 1;
     const int ngrp = (nnu + NCH - 1) / NCH;
     const int nitems = nlist * ngrp;
     double *smd = reinterpret_cast<double *>(sm);
+#if K5_LDS_TW
+    double2 *tl = sm + (size_t)NCH * bstride;
+    twl_fill(tl, tw_hbm, pmax);
+    const double2 *tw = tl;   // every twiddle below comes from LDS
+#else
+    const double2 *tw = tw_hbm;
+#endif
 
-    // register prefetch of the cells m = tid + k nt, k < K5_MC, of one item
+    // register prefetch of the cells m = tid + k nt, k < MC, of one item
     struct cell_t {
         double re[NCH], im[NCH];
     };
@@ -869,30 +922,39 @@ ringfft_kernel(const int32_t *__restrict__ ring_list, int nlist, int nside, int 
     };
     auto load_cell = [&](const double *cell, int m) {
         cell_t c;
+#if K5_ABLATE == 3
+        for (int q = 0; q < NCH; q++) { c.re[q] = 1.0 + m; c.im[q] = 0.5; }
+        return c;
+#endif
         if (NCH == 4) {
-            const double4 a = *reinterpret_cast<const double4 *>(cell + (size_t)m * 8);
-            const double4 b = *reinterpret_cast<const double4 *>(cell + (size_t)m * 8 + 4);
+            const double4 a = *reinterpret_cast<const double4 *>(cell + (unsigned)m * 8u);
+            const double4 b = *reinterpret_cast<const double4 *>(cell + (unsigned)m * 8u + 4u);
             c.re[0] = a.x; c.re[1 % NCH] = a.y; c.re[2 % NCH] = a.z; c.re[3 % NCH] = a.w;
             c.im[0] = b.x; c.im[1 % NCH] = b.y; c.im[2 % NCH] = b.z; c.im[3 % NCH] = b.w;
         } else if (NCH == 2) {
-            const double2 a = *reinterpret_cast<const double2 *>(cell + (size_t)m * 8);
-            const double2 b = *reinterpret_cast<const double2 *>(cell + (size_t)m * 8 + 4);
+            const double2 a = *reinterpret_cast<const double2 *>(cell + (unsigned)m * 8u);
+            const double2 b = *reinterpret_cast<const double2 *>(cell + (unsigned)m * 8u + 4u);
             c.re[0] = a.x; c.re[1 % NCH] = a.y;
             c.im[0] = b.x; c.im[1 % NCH] = b.y;
         } else {
-            c.re[0] = cell[(size_t)m * 8];
-            c.im[0] = cell[(size_t)m * 8 + 4];
+            c.re[0] = cell[(unsigned)m * 8u];
+            c.im[0] = cell[(unsigned)m * 8u + 4u];
         }
         return c;
     };
+    // Branch-free: every thread loads its MC cells (index clamped to the last cell of the row; cells at or
+    // beyond mcut(ring) hold stale data that the fold never consumes).  Conditional loads made hipcc drain
+    // vmcnt at every join, serialising the prefetch and exposing the whole HBM latency to the next fold.
     auto prefetch = [&](int item) {
+        // uniform base (+ k nt cells) and ONE per-thread 32-bit offset: saddr-form loads, no 64-bit address
+        // arithmetic or spilled per-cell offsets between them.  Cells past the row end belong to the next
+        // row / the workspace tail pad (alm2map_workspace_bytes adds it) and are never consumed.
         const double *cell = cell_ptr(item);
-        const int Lr = mcut[ring_list[item / ngrp]];  // cells m >= Lr are exactly zero (and were not written)
-        if (tid < Lr) pf0 = load_cell(cell, tid);
-        if (tid + nt < Lr) pf1 = load_cell(cell, tid + nt);
-        if (K5_MC > 2) {
-            if (tid + 2 * nt < Lr) pf2 = load_cell(cell, tid + 2 * nt);
-            if (tid + 3 * nt < Lr) pf3 = load_cell(cell, tid + 3 * nt);
+        pf0 = load_cell(cell, tid);
+        pf1 = load_cell(cell + (size_t)nt * 8, tid);
+        if (MC > 2) {
+            pf2 = load_cell(cell + (size_t)2 * nt * 8, tid);
+            pf3 = load_cell(cell + (size_t)3 * nt * 8, tid);
         }
     };
 
@@ -912,7 +974,7 @@ ringfft_kernel(const int32_t *__restrict__ ring_list, int nlist, int nside, int 
         int icap = 0;
         if (ring + 1 < nside) icap = ring + 1;
         else if (ring + 1 > 3 * nside) icap = 4 * nside - (ring + 1);
-        const int P = icap ? blu_P[icap - 1] : 0;
+        const int P = (BLU && icap) ? blu_P[icap - 1] : 0;
         const int flen = P ? P : h + 1;
         const int Lr = mcut[ring];
 
@@ -967,13 +1029,13 @@ ringfft_kernel(const int32_t *__restrict__ ring_list, int nlist, int nside, int 
         if (tid < Lr) fold_one(tid, pf0);
         ph = cmul(ph, phstep);
         if (tid + nt < Lr) fold_one(tid + nt, pf1);
-        if (K5_MC > 2) {
+        if (MC > 2) {
             ph = cmul(ph, phstep);
             if (tid + 2 * nt < Lr) fold_one(tid + 2 * nt, pf2);
             ph = cmul(ph, phstep);
             if (tid + 3 * nt < Lr) fold_one(tid + 3 * nt, pf3);
         }
-        for (int m = tid + K5_MC * nt; m < Lr; m += nt) {
+        for (int m = tid + MC * nt; m < Lr; m += nt) {
             ph = cmul(ph, phstep);
             fold_one(m, load_cell(cell, m));
         }
@@ -1023,13 +1085,18 @@ ringfft_kernel(const int32_t *__restrict__ ring_list, int nlist, int nside, int 
         __syncthreads();
         K5STAMP(t_z);
 
-        if (P == 0) {
+        if (!BLU || P == 0) {
+#if K5_ABLATE != 1
             fft_dif<1>(sm, bstride, NCH, h, tw, pmax);
+#endif
             K5STAMP(t_fft);
             for (int j = tid; j < h; j += nt) {
                 const int pos = fpad(fft_dif_pos(j, h));
 #pragma unroll
                 for (int c = 0; c < NCH; c++) {
+#if K5_ABLATE == 2
+                    if (sm[(size_t)c * bstride + pos].x == 1.2345e300)
+#endif
                     if (ch0 + c < nnu)
                         *reinterpret_cast<double2 *>(maps + (size_t)(ch0 + c) * npix + start + 2 * j) =
                             sm[(size_t)c * bstride + pos];
@@ -1038,7 +1105,11 @@ ringfft_kernel(const int32_t *__restrict__ ring_list, int nlist, int nside, int 
         } else {
             const double2 *f = filt + foff[icap - 1];
             const double invP = 1.0 / (double)P;
+#if K5_ABLATE == 1
+            if (false) {
+#else
             if (P >= K5_RADIX * K5_RADIX) {
+#endif
                 // >= 3 passes each way: the filter step and the final chirp/store are fused into the passes
                 const int rl = fft_dif_head<-1>(sm, bstride, NCH, P, tw, pmax);
                 if (rl == 16) fft_mid_fused<16>(sm, bstride, NCH, P, f);
@@ -1050,13 +1121,18 @@ ringfft_kernel(const int32_t *__restrict__ ring_list, int nlist, int nside, int 
                 K5STAMP(t_fft);
                 continue;
             }
+#if K5_ABLATE != 1
             fft_dif<-1>(sm, bstride, NCH, P, tw, pmax, f);  // filter multiplied in by the last pass
             fft_dit<1>(sm, bstride, NCH, P, tw, pmax);
+#endif
             K5STAMP(t_fft);
             for (int j = tid; j < h; j += nt) {
                 const double2 bj = bch[j];
 #pragma unroll
                 for (int c = 0; c < NCH; c++) {
+#if K5_ABLATE == 2
+                    if (bj.x == 1.2345e300)
+#endif
                     if (ch0 + c < nnu) {
                         double2 zv = cmul(sm[(size_t)c * bstride + fpad(j)], bj);
                         zv.x *= invP;
@@ -1096,13 +1172,20 @@ __global__ void __launch_bounds__(K5_THREADS)
 ringana_kernel(const int32_t *__restrict__ ring_list, int nlist, int nside, int lmax, int G, int nnu, long npix,
                const int32_t *__restrict__ nphi_a, const int64_t *__restrict__ start_a,
                const double *__restrict__ phi0_a, const double *__restrict__ maps, double *__restrict__ inter,
-               const double2 *__restrict__ tw, int pmax, const int32_t *__restrict__ blu_P,
+               const double2 *__restrict__ tw_hbm, int pmax, const int32_t *__restrict__ blu_P,
                const int64_t *__restrict__ boff, const int64_t *__restrict__ foff,
                const double2 *__restrict__ chirp, const double2 *__restrict__ filt, int bstride,
                const int32_t *__restrict__ mcut, const double *__restrict__ ring_w, int nvalid) {
     // nnu: channels incl. padding (every cell K4^T reads gets written); nvalid: channels present in `maps`
-    extern __shared__ __attribute__((aligned(16))) double2 sm[];  // [NCH][bstride]
+    extern __shared__ __attribute__((aligned(16))) double2 sm[];  // [NCH][bstride], then the twiddle table
     const int tid = threadIdx.x, nt = blockDim.x;
+#if K5_LDS_TW
+    double2 *tl = sm + (size_t)NCH * bstride;
+    twl_fill(tl, tw_hbm, pmax);
+    const double2 *tw = tl;
+#else
+    const double2 *tw = tw_hbm;
+#endif
     const int L = lmax + 1;
     const int ngrp = (nnu + NCH - 1) / NCH;
     const int nitems = nlist * ngrp;
@@ -1550,11 +1633,12 @@ int corahip_sht_plan_create(corahip_ctx *ctx, int nside, int lmax, corahip_sht_p
         HIP_TRY(hipMalloc((void **)&p->d_bchirp, sizeof(double2) * std::max<int64_t>(1, nb)));
         HIP_TRY(hipMalloc((void **)&p->d_bfilt, sizeof(double2) * std::max<int64_t>(1, nf)));
         if (nside > 1) {
-            const size_t shm = sizeof(double2) * (size_t)(fpad(maxlen) + 1);
+            const int tl_off = fpad(maxlen) + 1;
+            const size_t shm = sizeof(double2) * (size_t)(tl_off + TWL_ENTRIES(p->pmax));
             HIP_TRY(hipFuncSetAttribute((const void *)bluestein_table_kernel,
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
             bluestein_table_kernel<<<nside - 1, 256, shm, s>>>(p->d_blu_P, p->d_blu_boff, p->d_blu_foff,
-                                                                p->d_bchirp, p->d_bfilt, p->d_tw, p->pmax);
+                                                                p->d_bchirp, p->d_bfilt, p->d_tw, p->pmax, tl_off);
             LAUNCH_CHECK();
         }
     }
@@ -1583,8 +1667,9 @@ int corahip_sht_plan_create(corahip_ctx *ctx, int nside, int lmax, corahip_sht_p
             c.P = kv.first;
             c.bstride = fpad(c.P ? c.P : 2 * nside + 1) + 1;
             c.nch = 4;
-            while (c.nch > 1 && (size_t)c.nch * c.bstride * sizeof(double2) > lds_budget) c.nch >>= 1;
-            if ((size_t)c.nch * c.bstride * sizeof(double2) > 160 * 1024) {
+            const size_t tl_bytes = sizeof(double2) * TWL_ENTRIES(p->pmax);   // LDS twiddle table behind the buffers
+            while (c.nch > 1 && (size_t)c.nch * c.bstride * sizeof(double2) + tl_bytes > lds_budget) c.nch >>= 1;
+            if ((size_t)c.nch * c.bstride * sizeof(double2) + tl_bytes > 160 * 1024) {
                 corahip_set_error("nside %d: ring FFT of length %d does not fit in LDS", nside, c.bstride);
                 return CORAHIP_ENOMEM;
             }
@@ -1622,11 +1707,14 @@ int corahip_sht_lambda(corahip_ctx *ctx, const corahip_sht_plan *p, int m, int r
 }  // extern "C"
 
 static inline int nnu_pad_of(int nnu) { return (nnu + 7) & ~7; }
+// K5's register prefetch reads K5_MC * K5_THREADS cells from the start of a row without clamping: the last
+// row of the F_m buffer needs that much readable memory behind it
+#define K5_TAIL_PAD ((size_t)K5_MC * K5_THREADS * 64)
 
 extern "C" int corahip_alm2map_workspace_bytes(const corahip_sht_plan *p, int nnu, size_t *bytes) {
     ARG_CHECK(p != nullptr && bytes != nullptr && nnu >= 1);
     const size_t G = nnu_pad_of(nnu) / 4;
-    *bytes = (size_t)p->nring * G * p->L * 8 * sizeof(double);
+    *bytes = (size_t)p->nring * G * p->L * 8 * sizeof(double) + K5_TAIL_PAD;
     // an odd number of 4-channel groups cannot be consumed in place (K4 tiles are 16 columns
     // = 2 groups wide): the padded copy of the alm block lives in the workspace too
     if (((nnu + 3) / 4) & 1) *bytes += (size_t)p->nalm * G * 8 * sizeof(double);
@@ -1670,23 +1758,45 @@ static int alm2map_chunk(corahip_ctx *ctx, const corahip_sht_plan *p, const doub
         StageTimer t(ctx, "ringfft");
         const int G = nnu_chunk_pad / 4;
         const int k5_threads = K5_THREADS;
+        static const bool class_times = getenv("CORAHIP_K5_TIMES") != nullptr;   // diagnostics: per-class ms on stderr
         for (const auto &c : p->classes) {
-            const size_t shm = sizeof(double2) * (size_t)c.nch * c.bstride;
+            hipEvent_t ce0 = nullptr, ce1 = nullptr;
+            if (class_times) {
+                (void)hipEventCreate(&ce0);
+                (void)hipEventCreate(&ce1);
+                (void)hipEventRecord(ce0, ctx->stream);
+            }
+            const size_t shm = sizeof(double2) * ((size_t)c.nch * c.bstride + TWL_ENTRIES(p->pmax));
             const long nitems = (long)c.count * ((nnu_valid + c.nch - 1) / c.nch);
             const int per_cu = std::max<int>(1, (int)((160 * 1024) / std::max<size_t>(shm, 1)));
             dim3 grid((unsigned)std::min<long>(nitems, (long)ctx->num_cu * std::min(per_cu, 4)));
-#define RINGFFT_LAUNCH(NCH)                                                                                     \
-    HIP_TRY(hipFuncSetAttribute((const void *)ringfft_kernel<NCH>, hipFuncAttributeMaxDynamicSharedMemorySize,  \
+#define RINGFFT_LAUNCH(NCH, BLU)                                                                                     \
+    HIP_TRY(hipFuncSetAttribute((const void *)ringfft_kernel<NCH, BLU>, hipFuncAttributeMaxDynamicSharedMemorySize,  \
                                 160 * 1024));                                                                   \
-    ringfft_kernel<NCH><<<grid, k5_threads, shm, ctx->stream>>>(c.d_list, c.count, p->nside, p->lmax, G, nnu_valid, p->npix,     \
+    ringfft_kernel<NCH, BLU><<<grid, k5_threads, shm, ctx->stream>>>(c.d_list, c.count, p->nside, p->lmax, G, nnu_valid, p->npix,     \
                                                          p->d_nphi, p->d_start, p->d_phi0, inter, maps, p->d_tw, \
                                                          p->pmax, p->d_blu_P, p->d_blu_boff, p->d_blu_foff,      \
                                                          p->d_bchirp, p->d_bfilt, c.bstride, p->d_mcut)
-            if (c.nch == 4) { RINGFFT_LAUNCH(4); }
-            else if (c.nch == 2) { RINGFFT_LAUNCH(2); }
-            else { RINGFFT_LAUNCH(1); }
+            if (c.P == 0) {
+                if (c.nch == 4) { RINGFFT_LAUNCH(4, false); }
+                else if (c.nch == 2) { RINGFFT_LAUNCH(2, false); }
+                else { RINGFFT_LAUNCH(1, false); }
+            } else {
+                if (c.nch == 4) { RINGFFT_LAUNCH(4, true); }
+                else if (c.nch == 2) { RINGFFT_LAUNCH(2, true); }
+                else { RINGFFT_LAUNCH(1, true); }
+            }
 #undef RINGFFT_LAUNCH
             LAUNCH_CHECK();
+            if (class_times) {
+                float ms = 0.f;
+                (void)hipEventRecord(ce1, ctx->stream);
+                (void)hipEventSynchronize(ce1);
+                (void)hipEventElapsedTime(&ms, ce0, ce1);
+                fprintf(stderr, "K5 class P=%d nch=%d rings=%d: %.3f ms\n", c.P, c.nch, c.count, ms);
+                (void)hipEventDestroy(ce0);
+                (void)hipEventDestroy(ce1);
+            }
 #if K5_STAMPS
             {
                 unsigned long long hs[8];
@@ -1809,7 +1919,7 @@ extern "C" int corahip_map2alm(corahip_ctx *ctx, const corahip_sht_plan *p, cons
         StageTimer t(ctx, "ringana");
         const int k5_threads = K5_THREADS;
         for (const auto &c : p->classes) {
-            const size_t shm = sizeof(double2) * (size_t)c.nch * c.bstride;
+            const size_t shm = sizeof(double2) * ((size_t)c.nch * c.bstride + TWL_ENTRIES(p->pmax));
             const long nitems = (long)c.count * ((nnu_pad8 + c.nch - 1) / c.nch);
             dim3 grid((unsigned)std::min<long>(nitems, (long)ctx->num_cu * 4));
 #define RINGANA_LAUNCH(NCH)                                                                                      \
