@@ -170,9 +170,11 @@ __global__ void lambda_kernel(int lmax, int npair, int m, int r, const double *_
 // K4: Legendre contraction on FP64 MFMA
 // ------------------------------------------------------------------------------------
 #ifndef LEG_ABLATE
-#define LEG_ABLATE 0  // diagnostic builds only (make ablate): 1 no MFMA, 2 no recurrence, 3 no B reads
+#define LEG_ABLATE 0  // diagnostic builds only (make ablate): 1 no MFMA, 2 no recurrence, 3 no B reads, 4 no epilogue stores
 #endif
+#ifndef LEG_KT
 #define LEG_KT 32      // l rows per LDS stage
+#endif
 #define LEG_WAVES 8
 #define LEG_RINGS (16 * LEG_WAVES)  // ring pairs per workgroup
 #define LEG_NBUF 4     // LDS stage ring: one being read + three in flight
@@ -416,7 +418,12 @@ legendre_kernel(int lmax, int npair, int nring, int ncols, const double *__restr
 #else
 #pragma unroll
                     for (int t = 0; t < NT; t++) {
+#if LEG_ABLATE == 3  // diagnostic: no B operand reads from LDS
+                        const double bev = ae[0] + t, bov = ao[0] - t;
+                        asm volatile("" ::"v"(be), "v"(bo));
+#else
                         const double bev = be[16 * t], bov = bo[16 * t];
+#endif
 #pragma unroll
                         for (int q = 0; q < RT; q++) {
                             acce[q][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(ae[q], bev, acce[q][t], 0, 0, 0);
@@ -460,7 +467,11 @@ legendre_kernel(int lmax, int npair, int nring, int ncols, const double *__restr
                         const double srecv = __shfl_xor(odd_lane ? s0 : s1, 1);
                         const int rr = odd_lane ? r1 : r0;
                         const int ro = cur_rtile * TRINGS + (kq + 4 * rr + 16 * q) * LEG_WAVES + wave;
+#if LEG_ABLATE == 4  // diagnostic: no epilogue stores (unless a value is absurd: keeps the arithmetic alive)
+                        if (ro < npair && n0 == 1.2345e300) {
+#else
                         if (ro < npair) {
+#endif
                             const double2 nv = odd_lane ? make_double2(nrecv, n1) : make_double2(n0, nrecv);
                             *reinterpret_cast<double2 *>(inter + (((size_t)ro * G + g) * L + cur_m) * 8 + cv) = nv;
                             const int rs = nring - 1 - ro;
