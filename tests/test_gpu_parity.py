@@ -756,3 +756,140 @@ def test_makesky_cli_21cm_and_gaussianfg(tmp_path):
     r = CliRunner().invoke(makesky.cli, ["gaussianfg", "--nside", "8", "--pol", "full"])
     assert r.exit_code != 0 and "spin-2" in r.output
     del galaxy
+
+
+# ------------------------------------------------------------------ full-size pipeline / remaining BASELINE configs
+def _alm_power(alm_dev, lmax):
+    """C^_l per channel from alm_dev [nalm, G, 2, 4] counting only Re a_l0 (what the synthesis uses): [4G, L]."""
+    import torch
+
+    L = lmax + 1
+    dev = alm_dev.device
+    pw = alm_dev[:, :, 0, :] ** 2 + alm_dev[:, :, 1, :] ** 2          # [nalm, G, 4]
+    pw[:L] = alm_dev[:L, :, 0, :] ** 2                                 # m = 0: real part only
+    idx_l = torch.cat([torch.arange(m, L, device=dev) for m in range(L)])
+    wgt = torch.full((pw.shape[0],), 2.0, device=dev, dtype=torch.float64)
+    wgt[:L] = 1.0
+    out = torch.zeros((L,) + tuple(pw.shape[1:]), device=dev, dtype=torch.float64)
+    out.index_add_(0, idx_l, pw * wgt[:, None, None])
+    out = out / (2.0 * torch.arange(L, device=dev, dtype=torch.float64) + 1.0)[:, None, None]
+    return out.reshape(L, -1).T
+
+
+def test_config3_pipeline_full_size_recovered_spectrum(ctx):
+    """configs[2] END TO END at full size (Corr21cm, 256 channels 400-800 MHz, nside 1024, lmax 2048, device
+    Philox stream): (1) the spectrum of the drawn a_lm matches the integrated C_l(nu,nu) (2l+1/2)/(2l+1) within
+    sampling error for every channel, and adjacent channels have the model's cross-correlation; (2) the a_lm
+    recovered from the final MAPS by the analysis kernels equal the drawn ones to iteration accuracy - so
+    K1 -> K2 -> K3 -> K4 -> K5 is closed on the device at BASELINE size."""
+    import torch
+    from cora_amd.core import skysim
+    from cora_amd.signal import corr21cm
+    from cora_amd.util import hputil
+
+    nside, lmax, F = 1024, 2048, 256
+    L = lmax + 1
+    cr = corr21cm.Corr21cm()
+    freq = 400.0 + (np.arange(F) + 0.5) * (400.0 / F)
+    C = skysim.clarray_device(cr.angular_powerspectrum, lmax, freq, zromb=3)          # K1  [L, F, F]
+    T, info = skysim.factor_device(C)                                                  # K2
+    assert int(info.abs().sum().item()) == 0                                           # all Cholesky (cond ~ 4)
+    alm = ctx.draw_alm_philox(T, info, 20261003, lmax, F)                              # K3
+    ps = _alm_power(alm, lmax)                                                         # [F, L]
+    l = torch.arange(L, device=ctx.device, dtype=torch.float64)
+    expect = torch.diagonal(C, dim1=1, dim2=2).T * (2 * l + 0.5) / (2 * l + 1)         # [F, L]
+    sigma = expect * torch.sqrt(2.0 / (2 * l + 1))
+    z = ((ps - expect) / sigma)[:, 2:]
+    # (chi^2 with 2l+1 degrees of freedom: the extreme-value bound is applied where it is near Gaussian)
+    assert z[:, 30:].abs().max().item() < 6.5 and abs(z.mean().item()) < 0.05, (z[:, 30:].abs().max().item(), z.mean().item())
+    assert abs((z**2).mean().item() - 1.0) < 0.05
+    # cross-spectrum of channels 100/101 at l in [200, 2048]: correlation coefficient as in the model
+    a0, a1 = alm[:, 25, :, 0], alm[:, 25, :, 1]                                        # channels 100, 101
+    cross = (a0 * a1).sum(dim=1)
+    idx_l = torch.cat([torch.arange(m, L, device=ctx.device) for m in range(L)])
+    sel = idx_l >= 200
+    r_hat = (cross[sel].sum() / torch.sqrt((a0[sel] ** 2).sum() * (a1[sel] ** 2).sum())).item()
+    wl = (2 * l[200:] + 1)
+    r_mod = ((wl * C[200:, 100, 101]).sum() / torch.sqrt((wl * C[200:, 100, 100]).sum() * (wl * C[200:, 101, 101]).sum())).item()
+    assert abs(r_hat - r_mod) < 5e-3, (r_hat, r_mod)
+    del T, C
+    # (2) maps -> analysis -> a_lm for 8 channels
+    sub = alm[:, 24:26].contiguous()                                                   # channels 96..103
+    maps = ctx.alm2map(sub, nside, lmax, 8)                                            # K4 + K5
+    rec = hputil.map2alm_device(maps, nside, lmax, use_weights=True, niter=3)
+    sub0 = sub.clone()
+    sub0[:L, :, 1, :] = 0.0                                                            # Im a_l0 is not in the map
+    err = (rec - sub0).abs().max().item() / sub0.abs().max().item()
+    assert err < 2e-3, err
+    del alm, maps, rec
+    torch.cuda.empty_cache()
+
+
+def test_config4_three_components_frequency_shard(ctx):
+    """configs[3]: 21cm (zromb 3) + synchrotron + unresolved point sources (zromb 0) on a 512-channel grid,
+    nside 1024, lmax 2048 - the 64-channel shard one of eight ranks synthesises.  The sum of the component maps
+    equals the synthesis of the summed a_lm (linearity across components), every component's drawn spectrum
+    matches its own C_l, and C_0 = 0 components carry no monopole."""
+    import torch
+    from cora_amd.core import skysim
+    from cora_amd.foreground import galaxy, pointsource
+    from cora_amd.signal import corr21cm
+
+    nside, lmax, F, nu0, nnu = 1024, 2048, 512, 192, 64
+    L = lmax + 1
+    freq = 400.0 + (np.arange(F) + 0.5) * (400.0 / F)
+    comps = [(corr21cm.Corr21cm(), 3), (galaxy.FullSkySynchrotron(), 0), (pointsource.CombinedPointSources._UnresolvedBackground(), 0)]
+    l = torch.arange(L, device=ctx.device, dtype=torch.float64)
+    total_alm = None
+    total_map = None
+    for k, (model, zromb) in enumerate(comps):
+        C = skysim.clarray_device(model.angular_powerspectrum, lmax, freq, zromb=zromb)
+        T, info = skysim.factor_device(C)
+        alm = ctx.draw_alm_philox(T, info, 77 + k, lmax, F, nu0=nu0, nnu=nnu)
+        ps = _alm_power(alm, lmax)                                                     # [64, L]
+        expect = torch.diagonal(C, dim1=1, dim2=2).T[nu0:nu0 + nnu] * (2 * l + 0.5) / (2 * l + 1)
+        z = ((ps - expect) / (expect * torch.sqrt(2.0 / (2 * l + 1))))[:, 2:]
+        assert z[:, 30:].abs().max().item() < 6.5 and abs(z.mean().item()) < 0.1, (k, z[:, 30:].abs().max().item(), z.mean().item())
+        if k > 0:
+            assert float(ps[:, 0].abs().max().item()) == 0.0                            # C_0 = 0 (gaussianfg.py:108-115)
+        m = ctx.alm2map(alm, nside, lmax, nnu)
+        total_map = m.clone() if total_map is None else total_map + m
+        total_alm = alm.clone() if total_alm is None else total_alm + alm
+        del C, T, alm, m
+    both = ctx.alm2map(total_alm, nside, lmax, nnu)
+    assert (both - total_map).abs().max().item() <= 1e-11 * total_map.std().item()
+    # the synchrotron dominates and is red: brighter at the low-frequency end of the shard
+    assert total_map[0].std().item() > total_map[-1].std().item()
+    del both, total_map, total_alm
+    torch.cuda.empty_cache()
+
+
+def test_config5_geometry_synthesis_properties(ctx):
+    """configs[4] geometry (nside 2048, lmax 4096; one 8-channel slice of a rank's 128): the largest plan -
+    ring FFTs of 8192 pixels (two channels per workgroup), Bluestein length 8192, 8.4 M a_lm per channel.
+    Parseval and linearity of the synthesis, and lambda_lm at l = m = 4096 against the closed form."""
+    import torch
+
+    nside, lmax, nnu = 2048, 4096, 8
+    L = lmax + 1
+    nalm = L * (L + 1) // 2
+    gen = torch.Generator(device=ctx.device).manual_seed(9)
+    idx_l = torch.cat([torch.arange(m, L, device=ctx.device) for m in range(L)])
+    amp = 1.0 / (1.0 + idx_l.double())
+    a = torch.randn((nalm, 2, 2, 4), generator=gen, device=ctx.device, dtype=torch.float64) * amp[:, None, None, None]
+    b = torch.randn((nalm, 2, 2, 4), generator=gen, device=ctx.device, dtype=torch.float64) * amp[:, None, None, None]
+    ma = ctx.alm2map(a, nside, lmax, nnu).clone()
+    ps = _alm_power(a.clone(), lmax)                                                    # [8, L]
+    var_alm = (ps * (2 * torch.arange(L, device=ctx.device, dtype=torch.float64) + 1)).sum(dim=1) / (4 * np.pi)
+    rel = (((ma**2).mean(dim=1) - var_alm).abs() / var_alm).max().item()
+    assert rel < 2e-3, rel
+    mb = ctx.alm2map(b, nside, lmax, nnu).clone()
+    mc = ctx.alm2map(2.0 * a - 3.0 * b, nside, lmax, nnu)
+    assert (mc - (2.0 * ma - 3.0 * mb)).abs().max().item() < 1e-11 * mc.std().item()
+    # lambda_mm(theta) = (-1)^m sqrt((2m+1)!!/(4 pi (2m)!!)) sin^m(theta) at m = lmax, equator ring pair
+    lam = ctx.sht_lambda(nside, lmax, lmax, 2 * nside - 1).cpu().numpy()
+    import math
+    lg = 0.5 * (math.lgamma(2 * lmax + 2) - 2 * math.lgamma(lmax + 1) - (2 * lmax) * math.log(2.0) - math.log(4 * math.pi))
+    assert abs(lam[0] - math.exp(lg)) < 1e-9 * math.exp(lg)       # z = 0: sin theta = 1; (-1)^4096 = +1
+    del a, b, ma, mb, mc
+    torch.cuda.empty_cache()
