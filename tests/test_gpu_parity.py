@@ -237,6 +237,31 @@ def test_draw_fused_rng_equals_materialised_stream(ctx, golden):
     assert np.abs(a[:, 0, l, : l + 1] - ref).max() <= 1e-12 * np.abs(ref).max()
 
 
+def test_draw_more_than_128_columns(ctx):
+    """More than 128 columns (several column groups per l): fused-RNG draw against the materialised stream, for
+    triangular and dense (eigen-branch) factors, full and sharded channel ranges, row-sliced factors, and row
+    counts that are not multiples of the tiles."""
+    import torch
+
+    rng = np.random.default_rng(3)
+    for F, lmax in ((144, 21), (256, 140), (200, 33)):
+        A = rng.standard_normal((lmax + 1, F, F + 5))
+        C = A @ A.transpose(0, 2, 1)
+        T, info = ctx.factor_batched(ctx.to_device(C))
+        g = ctx.normals_philox(1234 + F, lmax, F)
+        for nu0, nnu in ((0, F), (F - 132, 132)):
+            a = ctx.alm_dev_to_square(ctx.draw_alm(T, info, g, lmax, F, nu0=nu0, nnu=nnu), lmax, nnu)
+            b = ctx.alm_dev_to_square(ctx.draw_alm_philox(T, info, 1234 + F, lmax, F, nu0=nu0, nnu=nnu), lmax, nnu)
+            assert (a - b).abs().max().item() <= 1e-13 * a.abs().max().item(), (F, nu0)
+            rows = T[:, nu0:nu0 + nnu, :].contiguous()
+            c = ctx.alm_dev_to_square(ctx.draw_alm_philox_rows(rows, info, 1234 + F, lmax, F, nu0, nnu), lmax, nnu)
+            assert torch.equal(b, c)
+        dense = torch.ones_like(info)           # treat the same factors as dense: all k contribute (upper part is 0)
+        d = ctx.alm_dev_to_square(ctx.draw_alm_philox(T, dense, 1234 + F, lmax, F), lmax, F)
+        a = ctx.alm_dev_to_square(ctx.draw_alm(T, info, g, lmax, F), lmax, F)
+        assert (a - d).abs().max().item() <= 1e-13 * a.abs().max().item()
+
+
 def test_philox_normals_match_stream_oracle(ctx):
     """normals_philox (fast in-kernel log / sqrt / sincos) == numpy restatement of the device stream."""
     from oracle import philox
