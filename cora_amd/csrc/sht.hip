@@ -1391,10 +1391,12 @@ legendre_adj_kernel(int lmax, int npair, int nring, int ncols, const double *__r
             for (int lb = lb0; lb <= lmax; lb += LB) {
                 const unsigned long long act = __ballot(ls4 <= lb + LB - 1);   // bit 4s: k-step s has a started ring
                 // lambda_{lb .. lb+31} of this lane's ring -> transpose buffer [ring][l - lb]
+                // (coefficients are read unconditionally - the table is padded by 32 entries - so that the scalar
+                // loads of a whole unrolled group are issued together; rows past lmax are discarded below)
 #pragma unroll 8
                 for (int j = 0; j < LB; j++) {
                     const int l = lb + j;
-                    const double2 c = (l <= lmax) ? cf[l] : make_double2(0.0, 0.0);
+                    const double2 c = cf[l];
                     double vv = fma(c.x * x, p1, -(c.y * p0));
                     const bool inj = (l == my_ls);
                     vv = inj ? sd.y : vv;
