@@ -81,7 +81,8 @@ def clarray_device(aps, lmax, zarray, zromb=3, zwidth=None):
         lsec = np.arange(l0, min(l0 + _GENERIC_LCHUNK, lmax + 1))
         clt = aps(lsec[:, np.newaxis, np.newaxis].astype(np.float64), za[np.newaxis, :, np.newaxis],
                   za[np.newaxis, np.newaxis, :])
-        clt = np.ascontiguousarray(np.broadcast_to(clt, (len(lsec), za.size, za.size)), dtype=np.float64)
+        # (a writable, contiguous copy: broadcast views are read-only and torch refuses to wrap those silently)
+        clt = np.array(np.broadcast_to(clt, (len(lsec), za.size, za.size)), dtype=np.float64, order="C", copy=True)
         out[l0 : l0 + len(lsec)] = ctx.romb_reduce(torch.from_numpy(clt).to(ctx.device), len(lsec), zlen, zint, w)
     return out
 

@@ -40,6 +40,8 @@ def main():
     st = {k: ctx.profile_get(k)[0] / a.reps for k in ("ringana", "legendre_adj")}
     nalm = (a.lmax + 1) * (a.lmax + 2) // 2
     flops = 8.0 * a.nside * nalm * a.nnu
+    hputil.map2alm_device(maps, a.nside, a.lmax)      # warm-up: workspace growth, allocator
+    torch.cuda.synchronize()
     t1 = time.time()
     hputil.map2alm_device(maps, a.nside, a.lmax)
     torch.cuda.synchronize()
