@@ -76,6 +76,11 @@ class Interpolater:
 
     __call__ = value
 
+    def value_array(self, x):
+        """Spline at every element of an array, same shape (cubicspline.pyx:107-123)."""
+        x = np.asarray(x, dtype=np.float64)
+        return self._eval(np.ravel(x, order="C")).reshape(x.shape)
+
     def _eval(self, xv):
         xs, ys, y2 = self._data[:, 0], self._data[:, 1], self._y2
         n = len(xs)
@@ -117,3 +122,8 @@ class LogInterpolater(Interpolater):
         return float(r[0]) if scalar else r
 
     __call__ = value
+
+    def value_log_array(self, x):
+        """exp(spline(log x)) at every element of an array (cubicspline.pyx:273-288)."""
+        x = np.asarray(x, dtype=np.float64)
+        return np.exp(self._eval(np.log(np.ravel(x, order="C")))).reshape(x.shape)

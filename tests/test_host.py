@@ -302,3 +302,19 @@ def test_ang2pix_inverts_pix2ang():
     for ns in (1, 2, 8, 32):
         th, ph = healpix.pix2ang_ring(ns)
         assert np.array_equal(hputil.ang2pix(ns, th, ph), np.arange(12 * ns * ns))
+
+
+def test_cubicspline_array_entry_points():
+    """value_array / value_log_array / __call__ agree and extrapolate a constant exactly
+    (the cases of the reference's tests/test_cubicspline.py::test_constant)."""
+    from cora_amd.util import cubicspline as cs
+
+    x = np.arange(1, 8)
+    data = np.dstack((x, np.ones(7)))[0]
+    pts = np.asarray([0.025, 1, 2.5, 4, 5.55, 7.01, 19])
+    p = cs.Interpolater(data)
+    assert (p(pts) == 1).all() and (p.value_array(np.asarray([-0.025, 1, 2.5, 4, 5.55, 7.01, 19])) == 1).all()
+    q = cs.LogInterpolater(data)
+    assert (q(pts) == 1).all() and (q.value_log_array(np.asarray([0.0125, 1, 2.5, 4, 5.55, 7.01, 19])) == 1).all()
+    grid = np.linspace(1.2, 6.8, 12).reshape(3, 4)
+    assert p.value_array(grid).shape == (3, 4) and np.array_equal(p.value_array(grid), p(grid.ravel()).reshape(3, 4))
