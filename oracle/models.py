@@ -145,8 +145,8 @@ class LogInterpolater(Interpolater):
 
 
 # ---------------------------------------------------------------- bilinear
-def bilinear_interp(arr, x, y):
-    """bilinearmap.pyx:14-59."""
+def bilinear_interp_numpy(arr, x, y):
+    """bilinearmap.pyx:14-59 in numpy."""
     nx, ny = arr.shape
     xx = np.clip(x, 0.0, nx - 1e-5)
     yy = np.clip(y, 0.0, ny - 1e-5)
@@ -158,6 +158,26 @@ def bilinear_interp(arr, x, y):
     wc = (xx - x0) * (y1 - yy)
     wd = (xx - x0) * (yy - y0)
     return wa * arr[x0, y0] + wb * arr[x0, y1] + wc * arr[x1, y0] + wd * arr[x1, y1]
+
+
+def bilinear_interp(arr, x, y):
+    """bilinearmap.pyx:14-59 in C/OpenMP over points (as the reference's prange), falling back to numpy for
+    non-contiguous tables.  Identical arithmetic: the two agree bit for bit (tests/test_oracle.py)."""
+    import ctypes
+
+    from . import sht
+
+    if not (isinstance(arr, np.ndarray) and arr.flags["C_CONTIGUOUS"] and arr.dtype == np.float64):
+        return bilinear_interp_numpy(arr, x, y)
+    x, y = np.broadcast_arrays(np.asarray(x, dtype=np.float64), np.asarray(y, dtype=np.float64))
+    xr, yr = np.ascontiguousarray(x).ravel(), np.ascontiguousarray(y).ravel()
+    out = np.empty(xr.size)
+    lib = sht._load()
+    dp = ctypes.POINTER(ctypes.c_double)
+    lib.oracle_bilinear_interp(arr.ctypes.data_as(dp), ctypes.c_long(arr.shape[0]), ctypes.c_long(arr.shape[1]),
+                               xr.ctypes.data_as(dp), yr.ctypes.data_as(dp), ctypes.c_long(xr.size),
+                               out.ctypes.data_as(dp))
+    return out.reshape(x.shape)
 
 
 # ---------------------------------------------------------------- 21cm model

@@ -36,6 +36,8 @@ def _load():
         _lib.oracle_legendre_anal.restype = None
         _lib.oracle_lambda_lm.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_double, dp]
         _lib.oracle_lambda_lm.restype = None
+        _lib.oracle_bilinear_interp.argtypes = [dp, ctypes.c_long, ctypes.c_long, dp, dp, ctypes.c_long, dp]
+        _lib.oracle_bilinear_interp.restype = None
         _lib.oracle_num_threads.restype = ctypes.c_int
     return _lib
 

@@ -198,6 +198,29 @@ void oracle_lambda_lm(int lmax, int m, double x, double sthv, double *out)
     }
 }
 
+/* cora/util/bilinearmap.pyx:14-59 restated (OpenMP over points like the reference's prange): clip to
+ * [0, n - 1e-5], truncate to the lower corner, four-corner weights.  n points, table arr [nx][ny] row-major. */
+void oracle_bilinear_interp(const double *arr, long nx, long ny, const double *x, const double *y, long n,
+                            double *out)
+{
+    const double ux = (double)nx - 1e-5, uy = (double)ny - 1e-5;
+#pragma omp parallel for schedule(static)
+    for (long i = 0; i < n; i++) {
+        double xx = x[i] < 0.0 ? 0.0 : (x[i] > ux ? ux : x[i]);
+        double yy = y[i] < 0.0 ? 0.0 : (y[i] > uy ? uy : y[i]);
+        long x0 = (long)xx, y0 = (long)yy;
+        long x1 = x0 + 1, y1 = y0 + 1;
+        /* the reference reads arr[x1][y1] unchecked; x1 = nx / y1 = ny can only occur within 1e-5 of the
+         * upper clip, which the hot path never reaches - clamp instead of reading out of bounds */
+        long xc = x1 < nx ? x1 : nx - 1, yc = y1 < ny ? y1 : ny - 1;
+        double wa = ((double)x1 - xx) * ((double)y1 - yy);
+        double wb = ((double)x1 - xx) * (yy - (double)y0);
+        double wc = (xx - (double)x0) * ((double)y1 - yy);
+        double wd = (xx - (double)x0) * (yy - (double)y0);
+        out[i] = wa * arr[x0 * ny + y0] + wb * arr[x0 * ny + yc] + wc * arr[xc * ny + y0] + wd * arr[xc * ny + yc];
+    }
+}
+
 int oracle_num_threads(void)
 {
 #ifdef _OPENMP

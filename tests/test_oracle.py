@@ -317,3 +317,19 @@ def test_map2alm_oracle_against_bruteforce_and_adjointness():
     a2 = rng.standard_normal(n2) + 1j * rng.standard_normal(n2)
     a2[: lmax2 + 1] = a2[: lmax2 + 1].real
     assert np.abs(sht.map2alm(sht.alm2map(a2, nside, lmax2), nside, lmax2) - a2).max() < 1e-8
+
+
+def test_bilinear_interp_c_equals_numpy():
+    """The C/OpenMP restatement of bilinearmap.interp equals the numpy one bit for bit (incl. the clips)."""
+    from oracle import models
+
+    rng = np.random.default_rng(2)
+    tab = rng.standard_normal((37, 53))
+    x = rng.uniform(-3, 40, size=(5, 1, 7))
+    y = rng.uniform(-3, 56, size=(1, 4, 7))
+    a = models.bilinear_interp(tab, x, y)
+    xb, yb = np.broadcast_arrays(x, y)
+    # stay away from the last 1e-5 of the table, where the reference itself would read out of bounds
+    ok = (xb < 36 - 1e-5) & (yb < 52 - 1e-5)
+    b = models.bilinear_interp_numpy(tab, np.where(ok, xb, 0.0), np.where(ok, yb, 0.0))
+    assert a.shape == (5, 4, 7) and np.array_equal(a[ok], b[ok])
