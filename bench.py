@@ -329,7 +329,7 @@ def cpu_baseline(model_name, F, freq, nside, lmax, zromb):
     ncore = len(os.sched_getaffinity(0))
     L = lmax + 1
     rng = np.random.default_rng(0)
-    # K1 sample: 4 l-chunks of 5 (the reference's chunking), all channels
+    # K1 sample: nl_s multipoles spread over the range, all channels
     if model_name == "21cm":
         om = models.Corr21cm()
         t0 = time.time()
@@ -343,7 +343,7 @@ def cpu_baseline(model_name, F, freq, nside, lmax, zromb):
     za = (freq[:, None] + np.linspace(-zhalf, zhalf, zint)[None, :]).ravel()
     import scipy.integrate as si
 
-    nl_s = 4 if F > 64 else 20
+    nl_s = 16 if F > 64 else 20
     lsec = np.linspace(1, lmax, nl_s).astype(int).astype(np.float64)
     t0 = time.time()
     zspace = 2.0 * zhalf / 2**zromb
@@ -366,7 +366,7 @@ def cpu_baseline(model_name, F, freq, nside, lmax, zromb):
         nd += l + 1
     t_k23 = (time.time() - t0) * (L * (L + 1) / 2) / nd
     # K4 + K5 sample: nmap channels through the C/OpenMP synthesis
-    nmap = 2 if nside >= 1024 else 4
+    nmap = 8 if nside >= 1024 else 4
     nalm = L * (L + 1) // 2
     t0 = time.time()
     for _ in range(nmap):
@@ -379,7 +379,7 @@ def cpu_baseline(model_name, F, freq, nside, lmax, zromb):
         "unit": "maps/s",
         "cores": ncore,
         "kind": "port",
-        "sample": "C_l integration on %d of %d l (numpy, as cora/core/skysim.py:51-67), factor+normals+T@g on those l "
+        "sample": "C_l integration on %d of %d l (numpy + C/OpenMP table lookups, as cora/core/skysim.py:51-67 with bilinearmap.pyx), factor+normals+T@g on those l "
                   "(scipy/numpy, scaled by nalm), C/OpenMP synthesis of %d of %d channels; each leg scaled linearly; "
                   "per-realisation seconds: clarray %.1f, factor+draw %.1f, synthesis %.1f (one-off 21cm table build %.1f s "
                   "not counted)" % (nl_s, L, nmap, F, t_k1, t_k23, t_sht, t_tables),
