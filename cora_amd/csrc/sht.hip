@@ -175,8 +175,12 @@ __global__ void lambda_kernel(int lmax, int npair, int m, int r, const double *_
 #ifndef LEG_KT
 #define LEG_KT 32      // l rows per LDS stage
 #endif
+#ifndef LEG_WAVES
 #define LEG_WAVES 8
-#define LEG_RINGS (16 * LEG_WAVES)  // ring pairs per workgroup
+#endif
+#define LEG_RINGS (16 * LEG_WAVES)  // ring pairs per workgroup (x RT)
+#define LMIN_RINGS 128              // granularity of the plan's per-(m, ring block) first-l table
+#define ADJ_WAVES 8                 // waves per workgroup of the analysis kernel
 #define LEG_NBUF 4     // LDS stage ring: one being read + three in flight
 
 // LDS-DMA issued from inline asm: hipcc does not count it, so it does not drain the DMA with a
@@ -203,7 +207,7 @@ __device__ static inline void glds16(const void *gsrc, unsigned lds_byte_addr) {
 // tiles = 128 VGPRs in both shipped shapes: <8,1> for >= 128 columns, <4,2> for 64-column shards, where a
 // second, independent recurrence per lane keeps the recurrence : MFMA ratio of the wide shape).
 template <int NT, int RT>
-__global__ void __launch_bounds__(512)
+__global__ void __launch_bounds__(64 * LEG_WAVES, LEG_WAVES <= 4 ? 2 : 1)
 legendre_kernel(int lmax, int npair, int nring, int ncols, const double *__restrict__ z,
                 const double2 *__restrict__ coef, const int32_t *__restrict__ lstart,
                 const double2 *__restrict__ seed, const int32_t *__restrict__ lmin_tab,
@@ -216,7 +220,8 @@ legendre_kernel(int lmax, int npair, int nring, int ncols, const double *__restr
     constexpr int RPW = LEG_KT / LEG_WAVES;             // a_lm rows each wave moves per stage
     constexpr int PIECES = RPW + 1;                     // LDS-DMA pieces per wave per stage (+ coefficients)
     constexpr int TRINGS = LEG_RINGS * RT;              // ring pairs per workgroup
-    static_assert(RPW == LEG_KT / 8, "one a_lm piece per macro-step");
+    constexpr int RPM = RPW / (LEG_KT / 8);             // a_lm pieces each wave issues per macro-step
+    static_assert(RPM * (LEG_KT / 8) == RPW && RPM >= 1, "whole a_lm pieces per macro-step");
     extern __shared__ __attribute__((aligned(16))) double lds[];
     int &s_next = *reinterpret_cast<int *>(lds + LEG_NBUF * STAGE);  // next work item (carved after the ring)
 
@@ -227,7 +232,7 @@ legendre_kernel(int lmax, int npair, int nring, int ncols, const double *__restr
     const int d = 2 * kq;
     const int L = lmax + 1;
     const int G = ncols >> 3;
-    const int ntile128 = (npair + LEG_RINGS - 1) / LEG_RINGS;   // granularity of lmin_tab
+    const int ntile128 = (npair + LMIN_RINGS - 1) / LMIN_RINGS;   // granularity of lmin_tab
     const int ntile = (npair + TRINGS - 1) / TRINGS;
     const int ncg = ncols / TCOLS;
     const int nitems = L * ncg * ntile;
@@ -250,11 +255,9 @@ legendre_kernel(int lmax, int npair, int nring, int ncols, const double *__restr
         w.m = gidx / ncg;
         w.cg = gidx - w.m * ncg;
         int lmin = lmax + 1;
-#pragma unroll
-        for (int q = 0; q < RT; q++) {
-            const int t128 = w.rtile * RT + q;
-            if (t128 < ntile128) lmin = min(lmin, lmin_tab[w.m * ntile128 + t128]);
-        }
+        const int t_first = (w.rtile * TRINGS) / LMIN_RINGS;
+        const int t_last = min((w.rtile * TRINGS + TRINGS - 1) / LMIN_RINGS, ntile128 - 1);
+        for (int t128 = t_first; t128 <= t_last; t128++) lmin = min(lmin, lmin_tab[w.m * ntile128 + t128]);
         w.l_begin = w.m + ((lmin - w.m) & ~7);
         w.nstage = lmin <= lmax ? (lmax - w.l_begin) / LEG_KT + 1 : 0;
         w.base_m = alm_idx(0, w.m, lmax);
@@ -359,7 +362,10 @@ legendre_kernel(int lmax, int npair, int nring, int ncols, const double *__restr
                 for (int ms = 0; ms < LEG_KT / 8; ms++) {
                     // one a_lm piece of the stage being refilled per macro-step: spreads the LDS-DMA issue
                     // over the MFMA work instead of an 8-wave burst behind the barrier (measured 7 % of time)
-                    if (refill) issue_row(w, st + LEG_NBUF - 1, ms);
+                    if (refill) {
+#pragma unroll
+                        for (int r = 0; r < RPM; r++) issue_row(w, st + LEG_NBUF - 1, ms * RPM + r);
+                    }
                     const int l0 = ls + 8 * ms;
                     if (l0 > lmax) continue;
                     // nothing of this wave starts before l0+14: skip the macro-step entirely
@@ -507,7 +513,7 @@ __global__ void lmin_kernel(int lmax, int npair, int ntile, const int32_t *__res
     const int m = blockIdx.x, t = threadIdx.x;
     if (t >= ntile) return;
     int v = lmax + 1;
-    for (int r = t * LEG_RINGS; r < min((t + 1) * LEG_RINGS, npair); r++) v = min(v, lstart[(long)m * npair + r]);
+    for (int r = t * LMIN_RINGS; r < min((t + 1) * LMIN_RINGS, npair); r++) v = min(v, lstart[(long)m * npair + r]);
     lmin_tab[m * ntile + t] = v;
 }
 
@@ -1313,12 +1319,12 @@ legendre_adj_kernel(int lmax, int npair, int nring, int ncols, const double *__r
                     const int32_t *__restrict__ mcut, const double *__restrict__ inter, double *__restrict__ part,
                     unsigned *__restrict__ queue) {
     constexpr int TCOLS = 16 * NCT;
-    constexpr int TRINGS = 64 * LEG_WAVES;     // 512 ring pairs per workgroup
+    constexpr int TRINGS = 64 * ADJ_WAVES;     // 512 ring pairs per workgroup
     constexpr int LB = 32;                     // l per block: 16 even + 16 odd (l - m)
     constexpr int LSTR = LB + 1;               // LDS row stride of the transpose: conflict-free both ways
     constexpr int WREG = 64 * LSTR;            // doubles per wave
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    int &s_next = *reinterpret_cast<int *>(lds + LEG_WAVES * WREG);
+    int &s_next = *reinterpret_cast<int *>(lds + ADJ_WAVES * WREG);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -1326,7 +1332,7 @@ legendre_adj_kernel(int lmax, int npair, int nring, int ncols, const double *__r
     const int L = lmax + 1;
     const int G = ncols >> 3;
     const long nalm = nalm_of(lmax);
-    const int ntile128 = (npair + LEG_RINGS - 1) / LEG_RINGS;
+    const int ntile128 = (npair + LMIN_RINGS - 1) / LMIN_RINGS;
     const int ntile = (npair + TRINGS - 1) / TRINGS;
     const int ncg = ncols / TCOLS;
     const int nitems = L * ncg * ntile;
@@ -1356,7 +1362,7 @@ legendre_adj_kernel(int lmax, int npair, int nring, int ncols, const double *__r
             double ge[16][NCT], go[16][NCT];
 #pragma unroll
             for (int s = 0; s < 16; s++) {
-                const int ro = rtile * TRINGS + (4 * s + kq) * LEG_WAVES + wave;
+                const int ro = rtile * TRINGS + (4 * s + kq) * ADJ_WAVES + wave;
                 const bool ok = ro < npair && m < mcut[min(ro, npair - 1)];
                 const int rs = nring - 1 - ro;
 #pragma unroll
@@ -1373,7 +1379,7 @@ legendre_adj_kernel(int lmax, int npair, int nring, int ncols, const double *__r
                 }
             }
             // ---- recurrence state of this lane's ring
-            const int ring = rtile * TRINGS + lane * LEG_WAVES + wave;
+            const int ring = rtile * TRINGS + lane * ADJ_WAVES + wave;
             double x = 0.0, p0 = 0.0, p1 = 0.0;
             double2 sd = make_double2(0.0, 0.0);
             int my_ls = lmax + 1;
@@ -1434,7 +1440,7 @@ legendre_adj_kernel(int lmax, int npair, int nring, int ncols, const double *__r
                     const int e = tid + 512 * u;          // element (par, t, r, lane) of the reduced tile
                     double sum = 0.0;
 #pragma unroll
-                    for (int w = 0; w < LEG_WAVES; w++) sum += lds[w * WREG + e];
+                    for (int w = 0; w < ADJ_WAVES; w++) sum += lds[w * WREG + e];
                     const int el = e & 63, r = (e >> 6) & 3, t = (e >> 8) % NCT, par = (e >> 8) / NCT;
                     const int l = lb + 2 * ((el >> 4) + 4 * r) + par;
                     if (l <= lmax) pout[(size_t)l * ncols + 16 * t + (el & 15)] = sum;
@@ -1597,7 +1603,7 @@ int corahip_sht_plan_create(corahip_ctx *ctx, int nside, int lmax, corahip_sht_p
         LAUNCH_CHECK();
     }
     {
-        const int ntile = (p->npair + LEG_RINGS - 1) / LEG_RINGS;
+        const int ntile = (p->npair + LMIN_RINGS - 1) / LMIN_RINGS;
         HIP_TRY(hipMalloc((void **)&p->d_queue, 64));
         HIP_TRY(hipMalloc((void **)&p->d_mcut, sizeof(int32_t) * (size_t)p->nring));
         mcut_kernel<<<(p->npair + 63) / 64, 64, 0, s>>>(lmax, p->npair, p->nring, p->d_lstart, p->d_mcut);
@@ -1886,7 +1892,7 @@ extern "C" int corahip_alm2map(corahip_ctx *ctx, const corahip_sht_plan *p, cons
 extern "C" int corahip_map2alm_workspace_bytes(const corahip_sht_plan *p, int nnu, size_t *bytes) {
     ARG_CHECK(p != nullptr && bytes != nullptr && nnu >= 1);
     const size_t G = nnu_pad_of(nnu) / 4;
-    const int ntile = (p->npair + 64 * LEG_WAVES - 1) / (64 * LEG_WAVES);
+    const int ntile = (p->npair + 64 * ADJ_WAVES - 1) / (64 * ADJ_WAVES);
     *bytes = (size_t)p->nring * G * p->L * 8 * sizeof(double)            // G_m cells (the `inter` layout)
              + (size_t)ntile * p->nalm * G * 8 * sizeof(double);         // per-ring-tile partial a_lm
     return 0;
@@ -1895,10 +1901,10 @@ extern "C" int corahip_map2alm_workspace_bytes(const corahip_sht_plan *p, int nn
 template <int NCT>
 static int launch_legendre_adj(corahip_ctx *ctx, const corahip_sht_plan *p, int ncols, const double *inter,
                                double *part) {
-    const size_t shm = sizeof(double) * (size_t)LEG_WAVES * 64 * 33 + 16;
+    const size_t shm = sizeof(double) * (size_t)ADJ_WAVES * 64 * 33 + 16;
     HIP_TRY(hipFuncSetAttribute((const void *)legendre_adj_kernel<NCT>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)shm));
-    const int ntile = (p->npair + 64 * LEG_WAVES - 1) / (64 * LEG_WAVES);
+    const int ntile = (p->npair + 64 * ADJ_WAVES - 1) / (64 * ADJ_WAVES);
     const long nitems = (long)p->L * (ncols / (16 * NCT)) * ntile;
     dim3 grid((unsigned)std::min<long>(nitems, (long)ctx->num_cu));
     HIP_TRY(hipMemsetAsync(p->d_queue, 0, 64, ctx->stream));
@@ -1956,7 +1962,7 @@ extern "C" int corahip_map2alm(corahip_ctx *ctx, const corahip_sht_plan *p, cons
         if (nt16 % 2 == 0) rc = launch_legendre_adj<2>(ctx, p, ncols, inter, part);
         else rc = launch_legendre_adj<1>(ctx, p, ncols, inter, part);
         if (rc) return rc;
-        const int ntile = (p->npair + 64 * LEG_WAVES - 1) / (64 * LEG_WAVES);
+        const int ntile = (p->npair + 64 * ADJ_WAVES - 1) / (64 * ADJ_WAVES);
         const long n = p->nalm * (long)ncols;
         alm_reduce_kernel<<<(int)std::min<long>((n + 255) / 256, 8192), 256, 0, ctx->stream>>>(part, n, ntile, alm_dev);
         LAUNCH_CHECK();
