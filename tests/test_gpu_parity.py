@@ -918,3 +918,30 @@ def test_config5_geometry_synthesis_properties(ctx):
     assert abs(lam[0] - math.exp(lg)) < 1e-9 * math.exp(lg)       # z = 0: sin theta = 1; (-1)^4096 = +1
     del a, b, ma, mb, mc
     torch.cuda.empty_cache()
+
+
+def test_c_abi_with_ctypes_only_no_torch(tmp_path, golden):
+    """The drop-in boundary on its own: tools/abi_ctypes_demo.py drives libcorahip.so with ctypes + numpy in a
+    process that never imports torch (the binding INTEGRATION.md shows), and its seeded maps / a_lm equal the
+    reference's own a_lm (golden) and the oracle synthesis; the analysis entry point inverts the maps."""
+    import os
+    import subprocess
+    import sys
+
+    from oracle import sht
+    from oracle import skysim as osk
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / "abi.npz")
+    p = subprocess.run([sys.executable, os.path.join(root, "tools", "abi_ctypes_demo.py"), "cla_21cm_F8_l64_zromb3", "32",
+                        "4", out], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and "ABI_DEMO ok" in p.stdout and p.stdout.strip().endswith("False"), p.stdout + p.stderr
+    r = np.load(out)
+    ref_alm = golden["alm_21cm_F8_l64_seed4"]                       # the reference's own mkfullsky(alms=True, rng=default_rng(4))
+    assert np.abs(r["alm"] - ref_alm).max() <= 1e-12 * np.abs(ref_alm).max()
+    for i in (0, 5):
+        m = sht.alm2map(osk.pack_alm(ref_alm[i, 0]), 32, 64)
+        assert np.abs(r["maps"][i] - m).max() <= 1e-11 * m.std()
+        a1 = sht.map2alm_adjoint(r["maps"][i], 32, 64, None)
+        got = osk.pack_alm(r["rec"][i, 0])
+        assert np.abs(got - a1).max() <= 1e-12 * np.abs(a1).max()
