@@ -51,6 +51,7 @@ struct corahip_sht_plan {
     struct ring_class {
         int P = 0;        // Bluestein length, 0 = direct power-of-two transform
         int nch = 4;      // channels transformed together per workgroup
+        int threads = 0;  // workgroup size (0: K5_THREADS)
         int bstride = 0;  // complex elements per channel buffer in LDS
         int count = 0;
         int32_t *d_list = nullptr;
@@ -1692,6 +1693,8 @@ int corahip_sht_plan_create(corahip_ctx *ctx, int nside, int lmax, corahip_sht_p
                 corahip_set_error("nside %d: ring FFT of length %d does not fit in LDS", nside, c.bstride);
                 return CORAHIP_ENOMEM;
             }
+            // (measured and rejected for the P = 4096 class: one channel per 4-wave workgroup, two workgroups per CU,
+            //  so that LDS and FP64 phases of different workgroups overlap: 12.8 -> 13.6 ms, the cells are read 4x)
             c.count = (int)kv.second.size();
             if ((rc = dev_upload(&c.d_list, kv.second, s))) return rc;
             p->classes.push_back(c);
@@ -1776,7 +1779,6 @@ static int alm2map_chunk(corahip_ctx *ctx, const corahip_sht_plan *p, const doub
     {
         StageTimer t(ctx, "ringfft");
         const int G = nnu_chunk_pad / 4;
-        const int k5_threads = K5_THREADS;
         static const bool class_times = getenv("CORAHIP_K5_TIMES") != nullptr;   // diagnostics: per-class ms on stderr
         for (const auto &c : p->classes) {
             hipEvent_t ce0 = nullptr, ce1 = nullptr;
@@ -1788,6 +1790,7 @@ static int alm2map_chunk(corahip_ctx *ctx, const corahip_sht_plan *p, const doub
             const size_t shm = sizeof(double2) * ((size_t)c.nch * c.bstride + TWL_ENTRIES(p->pmax));
             const long nitems = (long)c.count * ((nnu_valid + c.nch - 1) / c.nch);
             const int per_cu = std::max<int>(1, (int)((160 * 1024) / std::max<size_t>(shm, 1)));
+            const int k5_threads = c.threads ? c.threads : K5_THREADS;
             dim3 grid((unsigned)std::min<long>(nitems, (long)ctx->num_cu * std::min(per_cu, 4)));
 #define RINGFFT_LAUNCH(NCH, BLU)                                                                                     \
     HIP_TRY(hipFuncSetAttribute((const void *)ringfft_kernel<NCH, BLU>, hipFuncAttributeMaxDynamicSharedMemorySize,  \
