@@ -977,7 +977,7 @@ ringfft_kernel(const int32_t *__restrict__ ring_list, int nlist, int nside, int 
     };
 
 #if K5_STAMPS
-    unsigned long long k5_last, t_zero = 0, t_fold = 0, t_z = 0, t_fft = 0, t_out = 0, t_pre = 0;
+    unsigned long long k5_last, t_zero = 0, t_fold = 0, t_z = 0, t_fft = 0, t_out = 0, t_pre = 0, t_mid = 0, t_dit = 0;
     { unsigned long long _t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)::"memory"); k5_last = _t; }
 #endif
     int item = blockIdx.x;
@@ -996,15 +996,17 @@ ringfft_kernel(const int32_t *__restrict__ ring_list, int nlist, int nside, int 
         const int flen = P ? P : h + 1;
         const int Lr = mcut[ring];
 
-        const bool noalias = lmax <= h;
+        // every m present is <= h (polar rings: mcut(ring) << lmax): each bin gets at most one contribution, so the
+        // fold is a plain store, and only the bins behind the last cell need zeroing
+        const bool noalias = Lr - 1 <= h;
         const bool need_zero = !(noalias && Lr == h + 1 && P == 0);  // direct ring whose bins 0..h are all written
         K5STAMP(t_pre);
         __syncthreads();  // previous item's LDS reads are done
         if (need_zero) {
-            for (int j = tid; j < fpad(flen); j += nt)
+            for (int j = (noalias ? fpad(Lr) : 0) + tid; j < fpad(flen); j += nt)
 #pragma unroll
                 for (int c = 0; c < NCH; c++) sm[(size_t)c * bstride + j] = make_double2(0.0, 0.0);
-            __syncthreads();
+            if (!noalias) __syncthreads();   // (the stores of the fold and the zeroed tail are disjoint otherwise)
         }
 
         // ---- phase + alias fold onto bins 0..h of the Hermitian length-n spectrum X
@@ -1130,13 +1132,16 @@ ringfft_kernel(const int32_t *__restrict__ ring_list, int nlist, int nside, int 
 #endif
                 // >= 3 passes each way: the filter step and the final chirp/store are fused into the passes
                 const int rl = fft_dif_head<-1>(sm, bstride, NCH, P, tw, pmax);
+                K5STAMP(t_fft);      // stamps build: forward passes but the last
                 if (rl == 16) fft_mid_fused<16>(sm, bstride, NCH, P, f);
                 else if (rl == 8) fft_mid_fused<8>(sm, bstride, NCH, P, f);
                 else if (rl == 4) fft_mid_fused<4>(sm, bstride, NCH, P, f);
                 else fft_mid_fused<2>(sm, bstride, NCH, P, f);
+                K5STAMP(t_mid);      // last forward pass + filter + first inverse pass (registers)
                 fft_dit_middle<1>(sm, bstride, NCH, P, rl, tw, pmax);
+                K5STAMP(t_dit);      // middle inverse passes
                 fft_dit_last_out<1>(sm, bstride, NCH, P, tw, pmax, bch, invP, h, maps, npix, start, ch0, nnu);
-                K5STAMP(t_fft);
+                K5STAMP(t_out);      // last inverse pass + chirp + pixel stores
                 continue;
             }
 #if K5_ABLATE != 1
@@ -1170,6 +1175,8 @@ ringfft_kernel(const int32_t *__restrict__ ring_list, int nlist, int nside, int 
         atomicAdd(&g_k5_stamps[3], t_z);
         atomicAdd(&g_k5_stamps[4], t_fft);
         atomicAdd(&g_k5_stamps[5], t_out);
+        atomicAdd(&g_k5_stamps[6], t_mid);
+        atomicAdd(&g_k5_stamps[7], t_dit);
     }
 #endif
 }
@@ -1824,8 +1831,8 @@ static int alm2map_chunk(corahip_ctx *ctx, const corahip_sht_plan *p, const doub
                 unsigned long long hs[8];
                 HIP_TRY(hipStreamSynchronize(ctx->stream));
                 HIP_TRY(hipMemcpyFromSymbol(hs, HIP_SYMBOL(g_k5_stamps), sizeof(hs)));
-                fprintf(stderr, "K5 class P=%d nch=%d rings=%d: pre %llu zero %llu fold %llu z %llu fft %llu out %llu\n", c.P,
-                        c.nch, c.count, hs[0], hs[1], hs[2], hs[3], hs[4], hs[5]);
+                fprintf(stderr, "K5 class P=%d nch=%d rings=%d: pre %llu zero %llu fold %llu z %llu fft %llu out %llu mid %llu dit %llu\n", c.P,
+                        c.nch, c.count, hs[0], hs[1], hs[2], hs[3], hs[4], hs[5], hs[6], hs[7]);
                 unsigned long long z8[8] = {0};
                 HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_k5_stamps), z8, sizeof(z8)));
             }
