@@ -15,6 +15,9 @@
 
 #include <cstring>
 
+#ifndef CL_ABLATE
+#define CL_ABLATE 0  // diagnostic builds: 1 no table loads in the profile build, 2 interpolation for one multipole per thread only
+#endif
 #define CL_MAXZ 17  // zint <= 17 (zromb <= 4)
 
 #define CL_XS 512      // padded row length of the transposed tables (nkperp <= 511)
@@ -57,6 +60,8 @@ clarray21_kernel(const double *__restrict__ tt, int nkperp, int nkpar, double kp
     extern __shared__ __attribute__((aligned(16))) double sm[];
     double *prof = sm;                       // [zint][CL_XS + 2]
     double *lxcs_s = sm + zint * (CL_XS + 2);   // [zint]
+    double *par = lxcs_s + zint;                // [zint^2][8]: c0..c5, lxc of every sub-sample pair
+    int *ipar = reinterpret_cast<int *>(par + zint * zint * 8);   // [zint^2][4]: y0, first row, row count
     const int PS = CL_XS + 2;
     const int tid = threadIdx.x;
     const int i = pairs[blockIdx.x].x, j = pairs[blockIdx.x].y;
@@ -76,51 +81,73 @@ clarray21_kernel(const double *__restrict__ tt, int nkperp, int nkpar, double kp
     const double lx_lo = log10l[l_base] * xscale, lx_hi = log10l[l_end - 1] * xscale;
     const int kmax = (l_end - l_base + 255) / 256;  // multipoles per thread actually present
 
+    // ---- parameters of the zint^2 sub-sample pairs, computed ONCE per workgroup (one thread each) instead of by
+    //      every thread in front of every profile: the log10 / divisions were the largest part of the kernel
+    for (int t = tid; t < zint * zint; t += 256) {
+        const int a = t / zint, b = t - a * zint;
+        const int za = i * zint + a, zb = j * zint + b;
+        const double x1 = chi[za], x2 = chi[zb];
+        const double xc = 0.5 * (x1 + x2);
+        const double lxc = log10(xc * kperpmin) * xscale;
+        double yy = fabs(x2 - x1) * yscale;  // rpar / (pi / kparmax)
+        yy = yy < 0.0 ? 0.0 : (yy > uy ? uy : yy);
+        int y0 = (int)yy;
+        double wy = yy - (double)y0;
+        if (y0 + 1 > nkpar - 1) {  // stay in bounds where the reference reads past the table edge
+            y0 = nkpar - 2;
+            wy = 1.0;
+        }
+        const double W = w[a] * w[b] * pfd[za] * pfd[zb] / (xc * xc * M_PI);
+        const double cdd = W * bz[za] * bz[zb];
+        const double cdv = W * (fz[za] * bz[zb] + fz[zb] * bz[za]);
+        const double cvv = W * fz[za] * fz[zb];
+        double *pp = par + t * 8;
+        pp[0] = cdd * (1.0 - wy);
+        pp[1] = cdd * wy;
+        pp[2] = cdv * (1.0 - wy);
+        pp[3] = cdv * wy;
+        pp[4] = cvv * (1.0 - wy);
+        pp[5] = cvv * wy;
+        pp[6] = lxc;
+        double xhi = lx_hi - lxc, xlo = lx_lo - lxc;
+        xhi = xhi < 0.0 ? 0.0 : (xhi > ux ? ux : xhi);
+        xlo = xlo < 0.0 ? 0.0 : (xlo > ux ? ux : xlo);
+        ipar[t * 4 + 0] = y0;
+        ipar[t * 4 + 1] = (int)xlo;                       // first row needed
+        ipar[t * 4 + 2] = min((int)xhi + 2, nkperp);      // rows x0 .. nx-1 are needed
+    }
+    __syncthreads();
+
     for (int a = 0; a < zint; a++) {
-        const int za = i * zint + a;
-        const double x1 = chi[za];
         __syncthreads();
         // ---- profiles of the zint sub-sample pairs (a, b = 0..zint-1)
-        int nx_max = 0;
         for (int b = 0; b < zint; b++) {
-            const int zb = j * zint + b;
-            const double x2 = chi[zb];
-            const double xc = 0.5 * (x1 + x2);
-            const double lxc = log10(xc * kperpmin) * xscale;
-            double yy = fabs(x2 - x1) * yscale;  // rpar / (pi / kparmax)
-            yy = yy < 0.0 ? 0.0 : (yy > uy ? uy : yy);
-            int y0 = (int)yy;
-            double wy = yy - (double)y0;
-            if (y0 + 1 > nkpar - 1) {  // stay in bounds where the reference reads past the table edge
-                y0 = nkpar - 2;
-                wy = 1.0;
-            }
-            const double W = w[a] * w[b] * pfd[za] * pfd[zb] / (xc * xc * M_PI);
-            const double cdd = W * bz[za] * bz[zb];
-            const double cdv = W * (fz[za] * bz[zb] + fz[zb] * bz[za]);
-            const double cvv = W * fz[za] * fz[zb];
-            const double c0 = cdd * (1.0 - wy), c1 = cdd * wy, c2 = cdv * (1.0 - wy), c3 = cdv * wy;
-            const double c4 = cvv * (1.0 - wy), c5 = cvv * wy;
-            double xhi = lx_hi - lxc, xlo = lx_lo - lxc;
-            xhi = xhi < 0.0 ? 0.0 : (xhi > ux ? ux : xhi);
-            xlo = xlo < 0.0 ? 0.0 : (xlo > ux ? ux : xlo);
-            const int nx = min((int)xhi + 2, nkperp);  // rows x0 .. nx-1 are needed
-            const int x0r = (int)xlo;
-            nx_max = max(nx_max, nx);
+            const int t = a * zint + b;
+            const double *pp = par + t * 8;
+            const double c0 = pp[0], c1 = pp[1], c2 = pp[2], c3 = pp[3], c4 = pp[4], c5 = pp[5];
+            const int y0 = ipar[t * 4 + 0], x0r = ipar[t * 4 + 1], nx = ipar[t * 4 + 2];
             const double *r0 = tt + (size_t)y0 * CL_XS, *r1 = r0 + CL_XS;
             double *pb = prof + b * PS;
+#if CL_ABLATE == 1   // diagnostic: no table loads
+            for (int x = x0r + tid; x < nx; x += 256) pb[x] = c0 + c1 * x;
+            (void)r0; (void)r1; (void)c2; (void)c3; (void)c4; (void)c5;
+#else
             for (int x = x0r + tid; x < nx; x += 256)
                 pb[x] = c0 * r0[x] + c1 * r1[x] + c2 * r0[tsz + x] + c3 * r1[tsz + x] + c4 * r0[2 * tsz + x] +
                         c5 * r1[2 * tsz + x];
+#endif
             if (tid == 0) {
                 pb[nkperp] = 0.0;  // x1 = x0 + 1 is clamped to the last row below; slot kept finite
-                lxcs_s[b] = lxc;
+                lxcs_s[b] = pp[6];
             }
         }
         __syncthreads();
         // ---- 1-D interpolation for this thread's multipoles
 #pragma unroll
         for (int k = 0; k < CL_LPT; k++) {
+#if CL_ABLATE == 2   // diagnostic: no interpolation phase
+            if (k >= 1) break;
+#endif
             if (k >= kmax) break;  // uniform: l-sharded callers pass short l ranges
             double s = 0.0;
             for (int b = 0; b < zint; b++) {
@@ -286,7 +313,7 @@ static int clarray21_pairs(corahip_ctx *ctx, const double *dd, const double *dv,
     }
     const double xscale = (double)(nkperp - 1) / log10(kperpmax / kperpmin);
     const double yscale = kparmax / M_PI;
-    const size_t shm = sizeof(double) * ((size_t)zint * (CL_XS + 2) + zint);
+    const size_t shm = sizeof(double) * ((size_t)zint * (CL_XS + 2) + zint + (size_t)zint * zint * 10);
     HIP_TRY(hipFuncSetAttribute((const void *)clarray21_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
     for (int l_base = 0; l_base < nl; l_base += 256 * CL_LPT) {
         clarray21_kernel<<<(unsigned)npl_pad, 256, shm, ctx->stream>>>(tt, nkperp, nkpar, kperpmin, xscale, yscale, chi, pfd,
