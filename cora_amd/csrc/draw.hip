@@ -154,6 +154,9 @@ __global__ void normals_kernel(uint64_t seed, int lmax, int F, double *__restric
 // ------------------------------------------------------------------------------------
 // K3: per-l GEMM on FP64 MFMA
 // ------------------------------------------------------------------------------------
+#ifndef DRAW_ABLATE
+#define DRAW_ABLATE 0  // diagnostic builds of the fused-RNG kernel: 1 no RNG, 2 no MFMA, 3 no a_lm stores, 4 no staging of T
+#endif
 #define DRAW_KC 32   // nu' per LDS stage
 #define DRAW_ROWS 64 // (c,m) rows per block (4 waves x 16)
 
@@ -275,15 +278,18 @@ draw_rng_kernel(const double *__restrict__ T, size_t t_ldl, int t_row0, const in
     // (applied on the DMA source address), so that 16 rows read at the same k hit 16 distinct slots
     extern __shared__ __attribute__((aligned(16))) double lds[];  // [2][NC][ROWD]
 
+    // workgroup = 64 values of m x (re, im): waves 0,1 draw the real parts, waves 2,3 the imaginary parts of the
+    // SAME m, so that both halves of every 64-byte a_lm cell ([re x4 | im x4]) are written by one workgroup within
+    // a short time and merge in L2 (with re and im in different workgroups every cell reached HBM as two 32-byte
+    // partial writes: the kernel was bound by that, not by the RNG or the MFMAs - make DRAW_ABLATE builds)
     const int l = blockIdx.x;
     const int lp1 = l + 1;
-    const int nmb = (lp1 + 127) / 128;          // 128-row blocks per c
-    const int c_of = blockIdx.y / nmb, mb = blockIdx.y % nmb;
-    if (c_of > 1) return;
+    const int mb = blockIdx.y;
     const int col0 = blockIdx.z * NC;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c_of = wave >> 1;
     const int ri = lane & 15, kq = lane >> 4;
-    const int m0 = mb * 128 + wave * 32;        // first m of this wave
+    const int m0 = mb * 64 + (wave & 1) * 32;   // first m of this wave
     const int mpair = (m0 >> 1) + ri;           // this lane's m-pair: rows m = 2 mpair, 2 mpair + 1
     const bool pair_ok = 2 * mpair < lp1;
 
@@ -317,7 +323,11 @@ draw_rng_kernel(const double *__restrict__ T, size_t t_ldl, int t_row0, const in
             const int k = k0 + 2 * slot_src;
             const double *src = zeros;  // F is even on this path (host wrapper), so k + 1 < F whenever k < F
             if (col0 + n < nnu && nu < F && k + 1 < F) src = Tl + (size_t)nu * F + k;
+#if DRAW_ABLATE != 4   // diagnostic 4: no staging of T
             draw_glds16(src, lds_base + (unsigned)(((c & 1) * BUF + 4 * rq * ROWD) * sizeof(double)));
+#else
+            (void)src;
+#endif
         }
     };
     (void)full_k;
@@ -336,15 +346,23 @@ draw_rng_kernel(const double *__restrict__ T, size_t t_ldl, int t_row0, const in
             if (kbase >= kmax) break;
             const int kp = kbase + kq;
             double2 a = make_double2(0.0, 0.0);
+#if DRAW_ABLATE == 1   // diagnostic: no RNG
+            if (pair_ok && kp < F) a = make_double2(1.0 + kp, 0.5 * mpair);
+#else
             if (pair_ok && kp < F) a = philox_normal_pair(seed, l, F, c_of, kp, mpair);
+#endif
             const int kl = 4 * kk + kq;          // k within the chunk
 #pragma unroll
             for (int t = 0; t < NCT; t++) {
                 if (!dense && kbase > nu0 + col0 + 16 * t + 15) continue;
                 const int n = 16 * t + ri;
                 const double b = sb[n * ROWD + 2 * ((kl >> 1) ^ (n & 15)) + (kl & 1)];
+#if DRAW_ABLATE == 2   // diagnostic: no MFMA
+                asm volatile("" ::"v"(a.x), "v"(a.y), "v"(b));
+#else
                 acc0[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, b, acc0[t], 0, 0, 0);
                 acc1[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, b, acc1[t], 0, 0, 0);
+#endif
             }
         }
     }
@@ -363,6 +381,9 @@ draw_rng_kernel(const double *__restrict__ T, size_t t_ldl, int t_row0, const in
                 const int m = m0 + 2 * i + par;
                 if (m < lp1) {
                     const long idx = (long)m * (2 * lmax + 1 - m) / 2 + l;
+#if DRAW_ABLATE == 3   // diagnostic: no a_lm stores
+                    if (acc0[t][r] == 1.2345e300)
+#endif
                     alm[((size_t)idx * Gout + (col >> 2)) * 8 + c_of * 4 + (col & 3)] =
                         (par ? acc1[t][r] : acc0[t][r]) * sc;
                 }
@@ -382,7 +403,7 @@ static int launch_draw_rng(corahip_ctx *ctx, const double *T, size_t t_ldl, int 
     int rc = corahip_ctx_scratch(ctx, 3, 4096, (void **)&zeros);
     if (rc) return rc;
     HIP_TRY(hipMemsetAsync(zeros, 0, 4096, ctx->stream));
-    dim3 grid(lmax + 1, 2 * ((lmax + 1 + 127) / 128), (4 * Gout + NC - 1) / NC);
+    dim3 grid(lmax + 1, (lmax + 1 + 63) / 64, (4 * Gout + NC - 1) / NC);
     draw_rng_kernel<NCT><<<grid, 256, shm, ctx->stream>>>(T, t_ldl, t_row0, info, zeros, seed, lmax, F, nu0, nnu, Gout,
                                                           alm);
     LAUNCH_CHECK();
