@@ -143,7 +143,7 @@ def main():
         def run_k1_pairs(first, step):
             # this rank's channel pairs at ALL multipoles, laid out as one slab per destination rank
             return ctx.clarray_table21cm_pairs(*tabs, k1_in[0], k1_in[1], k1_in[2], k1_in[3], F, zint, w, lx,
-                                               first, step, sp.l_shard)
+                                               first, step, sp.l_shard, nblocks=step)
     else:
         al, bcov = plan["prepare"](larr.copy(), za)
         al_d, bcov_d = ctx.to_device(al[l_lo:l_hi]), ctx.to_device(bcov)

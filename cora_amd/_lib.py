@@ -188,12 +188,16 @@ class Context:
         return out
 
     def clarray_table21cm_pairs(self, dd, dv, vv, kperpmin, kperpmax, kparmax, chi, pfd, f, b, F, zint, w, log10l,
-                                pair_first, pair_step, l_block):
-        """Pair shard of the integration: [ceil(nl / l_block), npl, l_block] slabs (see include/corahip.h)."""
+                                pair_first, pair_step, l_block, nblocks=None):
+        """Pair shard of the integration: [nblocks >= ceil(nl / l_block), npl, l_block] slabs (see
+        include/corahip.h); nblocks = number of ranks when the slabs feed an all-to-all."""
         torch = _torch()
         nl = log10l.numel()
         npl = (F * (F + 1) // 2 + pair_step - 1) // pair_step
         nblk = (nl + l_block - 1) // l_block
+        if nblocks is not None:
+            assert nblocks >= nblk
+            nblk = nblocks
         out = torch.zeros((nblk, npl, l_block), dtype=torch.float64, device=self.device)
         nkperp, nkpar = dd.shape
         _check(self.lib.corahip_clarray_table21cm_pairs(
