@@ -55,10 +55,30 @@ def nside_for_lmax(lmax, accuracy_boost=1):
     return int(2 ** (accuracy_boost + np.ceil(np.log((lmax + 1) / 3.0) / np.log(2.0))))
 
 
+def _make_full_alm(alm_half, centered=False):
+    """a_lm for m >= 0 -> both signs of m, using a_{l,-m} = (-1)^m conj(a_lm) (cora/util/hputil.py:155-174).
+    Output [..., l, 2 mmax - 1]: FFT order (m >= 0 first, then m = -(mmax-1)..-1) or, ``centered``, m ascending."""
+    lmax, mmax = alm_half.shape[-2:]
+    alm = np.zeros(alm_half.shape[:-2] + (lmax, 2 * mmax - 1), dtype=alm_half.dtype)
+    neg = ((-1) ** np.arange(mmax)[:0:-1]) * alm_half[..., :, :0:-1].conj()
+    if not centered:
+        alm[..., :mmax] = alm_half
+        alm[..., mmax:] = neg
+    else:
+        alm[..., (mmax - 1):] = alm_half
+        alm[..., : (mmax - 1)] = neg
+    return alm
+
+
 def _make_half_alm(alm_full):
-    """[l, 2 lmax+1] (negative m in the second half) -> [l, m >= 0] (hputil.py:181-192)."""
+    """[l, 2 lside - 1] (FFT order in m) -> the m >= 0 coefficients of its REAL part: the projection
+    (a_lm + (-1)^m conj(a_{l,-m})) / 2 (cora/util/hputil.py:177-192)."""
     lside = alm_full.shape[-2]
-    return alm_full[..., :lside]
+    alm = np.zeros(alm_full.shape[:-2] + (lside, lside), dtype=alm_full.dtype)
+    alm[..., 0] = alm_full[..., :, 0]
+    for mi in range(1, lside):
+        alm[..., mi] = 0.5 * (alm_full[..., mi] + (-1) ** mi * alm_full[..., -mi].conj())
+    return alm
 
 
 def unpack_alm(alm, lmax, fullm=False):
@@ -213,6 +233,34 @@ def sphtrans_sky(skymap, lmax=None):
     flat = skymap.reshape(-1, skymap.shape[-1]).astype(np.float64)
     alm = _analyse(flat, lmax)
     return alm.reshape(skymap.shape[:-1] + (lmax + 1, lmax + 1))
+
+
+def sphtrans_complex(hpmap, lmax=None, centered=False, lside=None):
+    """Spherical harmonic transform of a complex map: a_lm for both signs of m (cora/util/hputil.py:237-263)."""
+    hpmap = np.asarray(hpmap)
+    if lmax is None:
+        lmax = 3 * int(round(np.sqrt(hpmap.size / 12.0))) - 1
+    both = _analyse(np.stack([hpmap.real, hpmap.imag]), lmax)
+    if lside is not None and lside > lmax:
+        pad = np.zeros((2, lside + 1, lside + 1), dtype=np.complex128)
+        pad[:, : lmax + 1, : lmax + 1] = both
+        both = pad
+    return _make_full_alm(both[0], centered=centered) + 1.0j * _make_full_alm(both[1], centered=centered)
+
+
+def sphtrans_inv_complex(alm, nside):
+    """Inverse transform onto a complex field from a_lm with both signs of m (cora/util/hputil.py:435-457).
+
+    Mirrors the reference formula exactly, including its sign: the imaginary part is built from
+    ``1j * (a - a_real)`` = minus the coefficients of Im f, so the result is the complex CONJUGATE of the field
+    whose :func:`sphtrans_complex` is ``alm``; and all of a_l0 goes to the real part (m = 0 modes of Im f drop)."""
+    alm = np.asarray(alm)
+    if alm.shape[1] != (2 * alm.shape[0] - 1):
+        raise Exception("a_lm array wrong shape: " + repr(alm.shape))
+    almr = _make_half_alm(alm)
+    almi = 1.0j * (alm[:, : almr.shape[1]] - almr)
+    both = _synth(np.stack([almr, almi]), nside)
+    return both[0] + 1.0j * both[1]
 
 
 def sph_ps(map1, map2=None, lmax=None):

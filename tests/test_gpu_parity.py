@@ -945,3 +945,39 @@ def test_c_abi_with_ctypes_only_no_torch(tmp_path, golden):
         a1 = sht.map2alm_adjoint(r["maps"][i], 32, 64, None)
         got = osk.pack_alm(r["rec"][i, 0])
         assert np.abs(got - a1).max() <= 1e-12 * np.abs(a1).max()
+
+
+def test_complex_transform_family(ctx):
+    """hputil.sphtrans_inv_complex / sphtrans_complex (cora/util/hputil.py:237-263,435-457): a complex field from
+    a_lm with both signs of m equals the oracle synthesis of its real/imaginary projections, and transforms back."""
+    from cora_amd.util import hputil
+    from oracle import sht
+    from oracle import skysim as osk
+
+    nside, lmax = 16, 20
+    L = lmax + 1
+    rng = np.random.default_rng(12)
+    full = np.zeros((L, 2 * L - 1), dtype=np.complex128)
+    for l in range(L):
+        for m in range(-l, l + 1):
+            full[l, m] = rng.standard_normal() + 1j * rng.standard_normal()     # FFT order: negative m at the end
+    # the reference's split puts ALL of a_l0 into the "real" part and synthesises only Re(a_l0): the m = 0 modes
+    # of the imaginary part of the field are dropped (hputil.py:451-457) - mirrored, so keep a_l0 real here
+    full[:, 0] = full[:, 0].real
+    z = hputil.sphtrans_inv_complex(full, nside)
+    almr = hputil._make_half_alm(full)
+    almi = 1.0j * (full[:, :L] - almr)
+    ref = sht.alm2map(osk.pack_alm(almr), nside, lmax) + 1j * sht.alm2map(osk.pack_alm(almi), nside, lmax)
+    assert np.abs(z - ref).max() <= 1e-11 * np.abs(ref).max()
+    # hputil.py:455 builds the imaginary part as 1j * (a - a_real) = -s_lm (s = coefficients of Im f): the
+    # reference's inverse returns the CONJUGATE of the field whose forward transform is `full` - mirrored
+    back = hputil.sphtrans_complex(np.conj(z), lmax)
+    assert back.shape == (L, 2 * L - 1) and np.abs(back - full).max() < 1e-5 * np.abs(full).max()
+    back = hputil.sphtrans_complex(z, lmax)
+    cen = hputil.sphtrans_complex(z, lmax, centered=True)
+    assert np.allclose(cen[:, lmax:], back[:, :L]) and np.allclose(cen[:, :lmax], back[:, L:])
+    with pytest.raises(Exception, match="wrong shape"):
+        hputil.sphtrans_inv_complex(np.zeros((4, 4), dtype=np.complex128), nside)
+    # a real field has a_{l,-m} = (-1)^m conj(a_lm): _make_full_alm / _make_half_alm are inverse there
+    half = hputil.unpack_alm(osk.pack_alm(almr), lmax)
+    assert np.allclose(hputil._make_half_alm(hputil._make_full_alm(half)), half)
