@@ -174,7 +174,7 @@ __global__ void lambda_kernel(int lmax, int npair, int m, int r, const double *_
 #define LEG_ABLATE 0  // diagnostic builds only (make ablate): 1 no MFMA, 2 no recurrence, 3 no B reads, 4 no epilogue stores
 #endif
 #ifndef LEG_KT
-#define LEG_KT 32      // l rows per LDS stage
+#define LEG_KT 48      // l rows per LDS stage (32 rows x 4 buffers: 75.6 ms; 48 x 3: 74.1 ms; 48 x 2 and 56 x 2: 74.2 ms; 64 needs > 64 coefficient lanes)
 #endif
 #ifndef LEG_WAVES
 #define LEG_WAVES 8
@@ -182,7 +182,9 @@ __global__ void lambda_kernel(int lmax, int npair, int m, int r, const double *_
 #define LEG_RINGS (16 * LEG_WAVES)  // ring pairs per workgroup (x RT)
 #define LMIN_RINGS 128              // granularity of the plan's per-(m, ring block) first-l table
 #define ADJ_WAVES 8                 // waves per workgroup of the analysis kernel
-#define LEG_NBUF 4     // LDS stage ring: one being read + three in flight
+#ifndef LEG_NBUF
+#define LEG_NBUF 3     // LDS stage ring: one being read + two in flight
+#endif
 
 // LDS-DMA issued from inline asm: hipcc does not count it, so it does not drain the DMA with a
 // vmcnt(0) in front of every later ds_read (which it does for the builtin: the DMA is a pending LDS
@@ -350,8 +352,8 @@ legendre_kernel(int lmax, int npair, int nring, int ncols, const double *__restr
             for (int st = 0; st < w.nstage; st++) {
                 // own pieces of stage st have landed when at most the pieces of the (up to LEG_NBUF-2) younger
                 // stages are still in flight (anything younger than those only makes the wait stricter)
-                if (st + 2 < w.nstage) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PIECES) : "memory");
-                else if (st + 1 < w.nstage) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
+                if (LEG_NBUF >= 4 && st + 2 < w.nstage) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PIECES) : "memory");
+                else if (LEG_NBUF >= 3 && st + 1 < w.nstage) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();  // everyone's pieces of stage st landed; everyone is done reading stage st-1
                 const bool refill = st + LEG_NBUF - 1 < w.nstage;
