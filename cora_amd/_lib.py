@@ -58,6 +58,9 @@ SIGNATURES = {
     "corahip_alm2map": (c_int, [c_void_p, c_void_p, PTR, c_int, PTR, c_void_p, c_size_t]),
     "corahip_map2alm_workspace_bytes": (c_int, [c_void_p, c_int, ctypes.POINTER(c_size_t)]),
     "corahip_map2alm": (c_int, [c_void_p, c_void_p, PTR, c_int, PTR, PTR, c_void_p, c_size_t]),
+    "corahip_xi_table_average": (c_int, [c_void_p, PTR, PTR, PTR, c_int, c_int, c_double, c_double, PTR, c_int, PTR, PTR,
+                                         c_int, c_int, PTR]),
+    "corahip_legendre_project": (c_int, [c_void_p, PTR, PTR, c_int, c_int, PTR, ctypes.c_long, PTR]),
     "corahip_sht_plan_rings": (c_int, [c_void_p, PTR, PTR, PTR, PTR]),
     "corahip_sht_lambda": (c_int, [c_void_p, c_void_p, c_int, c_int, PTR]),
 }
@@ -365,6 +368,23 @@ class Context:
                 g0 = c0 // 4
                 gn = min(G8, G4 - g0)
                 out[:, g0:g0 + gn].copy_(part[:, :gn])
+        return out
+
+    # -- n3: xi(r) -> C_l --------------------------------------------------------------
+    def xi_table_average(self, kx, ky, ky2, kind, x_t, f_t, mu, xa, xw, F, xint):
+        nm = mu.numel()
+        out = self.empty((nm, F, F))
+        _check(self.lib.corahip_xi_table_average(self.h, self._f64(kx), self._f64(ky), self._f64(ky2), kx.numel(), kind,
+                                                 float(x_t), float(f_t), self._f64(mu), nm, self._f64(xa), self._f64(xw),
+                                                 F, xint, self._f64(out)))
+        return out
+
+    def legendre_project(self, mu, wt, lmax, xi):
+        nm = mu.numel()
+        ncol = xi.numel() // nm
+        out = self.empty((lmax + 1, ncol))
+        _check(self.lib.corahip_legendre_project(self.h, self._f64(mu), self._f64(wt), nm, lmax, self._f64(xi),
+                                                 ncol, self._f64(out)))
         return out
 
     def sht_rings(self, nside, lmax):

@@ -32,8 +32,10 @@ struct corahip_ctx {
     std::vector<corahip_pending_event> pending;
     int num_cu = 256;
     // grow-only device scratch slots owned by the context (freed by ctx_destroy)
-    void *scratch[4] = {nullptr, nullptr, nullptr, nullptr};
-    size_t scratch_bytes[4] = {0, 0, 0, 0};
+    // slots: 0 K1 transposed tables, 1 K1 pair results / odd-F normal stream, 2 K1 pair list, 3 zeros,
+    //        4 Legendre matrix of legendre_project, 5 its zero-padded operand
+    void *scratch[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    size_t scratch_bytes[6] = {0, 0, 0, 0, 0, 0};
     // K1 pair list resident in scratch slot 2: (F, first, step, slots, device pointer it was written to)
     long pairs_key[4] = {-1, -1, -1, -1};
     void *pairs_ptr = nullptr;

@@ -68,7 +68,7 @@ int corahip_ctx_destroy(corahip_ctx *ctx) {
     }
     (void)hipEventDestroy(ctx->t0);
     (void)hipEventDestroy(ctx->t1);
-    for (int i = 0; i < 4; i++)
+    for (int i = 0; i < 6; i++)
         if (ctx->scratch[i]) (void)hipFree(ctx->scratch[i]);
     delete ctx;
     return 0;

@@ -101,6 +101,11 @@ class Interpolater:
         out[inside] = (a * ys[lo] + b * ys[hi] + (a**3 - a) * h**2 / 6 * y2[lo] + (b**3 - b) * h**2 / 6 * y2[hi])
         return out
 
+    def _device_spline(self):
+        """(kind, knots x, y, y'', x_t, f_t) for the device evaluation of this interpolater
+        (``corahip_xi_table_average``; kind 0 = plain, 1 = log-log, 2 = sinh)."""
+        return 0, self._data[:, 0].copy(), self._data[:, 1].copy(), self._y2.copy(), 1.0, 1.0
+
     def test(self, min, max, samp):
         h = 1.0 * (max - min) / samp
         xs = min + h * np.arange(samp)
@@ -127,3 +132,30 @@ class LogInterpolater(Interpolater):
         """exp(spline(log x)) at every element of an array (cubicspline.pyx:273-288)."""
         x = np.asarray(x, dtype=np.float64)
         return np.exp(self._eval(np.log(np.ravel(x, order="C")))).reshape(x.shape)
+
+    def _device_spline(self):
+        return 1, self._data[:, 0].copy(), self._data[:, 1].copy(), self._y2.copy(), 1.0, 1.0
+
+
+class SinhInterpolater(Interpolater):
+    """Cubic spline in asinh-scaled space, ``f_t sinh(spline(asinh(x / x_t)))`` (cubicspline.pyx:290-345): log-like
+    for |values| above the thresholds, linear below, so zero and negative values are allowed."""
+
+    def __init__(self, data, x_t, f_t):
+        self.x_t = float(x_t)
+        self.f_t = float(f_t)
+        Interpolater.__init__(self, np.arcsinh(np.asarray(data, dtype=np.float64) / np.array([x_t, f_t], dtype=np.float64)))
+
+    def value(self, x):
+        scalar = not isinstance(x, np.ndarray)
+        r = self.f_t * np.sinh(self._eval(np.arcsinh(np.atleast_1d(np.asarray(x, dtype=np.float64)) / self.x_t)))
+        return float(r[0]) if scalar else r
+
+    __call__ = value
+
+    def value_sinh_array(self, x):
+        x = np.asarray(x, dtype=np.float64)
+        return (self.f_t * np.sinh(self._eval(np.arcsinh(np.ravel(x, order="C") / self.x_t)))).reshape(x.shape)
+
+    def _device_spline(self):
+        return 2, self._data[:, 0].copy(), self._data[:, 1].copy(), self._y2.copy(), self.x_t, self.f_t

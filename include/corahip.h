@@ -187,6 +187,23 @@ int corahip_map2alm_workspace_bytes(const corahip_sht_plan *plan, int nnu, size_
 int corahip_map2alm(corahip_ctx *ctx, const corahip_sht_plan *plan, const double *maps, int nnu,
                     const double *ring_w, double *alm_dev, void *workspace, size_t workspace_bytes);
 
+/* ---- xi(r) -> C_l(chi, chi') ----------------------------------------------
+ * Replaces corrfunc.corr_to_clarray (cora/signal/corrfunc.py:290-400).
+ * xi_table_average: for every Gauss-Legendre node mu_m and channel pair (i, j) the radial-bin average
+ *   sum_ab xw_a xw_b xi(r(mu_m, xa[i xint + a], xa[j xint + b])),  r^2 = (x - x')^2 + 2 x x' (1 - mu)
+ *   (corrfunc.py:368-381) of a correlation function given as a natural cubic spline with end-slope
+ *   extrapolation (cora/util/cubicspline.pyx:126-231): knots (x, y, y'') [nk];
+ *   kind 0: spline(r); 1: exp(spline(log r)) (LogInterpolater); 2: f_t sinh(spline(asinh(r / x_t)))
+ *   (SinhInterpolater).  out [nm, F, F].
+ * legendre_project: out[l, n] = sum_m wt[m] P_l(mu[m]) xi[m, n], l = 0..lmax (corrfunc.py:387-397, where
+ *   wt = w 4 pi / wsum); xi [nm, ncol], out [lmax+1, ncol]: Legendre matrix by recurrence + FP64 MFMA GEMM. */
+int corahip_xi_table_average(corahip_ctx *ctx, const double *knots_x, const double *knots_y,
+                             const double *knots_y2, int nk, int kind, double x_t, double f_t,
+                             const double *mu, int nm, const double *xa, const double *xw, int F, int xint,
+                             double *out);
+int corahip_legendre_project(corahip_ctx *ctx, const double *mu, const double *wt, int nm, int lmax,
+                             const double *xi, long ncol, double *out);
+
 /* ring geometry of the plan (host arrays of length 4 nside - 1), for tests */
 int corahip_sht_plan_rings(const corahip_sht_plan *plan, int64_t *host_start, int32_t *host_nphi,
                            double *host_z, double *host_phi0);

@@ -189,6 +189,9 @@ def main():
     g["spl_y2"] = sp.data()[1]
     lsp = cubicspline.LogInterpolater(np.dstack((xk + 0.5, np.exp(yk)))[0])
     g["lspl_ye"] = lsp(np.abs(xe) + 0.25)
+    # SinhInterpolater (cubicspline.pyx:290-345): data may be zero / negative; thresholds x_t, f_t
+    ssp = cubicspline.SinhInterpolater(np.dstack((xk, yk))[0], 0.7, 0.05)
+    g["sspl_ye"] = ssp(xe)
 
     # ---- 21cm model -------------------------------------------------------------
     cr = corr21cm.Corr21cm()

@@ -318,3 +318,16 @@ def test_cubicspline_array_entry_points():
     assert (q(pts) == 1).all() and (q.value_log_array(np.asarray([0.0125, 1, 2.5, 4, 5.55, 7.01, 19])) == 1).all()
     grid = np.linspace(1.2, 6.8, 12).reshape(3, 4)
     assert p.value_array(grid).shape == (3, 4) and np.array_equal(p.value_array(grid), p(grid.ravel()).reshape(3, 4))
+
+
+def test_sinh_interpolater_matches_reference(golden):
+    """cubicspline.SinhInterpolater (cubicspline.pyx:290-345) against the reference's compiled class, incl. the
+    extrapolated points on both sides and zero / negative data."""
+    from cora_amd.util import cubicspline as cs
+
+    sp = cs.SinhInterpolater(np.dstack((golden["spl_xk"], golden["spl_yk"]))[0], 0.7, 0.05)
+    got = sp(golden["spl_xe"])
+    assert np.abs(got - golden["sspl_ye"]).max() <= 1e-13 * np.abs(golden["sspl_ye"]).max()
+    assert abs(sp(3.3) - float(sp(np.array([3.3]))[0])) < 1e-15
+    kind, kx, ky, ky2, x_t, f_t = sp._device_spline()
+    assert kind == 2 and x_t == 0.7 and f_t == 0.05 and kx.shape == ky.shape == ky2.shape == (12,)

@@ -1,6 +1,8 @@
 """The CPU oracle against (a) outputs of the reference itself (tests/golden/reference_vectors.npz,
 made by tests/golden/make_golden.py), (b) the reference's own known-answer tests
 (tests/test_corr.py), (c) definition-level checks of the synthesis that stands in for healpy."""
+import os
+
 import numpy as np
 import pytest
 
@@ -333,3 +335,23 @@ def test_bilinear_interp_c_equals_numpy():
     ok = (xb < 36 - 1e-5) & (yb < 52 - 1e-5)
     b = models.bilinear_interp_numpy(tab, np.where(ok, xb, 0.0), np.where(ok, yb, 0.0))
     assert a.shape == (5, 4, 7) and np.array_equal(a[ok], b[ok])
+
+
+def _xi_model(r):
+    r = np.asarray(r, dtype=np.float64)
+    return np.exp(-r / 60.0) * np.cos(r / 35.0) / (1.0 + (r / 15.0) ** 2)
+
+
+def test_corr_to_clarray_oracle_matches_reference_vectors():
+    """oracle/corrfunc.py against outputs of the reference's own corr_to_clarray / legendre_array
+    (tests/golden/make_golden_corrfunc.py): Gauss-Legendre nodes, bin half-widths, xwidth, normalisation."""
+    from oracle import corrfunc as ocf
+
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "corrfunc_vectors.npz"))
+    assert np.abs(ocf.legendre_array(12, g["legendre_l12_mu"]) - g["legendre_l12"]).max() < 1e-14
+    xa = g["xarray"]
+    for tag, lmax, kw in (("l40_xromb2_q2", 40, dict(xromb=2, q=2)), ("l40_xromb0_q3", 40, dict(xromb=0, q=3)),
+                          ("l24_xromb1_xw10", 24, dict(xromb=1, q=2, xwidth=10.0))):
+        got = ocf.corr_to_clarray(_xi_model, lmax, xa, **kw)
+        ref = g["cl_" + tag]
+        assert got.shape == ref.shape and np.abs(got - ref).max() <= 1e-13 * np.abs(ref).max(), tag
