@@ -116,28 +116,43 @@ dgemm_nn_kernel(const double *__restrict__ A, int lda, const double *__restrict_
 #pragma unroll
         for (int v = 0; v < 4; v++) acc[u][v] = (d4_t){0.0, 0.0, 0.0, 0.0};
 
-    auto stage = [&](int kc, int buf) {
-        // A tile: 128 rows x 16 k = 2048 doubles, 8 per thread (row = e / 16, k = e % 16: 128-byte runs per row)
+    // global -> registers -> LDS, split so that the loads of chunk c+1 are in flight while chunk c is multiplied
+    double ra[GM_T * GM_K / 256], rb[GM_K * GM_T / 256];
+    auto gload = [&](int kc) {
 #pragma unroll
-        for (int e = tid; e < GM_T * GM_K; e += 256) {
-            const int r = e / GM_K, k = e % GM_K;
+        for (int u = 0; u < GM_T * GM_K / 256; u++) {
+            const int e = tid + 256 * u;
+            const int r = e / GM_K, k = e % GM_K;     // A tile: 128 rows x 16 k (128-byte runs per row)
             const int gr = row0 + r;
-            As[buf][r * AS + k] = gr < Mr ? A[(size_t)gr * lda + kc + k] : 0.0;
+            ra[u] = gr < Mr ? A[(size_t)gr * lda + kc + k] : 0.0;
         }
-        // B tile: 16 k x 128 cols (coalesced along the columns)
 #pragma unroll
-        for (int e = tid; e < GM_K * GM_T; e += 256) {
-            const int k = e / GM_T, c = e % GM_T;
+        for (int u = 0; u < GM_K * GM_T / 256; u++) {
+            const int e = tid + 256 * u;
+            const int k = e / GM_T, c = e % GM_T;     // B tile: 16 k x 128 columns (coalesced along the columns)
             const int gc = col0 + c;
-            Bs[buf][k * BS + c] = gc < N ? B[(size_t)(kc + k) * ldb + gc] : 0.0;
+            rb[u] = gc < N ? B[(size_t)(kc + k) * ldb + gc] : 0.0;
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < GM_T * GM_K / 256; u++) {
+            const int e = tid + 256 * u;
+            As[buf][(e / GM_K) * AS + e % GM_K] = ra[u];
+        }
+#pragma unroll
+        for (int u = 0; u < GM_K * GM_T / 256; u++) {
+            const int e = tid + 256 * u;
+            Bs[buf][(e / GM_T) * BS + e % GM_T] = rb[u];
         }
     };
     const int nchunk = K / GM_K;
-    stage(0, 0);
+    gload(0);
+    lstore(0);
     __syncthreads();
     for (int c = 0; c < nchunk; c++) {
         const int buf = c & 1;
-        if (c + 1 < nchunk) stage((c + 1) * GM_K, buf ^ 1);
+        if (c + 1 < nchunk) gload((c + 1) * GM_K);
         const double *as = As[buf], *bs = Bs[buf];
 #pragma unroll
         for (int ks = 0; ks < GM_K / 4; ks++) {
@@ -151,6 +166,7 @@ dgemm_nn_kernel(const double *__restrict__ A, int lda, const double *__restrict_
 #pragma unroll
                 for (int v = 0; v < 4; v++) acc[u][v] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[v], acc[u][v], 0, 0, 0);
         }
+        if (c + 1 < nchunk) lstore(buf ^ 1);   // the other buffer was last read before the previous barrier
         __syncthreads();
     }
     // C/D layout: column = lane & 15, row = (lane >> 4) + 4 r
