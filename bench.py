@@ -77,7 +77,6 @@ def main():
     import torch
 
     from cora_amd import _lib
-    from cora_amd.core import skysim
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -105,110 +104,35 @@ def main():
     L = lmax + 1
     nalm = L * (L + 1) // 2
     npix = 12 * nside * nside
-    from cora_amd.parallel import allgather_factors, exchange_factor_rows, exchange_pair_slabs, shard_plan
-
-    sp = shard_plan(L, F, rank, world)
-    if args.emulate_shard > 1:
-        # worst rank per stage: rank 0 has the widest table range in K1, the last rank the full RNG in K3
-        sp = shard_plan(L, F, args.emulate_shard - 1, args.emulate_shard)
-        sp0 = shard_plan(L, F, 0, args.emulate_shard)
-        sp.l_lo, sp.l_hi = sp0.l_lo, sp0.l_hi
-    nnu, nu0 = sp.nnu, sp.nu0
+    from cora_amd.parallel import SkyShard
 
     ctx = _lib.get_context(local_rank)
     model = build_model(model_name)
     freq = nu_lo + (np.arange(F) + 0.5) * ((nu_hi - nu_lo) / F)
 
-    # ---- untimed setup: everything the timed region reads is put in HBM ------------------
+    # ---- untimed setup: everything the timed region reads is put in HBM (tables, plan, buffers) ----------
     t_setup = time.time()
-    zint = 2**zromb + 1 if zromb else 1
-    zhalf = abs(freq[1] - freq[0]) / 2.0
-    za = (freq[:, None] + np.linspace(-zhalf, zhalf, zint)[None, :]).ravel() if zromb else freq.copy()
-    w = ctx.to_device(skysim.romberg_weights(zromb))
-    plan = model._clarray_plan(model.angular_powerspectrum)
-    # l-shard of K1/K2 (contiguous; shards are padded to equal length inside the all-gather)
-    l_lo, l_hi = sp.l_lo, sp.l_hi
-    larr = np.arange(L, dtype=np.float64)
-    pair_sharded = plan["kind"] == "table21cm" and (multi or args.emulate_shard > 1) and F % max(world, args.emulate_shard, 1) == 0
-    if plan["kind"] == "table21cm":
-        p = plan["prepare"](ctx, za)
-        lx_full = np.log10(np.where(larr == 0.0, 1e-10, larr))
-        lx = ctx.to_device(lx_full if pair_sharded else lx_full[l_lo:l_hi])
-        k1_in = [ctx.to_device(p[k]) for k in ("chi", "pfd", "f", "b")]
-        tabs = (p["dd"], p["dv"], p["vv"], p["kperpmin"], p["kperpmax"], p["kparmax"])
-
-        def run_k1():
-            return ctx.clarray_table21cm(*tabs, k1_in[0], k1_in[1], k1_in[2], k1_in[3], F, zint, w, lx)
-
-        def run_k1_pairs(first, step):
-            # this rank's channel pairs at ALL multipoles, laid out as one slab per destination rank
-            return ctx.clarray_table21cm_pairs(*tabs, k1_in[0], k1_in[1], k1_in[2], k1_in[3], F, zint, w, lx,
-                                               first, step, sp.l_shard, nblocks=step)
-    else:
-        al, bcov = plan["prepare"](larr.copy(), za)
-        al_d, bcov_d = ctx.to_device(al[l_lo:l_hi]), ctx.to_device(bcov)
-
-        def run_k1():
-            return ctx.clarray_separable(al_d, bcov_d, F, zint, w)
-
-    ctx.sht_plan(nside, lmax)
-    alm_buf = ctx.empty((nalm, (nnu + 3) // 4, 2, 4))
-    maps_buf = ctx.empty((nnu, npix))
-    ctx.workspace(ctx.alm2map_workspace_bytes(ctx.sht_plan(nside, lmax), nnu))
+    shard = SkyShard(model, freq, nside, lmax, zromb=zromb, rank=rank, world=world, ctx=ctx, distributed=multi,
+                     emulate_world=args.emulate_shard)
+    nnu, nu0 = shard.nnu, shard.nu0
+    maps_buf = shard.maps_buf
     torch.cuda.synchronize()
     t_setup = time.time() - t_setup
 
     seed_box = [1000]
-
-    def cold_factors():
-        if args.emulate_shard > 1:
-            # the work of one rank of an N-rank job, without the exchanges
-            N = args.emulate_shard
-            if pair_sharded:
-                slab = run_k1_pairs(N - 1, N)
-                C = ctx.clarray_pairs_finish(slab.new_zeros((N,) + tuple(slab.shape[1:])), F, sp.l_hi - sp.l_lo)
-            else:
-                C = run_k1()
-            ctx.factor_batched(C)
-            return cached_full["f"]
-        if not multi:
-            C = run_k1()
-            T, info = ctx.factor_batched(C)
-            return T, info, False
-        if pair_sharded:
-            mine = exchange_pair_slabs(run_k1_pairs(rank, world), sp)     # all-to-all #1 (67 MB per rank at cfg3)
-            C = ctx.clarray_pairs_finish(mine, F, sp.l_hi - sp.l_lo)
-            T, info = ctx.factor_batched(C)
-            Tr, ia = exchange_factor_rows(T, info, sp)                   # all-to-all #2 (row blocks)
-            return Tr, ia, True
-        C = run_k1()
-        T, info = ctx.factor_batched(C)
-        Ta, ia = allgather_factors(T, info, sp)
-        return Ta, ia, False
-
+    cold_factors = shard.factors
     cached = {}
-    cached_full = {}
-    if args.emulate_shard > 1:
-        Cf = ctx.empty((L, F, F)).normal_()
-        Cf = Cf @ Cf.transpose(1, 2) + 0.1 * torch.eye(F, device=ctx.device, dtype=torch.float64)
-        Tf, inf = ctx.factor_batched(Cf)
-        cached_full["f"] = (Tf[:, nu0:nu0 + nnu, :].contiguous(), inf, True) if pair_sharded else (Tf, inf, False)
-        del Cf, Tf
 
     def step():
         if args.warm:
             if "f" not in cached:
                 cached["f"] = cold_factors()
-            T, info, rows = cached["f"]
+            fac = cached["f"]
         else:
-            T, info, rows = cold_factors()
+            fac = cold_factors()     # K1 (+ all-to-all) -> K2 (+ all-to-all)
         seed_box[0] += 1
-        # device Philox normals are generated inside the draw kernel (no 8.6 GB normal buffer)
-        if rows:
-            ctx.draw_alm_philox_rows(T, info, seed_box[0], lmax, F, nu0, nnu, out=alm_buf)
-        else:
-            ctx.draw_alm_philox(T, info, seed_box[0], lmax, F, nu0=nu0, nnu=nnu, out=alm_buf)
-        ctx.alm2map(alm_buf, nside, lmax, nnu, out=maps_buf)
+        # K3 (device Philox normals generated inside the draw kernel: no 8.6 GB normal buffer) -> K4 -> K5
+        shard.realise(seed_box[0], fac)
 
     def barrier():
         if dist is not None:
@@ -241,11 +165,7 @@ def main():
         tw = time.time()
         for _ in range(nw):
             seed_box[0] += 1
-            if fac[2]:
-                ctx.draw_alm_philox_rows(fac[0], fac[1], seed_box[0], lmax, F, nu0, nnu, out=alm_buf)
-            else:
-                ctx.draw_alm_philox(fac[0], fac[1], seed_box[0], lmax, F, nu0=nu0, nnu=nnu, out=alm_buf)
-            ctx.alm2map(alm_buf, nside, lmax, nnu, out=maps_buf)
+            shard.realise(seed_box[0], fac)
         barrier()
         warm_ms = (time.time() - tw) / nw * 1e3
         del fac

@@ -108,3 +108,137 @@ def exchange_factor_rows(T_local, info_local, plan):
     i_all = torch.empty((plan.l_pad,), dtype=info_local.dtype, device=info_local.device)
     dist.all_gather_into_tensor(i_all, pad_i)
     return recv.view(plan.l_pad, plan.nnu, F)[: plan.L], i_all[: plan.L]
+
+
+class SkyShard:
+    """One rank's share of a Gaussian sky realisation (what ``Sky3d.getsky()`` does on one GPU, cora/core/maps.py:227-237,
+    cut over ``world`` GPUs as described at the top of this module).  Everything the realisation reads is put in HBM
+    by the constructor; ``factors()`` is the cold part (C_l integration, exchange, factorisation, exchange),
+    ``realise(seed)`` draws with the device Philox stream - identical on every rank - and synthesises this rank's
+    channels ``[nu0, nu0 + nnu)``.  The maps stay on the GPU (torch tensor ``[nnu, npix]``).
+
+    model : a ``cora_amd`` Gaussian model exposing ``_clarray_plan`` (Corr21cm, ForegroundSCK subclasses)
+    freq  : all F channel centres (MHz);  zromb : Romberg order of the channel average (``oversample``)
+    distributed : run the exchanges (default: world > 1);  emulate_world : measurement hook - do the work of the most
+        loaded rank of an ``emulate_world``-rank job on this GPU without any communication (K1: last pair shard,
+        K2: rank 0's multipoles, K3-K5: the last channel shard, factors replaced by a random SPD stack).
+    """
+
+    def __init__(self, model, freq, nside, lmax, zromb=3, rank=0, world=1, ctx=None, distributed=None, emulate_world=0):
+        import numpy as np
+
+        from . import _lib
+        from .core import skysim
+
+        self.ctx = ctx if ctx is not None else _lib.get_context()
+        ctx = self.ctx
+        self.freq = np.asarray(freq, dtype=np.float64)
+        self.F = F = self.freq.size
+        self.nside, self.lmax, self.L = int(nside), int(lmax), int(lmax) + 1
+        self.rank, self.world = rank, world
+        self.distributed = (world > 1) if distributed is None else bool(distributed)
+        self.emulate_world = int(emulate_world)
+        L = self.L
+        self.plan = shard_plan(L, F, rank, world)
+        if self.emulate_world > 1:
+            N = self.emulate_world
+            self.plan = shard_plan(L, F, N - 1, N)
+            p0 = shard_plan(L, F, 0, N)
+            self.plan.l_lo, self.plan.l_hi = p0.l_lo, p0.l_hi
+        sp = self.plan
+        self.nu0, self.nnu = sp.nu0, sp.nnu
+        self.zint = zint = 2**zromb + 1 if zromb else 1
+        zhalf = abs(self.freq[1] - self.freq[0]) / 2.0 if F > 1 else 0.0
+        za = (self.freq[:, None] + np.linspace(-zhalf, zhalf, zint)[None, :]).ravel() if zromb else self.freq.copy()
+        self.w = ctx.to_device(skysim.romberg_weights(zromb))
+        cplan = model._clarray_plan(model.angular_powerspectrum)
+        nshard = max(world, self.emulate_world, 1)
+        self.pair_sharded = (cplan["kind"] == "table21cm" and (self.distributed or self.emulate_world > 1)
+                             and F % nshard == 0)
+        larr = np.arange(L, dtype=np.float64)
+        if cplan["kind"] == "table21cm":
+            p = cplan["prepare"](ctx, za)
+            lx_full = np.log10(np.where(larr == 0.0, 1e-10, larr))
+            self._lx = ctx.to_device(lx_full if self.pair_sharded else lx_full[sp.l_lo:sp.l_hi])
+            self._k1 = [ctx.to_device(p[k]) for k in ("chi", "pfd", "f", "b")]
+            self._tabs = (p["dd"], p["dv"], p["vv"], p["kperpmin"], p["kperpmax"], p["kparmax"])
+            self._sep = None
+        else:
+            al, bcov = cplan["prepare"](larr.copy(), za)
+            self._sep = (ctx.to_device(al[sp.l_lo:sp.l_hi]), ctx.to_device(bcov))
+        nalm = L * (L + 1) // 2
+        self.npix = 12 * self.nside * self.nside
+        ctx.sht_plan(self.nside, self.lmax)
+        self.alm_buf = ctx.empty((nalm, (self.nnu + 3) // 4, 2, 4))
+        self.maps_buf = ctx.empty((self.nnu, self.npix))
+        ctx.workspace(ctx.alm2map_workspace_bytes(ctx.sht_plan(self.nside, self.lmax), self.nnu))
+        self._emulated = None
+        if self.emulate_world > 1:
+            import torch
+
+            Cf = ctx.empty((L, F, F)).normal_()
+            Cf = Cf @ Cf.transpose(1, 2) + 0.1 * torch.eye(F, device=ctx.device, dtype=torch.float64)
+            Tf, inf = ctx.factor_batched(Cf)
+            self._emulated = ((Tf[:, self.nu0:self.nu0 + self.nnu, :].contiguous(), inf, True) if self.pair_sharded
+                              else (Tf, inf, False))
+
+    # -- K1 in its two shardings -----------------------------------------------------------
+    def _clarray_local(self):
+        ctx = self.ctx
+        if self._sep is not None:
+            return ctx.clarray_separable(self._sep[0], self._sep[1], self.F, self.zint, self.w)
+        return ctx.clarray_table21cm(*self._tabs, *self._k1, self.F, self.zint, self.w, self._lx)
+
+    def _clarray_pairs(self, first, step):
+        return self.ctx.clarray_table21cm_pairs(*self._tabs, *self._k1, self.F, self.zint, self.w, self._lx, first, step,
+                                                self.plan.l_shard, nblocks=step)
+
+    def factors(self):
+        """(T, info, rows): the factors this rank's draw needs; ``rows`` tells whether T holds only the rank's row
+        blocks ``[L, nnu, F]`` (pair-sharded path) or the full ``[L, F, F]`` stack."""
+        ctx, sp = self.ctx, self.plan
+        if self.emulate_world > 1:
+            N = self.emulate_world
+            if self.pair_sharded:
+                slab = self._clarray_pairs(N - 1, N)
+                C = ctx.clarray_pairs_finish(slab.new_zeros((N,) + tuple(slab.shape[1:])), self.F, sp.l_hi - sp.l_lo)
+            else:
+                C = self._clarray_local()
+            ctx.factor_batched(C)
+            return self._emulated
+        if not self.distributed:
+            T, info = ctx.factor_batched(self._clarray_local())
+            return T, info, False
+        if self.pair_sharded:
+            mine = exchange_pair_slabs(self._clarray_pairs(self.rank, self.world), sp)   # all-to-all #1
+            T, info = ctx.factor_batched(ctx.clarray_pairs_finish(mine, self.F, sp.l_hi - sp.l_lo))
+            Tr, ia = exchange_factor_rows(T, info, sp)                                     # all-to-all #2
+            return Tr, ia, True
+        T, info = ctx.factor_batched(self._clarray_local())
+        Ta, ia = allgather_factors(T, info, sp)
+        return Ta, ia, False
+
+    def realise(self, seed, factors=None):
+        """Maps ``[nnu, npix]`` (device tensor, reused between calls) of this rank's channels for ``seed``."""
+        ctx = self.ctx
+        T, info, rows = factors if factors is not None else self.factors()
+        if rows:
+            ctx.draw_alm_philox_rows(T, info, seed, self.lmax, self.F, self.nu0, self.nnu, out=self.alm_buf)
+        else:
+            ctx.draw_alm_philox(T, info, seed, self.lmax, self.F, nu0=self.nu0, nnu=self.nnu, out=self.alm_buf)
+        return ctx.alm2map(self.alm_buf, self.nside, self.lmax, self.nnu, out=self.maps_buf)
+
+
+def getsky_shard(sky, seed, rank=0, world=1, lmax=None):
+    """``Sky3d.getsky()`` for one rank of ``world`` GPUs: (maps [nnu, npix] device tensor, nu0) for a cora_amd
+    Gaussian model instance ``sky`` (frequencies, nside, oversample taken from it; lmax default 3 nside - 1 as
+    maps.py:230).  The process group must be initialised when world > 1."""
+    lmax = 3 * sky.nside - 1 if lmax is None else lmax
+    zromb = getattr(sky, "oversample", 3)
+    import numpy as np
+
+    shard = SkyShard(sky, sky.nu_pixels, sky.nside, lmax, zromb=zromb if zromb is not None else 3, rank=rank, world=world)
+    maps = shard.realise(int(seed))
+    freq = np.asarray(sky.nu_pixels, dtype=np.float64)[shard.nu0:shard.nu0 + shard.nnu]
+    mean = shard.ctx.to_device(np.asarray(sky.mean_nu(freq), dtype=np.float64) * np.ones(shard.nnu))
+    return maps + mean[:, None], shard.nu0

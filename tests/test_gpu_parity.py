@@ -1029,3 +1029,19 @@ def test_corr_to_clarray_spline_tables_on_device(ctx):
     # the interpolaters themselves: array entry points agree with scalar calls, extrapolation on both sides
     pts = np.array([0.0, 0.05, 0.1, 3.3, 4000.0, 9000.0])
     assert np.allclose(sinh.value_sinh_array(pts), [sinh(float(p)) for p in pts], rtol=1e-14, atol=0)
+
+
+def test_getsky_shard_equals_sky3d_getsky():
+    """parallel.getsky_shard (the N-rank pipeline object, here 1 rank) == Sky3d.getsky with the same device seed,
+    including the mean-temperature offset (cora/core/maps.py:227-237)."""
+    from cora_amd import DeviceRNG
+    from cora_amd.parallel import getsky_shard
+    from cora_amd.signal import corr21cm
+
+    cr = corr21cm.Corr21cm()
+    cr.nside = 16
+    cr.frequencies = np.array([500.0, 510.0, 520.0, 530.0, 540.0, 550.0, 560.0, 570.0])
+    cr.oversample = 2
+    ref = cr.getsky(rng=DeviceRNG(77))
+    maps, nu0 = getsky_shard(cr, 77)
+    assert nu0 == 0 and np.array_equal(maps.cpu().numpy(), ref)
