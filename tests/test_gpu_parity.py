@@ -1045,3 +1045,26 @@ def test_getsky_shard_equals_sky3d_getsky():
     ref = cr.getsky(rng=DeviceRNG(77))
     maps, nu0 = getsky_shard(cr, 77)
     assert nu0 == 0 and np.array_equal(maps.cpu().numpy(), ref)
+
+
+def test_small_and_ragged_sizes_next_rows(ctx):
+    """Edge sizes of the n1 / n3 entry points: tiny lmax (mu nodes not a multiple of the GEMM's K chunk), two
+    distances, one channel; nside 1 and 2 analysis with channel counts that are not multiples of 4 or 8."""
+    import torch
+    from cora_amd.signal import corrfunc
+    from cora_amd.util import hputil
+    from oracle import corrfunc as ocf
+    from oracle import sht
+
+    for lmax, xa, xromb, q in ((3, [100.0, 130.0], 0, 2), (5, [50.0, 60.0, 75.0], 1, 3), (17, [10.0, 20.0], 2, 2)):
+        got = corrfunc.corr_to_clarray(_xi_model, lmax, np.array(xa), xromb=xromb, q=q)
+        ref = ocf.corr_to_clarray(_xi_model, lmax, np.array(xa), xromb=xromb, q=q)
+        assert got.shape == ref.shape and np.abs(got - ref).max() <= 1e-12 * np.abs(ref).max(), (lmax, xromb)
+    rng = np.random.default_rng(1)
+    for nside, lmax, nnu in ((1, 2, 1), (2, 4, 3), (2, 5, 9), (4, 8, 13)):
+        maps = rng.standard_normal((nnu, 12 * nside * nside))
+        alm = ctx.map2alm(torch.from_numpy(maps).to(ctx.device), nside, lmax, None)
+        got = ctx.alm_dev_to_square(alm, lmax, nnu).cpu().numpy()[:, 0]
+        for k in (0, nnu - 1):
+            ref = hputil.unpack_alm(sht.map2alm_adjoint(maps[k], nside, lmax, None), lmax)
+            assert np.abs(got[k] - ref).max() <= 1e-12 * max(np.abs(ref).max(), 1e-300), (nside, lmax, nnu, k)
