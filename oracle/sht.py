@@ -36,6 +36,8 @@ def _load():
         _lib.oracle_legendre_anal.restype = None
         _lib.oracle_lambda_lm.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_double, dp]
         _lib.oracle_lambda_lm.restype = None
+        _lib.oracle_legendre_synth_spin2.argtypes = [ctypes.c_int, ctypes.c_int] + [dp] * 8
+        _lib.oracle_legendre_synth_spin2.restype = None
         _lib.oracle_bilinear_interp.argtypes = [dp, ctypes.c_long, ctypes.c_long, dp, dp, ctypes.c_long, dp]
         _lib.oracle_bilinear_interp.restype = None
         _lib.oracle_num_threads.restype = ctypes.c_int
@@ -291,3 +293,55 @@ def map2alm_bruteforce(hpmap, nside, lmax, ring_w=None):
         for l in range(m, lmax + 1):
             alm[alm_index(l, m, lmax)] = np.sum(wpix * hpmap * np.conj(sph_harm_y(l, m, theta, phi)))
     return alm
+
+
+# ------------------------------------------------------------------------------------
+# polarisation (spin-2) synthesis: healpy.alm2map([T, E, B], nside) as hputil.sphtrans_inv_real_pol uses it
+# (cora/util/hputil.py:394-432) - "next" row n4 of SURVEY 8(f).  Convention and formulas: oracle/sht_ref.c.
+# ------------------------------------------------------------------------------------
+def alm2map_spin2(alm_e, alm_b, nside, lmax):
+    """Packed E and B coefficients -> (Q, U) RING maps."""
+    ri = healpix.ring_info(nside)
+    npair = 2 * nside
+    L = lmax + 1
+    z = np.ascontiguousarray(ri["z"][:npair])
+    sth = np.ascontiguousarray(ri["sth"][:npair])
+    ae = np.ascontiguousarray(alm_e, dtype=np.complex128).view(np.float64)
+    ab = np.ascontiguousarray(alm_b, dtype=np.complex128).view(np.float64)
+    outs = [np.zeros((npair, L), dtype=np.complex128) for _ in range(4)]
+    _load().oracle_legendre_synth_spin2(lmax, npair, _dp(z), _dp(sth), _dp(ae), _dp(ab),
+                                        *[_dp(o.view(np.float64)) for o in outs])
+    qn, qs, un, us = outs
+    return synth_from_fm(qn, qs, nside), synth_from_fm(un, us, nside)
+
+
+def spin2_wx(l, m, theta):
+    """(W_lm, X_lm)(theta) from the scalar lambda_lm via scipy (independent of the C recurrence)."""
+    from scipy.special import sph_harm_y
+
+    x, s2 = np.cos(theta), np.sin(theta) ** 2
+    lam = sph_harm_y(l, m, theta, 0.0).real
+    lam1 = sph_harm_y(l - 1, m, theta, 0.0).real if l - 1 >= m else 0.0 * lam
+    if l < 2:
+        return 0.0 * lam, 0.0 * lam
+    N2 = 2.0 / np.sqrt((l + 2.0) * (l + 1.0) * l * (l - 1.0))
+    c = np.sqrt((2.0 * l + 1.0) / (2.0 * l - 1.0) * (l - m) / (l + m)) if l + m > 0 else 0.0
+    W = N2 * (-((l - m * m) / s2 + l * (l - 1.0) / 2.0) * lam + (l + m) * x / s2 * c * lam1)
+    X = N2 * m / s2 * ((l - 1.0) * x * lam - (l + m) * c * lam1)
+    return W, X
+
+
+def alm2map_spin2_bruteforce(alm_e, alm_b, nside, lmax):
+    """Definition-level (Q, U): Q +- iU = - sum (E +- iB) (W -+ X) e^{i m phi} over all m (negative m by the
+    reality conditions a_{l,-m} = (-1)^m conj(a_lm), W_{l,-m} = (-1)^m W_lm, X_{l,-m} = -(-1)^m X_lm)."""
+    theta, phi = healpix.pix2ang_ring(nside)
+    qpu = np.zeros(theta.size, dtype=np.complex128)      # Q + iU
+    for m in range(0, lmax + 1):
+        for l in range(max(m, 2), lmax + 1):
+            W, X = spin2_wx(l, m, theta)
+            e, b = alm_e[alm_index(l, m, lmax)], alm_b[alm_index(l, m, lmax)]
+            ph = np.exp(1j * m * phi)
+            qpu += -(e + 1j * b) * (W - X) * ph
+            if m > 0:      # the -m term: (E + iB)_{l,-m} = (-1)^m (conj E + i conj B), (W - X)_{l,-m} = (-1)^m (W + X)
+                qpu += -(np.conj(e) + 1j * np.conj(b)) * (W + X) * np.conj(ph)
+    return qpu.real, qpu.imag

@@ -198,6 +198,102 @@ void oracle_lambda_lm(int lmax, int m, double x, double sthv, double *out)
     }
 }
 
+
+/* Spin-2 (polarisation) synthesis, Legendre part: what the reference obtains from healpy.alm2map([T, E, B], nside)
+ * for Q and U through hputil.sphtrans_inv_real_pol (cora/util/hputil.py:394-432).  Convention (Zaldarriaga & Seljak
+ * 1997, the "COSMO" convention HEALPix documents):  Q +- iU = - sum_lm (a^E_lm +- i a^B_lm) (+-2)Y_lm, with
+ *   (+2)Y_lm = (W_lm - X_lm) e^{i m phi},  (-2)Y_lm = (W_lm + X_lm) e^{i m phi},
+ *   W_lm = 2 N_l [ -((l - m^2)/sin^2 + l(l-1)/2) lambda_lm + (l+m) (cos/sin^2) c_lm lambda_{l-1,m} ],
+ *   X_lm = 2 N_l (m/sin^2) [ (l-1) cos lambda_lm - (l+m) c_lm lambda_{l-1,m} ],
+ *   N_l = 1/sqrt((l+2)(l+1)l(l-1)),  c_lm = sqrt((2l+1)/(2l-1) (l-m)/(l+m))
+ * (checked against the eth-operator definition of the spin-weighted harmonics in tests/test_oracle.py), so that
+ *   Q_m = - sum_l (E_lm W_lm - i B_lm X_lm),   U_m = - sum_l (B_lm W_lm + i E_lm X_lm).
+ * W has the parity (-1)^{l+m} of lambda under theta -> pi - theta, X the opposite one.
+ * alme, almb: packed healpy order, interleaved (re, im); outputs [npair][lmax+1][2] for Q and U on the north ring
+ * and on its mirror.  PARITY UNPINNED against healpy (absent). */
+void oracle_legendre_synth_spin2(int lmax, int npair, const double *z, const double *sth, const double *alme,
+                                 const double *almb, double *qn, double *qs, double *un, double *us)
+{
+    const int L = lmax + 1;
+    double *lp = (double *)malloc(sizeof(double) * L);
+    lp[0] = -0.5 * log2(4.0 * M_PI);
+    for (int m = 1; m < L; m++)
+        lp[m] = lp[m - 1] + 0.5 * log2((2.0 * m + 1.0) / (2.0 * m));
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int r = 0; r < npair; r++) {
+        const double x = z[r], s2 = sth[r] * sth[r];
+        const double l2s = log2(sth[r]);
+        double *A = (double *)malloc(sizeof(double) * (L + 1));
+        double *IA = (double *)malloc(sizeof(double) * (L + 1));
+        for (int m = 0; m < L; m++) {
+            const long base = (long)m * (2 * lmax + 1 - m) / 2;
+            const double *ae = alme + 2 * base, *ab = almb + 2 * base;
+            const double m2 = (double)m * m;
+            A[m] = 0.0; IA[m] = 0.0;
+            for (int l = m + 1; l < L; l++) {
+                double ll = l;
+                A[l] = sqrt((4.0 * ll * ll - 1.0) / (ll * ll - m2));
+                IA[l] = 1.0 / A[l];
+            }
+            double L2 = lp[m] + m * l2s;
+            int sc = (int)floor(L2);
+            double lam = exp2(L2 - sc);
+            if (m & 1) lam = -lam;
+            double lam_prev = 0.0;
+            int l = m;
+            while (l < L && sc + ilogb(lam) < -900) {
+                double nxt = (l + 1 < L) ? A[l + 1] * (x * lam - lam_prev * IA[l]) : 0.0;
+                lam_prev = lam;
+                lam = nxt;
+                l++;
+                if (fabs(lam) > 0x1p300) { lam *= 0x1p-300; lam_prev *= 0x1p-300; sc += 300; }
+                if (lam == 0.0) break;
+            }
+            /* sums of W a and X a over even / odd (l - m), for the four real columns (Re E, Im E, Re B, Im B) */
+            double we[4] = {0, 0, 0, 0}, wo[4] = {0, 0, 0, 0}, xe[4] = {0, 0, 0, 0}, xo[4] = {0, 0, 0, 0};
+            if (l < L && lam != 0.0) {
+                lam = ldexp(lam, sc);
+                lam_prev = ldexp(lam_prev, sc);
+                for (; l < L; l++) {
+                    if (l >= 2) {
+                        const double ll = l;
+                        const double N2 = 2.0 / sqrt((ll + 2.0) * (ll + 1.0) * ll * (ll - 1.0));
+                        const double cl = (l > m) ? (2.0 * ll + 1.0) * IA[l] : 0.0;      /* (l+m) c_lm = (2l+1)/A_l */
+                        const double W = N2 * (-((ll - m2) / s2 + ll * (ll - 1.0) / 2.0) * lam + cl * x / s2 * lam_prev);
+                        const double X = N2 * m / s2 * ((ll - 1.0) * x * lam - cl * lam_prev);
+                        const double col[4] = {ae[2 * l], ae[2 * l + 1], ab[2 * l], ab[2 * l + 1]};
+                        double *w = ((l - m) & 1) ? wo : we, *xx = ((l - m) & 1) ? xo : xe;
+                        for (int c = 0; c < 4; c++) { w[c] += W * col[c]; xx[c] += X * col[c]; }
+                    }
+                    if (l + 1 < L) {
+                        double nxt = A[l + 1] * (x * lam - lam_prev * IA[l]);
+                        lam_prev = lam;
+                        lam = nxt;
+                    }
+                }
+            }
+            /* north: W_e + W_o, X_e + X_o; south: W_e - W_o, X_o - X_e */
+            for (int hemi = 0; hemi < 2; hemi++) {
+                double sw[4], sx[4];
+                for (int c = 0; c < 4; c++) {
+                    sw[c] = hemi ? we[c] - wo[c] : we[c] + wo[c];
+                    sx[c] = hemi ? xo[c] - xe[c] : xe[c] + xo[c];
+                }
+                double *q = (hemi ? qs : qn) + 2 * ((long)r * L + m);
+                double *u = (hemi ? us : un) + 2 * ((long)r * L + m);
+                /* Q = -(E W - i B X): Re = -(ReE W + ImB X), Im = -(ImE W - ReB X) */
+                q[0] = -(sw[0] + sx[3]);
+                q[1] = -(sw[1] - sx[2]);
+                /* U = -(B W + i E X): Re = -(ReB W - ImE X), Im = -(ImB W + ReE X) */
+                u[0] = -(sw[2] - sx[1]);
+                u[1] = -(sw[3] + sx[0]);
+            }
+        }
+        free(A); free(IA);
+    }
+    free(lp);
+}
+
 /* cora/util/bilinearmap.pyx:14-59 restated (OpenMP over points like the reference's prange): clip to
  * [0, n - 1e-5], truncate to the lower corner, four-corner weights.  n points, table arr [nx][ny] row-major. */
 void oracle_bilinear_interp(const double *arr, long nx, long ny, const double *x, const double *y, long n,
