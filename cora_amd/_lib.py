@@ -58,6 +58,7 @@ SIGNATURES = {
     "corahip_alm2map": (c_int, [c_void_p, c_void_p, PTR, c_int, PTR, c_void_p, c_size_t]),
     "corahip_map2alm_workspace_bytes": (c_int, [c_void_p, c_int, ctypes.POINTER(c_size_t)]),
     "corahip_map2alm": (c_int, [c_void_p, c_void_p, PTR, c_int, PTR, PTR, c_void_p, c_size_t]),
+    "corahip_alm2map_spin2": (c_int, [c_void_p, c_void_p, PTR, c_int, PTR, c_void_p, c_size_t]),
     "corahip_xi_table_average": (c_int, [c_void_p, PTR, PTR, PTR, c_int, c_int, c_double, c_double, PTR, c_int, PTR, PTR,
                                          c_int, c_int, PTR]),
     "corahip_legendre_project": (c_int, [c_void_p, PTR, PTR, c_int, c_int, PTR, ctypes.c_long, PTR]),
@@ -369,6 +370,15 @@ class Context:
                 gn = min(G8, G4 - g0)
                 out[:, g0:g0 + gn].copy_(part[:, :gn])
         return out
+
+    def alm2map_spin2(self, alm, nside, lmax, nnu, out=None):
+        """alm_dev of nnu = 2 nfreq interleaved (E, B) channels -> maps [nnu, npix] = interleaved (Q, U)."""
+        plan = self.sht_plan(nside, lmax)
+        maps = out if out is not None else self.empty((nnu, 12 * nside * nside))
+        need = self.alm2map_workspace_bytes(plan, nnu)
+        ws = self.workspace(need)
+        _check(self.lib.corahip_alm2map_spin2(self.h, plan, self._f64(alm), nnu, self._f64(maps), self._p(ws), need))
+        return maps
 
     # -- n3: xi(r) -> C_l --------------------------------------------------------------
     def xi_table_average(self, kx, ky, ky2, kind, x_t, f_t, mu, xa, xw, F, xint):

@@ -39,6 +39,7 @@ struct corahip_sht_plan {
     int32_t *d_lmin = nullptr;                            // [L][ntile] first l per (m, ring tile)
     unsigned *d_queue = nullptr;                          // K4 work-queue head
     int32_t *d_mcut = nullptr;                            // [nring] number of m with any non-negligible lambda_lm
+    double *d_polc = nullptr;                             // [nalm + 64][4] spin-2 coefficients (g1..g4), built on first use
     double *d_zeros = nullptr;                            // 4 KiB of zeros (source of padding rows for LDS-DMA)
     double2 *d_tw = nullptr;                              // e^{+2 pi i k/pmax}, k < pmax/2
     int pmax = 0, log_pmax = 0;
@@ -494,6 +495,243 @@ legendre_kernel(int lmax, int npair, int nring, int ncols, const double *__restr
         }
         if (!have_next) break;
         __syncthreads();  // everyone has read s_next before thread 0 overwrites it
+    }
+}
+
+// K4 for polarisation (spin 2): (E, B) -> (Q, U), what healpy.alm2map([T, E, B]) does for Q and U behind
+// hputil.sphtrans_inv_real_pol (cora/util/hputil.py:394-432).  Same structure as legendre_kernel (persistent
+// workgroups + queue, staggered-lane recurrence, LDS-DMA stage ring, even/odd parity accumulators), with the two
+// A operands per parity derived from the scalar recurrence:
+//     W_lm = (g1 r1 + g2) lambda_l + g3 r2 lambda_{l-1},     X_lm = g4 r2 lambda_l - m g3 r1 lambda_{l-1},
+//     r1 = 1/sin^2, r2 = cos/sin^2 per ring (lane),  (g1..g4)(l, m) from the plan's table (staged through LDS):
+//     g1 = -N2 (l - m^2), g2 = -N2 l(l-1)/2, g3 = N2 (2l+1)/A_l, g4 = N2 m (l-1), N2 = 2/sqrt((l+2)(l+1)l(l-1)).
+// The kernel accumulates S_W = sum_l W a and S_X = sum_l X a for the natural columns; channels are interleaved
+// (E_f, B_f) so that one a_lm cell [re x4 | im x4] holds (Re E, Re B, .., Im E, Im B, ..) and
+//     Re Q = -(S_W[ReE] + S_X[ImB]),  Im Q = -(S_W[ImE] - S_X[ReB]),  Re U = -(S_W[ReB] - S_X[ImE]),  Im U = -(S_W[ImB] + S_X[ReE])
+// is a lane-xor-5 exchange in the epilogue; Q_f, U_f leave in the cell positions of E_f, B_f.  W has the parity
+// (-1)^{l+m} of lambda under theta -> pi - theta, X the opposite: north = (W_e + W_o, X_e + X_o), south = (W_e - W_o, X_o - X_e).
+template <int NT>
+__global__ void __launch_bounds__(64 * LEG_WAVES)
+legendre_pol_kernel(int lmax, int npair, int nring, int ncols, const double *__restrict__ z,
+                    const double *__restrict__ sth, const double2 *__restrict__ coef,
+                    const double *__restrict__ polc, const int32_t *__restrict__ lstart,
+                    const double2 *__restrict__ seed, const int32_t *__restrict__ lmin_tab,
+                    const double *__restrict__ alm, const double *__restrict__ zeros, double *__restrict__ inter,
+                    unsigned *__restrict__ queue) {
+    constexpr int KT = 32;                  // l rows per stage (the 4 accumulator sets leave room for NT = 4 only)
+    constexpr int NBUF = 3;
+    constexpr int TCOLS = 16 * NT;
+    constexpr int STRIDE = TCOLS + 8;
+    constexpr int CROWS = KT + 8;
+    constexpr int STAGE = KT * STRIDE + 2 * CROWS + 4 * CROWS;   // a_lm rows + (A, B) pairs + (g1..g4) rows
+    constexpr int RPW = KT / LEG_WAVES;
+    constexpr int PIECES = RPW + 3;         // a_lm rows + the (A, B) piece + two pieces of the g table (see issue_coef)
+    constexpr int TRINGS = LEG_RINGS;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    int &s_next = *reinterpret_cast<int *>(lds + NBUF * STAGE);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    const int ri = lane & 15, kq = lane >> 4;
+    const int d = 2 * kq;
+    const int L = lmax + 1;
+    const int G = ncols >> 3;
+    const int ntile128 = (npair + LMIN_RINGS - 1) / LMIN_RINGS;
+    const int ntile = (npair + TRINGS - 1) / TRINGS;
+    const int ncg = ncols / TCOLS;
+    const int nitems = L * ncg * ntile;
+    const long last_row = nalm_of(lmax) - 1;
+    const unsigned lds_base_bytes = (unsigned)(size_t)(__attribute__((address_space(3))) double *)lds;
+
+    struct item_t {
+        int m, cg, rtile, l_begin, nstage;
+        long base_m;
+    };
+    auto decode = [&](int it) {
+        item_t w;
+        const int gidx = it / ntile;
+        w.rtile = it - gidx * ntile;
+        w.m = gidx / ncg;
+        w.cg = gidx - w.m * ncg;
+        int lmin = lmax + 1;
+        const int t_first = (w.rtile * TRINGS) / LMIN_RINGS;
+        const int t_last = min((w.rtile * TRINGS + TRINGS - 1) / LMIN_RINGS, ntile128 - 1);
+        for (int t128 = t_first; t128 <= t_last; t128++) lmin = min(lmin, lmin_tab[w.m * ntile128 + t128]);
+        w.l_begin = w.m + ((lmin - w.m) & ~7);
+        w.nstage = lmin <= lmax ? (lmax - w.l_begin) / KT + 1 : 0;
+        w.base_m = alm_idx(0, w.m, lmax);
+        return w;
+    };
+    auto issue_row = [&](const item_t &w, int st, int rr) {
+        const int row = wv + LEG_WAVES * rr;
+        long rowidx = w.base_m + w.l_begin + st * KT + row;
+        rowidx = rowidx < last_row ? rowidx : last_row;
+        const double *src = alm + (size_t)w.cg * TCOLS + (size_t)rowidx * ncols + 2 * lane;
+        const unsigned dst = lds_base_bytes + (unsigned)(((st % NBUF) * STAGE + row * STRIDE) * sizeof(double));
+        if (lane < 8 * NT) glds16(src, dst);
+    };
+    // coefficient pieces of a stage: CROWS (A, B) pairs (16 B each) and CROWS (g1..g4) rows (32 B each = 2 CROWS
+    // 16-byte chunks, contiguous in the table): 1 + 2 wave-instructions (CROWS = 40: 40 + 80 lanes)
+    auto issue_coef = [&](const item_t &w, int st) {
+        const int l0 = w.l_begin + st * KT;
+        const int l = l0 + lane;
+        const double *src = (l <= lmax) ? reinterpret_cast<const double *>(coef + w.base_m + l) : zeros;
+        const unsigned dst = lds_base_bytes + (unsigned)(((st % NBUF) * STAGE + KT * STRIDE) * sizeof(double));
+        if (lane < CROWS) glds16(src, dst);
+        const double *gsrc = polc + 4 * (size_t)(w.base_m + l0);     // the table is padded: rows past the end exist
+        const unsigned gdst = dst + (unsigned)(2 * CROWS * sizeof(double));
+        glds16(gsrc + 2 * lane, gdst);
+        if (lane < 2 * CROWS - 64) glds16(gsrc + 2 * (64 + lane), gdst + 64 * 16);
+    };
+    auto issue_stage = [&](const item_t &w, int st) {
+        issue_coef(w, st);
+#pragma unroll
+        for (int rr = 0; rr < RPW; rr++) issue_row(w, st, rr);
+    };
+
+    int item = blockIdx.x;
+    if (item >= nitems) return;
+    item_t w = decode(item);
+#pragma unroll
+    for (int st = 0; st < NBUF - 1; st++)
+        if (st < w.nstage) issue_stage(w, st);
+
+    for (;;) {
+        const int m = w.m;
+        const double mval = (double)m;
+        if (tid == 0) s_next = (int)(gridDim.x + atomicAdd(queue, 1u));
+        d4_t awe[NT], awo[NT], axe[NT], axo[NT];
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+            awe[t] = (d4_t){0.0, 0.0, 0.0, 0.0};
+            awo[t] = (d4_t){0.0, 0.0, 0.0, 0.0};
+            axe[t] = (d4_t){0.0, 0.0, 0.0, 0.0};
+            axo[t] = (d4_t){0.0, 0.0, 0.0, 0.0};
+        }
+        if (w.nstage > 0) {
+            const int ring = w.rtile * TRINGS + ri * LEG_WAVES + wave;
+            double x = 0.0, r1 = 0.0, r2 = 0.0, p0 = 0.0, p1 = 0.0;
+            double2 sd = make_double2(0.0, 0.0);
+            int my_ls = lmax + 1;
+            if (ring < npair) {
+                x = z[ring];
+                const double s = sth[ring];
+                r1 = 1.0 / (s * s);
+                r2 = x * r1;
+                const long o = (long)m * npair + ring;
+                my_ls = lstart[o];
+                sd = seed[o];
+            }
+            const int ls_min = my_ls;
+            int inj_l = my_ls;
+            const double2 *cf = coef + w.base_m;
+            {
+                const int lf = w.l_begin + d;
+                if (my_ls < lf) {
+                    p0 = sd.x;
+                    p1 = sd.y;
+                    for (int l = my_ls + 1; l < lf; l++) {
+                        const double2 c = (l <= lmax) ? cf[l] : make_double2(0.0, 0.0);
+                        const double vv = fma(c.x * x, p1, -(c.y * p0));
+                        p0 = p1;
+                        p1 = vv;
+                    }
+                    inj_l = 0x7fffffff;
+                }
+            }
+            for (int st = 0; st < w.nstage; st++) {
+                if (st + 1 < w.nstage) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                const bool refill = st + NBUF - 1 < w.nstage;
+                if (refill) issue_stage(w, st + NBUF - 1);
+                const int ls = w.l_begin + st * KT;
+                const double *sb = lds + (st % NBUF) * STAGE;
+                const double2 *sc = reinterpret_cast<const double2 *>(sb + KT * STRIDE) + d;
+                const double *sg = sb + KT * STRIDE + 2 * CROWS + 4 * d;
+#pragma unroll 1
+                for (int ms = 0; ms < KT / 8; ms++) {
+                    const int l0 = ls + 8 * ms;
+                    if (l0 > lmax) continue;
+                    if (__all(ls_min > l0 + 13)) continue;
+                    double2 c[8];
+#pragma unroll
+                    for (int j = 0; j < 8; j++) c[j] = sc[8 * ms + j];
+                    const int lf = l0 + d;
+                    // lambda at lf-1, lf (even l-m slot of this lane), lf+1 (odd slot); then 6 more steps
+                    double lm1 = p1, le = 0.0, lo = 0.0;
+#pragma unroll
+                    for (int j = 0; j < 8; j++) {
+                        double vv = fma(c[j].x * x, p1, -(c[j].y * p0));
+                        const bool inj = (lf + j == inj_l);
+                        vv = inj ? sd.y : vv;
+                        p0 = inj ? sd.x : p1;
+                        p1 = vv;
+                        if (j == 0) {
+                            le = vv;
+                            lm1 = p0;      // lambda_{lf-1} as the recurrence sees it (the seed if injected here)
+                        }
+                        if (j == 1) lo = vv;
+                    }
+                    double lem1 = lm1, lom1 = le;
+                    if (lf + 1 == inj_l) lom1 = sd.x;
+                    if (__all(ls_min > l0 + 7)) continue;
+                    // W, X at the two l of this lane
+                    const double4 ge = *reinterpret_cast<const double4 *>(sg + 4 * (8 * ms));
+                    const double4 go = *reinterpret_cast<const double4 *>(sg + 4 * (8 * ms + 1));
+                    const double We = fma(fma(ge.x, r1, ge.y), le, (ge.z * r2) * lem1);
+                    const double Xe = fma(ge.w * r2, le, -((mval * ge.z) * r1) * lem1);
+                    const double Wo = fma(fma(go.x, r1, go.y), lo, (go.z * r2) * lom1);
+                    const double Xo = fma(go.w * r2, lo, -((mval * go.z) * r1) * lom1);
+                    const double *be = sb + (8 * ms + d) * STRIDE + ri;
+                    const double *bo = be + STRIDE;
+#pragma unroll
+                    for (int t = 0; t < NT; t++) {
+                        const double bev = be[16 * t], bov = bo[16 * t];
+                        awe[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(We, bev, awe[t], 0, 0, 0);
+                        awo[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(Wo, bov, awo[t], 0, 0, 0);
+                        axe[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(Xe, bev, axe[t], 0, 0, 0);
+                        axo[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(Xo, bov, axo[t], 0, 0, 0);
+                    }
+                }
+            }
+        }
+
+        const int cur_rtile = w.rtile, cur_cg = w.cg, cur_m = w.m, cur_nstage = w.nstage;
+        __syncthreads();
+        item = __builtin_amdgcn_readfirstlane(s_next);
+        const bool have_next = item < nitems;
+        if (have_next) {
+            w = decode(item);
+#pragma unroll
+            for (int st = 0; st < NBUF - 1; st++)
+                if (st < w.nstage) issue_stage(w, st);
+        }
+        if (cur_nstage > 0) {
+            // sigma of the column inside its 8-wide cell: +1 for (Re B, Im E) columns, -1 for (Re E, Im B)
+            const int c8 = ri & 7;
+            const double sigma = (((c8 & 1) ^ ((c8 >> 2) & 1)) != 0) ? 1.0 : -1.0;
+#pragma unroll
+            for (int t = 0; t < NT; t++) {
+                const int col = cur_cg * TCOLS + 16 * t + ri;
+                const int g = col >> 3, cv = col & 7;
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const double swn = awe[t][r] + awo[t][r], sws = awe[t][r] - awo[t][r];
+                    const double sxn = axe[t][r] + axo[t][r], sxs = axo[t][r] - axe[t][r];
+                    const double pxn = __shfl_xor(sxn, 5), pxs = __shfl_xor(sxs, 5);
+                    const int ro = cur_rtile * TRINGS + (kq + 4 * r) * LEG_WAVES + wave;
+                    if (ro < npair) {
+                        inter[(((size_t)ro * G + g) * L + cur_m) * 8 + cv] = -(swn - sigma * pxn);
+                        const int rs = nring - 1 - ro;
+                        if (rs != ro) inter[(((size_t)rs * G + g) * L + cur_m) * 8 + cv] = -(sws - sigma * pxs);
+                    }
+                }
+            }
+        }
+        if (!have_next) break;
+        __syncthreads();
     }
 }
 
@@ -1503,6 +1741,7 @@ int corahip_sht_plan_destroy(corahip_ctx *ctx, corahip_sht_plan *p) {
     (void)hipFree(p->d_lmin);
     (void)hipFree(p->d_queue);
     (void)hipFree(p->d_mcut);
+    (void)hipFree(p->d_polc);
     (void)hipFree(p->d_blu_P);
     (void)hipFree(p->d_blu_boff);
     (void)hipFree(p->d_blu_foff);
@@ -1771,20 +2010,9 @@ static int launch_legendre(corahip_ctx *ctx, const corahip_sht_plan *p, int ncol
     return 0;
 }
 
-// alm_chunk: [nalm][ncols] with ncols = 2*nnu_pad (multiple of 16)
-static int alm2map_chunk(corahip_ctx *ctx, const corahip_sht_plan *p, const double *alm_chunk, int nnu_chunk_pad,
-                         int nnu_valid, double *maps, double *inter) {
-    const int ncols = 2 * nnu_chunk_pad;
-    const int ntile = ncols / 16;
-    int rc;
-    {
-        StageTimer t(ctx, "legendre");
-        if (ntile % 8 == 0) rc = launch_legendre<8, 1>(ctx, p, ncols, alm_chunk, inter);
-        else if (ntile % 4 == 0) rc = launch_legendre<4, 2>(ctx, p, ncols, alm_chunk, inter);
-        else if (ntile % 2 == 0) rc = launch_legendre<2, 2>(ctx, p, ncols, alm_chunk, inter);
-        else rc = launch_legendre<1, 2>(ctx, p, ncols, alm_chunk, inter);
-        if (rc) return rc;
-    }
+// K5 over the F_m cells of `inter` for nnu_valid channels -> maps
+static int run_ringfft(corahip_ctx *ctx, const corahip_sht_plan *p, const double *inter, int nnu_chunk_pad, int nnu_valid,
+                       double *maps) {
     {
         StageTimer t(ctx, "ringfft");
         const int G = nnu_chunk_pad / 4;
@@ -1842,6 +2070,23 @@ static int alm2map_chunk(corahip_ctx *ctx, const corahip_sht_plan *p, const doub
         }
     }
     return 0;
+}
+
+// alm_chunk: [nalm][ncols] with ncols = 2*nnu_pad (multiple of 16)
+static int alm2map_chunk(corahip_ctx *ctx, const corahip_sht_plan *p, const double *alm_chunk, int nnu_chunk_pad,
+                         int nnu_valid, double *maps, double *inter) {
+    const int ncols = 2 * nnu_chunk_pad;
+    const int ntile = ncols / 16;
+    int rc;
+    {
+        StageTimer t(ctx, "legendre");
+        if (ntile % 8 == 0) rc = launch_legendre<8, 1>(ctx, p, ncols, alm_chunk, inter);
+        else if (ntile % 4 == 0) rc = launch_legendre<4, 2>(ctx, p, ncols, alm_chunk, inter);
+        else if (ntile % 2 == 0) rc = launch_legendre<2, 2>(ctx, p, ncols, alm_chunk, inter);
+        else rc = launch_legendre<1, 2>(ctx, p, ncols, alm_chunk, inter);
+        if (rc) return rc;
+    }
+    return run_ringfft(ctx, p, inter, nnu_chunk_pad, nnu_valid, maps);
 }
 
 // gather channel groups [g0, g0+Gc) of alm_dev ([nalm][Gsrc][8]) into a dense [nalm][Gc][8] chunk;
@@ -1980,4 +2225,76 @@ extern "C" int corahip_map2alm(corahip_ctx *ctx, const corahip_sht_plan *p, cons
         LAUNCH_CHECK();
     }
     return 0;
+}
+
+// ------------------------------------------------------------------------------------
+// polarisation (spin-2) synthesis host side
+// ------------------------------------------------------------------------------------
+// (g1..g4)(l, m) of legendre_pol_kernel at alm_idx(l, m), long double on the host, once per plan
+static int ensure_polc(corahip_ctx *ctx, corahip_sht_plan *p) {
+    if (p->d_polc) return 0;
+    const int lmax = p->lmax;
+    std::vector<double> g((size_t)(p->nalm + 64) * 4, 0.0);
+    for (int m = 0; m <= lmax; m++)
+        for (int l = std::max(m, 2); l <= lmax; l++) {
+            const long double ll = l, mm = m;
+            const long double n2 = 2.0L / sqrtl((ll + 2.0L) * (ll + 1.0L) * ll * (ll - 1.0L));
+            const long double al = l > m ? sqrtl((4.0L * ll * ll - 1.0L) / (ll * ll - mm * mm)) : 0.0L;
+            double *o = &g[(size_t)alm_idx(l, m, lmax) * 4];
+            o[0] = (double)(-n2 * (ll - mm * mm));
+            o[1] = (double)(-n2 * ll * (ll - 1.0L) / 2.0L);
+            o[2] = l > m ? (double)(n2 * (2.0L * ll + 1.0L) / al) : 0.0;
+            o[3] = (double)(n2 * mm * (ll - 1.0L));
+        }
+    HIP_TRY(hipMalloc((void **)&p->d_polc, sizeof(double) * g.size()));
+    HIP_TRY(hipMemcpyAsync(p->d_polc, g.data(), sizeof(double) * g.size(), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+template <int NT>
+static int launch_legendre_pol(corahip_ctx *ctx, const corahip_sht_plan *p, int ncols, const double *alm, double *inter) {
+    constexpr int STRIDE = 16 * NT + 8;
+    const size_t shm = sizeof(double) * 3 * (32 * STRIDE + 6 * (32 + 8)) + 16;
+    HIP_TRY(hipFuncSetAttribute((const void *)legendre_pol_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)shm));
+    const int ntile = (p->npair + LEG_RINGS - 1) / LEG_RINGS;
+    const long nitems = (long)p->L * (ncols / (16 * NT)) * ntile;
+    const int per_cu = std::max<int>(1, std::min<int>(2, (int)((160 * 1024) / shm)));
+    dim3 grid((unsigned)std::min<long>(nitems, (long)ctx->num_cu * per_cu));
+    HIP_TRY(hipMemsetAsync(p->d_queue, 0, 64, ctx->stream));
+    legendre_pol_kernel<NT><<<grid, 64 * LEG_WAVES, shm, ctx->stream>>>(p->lmax, p->npair, p->nring, ncols, p->d_z, p->d_sth,
+                                                                       p->d_coef, p->d_polc, p->d_lstart, p->d_seed,
+                                                                       p->d_lmin, alm, p->d_zeros, inter, p->d_queue);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+// alm_dev: nnu = 2 nfreq channels interleaved (E_0, B_0, E_1, B_1, ...) -> maps [nnu, npix] = (Q_0, U_0, Q_1, U_1, ...)
+extern "C" int corahip_alm2map_spin2(corahip_ctx *ctx, corahip_sht_plan *p, const double *alm_dev, int nnu, double *maps,
+                                     void *workspace, size_t workspace_bytes) {
+    ARG_CHECK(ctx != nullptr && p != nullptr && alm_dev != nullptr && maps != nullptr && workspace != nullptr);
+    ARG_CHECK(nnu >= 2 && (nnu & 1) == 0);
+    ARG_CHECK(((nnu + 3) & ~3) == nnu_pad_of(nnu));     // the alm_dev group count must be the 8-padded one
+    size_t need;
+    corahip_alm2map_workspace_bytes(p, nnu, &need);
+    if (workspace_bytes < need) {
+        corahip_set_error("alm2map_spin2 workspace too small: %zu bytes, need %zu (process fewer channels per call)",
+                          workspace_bytes, need);
+        return CORAHIP_ENOMEM;
+    }
+    int rc = ensure_polc(ctx, p);
+    if (rc) return rc;
+    const int nnu_pad8 = nnu_pad_of(nnu);
+    const int ncols = 2 * nnu_pad8;
+    double *inter = (double *)workspace;
+    {
+        StageTimer t(ctx, "legendre_pol");
+        const int ntile = ncols / 16;
+        if (ntile % 4 == 0) rc = launch_legendre_pol<4>(ctx, p, ncols, alm_dev, inter);
+        else if (ntile % 2 == 0) rc = launch_legendre_pol<2>(ctx, p, ncols, alm_dev, inter);
+        else rc = launch_legendre_pol<1>(ctx, p, ncols, alm_dev, inter);
+        if (rc) return rc;
+    }
+    return run_ringfft(ctx, p, inter, nnu_pad8, nnu, maps);
 }

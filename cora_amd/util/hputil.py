@@ -123,18 +123,65 @@ def sphtrans_inv_real(alm, nside):
     return _synth(np.asarray(alm)[np.newaxis], nside)[0]
 
 
-def sphtrans_inv_sky(alm, nside):
-    """[freq, pol, l, m] a_lm -> [freq, pol, npix] sky (cora/util/hputil.py:500-531).
+def _synth_pol(alm_e, alm_b, nside):
+    """alm_e, alm_b: [n, L, L] complex -> (Q, U) maps [n, npix] each (spin-2 synthesis on the GPU)."""
+    import torch
 
-    Only the unpolarised branch is on the hot path; 3- or 4-component polarised input
-    (spin-2 synthesis) is outside this package's scope.
-    """
+    n, L, _ = alm_e.shape
+    lmax = L - 1
+    packed = np.empty((2 * n, L * (L + 1) // 2), dtype=np.complex128)
+    for i in range(n):
+        packed[2 * i] = pack_alm(alm_e[i])
+        packed[2 * i + 1] = pack_alm(alm_b[i])
+    ctx = _lib.get_context()
+    out = np.empty((2 * n, nside2npix(nside)))
+    # the spin-2 entry point wants its channel count in whole groups of 8 (or 5..7 mod 8): chunks of 4 fields
+    for c0 in range(0, 2 * n, 8):
+        c1 = min(c0 + 8, 2 * n)
+        blk = packed[c0:c1]
+        if (c1 - c0) % 8 not in (0, 6):          # pad with zero fields to 8 channels
+            blk = np.concatenate([blk, np.zeros((8 - (c1 - c0), packed.shape[1]), dtype=np.complex128)])
+        dev = ctx.alm_packed_to_dev(torch.from_numpy(np.ascontiguousarray(blk)).to(ctx.device), lmax)
+        maps = ctx.alm2map_spin2(dev, int(nside), lmax, blk.shape[0])
+        out[c0:c1] = maps[: c1 - c0].cpu().numpy()
+    return out[0::2], out[1::2]
+
+
+def sphtrans_inv_real_pol(alm, nside):
+    """Inverse transform onto a real polarised field: alm [npol, L, L] for T, E, B (and V) -> T, Q, U (and V) maps
+    [npol, npix] (cora/util/hputil.py:394-432; healpy.alm2map of the three packed arrays).  Q and U come from the
+    spin-2 synthesis kernel (convention: Zaldarriaga & Seljak 1997, the one HEALPix documents), T and V from the
+    scalar one."""
+    alm = np.asarray(alm)
+    npol = alm.shape[0]
+    if alm.shape[1] != alm.shape[2] or not (npol == 3 or npol == 4):
+        raise Exception("a_lm array wrong shape.")
+    maps = np.zeros((npol, nside2npix(nside)), dtype=np.float64)
+    scal = _synth(alm[[0] + ([3] if npol == 4 else [])], nside)
+    maps[0] = scal[0]
+    q, u = _synth_pol(alm[1:2], alm[2:3], nside)
+    maps[1], maps[2] = q[0], u[0]
+    if npol == 4:
+        maps[3] = scal[1]
+    return maps
+
+
+def sphtrans_inv_sky(alm, nside):
+    """[freq, pol, l, m] a_lm -> [freq, pol, npix] sky (cora/util/hputil.py:500-531): the polarised transform when
+    the pol axis has 3 or 4 entries (T, E, B[, V] -> T, Q, U[, V]), else the scalar one; all frequencies in batches."""
+    alm = np.asarray(alm)
     nfreq, npol = alm.shape[0], alm.shape[1]
-    if npol >= 3:
-        raise NotImplementedError("polarised synthesis (hputil.py:394-432) is out of scope of cora_amd")
     if alm.shape[3] != alm.shape[2]:
         raise Exception("a_lm array wrong shape.")
     sky = np.empty((nfreq, npol, nside2npix(nside)), dtype=np.float64)
+    if npol >= 3:
+        if npol > 4:
+            raise Exception("a_lm array wrong shape.")
+        sky[:, 0] = _synth(alm[:, 0], nside)
+        sky[:, 1], sky[:, 2] = _synth_pol(alm[:, 1], alm[:, 2], nside)
+        if npol == 4:
+            sky[:, 3] = _synth(alm[:, 3], nside)
+        return sky
     for p in range(npol):
         sky[:, p] = _synth(np.asarray(alm[:, p]), nside)
     return sky

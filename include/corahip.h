@@ -187,6 +187,15 @@ int corahip_map2alm_workspace_bytes(const corahip_sht_plan *plan, int nnu, size_
 int corahip_map2alm(corahip_ctx *ctx, const corahip_sht_plan *plan, const double *maps, int nnu,
                     const double *ring_w, double *alm_dev, void *workspace, size_t workspace_bytes);
 
+/* ---- polarisation: spin-2 synthesis ----------------------------------------
+ * Replaces the Q, U part of healpy.alm2map([T, E, B], nside) behind hputil.sphtrans_inv_real_pol
+ * (cora/util/hputil.py:394-432):  Q +- iU = - sum_lm (a^E_lm +- i a^B_lm) (+-2)Y_lm  (Zaldarriaga & Seljak 1997).
+ * alm_dev holds nnu = 2 nfreq channels interleaved (E_0, B_0, E_1, B_1, ...) in the usual layout (nnu_pad8/4 groups
+ * must equal nnu_pad4/4, i.e. nnu mod 8 in {0, 5, 6, 7}); maps [nnu, npix] RING = (Q_0, U_0, Q_1, U_1, ...).
+ * T (and V) go through corahip_alm2map.  Workspace: corahip_alm2map_workspace_bytes(plan, nnu).             */
+int corahip_alm2map_spin2(corahip_ctx *ctx, corahip_sht_plan *plan, const double *alm_dev, int nnu,
+                          double *maps, void *workspace, size_t workspace_bytes);
+
 /* ---- xi(r) -> C_l(chi, chi') ----------------------------------------------
  * Replaces corrfunc.corr_to_clarray (cora/signal/corrfunc.py:290-400).
  * xi_table_average: for every Gauss-Legendre node mu_m and channel pair (i, j) the radial-bin average

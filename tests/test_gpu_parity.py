@@ -1068,3 +1068,53 @@ def test_small_and_ragged_sizes_next_rows(ctx):
         for k in (0, nnu - 1):
             ref = hputil.unpack_alm(sht.map2alm_adjoint(maps[k], nside, lmax, None), lmax)
             assert np.abs(got[k] - ref).max() <= 1e-12 * max(np.abs(ref).max(), 1e-300), (nside, lmax, nnu, k)
+
+
+# ------------------------------------------------------------------ n4: polarised (spin-2) synthesis
+@pytest.mark.parametrize("nside,lmax,nfreq", [(4, 8, 1), (8, 20, 3), (16, 47, 4), (32, 64, 8), (64, 150, 2)])
+def test_alm2map_spin2_vs_oracle(ctx, nside, lmax, nfreq):
+    """(E, B) -> (Q, U) on the GPU (legendre_pol_kernel + the ring FFT) against the CPU oracle, through the C ABI."""
+    import torch
+    from oracle import sht
+
+    rng = np.random.default_rng(7 * nside + nfreq)
+    n = (lmax + 1) * (lmax + 2) // 2
+    nch = 2 * nfreq
+    npad = nch if nch % 8 in (0, 6) else (nch + 7) // 8 * 8
+    packed = np.zeros((npad, n), dtype=np.complex128)
+    packed[:nch] = rng.standard_normal((nch, n)) + 1j * rng.standard_normal((nch, n))
+    packed[:, : lmax + 1] = packed[:, : lmax + 1].real
+    dev = ctx.alm_packed_to_dev(torch.from_numpy(packed).to(ctx.device), lmax)
+    maps = ctx.alm2map_spin2(dev, nside, lmax, npad).cpu().numpy()
+    for f in range(nfreq):
+        q, u = sht.alm2map_spin2(packed[2 * f], packed[2 * f + 1], nside, lmax)
+        assert np.abs(maps[2 * f] - q).max() <= 1e-11 * q.std(), (f, np.abs(maps[2 * f] - q).max() / q.std())
+        assert np.abs(maps[2 * f + 1] - u).max() <= 1e-11 * u.std(), f
+    assert np.all(maps[nch:] == 0)
+
+
+def test_sphtrans_inv_pol_api(ctx):
+    """hputil.sphtrans_inv_real_pol / sphtrans_inv_sky with 3 and 4 polarisation entries (hputil.py:394-432,500-531)."""
+    from cora_amd.util import hputil
+    from oracle import sht
+    from oracle import skysim as osk
+
+    nside, lmax, nfreq = 8, 16, 3
+    L = lmax + 1
+    rng = np.random.default_rng(21)
+    alm = np.zeros((nfreq, 4, L, L), dtype=np.complex128)
+    for l in range(L):
+        alm[:, :, l, : l + 1] = rng.standard_normal((nfreq, 4, l + 1)) + 1j * rng.standard_normal((nfreq, 4, l + 1))
+    alm[:, :, :, 0] = alm[:, :, :, 0].real
+    sky = hputil.sphtrans_inv_sky(alm, nside)
+    assert sky.shape == (nfreq, 4, 12 * nside * nside)
+    for f in range(nfreq):
+        t = sht.alm2map(osk.pack_alm(alm[f, 0]), nside, lmax)
+        v = sht.alm2map(osk.pack_alm(alm[f, 3]), nside, lmax)
+        q, u = sht.alm2map_spin2(osk.pack_alm(alm[f, 1]), osk.pack_alm(alm[f, 2]), nside, lmax)
+        for got, ref in ((sky[f, 0], t), (sky[f, 1], q), (sky[f, 2], u), (sky[f, 3], v)):
+            assert np.abs(got - ref).max() <= 1e-11 * ref.std()
+    one = hputil.sphtrans_inv_real_pol(alm[1, :3], nside)
+    assert one.shape == (3, 12 * nside * nside) and np.abs(one - sky[1, :3]).max() <= 1e-12 * np.abs(one).max()
+    with pytest.raises(Exception, match="wrong shape"):
+        hputil.sphtrans_inv_real_pol(alm[0, :2], nside)
