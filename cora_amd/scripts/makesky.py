@@ -182,18 +182,23 @@ def gaussianfg(fstate, nside, pol, filename, seed):
     from ..foreground import galaxy as galaxy_mod
     from ..util import hputil
 
-    if pol == "full":
-        raise click.ClickException("--pol full needs the polarised (spin-2) synthesis, which is not part of cora_amd; "
-                                   "use --pol zero or --pol none")
     fsyn = galaxy_mod.FullSkySynchrotron()
+    fpol = galaxy_mod.FullSkyPolarisedSynchrotron()
     fsyn.frequencies = fstate.frequencies
     nfreq = len(fsyn.frequencies)
     lmax = 3 * nside
-    cv_fg = skysim.clarray(fsyn.angular_powerspectrum, lmax, fsyn.nu_pixels)        # [lmax+1, nfreq, nfreq]
+    npol = 4 if pol == "full" else 1
+    # block-diagonal covariance over (pol, freq): T from the unpolarised model, E and B from the polarised one, V = 0
+    cv_fg = np.zeros((lmax + 1, npol, nfreq, npol, nfreq))
+    cv_fg[:, 0, :, 0, :] = skysim.clarray(fsyn.angular_powerspectrum, lmax, fsyn.nu_pixels)
+    if pol == "full":
+        cv_fg[:, 1, :, 1, :] = skysim.clarray(fpol.angular_powerspectrum, lmax, fsyn.nu_pixels)
+        cv_fg[:, 2, :, 2, :] = skysim.clarray(fpol.angular_powerspectrum, lmax, fsyn.nu_pixels)
+    cv_fg = cv_fg.reshape(lmax + 1, npol * nfreq, npol * nfreq)
     rng = np.random.default_rng(seed) if seed is not None else None
-    alms = skysim.mkfullsky(cv_fg, nside, alms=True, rng=rng).reshape(1, nfreq, lmax + 1, lmax + 1)
-    maps = hputil.sphtrans_inv_sky(alms.transpose((1, 0, 2, 3)), nside)               # [nfreq, 1, npix]
-    write_map(filename, maps[:, 0], fsyn.frequencies, fstate.freq_width, pol != "none")
+    alms = skysim.mkfullsky(cv_fg, nside, alms=True, rng=rng).reshape(npol, nfreq, lmax + 1, lmax + 1)
+    maps = hputil.sphtrans_inv_sky(alms.transpose((1, 0, 2, 3)), nside)               # [nfreq, npol, npix]
+    write_map(filename, maps if pol == "full" else maps[:, 0], fsyn.frequencies, fstate.freq_width, pol != "none")
 
 
 @cli.command()

@@ -778,8 +778,16 @@ def test_makesky_cli_21cm_and_gaussianfg(tmp_path):
     assert g["map"].shape == (3, 1, 768) and np.isfinite(g["map"]).all() and g["map"].std() > 0
     # brighter at low frequency (synchrotron spectral index -2.8)
     assert g["map"][0].std() > g["map"][2].std()
-    r = CliRunner().invoke(makesky.cli, ["gaussianfg", "--nside", "8", "--pol", "full"])
-    assert r.exit_code != 0 and "spin-2" in r.output
+    # --pol full: T from the unpolarised model, Q/U from E/B draws of the polarised one through the spin-2 synthesis
+    out3 = str(tmp_path / "fgpol.h5")
+    r = CliRunner().invoke(makesky.cli, ["gaussianfg", "--nside", "8", "--freq", "400", "800", "2", "--freq-mode", "edge",
+                                         "--pol", "full", "--seed", "5", "--filename", out3])
+    assert r.exit_code == 0, r.output
+    h = np.load(out3 + ".npz")
+    assert h["map"].shape == (2, 4, 768) and np.isfinite(h["map"]).all()
+    st = h["map"].std(axis=-1)
+    assert np.all(st[:, 1] > 0) and np.all(st[:, 2] > 0) and np.all(st[:, 1:3] < st[:, :1])      # Q, U present, fainter than T
+    assert np.all(st[:, 3] < 1e-5 * st[:, 0])                    # V: only the 1e-14 diagonal jitter of mkfullsky
     del galaxy
 
 
