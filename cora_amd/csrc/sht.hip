@@ -1758,6 +1758,13 @@ int corahip_sht_plan_create(corahip_ctx *ctx, int nside, int lmax, corahip_sht_p
     ARG_CHECK(lmax >= 0 && lmax <= 16384);
     HIP_TRY(hipSetDevice(ctx->device));
     corahip_sht_plan *p = new corahip_sht_plan();
+    // every early return below (HIP_TRY / rc checks) releases what was allocated so far
+    struct plan_guard {
+        corahip_sht_plan *p;
+        ~plan_guard() {
+            if (p) corahip_sht_plan_destroy(nullptr, p);
+        }
+    } guard{p};
     p->nside = nside;
     p->lmax = lmax;
     p->L = lmax + 1;
@@ -1949,6 +1956,7 @@ int corahip_sht_plan_create(corahip_ctx *ctx, int nside, int lmax, corahip_sht_p
         }
     }
     HIP_TRY(hipStreamSynchronize(s));
+    guard.p = nullptr;
     *out = p;
     return 0;
 }
