@@ -50,6 +50,45 @@ def ang2pix(nside, theta, phi, lonlat=False):
     return out if out.ndim else int(out)
 
 
+def pix2ang(nside, ipix):
+    """(theta, phi) of RING pixel centres (what the reference takes from ``healpy.pix2ang``): caps
+    z = 1 - i^2/(3 nside^2), phi = (j + 1/2) pi/(2 i); belt z = 4/3 - 2 i/(3 nside), phi = (j + s/2) pi/(2 nside)."""
+    nside = int(nside)
+    ipix = np.asarray(ipix, dtype=np.int64)
+    npix = 12 * nside * nside
+    ncap = 2 * nside * (nside - 1)
+    p = np.where(ipix >= npix - ncap, npix - 1 - ipix, ipix)             # mirror the south cap onto the north
+    # north cap: ring i (1-based) holds pixels 2 i (i - 1) .. 2 i (i + 1) - 1
+    i_cap = ((1 + np.sqrt(1 + 2 * np.minimum(p, max(ncap - 1, 0)).astype(np.float64))) / 2).astype(np.int64)
+    i_cap = np.where(2 * i_cap * (i_cap - 1) > p, i_cap - 1, i_cap)
+    i_cap = np.where(2 * i_cap * (i_cap + 1) <= p, i_cap + 1, i_cap)
+    i_cap = np.maximum(i_cap, 1)
+    j_cap = p - 2 * i_cap * (i_cap - 1)
+    z_cap = 1.0 - i_cap.astype(np.float64) ** 2 / (3.0 * nside * nside)
+    phi_cap = (j_cap + 0.5) * np.pi / (2.0 * i_cap)
+    # equatorial belt
+    pb = ipix - ncap
+    i_b = pb // (4 * nside) + nside
+    j_b = pb % (4 * nside)
+    s_b = (i_b - nside + 1) & 1
+    z_b = 4.0 / 3.0 - 2.0 * i_b / (3.0 * nside)
+    phi_b = (j_b + 0.5 * s_b) * np.pi / (2.0 * nside)
+    in_n = ipix < ncap
+    in_s = ipix >= npix - ncap
+    z = np.where(in_n, z_cap, np.where(in_s, -z_cap, z_b))
+    # a mirrored south-cap pixel runs backwards in phi on its ring
+    phi = np.where(in_n, phi_cap, np.where(in_s, 2.0 * np.pi - phi_cap, phi_b))
+    return np.arccos(z), phi
+
+
+def ang_positions(nside):
+    """Angular position [theta, phi] of every pixel: [npix, 2] (cora/util/hputil.py:53-73)."""
+    npix = nside2npix(int(nside))
+    angpos = np.empty([npix, 2], dtype=np.float64)
+    angpos[:, 0], angpos[:, 1] = pix2ang(nside, np.arange(npix))
+    return angpos
+
+
 def nside_for_lmax(lmax, accuracy_boost=1):
     """cora/util/hputil.py:76-90."""
     return int(2 ** (accuracy_boost + np.ceil(np.log((lmax + 1) / 3.0) / np.log(2.0))))

@@ -302,6 +302,10 @@ def test_ang2pix_inverts_pix2ang():
     for ns in (1, 2, 8, 32):
         th, ph = healpix.pix2ang_ring(ns)
         assert np.array_equal(hputil.ang2pix(ns, th, ph), np.arange(12 * ns * ns))
+        # the package's own pix2ang / ang_positions (hputil.py:53-73) against the oracle geometry, and round trip
+        ap = hputil.ang_positions(ns)
+        assert ap.shape == (12 * ns * ns, 2) and np.abs(ap[:, 0] - th).max() < 1e-14 and np.abs(ap[:, 1] - ph).max() < 1e-14
+        assert np.array_equal(hputil.ang2pix(ns, ap[:, 0], ap[:, 1]), np.arange(12 * ns * ns))
 
 
 def test_cubicspline_array_entry_points():
