@@ -2,7 +2,7 @@
 //
 // Replaces nputil.complex_std_normal (cora/util/nputil.py:104-125) in its device
 // (counter-based) form and the np.dot of cora/core/skysim.py:121, writing a_lm in
-// the device layout consumed by the synthesis ([nalm][g][c][v], see sht.hip).
+// the device layout consumed by the synthesis ([nalm][g][c][v], see sht_internal.h).
 //
 // K3 is one FP64 MFMA GEMM per l: C[(c,m)][nu] = sum_nu' G[(c,m)][nu'] * T_l[nu][nu'],
 // rows = the 2(l+1) real/imag normal vectors of that l, cols = channels.  T_l is staged
@@ -255,7 +255,7 @@ draw_kernel(const double *__restrict__ T, size_t t_ldl, int t_row0, const int32_
 // read.  Wave tile = 32 rows (16 m-pairs of one c: the two Box-Muller outputs feed the even-m and the
 // odd-m row tile) x 16*NCT channels; workgroup = 4 waves = 128 rows.
 // ------------------------------------------------------------------------------------
-// LDS-DMA of 16 bytes per lane from inline asm (see sht.hip: hipcc would drain a builtin DMA with
+// LDS-DMA of 16 bytes per lane from inline asm (see sht_internal.h: hipcc would drain a builtin DMA with
 // vmcnt(0) before every later ds_read); lane i's bytes land at lds_byte_addr + 16 i.
 __device__ static inline void draw_glds16(const void *gsrc, unsigned lds_byte_addr) {
     unsigned keep;

@@ -1,0 +1,194 @@
+// sht_analysis.hip - K4^T: the adjoint Legendre contraction of healpy.map2alm's quadrature pass on FP64 MFMA and the
+// deterministic reduction over ring tiles.  See sht_internal.h.
+#include "sht_internal.h"
+
+// K4^T  legendre_adj_kernel: a_lm(col) = sum_rings lambda_lm(ring) [G_m(north) + (-1)^{l+m} G_m(south)](col)
+// on FP64 MFMA with M = l, K = ring pairs, N = columns (channel re/im).  Work item = (m, 16 NCT columns,
+// tile of 512 ring pairs).  A wave owns 64 ring pairs: lane = ring steps the recurrence once per l (no
+// redundancy), the 32 lambda values of an l-block go through a wave-private LDS transpose into the A-operand
+// layout (16 same-parity l x 4 rings), and the wave's G tile (64 rings x 16 NCT columns, even = N+S and
+// odd = N-S combinations) stays in REGISTERS as the B operand for the whole item.  The eight waves hold
+// different rings, so their [32 l x 16 NCT] partial sums are added through LDS once per l-block; the four
+// ring tiles of an (m, column group) go to separate partial buffers summed by alm_reduce_kernel
+// (deterministic - no atomics).
+template <int NCT>
+__global__ void __launch_bounds__(512)
+legendre_adj_kernel(int lmax, int npair, int nring, int ncols, const double *__restrict__ z,
+                    const double2 *__restrict__ coef, const int32_t *__restrict__ lstart,
+                    const double2 *__restrict__ seed, const int32_t *__restrict__ lmin_tab,
+                    const int32_t *__restrict__ mcut, const double *__restrict__ inter, double *__restrict__ part,
+                    unsigned *__restrict__ queue) {
+    constexpr int TCOLS = 16 * NCT;
+    constexpr int TRINGS = 64 * ADJ_WAVES;     // 512 ring pairs per workgroup
+    constexpr int LB = 32;                     // l per block: 16 even + 16 odd (l - m)
+    constexpr int LSTR = LB + 1;               // LDS row stride of the transpose: conflict-free both ways
+    constexpr int WREG = 64 * LSTR;            // doubles per wave
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    int &s_next = *reinterpret_cast<int *>(lds + ADJ_WAVES * WREG);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int ri = lane & 15, kq = lane >> 4;
+    const int L = lmax + 1;
+    const int G = ncols >> 3;
+    const long nalm = nalm_of(lmax);
+    const int ntile128 = (npair + LMIN_RINGS - 1) / LMIN_RINGS;
+    const int ntile = (npair + TRINGS - 1) / TRINGS;
+    const int ncg = ncols / TCOLS;
+    const int nitems = L * ncg * ntile;
+    double *lamw = lds + wave * WREG;
+
+    int item = blockIdx.x;
+    while (item < nitems) {
+        if (tid == 0) s_next = (int)(gridDim.x + atomicAdd(queue, 1u));
+        const int gidx = item / ntile;
+        const int rtile = item - gidx * ntile;
+        const int m = gidx / ncg;
+        const int cg = gidx - m * ncg;
+        int lmin = lmax + 1;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int t128 = rtile * 4 + q;
+            if (t128 < ntile128) lmin = min(lmin, lmin_tab[m * ntile128 + t128]);
+        }
+        const long base_m = alm_idx(0, m, lmax);
+        const int lb0 = lmin <= lmax ? m + ((lmin - m) & ~(LB - 1)) : lmax + 1;
+        double *pout = part + ((size_t)rtile * nalm + base_m) * ncols + (size_t)cg * TCOLS;
+        // multipoles this tile cannot reach contribute zero
+        for (int e = tid; e < (lb0 - m) * TCOLS; e += 512) pout[(size_t)(m + e / TCOLS) * ncols + e % TCOLS] = 0.0;
+
+        if (lb0 <= lmax) {
+            // ---- this wave's G tile -> registers (B operand): k-step s covers rings 4s..4s+3 of the wave
+            double ge[16][NCT], go[16][NCT];
+#pragma unroll
+            for (int s = 0; s < 16; s++) {
+                const int ro = rtile * TRINGS + (4 * s + kq) * ADJ_WAVES + wave;
+                const bool ok = ro < npair && m < mcut[min(ro, npair - 1)];
+                const int rs = nring - 1 - ro;
+#pragma unroll
+                for (int t = 0; t < NCT; t++) {
+                    const int col = cg * TCOLS + 16 * t + ri;
+                    const size_t off = ((size_t)(col >> 3) * L + m) * 8 + (col & 7);
+                    double gn = 0.0, gsv = 0.0;
+                    if (ok) {
+                        gn = inter[(size_t)ro * G * L * 8 + off];
+                        if (rs != ro) gsv = inter[(size_t)rs * G * L * 8 + off];
+                    }
+                    ge[s][t] = gn + gsv;
+                    go[s][t] = gn - gsv;
+                }
+            }
+            // ---- recurrence state of this lane's ring
+            const int ring = rtile * TRINGS + lane * ADJ_WAVES + wave;
+            double x = 0.0, p0 = 0.0, p1 = 0.0;
+            double2 sd = make_double2(0.0, 0.0);
+            int my_ls = lmax + 1;
+            if (ring < npair) {
+                x = z[ring];
+                const long o = (long)m * npair + ring;
+                my_ls = lstart[o];
+                sd = seed[o];
+            }
+            // first l of each group of 4 lanes (= one MFMA k-step): lets whole k-steps be skipped
+            int ls4 = min(my_ls, __shfl_xor(my_ls, 1));
+            ls4 = min(ls4, __shfl_xor(ls4, 2));
+            const double2 *cf = coef + base_m;
+
+            for (int lb = lb0; lb <= lmax; lb += LB) {
+                const unsigned long long act = __ballot(ls4 <= lb + LB - 1);   // bit 4s: k-step s has a started ring
+                // lambda_{lb .. lb+31} of this lane's ring -> transpose buffer [ring][l - lb]
+                // (coefficients are read unconditionally - the table is padded by 32 entries - so that the scalar
+                // loads of a whole unrolled group are issued together; rows past lmax are discarded below)
+#pragma unroll 8
+                for (int j = 0; j < LB; j++) {
+                    const int l = lb + j;
+                    const double2 c = cf[l];
+                    double vv = fma(c.x * x, p1, -(c.y * p0));
+                    const bool inj = (l == my_ls);
+                    vv = inj ? sd.y : vv;
+                    p0 = inj ? sd.x : p1;
+                    p1 = vv;
+                    lamw[lane * LSTR + j] = vv;
+                }
+                d4_t acc[2][NCT];
+#pragma unroll
+                for (int par = 0; par < 2; par++)
+#pragma unroll
+                    for (int t = 0; t < NCT; t++) acc[par][t] = (d4_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int s = 0; s < 16; s++) {
+                    if (!((act >> (4 * s)) & 1ull)) continue;
+                    const double ae = lamw[(4 * s + kq) * LSTR + 2 * ri];
+                    const double ao = lamw[(4 * s + kq) * LSTR + 2 * ri + 1];
+#pragma unroll
+                    for (int t = 0; t < NCT; t++) {
+                        acc[0][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(ae, ge[s][t], acc[0][t], 0, 0, 0);
+                        acc[1][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(ao, go[s][t], acc[1][t], 0, 0, 0);
+                    }
+                }
+                // ---- add the eight waves' partial tiles through LDS (the wave's transpose buffer is free now:
+                //      LDS operations of one wave are ordered)
+#pragma unroll
+                for (int par = 0; par < 2; par++)
+#pragma unroll
+                    for (int t = 0; t < NCT; t++)
+#pragma unroll
+                        for (int r = 0; r < 4; r++) lamw[((par * NCT + t) * 4 + r) * 64 + lane] = acc[par][t][r];
+                __syncthreads();
+#pragma unroll
+                for (int u = 0; u < NCT; u++) {
+                    const int e = tid + 512 * u;          // element (par, t, r, lane) of the reduced tile
+                    double sum = 0.0;
+#pragma unroll
+                    for (int w = 0; w < ADJ_WAVES; w++) sum += lds[w * WREG + e];
+                    const int el = e & 63, r = (e >> 6) & 3, t = (e >> 8) % NCT, par = (e >> 8) / NCT;
+                    const int l = lb + 2 * ((el >> 4) + 4 * r) + par;
+                    if (l <= lmax) pout[(size_t)l * ncols + 16 * t + (el & 15)] = sum;
+                }
+                __syncthreads();
+            }
+        }
+        __syncthreads();
+        item = __builtin_amdgcn_readfirstlane(s_next);
+        __syncthreads();
+    }
+}
+
+// alm_dev[idx][col] = sum over ring tiles of part[rt][idx][col]
+__global__ void alm_reduce_kernel(const double *__restrict__ part, long n, int ntile, double *__restrict__ alm) {
+    for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (long)gridDim.x * blockDim.x) {
+        double s = 0.0;
+        for (int t = 0; t < ntile; t++) s += part[(size_t)t * n + q];
+        alm[q] = s;
+    }
+}
+template <int NCT>
+static int launch_legendre_adj(corahip_ctx *ctx, const corahip_sht_plan *p, int ncols, const double *inter,
+                               double *part) {
+    const size_t shm = sizeof(double) * (size_t)ADJ_WAVES * 64 * 33 + 16;
+    HIP_TRY(hipFuncSetAttribute((const void *)legendre_adj_kernel<NCT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)shm));
+    const int ntile = (p->npair + 64 * ADJ_WAVES - 1) / (64 * ADJ_WAVES);
+    const long nitems = (long)p->L * (ncols / (16 * NCT)) * ntile;
+    dim3 grid((unsigned)std::min<long>(nitems, (long)ctx->num_cu));
+    HIP_TRY(hipMemsetAsync(p->d_queue, 0, 64, ctx->stream));
+    legendre_adj_kernel<NCT><<<grid, 512, shm, ctx->stream>>>(p->lmax, p->npair, p->nring, ncols, p->d_z, p->d_coef,
+                                                             p->d_lstart, p->d_seed, p->d_lmin, p->d_mcut, inter, part,
+                                                             p->d_queue);
+    LAUNCH_CHECK();
+    return 0;
+}
+int sht_legendre_adj(corahip_ctx *ctx, const corahip_sht_plan *p, int ncols, const double *inter, double *part,
+                     double *alm_dev) {
+    StageTimer t(ctx, "legendre_adj");
+    const int nt16 = ncols / 16;
+    int rc;
+    if (nt16 % 2 == 0) rc = launch_legendre_adj<2>(ctx, p, ncols, inter, part);
+    else rc = launch_legendre_adj<1>(ctx, p, ncols, inter, part);
+    if (rc) return rc;
+    const int ntile = (p->npair + 64 * ADJ_WAVES - 1) / (64 * ADJ_WAVES);
+    const long n = p->nalm * (long)ncols;
+    alm_reduce_kernel<<<(int)std::min<long>((n + 255) / 256, 8192), 256, 0, ctx->stream>>>(part, n, ntile, alm_dev);
+    LAUNCH_CHECK();
+    return 0;
+}

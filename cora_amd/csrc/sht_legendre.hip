@@ -1,0 +1,613 @@
+// sht_legendre.hip - K4: the Legendre contraction of the synthesis on FP64 MFMA, scalar (legendre_kernel) and
+// spin-2 (legendre_pol_kernel) forms, and their launchers.  See sht_internal.h.
+#include "sht_internal.h"
+
+// Lane roles (wave = 16 rings x 4 k-slots, the A operand of v_mfma_f64_16x16x4_f64):
+// lane (ri = lane&15, kq = lane>>4) runs the recurrence of ring ri STAGGERED by 2 kq steps, so that
+// at every macro-step (8 consecutive l, base l0) the first two values it produces are exactly the
+// ones its k-slot must feed: lambda at l0+2kq (even l-m -> north+south accumulator) and l0+2kq+1
+// (odd).  No cross-lane movement, no selects; the price is that the recurrence coefficients are
+// no longer wave-uniform (4 distinct rows per step) - they are staged through LDS with the a_lm
+// rows and read with one broadcast ds_read_b128 per step.
+// NT = 16-column tiles per wave, RT = 16-ring row tiles per wave (RT x NT x 2 parities = 16 accumulator
+// tiles = 128 VGPRs in both shipped shapes: <8,1> for >= 128 columns, <4,2> for 64-column shards, where a
+// second, independent recurrence per lane keeps the recurrence : MFMA ratio of the wide shape).
+template <int NT, int RT>
+__global__ void __launch_bounds__(64 * LEG_WAVES, LEG_WAVES <= 4 ? 2 : 1)
+legendre_kernel(int lmax, int npair, int nring, int ncols, const double *__restrict__ z,
+                const double2 *__restrict__ coef, const int32_t *__restrict__ lstart,
+                const double2 *__restrict__ seed, const int32_t *__restrict__ lmin_tab,
+                const double *__restrict__ alm, const double *__restrict__ zeros, double *__restrict__ inter,
+                unsigned *__restrict__ queue) {
+    constexpr int TCOLS = 16 * NT;          // columns of this block
+    constexpr int STRIDE = TCOLS + 8;       // LDS row stride (doubles): 2 rows apart = 128 B mod 256
+    constexpr int CROWS = LEG_KT + 8;       // coefficient rows per stage (staggered lanes look 6 ahead)
+    constexpr int STAGE = LEG_KT * STRIDE + 2 * CROWS;  // doubles per stage: a_lm rows + (A,B) pairs
+    constexpr int RPW = LEG_KT / LEG_WAVES;             // a_lm rows each wave moves per stage
+    constexpr int PIECES = RPW + 1;                     // LDS-DMA pieces per wave per stage (+ coefficients)
+    constexpr int TRINGS = LEG_RINGS * RT;              // ring pairs per workgroup
+    constexpr int RPM = RPW / (LEG_KT / 8);             // a_lm pieces each wave issues per macro-step
+    static_assert(RPM * (LEG_KT / 8) == RPW && RPM >= 1, "whole a_lm pieces per macro-step");
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    int &s_next = *reinterpret_cast<int *>(lds + LEG_NBUF * STAGE);  // next work item (carved after the ring)
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    const int ri = lane & 15, kq = lane >> 4;
+    const int d = 2 * kq;
+    const int L = lmax + 1;
+    const int G = ncols >> 3;
+    const int ntile128 = (npair + LMIN_RINGS - 1) / LMIN_RINGS;   // granularity of lmin_tab
+    const int ntile = (npair + TRINGS - 1) / TRINGS;
+    const int ncg = ncols / TCOLS;
+    const int nitems = L * ncg * ntile;
+    const long last_row = nalm_of(lmax) - 1;
+    const unsigned lds_base_bytes = (unsigned)(size_t)(__attribute__((address_space(3))) double *)lds;
+    const bool odd_lane = lane & 1;
+
+    // Persistent workgroups.  Work item = (m, column group, ring tile); consecutive items are the ring
+    // tiles of one a_lm slice, so the workgroups running at the same time share slices in L2 (they are
+    // dealt over all 8 XCDs; packing a slice group onto ONE XCD was measured 24 % slower: every resident
+    // workgroup of the XCD then hits the same 1-2 L2 channels in lock step).  Small m (long K) first.
+    struct item_t {
+        int m, cg, rtile, l_begin, nstage;
+        long base_m;
+    };
+    auto decode = [&](int it) {
+        item_t w;
+        const int gidx = it / ntile;
+        w.rtile = it - gidx * ntile;
+        w.m = gidx / ncg;
+        w.cg = gidx - w.m * ncg;
+        int lmin = lmax + 1;
+        const int t_first = (w.rtile * TRINGS) / LMIN_RINGS;
+        const int t_last = min((w.rtile * TRINGS + TRINGS - 1) / LMIN_RINGS, ntile128 - 1);
+        for (int t128 = t_first; t128 <= t_last; t128++) lmin = min(lmin, lmin_tab[w.m * ntile128 + t128]);
+        w.l_begin = w.m + ((lmin - w.m) & ~7);
+        w.nstage = lmin <= lmax ? (lmax - w.l_begin) / LEG_KT + 1 : 0;
+        w.base_m = alm_idx(0, w.m, lmax);
+        return w;
+    };
+    // LDS-DMA pieces: every wave issues exactly PIECES per stage (counted vmcnt): RPW a_lm rows (rows past
+    // lmax are never used - their lambda is 0 - so any valid row is read, keeping the address scalar) and
+    // the CROWS coefficient pairs (all waves write the same bytes).
+    auto issue_row = [&](const item_t &w, int st, int rr) {
+        const int row = wv + LEG_WAVES * rr;
+        long rowidx = w.base_m + w.l_begin + st * LEG_KT + row;
+        rowidx = rowidx < last_row ? rowidx : last_row;
+        const double *src = alm + (size_t)w.cg * TCOLS + (size_t)rowidx * ncols + 2 * lane;
+        const unsigned dst = lds_base_bytes + (unsigned)(((st % LEG_NBUF) * STAGE + row * STRIDE) * sizeof(double));
+        if (lane < 8 * NT) glds16(src, dst);
+    };
+    auto issue_coef = [&](const item_t &w, int st) {
+        const int l = w.l_begin + st * LEG_KT + lane;
+        const double *src = (l <= lmax) ? reinterpret_cast<const double *>(coef + w.base_m + l) : zeros;
+        const unsigned dst = lds_base_bytes + (unsigned)(((st % LEG_NBUF) * STAGE + LEG_KT * STRIDE) * sizeof(double));
+        if (lane < CROWS) glds16(src, dst);
+    };
+    auto issue_stage = [&](const item_t &w, int st) {
+        issue_coef(w, st);
+#pragma unroll
+        for (int rr = 0; rr < RPW; rr++) issue_row(w, st, rr);
+    };
+
+    // dynamic work queue (one atomic per item, fetched one item ahead): items differ a lot in length
+    // (polar ring tiles start late, large m is short), a static assignment left ~10 % on the table
+    int item = blockIdx.x;  // the first gridDim.x items are pre-assigned; the queue starts behind them
+    if (item >= nitems) return;
+    item_t w = decode(item);
+#pragma unroll
+    for (int st = 0; st < LEG_NBUF - 1; st++)
+        if (st < w.nstage) issue_stage(w, st);
+
+    for (;;) {
+        const int m = w.m;
+        if (tid == 0) s_next = (int)(gridDim.x + atomicAdd(queue, 1u));  // latency hidden behind this item
+        d4_t acce[RT][NT], acco[RT][NT];
+#pragma unroll
+        for (int q = 0; q < RT; q++)
+#pragma unroll
+            for (int t = 0; t < NT; t++) {
+                acce[q][t] = (d4_t){0.0, 0.0, 0.0, 0.0};
+                acco[q][t] = (d4_t){0.0, 0.0, 0.0, 0.0};
+            }
+        if (w.nstage > 0) {
+            // rings are dealt to the waves interleaved (ring = tile base + 8 (ri + 16 q) + wave) so that every
+            // wave of the workgroup has the same mix of first-contributing l and reaches the barriers together
+            double x[RT], p0[RT], p1[RT];
+            double2 sd[RT];
+            int my_ls[RT], inj_l[RT];
+            const double2 *cf = coef + w.base_m;
+            int ls_min = lmax + 1;
+#pragma unroll
+            for (int q = 0; q < RT; q++) {
+                const int ring = w.rtile * TRINGS + (ri + 16 * q) * LEG_WAVES + wave;
+                x[q] = 0.0;
+                my_ls[q] = lmax + 1;
+                sd[q] = make_double2(0.0, 0.0);
+                if (ring < npair) {
+                    x[q] = z[ring];
+                    const long o = (long)m * npair + ring;
+                    my_ls[q] = lstart[o];
+                    sd[q] = seed[o];
+                }
+                ls_min = min(ls_min, my_ls[q]);
+                // per-lane start state: (lambda_{lf-2}, lambda_{lf-1}) with lf = l_begin + d the first l of this
+                // lane.  If the ring's first contributing l lies before lf, advance from the seeds.
+                p0[q] = 0.0;
+                p1[q] = 0.0;
+                inj_l[q] = my_ls[q];  // l at which the seeds are injected
+                const int lf = w.l_begin + d;
+                if (my_ls[q] < lf) {
+                    p0[q] = sd[q].x;
+                    p1[q] = sd[q].y;
+                    for (int l = my_ls[q] + 1; l < lf; l++) {
+                        const double2 c = (l <= lmax) ? cf[l] : make_double2(0.0, 0.0);
+                        const double vv = fma(c.x * x[q], p1[q], -(c.y * p0[q]));
+                        p0[q] = p1[q];
+                        p1[q] = vv;
+                    }
+                    inj_l[q] = 0x7fffffff;
+                }
+            }
+
+            for (int st = 0; st < w.nstage; st++) {
+                // own pieces of stage st have landed when at most the pieces of the (up to LEG_NBUF-2) younger
+                // stages are still in flight (anything younger than those only makes the wait stricter)
+                if (LEG_NBUF >= 4 && st + 2 < w.nstage) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PIECES) : "memory");
+                else if (LEG_NBUF >= 3 && st + 1 < w.nstage) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();  // everyone's pieces of stage st landed; everyone is done reading stage st-1
+                const bool refill = st + LEG_NBUF - 1 < w.nstage;
+                if (refill) issue_coef(w, st + LEG_NBUF - 1);
+                const int ls = w.l_begin + st * LEG_KT;
+                const double *sb = lds + (st % LEG_NBUF) * STAGE;
+                const double2 *sc = reinterpret_cast<const double2 *>(sb + LEG_KT * STRIDE) + d;
+#pragma unroll 1
+                for (int ms = 0; ms < LEG_KT / 8; ms++) {
+                    // one a_lm piece of the stage being refilled per macro-step: spreads the LDS-DMA issue
+                    // over the MFMA work instead of an 8-wave burst behind the barrier (measured 7 % of time)
+                    if (refill) {
+#pragma unroll
+                        for (int r = 0; r < RPM; r++) issue_row(w, st + LEG_NBUF - 1, ms * RPM + r);
+                    }
+                    const int l0 = ls + 8 * ms;
+                    if (l0 > lmax) continue;
+                    // nothing of this wave starts before l0+14: skip the macro-step entirely
+                    if (__all(ls_min > l0 + 13)) continue;
+                    double ae[RT], ao[RT];
+#if LEG_ABLATE == 2  // diagnostic: no recurrence
+#pragma unroll
+                    for (int q = 0; q < RT; q++) {
+                        ae[q] = x[q];
+                        ao[q] = x[q] + 1.0;
+                        asm volatile("" : "+v"(ae[q]), "+v"(ao[q]));
+                    }
+#else
+                    __builtin_amdgcn_s_setprio(2);  // the short recurrence outranks the partner wave's MFMAs
+                    double2 c[8];
+#pragma unroll
+                    for (int j = 0; j < 8; j++) c[j] = sc[8 * ms + j];
+                    const int lf = l0 + d;
+                    bool any_inj = false;
+#pragma unroll
+                    for (int q = 0; q < RT; q++) any_inj |= (inj_l[q] >= lf && inj_l[q] < lf + 8);
+                    if (__any(any_inj)) {
+#pragma unroll
+                        for (int q = 0; q < RT; q++) {
+#pragma unroll
+                            for (int j = 0; j < 8; j++) {
+                                double vv = fma(c[j].x * x[q], p1[q], -(c[j].y * p0[q]));
+                                const bool inj = (lf + j == inj_l[q]);
+                                vv = inj ? sd[q].y : vv;
+                                p0[q] = inj ? sd[q].x : p1[q];
+                                p1[q] = vv;
+                                if (j == 0) ae[q] = vv;
+                                if (j == 1) ao[q] = vv;
+                            }
+                        }
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 8; j++) {
+#pragma unroll
+                            for (int q = 0; q < RT; q++) {
+                                const double vv = fma(c[j].x * x[q], p1[q], -(c[j].y * p0[q]));
+                                p0[q] = p1[q];
+                                p1[q] = vv;
+                                if (j == 0) ae[q] = vv;
+                                if (j == 1) ao[q] = vv;
+                            }
+                        }
+                    }
+                    __builtin_amdgcn_s_setprio(0);
+#endif
+                    if (__all(ls_min > l0 + 7)) continue;  // all A operands of this macro-step are zero
+                    const double *be = sb + (8 * ms + d) * STRIDE + ri;
+                    const double *bo = be + STRIDE;
+#if LEG_ABLATE == 1  // diagnostic: no MFMA (keep the operands alive)
+                    asm volatile("" ::"v"(ae[0]), "v"(ao[0]), "v"(be), "v"(bo));
+#else
+#pragma unroll
+                    for (int t = 0; t < NT; t++) {
+#if LEG_ABLATE == 3  // diagnostic: no B operand reads from LDS
+                        const double bev = ae[0] + t, bov = ao[0] - t;
+                        asm volatile("" ::"v"(be), "v"(bo));
+#else
+                        const double bev = be[16 * t], bov = bo[16 * t];
+#endif
+#pragma unroll
+                        for (int q = 0; q < RT; q++) {
+                            acce[q][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(ae[q], bev, acce[q][t], 0, 0, 0);
+                            acco[q][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(ao[q], bov, acco[q][t], 0, 0, 0);
+                        }
+                    }
+#endif
+                }
+            }
+        }
+
+        // ---- next item: start its first stages now, so they land behind this item's epilogue stores
+        const int cur_rtile = w.rtile, cur_cg = w.cg, cur_m = w.m, cur_nstage = w.nstage;
+        __syncthreads();  // all waves are done reading the stage ring; s_next is visible
+        item = __builtin_amdgcn_readfirstlane(s_next);
+        const bool have_next = item < nitems;
+        if (have_next) {
+            w = decode(item);
+#pragma unroll
+            for (int st = 0; st < LEG_NBUF - 1; st++)
+                if (st < w.nstage) issue_stage(w, st);
+        }
+
+        // ---- epilogue: north = even + odd, south mirror = even - odd.  Adjacent lanes (columns n, n+1 of the
+        //      same rows) swap one value each so that every lane stores 16 bytes: half the store instructions.
+        //      A tile with no contributing l at all is not written: K5 never reads cells with m >= mcut(ring).
+        if (cur_nstage > 0) {
+#pragma unroll
+            for (int q = 0; q < RT; q++)
+#pragma unroll
+                for (int t = 0; t < NT; t++) {
+                    const int col = cur_cg * TCOLS + 16 * t + (ri & ~1);  // even column of the lane pair
+                    const int g = col >> 3, cv = col & 7;
+#pragma unroll
+                    for (int rp = 0; rp < 2; rp++) {
+                        const int r0 = 2 * rp, r1 = 2 * rp + 1;
+                        const double n0 = acce[q][t][r0] + acco[q][t][r0], n1 = acce[q][t][r1] + acco[q][t][r1];
+                        const double s0 = acce[q][t][r0] - acco[q][t][r0], s1 = acce[q][t][r1] - acco[q][t][r1];
+                        // even lane keeps row r0 and sends its r1 value; odd lane keeps row r1 and sends its r0 value
+                        const double nrecv = __shfl_xor(odd_lane ? n0 : n1, 1);
+                        const double srecv = __shfl_xor(odd_lane ? s0 : s1, 1);
+                        const int rr = odd_lane ? r1 : r0;
+                        const int ro = cur_rtile * TRINGS + (kq + 4 * rr + 16 * q) * LEG_WAVES + wave;
+#if LEG_ABLATE == 4  // diagnostic: no epilogue stores (unless a value is absurd: keeps the arithmetic alive)
+                        if (ro < npair && n0 == 1.2345e300) {
+#else
+                        if (ro < npair) {
+#endif
+                            const double2 nv = odd_lane ? make_double2(nrecv, n1) : make_double2(n0, nrecv);
+                            *reinterpret_cast<double2 *>(inter + (((size_t)ro * G + g) * L + cur_m) * 8 + cv) = nv;
+                            const int rs = nring - 1 - ro;
+                            if (rs != ro) {
+                                const double2 sv = odd_lane ? make_double2(srecv, s1) : make_double2(s0, srecv);
+                                *reinterpret_cast<double2 *>(inter + (((size_t)rs * G + g) * L + cur_m) * 8 + cv) = sv;
+                            }
+                        }
+                    }
+                }
+        }
+        if (!have_next) break;
+        __syncthreads();  // everyone has read s_next before thread 0 overwrites it
+    }
+}
+
+// K4 for polarisation (spin 2): (E, B) -> (Q, U), what healpy.alm2map([T, E, B]) does for Q and U behind
+// hputil.sphtrans_inv_real_pol (cora/util/hputil.py:394-432).  Same structure as legendre_kernel (persistent
+// workgroups + queue, staggered-lane recurrence, LDS-DMA stage ring, even/odd parity accumulators), with the two
+// A operands per parity derived from the scalar recurrence:
+//     W_lm = (g1 r1 + g2) lambda_l + g3 r2 lambda_{l-1},     X_lm = g4 r2 lambda_l - m g3 r1 lambda_{l-1},
+//     r1 = 1/sin^2, r2 = cos/sin^2 per ring (lane),  (g1..g4)(l, m) from the plan's table (staged through LDS):
+//     g1 = -N2 (l - m^2), g2 = -N2 l(l-1)/2, g3 = N2 (2l+1)/A_l, g4 = N2 m (l-1), N2 = 2/sqrt((l+2)(l+1)l(l-1)).
+// The kernel accumulates S_W = sum_l W a and S_X = sum_l X a for the natural columns; channels are interleaved
+// (E_f, B_f) so that one a_lm cell [re x4 | im x4] holds (Re E, Re B, .., Im E, Im B, ..) and
+//     Re Q = -(S_W[ReE] + S_X[ImB]),  Im Q = -(S_W[ImE] - S_X[ReB]),  Re U = -(S_W[ReB] - S_X[ImE]),  Im U = -(S_W[ImB] + S_X[ReE])
+// is a lane-xor-5 exchange in the epilogue; Q_f, U_f leave in the cell positions of E_f, B_f.  W has the parity
+// (-1)^{l+m} of lambda under theta -> pi - theta, X the opposite: north = (W_e + W_o, X_e + X_o), south = (W_e - W_o, X_o - X_e).
+template <int NT>
+__global__ void __launch_bounds__(64 * LEG_WAVES)
+legendre_pol_kernel(int lmax, int npair, int nring, int ncols, const double *__restrict__ z,
+                    const double *__restrict__ sth, const double2 *__restrict__ coef,
+                    const double *__restrict__ polc, const int32_t *__restrict__ lstart,
+                    const double2 *__restrict__ seed, const int32_t *__restrict__ lmin_tab,
+                    const double *__restrict__ alm, const double *__restrict__ zeros, double *__restrict__ inter,
+                    unsigned *__restrict__ queue) {
+    constexpr int KT = 32;                  // l rows per stage (the 4 accumulator sets leave room for NT = 4 only)
+    constexpr int NBUF = 3;
+    constexpr int TCOLS = 16 * NT;
+    constexpr int STRIDE = TCOLS + 8;
+    constexpr int CROWS = KT + 8;
+    constexpr int STAGE = KT * STRIDE + 2 * CROWS + 4 * CROWS;   // a_lm rows + (A, B) pairs + (g1..g4) rows
+    constexpr int RPW = KT / LEG_WAVES;
+    constexpr int PIECES = RPW + 3;         // a_lm rows + the (A, B) piece + two pieces of the g table (see issue_coef)
+    constexpr int TRINGS = LEG_RINGS;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    int &s_next = *reinterpret_cast<int *>(lds + NBUF * STAGE);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    const int ri = lane & 15, kq = lane >> 4;
+    const int d = 2 * kq;
+    const int L = lmax + 1;
+    const int G = ncols >> 3;
+    const int ntile128 = (npair + LMIN_RINGS - 1) / LMIN_RINGS;
+    const int ntile = (npair + TRINGS - 1) / TRINGS;
+    const int ncg = ncols / TCOLS;
+    const int nitems = L * ncg * ntile;
+    const long last_row = nalm_of(lmax) - 1;
+    const unsigned lds_base_bytes = (unsigned)(size_t)(__attribute__((address_space(3))) double *)lds;
+
+    struct item_t {
+        int m, cg, rtile, l_begin, nstage;
+        long base_m;
+    };
+    auto decode = [&](int it) {
+        item_t w;
+        const int gidx = it / ntile;
+        w.rtile = it - gidx * ntile;
+        w.m = gidx / ncg;
+        w.cg = gidx - w.m * ncg;
+        int lmin = lmax + 1;
+        const int t_first = (w.rtile * TRINGS) / LMIN_RINGS;
+        const int t_last = min((w.rtile * TRINGS + TRINGS - 1) / LMIN_RINGS, ntile128 - 1);
+        for (int t128 = t_first; t128 <= t_last; t128++) lmin = min(lmin, lmin_tab[w.m * ntile128 + t128]);
+        w.l_begin = w.m + ((lmin - w.m) & ~7);
+        w.nstage = lmin <= lmax ? (lmax - w.l_begin) / KT + 1 : 0;
+        w.base_m = alm_idx(0, w.m, lmax);
+        return w;
+    };
+    auto issue_row = [&](const item_t &w, int st, int rr) {
+        const int row = wv + LEG_WAVES * rr;
+        long rowidx = w.base_m + w.l_begin + st * KT + row;
+        rowidx = rowidx < last_row ? rowidx : last_row;
+        const double *src = alm + (size_t)w.cg * TCOLS + (size_t)rowidx * ncols + 2 * lane;
+        const unsigned dst = lds_base_bytes + (unsigned)(((st % NBUF) * STAGE + row * STRIDE) * sizeof(double));
+        if (lane < 8 * NT) glds16(src, dst);
+    };
+    // coefficient pieces of a stage: CROWS (A, B) pairs (16 B each) and CROWS (g1..g4) rows (32 B each = 2 CROWS
+    // 16-byte chunks, contiguous in the table): 1 + 2 wave-instructions (CROWS = 40: 40 + 80 lanes)
+    auto issue_coef = [&](const item_t &w, int st) {
+        const int l0 = w.l_begin + st * KT;
+        const int l = l0 + lane;
+        const double *src = (l <= lmax) ? reinterpret_cast<const double *>(coef + w.base_m + l) : zeros;
+        const unsigned dst = lds_base_bytes + (unsigned)(((st % NBUF) * STAGE + KT * STRIDE) * sizeof(double));
+        if (lane < CROWS) glds16(src, dst);
+        const double *gsrc = polc + 4 * (size_t)(w.base_m + l0);     // the table is padded: rows past the end exist
+        const unsigned gdst = dst + (unsigned)(2 * CROWS * sizeof(double));
+        glds16(gsrc + 2 * lane, gdst);
+        if (lane < 2 * CROWS - 64) glds16(gsrc + 2 * (64 + lane), gdst + 64 * 16);
+    };
+    auto issue_stage = [&](const item_t &w, int st) {
+        issue_coef(w, st);
+#pragma unroll
+        for (int rr = 0; rr < RPW; rr++) issue_row(w, st, rr);
+    };
+
+    int item = blockIdx.x;
+    if (item >= nitems) return;
+    item_t w = decode(item);
+#pragma unroll
+    for (int st = 0; st < NBUF - 1; st++)
+        if (st < w.nstage) issue_stage(w, st);
+
+    for (;;) {
+        const int m = w.m;
+        const double mval = (double)m;
+        if (tid == 0) s_next = (int)(gridDim.x + atomicAdd(queue, 1u));
+        d4_t awe[NT], awo[NT], axe[NT], axo[NT];
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+            awe[t] = (d4_t){0.0, 0.0, 0.0, 0.0};
+            awo[t] = (d4_t){0.0, 0.0, 0.0, 0.0};
+            axe[t] = (d4_t){0.0, 0.0, 0.0, 0.0};
+            axo[t] = (d4_t){0.0, 0.0, 0.0, 0.0};
+        }
+        if (w.nstage > 0) {
+            const int ring = w.rtile * TRINGS + ri * LEG_WAVES + wave;
+            double x = 0.0, r1 = 0.0, r2 = 0.0, p0 = 0.0, p1 = 0.0;
+            double2 sd = make_double2(0.0, 0.0);
+            int my_ls = lmax + 1;
+            if (ring < npair) {
+                x = z[ring];
+                const double s = sth[ring];
+                r1 = 1.0 / (s * s);
+                r2 = x * r1;
+                const long o = (long)m * npair + ring;
+                my_ls = lstart[o];
+                sd = seed[o];
+            }
+            const int ls_min = my_ls;
+            int inj_l = my_ls;
+            const double2 *cf = coef + w.base_m;
+            {
+                const int lf = w.l_begin + d;
+                if (my_ls < lf) {
+                    p0 = sd.x;
+                    p1 = sd.y;
+                    for (int l = my_ls + 1; l < lf; l++) {
+                        const double2 c = (l <= lmax) ? cf[l] : make_double2(0.0, 0.0);
+                        const double vv = fma(c.x * x, p1, -(c.y * p0));
+                        p0 = p1;
+                        p1 = vv;
+                    }
+                    inj_l = 0x7fffffff;
+                }
+            }
+            for (int st = 0; st < w.nstage; st++) {
+                if (st + 1 < w.nstage) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                const bool refill = st + NBUF - 1 < w.nstage;
+                if (refill) issue_stage(w, st + NBUF - 1);
+                const int ls = w.l_begin + st * KT;
+                const double *sb = lds + (st % NBUF) * STAGE;
+                const double2 *sc = reinterpret_cast<const double2 *>(sb + KT * STRIDE) + d;
+                const double *sg = sb + KT * STRIDE + 2 * CROWS + 4 * d;
+#pragma unroll 1
+                for (int ms = 0; ms < KT / 8; ms++) {
+                    const int l0 = ls + 8 * ms;
+                    if (l0 > lmax) continue;
+                    if (__all(ls_min > l0 + 13)) continue;
+                    double2 c[8];
+#pragma unroll
+                    for (int j = 0; j < 8; j++) c[j] = sc[8 * ms + j];
+                    const int lf = l0 + d;
+                    // lambda at lf-1, lf (even l-m slot of this lane), lf+1 (odd slot); then 6 more steps
+                    double lm1 = p1, le = 0.0, lo = 0.0;
+#pragma unroll
+                    for (int j = 0; j < 8; j++) {
+                        double vv = fma(c[j].x * x, p1, -(c[j].y * p0));
+                        const bool inj = (lf + j == inj_l);
+                        vv = inj ? sd.y : vv;
+                        p0 = inj ? sd.x : p1;
+                        p1 = vv;
+                        if (j == 0) {
+                            le = vv;
+                            lm1 = p0;      // lambda_{lf-1} as the recurrence sees it (the seed if injected here)
+                        }
+                        if (j == 1) lo = vv;
+                    }
+                    double lem1 = lm1, lom1 = le;
+                    if (lf + 1 == inj_l) lom1 = sd.x;
+                    if (__all(ls_min > l0 + 7)) continue;
+                    // W, X at the two l of this lane
+                    const double4 ge = *reinterpret_cast<const double4 *>(sg + 4 * (8 * ms));
+                    const double4 go = *reinterpret_cast<const double4 *>(sg + 4 * (8 * ms + 1));
+                    const double We = fma(fma(ge.x, r1, ge.y), le, (ge.z * r2) * lem1);
+                    const double Xe = fma(ge.w * r2, le, -((mval * ge.z) * r1) * lem1);
+                    const double Wo = fma(fma(go.x, r1, go.y), lo, (go.z * r2) * lom1);
+                    const double Xo = fma(go.w * r2, lo, -((mval * go.z) * r1) * lom1);
+                    const double *be = sb + (8 * ms + d) * STRIDE + ri;
+                    const double *bo = be + STRIDE;
+#pragma unroll
+                    for (int t = 0; t < NT; t++) {
+                        const double bev = be[16 * t], bov = bo[16 * t];
+                        awe[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(We, bev, awe[t], 0, 0, 0);
+                        awo[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(Wo, bov, awo[t], 0, 0, 0);
+                        axe[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(Xe, bev, axe[t], 0, 0, 0);
+                        axo[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(Xo, bov, axo[t], 0, 0, 0);
+                    }
+                }
+            }
+        }
+
+        const int cur_rtile = w.rtile, cur_cg = w.cg, cur_m = w.m, cur_nstage = w.nstage;
+        __syncthreads();
+        item = __builtin_amdgcn_readfirstlane(s_next);
+        const bool have_next = item < nitems;
+        if (have_next) {
+            w = decode(item);
+#pragma unroll
+            for (int st = 0; st < NBUF - 1; st++)
+                if (st < w.nstage) issue_stage(w, st);
+        }
+        if (cur_nstage > 0) {
+            // sigma of the column inside its 8-wide cell: +1 for (Re B, Im E) columns, -1 for (Re E, Im B)
+            const int c8 = ri & 7;
+            const double sigma = (((c8 & 1) ^ ((c8 >> 2) & 1)) != 0) ? 1.0 : -1.0;
+#pragma unroll
+            for (int t = 0; t < NT; t++) {
+                const int col = cur_cg * TCOLS + 16 * t + ri;
+                const int g = col >> 3, cv = col & 7;
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const double swn = awe[t][r] + awo[t][r], sws = awe[t][r] - awo[t][r];
+                    const double sxn = axe[t][r] + axo[t][r], sxs = axo[t][r] - axe[t][r];
+                    const double pxn = __shfl_xor(sxn, 5), pxs = __shfl_xor(sxs, 5);
+                    const int ro = cur_rtile * TRINGS + (kq + 4 * r) * LEG_WAVES + wave;
+                    if (ro < npair) {
+                        inter[(((size_t)ro * G + g) * L + cur_m) * 8 + cv] = -(swn - sigma * pxn);
+                        const int rs = nring - 1 - ro;
+                        if (rs != ro) inter[(((size_t)rs * G + g) * L + cur_m) * 8 + cv] = -(sws - sigma * pxs);
+                    }
+                }
+            }
+        }
+        if (!have_next) break;
+        __syncthreads();
+    }
+}
+template <int NT, int RT>
+static int launch_legendre(corahip_ctx *ctx, const corahip_sht_plan *p, int ncols, const double *alm, double *inter) {
+    constexpr int STRIDE = 16 * NT + 8;
+    const size_t shm = sizeof(double) * LEG_NBUF * (LEG_KT * STRIDE + 2 * (LEG_KT + 8)) + 16;
+    HIP_TRY(hipFuncSetAttribute((const void *)legendre_kernel<NT, RT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)shm));
+    const int ntile = (p->npair + LEG_RINGS * RT - 1) / (LEG_RINGS * RT);
+    const long nitems = (long)p->L * (ncols / (16 * NT)) * ntile;
+    // persistent: as many workgroups as fit (LDS-limited: one per CU for NT = 8)
+    const int per_cu = std::max<int>(1, std::min<int>(2, (int)((160 * 1024) / shm)));
+    dim3 grid((unsigned)std::min<long>(nitems, (long)ctx->num_cu * per_cu));
+    HIP_TRY(hipMemsetAsync(p->d_queue, 0, 64, ctx->stream));
+    legendre_kernel<NT, RT><<<grid, 64 * LEG_WAVES, shm, ctx->stream>>>(p->lmax, p->npair, p->nring, ncols, p->d_z,
+                                                                       p->d_coef, p->d_lstart, p->d_seed, p->d_lmin,
+                                                                       alm, p->d_zeros, inter, p->d_queue);
+    LAUNCH_CHECK();
+    return 0;
+}
+int sht_legendre(corahip_ctx *ctx, const corahip_sht_plan *p, int ncols, const double *alm, double *inter) {
+    StageTimer t(ctx, "legendre");
+    const int ntile = ncols / 16;
+    if (ntile % 8 == 0) return launch_legendre<8, 1>(ctx, p, ncols, alm, inter);
+    if (ntile % 4 == 0) return launch_legendre<4, 2>(ctx, p, ncols, alm, inter);
+    if (ntile % 2 == 0) return launch_legendre<2, 2>(ctx, p, ncols, alm, inter);
+    return launch_legendre<1, 2>(ctx, p, ncols, alm, inter);
+}
+
+// (g1..g4)(l, m) of legendre_pol_kernel at alm_idx(l, m), long double on the host, once per plan
+static int ensure_polc(corahip_ctx *ctx, corahip_sht_plan *p) {
+    if (p->d_polc) return 0;
+    const int lmax = p->lmax;
+    std::vector<double> g((size_t)(p->nalm + 64) * 4, 0.0);
+    for (int m = 0; m <= lmax; m++)
+        for (int l = std::max(m, 2); l <= lmax; l++) {
+            const long double ll = l, mm = m;
+            const long double n2 = 2.0L / sqrtl((ll + 2.0L) * (ll + 1.0L) * ll * (ll - 1.0L));
+            const long double al = l > m ? sqrtl((4.0L * ll * ll - 1.0L) / (ll * ll - mm * mm)) : 0.0L;
+            double *o = &g[(size_t)alm_idx(l, m, lmax) * 4];
+            o[0] = (double)(-n2 * (ll - mm * mm));
+            o[1] = (double)(-n2 * ll * (ll - 1.0L) / 2.0L);
+            o[2] = l > m ? (double)(n2 * (2.0L * ll + 1.0L) / al) : 0.0;
+            o[3] = (double)(n2 * mm * (ll - 1.0L));
+        }
+    HIP_TRY(hipMalloc((void **)&p->d_polc, sizeof(double) * g.size()));
+    HIP_TRY(hipMemcpyAsync(p->d_polc, g.data(), sizeof(double) * g.size(), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+template <int NT>
+static int launch_legendre_pol(corahip_ctx *ctx, const corahip_sht_plan *p, int ncols, const double *alm, double *inter) {
+    constexpr int STRIDE = 16 * NT + 8;
+    const size_t shm = sizeof(double) * 3 * (32 * STRIDE + 6 * (32 + 8)) + 16;
+    HIP_TRY(hipFuncSetAttribute((const void *)legendre_pol_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)shm));
+    const int ntile = (p->npair + LEG_RINGS - 1) / LEG_RINGS;
+    const long nitems = (long)p->L * (ncols / (16 * NT)) * ntile;
+    const int per_cu = std::max<int>(1, std::min<int>(2, (int)((160 * 1024) / shm)));
+    dim3 grid((unsigned)std::min<long>(nitems, (long)ctx->num_cu * per_cu));
+    HIP_TRY(hipMemsetAsync(p->d_queue, 0, 64, ctx->stream));
+    legendre_pol_kernel<NT><<<grid, 64 * LEG_WAVES, shm, ctx->stream>>>(p->lmax, p->npair, p->nring, ncols, p->d_z, p->d_sth,
+                                                                       p->d_coef, p->d_polc, p->d_lstart, p->d_seed,
+                                                                       p->d_lmin, alm, p->d_zeros, inter, p->d_queue);
+    LAUNCH_CHECK();
+    return 0;
+}
+int sht_legendre_pol(corahip_ctx *ctx, corahip_sht_plan *p, int ncols, const double *alm, double *inter) {
+    int rc = ensure_polc(ctx, p);
+    if (rc) return rc;
+    StageTimer t(ctx, "legendre_pol");
+    const int ntile = ncols / 16;
+    if (ntile % 4 == 0) return launch_legendre_pol<4>(ctx, p, ncols, alm, inter);
+    if (ntile % 2 == 0) return launch_legendre_pol<2>(ctx, p, ncols, alm, inter);
+    return launch_legendre_pol<1>(ctx, p, ncols, alm, inter);
+}

@@ -1,0 +1,432 @@
+// sht_plan.hip - the (nside, lmax) plan of the HEALPix transforms: ring geometry, recurrence coefficients,
+// polar seed table (first contributing l and the two recurrence values there), per-(m, ring block) first-l table,
+// per-ring m cut-off, twiddles, Bluestein chirps / filters and the K5 launch classes.  See sht_internal.h.
+#include "sht_internal.h"
+
+// ------------------------------------------------------------------------------------
+// plan-time kernels
+// ------------------------------------------------------------------------------------
+__device__ static inline void scaled_pow(double s, int n, double &mant, int &ex) {
+    // s^n = mant * 2^ex with mant in [0.5, 1); exponentiation by squaring, renormalised
+    int e;
+    double f = frexp(s, &e);
+    double rm = 1.0;
+    int re = 0;
+    double bm = f;
+    int be = e;
+    while (n) {
+        if (n & 1) {
+            rm *= bm;
+            re += be;
+            int t;
+            rm = frexp(rm, &t);
+            re += t;
+        }
+        bm *= bm;
+        be *= 2;
+        int t;
+        bm = frexp(bm, &t);
+        be += t;
+        n >>= 1;
+    }
+    mant = rm;
+    ex = re;
+}
+
+#define SEED_MIN_EXP (-900)
+
+// lstart[m][r]: first l at which |lambda_lm(ring r)| >= 2^SEED_MIN_EXP, with the two
+// recurrence values there; terms below are < 1e-270 and are dropped (libsharp does the same).
+__global__ void seed_kernel(int lmax, int npair, const double *__restrict__ z, const double *__restrict__ sth,
+                            const double *__restrict__ pref, const double2 *__restrict__ coef,
+                            int32_t *__restrict__ lstart, double2 *__restrict__ seed) {
+    int r = blockIdx.x * blockDim.x + threadIdx.x;
+    int m = blockIdx.y;
+    if (r >= npair) return;
+    double x = z[r];
+    double pm;
+    int pe;
+    scaled_pow(sth[r], m, pm, pe);
+    int t;
+    double mant = frexp(pm * pref[m], &t);
+    int sc = pe + t;
+    if (m & 1) mant = -mant;
+    long o = (long)m * npair + r;
+    if (sc >= SEED_MIN_EXP) {
+        lstart[o] = m;
+        seed[o] = make_double2(0.0, ldexp(mant, sc));
+        return;
+    }
+    const double2 *cf = coef + alm_idx(0, m, lmax);
+    double p0 = 0.0, p1 = mant;  // scaled by 2^sc
+    int found = lmax + 1;
+    double s0 = 0.0, s1 = 0.0;
+    for (int l = m + 1; l <= lmax; l++) {
+        double2 c = cf[l];
+        double v = fma(c.x * x, p1, -(c.y * p0));
+        p0 = p1;
+        p1 = v;
+        if (fabs(p1) > 0x1p100) {
+            p0 *= 0x1p-100;
+            p1 *= 0x1p-100;
+            sc += 100;
+        }
+        if (p1 != 0.0 && sc + ilogb(p1) >= SEED_MIN_EXP) {
+            found = l;
+            s0 = ldexp(p0, sc);
+            s1 = ldexp(p1, sc);
+            break;
+        }
+    }
+    lstart[o] = found;
+    seed[o] = make_double2(s0, s1);
+}
+
+// test hook: lambda_lm for one (m, ring pair), l = m..lmax
+__global__ void lambda_kernel(int lmax, int npair, int m, int r, const double *__restrict__ z,
+                              const double2 *__restrict__ coef, const int32_t *__restrict__ lstart,
+                              const double2 *__restrict__ seed, double *__restrict__ out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double x = z[r];
+    long o = (long)m * npair + r;
+    int ls = lstart[o];
+    double2 sd = seed[o];
+    const double2 *cf = coef + alm_idx(0, m, lmax);
+    double p0 = 0.0, p1 = 0.0;
+    for (int l = m; l <= lmax; l++) {
+        double2 c = cf[l];
+        double v = fma(c.x * x, p1, -(c.y * p0));
+        bool inj = (l == ls);
+        v = inj ? sd.y : v;
+        p0 = inj ? sd.x : p1;
+        p1 = v;
+        out[l - m] = v;
+    }
+}
+// per ring: mcut = number of m (from 0) whose lambda_lm reach 2^-900 for some l <= lmax; F_m of the ring
+// is exactly zero beyond (lstart is monotone in m), so K4 need not write and K5 need not read those cells
+__global__ void mcut_kernel(int lmax, int npair, int nring, const int32_t *__restrict__ lstart,
+                            int32_t *__restrict__ mcut) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= npair) return;
+    int c = 0;
+    for (int m = 0; m <= lmax; m++)
+        if (lstart[(long)m * npair + r] <= lmax) c = m + 1;
+    mcut[r] = c;
+    mcut[nring - 1 - r] = c;
+}
+
+// per (m, ring tile) minimum of lstart: the first l the tile's workgroup has to visit
+__global__ void lmin_kernel(int lmax, int npair, int ntile, const int32_t *__restrict__ lstart,
+                            int32_t *__restrict__ lmin_tab) {
+    const int m = blockIdx.x, t = threadIdx.x;
+    if (t >= ntile) return;
+    int v = lmax + 1;
+    for (int r = t * LMIN_RINGS; r < min((t + 1) * LMIN_RINGS, npair); r++) v = min(v, lstart[(long)m * npair + r]);
+    lmin_tab[m * ntile + t] = v;
+}
+// Bluestein tables for cap ring i (h = 2i not a power of two): chirp b_j = e^{i pi j^2/h}, j < h,
+// and filt = FFT_P(conj chirp wrapped), stored in the digit-reversed order fft_dif produces.
+__global__ void __launch_bounds__(256)
+bluestein_table_kernel(const int32_t *__restrict__ blu_P, const int64_t *__restrict__ boff,
+                       const int64_t *__restrict__ foff, double2 *__restrict__ chirp, double2 *__restrict__ filt,
+                       const double2 *__restrict__ tw, int pmax, int tl_off) {
+    extern __shared__ __attribute__((aligned(16))) double2 fbuf[];   // [fpad(maxlen) + 1] then the twiddle table
+    const int i = blockIdx.x + 1;
+    const int P = blu_P[i - 1];
+    if (P == 0) return;
+#if K5_LDS_TW
+    double2 *tl = fbuf + tl_off;
+    twl_fill(tl, tw, pmax);
+#else
+    const double2 *tl = tw;
+#endif
+    const int h = 2 * i;
+    double2 *b = chirp + boff[i - 1];
+    for (int j = threadIdx.x; j < fpad(P); j += blockDim.x) fbuf[j] = make_double2(0.0, 0.0);
+    __syncthreads();
+    for (int j = threadIdx.x; j < h; j += blockDim.x) {
+        const long q = ((long)j * j) % (2 * h);
+        double s, c;
+        sincospi((double)q / (double)h, &s, &c);
+        b[j] = make_double2(c, s);
+        fbuf[fpad(j)] = make_double2(c, -s);
+        if (j > 0) fbuf[fpad(P - j)] = make_double2(c, -s);
+    }
+    __syncthreads();
+    fft_dif<-1>(fbuf, 0, 1, P, tl, pmax);
+    double2 *f = filt + foff[i - 1];
+    for (int j = threadIdx.x; j < P; j += blockDim.x) f[j] = fbuf[fpad(j)];
+}
+// ------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------
+template <typename T>
+static int dev_upload(T **dptr, const std::vector<T> &h, hipStream_t s) {
+    HIP_TRY(hipMalloc((void **)dptr, std::max<size_t>(1, h.size()) * sizeof(T)));
+    if (!h.empty()) {
+        HIP_TRY(hipMemcpyAsync(*dptr, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, s));
+        HIP_TRY(hipStreamSynchronize(s));
+    }
+    return 0;
+}
+
+extern "C" {
+
+int corahip_sht_plan_destroy(corahip_ctx *ctx, corahip_sht_plan *p) {
+    if (!p) return 0;
+    (void)hipFree(p->d_z);
+    (void)hipFree(p->d_sth);
+    (void)hipFree(p->d_nphi);
+    (void)hipFree(p->d_start);
+    (void)hipFree(p->d_phi0);
+    (void)hipFree(p->d_coef);
+    (void)hipFree(p->d_lstart);
+    (void)hipFree(p->d_seed);
+    (void)hipFree(p->d_tw);
+    (void)hipFree(p->d_zeros);
+    (void)hipFree(p->d_lmin);
+    (void)hipFree(p->d_queue);
+    (void)hipFree(p->d_mcut);
+    (void)hipFree(p->d_polc);
+    (void)hipFree(p->d_blu_P);
+    (void)hipFree(p->d_blu_boff);
+    (void)hipFree(p->d_blu_foff);
+    (void)hipFree(p->d_bchirp);
+    (void)hipFree(p->d_bfilt);
+    for (auto &c : p->classes) (void)hipFree(c.d_list);
+    delete p;
+    return 0;
+}
+
+int corahip_sht_plan_create(corahip_ctx *ctx, int nside, int lmax, corahip_sht_plan **out) {
+    ARG_CHECK(ctx != nullptr && out != nullptr);
+    ARG_CHECK(nside >= 1 && is_pow2(nside) && nside <= 8192);
+    ARG_CHECK(lmax >= 0 && lmax <= 16384);
+    HIP_TRY(hipSetDevice(ctx->device));
+    corahip_sht_plan *p = new corahip_sht_plan();
+    // every early return below (HIP_TRY / rc checks) releases what was allocated so far
+    struct plan_guard {
+        corahip_sht_plan *p;
+        ~plan_guard() {
+            if (p) corahip_sht_plan_destroy(nullptr, p);
+        }
+    } guard{p};
+    p->nside = nside;
+    p->lmax = lmax;
+    p->L = lmax + 1;
+    p->npair = 2 * nside;
+    p->nring = 4 * nside - 1;
+    p->npix = 12L * nside * nside;
+    p->nalm = nalm_of(lmax);
+    const int nring = p->nring;
+    p->h_start.resize(nring);
+    p->h_nphi.resize(nring);
+    p->h_z.resize(nring);
+    p->h_sth.resize(nring);
+    p->h_phi0.resize(nring);
+    // HEALPix RING geometry (pix2ang_ring conventions)
+    const double fact2 = 4.0 / (double)p->npix;       // 1/(3 nside^2)
+    const double fact1 = 2.0 * nside * fact2;         // 2/(3 nside)
+    for (int r = 0; r < nring; r++) {
+        const int i = r + 1;
+        if (i < nside) {
+            const double tmp = (double)i * i * fact2;
+            p->h_z[r] = 1.0 - tmp;
+            p->h_sth[r] = sqrt(tmp * (2.0 - tmp));
+            p->h_nphi[r] = 4 * i;
+            p->h_phi0[r] = M_PI / (4.0 * i);
+            p->h_start[r] = 2L * i * (i - 1);
+        } else if (i <= 3 * nside) {
+            const double zz = (2 * nside - i) * fact1;
+            p->h_z[r] = zz;
+            p->h_sth[r] = sqrt((1.0 - zz) * (1.0 + zz));
+            p->h_nphi[r] = 4 * nside;
+            p->h_phi0[r] = (((i - nside) & 1) == 0) ? M_PI / (4.0 * nside) : 0.0;
+            p->h_start[r] = 2L * nside * (nside - 1) + (long)(i - nside) * 4 * nside;
+        } else {
+            const int ip = 4 * nside - i;
+            const double tmp = (double)ip * ip * fact2;
+            p->h_z[r] = -(1.0 - tmp);
+            p->h_sth[r] = sqrt(tmp * (2.0 - tmp));
+            p->h_nphi[r] = 4 * ip;
+            p->h_phi0[r] = M_PI / (4.0 * ip);
+            p->h_start[r] = p->npix - 2L * ip * (ip + 1);
+        }
+    }
+    hipStream_t s = ctx->stream;
+    int rc;
+    {
+        std::vector<double> zz(p->h_z.begin(), p->h_z.begin() + p->npair);
+        std::vector<double> ss(p->h_sth.begin(), p->h_sth.begin() + p->npair);
+        if ((rc = dev_upload(&p->d_z, zz, s))) return rc;
+        if ((rc = dev_upload(&p->d_sth, ss, s))) return rc;
+    }
+    if ((rc = dev_upload(&p->d_nphi, p->h_nphi, s))) return rc;
+    if ((rc = dev_upload(&p->d_start, p->h_start, s))) return rc;
+    if ((rc = dev_upload(&p->d_phi0, p->h_phi0, s))) return rc;
+
+    // recurrence coefficients: lambda_l = A_l x lambda_{l-1} - B_l lambda_{l-2},
+    // A_l = alpha_lm, B_l = alpha_lm/alpha_{l-1,m}, alpha_lm = sqrt((4l^2-1)/(l^2-m^2))
+    {
+        std::vector<double2> coef(p->nalm + 32, make_double2(0.0, 0.0));  // +32: K4 prefetches past the end
+        for (int m = 0; m <= lmax; m++) {
+            long double aprev = 0.0L;
+            for (int l = m; l <= lmax; l++) {
+                const long o = alm_idx(l, m, lmax);
+                if (l == m) {
+                    coef[o] = make_double2(0.0, 0.0);
+                    continue;
+                }
+                const long double ll = l, mm = m;
+                const long double al = sqrtl((4.0L * ll * ll - 1.0L) / (ll * ll - mm * mm));
+                coef[o] = make_double2((double)al, l == m + 1 ? 0.0 : (double)(al / aprev));
+                aprev = al;
+            }
+        }
+        if ((rc = dev_upload(&p->d_coef, coef, s))) return rc;
+    }
+    // |lambda_mm| prefactor sqrt((2m+1)!!/(4 pi (2m)!!))
+    double *d_pref = nullptr;
+    {
+        std::vector<double> pref(p->L);
+        long double pr = 1.0L / sqrtl(4.0L * acosl(-1.0L));
+        pref[0] = (double)pr;
+        for (int m = 1; m <= lmax; m++) {
+            pr *= sqrtl((2.0L * m + 1.0L) / (2.0L * m));
+            pref[m] = (double)pr;
+        }
+        if ((rc = dev_upload(&d_pref, pref, s))) return rc;
+    }
+    HIP_TRY(hipMalloc((void **)&p->d_lstart, sizeof(int32_t) * (size_t)p->L * p->npair));
+    HIP_TRY(hipMalloc((void **)&p->d_seed, sizeof(double2) * (size_t)p->L * p->npair));
+    {
+        dim3 grid((p->npair + 63) / 64, p->L);
+        seed_kernel<<<grid, 64, 0, s>>>(lmax, p->npair, p->d_z, p->d_sth, d_pref, p->d_coef, p->d_lstart, p->d_seed);
+        LAUNCH_CHECK();
+    }
+    {
+        const int ntile = (p->npair + LMIN_RINGS - 1) / LMIN_RINGS;
+        HIP_TRY(hipMalloc((void **)&p->d_queue, 64));
+        HIP_TRY(hipMalloc((void **)&p->d_mcut, sizeof(int32_t) * (size_t)p->nring));
+        mcut_kernel<<<(p->npair + 63) / 64, 64, 0, s>>>(lmax, p->npair, p->nring, p->d_lstart, p->d_mcut);
+        LAUNCH_CHECK();
+        HIP_TRY(hipMalloc((void **)&p->d_lmin, sizeof(int32_t) * (size_t)p->L * ntile));
+        lmin_kernel<<<p->L, 64 * ((ntile + 63) / 64), 0, s>>>(lmax, p->npair, ntile, p->d_lstart, p->d_lmin);
+        LAUNCH_CHECK();
+    }
+    HIP_TRY(hipStreamSynchronize(s));
+    (void)hipFree(d_pref);
+
+    HIP_TRY(hipMalloc((void **)&p->d_zeros, 4096));
+    HIP_TRY(hipMemsetAsync(p->d_zeros, 0, 4096, s));
+    // FFT twiddles and Bluestein tables
+    p->pmax = std::max(4 * nside, 4);
+    p->log_pmax = ilog2(p->pmax);
+    {
+        std::vector<double2> tw(p->pmax / 2);
+        for (int k = 0; k < p->pmax / 2; k++) {
+            const long double a = 2.0L * acosl(-1.0L) * k / p->pmax;
+            tw[k] = make_double2((double)cosl(a), (double)sinl(a));
+        }
+        if ((rc = dev_upload(&p->d_tw, tw, s))) return rc;
+    }
+    {
+        std::vector<int32_t> bp(nside, 0);
+        std::vector<int64_t> bo(nside, 0), fo(nside, 0);
+        int64_t nb = 0, nf = 0;
+        int maxlen = 2 * nside + 1;  // belt: h + 1
+        for (int i = 1; i < nside; i++) {
+            const int h = 2 * i;
+            if (is_pow2(h)) continue;
+            int P = 1;
+            while (P < 2 * h - 1) P <<= 1;
+            bp[i - 1] = P;
+            bo[i - 1] = nb;
+            fo[i - 1] = nf;
+            nb += h;
+            nf += P;
+            maxlen = std::max(maxlen, P);
+        }
+        p->max_fft_len = maxlen;
+        if ((rc = dev_upload(&p->d_blu_P, bp, s))) return rc;
+        if ((rc = dev_upload(&p->d_blu_boff, bo, s))) return rc;
+        if ((rc = dev_upload(&p->d_blu_foff, fo, s))) return rc;
+        HIP_TRY(hipMalloc((void **)&p->d_bchirp, sizeof(double2) * std::max<int64_t>(1, nb)));
+        HIP_TRY(hipMalloc((void **)&p->d_bfilt, sizeof(double2) * std::max<int64_t>(1, nf)));
+        if (nside > 1) {
+            const int tl_off = fpad(maxlen) + 1;
+            const size_t shm = sizeof(double2) * (size_t)(tl_off + TWL_ENTRIES(p->pmax));
+            HIP_TRY(hipFuncSetAttribute((const void *)bluestein_table_kernel,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+            bluestein_table_kernel<<<nside - 1, 256, shm, s>>>(p->d_blu_P, p->d_blu_boff, p->d_blu_foff,
+                                                                p->d_bchirp, p->d_bfilt, p->d_tw, p->pmax, tl_off);
+            LAUNCH_CHECK();
+        }
+    }
+    // K5 ring classes
+    {
+        std::map<int, std::vector<int32_t>> by_len;
+        for (int r = 0; r < nring; r++) {
+            const int i = r + 1;
+            int icap = 0;
+            if (i < nside) icap = i;
+            else if (i > 3 * nside) icap = 4 * nside - i;
+            int P = 0;
+            if (icap) {
+                const int h = 2 * icap;
+                if (!is_pow2(h)) {
+                    P = 1;
+                    while (P < 2 * h - 1) P <<= 1;
+                }
+            }
+            by_len[P].push_back(r);
+        }
+        size_t lds_budget = 160 * 1024;
+        if (getenv("CORAHIP_K5_LDS_KB")) lds_budget = (size_t)atoi(getenv("CORAHIP_K5_LDS_KB")) * 1024;
+        for (auto &kv : by_len) {
+            corahip_sht_plan::ring_class c;
+            c.P = kv.first;
+            c.bstride = fpad(c.P ? c.P : 2 * nside + 1) + 1;
+            c.nch = 4;
+            const size_t tl_bytes = sizeof(double2) * TWL_ENTRIES(p->pmax);   // LDS twiddle table behind the buffers
+            while (c.nch > 1 && (size_t)c.nch * c.bstride * sizeof(double2) + tl_bytes > lds_budget) c.nch >>= 1;
+            if ((size_t)c.nch * c.bstride * sizeof(double2) + tl_bytes > 160 * 1024) {
+                corahip_set_error("nside %d: ring FFT of length %d does not fit in LDS", nside, c.bstride);
+                return CORAHIP_ENOMEM;
+            }
+            // (measured and rejected for the P = 4096 class: one channel per 4-wave workgroup, two workgroups per CU,
+            //  so that LDS and FP64 phases of different workgroups overlap: 12.8 -> 13.6 ms, the cells are read 4x)
+            c.count = (int)kv.second.size();
+            if ((rc = dev_upload(&c.d_list, kv.second, s))) return rc;
+            p->classes.push_back(c);
+        }
+    }
+    HIP_TRY(hipStreamSynchronize(s));
+    guard.p = nullptr;
+    *out = p;
+    return 0;
+}
+
+int corahip_sht_plan_rings(const corahip_sht_plan *p, int64_t *host_start, int32_t *host_nphi, double *host_z,
+                           double *host_phi0) {
+    ARG_CHECK(p != nullptr);
+    for (int r = 0; r < p->nring; r++) {
+        if (host_start) host_start[r] = p->h_start[r];
+        if (host_nphi) host_nphi[r] = p->h_nphi[r];
+        if (host_z) host_z[r] = p->h_z[r];
+        if (host_phi0) host_phi0[r] = p->h_phi0[r];
+    }
+    return 0;
+}
+
+int corahip_sht_lambda(corahip_ctx *ctx, const corahip_sht_plan *p, int m, int ring_pair, double *out) {
+    ARG_CHECK(ctx != nullptr && p != nullptr && out != nullptr);
+    ARG_CHECK(m >= 0 && m <= p->lmax && ring_pair >= 0 && ring_pair < p->npair);
+    lambda_kernel<<<1, 64, 0, ctx->stream>>>(p->lmax, p->npair, m, ring_pair, p->d_z, p->d_coef, p->d_lstart,
+                                             p->d_seed, out);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+}  // extern "C"
