@@ -1,124 +1,120 @@
-"""Counterpart of cora/core/maps.py: map geometry / frequency bookkeeping and the
-``Sky3d`` orchestration of the hot path (``getsky`` -> clarray -> mkfullsky)."""
+"""Sky-map geometry classes and the ``Sky3d`` entry point of the hot path.
+
+API counterpart of cora/core/maps.py (same class / attribute names so that code written
+against the reference keeps working); the numerical work in ``Sky3d`` goes to the HIP
+kernels through :mod:`cora_amd.core.skysim`.
+"""
 import numpy as np
 
 from ..util import constants
 from . import skysim
 
 
-class Map2d(object):
-    r"""A 2-d sky map (cora/core/maps.py:7-74).
+def _cell_centres(extent, count):
+    # centres of `count` equal cells tiling [0, extent]
+    return (0.5 + np.arange(count)) * (extent / count)
 
-    Attributes
-    ----------
-    x_width, y_width : float
-        Angular size along each axis (in degrees).
-    x_num, y_num : int
-        Number of pixels along each angular axis.
+
+class Map2d(object):
+    """Angular patch description (reference: cora/core/maps.py:7-74).
+
+    ``x_width`` / ``y_width`` are in degrees, ``x_num`` / ``y_num`` are pixel counts and
+    ``nside`` is the HEALPix resolution used by the full-sky subclasses.
     """
 
-    x_width = 5.0
-    y_width = 5.0
-    x_num = 128
-    y_num = 128
+    # fields transferred by like_map(); subclasses extend the tuple
+    _geometry_fields = ("x_width", "y_width", "x_num", "y_num", "_nside")
+
+    x_width = y_width = 5.0
+    x_num = y_num = 128
     _nside = 128
 
     @classmethod
     def like_map(cls, mapobj, *args, **kwargs):
-        c = cls(*args, **kwargs)
-        for attr in ("x_width", "y_width", "x_num", "y_num", "_nside"):
-            setattr(c, attr, getattr(mapobj, attr))
-        return c
+        """New instance of ``cls`` sharing the geometry of ``mapobj``."""
+        new = cls(*args, **kwargs)
+        new._adopt_geometry(mapobj)
+        return new
+
+    def _adopt_geometry(self, other):
+        for name in self._geometry_fields:
+            setattr(self, name, getattr(other, name))
 
     def _width_array(self):
-        return np.array([self.x_width, self.y_width], dtype=np.float64) * constants.degree
+        deg = constants.degree
+        return np.asarray((self.x_width * deg, self.y_width * deg), dtype=np.float64)
 
     def _num_array(self):
-        return np.array([self.x_num, self.y_num], dtype=int)
+        return np.asarray((self.x_num, self.y_num), dtype=int)
 
-    @property
-    def x_pixels(self):
-        return (np.arange(self.x_num) + 0.5) * (self.x_width / self.x_num)
+    x_pixels = property(lambda self: _cell_centres(self.x_width, self.x_num))
+    y_pixels = property(lambda self: _cell_centres(self.y_width, self.y_num))
 
-    @property
-    def y_pixels(self):
-        return (np.arange(self.y_num) + 0.5) * (self.y_width / self.y_num)
-
-    @property
-    def nside(self):
-        """The resolution of the Healpix map (must be power of 2)."""
+    def _get_nside(self):
         return self._nside
 
-    @nside.setter
-    def nside(self, value):
-        ns = int(value)
-        lns = np.log2(ns)
-        if int(lns) != lns or lns < 0:
+    def _set_nside(self, value):
+        value = int(value)
+        # a positive power of two has exactly one bit set
+        if value < 1 or value & (value - 1):
             raise Exception("Not a valid value of nside.")
-        self._nside = ns
+        self._nside = value
+
+    nside = property(_get_nside, _set_nside, doc="HEALPix resolution (a power of two).")
 
 
 class Map3d(Map2d):
-    r"""A 3-d sky map (cora/core/maps.py:77-200): adds the frequency axis.
+    """Angular patch plus a frequency axis (reference: cora/core/maps.py:77-200).
 
-    ``nu_lower``/``nu_upper`` are the band edges with ``nu_num`` channels between them,
-    unless explicit ``frequencies`` are set.
+    Channels are either given explicitly through ``frequencies`` or are the ``nu_num``
+    equal-width channel centres between ``nu_lower`` and ``nu_upper`` (MHz).
     """
 
-    nu_lower = 500.0
-    nu_upper = 900.0
-    _frequencies = None
-    _nu_num = 128
+    _geometry_fields = Map2d._geometry_fields + ("nu_upper", "nu_lower")
 
-    @classmethod
-    def like_map(cls, mapobj, *args, **kwargs):
-        c = cls(*args, **kwargs)
-        for attr in ("x_width", "y_width", "x_num", "y_num", "_nside", "nu_upper", "nu_lower"):
-            setattr(c, attr, getattr(mapobj, attr))
-        c.nu_num = mapobj.nu_num
-        c._frequencies = mapobj._frequencies
-        return c
+    nu_lower, nu_upper = 500.0, 900.0
+    _nu_num = 128
+    _frequencies = None
+
+    def _adopt_geometry(self, other):
+        Map2d._adopt_geometry(self, other)
+        self.nu_num = other.nu_num
+        self._frequencies = other._frequencies
 
     def _width_array(self):
-        return np.array([self.nu_upper - self.nu_lower, self.x_width * constants.degree,
-                         self.y_width * constants.degree], dtype=np.float64)
+        band = self.nu_upper - self.nu_lower
+        return np.concatenate(([band], Map2d._width_array(self)))
 
     def _num_array(self):
-        return np.array([self.nu_num, self.x_num, self.y_num], dtype=int)
+        return np.concatenate(([self.nu_num], Map2d._num_array(self))).astype(int)
 
-    @property
-    def nu_num(self):
-        return len(self.frequencies)
+    def _get_frequencies(self):
+        if self._frequencies is None:
+            return self.nu_lower + _cell_centres(self.nu_upper - self.nu_lower, self._nu_num)
+        return self._frequencies
 
-    @nu_num.setter
-    def nu_num(self, num):
-        self._nu_num = num
-
-    @property
-    def frequencies(self):
-        """List of frequencies in the map (channel centres, MHz)."""
-        if self._frequencies is not None:
-            return self._frequencies
-        width = (self.nu_upper - self.nu_lower) / self._nu_num
-        return self.nu_lower + (np.arange(self._nu_num) + 0.5) * width
-
-    @frequencies.setter
-    def frequencies(self, freq):
+    def _set_frequencies(self, freq):
         self._frequencies = freq
 
-    # Alias for frequencies for supporting old code.
+    frequencies = property(_get_frequencies, _set_frequencies,
+                           doc="Channel centres in MHz.")
+    # older spelling still used by callers of the reference
     nu_pixels = frequencies
+
+    def _set_nu_num(self, num):
+        self._nu_num = num
+
+    nu_num = property(lambda self: len(self.frequencies), _set_nu_num,
+                      doc="Number of channels.")
 
 
 class Sky3d(Map3d):
-    """Base class for full-sky multi-frequency maps (cora/core/maps.py:203-252).
+    """Full-sky, multi-frequency Gaussian field (reference: cora/core/maps.py:203-252).
 
-    Attributes
-    ----------
-    oversample : int
-        Romberg order of the channel-width integration of C_l.
-    lmax : int or None
-        Extension: band limit of the realisation; ``None`` = the reference's ``3*nside-1``.
+    Subclasses supply ``angular_powerspectrum(l, nu1, nu2)`` and optionally ``mean_nu``.
+    ``oversample`` is the Romberg order of the channel-width integral of C_l; ``lmax``
+    (an extension) overrides the band limit, which defaults to the reference's
+    ``3 * nside - 1``.
     """
 
     oversample = 3
@@ -127,35 +123,42 @@ class Sky3d(Map3d):
     def angular_powerspectrum(self, l, nu1, nu2):
         raise Exception("Not implemented in base class.")
 
-    def mean_nu(self, freq):
-        return np.zeros_like(freq)
-
     def getfield(self):
         raise Exception("Not implemented in base class.")
 
+    def mean_nu(self, freq):
+        return np.zeros_like(freq)
+
     def _lmax(self):
-        return 3 * self.nside - 1 if self.lmax is None else int(self.lmax)
+        if self.lmax is None:
+            return 3 * self.nside - 1
+        return int(self.lmax)
+
+    def _channels(self):
+        return np.asarray(self.nu_pixels, dtype=np.float64)
 
     def getsky(self, rng=None):
-        """Create a map of the unpolarised sky, ``[nfreq, npix]`` (maps.py:227-237).
+        """Realisation of the unpolarised sky, ``[nfreq, npix]`` (maps.py:227-237).
 
-        ``rng`` (extension; the reference always uses numpy's global state) is passed to
-        :func:`skysim.mkfullsky`.
+        ``rng`` is an extension (the reference draws from numpy's global state) and is
+        handed to :func:`skysim.mkfullsky_device`.
         """
-        freq = np.asarray(self.nu_pixels, dtype=np.float64)
-        cla = skysim.clarray_device(self.angular_powerspectrum, self._lmax(), freq, zromb=self.oversample)
-        sky = skysim.mkfullsky_device(cla, self.nside, rng=rng).cpu().numpy()
-        return self.mean_nu(freq)[:, np.newaxis] + sky
+        nu = self._channels()
+        cl = skysim.clarray_device(self.angular_powerspectrum, self._lmax(), nu,
+                                   zromb=self.oversample)
+        fluct = skysim.mkfullsky_device(cl, self.nside, rng=rng).cpu().numpy()
+        fluct += self.mean_nu(nu)[:, np.newaxis]
+        return fluct
 
     def getpolsky(self, rng=None):
-        """Fully polarised sky ``[nfreq, 4, npix]`` with Q = U = V = 0 (maps.py:239-247)."""
-        sky_I = self.getsky(rng=rng)
-        sky_IQU = np.zeros((sky_I.shape[0], 4, sky_I.shape[1]), dtype=sky_I.dtype)
-        sky_IQU[:, 0] = sky_I
-        return sky_IQU
+        """``[nfreq, 4, npix]`` Stokes cube with only I populated (maps.py:239-247)."""
+        stokes_i = self.getsky(rng=rng)
+        nfreq, npix = stokes_i.shape
+        cube = np.zeros((nfreq, 4, npix), dtype=stokes_i.dtype)
+        cube[:, 0, :] = stokes_i
+        return cube
 
     def getalms(self, lmax, rng=None):
-        """a_lm ``[nfreq, 1, lmax+1, lmax+1]`` (maps.py:249-252; default Romberg order 3)."""
-        freq = np.asarray(self.nu_pixels, dtype=np.float64)
-        cla = skysim.clarray_device(self.angular_powerspectrum, lmax, freq)
-        return skysim.mkfullsky_device(cla, self.nside, alms=True, rng=rng).cpu().numpy()
+        """Harmonic coefficients ``[nfreq, 1, lmax+1, lmax+1]`` (maps.py:249-252)."""
+        cl = skysim.clarray_device(self.angular_powerspectrum, lmax, self._channels())
+        return skysim.mkfullsky_device(cl, self.nside, alms=True, rng=rng).cpu().numpy()

@@ -1,15 +1,22 @@
-"""Counterpart of cora/foreground/gaussianfg.py: separable Gaussian foregrounds
-C_l(nu, nu') = A_l B(nu, nu') in the style of Santos, Cooray & Knox (astro-ph/0408515)."""
+"""Separable Gaussian foreground models, C_l(nu, nu') = A_l * B(nu, nu').
+
+API counterpart of cora/foreground/gaussianfg.py (model family of Santos, Cooray & Knox,
+astro-ph/0408515).  The split into an angular factor and a frequency covariance is what
+lets K1 evaluate these models as a single outer product on the device.
+"""
 import numpy as np
 
 from ..core import maps
 
 
 class ForegroundMap(maps.Sky3d):
-    r"""Foregrounds with separable angular and frequency covariance (gaussianfg.py:20-84)."""
+    """Base of the separable models (reference: gaussianfg.py:20-84).
+
+    A subclass provides ``angular_ps(l)`` (vectorised A_l) and
+    ``frequency_covariance(nu1, nu2)``; their product is the ``angular_powerspectrum``.
+    """
 
     def angular_ps(self, l):
-        r"""The angular function A_l (vectorised)."""
         pass
 
     def frequency_covariance(self, nu1, nu2):
@@ -19,78 +26,67 @@ class ForegroundMap(maps.Sky3d):
         return self.angular_ps(l) * self.frequency_covariance(nu1, nu2)
 
     def _clarray_plan(self, aps):
-        """Protocol used by ``skysim.clarray``: C_l = A_l x B, one outer-product kernel."""
+        # skysim.clarray asks the model whether it can describe `aps` in closed form.
+        # Only the un-overridden product above qualifies.
         if getattr(aps, "__func__", None) is not ForegroundMap.angular_powerspectrum:
             return None
 
         def prepare(larr, za):
-            al = np.asarray(self.angular_ps(larr), dtype=np.float64)
-            bcov = self.frequency_covariance(za[:, np.newaxis], za[np.newaxis, :])
-            return al, np.ascontiguousarray(bcov, dtype=np.float64)
+            a_l = np.asarray(self.angular_ps(larr), dtype=np.float64)
+            b = self.frequency_covariance(za[:, np.newaxis], za[np.newaxis, :])
+            return a_l, np.ascontiguousarray(b, dtype=np.float64)
 
-        return dict(kind="separable", prepare=prepare)
+        return {"kind": "separable", "prepare": prepare}
 
     def getfield(self):
-        raise NotImplementedError("flat-sky foreground cubes (gaussianfg.py:43-84) are out of scope of cora_amd")
+        raise NotImplementedError(
+            "flat-sky foreground cubes (gaussianfg.py:43-84) are out of scope of cora_amd")
 
 
 class ForegroundSCK(ForegroundMap):
-    r"""SCK-style foregrounds; needs ``A``, ``alpha``, ``beta``, ``zeta`` (gaussianfg.py:87-130).
+    """Power laws in l and nu with a log-normal frequency coherence (gaussianfg.py:87-130).
 
-    C_l = A (l/l_0)^-beta (nu1 nu2/nu_0^2)^-alpha exp(-(ln(nu1/nu2))^2 / (2 zeta^2)), C_0 = 0.
+    C_l = A (l/l_0)^-beta (nu1 nu2 / nu_0^2)^-alpha exp(-ln(nu1/nu2)^2 / (2 zeta^2)),
+    with the monopole forced to zero.  Concrete models set ``A, alpha, beta, zeta``.
     """
 
-    nu_0 = 130.0
     l_0 = 1000.0
+    nu_0 = 130.0
 
     def angular_ps(self, larray):
-        if isinstance(larray, np.ndarray):
-            mask0 = np.where(larray == 0)
-            larray[mask0] = 1.0  # in place, as the reference does (gaussianfg.py:108-110)
-        psarray = self.A * (larray / self.l_0) ** (-self.beta)
-        if isinstance(larray, np.ndarray):
-            psarray[mask0] = 0.0
-        return psarray
-
-    def frequency_covariance(self, nu1, nu2):
-        return (self.frequency_variance(nu1) * self.frequency_variance(nu2)) ** 0.5 * self.frequency_correlation(
-            nu1, nu2)
+        if not isinstance(larray, np.ndarray):
+            return self.A * (larray / self.l_0) ** (-self.beta)
+        # The reference overwrites l = 0 entries of the caller's array with 1
+        # (gaussianfg.py:108-110); callers observe that, so it is kept.
+        monopole = np.where(larray == 0)
+        larray[monopole] = 1.0
+        a_l = self.A * (larray / self.l_0) ** (-self.beta)
+        a_l[monopole] = 0.0
+        return a_l
 
     def frequency_variance(self, nu):
-        r"""Variance on a single frequency slice."""
+        """B(nu, nu)."""
         return (nu / self.nu_0) ** (-2 * self.alpha)
 
     def frequency_correlation(self, nu1, nu2):
-        r"""Correlation between two frequency slices."""
+        """B(nu1, nu2) / sqrt(B(nu1, nu1) B(nu2, nu2))."""
         return np.exp(-0.5 * (np.log(nu1 / nu2) / self.zeta) ** 2)
 
     def frequency_correlation_dlog(self, dlognu):
         return np.exp(-(dlognu**2) / (2 * self.zeta**2))
 
-
-class Synchrotron(ForegroundSCK):
-    A = 7.00e-4
-    alpha = 2.80
-    beta = 2.4
-    zeta = 4.0
+    def frequency_covariance(self, nu1, nu2):
+        sigma2 = (self.frequency_variance(nu1) * self.frequency_variance(nu2)) ** 0.5
+        return sigma2 * self.frequency_correlation(nu1, nu2)
 
 
-class ExtraGalacticFreeFree(ForegroundSCK):
-    A = 1.40e-8
-    alpha = 2.10
-    beta = 1.0
-    zeta = 35.0
+def _sck_model(name, A, alpha, beta, zeta):
+    return type(name, (ForegroundSCK,),
+                {"A": A, "alpha": alpha, "beta": beta, "zeta": zeta, "__module__": __name__})
 
 
-class GalacticFreeFree(ForegroundSCK):
-    A = 8.80e-8
-    alpha = 2.15
-    beta = 3.0
-    zeta = 35.0
-
-
-class PointSources(ForegroundSCK):
-    A = 5.70e-5
-    alpha = 2.07
-    beta = 1.1
-    zeta = 1.0
+# Table 1 of Santos, Cooray & Knox as used by the reference (gaussianfg.py:133-158)
+Synchrotron = _sck_model("Synchrotron", 7.00e-4, 2.80, 2.4, 4.0)
+ExtraGalacticFreeFree = _sck_model("ExtraGalacticFreeFree", 1.40e-8, 2.10, 1.0, 35.0)
+GalacticFreeFree = _sck_model("GalacticFreeFree", 8.80e-8, 2.15, 3.0, 35.0)
+PointSources = _sck_model("PointSources", 5.70e-5, 2.07, 1.1, 1.0)
