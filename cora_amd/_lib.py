@@ -62,6 +62,11 @@ SIGNATURES = {
     "corahip_xi_table_average": (c_int, [c_void_p, PTR, PTR, PTR, c_int, c_int, c_double, c_double, PTR, c_int, PTR, PTR,
                                          c_int, c_int, PTR]),
     "corahip_legendre_project": (c_int, [c_void_p, PTR, PTR, c_int, c_int, PTR, ctypes.c_long, PTR]),
+    "corahip_fft_c2c": (c_int, [c_void_p, PTR, c_int, PTR, c_int, c_int]),
+    "corahip_irfftn": (c_int, [c_void_p, PTR, c_int, PTR, c_int, PTR]),
+    "corahip_rfftn": (c_int, [c_void_p, PTR, c_int, PTR, c_int, PTR]),
+    "corahip_randomfield_draw": (c_int, [c_void_p, PTR, ctypes.c_int64, ctypes.c_uint64, PTR]),
+    "corahip_fg_mix": (c_int, [c_void_p, PTR, PTR, PTR, c_int, c_int, ctypes.c_int64, PTR]),
     "corahip_sht_plan_rings": (c_int, [c_void_p, PTR, PTR, PTR, PTR]),
     "corahip_sht_lambda": (c_int, [c_void_p, c_void_p, c_int, c_int, PTR]),
 }
@@ -395,6 +400,64 @@ class Context:
         out = self.empty((lmax + 1, ncol))
         _check(self.lib.corahip_legendre_project(self.h, self._f64(mu), self._f64(wt), nm, lmax, self._f64(xi),
                                                  ncol, self._f64(out)))
+        return out
+
+    # -- n4: flat-sky fields -----------------------------------------------------------
+    def _c128(self, t):
+        torch = _torch()
+        assert t.dtype == torch.complex128 and t.device == self.device
+        return self._p(t)
+
+    @staticmethod
+    def _dims(shape):
+        return (ctypes.c_int64 * len(shape))(*[int(x) for x in shape])
+
+    def fft_c2c(self, data, axis, inverse=False):
+        """In-place numpy.fft.fft / ifft of a complex128 device array along one axis."""
+        axis = axis % data.dim()
+        _check(self.lib.corahip_fft_c2c(self.h, self._c128(data), data.dim(), self._dims(data.shape), axis,
+                                        1 if inverse else 0))
+        return data
+
+    def irfftn(self, spec, naxes=None, last=None):
+        """numpy.fft.irfftn over the last ``naxes`` axes (default all); ``spec`` is overwritten."""
+        nd = spec.dim()
+        naxes = nd if naxes is None else naxes
+        rshape = list(spec.shape)
+        rshape[-1] = 2 * (spec.shape[-1] - 1) if last is None else int(last)
+        if rshape[-1] // 2 + 1 != spec.shape[-1]:
+            raise CoraHipError("irfftn: last axis %d does not match %d spectral bins" % (rshape[-1], spec.shape[-1]))
+        out = self.empty(tuple(rshape))
+        _check(self.lib.corahip_irfftn(self.h, self._c128(spec), nd, self._dims(rshape), naxes, self._f64(out)))
+        return out
+
+    def rfftn(self, arr, naxes=None):
+        """numpy.fft.rfftn over the last ``naxes`` axes (default all) of a float64 device array."""
+        torch = _torch()
+        nd = arr.dim()
+        naxes = nd if naxes is None else naxes
+        cshape = list(arr.shape)
+        cshape[-1] = arr.shape[-1] // 2 + 1
+        spec = torch.empty(tuple(cshape), dtype=torch.complex128, device=self.device)
+        _check(self.lib.corahip_rfftn(self.h, self._f64(arr), nd, self._dims(arr.shape), naxes, self._c128(spec)))
+        return spec
+
+    def randomfield_draw(self, kweight, seed):
+        """(N(0,1) + i N(0,1)) * kweight from the Philox device stream (counter = flat element index)."""
+        torch = _torch()
+        spec = torch.empty(tuple(kweight.shape), dtype=torch.complex128, device=self.device)
+        _check(self.lib.corahip_randomfield_draw(self.h, self._f64(kweight), kweight.numel(), int(seed),
+                                                 self._c128(spec)))
+        return spec
+
+    def fg_mix(self, freq_weight, normals, aff):
+        """out[f] = aff * sum_c freq_weight[f, c] normals[c]  (complex [F, *aff.shape])."""
+        torch = _torch()
+        F, ncorr = freq_weight.shape
+        assert normals.shape[0] == ncorr and tuple(normals.shape[1:]) == tuple(aff.shape)
+        out = torch.empty((F,) + tuple(aff.shape), dtype=torch.complex128, device=self.device)
+        _check(self.lib.corahip_fg_mix(self.h, self._f64(freq_weight), self._f64(normals), self._c128(aff), F, ncorr,
+                                       aff.numel(), self._c128(out)))
         return out
 
     def sht_rings(self, nside, lmax):

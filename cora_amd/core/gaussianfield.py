@@ -1,72 +1,104 @@
-"""Counterpart of cora/core/gaussianfield.py: flat-sky Gaussian random fields.
+"""Flat-sky Gaussian random fields on the GPU.
 
-API-surface row: ``RandomField`` keeps cora's interface so the
-model classes that mix it in keep working.  The flat-sky path is NOT part of the HIP hot
-path (it is the "next" row n4); it is host numpy exactly as in the reference
-(``randn * kweight -> irfftn``, gaussianfield.py:70-120) and no GPU claim is made for it.
+API counterpart of cora/core/gaussianfield.py (SURVEY 8 row a12 / "next" row n4): the same classes
+and attributes, with ``getfield`` = (normals * kweight) -> ``irfftn`` running in ``csrc/flatsky.hip``.
+The k-space weights come from the user's ``powerspectrum`` callable (host, once) and then stay
+resident on the device.
 """
 import numpy as np
 
-from ..util import constants, fftutil
+from .. import _lib
+from ..util import fftutil
 from . import maps
 
 
 class RandomField(object):
-    r"""n-dimensional Gaussian random field with a user-supplied ``powerspectrum(karray)``.
+    """n-dimensional Gaussian field with power spectrum ``powerspectrum(karray)``.
 
     Parameters
     ----------
-    npix : array_like
-        Number of pixels along each axis.
-    wsize : array_like, optional
-        Physical size of each axis (defaults to ``npix``).
+    npix : sequence of int
+        Pixels along each axis.
+    wsize : sequence of float, optional
+        Extent of each axis (any units); ``npix`` when omitted, i.e. unit pixels.
     """
 
     _kweightgen = False
+    _kweight_dev = None
+    _n = None
+    _w = None
 
     def __init__(self, npix=None, wsize=None):
-        self._n = np.array(npix) if npix is not None else npix
-        self._w = np.array(wsize) if wsize is not None else self._n
+        self._n = None if npix is None else np.array(npix)
+        self._w = self._n if wsize is None else np.array(wsize)
+
+    def _check_input(self):
+        # same three conditions and messages as gaussianfield.py:34-42
+        if self._n is None or self._w is None:
+            raise Exception("Either self._n or self._w has not been set.")
+        if len(self._n) != len(self._w):
+            raise Exception("Width array must be the same length as number of pixels.")
+        if not ((np.asarray(self._n) > 0).all() and (np.asarray(self._w) > 0).all()):
+            raise Exception("Array elements must be positive.")
 
     def powerspectrum(self, karray):
-        return (karray**2).sum(axis=3)
+        """P(k) for an array of wavevectors ``[..., ndim]`` (angular wavenumbers, 2 pi / length)."""
+        raise Exception("Abstract method: need to override.")
 
     def generate_kweight(self, regen=False):
-        """k-space weights sqrt(P(k)) * prod(n)/sqrt(2 prod(w)), DC mode zero (gaussianfield.py:70-100)."""
+        """``sqrt(P(k)) prod(n) / sqrt(2 prod(w))`` on the rfftn grid, non-finite DC -> 0 (gaussianfield.py:70-100)."""
+        self._check_input()
         if self._kweightgen and not regen:
             return
-        spacing = self._w / self._n
-        kvec = fftutil.rfftfreqn(self._n, spacing / (2 * np.pi))
-        self._kweight = self.powerspectrum(kvec) ** 0.5 * self._n.prod() / (2.0 * self._w.prod()) ** 0.5
-        self._kweight[tuple([0] * len(self._n))] = 0.0
+        n = np.asarray(self._n)
+        w = np.asarray(self._w, dtype=np.float64)
+        kvec = fftutil.rfftfreqn(n, (w / n) / (2 * np.pi))
+        kw = self.powerspectrum(kvec) ** 0.5 * n.prod() / (2.0 * w.prod()) ** 0.5
+        if not np.isfinite(kw.flat[0]):
+            kw.flat[0] = 0.0
+        self._kweight = kw
+        self._kweight_dev = None
         self._kweightgen = True
 
-    def getfield(self):
-        """One realisation (gaussianfield.py:102-120); uses numpy's global random state."""
+    def _device_kweight(self):
+        if self._kweight_dev is None:
+            self._kweight_dev = _lib.get_context().to_device(self._kweight)
+        return self._kweight_dev
+
+    def getfield_device(self, seed=None):
+        """One realisation as a device tensor.
+
+        ``seed=None`` reproduces the reference: two ``np.random.standard_normal`` arrays from numpy's
+        global state (gaussianfield.py:115), uploaded.  An integer ``seed`` (extension) draws the
+        normals on the GPU from the Philox stream (element index = counter), nothing crosses PCIe.
+        """
         self.generate_kweight()
-        s = self._kweight.shape
-        f = np.random.standard_normal(s) + 1.0j * np.random.standard_normal(s)
-        f *= self._kweight
-        return fftutil.irfftn(f)
+        ctx = _lib.get_context()
+        if seed is None:
+            s = self._kweight.shape
+            f = np.random.standard_normal(s) + 1.0j * np.random.standard_normal(s)
+            f *= self._kweight
+            spec = ctx.to_device(f, dtype=np.complex128)
+        else:
+            spec = ctx.randomfield_draw(self._device_kweight(), seed)
+        return ctx.irfftn(spec)
+
+    def getfield(self, seed=None):
+        """One realisation, shape ``n`` with the last axis rounded down to even (gaussianfield.py:102-120)."""
+        return self.getfield_device(seed=seed).cpu().numpy()
 
 
-class RandomFieldA2F(RandomField, maps.Map3d):
-    """Two angular dimensions + frequency (gaussianfield.py:123-138)."""
-
-    @classmethod
-    def like_map(cls, mapobj, *args, **kwargs):
-        c = super(RandomFieldA2F, cls).like_map(mapobj, *args, **kwargs)
-        c._n = c._num_array()
-        c._w = c._width_array()
-        return c
+class _MapGeometryField(RandomField):
+    # shared by the two map mix-ins: pixel counts and widths come from the Map2d / Map3d attributes
+    def generate_kweight(self, *args):
+        self._n = self._num_array()
+        self._w = self._width_array()
+        RandomField.generate_kweight(self, *args)
 
 
-class RandomFieldA2(RandomField, maps.Map2d):
-    """Two angular dimensions (gaussianfield.py:141-156)."""
+class RandomFieldA2F(_MapGeometryField, maps.Map3d):
+    """Frequency x two angles; geometry from the ``Map3d`` attributes (gaussianfield.py:123-138)."""
 
-    @classmethod
-    def like_map(cls, mapobj, *args, **kwargs):
-        c = super(RandomFieldA2, cls).like_map(mapobj, *args, **kwargs)
-        c._n = c._num_array()[-2:]
-        c._w = c._width_array()[-2:]
-        return c
+
+class RandomFieldA2(_MapGeometryField, maps.Map2d):
+    """Two angles; geometry from the ``Map2d`` attributes (gaussianfield.py:141-156)."""

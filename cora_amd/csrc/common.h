@@ -23,6 +23,14 @@ struct corahip_pending_event {
     hipEvent_t e0, e1;
 };
 
+// tables of one line-FFT length of the flat-sky engine (flatsky.hip); device pointers
+struct corahip_linefft_plan {
+    int n = 0, P = 0, logP = 0, blu = 0;
+    double2 *tw = nullptr;     // [P]  exp(-2 pi i k / P)
+    double2 *chirp = nullptr;  // [n]  exp(-i pi k^2 / n)                       (Bluestein lengths only)
+    double2 *filt = nullptr;   // [P]  FFT_P(wrapped conj chirp) / P, bit-reversed (Bluestein lengths only)
+};
+
 struct corahip_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -39,6 +47,8 @@ struct corahip_ctx {
     // K1 pair list resident in scratch slot 2: (F, first, step, slots, device pointer it was written to)
     long pairs_key[4] = {-1, -1, -1, -1};
     void *pairs_ptr = nullptr;
+    // flat-sky line-FFT tables by transform length
+    std::map<int, corahip_linefft_plan> linefft;
 };
 
 // returns a device buffer of at least `bytes` for `slot`, reallocating only when it must grow

@@ -70,6 +70,11 @@ int corahip_ctx_destroy(corahip_ctx *ctx) {
     (void)hipEventDestroy(ctx->t1);
     for (int i = 0; i < 6; i++)
         if (ctx->scratch[i]) (void)hipFree(ctx->scratch[i]);
+    for (auto &kv : ctx->linefft) {
+        if (kv.second.tw) (void)hipFree(kv.second.tw);
+        if (kv.second.chirp) (void)hipFree(kv.second.chirp);
+        if (kv.second.filt) (void)hipFree(kv.second.filt);
+    }
     delete ctx;
     return 0;
 }

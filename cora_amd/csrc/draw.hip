@@ -10,111 +10,7 @@
 // from the stream-ordered buffer (each element is used by exactly one wave).
 #include "common.h"
 
-// ------------------------------------------------------------------------------------
-// Philox4x32-10 counter-based generator -> N(0,1) by Box-Muller, stream order
-// ------------------------------------------------------------------------------------
-__device__ static inline void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
-    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
-    const uint64_t p0 = (uint64_t)M0 * c[0];
-    const uint64_t p1 = (uint64_t)M1 * c[2];
-    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
-    const uint32_t n1 = (uint32_t)p1;
-    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
-    const uint32_t n3 = (uint32_t)p0;
-    c[0] = n0;
-    c[1] = n1;
-    c[2] = n2;
-    c[3] = n3;
-}
-
-__device__ static inline void philox4x32_10(uint64_t counter, uint64_t key, uint32_t (&out)[4]) {
-    uint32_t c[4] = {(uint32_t)counter, (uint32_t)(counter >> 32), 0u, 0u};
-    uint32_t k0 = (uint32_t)key, k1 = (uint32_t)(key >> 32);
-#pragma unroll
-    for (int r = 0; r < 10; r++) {
-        philox_round(c, k0, k1);
-        k0 += 0x9E3779B9u;
-        k1 += 0xBB67AE85u;
-    }
-    out[0] = c[0];
-    out[1] = c[1];
-    out[2] = c[2];
-    out[3] = c[3];
-}
-
-// Box-Muller in FP64 with short, branch-free kernels (the generic libm log/sincospi cost ~130 DP instructions
-// per pair and made the RNG, not the MFMAs, the bound of K3): every step is accurate to ~1e-16.
-//   ln x   : x = 2^e m, m in [1/sqrt2, sqrt2); c = round(64 m)/64; r = m (1/c) - 1 (one fma, |r| <= 0.0111);
-//            ln x = e ln2 - ln(1/c) + log1p(r), log1p by its degree-8 Taylor polynomial (remainder 3e-17 r).
-//            c = 1 is a centre, so x -> 1 keeps full RELATIVE accuracy (the radius there is sqrt(-2 ln x)).
-//   sqrt t : v_rsq_f64 seed + two Goldschmidt steps + one residual correction.
-//   sin/cos(2 pi u): octant from the top three bits of u (exact), argument in [0, pi/4], the classic
-//            degree-13/14 minimax kernels (Sun fdlibm k_sin/k_cos coefficients; max error 1.1e-16).
-__device__ static const double2 LOG_TAB[47] = {
-#include "log_tab.inc"
-};
-
-__device__ static inline double fast_log01(double x) {  // x in (0, 1]
-    double m = __builtin_amdgcn_frexp_mant(x);           // [0.5, 1)
-    int e = __builtin_amdgcn_frexp_exp(x);
-    const bool lo = m < 0.70710678118654752440;
-    m = lo ? m + m : m;                                  // [1/sqrt2, sqrt2)
-    e = lo ? e - 1 : e;
-    const int i = (int)__builtin_rint(m * 64.0);         // 45 .. 91
-    const double2 tc = LOG_TAB[i - 45];
-    const double r = fma(m, tc.x, -1.0);
-    double p = -1.0 / 8.0;
-    p = fma(p, r, 1.0 / 7.0);
-    p = fma(p, r, -1.0 / 6.0);
-    p = fma(p, r, 1.0 / 5.0);
-    p = fma(p, r, -1.0 / 4.0);
-    p = fma(p, r, 1.0 / 3.0);
-    p = fma(p, r, -1.0 / 2.0);
-    p = fma(p * r, r, r);                                // log1p(r)
-    return fma((double)e, 0.69314718055994530942, tc.y + p);
-}
-
-__device__ static inline double fast_sqrt_pos(double t) {  // t in [0, ~80]
-    const double y = __builtin_amdgcn_rsq(t);
-    double g = t * y, h = 0.5 * y;
-    double r = fma(-h, g, 0.5);
-    g = fma(g, r, g);
-    h = fma(h, r, h);
-    r = fma(-h, g, 0.5);
-    g = fma(g, r, g);
-    h = fma(h, r, h);
-    const double dd = fma(-g, g, t);
-    g = fma(dd, h, g);
-    return t > 0.0 ? g : 0.0;
-}
-
-// cos(2 pi u), sin(2 pi u) for u in (0, 1)
-__device__ static inline void fast_sincos2pi(double u, double &sn, double &cs) {
-    const double a = 8.0 * u;                 // exact
-    const int q = (int)a;                     // octant 0..7 (a < 8 always: u <= 1 - 2^-54 rounds to at most 1.0 ...)
-    const double f = a - (double)q;           // exact, [0, 1)
-    const double g = (q & 1) ? 1.0 - f : f;   // reflect odd octants
-    const double x = g * 0.78539816339744830962;
-    const double z = x * x;
-    double ps = 1.58969099521155010221e-10;
-    ps = fma(ps, z, -2.50507602534068634195e-08);
-    ps = fma(ps, z, 2.75573137070700676789e-06);
-    ps = fma(ps, z, -1.98412698298579493134e-04);
-    ps = fma(ps, z, 8.33333333332248946124e-03);
-    ps = fma(ps, z, -1.66666666666666324348e-01);
-    const double s = fma(x * z, ps, x);
-    double pc = -1.13596475577881948265e-11;
-    pc = fma(pc, z, 2.08757232129817482790e-09);
-    pc = fma(pc, z, -2.75573143513906633035e-07);
-    pc = fma(pc, z, 2.48015872894767294178e-05);
-    pc = fma(pc, z, -1.38888888888741095749e-03);
-    pc = fma(pc, z, 4.16666666666666019037e-02);
-    const double c = fma(z * z, pc, fma(-0.5, z, 1.0));
-    const bool swap = ((q + 1) >> 1) & 1;     // octants 1,2,5,6
-    const double cc = swap ? s : c, ss = swap ? c : s;
-    cs = (((q + 2) >> 2) & 1) ? -cc : cc;     // octants 2..5
-    sn = (q & 4) ? -ss : ss;                  // octants 4..7
-}
+#include "rng_dev.h"
 
 // The device stream: the normals of (l, c = re/im, nu', m) and (.., m+1), m even, are the two
 // Box-Muller outputs of Philox counter {lo = m/2, hi = l*2F + c*F + nu'} under key = seed:

@@ -1,0 +1,439 @@
+// flatsky.hip - flat-sky Gaussian random fields: n-dimensional real FFTs and the fused field draw
+//
+// Replaces, for the flat-sky half of SURVEY 8(f) n4, the numpy transforms behind
+// RandomField.getfield (cora/core/gaussianfield.py:102-120: (randn + i randn) kweight -> irfftn),
+// fftutil.rfftn / irfftn (cora/util/fftutil.py:64-87) and the mixed ifft/irfft of
+// ForegroundMap.getfield (cora/foreground/gaussianfg.py:72-84).
+//
+// One kernel does a batch of 1-D transforms ("lines") along one axis of a C-contiguous array, a tile of
+// T adjacent lines per workgroup staged through LDS so that global accesses stay coalesced whatever the
+// stride of the axis:
+//   - power-of-two lengths: in-LDS radix-4 (+ one radix-2) decimation-in-time passes on bit-reversed input;
+//   - every other length (the reference pads cubes to arbitrary sizes, corr.py:655-671): Bluestein with
+//     plan-time chirp and filter tables, DIF forward -> filter (stored bit-reversed) -> DIT, so no
+//     permutation pass exists;
+//   - inverse transforms by conjugation on load and store; real transforms as a Hermitian-extended
+//     (c2r) or zero-imaginary (r2c) complex line - numpy.fft.irfft semantics: the imaginary parts of
+//     the DC and Nyquist bins are ignored.
+// Line length <= 4096 (LDS holds a tile of P <= 8192 points).
+#include <cmath>
+#include <complex>
+#include <vector>
+
+#include "common.h"
+#include "rng_dev.h"
+
+#define FS_THREADS 256
+#define FS_MAXN 4096
+
+__device__ static inline double2 cmul(double2 a, double2 b) {
+    return make_double2(fma(a.x, b.x, -a.y * b.y), fma(a.x, b.y, a.y * b.x));
+}
+__device__ static inline double2 cadd(double2 a, double2 b) { return make_double2(a.x + b.x, a.y + b.y); }
+__device__ static inline double2 csub(double2 a, double2 b) { return make_double2(a.x - b.x, a.y - b.y); }
+__device__ static inline double2 mul_mi(double2 a) { return make_double2(a.y, -a.x); }  // a * (-i)
+__device__ static inline unsigned brev_n(unsigned i, int logP) { return logP ? (__brev(i) >> (32 - logP)) : 0u; }
+
+// decimation in time, forward sign: position i holds x[bitrev(i)] on entry, X[i] on exit; `lines` lines of P
+__device__ static void lds_dit(double2 *buf, int P, int logP, int lines, const double2 *__restrict__ tw) {
+    int h = 1;
+    if (logP & 1) {
+        for (int w = threadIdx.x; w < lines * (P >> 1); w += FS_THREADS) {
+            double2 *p = buf + 2 * w;
+            const double2 a = p[0], b = p[1];
+            p[0] = cadd(a, b);
+            p[1] = csub(a, b);
+        }
+        __syncthreads();
+        h = 2;
+    }
+    const int q = P >> 2, lq = logP - 2;
+    for (; h < P; h <<= 2) {
+        const int s1 = P / (2 * h), s2 = P / (4 * h);
+        for (int w = threadIdx.x; w < lines * q; w += FS_THREADS) {
+            const int t = w >> lq, j = w & (q - 1);
+            const int pos = j & (h - 1), grp = j / h;
+            double2 *p = buf + t * P + grp * 4 * h + pos;
+            const double2 w1 = tw[pos * s1], w2 = tw[pos * s2];
+            const double2 a = p[0], b = cmul(w1, p[h]), c = p[2 * h], d = cmul(w1, p[3 * h]);
+            const double2 a1 = cadd(a, b), b1 = csub(a, b);
+            const double2 c1 = cmul(w2, cadd(c, d)), d1 = cmul(mul_mi(w2), csub(c, d));
+            p[0] = cadd(a1, c1);
+            p[h] = cadd(b1, d1);
+            p[2 * h] = csub(a1, c1);
+            p[3 * h] = csub(b1, d1);
+        }
+        __syncthreads();
+    }
+}
+
+// decimation in frequency, forward sign: natural order in, position i holds X[bitrev(i)] on exit
+__device__ static void lds_dif(double2 *buf, int P, int logP, int lines, const double2 *__restrict__ tw) {
+    const int q = P >> 2, lq = logP - 2;
+    const int hmin = (logP & 1) ? 2 : 1;
+    for (int h = P >> 2; h >= hmin; h >>= 2) {
+        const int s1 = P / (2 * h), s2 = P / (4 * h);
+        for (int w = threadIdx.x; w < lines * q; w += FS_THREADS) {
+            const int t = w >> lq, j = w & (q - 1);
+            const int pos = j & (h - 1), grp = j / h;
+            double2 *p = buf + t * P + grp * 4 * h + pos;
+            const double2 w1 = tw[pos * s1], w2 = tw[pos * s2];
+            const double2 x0 = p[0], x1 = p[h], x2 = p[2 * h], x3 = p[3 * h];
+            const double2 a1 = cadd(x0, x2), c1 = cmul(w2, csub(x0, x2));
+            const double2 b1 = cadd(x1, x3), d1 = cmul(mul_mi(w2), csub(x1, x3));
+            p[0] = cadd(a1, b1);
+            p[h] = cmul(w1, csub(a1, b1));
+            p[2 * h] = cadd(c1, d1);
+            p[3 * h] = cmul(w1, csub(c1, d1));
+        }
+        __syncthreads();
+    }
+    if (logP & 1) {
+        for (int w = threadIdx.x; w < lines * (P >> 1); w += FS_THREADS) {
+            double2 *p = buf + 2 * w;
+            const double2 a = p[0], b = p[1];
+            p[0] = cadd(a, b);
+            p[1] = csub(a, b);
+        }
+        __syncthreads();
+    }
+}
+
+struct linefft_args {
+    const double *in;
+    double *out;
+    long nouter, inner;  // lines = nouter * inner; element j of line (o, i) is at ((o n_mem + j) inner + i)
+    int n;               // transform length
+    int nh;              // n / 2 + 1 (real modes)
+    int T;               // lines per tile
+    int inverse;         // sign +, for MODE 0
+    double scale;
+    int P, logP, blu;
+    const double2 *tw, *chirp, *filt;
+};
+
+// MODE 0: complex -> complex (in place allowed), 1: half-complex -> real (inverse), 2: real -> half-complex
+template <int MODE>
+__global__ void __launch_bounds__(FS_THREADS) linefft_kernel(const linefft_args A) {
+    extern __shared__ double2 fs_lds[];
+    const int n = A.n, P = A.P, logP = A.logP, T = A.T;
+    const bool inv = MODE == 1 || (MODE == 0 && A.inverse);
+    const double2 *in2 = reinterpret_cast<const double2 *>(A.in);
+    double2 *out2 = reinterpret_cast<double2 *>(A.out);
+    const long chunks = (A.inner + T - 1) / T;  // tiles per outer index (inner > 1)
+    const long nlines = A.nouter * A.inner;
+    const long ntiles = A.inner == 1 ? (nlines + T - 1) / T : A.nouter * chunks;
+
+    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        long outer, i0;
+        int teff;
+        if (A.inner == 1) {
+            outer = tile * T;  // first line
+            i0 = 0;
+            teff = (int)min((long)T, nlines - outer);
+        } else {
+            outer = tile / chunks;
+            i0 = (tile - outer * chunks) * T;
+            teff = (int)min((long)T, A.inner - i0);
+        }
+        // ---- load -------------------------------------------------------------------------------
+        if (A.blu) {
+            for (int e = threadIdx.x; e < teff * (P - n); e += FS_THREADS) {
+                const int t = e / (P - n), j = n + e % (P - n);
+                fs_lds[t * P + j] = make_double2(0.0, 0.0);
+            }
+        }
+        if (MODE == 0) {
+            for (int e = threadIdx.x; e < teff * n; e += FS_THREADS) {
+                int t, j;
+                long addr;
+                if (A.inner == 1) {
+                    t = e / n, j = e - t * n;
+                    addr = (outer + t) * n + j;
+                } else {
+                    j = e / teff, t = e - j * teff;
+                    addr = (outer * n + j) * A.inner + i0 + t;
+                }
+                double2 v = in2[addr];
+                if (inv) v.y = -v.y;
+                if (A.blu)
+                    fs_lds[t * P + j] = cmul(v, A.chirp[j]);
+                else
+                    fs_lds[t * P + brev_n(j, logP)] = v;
+            }
+        } else if (MODE == 1) {
+            const int nh = A.nh;
+            for (int e = threadIdx.x; e < teff * nh; e += FS_THREADS) {
+                const int t = e / nh, k = e - t * nh;
+                double2 v = in2[(outer + t) * nh + k];
+                if (k == 0 || 2 * k == n) v.y = 0.0;
+                // conj of the Hermitian extension: position k gets conj(c_k), position n-k gets c_k
+                const double2 lo = make_double2(v.x, -v.y);
+                if (A.blu) {
+                    fs_lds[t * P + k] = cmul(lo, A.chirp[k]);
+                    if (k > 0 && 2 * k < n) fs_lds[t * P + n - k] = cmul(v, A.chirp[n - k]);
+                } else {
+                    fs_lds[t * P + brev_n(k, logP)] = lo;
+                    if (k > 0 && 2 * k < n) fs_lds[t * P + brev_n(n - k, logP)] = v;
+                }
+            }
+        } else {
+            for (int e = threadIdx.x; e < teff * n; e += FS_THREADS) {
+                const int t = e / n, j = e - t * n;
+                const double2 v = make_double2(A.in[(outer + t) * n + j], 0.0);
+                if (A.blu)
+                    fs_lds[t * P + j] = cmul(v, A.chirp[j]);
+                else
+                    fs_lds[t * P + brev_n(j, logP)] = v;
+            }
+        }
+        __syncthreads();
+        // ---- transform --------------------------------------------------------------------------
+        if (A.blu) {
+            lds_dif(fs_lds, P, logP, teff, A.tw);
+            for (int e = threadIdx.x; e < teff * P; e += FS_THREADS) {
+                const double2 z = cmul(fs_lds[e], A.filt[e & (P - 1)]);
+                fs_lds[e] = make_double2(z.x, -z.y);
+            }
+            __syncthreads();
+        }
+        lds_dit(fs_lds, P, logP, teff, A.tw);
+        // ---- store ------------------------------------------------------------------------------
+        const int nout = MODE == 2 ? A.nh : n;
+        for (int e = threadIdx.x; e < teff * nout; e += FS_THREADS) {
+            int t, k;
+            long addr;
+            if (A.inner == 1) {
+                t = e / nout, k = e - t * nout;
+                addr = (outer + t) * nout + k;
+            } else {
+                k = e / teff, t = e - k * teff;
+                addr = (outer * n + k) * A.inner + i0 + t;
+            }
+            double2 v = fs_lds[t * P + k];
+            if (A.blu) v = cmul(make_double2(v.x, -v.y), A.chirp[k]);
+            if (MODE == 1) {
+                A.out[addr] = v.x * A.scale;
+            } else {
+                if (inv) v.y = -v.y;
+                out2[addr] = make_double2(v.x * A.scale, v.y * A.scale);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// spec[e] = (N(0,1) + i N(0,1)) kweight[e], the pair being the Box-Muller outputs of Philox counter e
+__global__ void randomfield_draw_kernel(const double *__restrict__ kw, long count, uint64_t seed,
+                                        double2 *__restrict__ spec) {
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < count; e += (long)gridDim.x * blockDim.x) {
+        const double2 z = philox_boxmuller((uint64_t)e, seed);
+        const double w = kw[e];
+        spec[e] = make_double2(z.x * w, z.y * w);
+    }
+}
+
+// out[f][m] = aff[m] * sum_c W[f][c] g[c][m]: the frequency mixing of ForegroundMap.getfield
+// (cora/foreground/gaussianfg.py:79-82): real normals g, complex angular spectrum aff
+__global__ void fg_mix_kernel(const double *__restrict__ W, const double *__restrict__ g,
+                              const double2 *__restrict__ aff, int ncorr, long M, double2 *__restrict__ out) {
+    const int f = blockIdx.y;
+    const double *wr = W + (size_t)f * ncorr;
+    for (long m = (long)blockIdx.x * blockDim.x + threadIdx.x; m < M; m += (long)gridDim.x * blockDim.x) {
+        double s = 0.0;
+        for (int c = 0; c < ncorr; c++) s = fma(wr[c], g[(size_t)c * M + m], s);
+        const double2 a = aff[m];
+        out[(size_t)f * M + m] = make_double2(s * a.x, s * a.y);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+typedef std::complex<long double> cld;
+
+static void host_fft(std::vector<cld> &x) {  // forward, power-of-two, recursive (plan time only)
+    const size_t n = x.size();
+    if (n < 2) return;
+    std::vector<cld> ev(n / 2), od(n / 2);
+    for (size_t i = 0; i < n / 2; i++) ev[i] = x[2 * i], od[i] = x[2 * i + 1];
+    host_fft(ev);
+    host_fft(od);
+    const long double PI = 3.14159265358979323846264338327950288L;
+    for (size_t k = 0; k < n / 2; k++) {
+        const long double a = -2.0L * PI * (long double)k / (long double)n;
+        const cld t = cld(cosl(a), sinl(a)) * od[k];
+        x[k] = ev[k] + t;
+        x[k + n / 2] = ev[k] - t;
+    }
+}
+
+static int get_linefft_plan(corahip_ctx *ctx, int n, const corahip_linefft_plan **out) {
+    auto it = ctx->linefft.find(n);
+    if (it != ctx->linefft.end()) {
+        *out = &it->second;
+        return 0;
+    }
+    const long double PI = 3.14159265358979323846264338327950288L;
+    corahip_linefft_plan pl;
+    pl.n = n;
+    pl.blu = (n & (n - 1)) != 0;
+    int P = 1;
+    while (P < (pl.blu ? 2 * n - 1 : n)) P <<= 1;
+    pl.P = P;
+    pl.logP = 0;
+    while ((1 << pl.logP) < P) pl.logP++;
+    std::vector<double2> tw(P);
+    for (int k = 0; k < P; k++) {
+        const long double a = -2.0L * PI * (long double)k / (long double)P;
+        tw[k] = make_double2((double)cosl(a), (double)sinl(a));
+    }
+    HIP_TRY(hipMalloc((void **)&pl.tw, sizeof(double2) * P));
+    HIP_TRY(hipMemcpy(pl.tw, tw.data(), sizeof(double2) * P, hipMemcpyHostToDevice));
+    if (pl.blu) {
+        std::vector<double2> chirp(n), filt(P);
+        std::vector<cld> b(P, cld(0, 0));
+        for (long k = 0; k < n; k++) {
+            const long r = (k * k) % (2L * n);  // k^2 mod 2n keeps the angle exact
+            const long double a = PI * (long double)r / (long double)n;
+            chirp[k] = make_double2((double)cosl(a), (double)-sinl(a));
+            const cld bk(cosl(a), sinl(a));
+            b[k] = bk;
+            if (k) b[P - k] = bk;
+        }
+        host_fft(b);
+        for (int i = 0; i < P; i++) {
+            unsigned r = 0;
+            for (int bit = 0; bit < pl.logP; bit++) r |= ((i >> bit) & 1u) << (pl.logP - 1 - bit);
+            filt[i] = make_double2((double)(b[r].real() / P), (double)(b[r].imag() / P));
+        }
+        HIP_TRY(hipMalloc((void **)&pl.chirp, sizeof(double2) * n));
+        HIP_TRY(hipMemcpy(pl.chirp, chirp.data(), sizeof(double2) * n, hipMemcpyHostToDevice));
+        HIP_TRY(hipMalloc((void **)&pl.filt, sizeof(double2) * P));
+        HIP_TRY(hipMemcpy(pl.filt, filt.data(), sizeof(double2) * P, hipMemcpyHostToDevice));
+    }
+    auto ins = ctx->linefft.emplace(n, pl);
+    *out = &ins.first->second;
+    return 0;
+}
+
+template <int MODE>
+static int launch_linefft(corahip_ctx *ctx, const double *in, double *out, long nouter, int n, long inner,
+                          int inverse, double scale) {
+    ARG_CHECK(n >= 1 && n <= FS_MAXN);
+    if (nouter * inner == 0) return 0;
+    const corahip_linefft_plan *pl;
+    int rc = get_linefft_plan(ctx, n, &pl);
+    if (rc) return rc;
+    linefft_args A;
+    A.in = in;
+    A.out = out;
+    A.nouter = nouter;
+    A.inner = inner;
+    A.n = n;
+    A.nh = n / 2 + 1;
+    A.inverse = inverse;
+    A.scale = scale;
+    A.P = pl->P;
+    A.logP = pl->logP;
+    A.blu = pl->blu;
+    A.tw = pl->tw;
+    A.chirp = pl->chirp;
+    A.filt = pl->filt;
+    int T = 4096 / pl->P;
+    T = T < 1 ? 1 : (T > 16 ? 16 : T);
+    A.T = T;
+    const size_t shm = sizeof(double2) * (size_t)T * pl->P;
+    const long chunks = (inner + T - 1) / T;
+    const long ntiles = inner == 1 ? (nouter + T - 1) / T : nouter * chunks;
+    const long maxgrid = (long)ctx->num_cu * (shm > 65536 ? 1 : 2);
+    const int grid = (int)(ntiles < maxgrid ? ntiles : maxgrid);
+    HIP_TRY(hipFuncSetAttribute((const void *)linefft_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)shm));
+    hipLaunchKernelGGL(linefft_kernel<MODE>, dim3(grid), dim3(FS_THREADS), shm, ctx->stream, A);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+static long prod(const int64_t *d, int a, int b) {
+    long p = 1;
+    for (int i = a; i < b; i++) p *= d[i];
+    return p;
+}
+
+extern "C" {
+
+int corahip_fft_c2c(corahip_ctx *ctx, double *data, int ndim, const int64_t *dims, int axis, int inverse) {
+    ARG_CHECK(ctx && data && dims && ndim >= 1 && ndim <= 8 && axis >= 0 && axis < ndim);
+    for (int i = 0; i < ndim; i++) ARG_CHECK(dims[i] >= 1);
+    StageTimer st(ctx, "flatfft");
+    const int n = (int)dims[axis];
+    ARG_CHECK(dims[axis] <= FS_MAXN);
+    return launch_linefft<0>(ctx, data, data, prod(dims, 0, axis), n, prod(dims, axis + 1, ndim), inverse,
+                             inverse ? 1.0 / n : 1.0);
+}
+
+int corahip_irfftn(corahip_ctx *ctx, double *spec, int ndim, const int64_t *rdims, int naxes, double *out) {
+    ARG_CHECK(ctx && spec && out && rdims && ndim >= 1 && ndim <= 8 && naxes >= 1 && naxes <= ndim);
+    int64_t cd[8];
+    for (int i = 0; i < ndim; i++) {
+        ARG_CHECK(rdims[i] >= 1);
+        cd[i] = rdims[i];
+    }
+    for (int i = ndim - naxes; i < ndim; i++) ARG_CHECK(rdims[i] <= FS_MAXN);
+    cd[ndim - 1] = rdims[ndim - 1] / 2 + 1;
+    StageTimer st(ctx, "flatfft");
+    for (int ax = ndim - naxes; ax < ndim - 1; ax++) {
+        const int n = (int)cd[ax];
+        int rc = launch_linefft<0>(ctx, spec, spec, prod(cd, 0, ax), n, prod(cd, ax + 1, ndim), 1, 1.0 / n);
+        if (rc) return rc;
+    }
+    const int n = (int)rdims[ndim - 1];
+    return launch_linefft<1>(ctx, spec, out, prod(rdims, 0, ndim - 1), n, 1, 1, 1.0 / n);
+}
+
+int corahip_rfftn(corahip_ctx *ctx, const double *in, int ndim, const int64_t *rdims, int naxes, double *spec) {
+    ARG_CHECK(ctx && spec && in && rdims && ndim >= 1 && ndim <= 8 && naxes >= 1 && naxes <= ndim);
+    int64_t cd[8];
+    for (int i = 0; i < ndim; i++) {
+        ARG_CHECK(rdims[i] >= 1);
+        cd[i] = rdims[i];
+    }
+    for (int i = ndim - naxes; i < ndim; i++) ARG_CHECK(rdims[i] <= FS_MAXN);
+    cd[ndim - 1] = rdims[ndim - 1] / 2 + 1;
+    StageTimer st(ctx, "flatfft");
+    int rc = launch_linefft<2>(ctx, in, spec, prod(rdims, 0, ndim - 1), (int)rdims[ndim - 1], 1, 0, 1.0);
+    if (rc) return rc;
+    for (int ax = ndim - 2; ax >= ndim - naxes; ax--) {
+        rc = launch_linefft<0>(ctx, spec, spec, prod(cd, 0, ax), (int)cd[ax], prod(cd, ax + 1, ndim), 0, 1.0);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+int corahip_randomfield_draw(corahip_ctx *ctx, const double *kweight, int64_t count, uint64_t seed, double *spec) {
+    ARG_CHECK(ctx && kweight && spec && count >= 0);
+    if (count == 0) return 0;
+    StageTimer st(ctx, "flatdraw");
+    long blocks = (count + 255) / 256;
+    const long cap = (long)ctx->num_cu * 16;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(randomfield_draw_kernel, dim3((int)blocks), dim3(256), 0, ctx->stream, kweight, (long)count,
+                       seed, reinterpret_cast<double2 *>(spec));
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int corahip_fg_mix(corahip_ctx *ctx, const double *freq_weight, const double *normals, const double *aff, int F,
+                   int ncorr, int64_t M, double *out) {
+    ARG_CHECK(ctx && freq_weight && normals && aff && out && F >= 1 && ncorr >= 1 && M >= 1);
+    StageTimer st(ctx, "fg_mix");
+    long bx = (M + 255) / 256;
+    if (bx > 65535) bx = 65535;
+    hipLaunchKernelGGL(fg_mix_kernel, dim3((unsigned)bx, (unsigned)F), dim3(256), 0, ctx->stream, freq_weight, normals,
+                       reinterpret_cast<const double2 *>(aff), ncorr, (long)M, reinterpret_cast<double2 *>(out));
+    LAUNCH_CHECK();
+    return 0;
+}
+
+}  // extern "C"

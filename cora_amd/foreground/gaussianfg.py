@@ -6,7 +6,9 @@ lets K1 evaluate these models as a single outer product on the device.
 """
 import numpy as np
 
-from ..core import maps
+from .. import _lib
+from ..core import gaussianfield, maps
+from ..util import nputil
 
 
 class ForegroundMap(maps.Sky3d):
@@ -38,9 +40,39 @@ class ForegroundMap(maps.Sky3d):
 
         return {"kind": "separable", "prepare": prepare}
 
+    _weight_gen = False
+
+    def generate_weight(self, regen=False):
+        """Frequency root and angular field generator of the flat-sky cube (gaussianfg.py:43-70)."""
+        if self._weight_gen and not regen:
+            return
+        nu = np.asarray(self.nu_pixels, dtype=np.float64)
+        cov = self.frequency_covariance(nu[np.newaxis, :], nu[:, np.newaxis])
+        root, self._num_corr_freq = nputil.matrix_root_manynull(cov)
+        # the eigen-decomposition branch of the reference hands back a [1, F, k] root, with which its own
+        # getfield raises in tensordot (gaussianfg.py:80); use the [F, k] matrix it means
+        self._freq_weight = root[0] if root.ndim == 3 else root
+        patch = gaussianfield.RandomFieldA2.like_map(self)
+        patch.powerspectrum = lambda karray: self.angular_ps((karray**2).sum(axis=2) ** 0.5)
+        self._ang_field = patch
+        self._weight_gen = True
+
+    def getfield_device(self):
+        """Flat-sky cube ``[nfreq, x_num, y_num]`` as a device tensor (gaussianfg.py:72-84).
+
+        One angular realisation is transformed back to k-space, multiplied by frequency-correlated
+        normals (numpy global state, as the reference) and inverse transformed over the two angles -
+        rfftn, mixing and the batched irfft2 all run in csrc/flatsky.hip.
+        """
+        self.generate_weight()
+        ctx = _lib.get_context()
+        aff = ctx.rfftn(self._ang_field.getfield_device())
+        normals = np.random.standard_normal((self._num_corr_freq,) + tuple(aff.shape))
+        mixed = ctx.fg_mix(ctx.to_device(self._freq_weight), ctx.to_device(normals), aff)
+        return ctx.irfftn(mixed, naxes=2)
+
     def getfield(self):
-        raise NotImplementedError(
-            "flat-sky foreground cubes (gaussianfg.py:43-84) are out of scope of cora_amd")
+        return self.getfield_device().cpu().numpy()
 
 
 class ForegroundSCK(ForegroundMap):

@@ -213,6 +213,30 @@ int corahip_xi_table_average(corahip_ctx *ctx, const double *knots_x, const doub
 int corahip_legendre_project(corahip_ctx *ctx, const double *mu, const double *wt, int nm, int lmax,
                              const double *xi, long ncol, double *out);
 
+/* ---- flat-sky Gaussian fields (flat-sky half) ------------------------------
+ * n-dimensional FFTs over C-contiguous device arrays, complex = interleaved (re, im) float64; every
+ * transformed axis has length <= 4096, any length (powers of two directly, others by Bluestein).
+ * fft_c2c:   in-place transform of one axis; inverse = 0: sum x e^{-2 pi i jk/n}; 1: e^{+...} / n
+ *            (numpy.fft.fft / ifft along `axis`).
+ * irfftn:    numpy.fft.irfftn over the LAST naxes axes (cora/util/fftutil.py:80-87 with naxes = ndim;
+ *            the ifft + irfft of cora/foreground/gaussianfg.py:82-84 with naxes = 2): spec has shape
+ *            rdims with the last axis rdims[-1]/2 + 1 and is OVERWRITTEN; out has shape rdims.
+ * rfftn:     numpy.fft.rfftn over the last naxes axes (fftutil.py:64-77); in real rdims, spec as above.
+ * randomfield_draw: spec[e] = (g1 + i g2) kweight[e] with (g1, g2) the two Box-Muller normals of
+ *            Philox4x32-10 counter e under key = seed - the device form of
+ *            RandomField.getfield's `randn + 1j randn` (cora/core/gaussianfield.py:115-116); count
+ *            complex elements.  Follow with irfftn for the field.
+ * fg_mix:    out[f, m] = aff[m] sum_c freq_weight[f, c] normals[c, m]  (complex [F, M]; aff complex [M],
+ *            normals real [ncorr, M]) - the tensordot of ForegroundMap.getfield
+ *            (cora/foreground/gaussianfg.py:79-82); follow with irfftn(naxes = 2).                 */
+int corahip_fft_c2c(corahip_ctx *ctx, double *data, int ndim, const int64_t *dims, int axis, int inverse);
+int corahip_irfftn(corahip_ctx *ctx, double *spec, int ndim, const int64_t *rdims, int naxes, double *out);
+int corahip_rfftn(corahip_ctx *ctx, const double *in, int ndim, const int64_t *rdims, int naxes, double *spec);
+int corahip_randomfield_draw(corahip_ctx *ctx, const double *kweight, int64_t count, uint64_t seed,
+                             double *spec);
+int corahip_fg_mix(corahip_ctx *ctx, const double *freq_weight, const double *normals, const double *aff,
+                   int F, int ncorr, int64_t M, double *out);
+
 /* ring geometry of the plan (host arrays of length 4 nside - 1), for tests */
 int corahip_sht_plan_rings(const corahip_sht_plan *plan, int64_t *host_start, int32_t *host_nphi,
                            double *host_z, double *host_phi0);

@@ -43,11 +43,9 @@ def philox4x32_10(c0, c1, c2, c3, k0, k1):
     return tuple(v.astype(np.uint32) for v in c)
 
 
-def normal_pairs(seed, l, F, c, nup, mpair):
-    """The two normals of counter (mpair, l*2F + c*F + nup) - broadcasting over array arguments."""
-    hi = (np.asarray(l, dtype=np.uint64) * np.uint64(2 * F) + np.asarray(c, dtype=np.uint64) * np.uint64(F)
-          + np.asarray(nup, dtype=np.uint64)) & _MASK
-    r0, r1, r2, r3 = philox4x32_10(mpair, hi, 0, 0, seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
+def boxmuller_counter(seed, lo, hi):
+    """The two normals of Philox counter (lo, hi, 0, 0) under key = seed (broadcasts over arrays)."""
+    r0, r1, r2, r3 = philox4x32_10(lo, hi, 0, 0, seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
     k1 = (r0.astype(np.uint64) << np.uint64(21)) | (r1.astype(np.uint64) >> np.uint64(11))
     k2 = (r2.astype(np.uint64) << np.uint64(21)) | (r3.astype(np.uint64) >> np.uint64(11))
     u1 = (k1.astype(np.float64) + 0.5) * 2.0**-53
@@ -65,6 +63,13 @@ def normal_pairs(seed, l, F, c, nup, mpair):
     cs = np.where(((q + 2) >> 2) & 1, -cc, cc)
     sn = np.where(q & 4, -ss, ss)
     return rad * cs, rad * sn
+
+
+def normal_pairs(seed, l, F, c, nup, mpair):
+    """The two normals of counter (mpair, l*2F + c*F + nup) - broadcasting over array arguments."""
+    hi = (np.asarray(l, dtype=np.uint64) * np.uint64(2 * F) + np.asarray(c, dtype=np.uint64) * np.uint64(F)
+          + np.asarray(nup, dtype=np.uint64)) & _MASK
+    return boxmuller_counter(seed, mpair, hi)
 
 
 def device_normals(seed, lmax, F):

@@ -225,23 +225,6 @@ def test_cubicspline_accuracy(golden):
     assert np.abs(lsp(np.abs(golden["spl_xe"]) + 0.25) / golden["lspl_ye"] - 1).max() < 1e-12
 
 
-# ------------------------------------------------------------------ flat-sky API surface
-def test_random_field_api():
-    from cora_amd.core import gaussianfield, maps
-
-    rf = gaussianfield.RandomField(npix=[8, 8, 8], wsize=[1.0, 1.0, 2.0])
-    rf.powerspectrum = lambda k: 1.0 / (1.0 + (k**2).sum(axis=3))
-    np.random.seed(0)
-    f = rf.getfield()
-    assert f.shape == (8, 8, 8) and np.isrealobj(f) and abs(f.mean()) < 1e-12
-    m = maps.Map3d()
-    m.x_num, m.y_num, m.nu_num = 4, 6, 8
-    a2f = gaussianfield.RandomFieldA2F.like_map(m)
-    assert list(a2f._n) == [8, 4, 6]
-    a2 = gaussianfield.RandomFieldA2.like_map(m)
-    assert list(a2._n) == [4, 6]
-
-
 def test_makesky_freqstate_matches_reference_vectors():
     """FreqState (cora/scripts/makesky.py:44-92) against outputs of the reference's own class
     (tests/golden/make_golden_makesky.py) in every channelisation mode."""
