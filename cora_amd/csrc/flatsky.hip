@@ -23,7 +23,15 @@
 #include "common.h"
 #include "rng_dev.h"
 
-#define FS_THREADS 256
+#ifndef FS_ABLATE
+#define FS_ABLATE 0   // diagnostic builds (wrong results): 1 no LDS passes, 2 also no bit-reversed commit
+#endif
+#ifndef FS_THREADS
+#define FS_THREADS 512
+#endif
+#ifndef FS_LDS_ELEMS
+#define FS_LDS_ELEMS 4096   // complex elements per tile (64 KB)
+#endif
 #define FS_MAXN 4096
 
 __device__ static inline double2 cmul(double2 a, double2 b) {
@@ -32,10 +40,18 @@ __device__ static inline double2 cmul(double2 a, double2 b) {
 __device__ static inline double2 cadd(double2 a, double2 b) { return make_double2(a.x + b.x, a.y + b.y); }
 __device__ static inline double2 csub(double2 a, double2 b) { return make_double2(a.x - b.x, a.y - b.y); }
 __device__ static inline double2 mul_mi(double2 a) { return make_double2(a.y, -a.x); }  // a * (-i)
-__device__ static inline unsigned brev_n(unsigned i, int logP) { return logP ? (__brev(i) >> (32 - logP)) : 0u; }
+__device__ static inline unsigned brev_n(unsigned i, int logP) {
+#if FS_ABLATE == 2
+    return i;
+#endif
+    return logP ? (__brev(i) >> (32 - logP)) : 0u;
+}
 
 // decimation in time, forward sign: position i holds x[bitrev(i)] on entry, X[i] on exit; `lines` lines of P
-__device__ static void lds_dit(double2 *buf, int P, int logP, int lines, const double2 *__restrict__ tw) {
+// `tw` holds e^{-2 pi i k / P} for k < P/4 (only the quarter circle is ever indexed); the kernel keeps it in LDS:
+// a twiddle fetched from global memory inside a pass would wait (vmcnt is in-order) for the register prefetch
+// of the next tile issued just before the passes.
+__device__ __forceinline__ static void lds_dit(double2 *buf, int P, int logP, int lines, const double2 *tw) {
     int h = 1;
     if (logP & 1) {
         for (int w = threadIdx.x; w < lines * (P >> 1); w += FS_THREADS) {
@@ -49,12 +65,12 @@ __device__ static void lds_dit(double2 *buf, int P, int logP, int lines, const d
     }
     const int q = P >> 2, lq = logP - 2;
     for (; h < P; h <<= 2) {
-        const int s1 = P / (2 * h), s2 = P / (4 * h);
+        const int s2 = P / (4 * h);
         for (int w = threadIdx.x; w < lines * q; w += FS_THREADS) {
             const int t = w >> lq, j = w & (q - 1);
             const int pos = j & (h - 1), grp = j / h;
             double2 *p = buf + t * P + grp * 4 * h + pos;
-            const double2 w1 = tw[pos * s1], w2 = tw[pos * s2];
+            const double2 w2 = tw[pos * s2], w1 = cmul(w2, w2);
             const double2 a = p[0], b = cmul(w1, p[h]), c = p[2 * h], d = cmul(w1, p[3 * h]);
             const double2 a1 = cadd(a, b), b1 = csub(a, b);
             const double2 c1 = cmul(w2, cadd(c, d)), d1 = cmul(mul_mi(w2), csub(c, d));
@@ -68,16 +84,16 @@ __device__ static void lds_dit(double2 *buf, int P, int logP, int lines, const d
 }
 
 // decimation in frequency, forward sign: natural order in, position i holds X[bitrev(i)] on exit
-__device__ static void lds_dif(double2 *buf, int P, int logP, int lines, const double2 *__restrict__ tw) {
+__device__ __forceinline__ static void lds_dif(double2 *buf, int P, int logP, int lines, const double2 *tw) {
     const int q = P >> 2, lq = logP - 2;
     const int hmin = (logP & 1) ? 2 : 1;
     for (int h = P >> 2; h >= hmin; h >>= 2) {
-        const int s1 = P / (2 * h), s2 = P / (4 * h);
+        const int s2 = P / (4 * h);
         for (int w = threadIdx.x; w < lines * q; w += FS_THREADS) {
             const int t = w >> lq, j = w & (q - 1);
             const int pos = j & (h - 1), grp = j / h;
             double2 *p = buf + t * P + grp * 4 * h + pos;
-            const double2 w1 = tw[pos * s1], w2 = tw[pos * s2];
+            const double2 w2 = tw[pos * s2], w1 = cmul(w2, w2);
             const double2 x0 = p[0], x1 = p[h], x2 = p[2 * h], x3 = p[3 * h];
             const double2 a1 = cadd(x0, x2), c1 = cmul(w2, csub(x0, x2));
             const double2 b1 = cadd(x1, x3), d1 = cmul(mul_mi(w2), csub(x1, x3));
@@ -109,12 +125,19 @@ struct linefft_args {
     int inverse;         // sign +, for MODE 0
     double scale;
     int P, logP, blu;
+    int twl;             // quarter-circle twiddle table kept in LDS behind the tile (P <= 4096)
     const double2 *tw, *chirp, *filt;
 };
 
 // MODE 0: complex -> complex (in place allowed), 1: half-complex -> real (inverse), 2: real -> half-complex
+//
+// Persistent workgroups walk the tiles; the global loads of the NEXT tile are issued into registers before
+// the LDS passes of the current one and committed to LDS after its stores, so HBM latency hides behind the
+// transform (FS_NLOAD loads in flight per thread).
+#define FS_WG_PER_CU (FS_THREADS >= 1024 ? 1 : 2)
+#define FS_NLOAD ((FS_LDS_ELEMS + FS_THREADS - 1) / FS_THREADS)
 template <int MODE>
-__global__ void __launch_bounds__(FS_THREADS) linefft_kernel(const linefft_args A) {
+__global__ void __launch_bounds__(FS_THREADS, FS_WG_PER_CU) linefft_kernel(const linefft_args A) {
     extern __shared__ double2 fs_lds[];
     const int n = A.n, P = A.P, logP = A.logP, T = A.T;
     const bool inv = MODE == 1 || (MODE == 0 && A.inverse);
@@ -123,93 +146,122 @@ __global__ void __launch_bounds__(FS_THREADS) linefft_kernel(const linefft_args 
     const long chunks = (A.inner + T - 1) / T;  // tiles per outer index (inner > 1)
     const long nlines = A.nouter * A.inner;
     const long ntiles = A.inner == 1 ? (nlines + T - 1) / T : A.nouter * chunks;
+    const int nin = MODE == 1 ? A.nh : n;       // input elements per line
+    const int nout = MODE == 2 ? A.nh : n;      // output elements per line
 
-    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    struct tile_t {
         long outer, i0;
         int teff;
+    };
+    auto tile_of = [&](long tile) {
+        tile_t tl;
         if (A.inner == 1) {
-            outer = tile * T;  // first line
-            i0 = 0;
-            teff = (int)min((long)T, nlines - outer);
+            tl.outer = tile * T;  // first line
+            tl.i0 = 0;
+            tl.teff = (int)min((long)T, nlines - tl.outer);
         } else {
-            outer = tile / chunks;
-            i0 = (tile - outer * chunks) * T;
-            teff = (int)min((long)T, A.inner - i0);
+            tl.outer = tile / chunks;
+            tl.i0 = (tile - tl.outer * chunks) * T;
+            tl.teff = (int)min((long)T, A.inner - tl.i0);
         }
-        // ---- load -------------------------------------------------------------------------------
+        return tl;
+    };
+    // element e of a tile -> (line t, index j along the axis, global element offset) for `len` elements per line
+    auto locate = [&](const tile_t &tl, int e, int len, int &t, int &j) -> long {
+        if (A.inner == 1) {
+            t = e / len, j = e - t * len;
+            return (tl.outer + t) * len + j;
+        }
+        j = e / tl.teff, t = e - j * tl.teff;
+        return (tl.outer * len + j) * A.inner + tl.i0 + t;
+    };
+    double2 R[FS_NLOAD];
+    auto prefetch = [&](const tile_t &tl) {
+#pragma unroll
+        for (int u = 0; u < FS_NLOAD; u++) {
+            const int e = threadIdx.x + u * FS_THREADS;
+            if (e < tl.teff * nin) {
+                int t, j;
+                const long addr = locate(tl, e, nin, t, j);
+                R[u] = MODE == 2 ? make_double2(A.in[addr], 0.0) : in2[addr];
+            }
+        }
+    };
+    auto commit = [&](const tile_t &tl) {
         if (A.blu) {
-            for (int e = threadIdx.x; e < teff * (P - n); e += FS_THREADS) {
+            for (int e = threadIdx.x; e < tl.teff * (P - n); e += FS_THREADS) {
                 const int t = e / (P - n), j = n + e % (P - n);
                 fs_lds[t * P + j] = make_double2(0.0, 0.0);
             }
         }
-        if (MODE == 0) {
-            for (int e = threadIdx.x; e < teff * n; e += FS_THREADS) {
+#pragma unroll
+        for (int u = 0; u < FS_NLOAD; u++) {
+            const int e = threadIdx.x + u * FS_THREADS;
+            if (e < tl.teff * nin) {
                 int t, j;
-                long addr;
-                if (A.inner == 1) {
-                    t = e / n, j = e - t * n;
-                    addr = (outer + t) * n + j;
+                (void)locate(tl, e, nin, t, j);
+                double2 v = R[u];
+                if (MODE == 1) {
+                    if (j == 0 || 2 * j == n) v.y = 0.0;
+                    // conj of the Hermitian extension: position j gets conj(c_j), position n-j gets c_j
+                    const double2 lo = make_double2(v.x, -v.y);
+                    const bool mirror = j > 0 && 2 * j < n;
+                    if (A.blu) {
+                        fs_lds[t * P + j] = cmul(lo, A.chirp[j]);
+                        if (mirror) fs_lds[t * P + n - j] = cmul(v, A.chirp[n - j]);
+                    } else {
+                        fs_lds[t * P + brev_n(j, logP)] = lo;
+                        if (mirror) fs_lds[t * P + brev_n(n - j, logP)] = v;
+                    }
                 } else {
-                    j = e / teff, t = e - j * teff;
-                    addr = (outer * n + j) * A.inner + i0 + t;
+                    if (inv) v.y = -v.y;
+                    if (A.blu)
+                        fs_lds[t * P + j] = cmul(v, A.chirp[j]);
+                    else
+                        fs_lds[t * P + brev_n(j, logP)] = v;
                 }
-                double2 v = in2[addr];
-                if (inv) v.y = -v.y;
-                if (A.blu)
-                    fs_lds[t * P + j] = cmul(v, A.chirp[j]);
-                else
-                    fs_lds[t * P + brev_n(j, logP)] = v;
-            }
-        } else if (MODE == 1) {
-            const int nh = A.nh;
-            for (int e = threadIdx.x; e < teff * nh; e += FS_THREADS) {
-                const int t = e / nh, k = e - t * nh;
-                double2 v = in2[(outer + t) * nh + k];
-                if (k == 0 || 2 * k == n) v.y = 0.0;
-                // conj of the Hermitian extension: position k gets conj(c_k), position n-k gets c_k
-                const double2 lo = make_double2(v.x, -v.y);
-                if (A.blu) {
-                    fs_lds[t * P + k] = cmul(lo, A.chirp[k]);
-                    if (k > 0 && 2 * k < n) fs_lds[t * P + n - k] = cmul(v, A.chirp[n - k]);
-                } else {
-                    fs_lds[t * P + brev_n(k, logP)] = lo;
-                    if (k > 0 && 2 * k < n) fs_lds[t * P + brev_n(n - k, logP)] = v;
-                }
-            }
-        } else {
-            for (int e = threadIdx.x; e < teff * n; e += FS_THREADS) {
-                const int t = e / n, j = e - t * n;
-                const double2 v = make_double2(A.in[(outer + t) * n + j], 0.0);
-                if (A.blu)
-                    fs_lds[t * P + j] = cmul(v, A.chirp[j]);
-                else
-                    fs_lds[t * P + brev_n(j, logP)] = v;
             }
         }
+    };
+
+    long tile = blockIdx.x;
+    if (tile >= ntiles) return;
+    double2 *twl = fs_lds + T * P;
+    if (A.twl)
+        for (int k = threadIdx.x; k < (P >> 2); k += FS_THREADS) twl[k] = A.tw[k];
+    tile_t cur = tile_of(tile);
+    prefetch(cur);
+    while (true) {
+        commit(cur);
         __syncthreads();
+        const long next = tile + gridDim.x;
+        tile_t nxt = cur;
+        if (next < ntiles) {
+            nxt = tile_of(next);
+            prefetch(nxt);
+        }
         // ---- transform --------------------------------------------------------------------------
         if (A.blu) {
-            lds_dif(fs_lds, P, logP, teff, A.tw);
-            for (int e = threadIdx.x; e < teff * P; e += FS_THREADS) {
+            if (A.twl)
+                lds_dif(fs_lds, P, logP, cur.teff, twl);
+            else
+                lds_dif(fs_lds, P, logP, cur.teff, A.tw);
+            for (int e = threadIdx.x; e < cur.teff * P; e += FS_THREADS) {
                 const double2 z = cmul(fs_lds[e], A.filt[e & (P - 1)]);
                 fs_lds[e] = make_double2(z.x, -z.y);
             }
             __syncthreads();
         }
-        lds_dit(fs_lds, P, logP, teff, A.tw);
+        if (FS_ABLATE == 0) {
+            if (A.twl)
+                lds_dit(fs_lds, P, logP, cur.teff, twl);
+            else
+                lds_dit(fs_lds, P, logP, cur.teff, A.tw);
+        }
         // ---- store ------------------------------------------------------------------------------
-        const int nout = MODE == 2 ? A.nh : n;
-        for (int e = threadIdx.x; e < teff * nout; e += FS_THREADS) {
+        for (int e = threadIdx.x; e < cur.teff * nout; e += FS_THREADS) {
             int t, k;
-            long addr;
-            if (A.inner == 1) {
-                t = e / nout, k = e - t * nout;
-                addr = (outer + t) * nout + k;
-            } else {
-                k = e / teff, t = e - k * teff;
-                addr = (outer * n + k) * A.inner + i0 + t;
-            }
+            const long addr = locate(cur, e, nout, t, k);
             double2 v = fs_lds[t * P + k];
             if (A.blu) v = cmul(make_double2(v.x, -v.y), A.chirp[k]);
             if (MODE == 1) {
@@ -219,7 +271,10 @@ __global__ void __launch_bounds__(FS_THREADS) linefft_kernel(const linefft_args 
                 out2[addr] = make_double2(v.x * A.scale, v.y * A.scale);
             }
         }
+        if (next >= ntiles) break;
         __syncthreads();
+        tile = next;
+        cur = nxt;
     }
 }
 
@@ -325,6 +380,7 @@ static int launch_linefft(corahip_ctx *ctx, const double *in, double *out, long 
     const corahip_linefft_plan *pl;
     int rc = get_linefft_plan(ctx, n, &pl);
     if (rc) return rc;
+    StageTimer pass_timer(ctx, MODE == 1 ? "fft_c2r" : (MODE == 2 ? "fft_r2c" : (inner == 1 ? "fft_c2c_contig" : "fft_c2c_strided")));
     linefft_args A;
     A.in = in;
     A.out = out;
@@ -340,13 +396,15 @@ static int launch_linefft(corahip_ctx *ctx, const double *in, double *out, long 
     A.tw = pl->tw;
     A.chirp = pl->chirp;
     A.filt = pl->filt;
-    int T = 4096 / pl->P;
+    int T = FS_LDS_ELEMS / pl->P;
     T = T < 1 ? 1 : (T > 16 ? 16 : T);
     A.T = T;
-    const size_t shm = sizeof(double2) * (size_t)T * pl->P;
+    A.twl = pl->P <= 4096;
+    const size_t shm = sizeof(double2) * ((size_t)T * pl->P + (A.twl ? pl->P / 4 : 0));
     const long chunks = (inner + T - 1) / T;
     const long ntiles = inner == 1 ? (nouter + T - 1) / T : nouter * chunks;
-    const long maxgrid = (long)ctx->num_cu * (shm > 65536 ? 1 : 2);
+    const long per_cu = (FS_WG_PER_CU == 2 && shm * 2 <= 160 * 1024) ? 2 : 1;   // launch bounds allow two 8-wave workgroups per CU
+    const long maxgrid = (long)ctx->num_cu * per_cu;
     const int grid = (int)(ntiles < maxgrid ? ntiles : maxgrid);
     HIP_TRY(hipFuncSetAttribute((const void *)linefft_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)shm));
