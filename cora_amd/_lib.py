@@ -67,6 +67,10 @@ SIGNATURES = {
     "corahip_rfftn": (c_int, [c_void_p, PTR, c_int, PTR, c_int, PTR]),
     "corahip_randomfield_draw": (c_int, [c_void_p, PTR, ctypes.c_int64, ctypes.c_uint64, PTR]),
     "corahip_fg_mix": (c_int, [c_void_p, PTR, PTR, PTR, c_int, c_int, ctypes.c_int64, PTR]),
+    "corahip_spec_mul_real": (c_int, [c_void_p, PTR, PTR, ctypes.c_int64]),
+    "corahip_cube_affine": (c_int, [c_void_p, PTR, PTR, PTR, PTR, PTR, c_int, ctypes.c_int64, PTR]),
+    "corahip_raytrace_slices": (c_int, [c_void_p, PTR, c_int, c_int, c_int, PTR, PTR, PTR, PTR, c_double, c_double,
+                                        c_int, c_int, c_int, PTR]),
     "corahip_sht_plan_rings": (c_int, [c_void_p, PTR, PTR, PTR, PTR]),
     "corahip_sht_lambda": (c_int, [c_void_p, c_void_p, c_int, c_int, PTR]),
 }
@@ -458,6 +462,29 @@ class Context:
         out = torch.empty((F,) + tuple(aff.shape), dtype=torch.complex128, device=self.device)
         _check(self.lib.corahip_fg_mix(self.h, self._f64(freq_weight), self._f64(normals), self._c128(aff), F, ncorr,
                                        aff.numel(), self._c128(out)))
+        return out
+
+    def spec_mul_real(self, spec, weight):
+        assert tuple(spec.shape) == tuple(weight.shape)
+        _check(self.lib.corahip_spec_mul_real(self.h, self._c128(spec), self._f64(weight), spec.numel()))
+        return spec
+
+    def cube_affine(self, df, vf, a, b, c):
+        """out[z] = a[z] df[z] + b[z] vf[z] + c[z]; ``vf`` may be None."""
+        n0 = df.shape[0]
+        out = self.empty(tuple(df.shape))
+        _check(self.lib.corahip_cube_affine(self.h, self._f64(df), None if vf is None else self._f64(vf), self._f64(a),
+                                            None if vf is None else self._f64(b), self._f64(c), n0, df.numel() // n0,
+                                            self._f64(out)))
+        return out
+
+    def raytrace_slices(self, cube, zc, scale, tx, ty, wx, wy):
+        n0, n1, n2 = cube.shape
+        numz, numx, numy = zc.numel(), tx.numel(), ty.numel()
+        out = self.empty((numz, numx, numy))
+        _check(self.lib.corahip_raytrace_slices(self.h, self._f64(cube), n0, n1, n2, self._f64(zc), self._f64(scale),
+                                                self._f64(tx), self._f64(ty), float(wx), float(wy), numz, numx, numy,
+                                                self._f64(out)))
         return out
 
     def sht_rings(self, nside, lmax):

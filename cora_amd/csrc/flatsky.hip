@@ -302,6 +302,64 @@ __global__ void fg_mix_kernel(const double *__restrict__ W, const double *__rest
     }
 }
 
+// spec[e] *= w[e]  (complex spectrum times a real k-space weight: the mu^2 of corr.py:590-599)
+__global__ void spec_mul_real_kernel(double2 *__restrict__ spec, const double *__restrict__ w, long count) {
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < count; e += (long)gridDim.x * blockDim.x) {
+        const double2 v = spec[e];
+        const double f = w[e];
+        spec[e] = make_double2(v.x * f, v.y * f);
+    }
+}
+
+// out[z][p] = a[z] df[z][p] (+ b[z] vf[z][p]) + c[z]: the per-slice growth / bias / mean of corr.py:712-726
+__global__ void cube_affine_kernel(const double *__restrict__ df, const double *__restrict__ vf,
+                                   const double *__restrict__ a, const double *__restrict__ b,
+                                   const double *__restrict__ c, long plane, double *__restrict__ out) {
+    const int z = blockIdx.y;
+    const double az = a[z], bz = vf ? b[z] : 0.0, cz = c[z];
+    for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < plane; p += (long)gridDim.x * blockDim.x) {
+        const size_t e = (size_t)z * plane + p;
+        // same operation order as the reference: (df a) + (vf b), then + mean
+        double v = df[e] * az;
+        if (vf) v += vf[e] * bz;
+        out[e] = v + cz;
+    }
+}
+
+// Ray-traced resampling of the comoving cube onto (redshift slice, angle, angle): scipy.ndimage.map_coordinates
+// with order = 1 and the default mode 'constant' (corr.py:744-768): trilinear interpolation at
+//   (zc[i], (tx[ix] s[i]) / wx (n1 - 1) + (n1 - 1)/2, (ty[iy] s[i]) / wy (n2 - 1) + (n2 - 1)/2),
+// exactly 0 when any coordinate lies outside [0, n - 1] (no interpolation towards the fill value).
+__global__ void raytrace_kernel(const double *__restrict__ cube, int n0, int n1, int n2, const double *__restrict__ zc,
+                                const double *__restrict__ s, const double *__restrict__ tx,
+                                const double *__restrict__ ty, double wx, double wy, int numx, int numy,
+                                double *__restrict__ out) {
+    const int i = blockIdx.y;
+    const double cz = zc[i], si = s[i];
+    const long plane = (long)numx * numy;
+    for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < plane; p += (long)gridDim.x * blockDim.x) {
+        const int ix = (int)(p / numy), iy = (int)(p - (long)ix * numy);
+        const double cx = (tx[ix] * si) / wx * (n1 - 1.0) + 0.5 * (n1 - 1.0);
+        const double cy = (ty[iy] * si) / wy * (n2 - 1.0) + 0.5 * (n2 - 1.0);
+        double v = 0.0;
+        if (cz >= 0.0 && cz <= n0 - 1.0 && cx >= 0.0 && cx <= n1 - 1.0 && cy >= 0.0 && cy <= n2 - 1.0) {
+            const int z0 = (int)cz, x0 = (int)cx, y0 = (int)cy;   // floor: coordinates are >= 0
+            const double fz = cz - z0, fx = cx - x0, fy = cy - y0;
+            const int z1 = z0 + 1 < n0 ? z0 + 1 : z0, x1 = x0 + 1 < n1 ? x0 + 1 : x0, y1 = y0 + 1 < n2 ? y0 + 1 : y0;
+            const double wz[2] = {1.0 - fz, fz}, wxx[2] = {1.0 - fx, fx}, wyy[2] = {1.0 - fy, fy};
+            const int zi[2] = {z0, z1}, xi[2] = {x0, x1}, yi[2] = {y0, y1};
+#pragma unroll
+            for (int a = 0; a < 2; a++)
+#pragma unroll
+                for (int b = 0; b < 2; b++)
+#pragma unroll
+                    for (int c = 0; c < 2; c++)
+                        v += wz[a] * wxx[b] * wyy[c] * cube[((size_t)zi[a] * n1 + xi[b]) * n2 + yi[c]];
+        }
+        out[(size_t)i * plane + p] = v;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
@@ -490,6 +548,46 @@ int corahip_fg_mix(corahip_ctx *ctx, const double *freq_weight, const double *no
     if (bx > 65535) bx = 65535;
     hipLaunchKernelGGL(fg_mix_kernel, dim3((unsigned)bx, (unsigned)F), dim3(256), 0, ctx->stream, freq_weight, normals,
                        reinterpret_cast<const double2 *>(aff), ncorr, (long)M, reinterpret_cast<double2 *>(out));
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int corahip_spec_mul_real(corahip_ctx *ctx, double *spec, const double *weight, int64_t count) {
+    ARG_CHECK(ctx && spec && weight && count >= 0);
+    if (count == 0) return 0;
+    StageTimer st(ctx, "spec_mul");
+    long blocks = (count + 255) / 256;
+    const long cap = (long)ctx->num_cu * 16;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(spec_mul_real_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream,
+                       reinterpret_cast<double2 *>(spec), weight, (long)count);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int corahip_cube_affine(corahip_ctx *ctx, const double *df, const double *vf, const double *a, const double *b,
+                        const double *c, int n0, int64_t plane, double *out) {
+    ARG_CHECK(ctx && df && a && c && out && (vf == nullptr || b != nullptr) && n0 >= 1 && n0 <= 65535 && plane >= 1);
+    StageTimer st(ctx, "cube_affine");
+    long bx = (plane + 255) / 256;
+    if (bx > 4096) bx = 4096;
+    hipLaunchKernelGGL(cube_affine_kernel, dim3((unsigned)bx, (unsigned)n0), dim3(256), 0, ctx->stream, df, vf, a, b, c,
+                       (long)plane, out);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int corahip_raytrace_slices(corahip_ctx *ctx, const double *cube, int n0, int n1, int n2, const double *zc,
+                            const double *scale, const double *tx, const double *ty, double wx, double wy, int numz,
+                            int numx, int numy, double *out) {
+    ARG_CHECK(ctx && cube && zc && scale && tx && ty && out);
+    ARG_CHECK(n0 >= 1 && n1 >= 1 && n2 >= 1 && numz >= 1 && numz <= 65535 && numx >= 1 && numy >= 1 && wx != 0.0 &&
+              wy != 0.0);
+    StageTimer st(ctx, "raytrace");
+    long bx = ((long)numx * numy + 255) / 256;
+    if (bx > 4096) bx = 4096;
+    hipLaunchKernelGGL(raytrace_kernel, dim3((unsigned)bx, (unsigned)numz), dim3(256), 0, ctx->stream, cube, n0, n1, n2,
+                       zc, scale, tx, ty, wx, wy, numx, numy, out);
     LAUNCH_CHECK();
     return 0;
 }

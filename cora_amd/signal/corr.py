@@ -8,8 +8,12 @@ Evaluation (device): K1 in csrc/clarray.hip, either fused with the Romberg chann
 average (through ``skysim.clarray``) or at arbitrary broadcast points (calling
 ``angular_powerspectrum`` directly).
 
-Everything else in the reference's corr.py (flat-sky cubes, multipole correlation
-functions, ``angular_powerspectrum_full``) is outside this package's scope.
+The flat-sky redshift-space cube (``_realisation_dv`` / ``realisation``, corr.py:562-770) runs on
+the GPU through csrc/flatsky.hip: Gaussian field draw, the mu^2 velocity field by rfftn / irfftn,
+per-slice growth factors and the ray-traced trilinear resampling.
+
+The multipole correlation functions and ``angular_powerspectrum_full`` of the reference's corr.py
+are outside this package's scope.
 """
 import math
 
@@ -17,6 +21,9 @@ import numpy as np
 import scipy.fftpack
 
 from .. import _lib
+from ..core import gaussianfield
+from ..util import constants, fftutil
+from ..util import cubicspline as cs
 from ..util.cosmology import Cosmology
 
 
@@ -76,6 +83,112 @@ class RedshiftCorrelation(object):
 
     def mean(self, z):
         return np.ones_like(z) * 0.0
+
+    # ---- flat-sky redshift-space cube (corr.py:547-770) ----------------------------------
+    _sigma_v = 0.0
+
+    def sigma_v(self, z):
+        """Pairwise velocity dispersion, ``_sigma_v`` km/s -> h^-1 Mpc (corr.py:549-556)."""
+        return np.ones_like(z) * (self._sigma_v / 100.0)
+
+    def velocity_damping(self, kpar):
+        """Lorentzian damping of the line-of-sight modes (corr.py:558-560)."""
+        return (1.0 + (kpar * self.sigma_v(self.ps_redshift)) ** 2.0) ** -1.0
+
+    def _cube_generator(self, d, n):
+        # field generator + mu^2 array of one cube geometry, resident on the device and reused between calls
+        key = (tuple(float(x) for x in d), tuple(int(x) for x in n))
+        cache = self.__dict__.setdefault("_cube_cache", {})
+        if key not in cache:
+            rfv = gaussianfield.RandomField(npix=np.array(n), wsize=np.array(d))
+            rfv.powerspectrum = lambda karray: (self.ps_vv((karray**2).sum(axis=3) ** 0.5)
+                                                * self.velocity_damping(karray[..., 0]))
+            rfv.generate_kweight()
+            kvec = fftutil.rfftfreqn(rfv._n, (rfv._w / rfv._n) / (2 * math.pi))
+            with np.errstate(invalid="ignore", divide="ignore"):
+                mu2 = kvec[..., 0] ** 2 / (kvec**2).sum(axis=3)
+            mu2.flat[0] = 0.0
+            cache.clear()
+            cache[key] = (rfv, _lib.get_context().to_device(mu2))
+        return cache[key]
+
+    def _realisation_dv_device(self, d, n, seed=None):
+        """Density and line-of-sight velocity cubes as device tensors (corr.py:562-603).
+
+        ``seed=None`` uses numpy's global state exactly as the reference; an integer draws on the GPU.
+        """
+        if not self._vv_only:
+            raise Exception("Doesn't work for independent fields, I need to think a bit more first.")
+        ctx = _lib.get_context()
+        rfv, mu2 = self._cube_generator(d, n)
+        df = rfv.getfield_device(seed=seed)
+        spec = ctx.spec_mul_real(ctx.rfftn(df), mu2)
+        vf = ctx.irfftn(spec)
+        return df, vf
+
+    def _realisation_dv(self, d, n):
+        df, vf = self._realisation_dv_device(d, n)
+        return df.cpu().numpy(), vf.cpu().numpy()
+
+    def realisation(self, z1, z2, thetax, thetay, numz, numx, numy, zspace=True, refinement=1,
+                    report_physical=False, density_only=False, no_mean=False, no_evolution=False, pad=5,
+                    seed=None, device=False):
+        """Simulate a redshift-space volume ``[numz, numx, numy]`` in the flat-sky approximation.
+
+        Same arguments and geometry as corr.py:605-770: a padded comoving box between ``z1`` and ``z2`` is
+        filled with a Gaussian density field and its mu^2 velocity field, scaled slice by slice with
+        D(z), b(z), f(z), the prefactor and the mean, and resampled along the lines of sight onto regular
+        angle / redshift (``zspace``) or angle / scale-factor bins by trilinear interpolation.  ``seed`` and
+        ``device`` are extensions: device-side normals, and device tensors instead of numpy arrays.
+        """
+        cosmo = self.cosmology
+        d1, d2 = cosmo.proper_distance(z1), cosmo.proper_distance(z2)
+        c1, c2 = cosmo.comoving_distance(z1), cosmo.comoving_distance(z2)
+        c_center = (c1 + c2) / 2.0
+        d = np.array([c2 - c1, thetax * d2 * constants.degree, thetay * d2 * constants.degree])
+        n = np.array([numz, int(d2 / d1 * numx), int(d2 / d1 * numy)])
+        if (n[-1] + pad) % 2 != 0:
+            pad += 1
+        d = d * (n + pad).astype(float) / n.astype(float)
+        c1 = c_center - (c_center - c1) * (n[0] + pad) / float(n[0])
+        c2 = c_center + (c2 - c_center) * (n[0] + pad) / float(n[0])
+        n = refinement * (n + pad)
+
+        ctx = _lib.get_context()
+        df, vf = self._realisation_dv_device(d, n, seed=seed)
+        n = tuple(df.shape)
+
+        # redshift of every slice of the box, then the slice factors
+        comoving_inv = inverse_approx(cosmo.comoving_distance, z1, z2)
+        za = comoving_inv(np.linspace(c1, c2, n[0], endpoint=True))
+        mz = self.mean(za)
+        Dz = self.growth_factor(za) / self.growth_factor(self.ps_redshift)
+        dfac = Dz * self.prefactor(za) * self.bias_z(za)
+        vfac = Dz * self.prefactor(za) * self.growth_rate(za)
+        if no_evolution:
+            dfac = np.full(n[0], np.mean(dfac))
+            vfac = np.full(n[0], np.mean(vfac))
+        mean = np.zeros(n[0]) if no_mean else mz * np.ones(n[0])
+        rsf = ctx.cube_affine(df, None if density_only else vf, ctx.to_device(dfac), ctx.to_device(vfac),
+                              ctx.to_device(mean))
+
+        # lines of sight: regular in redshift or in scale factor
+        if zspace:
+            za = np.linspace(z1, z2, numz, endpoint=False)
+        else:
+            za = 1.0 / np.linspace(1.0 / (1 + z2), 1.0 / (1 + z1), numz, endpoint=False)[::-1] - 1.0
+        da = cosmo.proper_distance(za)
+        xa = cosmo.comoving_distance(za)
+        tx = np.linspace(-thetax / 2.0, thetax / 2.0, numx) * constants.degree
+        ty = np.linspace(-thetay / 2.0, thetay / 2.0, numy) * constants.degree
+        zc = (xa - c1) / (c2 - c1) * (n[0] - 1.0)
+        acube = ctx.raytrace_slices(rsf, ctx.to_device(zc), ctx.to_device(da), ctx.to_device(tx), ctx.to_device(ty),
+                                    d[1], d[2])
+        if not device:
+            acube, rsf = acube.cpu().numpy(), (rsf.cpu().numpy() if report_physical else rsf)
+        if report_physical:
+            return acube, rsf, (c1, c2, d[1], d[2])
+        return acube
 
     # ---- table build / cache (corr.py:870-887, 909-942) ---------------------------------
     def _build_tables(self):
@@ -162,3 +275,9 @@ class RedshiftCorrelation(object):
         return res if res.ndim else float(res)
 
     angular_powerspectrum = angular_powerspectrum_fft
+
+
+def inverse_approx(f, x1, x2):
+    """Spline of the inverse of a monotonic ``f`` sampled at 1000 points of [x1, x2] (corr.py:1053-1076)."""
+    xa = np.linspace(x1, x2, 1000)
+    return cs.Interpolater(f(xa), xa)

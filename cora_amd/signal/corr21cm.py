@@ -86,3 +86,20 @@ class Corr21cm(corr.RedshiftCorrelation, maps.Sky3d):
 
     def mean_nu(self, freq):
         return self.mean(constants.nu21 / freq - 1.0)
+
+    def _band_redshifts(self):
+        return constants.nu21 / self.nu_upper - 1.0, constants.nu21 / self.nu_lower - 1.0
+
+    def getfield(self, seed=None):
+        """Flat-sky realisation of the 21cm signal ``[nu_num, x_num, y_num]``, lowest frequency first
+        (corr21cm.py:241-257)."""
+        z1, z2 = self._band_redshifts()
+        cube = self.realisation(z1, z2, self.x_width, self.y_width, self.nu_num, self.x_num, self.y_num,
+                                zspace=False, seed=seed)
+        return cube[::-1, :, :].copy()
+
+    def get_kiyo_field(self, refinement=1, seed=None):
+        """As :meth:`getfield` but highest frequency first and with a refined box (corr21cm.py:259-276)."""
+        z1, z2 = self._band_redshifts()
+        return self.realisation(z1, z2, self.x_width, self.y_width, self.nu_num, self.x_num, self.y_num,
+                                refinement=refinement, zspace=False, seed=seed)

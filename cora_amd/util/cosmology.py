@@ -64,6 +64,18 @@ class Cosmology:
         return _intf_0_z(lambda z1: constants.c / self.H(z1), z) / self._unit_distance
 
 
+    def proper_distance(self, z):
+        """Comoving transverse separation per unit angle (cosmology.py:212-241): chi, curved by omega_k."""
+        x = self.comoving_distance(z)
+        om_k = self.omega_k
+        dhi = np.sqrt(np.fabs(om_k)) * self.H() / constants.c * self._unit_distance
+        if om_k < 0.0:
+            x = np.sin(x * dhi) / dhi
+        elif om_k > 0.0:
+            x = np.sinh(x * dhi) / dhi
+        return x
+
+
 def _intf_0_z(f, z):
     if not isinstance(z, np.ndarray):
         return _intf_0_z(f, np.array([z], dtype=np.float64))[0]

@@ -236,6 +236,20 @@ int corahip_randomfield_draw(corahip_ctx *ctx, const double *kweight, int64_t co
                              double *spec);
 int corahip_fg_mix(corahip_ctx *ctx, const double *freq_weight, const double *normals, const double *aff,
                    int F, int ncorr, int64_t M, double *out);
+/* The redshift-space cube of RedshiftCorrelation.realisation / Corr21cm.getfield (cora/signal/corr.py:562-770,
+ * cora/signal/corr21cm.py:241-257) on top of the transforms above:
+ * spec_mul_real:   spec[e] *= weight[e] (complex x real; the mu^2 factor of corr.py:590-599), count elements.
+ * cube_affine:     out[z, p] = a[z] df[z, p] + b[z] vf[z, p] + c[z] (corr.py:712-726); vf (and b) may be NULL.
+ * raytrace_slices: scipy.ndimage.map_coordinates(cube, order=1, mode='constant') at the coordinates of
+ *                  corr.py:744-768: out[i, ix, iy] = cube(zc[i], (tx[ix] scale[i]) / wx (n1-1) + (n1-1)/2,
+ *                  (ty[iy] scale[i]) / wy (n2-1) + (n2-1)/2), 0 outside [0, n-1]; cube [n0, n1, n2],
+ *                  out [numz, numx, numy].                                                         */
+int corahip_spec_mul_real(corahip_ctx *ctx, double *spec, const double *weight, int64_t count);
+int corahip_cube_affine(corahip_ctx *ctx, const double *df, const double *vf, const double *a, const double *b,
+                        const double *c, int n0, int64_t plane, double *out);
+int corahip_raytrace_slices(corahip_ctx *ctx, const double *cube, int n0, int n1, int n2, const double *zc,
+                            const double *scale, const double *tx, const double *ty, double wx, double wy,
+                            int numz, int numx, int numy, double *out);
 
 /* ring geometry of the plan (host arrays of length 4 nside - 1), for tests */
 int corahip_sht_plan_rings(const corahip_sht_plan *plan, int64_t *host_start, int32_t *host_nphi,

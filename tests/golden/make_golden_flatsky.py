@@ -58,6 +58,56 @@ def _legacy_geometry(obj):
     obj._width_array = lambda: legacy(wid())
 
 
+def redshift_cube_vectors(gaussianfield):
+    """``Corr21cm.getfield`` -> ``RedshiftCorrelation.realisation`` -> ``_realisation_dv`` (corr.py:562-760,
+    corr21cm.py:241-257).  ``_realisation_dv`` builds ``RandomField(npix=n, wsize=d)`` from plain arrays, whose
+    ``npix != None`` test (gaussianfield.py:30) current numpy refuses: the class is wrapped so that its arguments
+    arrive as legacy arrays.  Needs the reference's compiled cubicspline (make_golden._build_cython)."""
+    import tempfile
+
+    for name in ("cora.util.cubicspline", "cora.util.bilinearmap"):
+        sys.modules.pop(name, None)
+    make_golden._build_cython(tempfile.mkdtemp(prefix="cora_golden_fs_"))
+    for name in [m for m in sys.modules if m.startswith("cora.signal") or m.startswith("cora.foreground")]:
+        sys.modules.pop(name)       # re-import against the real cubicspline
+    from cora.signal import corr21cm
+
+    base = gaussianfield.RandomField
+
+    class LegacyArgsField(base):
+        def __init__(self, npix=None, wsize=None):
+            base.__init__(self, npix=legacy(npix), wsize=legacy(wsize))
+            self._n, self._w = legacy(self._n), legacy(self._w)   # np.array() in __init__ drops the subclass
+
+    gaussianfield.RandomField = LegacyArgsField
+    out = {}
+    try:
+        for tag, kw in (("cube_a", dict(nu_num=6, x_num=8, y_num=10, x_width=3.0, y_width=4.0, nu_lower=700.0, nu_upper=720.0)),
+                        ("cube_b", dict(nu_num=5, x_num=7, y_num=6, x_width=2.0, y_width=2.0, nu_lower=500.0, nu_upper=540.0))):
+            cr = corr21cm.Corr21cm()
+            for k, v in kw.items():
+                setattr(cr, k, v)
+            z1 = 1420.40575177 / cr.nu_upper - 1.0
+            z2 = 1420.40575177 / cr.nu_lower - 1.0
+            np.random.seed(41)
+            out[tag + "__getfield"] = cr.getfield()
+            np.random.seed(41)
+            acube, rsf, geom = cr.realisation(z1, z2, cr.x_width, cr.y_width, cr.nu_num, cr.x_num, cr.y_num,
+                                              zspace=False, report_physical=True)
+            out[tag + "__acube"] = acube
+            out[tag + "__rsf"] = rsf
+            out[tag + "__geom"] = np.array(geom)
+            np.random.seed(41)
+            out[tag + "__density_only_nomean_zspace"] = cr.realisation(
+                z1, z2, cr.x_width, cr.y_width, cr.nu_num, cr.x_num, cr.y_num, density_only=True, no_mean=True,
+                no_evolution=True, refinement=2)
+            out[tag + "__params"] = np.array([kw[k] for k in ("nu_num", "x_num", "y_num", "x_width", "y_width",
+                                                              "nu_lower", "nu_upper")], dtype=np.float64)
+    finally:
+        gaussianfield.RandomField = base
+    return out
+
+
 def main():
     make_golden._install_shims()
     for name in ("cora.util.cubicspline", "cora.util.bilinearmap"):
@@ -127,6 +177,8 @@ def main():
     g["syn__freq_weight"] = syn._freq_weight
     g["syn__num_corr_freq"] = np.array(syn._num_corr_freq)
     g["syn__ang_kweight"] = syn._ang_field._kweight
+
+    g.update(redshift_cube_vectors(gaussianfield))
 
     path = os.path.join(OUT, "flatsky_vectors.npz")
     np.savez_compressed(path, **g)

@@ -226,3 +226,122 @@ def test_device_seeded_field_vs_oracle_stream_and_spectrum(ctx):
     # Parseval through the HIP transforms: sum f^2 = (1/N) (sum over the full spectrum)
     full = 2.0 * (np.abs(spec) ** 2).sum() - (np.abs(spec[..., 0]) ** 2).sum() - (np.abs(spec[..., -1]) ** 2).sum()
     assert abs(float((fld**2).sum().item()) * n**3 / full - 1.0) < 1e-12
+
+
+# ------------------------------------------------------------------ redshift-space cube (Corr21cm.getfield)
+CUBES = ("cube_a", "cube_b")
+
+
+def _cube_args(fsg, tag):
+    nu_num, x_num, y_num, xw, yw, nlo, nhi = fsg[tag + "__params"]
+    return int(nu_num), int(x_num), int(y_num), float(xw), float(yw), float(nlo), float(nhi)
+
+
+def test_oracle_redshift_cube_matches_reference_vectors(fsg):
+    """oracle/flatsky.py::realisation vs outputs of the reference's own Corr21cm.getfield / realisation
+    (same global-numpy-state normals), and its scipy call vs the definition-level trilinear restatement."""
+    import scipy.ndimage
+
+    from oracle import flatsky as ofs
+    from oracle import models
+
+    m = models.Corr21cm()
+    for tag in CUBES:
+        nu_num, x_num, y_num, xw, yw, nlo, nhi = _cube_args(fsg, tag)
+        z1, z2 = ofs.NU21 / nhi - 1.0, ofs.NU21 / nlo - 1.0
+        np.random.seed(41)
+        ac, rsf, geom = ofs.realisation(m, z1, z2, xw, yw, nu_num, x_num, y_num, np.random.standard_normal, zspace=False)
+        assert _rel(ac, fsg[tag + "__acube"]) < 1e-14 and _rel(rsf, fsg[tag + "__rsf"]) < 1e-14
+        assert np.allclose(geom, fsg[tag + "__geom"], rtol=1e-15)
+        assert _rel(ac[::-1], fsg[tag + "__getfield"]) < 1e-14
+        np.random.seed(41)
+        ac2 = ofs.realisation(m, z1, z2, xw, yw, nu_num, x_num, y_num, np.random.standard_normal, density_only=True,
+                              no_mean=True, no_evolution=True, refinement=2)[0]
+        assert _rel(ac2, fsg[tag + "__density_only_nomean_zspace"]) < 1e-14
+    rng = np.random.default_rng(0)
+    co = rng.uniform(-1.0, max(rsf.shape) + 0.5, size=(3, 300))
+    co[:, :5] = 0.0
+    co[0, 5], co[1, 6], co[2, 7] = rsf.shape[0] - 1, rsf.shape[1] - 1, rsf.shape[2] - 1
+    assert np.abs(ofs.trilinear_constant(rsf, co) - scipy.ndimage.map_coordinates(rsf, co, order=1)).max() < 1e-18
+
+
+@pytest.mark.gpu
+def test_corr21cm_getfield_matches_reference_vectors(fsg):
+    """The HIP cube builder (field draw -> rfftn x mu^2 -> irfftn -> slice factors -> ray tracing) with the
+    reference's normals vs the reference's own outputs."""
+    from cora_amd.signal import corr21cm
+
+    for tag in CUBES:
+        nu_num, x_num, y_num, xw, yw, nlo, nhi = _cube_args(fsg, tag)
+        cr = corr21cm.Corr21cm()
+        cr.nu_num, cr.x_num, cr.y_num, cr.x_width, cr.y_width, cr.nu_lower, cr.nu_upper = nu_num, x_num, y_num, xw, yw, nlo, nhi
+        z1, z2 = cr._band_redshifts()
+        np.random.seed(41)
+        cube = cr.getfield()
+        assert cube.shape == fsg[tag + "__getfield"].shape and _rel(cube, fsg[tag + "__getfield"]) < 1e-12, tag
+        np.random.seed(41)
+        ac, rsf, geom = cr.realisation(z1, z2, xw, yw, nu_num, x_num, y_num, zspace=False, report_physical=True)
+        assert _rel(rsf, fsg[tag + "__rsf"]) < 1e-12 and _rel(ac, fsg[tag + "__acube"]) < 1e-12
+        assert np.allclose(geom, fsg[tag + "__geom"], rtol=1e-14)
+        np.random.seed(41)
+        ac2 = cr.realisation(z1, z2, xw, yw, nu_num, x_num, y_num, density_only=True, no_mean=True, no_evolution=True,
+                             refinement=2)
+        assert _rel(ac2, fsg[tag + "__density_only_nomean_zspace"]) < 1e-12
+        np.random.seed(41)
+        df, vf = cr._realisation_dv(np.array([50.0, 40.0, 30.0]), np.array([6, 8, 10]))
+        assert df.shape == vf.shape == (6, 8, 10)
+
+
+@pytest.mark.gpu
+def test_raytrace_kernel_edges_and_affine(ctx):
+    """raytrace_slices vs the definition-level trilinear restatement, with lines of sight that leave the box
+    (exact 0 outside [0, n-1], exact sample on the last plane), and cube_affine with and without velocities."""
+    from oracle import flatsky as ofs
+
+    rng = np.random.default_rng(3)
+    cube = rng.standard_normal((7, 9, 11))
+    zc = np.array([0.0, 0.3, 5.999, 6.0, 6.0000001, -1e-12, 3.5])
+    scale = np.array([1.0, 0.7, 1.3, 2.0, 1.0, 1.0, 2.5])      # 2.0 / 2.5 push the outer pixels out of the box
+    tx = np.linspace(-0.5, 0.5, 6)
+    ty = np.linspace(-0.5, 0.5, 5)
+    wx, wy = 1.0, 1.0
+    got = ctx.raytrace_slices(ctx.to_device(cube), ctx.to_device(zc), ctx.to_device(scale), ctx.to_device(tx),
+                              ctx.to_device(ty), wx, wy).cpu().numpy()
+    tgy, tgx = np.meshgrid(ty, tx)
+    want = np.zeros_like(got)
+    for i in range(len(zc)):
+        co = np.stack([np.full_like(tgx, zc[i]), (tgx * scale[i]) / wx * 8.0 + 4.0, (tgy * scale[i]) / wy * 10.0 + 5.0])
+        want[i] = ofs.trilinear_constant(cube, co)
+    assert np.abs(got - want).max() < 1e-14
+    assert (got[4] == 0).all() and (got[5] == 0).all() and (got[3, 0, 0] == 0) and np.abs(got[3]).max() > 0
+    a, b, c = rng.standard_normal(7), rng.standard_normal(7), rng.standard_normal(7)
+    vf = rng.standard_normal(cube.shape)
+    dev = [ctx.to_device(x) for x in (cube, vf, a, b, c)]
+    full = ctx.cube_affine(dev[0], dev[1], dev[2], dev[3], dev[4]).cpu().numpy()
+    assert np.abs(full - (cube * a[:, None, None] + vf * b[:, None, None] + c[:, None, None])).max() < 1e-14
+    dens = ctx.cube_affine(dev[0], None, dev[2], dev[3], dev[4]).cpu().numpy()
+    assert np.abs(dens - (cube * a[:, None, None] + c[:, None, None])).max() < 1e-15
+
+
+@pytest.mark.gpu
+def test_corr21cm_getfield_device_seed_vs_oracle():
+    """Throughput mode of the cube: normals from the device Philox stream == oracle fed with its restatement."""
+    from cora_amd.signal import corr21cm
+    from oracle import flatsky as ofs
+    from oracle import models, philox
+
+    cr = corr21cm.Corr21cm()
+    cr.nu_num, cr.x_num, cr.y_num, cr.x_width, cr.y_width, cr.nu_lower, cr.nu_upper = 6, 12, 10, 3.0, 2.5, 600.0, 640.0
+    cube = cr.getfield(seed=9)
+
+    def stream(shape, state={"first": True}):
+        e = np.arange(int(np.prod(shape)), dtype=np.uint64)
+        a, b = philox.boxmuller_counter(9, e & np.uint64(0xFFFFFFFF), e >> np.uint64(32))
+        first = state["first"]
+        state["first"] = False
+        return (a if first else b).reshape(shape)
+
+    z1, z2 = cr._band_redshifts()
+    want = ofs.realisation(models.Corr21cm(), z1, z2, 3.0, 2.5, 6, 12, 10, stream, zspace=False)[0][::-1]
+    assert cube.shape == (6, 12, 10) and _rel(cube, want) < 1e-11
+    assert np.array_equal(cube, cr.getfield(seed=9))

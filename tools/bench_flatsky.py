@@ -57,3 +57,30 @@ for n in sizes:
     torch.cuda.empty_cache()
     out.append(rec)
     print(json.dumps(rec), flush=True)
+
+# ---- Corr21cm.getfield (redshift-space cube: draw -> irfftn -> rfftn x mu^2 -> irfftn -> slice factors -> ray trace)
+if os.environ.get("CUBE", "1") == "1":
+    from cora_amd.signal import corr21cm
+
+    for nu_num, npx in ((128, 128), (256, 256), (256, 512)):
+        cr = corr21cm.Corr21cm()
+        cr.nu_num, cr.x_num, cr.y_num, cr.x_width, cr.y_width = nu_num, npx, npx, 5.0, 5.0
+        cr.nu_lower, cr.nu_upper = 600.0, 700.0
+        z1, z2 = cr._band_redshifts()
+        t0 = time.perf_counter()
+        cr.realisation(z1, z2, 5.0, 5.0, nu_num, npx, npx, zspace=False, seed=1, device=True)   # builds k-weights (host, once)
+        torch.cuda.synchronize()
+        first = time.perf_counter() - t0
+        box = list(cr._cube_cache.keys())[0][1]
+        ctx.profile_reset()
+        ctx.profile_enable(True)
+        reps = 5
+        t0 = time.perf_counter()
+        for r in range(reps):
+            out_cube = cr.realisation(z1, z2, 5.0, 5.0, nu_num, npx, npx, zspace=False, seed=2 + r, device=True)
+        torch.cuda.synchronize()
+        wall = (time.perf_counter() - t0) / reps * 1e3
+        st = {k: round(ctx.profile_get(k)[0] / reps, 3) for k in ("flatdraw", "flatfft", "spec_mul", "cube_affine", "raytrace")}
+        ctx.profile_enable(False)
+        print(json.dumps({"corr21cm_getfield": [nu_num, npx, npx], "comoving_box": box, "first_call_s": first,
+                          "wall_ms": wall, "device_ms": st, "cubes_per_s": 1e3 / wall}), flush=True)
