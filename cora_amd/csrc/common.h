@@ -29,6 +29,7 @@ struct corahip_linefft_plan {
     double2 *tw = nullptr;     // [P]  exp(-2 pi i k / P)
     double2 *chirp = nullptr;  // [n]  exp(-i pi k^2 / n)                       (Bluestein lengths only)
     double2 *filt = nullptr;   // [P]  FFT_P(wrapped conj chirp) / P, bit-reversed (Bluestein lengths only)
+    double2 *rtw = nullptr;    // [n/2 + 1]  e^{+2 pi i k / 2n}: (un)packing of a real transform of length 2n
 };
 
 struct corahip_ctx {

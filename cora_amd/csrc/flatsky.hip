@@ -47,6 +47,16 @@ __device__ static inline unsigned brev_n(unsigned i, int logP) {
     return logP ? (__brev(i) >> (32 - logP)) : 0u;
 }
 
+// e / d for 0 <= e < 2^23 with rcp = 1.0f / d: one float multiply and a +-1 correction instead of the
+// ~35-instruction integer division (the element loops below were 80 % integer division before)
+__device__ static inline int fastdiv(int e, int d, float rcp, int &rem) {
+    int t = (int)((float)e * rcp);
+    rem = e - t * d;
+    if (rem < 0) t--, rem += d;
+    if (rem >= d) t++, rem -= d;
+    return t;
+}
+
 // decimation in time, forward sign: position i holds x[bitrev(i)] on entry, X[i] on exit; `lines` lines of P
 // `tw` holds e^{-2 pi i k / P} for k < P/4 (only the quarter circle is ever indexed); the kernel keeps it in LDS:
 // a twiddle fetched from global memory inside a pass would wait (vmcnt is in-order) for the register prefetch
@@ -64,13 +74,14 @@ __device__ __forceinline__ static void lds_dit(double2 *buf, int P, int logP, in
         h = 2;
     }
     const int q = P >> 2, lq = logP - 2;
-    for (; h < P; h <<= 2) {
-        const int s2 = P / (4 * h);
+    int lh = (logP & 1);                        // log2 h: every index below is a shift / mask (no integer division)
+    for (; h < P; h <<= 2, lh += 2) {
+        const int ls2 = logP - 2 - lh;          // log2 of the twiddle stride P / 4h
         for (int w = threadIdx.x; w < lines * q; w += FS_THREADS) {
             const int t = w >> lq, j = w & (q - 1);
-            const int pos = j & (h - 1), grp = j / h;
-            double2 *p = buf + t * P + grp * 4 * h + pos;
-            const double2 w2 = tw[pos * s2], w1 = cmul(w2, w2);
+            const int pos = j & (h - 1), grp = j >> lh;
+            double2 *p = buf + t * P + ((grp << 2) << lh) + pos;
+            const double2 w2 = tw[pos << ls2], w1 = cmul(w2, w2);
             const double2 a = p[0], b = cmul(w1, p[h]), c = p[2 * h], d = cmul(w1, p[3 * h]);
             const double2 a1 = cadd(a, b), b1 = csub(a, b);
             const double2 c1 = cmul(w2, cadd(c, d)), d1 = cmul(mul_mi(w2), csub(c, d));
@@ -87,13 +98,14 @@ __device__ __forceinline__ static void lds_dit(double2 *buf, int P, int logP, in
 __device__ __forceinline__ static void lds_dif(double2 *buf, int P, int logP, int lines, const double2 *tw) {
     const int q = P >> 2, lq = logP - 2;
     const int hmin = (logP & 1) ? 2 : 1;
-    for (int h = P >> 2; h >= hmin; h >>= 2) {
-        const int s2 = P / (4 * h);
+    int lh = logP - 2;
+    for (int h = P >> 2; h >= hmin; h >>= 2, lh -= 2) {
+        const int ls2 = logP - 2 - lh;
         for (int w = threadIdx.x; w < lines * q; w += FS_THREADS) {
             const int t = w >> lq, j = w & (q - 1);
-            const int pos = j & (h - 1), grp = j / h;
-            double2 *p = buf + t * P + grp * 4 * h + pos;
-            const double2 w2 = tw[pos * s2], w1 = cmul(w2, w2);
+            const int pos = j & (h - 1), grp = j >> lh;
+            double2 *p = buf + t * P + ((grp << 2) << lh) + pos;
+            const double2 w2 = tw[pos << ls2], w1 = cmul(w2, w2);
             const double2 x0 = p[0], x1 = p[h], x2 = p[2 * h], x3 = p[3 * h];
             const double2 a1 = cadd(x0, x2), c1 = cmul(w2, csub(x0, x2));
             const double2 b1 = cadd(x1, x3), d1 = cmul(mul_mi(w2), csub(x1, x3));
@@ -126,10 +138,17 @@ struct linefft_args {
     double scale;
     int P, logP, blu;
     int twl;             // quarter-circle twiddle table kept in LDS behind the tile (P <= 4096)
+    int h;               // modes 3/4: complex length n_real / 2 (= n), the real length is 2 h
     const double2 *tw, *chirp, *filt;
+    const double2 *rtw;  // modes 3/4: e^{+2 pi i k / (2h)}, k = 0 .. h/2
 };
 
 // MODE 0: complex -> complex (in place allowed), 1: half-complex -> real (inverse), 2: real -> half-complex
+// (1 and 2 transform a full-length complex line and serve odd lengths); 3 / 4: the same two for EVEN real lengths
+// 2h through ONE complex transform of length h (A.n = h): c2r packs Z_k = (X_k + conj X_{h-k}) + i W^k (X_k -
+// conj X_{h-k}), W = e^{2 pi i / 2h}, whose inverse transform is x_{2j} + i x_{2j+1}; r2c transforms
+// z_j = x_{2j} + i x_{2j+1} and unpacks X_k = E_k + W^{-k} O_k, X_{h-k} = conj(E_k - W^{-k} O_k) with
+// E_k = (Z_k + conj Z_{h-k}) / 2, O_k = (Z_k - conj Z_{h-k}) / 2i.
 //
 // Persistent workgroups walk the tiles; the global loads of the NEXT tile are issued into registers before
 // the LDS passes of the current one and committed to LDS after its stores, so HBM latency hides behind the
@@ -141,17 +160,24 @@ __global__ void __launch_bounds__(FS_THREADS, FS_WG_PER_CU) linefft_kernel(const
     extern __shared__ double2 fs_lds[];
     const int n = A.n, P = A.P, logP = A.logP, T = A.T;
     const bool inv = MODE == 1 || (MODE == 0 && A.inverse);
+    const int h = A.h, hp = (h >> 1) + 1;      // modes 3/4: pairs (k, h - k), k = 0 .. h/2
     const double2 *in2 = reinterpret_cast<const double2 *>(A.in);
     double2 *out2 = reinterpret_cast<double2 *>(A.out);
     const long chunks = (A.inner + T - 1) / T;  // tiles per outer index (inner > 1)
     const long nlines = A.nouter * A.inner;
     const long ntiles = A.inner == 1 ? (nlines + T - 1) / T : A.nouter * chunks;
-    const int nin = MODE == 1 ? A.nh : n;       // input elements per line
-    const int nout = MODE == 2 ? A.nh : n;      // output elements per line
+    const int nin = MODE == 1 ? A.nh : (MODE == 3 ? n + 1 : n);   // input elements per line (mode 4: double2 = 2 reals)
+    const int nout = MODE == 2 ? A.nh : (MODE == 4 ? n + 1 : n);  // output elements per line (mode 3: double2 = 2 reals)
+
+    // LDS behind the tile: quarter-circle twiddles; modes 3/4: W^k, k <= h/2, then one slot per line for X_h
+    double2 *twl = fs_lds + T * P;
+    double2 *rtwl = twl + (A.twl ? (P >> 2) : 0);
+    double2 *xh = rtwl + hp;
 
     struct tile_t {
         long outer, i0;
         int teff;
+        float rcp_teff;
     };
     auto tile_of = [&](long tile) {
         tile_t tl;
@@ -164,15 +190,17 @@ __global__ void __launch_bounds__(FS_THREADS, FS_WG_PER_CU) linefft_kernel(const
             tl.i0 = (tile - tl.outer * chunks) * T;
             tl.teff = (int)min((long)T, A.inner - tl.i0);
         }
+        tl.rcp_teff = 1.0f / (float)tl.teff;
         return tl;
     };
     // element e of a tile -> (line t, index j along the axis, global element offset) for `len` elements per line
-    auto locate = [&](const tile_t &tl, int e, int len, int &t, int &j) -> long {
+    const float rcp_nin = 1.0f / (float)nin, rcp_nout = 1.0f / (float)nout, rcp_hp = 1.0f / (float)hp;
+    auto locate = [&](const tile_t &tl, int e, int len, float rcp_len, int &t, int &j) -> long {
         if (A.inner == 1) {
-            t = e / len, j = e - t * len;
+            t = fastdiv(e, len, rcp_len, j);
             return (tl.outer + t) * len + j;
         }
-        j = e / tl.teff, t = e - j * tl.teff;
+        j = fastdiv(e, tl.teff, tl.rcp_teff, t);
         return (tl.outer * len + j) * A.inner + tl.i0 + t;
     };
     double2 R[FS_NLOAD];
@@ -182,16 +210,18 @@ __global__ void __launch_bounds__(FS_THREADS, FS_WG_PER_CU) linefft_kernel(const
             const int e = threadIdx.x + u * FS_THREADS;
             if (e < tl.teff * nin) {
                 int t, j;
-                const long addr = locate(tl, e, nin, t, j);
+                const long addr = locate(tl, e, nin, rcp_nin, t, j);
                 R[u] = MODE == 2 ? make_double2(A.in[addr], 0.0) : in2[addr];
             }
         }
     };
     auto commit = [&](const tile_t &tl) {
         if (A.blu) {
+            const float rcp_z = 1.0f / (float)(P - n);
             for (int e = threadIdx.x; e < tl.teff * (P - n); e += FS_THREADS) {
-                const int t = e / (P - n), j = n + e % (P - n);
-                fs_lds[t * P + j] = make_double2(0.0, 0.0);
+                int j;
+                const int t = fastdiv(e, P - n, rcp_z, j);
+                fs_lds[t * P + n + j] = make_double2(0.0, 0.0);
             }
         }
 #pragma unroll
@@ -199,9 +229,15 @@ __global__ void __launch_bounds__(FS_THREADS, FS_WG_PER_CU) linefft_kernel(const
             const int e = threadIdx.x + u * FS_THREADS;
             if (e < tl.teff * nin) {
                 int t, j;
-                (void)locate(tl, e, nin, t, j);
+                (void)locate(tl, e, nin, rcp_nin, t, j);
                 double2 v = R[u];
-                if (MODE == 1) {
+                if (MODE == 3) {
+                    // raw spectrum at natural positions; the packing pass below works on pairs in place
+                    if (j == h)
+                        xh[t] = v;
+                    else
+                        fs_lds[t * P + j] = v;
+                } else if (MODE == 1) {
                     if (j == 0 || 2 * j == n) v.y = 0.0;
                     // conj of the Hermitian extension: position j gets conj(c_j), position n-j gets c_j
                     const double2 lo = make_double2(v.x, -v.y);
@@ -226,9 +262,10 @@ __global__ void __launch_bounds__(FS_THREADS, FS_WG_PER_CU) linefft_kernel(const
 
     long tile = blockIdx.x;
     if (tile >= ntiles) return;
-    double2 *twl = fs_lds + T * P;
     if (A.twl)
         for (int k = threadIdx.x; k < (P >> 2); k += FS_THREADS) twl[k] = A.tw[k];
+    if (MODE >= 3)
+        for (int k = threadIdx.x; k < hp; k += FS_THREADS) rtwl[k] = A.rtw[k];
     tile_t cur = tile_of(tile);
     prefetch(cur);
     while (true) {
@@ -239,6 +276,27 @@ __global__ void __launch_bounds__(FS_THREADS, FS_WG_PER_CU) linefft_kernel(const
         if (next < ntiles) {
             nxt = tile_of(next);
             prefetch(nxt);
+        }
+        if (MODE == 3) {
+            // pack pairs (k, h-k) in place -> conj(Z) (the inverse transform runs as conj(FFT(conj .)))
+            for (int e = threadIdx.x; e < cur.teff * hp; e += FS_THREADS) {
+                int k;
+                const int t = fastdiv(e, hp, rcp_hp, k), k2 = h - k;
+                double2 *ln = fs_lds + t * P;
+                double2 xk = ln[k], xc = k == 0 ? xh[t] : ln[k2];
+                if (k == 0) xk.y = 0.0, xc.y = 0.0;               // Im of the DC / Nyquist bins is ignored
+                const double2 E = make_double2(xk.x + xc.x, xk.y - xc.y);
+                const double2 O = cmul(make_double2(xk.x - xc.x, xk.y + xc.y), rtwl[k]);
+                double2 a = make_double2(E.x - O.y, -(E.y + O.x));      // conj(E + i O)
+                double2 b = make_double2(E.x + O.y, -(O.x - E.y));      // conj(conj E + i conj O)
+                if (A.blu) {
+                    a = cmul(a, A.chirp[k]);
+                    if (k2 < h) b = cmul(b, A.chirp[k2]);
+                }
+                ln[k] = a;
+                if (k2 != k && k2 < h) ln[k2] = b;
+            }
+            __syncthreads();
         }
         // ---- transform --------------------------------------------------------------------------
         if (A.blu) {
@@ -252,19 +310,46 @@ __global__ void __launch_bounds__(FS_THREADS, FS_WG_PER_CU) linefft_kernel(const
             }
             __syncthreads();
         }
-        if (FS_ABLATE == 0) {
+        if (MODE == 3 && !A.blu) {
+            // natural order in (the packed pairs), bit-reversed out; the store below reads through the permutation
+            if (A.twl)
+                lds_dif(fs_lds, P, logP, cur.teff, twl);
+            else
+                lds_dif(fs_lds, P, logP, cur.teff, A.tw);
+        } else if (FS_ABLATE == 0) {
             if (A.twl)
                 lds_dit(fs_lds, P, logP, cur.teff, twl);
             else
                 lds_dit(fs_lds, P, logP, cur.teff, A.tw);
         }
         // ---- store ------------------------------------------------------------------------------
+        // transform value Y_k of line t in natural order
+        auto result = [&](int t, int k) {
+            double2 v = fs_lds[t * P + ((MODE == 3 && !A.blu) ? (int)brev_n(k, logP) : k)];
+            if (A.blu) v = cmul(make_double2(v.x, -v.y), A.chirp[k]);
+            return v;
+        };
+        if (MODE == 4) {
+            for (int e = threadIdx.x; e < cur.teff * hp; e += FS_THREADS) {
+                int k;
+                const int t = fastdiv(e, hp, rcp_hp, k), k2 = h - k;
+                const double2 zk = result(t, k), zc = result(t, k2 == h ? 0 : k2);
+                const double2 Ea = make_double2(0.5 * (zk.x + zc.x), 0.5 * (zk.y - zc.y));
+                const double2 Oa = make_double2(0.5 * (zk.y + zc.y), -0.5 * (zk.x - zc.x));   // (zk - conj zc) / 2i
+                const double2 w = rtwl[k];
+                const double2 B = cmul(make_double2(w.x, -w.y), Oa);
+                double2 *o = out2 + (cur.outer + t) * (long)(h + 1);
+                o[k] = make_double2((Ea.x + B.x) * A.scale, (Ea.y + B.y) * A.scale);
+                if (k2 != k) o[k2] = make_double2((Ea.x - B.x) * A.scale, -(Ea.y - B.y) * A.scale);
+            }
+        } else
         for (int e = threadIdx.x; e < cur.teff * nout; e += FS_THREADS) {
             int t, k;
-            const long addr = locate(cur, e, nout, t, k);
-            double2 v = fs_lds[t * P + k];
-            if (A.blu) v = cmul(make_double2(v.x, -v.y), A.chirp[k]);
-            if (MODE == 1) {
+            const long addr = locate(cur, e, nout, rcp_nout, t, k);
+            double2 v = result(t, k);
+            if (MODE == 3) {
+                out2[addr] = make_double2(v.x * A.scale, -v.y * A.scale);   // conj: x_{2j} + i x_{2j+1}
+            } else if (MODE == 1) {
                 A.out[addr] = v.x * A.scale;
             } else {
                 if (inv) v.y = -v.y;
@@ -425,6 +510,15 @@ static int get_linefft_plan(corahip_ctx *ctx, int n, const corahip_linefft_plan 
         HIP_TRY(hipMalloc((void **)&pl.filt, sizeof(double2) * P));
         HIP_TRY(hipMemcpy(pl.filt, filt.data(), sizeof(double2) * P, hipMemcpyHostToDevice));
     }
+    {   // unpacking twiddles of the real transform of length 2n through this complex plan: e^{+2 pi i k / 2n}, k <= n/2
+        std::vector<double2> rtw(n / 2 + 1);
+        for (int k = 0; k <= n / 2; k++) {
+            const long double a = PI * (long double)k / (long double)n;
+            rtw[k] = make_double2((double)cosl(a), (double)sinl(a));
+        }
+        HIP_TRY(hipMalloc((void **)&pl.rtw, sizeof(double2) * rtw.size()));
+        HIP_TRY(hipMemcpy(pl.rtw, rtw.data(), sizeof(double2) * rtw.size(), hipMemcpyHostToDevice));
+    }
     auto ins = ctx->linefft.emplace(n, pl);
     *out = &ins.first->second;
     return 0;
@@ -438,7 +532,7 @@ static int launch_linefft(corahip_ctx *ctx, const double *in, double *out, long 
     const corahip_linefft_plan *pl;
     int rc = get_linefft_plan(ctx, n, &pl);
     if (rc) return rc;
-    StageTimer pass_timer(ctx, MODE == 1 ? "fft_c2r" : (MODE == 2 ? "fft_r2c" : (inner == 1 ? "fft_c2c_contig" : "fft_c2c_strided")));
+    StageTimer pass_timer(ctx, (MODE == 1 || MODE == 3) ? "fft_c2r" : ((MODE == 2 || MODE == 4) ? "fft_r2c" : (inner == 1 ? "fft_c2c_contig" : "fft_c2c_strided")));
     linefft_args A;
     A.in = in;
     A.out = out;
@@ -454,11 +548,16 @@ static int launch_linefft(corahip_ctx *ctx, const double *in, double *out, long 
     A.tw = pl->tw;
     A.chirp = pl->chirp;
     A.filt = pl->filt;
+    A.rtw = pl->rtw;
+    A.h = n;
     int T = FS_LDS_ELEMS / pl->P;
     T = T < 1 ? 1 : (T > 16 ? 16 : T);
+    if (MODE == 3)   // n + 1 input elements per line must fit the register prefetch of a tile
+        while (T > 1 && (long)T * (n + 1) > (long)FS_NLOAD * FS_THREADS) T--;
     A.T = T;
     A.twl = pl->P <= 4096;
-    const size_t shm = sizeof(double2) * ((size_t)T * pl->P + (A.twl ? pl->P / 4 : 0));
+    const size_t shm = sizeof(double2) * ((size_t)T * pl->P + (A.twl ? pl->P / 4 : 0) +
+                                          (MODE >= 3 ? (size_t)(n / 2 + 1) + T : 0));
     const long chunks = (inner + T - 1) / T;
     const long ntiles = inner == 1 ? (nouter + T - 1) / T : nouter * chunks;
     const long per_cu = (FS_WG_PER_CU == 2 && shm * 2 <= 160 * 1024) ? 2 : 1;   // launch bounds allow two 8-wave workgroups per CU
@@ -505,6 +604,8 @@ int corahip_irfftn(corahip_ctx *ctx, double *spec, int ndim, const int64_t *rdim
         if (rc) return rc;
     }
     const int n = (int)rdims[ndim - 1];
+    if (n % 2 == 0)   // even length: one complex transform of half the length
+        return launch_linefft<3>(ctx, spec, out, prod(rdims, 0, ndim - 1), n / 2, 1, 1, 1.0 / n);
     return launch_linefft<1>(ctx, spec, out, prod(rdims, 0, ndim - 1), n, 1, 1, 1.0 / n);
 }
 
@@ -518,7 +619,9 @@ int corahip_rfftn(corahip_ctx *ctx, const double *in, int ndim, const int64_t *r
     for (int i = ndim - naxes; i < ndim; i++) ARG_CHECK(rdims[i] <= FS_MAXN);
     cd[ndim - 1] = rdims[ndim - 1] / 2 + 1;
     StageTimer st(ctx, "flatfft");
-    int rc = launch_linefft<2>(ctx, in, spec, prod(rdims, 0, ndim - 1), (int)rdims[ndim - 1], 1, 0, 1.0);
+    const int nlast = (int)rdims[ndim - 1];
+    int rc = nlast % 2 == 0 ? launch_linefft<4>(ctx, in, spec, prod(rdims, 0, ndim - 1), nlast / 2, 1, 0, 1.0)
+                            : launch_linefft<2>(ctx, in, spec, prod(rdims, 0, ndim - 1), nlast, 1, 0, 1.0);
     if (rc) return rc;
     for (int ax = ndim - 2; ax >= ndim - naxes; ax--) {
         rc = launch_linefft<0>(ctx, spec, spec, prod(cd, 0, ax), (int)cd[ax], prod(cd, ax + 1, ndim), 0, 1.0);
