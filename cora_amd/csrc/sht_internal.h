@@ -199,10 +199,39 @@ struct DftR<16, SIGN> {
     }
 };
 
-// LDS index padding of the FFT buffers: one spare slot per 8 elements plus 8 per 128.  Makes the
-// unit-stride last pass (lane t owns elements R t .. R t + R-1) and the stride-8/16 middle pass at
-// most 2-way bank conflicted for ds_read/write_b128 instead of 8..16-way.
+// LDS layout of an FFT buffer: logical element i lives at fpad(i); fpad_len(n) slots hold n elements.
+// K5_SWZ = 0 (shipped): one spare slot per 8 elements plus 8 per 128.  A simulation of ds_read_b128 /
+// ds_write_b128 with their real lane groups (MI355X_MICROARCH.md LDS table: reads are served in 4 groups of 16
+// NON-contiguous lanes, writes in 8 x 8) gives this padding 1.5x the conflict-free LDS cycles on every
+// radix-16/8/4/2 pass of N = 1024 ... 4096 - the 0.31 = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE measured for all
+// three instantiations (profiles/r01_k5_lds_pmc.csv): a padded unit-stride run is no longer aligned to the bank
+// rows the lane groups assume.
+// K5_SWZ = 1: an XOR swizzle of the 16-byte slot inside its 256-byte bank row by parities of the row index
+// x = i >> 4 (bit0 = x0^x5, bit1 = x0^x1, bit2 = x0^x2^x4, bit3 = x0^x3^x4), found by hill-climbing in that
+// simulation: every pass conflict-free.  Measured: the counter ratio falls to 0.21 / 0.17 / 0.07 (belt / Bluestein
+// classes; the rest is the fold, cell and Hermitian stages), the kernel gets 0.7 ms SLOWER (26.9 -> 27.6 ms, A/B on
+// one box): the ring FFT is bound by its FP64 VALU work, not by the LDS array, and the swizzle costs four more
+// integer operations per element than the padding.  Kept as a switch; the flat-sky line FFT (flatsky.hip), whose
+// radix-4 stages ARE LDS-bound, ships its own swizzle.
+#ifndef K5_SWZ
+#define K5_SWZ 0
+#endif
+#if K5_SWZ
+__host__ __device__ static inline int fpad(int i) {
+    const int x = i >> 4;
+    int s = (0 - (x & 1)) & 15;        // x0 -> all four bits
+    s ^= (x & 14);                     // x1, x2, x3 -> bits 1, 2, 3
+    s ^= (0 - ((x >> 4) & 1)) & 12;    // x4 -> bits 2, 3
+    s ^= (x >> 5) & 1;                 // x5 -> bit 0
+    return i ^ s;
+}
+__host__ __device__ static inline int fpad_len(int n) { return (n + 15) & ~15; }
+#define K5_CH_SKEW 4                   // channel buffers start a quarter bank row apart
+#else
 __host__ __device__ static inline int fpad(int i) { return i + (i >> 3) + ((i >> 7) << 3); }
+__host__ __device__ static inline int fpad_len(int n) { return fpad(n); }
+#define K5_CH_SKEW 1
+#endif
 
 // e^{+2 pi i idx/pmax} from the half-circle table in HBM, tw[k] = e^{+2 pi i k/pmax}, k < pmax/2
 __device__ static inline double2 tw_global(const double2 *__restrict__ tw, int pmax, int idx) {

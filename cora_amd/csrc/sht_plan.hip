@@ -131,7 +131,7 @@ __global__ void __launch_bounds__(256)
 bluestein_table_kernel(const int32_t *__restrict__ blu_P, const int64_t *__restrict__ boff,
                        const int64_t *__restrict__ foff, double2 *__restrict__ chirp, double2 *__restrict__ filt,
                        const double2 *__restrict__ tw, int pmax, int tl_off) {
-    extern __shared__ __attribute__((aligned(16))) double2 fbuf[];   // [fpad(maxlen) + 1] then the twiddle table
+    extern __shared__ __attribute__((aligned(16))) double2 fbuf[];   // [fpad_len(maxlen) + 1] then the twiddle table
     const int i = blockIdx.x + 1;
     const int P = blu_P[i - 1];
     if (P == 0) return;
@@ -143,7 +143,7 @@ bluestein_table_kernel(const int32_t *__restrict__ blu_P, const int64_t *__restr
 #endif
     const int h = 2 * i;
     double2 *b = chirp + boff[i - 1];
-    for (int j = threadIdx.x; j < fpad(P); j += blockDim.x) fbuf[j] = make_double2(0.0, 0.0);
+    for (int j = threadIdx.x; j < fpad_len(P); j += blockDim.x) fbuf[j] = make_double2(0.0, 0.0);
     __syncthreads();
     for (int j = threadIdx.x; j < h; j += blockDim.x) {
         const long q = ((long)j * j) % (2 * h);
@@ -355,7 +355,7 @@ int corahip_sht_plan_create(corahip_ctx *ctx, int nside, int lmax, corahip_sht_p
         HIP_TRY(hipMalloc((void **)&p->d_bchirp, sizeof(double2) * std::max<int64_t>(1, nb)));
         HIP_TRY(hipMalloc((void **)&p->d_bfilt, sizeof(double2) * std::max<int64_t>(1, nf)));
         if (nside > 1) {
-            const int tl_off = fpad(maxlen) + 1;
+            const int tl_off = fpad_len(maxlen) + 1;
             const size_t shm = sizeof(double2) * (size_t)(tl_off + TWL_ENTRIES(p->pmax));
             HIP_TRY(hipFuncSetAttribute((const void *)bluestein_table_kernel,
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
@@ -387,7 +387,7 @@ int corahip_sht_plan_create(corahip_ctx *ctx, int nside, int lmax, corahip_sht_p
         for (auto &kv : by_len) {
             corahip_sht_plan::ring_class c;
             c.P = kv.first;
-            c.bstride = fpad(c.P ? c.P : 2 * nside + 1) + 1;
+            c.bstride = fpad_len(c.P ? c.P : 2 * nside + 1) + K5_CH_SKEW;
             c.nch = 4;
             const size_t tl_bytes = sizeof(double2) * TWL_ENTRIES(p->pmax);   // LDS twiddle table behind the buffers
             while (c.nch > 1 && (size_t)c.nch * c.bstride * sizeof(double2) + tl_bytes > lds_budget) c.nch >>= 1;

@@ -109,9 +109,9 @@ ringfft_kernel(const int32_t *__restrict__ ring_list, int nlist, int nside, int 
         K5STAMP(t_pre);
         __syncthreads();  // previous item's LDS reads are done
         if (need_zero) {
-            for (int j = (noalias ? fpad(Lr) : 0) + tid; j < fpad(flen); j += nt)
+            for (int j = (noalias ? Lr : 0) + tid; j < flen; j += nt)
 #pragma unroll
-                for (int c = 0; c < NCH; c++) sm[(size_t)c * bstride + j] = make_double2(0.0, 0.0);
+                for (int c = 0; c < NCH; c++) sm[(size_t)c * bstride + fpad(j)] = make_double2(0.0, 0.0);
             if (!noalias) __syncthreads();   // (the stores of the fold and the zeroed tail are disjoint otherwise)
         }
 
