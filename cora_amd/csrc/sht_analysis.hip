@@ -5,8 +5,8 @@
 // K4^T  legendre_adj_kernel: a_lm(col) = sum_rings lambda_lm(ring) [G_m(north) + (-1)^{l+m} G_m(south)](col)
 // on FP64 MFMA with M = l, K = ring pairs, N = columns (channel re/im).  Work item = (m, 16 NCT columns,
 // tile of 512 ring pairs).  A wave owns 64 ring pairs: lane = ring steps the recurrence once per l (no
-// redundancy), the 32 lambda values of an l-block go through a wave-private LDS transpose into the A-operand
-// layout (16 same-parity l x 4 rings), and the wave's G tile (64 rings x 16 NCT columns, even = N+S and
+// redundancy), the 32 lambda values of an l-block go through a wave-private LDS transpose ([ring][parity][16])
+// into the A-operand layout (16 same-parity l x 4 rings), and the wave's G tile (64 rings x 16 NCT columns, even = N+S and
 // odd = N-S combinations) stays in REGISTERS as the B operand for the whole item.  The eight waves hold
 // different rings, so their [32 l x 16 NCT] partial sums are added through LDS once per l-block; the four
 // ring tiles of an (m, column group) go to separate partial buffers summed by alm_reduce_kernel
@@ -108,7 +108,7 @@ legendre_adj_kernel(int lmax, int npair, int nring, int ncols, const double *__r
                     vv = inj ? sd.y : vv;
                     p0 = inj ? sd.x : p1;
                     p1 = vv;
-                    lamw[lane * LSTR + j] = vv;
+                    lamw[lane * LSTR + (j & 1) * 16 + (j >> 1)] = vv;   // row = [16 even l | 16 odd l]
                 }
                 d4_t acc[2][NCT];
 #pragma unroll
@@ -118,8 +118,11 @@ legendre_adj_kernel(int lmax, int npair, int nring, int ncols, const double *__r
 #pragma unroll
                 for (int s = 0; s < 16; s++) {
                     if (!((act >> (4 * s)) & 1ull)) continue;
-                    const double ae = lamw[(4 * s + kq) * LSTR + 2 * ri];
-                    const double ao = lamw[(4 * s + kq) * LSTR + 2 * ri + 1];
+                    // parities in separate halves of the row: each read is unit-stride over the 16 lanes of a
+                    // k-slot (interleaved, the pair became one ds_read2_b64 whose 16-lane groups stride 4 dwords
+                    // over 32 banks: 2-way conflicts, SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.25)
+                    const double ae = lamw[(4 * s + kq) * LSTR + ri];
+                    const double ao = lamw[(4 * s + kq) * LSTR + 16 + ri];
 #pragma unroll
                     for (int t = 0; t < NCT; t++) {
                         acc[0][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(ae, ge[s][t], acc[0][t], 0, 0, 0);
