@@ -59,6 +59,8 @@ SIGNATURES = {
     "corahip_map2alm_workspace_bytes": (c_int, [c_void_p, c_int, ctypes.POINTER(c_size_t)]),
     "corahip_map2alm": (c_int, [c_void_p, c_void_p, PTR, c_int, PTR, PTR, c_void_p, c_size_t]),
     "corahip_alm2map_spin2": (c_int, [c_void_p, c_void_p, PTR, c_int, PTR, c_void_p, c_size_t]),
+    "corahip_spin2_ring_scale": (c_int, [c_void_p, c_void_p, PTR, c_int, PTR]),
+    "corahip_spin2_combine": (c_int, [c_void_p, c_void_p, PTR, c_int, c_int, PTR, c_int]),
     "corahip_xi_table_average": (c_int, [c_void_p, PTR, PTR, PTR, c_int, c_int, c_double, c_double, PTR, c_int, PTR, PTR,
                                          c_int, c_int, PTR]),
     "corahip_legendre_project": (c_int, [c_void_p, PTR, PTR, c_int, c_int, PTR, ctypes.c_long, PTR]),
@@ -388,6 +390,24 @@ class Context:
         ws = self.workspace(need)
         _check(self.lib.corahip_alm2map_spin2(self.h, plan, self._f64(alm), nnu, self._f64(maps), self._p(ws), need))
         return maps
+
+    # -- spin-2 analysis (composition of scalar passes) ---------------------------------------
+    def map2alm_spin2(self, maps_qu, nside, lmax, ring_w=None):
+        """One quadrature pass (Q_f, U_f interleaved) [2 nf, npix] -> alm_dev [nalm, G, 2, 4] with (E_f, B_f)
+        interleaved, G = nnu_pad8(2 nf) / 4 (the layout alm2map_spin2 takes)."""
+        plan = self.sht_plan(nside, lmax)
+        n2, npix = maps_qu.shape
+        assert n2 % 2 == 0 and npix == 12 * nside * nside
+        nf = n2 // 2
+        nalm = (lmax + 1) * (lmax + 2) // 2
+        maps6 = self.empty((6 * nf, npix))
+        _check(self.lib.corahip_spin2_ring_scale(self.h, plan, self._f64(maps_qu), nf, self._f64(maps6)))
+        a6 = self.map2alm(maps6, nside, lmax, ring_w)
+        del maps6
+        gout = (2 * nf + 7) // 8 * 2
+        out = self.empty((nalm, gout, 2, 4))
+        _check(self.lib.corahip_spin2_combine(self.h, plan, self._f64(a6), a6.shape[1], nf, self._f64(out), gout))
+        return out
 
     # -- n3: xi(r) -> C_l --------------------------------------------------------------
     def xi_table_average(self, kx, ky, ky2, kind, x_t, f_t, mu, xa, xw, F, xint):

@@ -602,6 +602,7 @@ static int launch_legendre_pol(corahip_ctx *ctx, const corahip_sht_plan *p, int 
     LAUNCH_CHECK();
     return 0;
 }
+int sht_ensure_polc(corahip_ctx *ctx, corahip_sht_plan *p) { return ensure_polc(ctx, p); }
 int sht_legendre_pol(corahip_ctx *ctx, corahip_sht_plan *p, int ncols, const double *alm, double *inter) {
     int rc = ensure_polc(ctx, p);
     if (rc) return rc;

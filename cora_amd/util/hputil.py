@@ -281,6 +281,41 @@ def map2alm_device(maps, nside, lmax, use_weights=None, niter=None):
     return alm
 
 
+def map2alm_pol_device(maps_qu, nside, lmax, use_weights=None, niter=None):
+    """Device maps [2 n, npix], (Q_f, U_f) interleaved -> alm_dev with (E_f, B_f) interleaved: the (Q, U) half of
+    healpy.map2alm([T, Q, U], use_weights, iter) - a quadrature pass composed of scalar passes over ring-scaled
+    maps (csrc/sht_polana.hip) plus `niter` refinements alm <- alm + A(map - S alm) with the spin-2 synthesis."""
+    ctx = _lib.get_context()
+    use_weights = _weight if use_weights is None else use_weights
+    niter = _iter if niter is None else niter
+    w = ctx.to_device(ring_weights(nside)) if use_weights else None
+    n2 = maps_qu.shape[0]
+    alm = ctx.map2alm_spin2(maps_qu, int(nside), int(lmax), w)
+    nnu_pad = 4 * alm.shape[1]
+    for _ in range(niter):
+        back = ctx.alm2map_spin2(alm, int(nside), int(lmax), nnu_pad)[:n2]
+        alm = alm + ctx.map2alm_spin2(maps_qu - back, int(nside), int(lmax), w)
+        del back
+    return alm
+
+
+def _analyse_pol(q, u, lmax):
+    """Host (Q, U) maps [n, npix] each -> (E, B) alm[l, m] arrays [n, lmax+1, lmax+1] each."""
+    import torch
+
+    q = np.ascontiguousarray(q, dtype=np.float64)
+    n, npix = q.shape
+    nside = int(round(np.sqrt(npix / 12.0)))
+    if 12 * nside * nside != npix:
+        raise ValueError("Wrong pixel number (it is not 12*nside**2)")   # healpy.npix2nside
+    qu = np.empty((2 * n, npix))
+    qu[0::2], qu[1::2] = q, u
+    ctx = _lib.get_context()
+    alm = map2alm_pol_device(torch.from_numpy(qu).to(ctx.device), nside, lmax)
+    sq = ctx.alm_dev_to_square(alm, lmax, 4 * alm.shape[1]).cpu().numpy()[: 2 * n, 0]   # (padding channels dropped)
+    return sq[0::2], sq[1::2]
+
+
 def _analyse(hpmaps, lmax):
     """[n, npix] host maps -> [n, lmax+1, lmax+1] complex alm[l, m] (m > l entries zero)."""
     import torch
@@ -307,13 +342,52 @@ def sphtrans_real(hpmap, lmax=None, lside=None):
     return alm
 
 
+def sphtrans_real_pol(hpmaps, lmax=None, lside=None):
+    """T, Q, U (and V) maps [npol, npix] -> a^T, a^E, a^B (and a^V) as alm[pol, l, m], m >= 0
+    (cora/util/hputil.py:274-323: healpy.map2alm of the T, Q, U triple, V on its own)."""
+    hpmaps = np.ascontiguousarray(hpmaps, dtype=np.float64)
+    npol = len(hpmaps)
+    if lmax is None:
+        lmax = 3 * int(round(np.sqrt(hpmaps[0].size / 12.0))) - 1
+    if lside is None or lside < lmax:
+        lside = lmax
+    alms = np.zeros([npol, lside + 1, lside + 1], dtype=np.complex128)
+    scal = _analyse(hpmaps[[0] + ([3] if npol == 4 else [])], lmax)
+    alms[0, : lmax + 1, : lmax + 1] = scal[0]
+    e, b = _analyse_pol(hpmaps[1:2], hpmaps[2:3], lmax)
+    alms[1, : lmax + 1, : lmax + 1], alms[2, : lmax + 1, : lmax + 1] = e[0], b[0]
+    if npol == 4:
+        alms[3, : lmax + 1, : lmax + 1] = scal[1]
+    return alms
+
+
+def sphtrans_complex_pol(hpmaps, lmax=None, centered=False, lside=None):
+    """Complex T, Q, U (and V) maps -> a_lm for both signs of m (cora/util/hputil.py:326-366)."""
+    hpmaps = np.asarray(hpmaps)
+    if lmax is None:
+        lmax = 3 * int(round(np.sqrt(hpmaps[0].size / 12.0))) - 1
+    alm = _make_full_alm(sphtrans_real_pol(hpmaps.real, lmax=lmax, lside=lside), centered=centered)
+    alm += 1.0j * _make_full_alm(sphtrans_real_pol(hpmaps.imag, lmax=lmax, lside=lside), centered=centered)
+    return alm
+
+
 def sphtrans_sky(skymap, lmax=None):
-    """[freq, npix] (or [freq, 1|2, npix]) sky -> alm [freq, (pol,) l, m] (cora/util/hputil.py:460-497).
-    All frequency slices go through the GPU in one batch; the polarised branch (3 or 4 components) is
-    outside this package's scope."""
+    """[freq, npix] (or [freq, pol, npix]) sky -> alm [freq, (pol,) l, m] (cora/util/hputil.py:460-497).
+    All frequency slices go through the GPU in one batch; with 3 or 4 polarisation components the
+    (Q, U) planes take the spin-2 analysis, T (and V) the scalar one."""
     skymap = np.asarray(skymap)
     if skymap.ndim == 3 and skymap.shape[1] >= 3:
-        raise NotImplementedError("polarised analysis (hputil.py:265-330) is out of scope of cora_amd")
+        if skymap.shape[1] > 4:
+            raise Exception("Wrong number of polarisation components.")
+        if lmax is None:
+            lmax = 3 * int(round(np.sqrt(skymap.shape[-1] / 12.0))) - 1
+        nfreq, npol = skymap.shape[:2]
+        alm = np.zeros((nfreq, npol, lmax + 1, lmax + 1), dtype=np.complex128)
+        alm[:, 0] = _analyse(skymap[:, 0].astype(np.float64), lmax)
+        alm[:, 1], alm[:, 2] = _analyse_pol(skymap[:, 1], skymap[:, 2], lmax)
+        if npol == 4:
+            alm[:, 3] = _analyse(skymap[:, 3].astype(np.float64), lmax)
+        return alm
     if lmax is None:
         lmax = 3 * int(round(np.sqrt(skymap.shape[-1] / 12.0))) - 1
     flat = skymap.reshape(-1, skymap.shape[-1]).astype(np.float64)

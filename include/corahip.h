@@ -196,6 +196,20 @@ int corahip_map2alm(corahip_ctx *ctx, const corahip_sht_plan *plan, const double
 int corahip_alm2map_spin2(corahip_ctx *ctx, corahip_sht_plan *plan, const double *alm_dev, int nnu,
                           double *maps, void *workspace, size_t workspace_bytes);
 
+/* ---- spin-2 analysis ((Q, U) -> (E, B); cora/util/hputil.py:274-323 sphtrans_real_pol -> healpy.map2alm) ----
+ * Composed from scalar quadrature passes (csrc/sht_polana.hip): spin2_ring_scale writes, for every field f with
+ * maps (Q_f, U_f) = channels (2f, 2f+1) of maps_qu [2 nfields, npix], the six maps
+ * [Q, r1 Q, r2 Q, U, r1 U, r2 U] (r1 = 1/sin^2 theta, r2 = cos theta / sin^2 theta of the pixel's ring) as channels
+ * 6f .. 6f+5 of maps6; after corahip_map2alm(maps6, 6 nfields) spin2_combine forms
+ *   E = -(sum_rings W Q~ - i X U~),  B = -(sum_rings W U~ + i X Q~)
+ * into alm_eb_dev [nalm][gout][2][4] with (E_f, B_f) = channels (2f, 2f+1), the layout corahip_alm2map_spin2
+ * consumes; alm6_dev is [nalm][g6][2][4] (g6, gout: channel groups of four, padding channels zero).  One call sequence = one quadrature pass; healpy's iter = N is
+ * alm += A(map - S alm) with corahip_alm2map_spin2 as S, composed by the caller.                      */
+int corahip_spin2_ring_scale(corahip_ctx *ctx, corahip_sht_plan *plan, const double *maps_qu, int nfields,
+                             double *maps6);
+int corahip_spin2_combine(corahip_ctx *ctx, corahip_sht_plan *plan, const double *alm6_dev, int g6, int nfields,
+                          double *alm_eb_dev, int gout);
+
 /* ---- xi(r) -> C_l(chi, chi') ----------------------------------------------
  * Replaces corrfunc.corr_to_clarray (cora/signal/corrfunc.py:290-400).
  * xi_table_average: for every Gauss-Legendre node mu_m and channel pair (i, j) the radial-bin average

@@ -345,3 +345,86 @@ def alm2map_spin2_bruteforce(alm_e, alm_b, nside, lmax):
             if m > 0:      # the -m term: (E + iB)_{l,-m} = (-1)^m (conj E + i conj B), (W - X)_{l,-m} = (-1)^m (W + X)
                 qpu += -(np.conj(e) + 1j * np.conj(b)) * (W + X) * np.conj(ph)
     return qpu.real, qpu.imag
+
+
+# ------------------------------------------------------------------------------------
+# polarisation (spin-2) ANALYSIS: healpy.map2alm([T, Q, U], ...) as hputil.sphtrans_real_pol uses it
+# (cora/util/hputil.py:274-323).  (E, B)_lm = - sum_pix w (4 pi / npix) [(W Q - i X U), (W U + i X Q)] e^{-i m phi}:
+# half the sum / difference of the quadratures of -(Q +- iU) (W -+ X) e^{-i m phi}, the spin +-2 harmonics being
+# (W -+ X) e^{i m phi} in the convention of the synthesis above (Zaldarriaga & Seljak 1997).
+# ------------------------------------------------------------------------------------
+def _wx_from_lambda(lmax, m, z):
+    """W_lm, X_lm for l = m..lmax at cos(theta) = z from this oracle's own lambda recurrence."""
+    lam = lambda_lm(lmax, m, z)
+    l = np.arange(m, lmax + 1, dtype=np.float64)
+    lam1 = np.concatenate([[0.0], lam[:-1]])          # lambda_{l-1,m}, zero below l = m
+    s2 = (1.0 - z) * (1.0 + z)
+    W = np.zeros_like(lam)
+    X = np.zeros_like(lam)
+    ok = l >= 2
+    lo = l[ok]
+    N2 = 2.0 / np.sqrt((lo + 2.0) * (lo + 1.0) * lo * (lo - 1.0))
+    c = np.where(lo + m > 0, np.sqrt((2.0 * lo + 1.0) / (2.0 * lo - 1.0) * (lo - m) / np.maximum(lo + m, 1.0)), 0.0)
+    W[ok] = N2 * (-((lo - m * m) / s2 + lo * (lo - 1.0) / 2.0) * lam[ok] + (lo + m) * z / s2 * c * lam1[ok])
+    X[ok] = N2 * m / s2 * ((lo - 1.0) * z * lam[ok] - (lo + m) * c * lam1[ok])
+    return W, X
+
+
+def map2alm_spin2_adjoint(q, u, nside, lmax, ring_w=None):
+    """One quadrature pass (Q, U) RING maps -> packed (E, B)."""
+    ri = healpix.ring_info(nside)
+    npair = 2 * nside
+    nring = 4 * nside - 1
+    qn, qs = anal_to_gm(np.asarray(q, dtype=np.float64), nside, lmax, ring_w)
+    un, us = anal_to_gm(np.asarray(u, dtype=np.float64), nside, lmax, ring_w)
+    nalm = (lmax + 1) * (lmax + 2) // 2
+    e = np.zeros(nalm, dtype=np.complex128)
+    b = np.zeros(nalm, dtype=np.complex128)
+    for m in range(lmax + 1):
+        i0 = alm_index(m, m, lmax)
+        for r in range(npair):
+            z = float(ri["z"][r])
+            W, X = _wx_from_lambda(lmax, m, z)
+            l = np.arange(m, lmax + 1)
+            sgn = np.where((l + m) % 2 == 0, 1.0, -1.0)      # W(-z) = sgn W(z), X(-z) = -sgn X(z)
+            south = (nring - 1 - r) != r
+            wq = W * qn[r, m] + (sgn * W * qs[r, m] if south else 0.0)
+            wu = W * un[r, m] + (sgn * W * us[r, m] if south else 0.0)
+            xq = X * qn[r, m] + (-sgn * X * qs[r, m] if south else 0.0)
+            xu = X * un[r, m] + (-sgn * X * us[r, m] if south else 0.0)
+            e[i0 : i0 + l.size] += -(wq - 1j * xu)
+            b[i0 : i0 + l.size] += -(wu + 1j * xq)
+    return e, b
+
+
+def map2alm_spin2(q, u, nside, lmax, use_weights=True, niter=2):
+    """healpy.map2alm([T, Q, U], lmax, use_weights, iter) restricted to (Q, U): quadrature + Jacobi refinement."""
+    w = ring_weights(nside) if use_weights else None
+    e, b = map2alm_spin2_adjoint(q, u, nside, lmax, w)
+    for _ in range(niter):
+        q1, u1 = alm2map_spin2(e, b, nside, lmax)
+        de, db = map2alm_spin2_adjoint(q - q1, u - u1, nside, lmax, w)
+        e, b = e + de, b + db
+    return e, b
+
+
+def map2alm_spin2_bruteforce(q, u, nside, lmax, ring_w=None):
+    """Definition-level pixel sum with the scipy-based W / X (independent of the recurrence); tiny sizes."""
+    theta, phi = healpix.pix2ang_ring(nside)
+    ri = healpix.ring_info(nside)
+    nring = 4 * nside - 1
+    wpix = np.empty(theta.size)
+    for r in range(nring):
+        n, s = int(ri["nphi"][r]), int(ri["start"][r])
+        wpix[s : s + n] = 1.0 if ring_w is None else ring_w[min(r, nring - 1 - r)]
+    wpix *= 4.0 * np.pi / theta.size
+    nalm = (lmax + 1) * (lmax + 2) // 2
+    e = np.zeros(nalm, dtype=np.complex128)
+    b = np.zeros(nalm, dtype=np.complex128)
+    for m in range(lmax + 1):
+        ph = np.exp(-1j * m * phi)
+        for l in range(max(m, 2), lmax + 1):
+            W, X = spin2_wx(l, m, theta)
+            e[alm_index(l, m, lmax)] = -np.sum(wpix * (W * q - 1j * X * u) * ph)
+            b[alm_index(l, m, lmax)] = -np.sum(wpix * (W * u + 1j * X * q) * ph)
+    return e, b

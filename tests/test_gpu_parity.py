@@ -1126,3 +1126,63 @@ def test_sphtrans_inv_pol_api(ctx):
     assert one.shape == (3, 12 * nside * nside) and np.abs(one - sky[1, :3]).max() <= 1e-12 * np.abs(one).max()
     with pytest.raises(Exception, match="wrong shape"):
         hputil.sphtrans_inv_real_pol(alm[0, :2], nside)
+
+
+# ------------------------------------------------------------------ polarised (spin-2) analysis
+@pytest.mark.parametrize("nside,lmax,nf,weights", [(4, 8, 1, False), (8, 12, 2, True), (16, 32, 3, True), (32, 64, 5, False)])
+def test_map2alm_spin2_quadrature_vs_oracle(ctx, nside, lmax, nf, weights):
+    """One (Q, U) -> (E, B) quadrature pass, composed on the device from six scalar passes over ring-scaled maps,
+    vs the oracle's direct W / X quadrature."""
+    import torch
+    from oracle import sht
+
+    rng = np.random.default_rng(7 * nside + nf)
+    npix = 12 * nside * nside
+    qu = rng.standard_normal((2 * nf, npix))
+    w = sht.ring_weights(nside) if weights else None
+    dev = ctx.map2alm_spin2(torch.from_numpy(qu).to(ctx.device), nside, lmax, ctx.to_device(w) if weights else None)
+    sq = ctx.alm_dev_to_square(dev, lmax, 4 * dev.shape[1]).cpu().numpy()[: 2 * nf, 0]          # [2 nf, l, m]
+    for f in range(nf):
+        e, b = sht.map2alm_spin2_adjoint(qu[2 * f], qu[2 * f + 1], nside, lmax, w)
+        scale = max(np.abs(e).max(), np.abs(b).max())
+        for m in range(lmax + 1):
+            for l in range(m, lmax + 1):
+                i = sht.alm_index(l, m, lmax)
+                assert abs(sq[2 * f, l, m] - e[i]) < 2e-12 * scale and abs(sq[2 * f + 1, l, m] - b[i]) < 2e-12 * scale
+    assert np.abs(sq[:, :2]).max() == 0.0                                       # l < 2 carries no spin-2 power
+
+
+def test_sphtrans_real_pol_round_trip_and_api(ctx):
+    """hputil.sphtrans_real_pol / sphtrans_complex_pol / the polarised branch of sphtrans_sky: healpy.map2alm(iter=2,
+    use_weights) semantics vs the oracle, and recovery of band-limited T, E, B (V) through sphtrans_inv_real_pol."""
+    from cora_amd.util import hputil
+    from oracle import sht
+
+    nside, lmax = 16, 24
+    L = lmax + 1
+    rng = np.random.default_rng(3)
+    alm = np.zeros((4, L, L), dtype=np.complex128)
+    for p in range(4):
+        for l in range(2 if p in (1, 2) else 0, L):
+            alm[p, l, : l + 1] = (rng.standard_normal(l + 1) + 1j * rng.standard_normal(l + 1)) / (1.0 + l)
+            alm[p, l, 0] = alm[p, l, 0].real
+    maps = hputil.sphtrans_inv_real_pol(alm, nside)                             # T, Q, U, V
+    back = hputil.sphtrans_real_pol(maps, lmax=lmax)
+    assert back.shape == (4, L, L)
+    assert np.abs(back - alm).max() < 5e-6 * np.abs(alm).max()                  # two Jacobi refinements at lmax = 1.5 nside
+    e, b = sht.map2alm_spin2(maps[1], maps[2], nside, lmax, use_weights=True, niter=2)
+    t = sht.map2alm(maps[0], nside, lmax, use_weights=True, niter=2)
+    for m in range(L):
+        for l in range(m, L):
+            i = sht.alm_index(l, m, lmax)
+            assert abs(back[1, l, m] - e[i]) < 1e-11 and abs(back[2, l, m] - b[i]) < 1e-11 and abs(back[0, l, m] - t[i]) < 1e-11
+    three = hputil.sphtrans_real_pol(maps[:3], lmax=lmax, lside=lmax + 3)
+    assert three.shape == (3, lmax + 4, lmax + 4) and np.array_equal(three[:, :L, :L], back[:3])
+    sky = np.stack([maps, 2.0 * maps])                                          # [freq, pol, npix]
+    alm_sky = hputil.sphtrans_sky(sky, lmax=lmax)
+    assert alm_sky.shape == (2, 4, L, L)
+    assert np.abs(alm_sky[0] - back).max() < 1e-12 and np.abs(alm_sky[1] - 2.0 * back).max() < 1e-11
+    cplx = hputil.sphtrans_complex_pol(maps[:3] + 1j * maps[:3][::-1], lmax=lmax)
+    assert cplx.shape == (3, L, 2 * L - 1)
+    ref = hputil._make_full_alm(back[:3]) + 1j * hputil._make_full_alm(hputil.sphtrans_real_pol(maps[:3][::-1], lmax=lmax))
+    assert np.abs(cplx - ref).max() < 1e-12
