@@ -687,8 +687,10 @@ def test_sphtrans_and_sph_ps_api(ctx):
     assert np.abs(sky[0] - r[: lmax + 1, : lmax + 1]).max() < 1e-13
     sky3 = hputil.sphtrans_sky(np.stack([m0, m1])[:, None, :], lmax)
     assert sky3.shape == (2, 1, lmax + 1, lmax + 1) and np.array_equal(sky3[:, 0], sky)
-    with pytest.raises(NotImplementedError):
-        hputil.sphtrans_sky(np.zeros((2, 3, 12 * nside * nside)), lmax)
+    zero_pol = hputil.sphtrans_sky(np.zeros((2, 3, 12 * nside * nside)), lmax)      # polarised branch (3 components)
+    assert zero_pol.shape == (2, 3, lmax + 1, lmax + 1) and not zero_pol.any()
+    with pytest.raises(Exception, match="polarisation components"):
+        hputil.sphtrans_sky(np.zeros((2, 5, 12 * nside * nside)), lmax)
     al0, al1 = hputil.unpack_alm(a[0], lmax), hputil.unpack_alm(a[1], lmax)
     ll = 2.0 * np.arange(lmax + 1) + 1.0
     auto = (np.abs(al0[:, 0]) ** 2 + 2 * (np.abs(al0[:, 1:]) ** 2).sum(axis=1)) / ll
