@@ -8,42 +8,118 @@
 //   dgemm_nn_kernel      C[L x N] = A[L x M] B[M x N] on FP64 MFMA, 128 x 128 tiles, LDS-staged 16-deep K chunks
 #include "common.h"
 
-// natural cubic spline with end-slope extrapolation, as cubicspline.pyx:126-175 (knots in LDS)
-__device__ static inline double spline_eval(const double *__restrict__ xs, const double *__restrict__ ys,
-                                            const double *__restrict__ y2, int n, double x) {
-    if (x < xs[0]) {
-        const double h = xs[1] - xs[0];
-        return ((ys[1] - ys[0]) / h - h * y2[1] / 6.0) * (x - xs[0]) + ys[0];
+#include "rng_dev.h"   // fast_log01 (valid for any positive normal argument), fast_sqrt_pos
+
+// natural cubic spline with end-slope extrapolation, as cubicspline.pyx:126-175.  Knot tables in LDS:
+// xs, ys, y2 and per interval 1/h and h^2/6 (no divisions per evaluation); the interval comes from a uniform
+// look-up grid over [xs[0], xs[n-1]] (lut[g] = last knot at or before the left edge of cell g) walked forward to
+// the reference's bisection result - the last knot with xs[k] <= x - instead of ~log2(n) dependent LDS reads.
+struct spline_lds {
+    const double *xs, *ys, *y2, *invh, *h2o6;
+    const int *lut;
+    int n, nlut;
+    double x0, inv_dx;
+};
+__device__ static inline double spline_eval(const spline_lds &S, double x) {
+    const int n = S.n;
+    if (x < S.xs[0]) {
+        const double h = S.xs[1] - S.xs[0];
+        return ((S.ys[1] - S.ys[0]) / h - h * S.y2[1] / 6.0) * (x - S.xs[0]) + S.ys[0];
     }
-    if (x >= xs[n - 1]) {
-        const double h = xs[n - 1] - xs[n - 2];
-        return ((ys[n - 1] - ys[n - 2]) / h + h * y2[n - 2] / 6.0) * (x - xs[n - 1]) + ys[n - 1];
+    if (x >= S.xs[n - 1]) {
+        const double h = S.xs[n - 1] - S.xs[n - 2];
+        return ((S.ys[n - 1] - S.ys[n - 2]) / h + h * S.y2[n - 2] / 6.0) * (x - S.xs[n - 1]) + S.ys[n - 1];
     }
-    int kl = 0, kh = n;
-    while (kh - kl > 1) {   // bisection exactly as the reference: interval [kl, kl+1) with xs[kl] <= x
-        const int kn = (kh + kl) >> 1;
-        if (xs[kn] > x) kh = kn;
-        else kl = kn;
-    }
-    const double h = xs[kl + 1] - xs[kl];
-    const double a = (xs[kl + 1] - x) / h, b = (x - xs[kl]) / h;
-    return a * ys[kl] + b * ys[kl + 1] + ((a * a * a - a) * y2[kl] + (b * b * b - b) * y2[kl + 1]) * (h * h) / 6.0;
+    int g = (int)((x - S.x0) * S.inv_dx);
+    g = g < 0 ? 0 : (g >= S.nlut ? S.nlut - 1 : g);
+    int kl = S.lut[g];
+    while (kl > 0 && S.xs[kl] > x) kl--;            // (rounding of the cell index at a cell edge)
+    while (kl + 2 < n && S.xs[kl + 1] <= x) kl++;
+    const double ih = S.invh[kl];
+    const double a = (S.xs[kl + 1] - x) * ih, b = (x - S.xs[kl]) * ih;
+    return a * S.ys[kl] + b * S.ys[kl + 1] + ((a * a * a - a) * S.y2[kl] + (b * b * b - b) * S.y2[kl + 1]) * S.h2o6[kl];
+}
+
+// asinh(u), u >= 0: log(u + sqrt(u^2 + 1)) with the short log / sqrt of rng_dev.h (the argument is >= 1, where
+// fast_log01 keeps full relative accuracy); below 2^-6 the odd series (the log would cancel)
+__device__ static inline double fast_asinh_pos(double u) {
+    const double u2 = u * u;
+    const double big = fast_log01(u + fast_sqrt_pos(u2 + 1.0));
+    const double small = u * (1.0 + u2 * (-1.0 / 6.0 + u2 * (3.0 / 40.0 + u2 * (-15.0 / 336.0 + u2 * (105.0 / 3456.0)))));
+    return u < 0.015625 ? small : big;
+}
+// sinh(y) for |y| < ~700, branch-free: E = expm1(|y|) = 2^k p + (2^k - 1) with p = expm1(r), r = |y| - k ln2
+// (|r| <= ln2 / 2, degree-13 Taylor polynomial: remainder 4e-18), sinh = (E + E / (E + 1)) / 2
+__device__ static inline double fast_expm1_pos(double ay) {   // ay >= 0
+    const double kf = __builtin_rint(ay * 1.44269504088896340736);
+    const double r = fma(-kf, 1.90821492927058770002e-10, fma(-kf, 6.93147180369123816490e-01, ay));   // ln2 hi / lo
+    double p = 1.0 / 6227020800.0;
+    p = fma(p, r, 1.0 / 479001600.0);
+    p = fma(p, r, 1.0 / 39916800.0);
+    p = fma(p, r, 1.0 / 3628800.0);
+    p = fma(p, r, 1.0 / 362880.0);
+    p = fma(p, r, 1.0 / 40320.0);
+    p = fma(p, r, 1.0 / 5040.0);
+    p = fma(p, r, 1.0 / 720.0);
+    p = fma(p, r, 1.0 / 120.0);
+    p = fma(p, r, 1.0 / 24.0);
+    p = fma(p, r, 1.0 / 6.0);
+    p = fma(p, r, 0.5);
+    p = fma(p * r, r, r);                       // expm1(r)
+    const int k = (int)kf;
+    const double two_k = __builtin_amdgcn_ldexp(1.0, k);
+    return fma(two_k, p, two_k - 1.0);
+}
+__device__ static inline double fast_sinh(double y) {
+    const double E = fast_expm1_pos(fabs(y));
+    const double s = 0.5 * (E + E / (E + 1.0));
+    return y < 0.0 ? -s : s;
+}
+// e^y, |y| < ~700 (e^{-inf} = 0)
+__device__ static inline double fast_exp(double y) {
+    const double ay = fabs(y);
+    if (!(ay < 700.0)) return y < 0.0 ? 0.0 : exp(y);
+    const double E1 = fast_expm1_pos(ay) + 1.0;
+    return y < 0.0 ? 1.0 / E1 : E1;
 }
 
 // kind: 0 plain, 1 log-log (exp(spline(log r))), 2 sinh (f_t sinh(spline(asinh(r / x_t))))
 __global__ void __launch_bounds__(256)
 xi_table_kernel(const double *__restrict__ kx, const double *__restrict__ ky, const double *__restrict__ ky2, int nk,
-                int kind, double x_t, double f_t, const double *__restrict__ mu, int nm,
+                int nlut, int kind, double x_t, double f_t, const double *__restrict__ mu, int nm,
                 const double *__restrict__ xa, const double *__restrict__ xw, int F, int xint,
                 double *__restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
-    double *sx = sm, *sy = sm + nk, *s2 = sm + 2 * nk;
+    double *sx = sm, *sy = sm + nk, *s2 = sm + 2 * nk, *sih = sm + 3 * nk, *sh2 = sm + 4 * nk;
+    int *slut = reinterpret_cast<int *>(sm + 5 * nk);
     for (int t = threadIdx.x; t < nk; t += blockDim.x) {
         sx[t] = kx[t];
         sy[t] = ky[t];
         s2[t] = ky2[t];
+        if (t + 1 < nk) {
+            const double h = kx[t + 1] - kx[t];
+            sih[t] = 1.0 / h;
+            sh2[t] = (h * h) / 6.0;
+        }
     }
     __syncthreads();
+    spline_lds S;
+    S.xs = sx, S.ys = sy, S.y2 = s2, S.invh = sih, S.h2o6 = sh2, S.lut = slut, S.n = nk, S.nlut = nlut;
+    S.x0 = sx[0];
+    const double dx = (sx[nk - 1] - sx[0]) / (double)nlut;
+    S.inv_dx = 1.0 / dx;
+    for (int g = threadIdx.x; g < nlut; g += blockDim.x) {
+        const double xl = S.x0 + g * dx;        // left edge of the cell: bisection for the last knot <= xl
+        int kl = 0, kh = nk;
+        while (kh - kl > 1) {
+            const int kn = (kh + kl) >> 1;
+            if (sx[kn] > xl) kh = kn;
+            else kl = kn;
+        }
+        slut[g] = kl;
+    }
+    __syncthreads();
+    const double inv_xt = 1.0 / x_t;
     const long npair = (long)F * (F + 1) / 2;
     const long total = (long)nm * npair;
     for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (long)gridDim.x * blockDim.x) {
@@ -62,12 +138,12 @@ xi_table_kernel(const double *__restrict__ kx, const double *__restrict__ ky, co
             double row = 0.0;
             for (int b = 0; b < xint; b++) {
                 const double x2 = xa[j * xint + b];
-                const double dx = x1 - x2;
-                const double r = sqrt(dx * dx + 2.0 * x1 * x2 * om);
+                const double dx12 = x1 - x2;
+                const double r = sqrt(dx12 * dx12 + 2.0 * x1 * x2 * om);
                 double v;
-                if (kind == 1) v = exp(spline_eval(sx, sy, s2, nk, log(r)));
-                else if (kind == 2) v = f_t * sinh(spline_eval(sx, sy, s2, nk, asinh(r / x_t)));
-                else v = spline_eval(sx, sy, s2, nk, r);
+                if (kind == 1) v = fast_exp(spline_eval(S, r > 0.0 ? fast_log01(r) : -INFINITY));
+                else if (kind == 2) v = f_t * fast_sinh(spline_eval(S, fast_asinh_pos(r * inv_xt)));
+                else v = spline_eval(S, r);
                 row += xw[b] * v;
             }
             acc += xw[a] * row;
@@ -191,12 +267,13 @@ int corahip_xi_table_average(corahip_ctx *ctx, const double *knots_x, const doub
     ARG_CHECK(ctx != nullptr && knots_x && knots_y && knots_y2 && mu && xa && xw && out);
     ARG_CHECK(nk >= 4 && nk <= 6000 && kind >= 0 && kind <= 2 && nm >= 1 && F >= 1 && xint >= 1);
     StageTimer t(ctx, "xi_average");
-    const size_t shm = sizeof(double) * 3 * (size_t)nk;
+    const int nlut = 4 * nk;
+    const size_t shm = sizeof(double) * 5 * (size_t)nk + sizeof(int) * (size_t)nlut;
     HIP_TRY(hipFuncSetAttribute((const void *)xi_table_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
     const long total = (long)nm * F * (F + 1) / 2;
     const int blocks = (int)std::min<long>((total + 255) / 256, (long)ctx->num_cu * 8);
-    xi_table_kernel<<<blocks, 256, shm, ctx->stream>>>(knots_x, knots_y, knots_y2, nk, kind, x_t, f_t, mu, nm, xa, xw, F,
-                                                      xint, out);
+    xi_table_kernel<<<blocks, 256, shm, ctx->stream>>>(knots_x, knots_y, knots_y2, nk, nlut, kind, x_t, f_t, mu, nm, xa, xw,
+                                                      F, xint, out);
     LAUNCH_CHECK();
     return 0;
 }
