@@ -462,6 +462,9 @@ __device__ __forceinline__ static void fft_dit_last_out(const double2 *buf, int 
         }
     }
 }
+#ifndef K5_MC_BLU4
+#define K5_MC_BLU4 2   // prefetched cells of the four-channel Bluestein instantiation (2 spills 11 VGPRs)
+#endif
 #define K5_MC (K5_RADIX == 16 ? 4 : 2)  // cells per thread held in registers for the next item (rest read in place)
 #ifndef K5_STAMPS
 #define K5_STAMPS 0  // diagnostic build: s_memtime phase breakdown

@@ -19,7 +19,7 @@ ringfft_kernel(const int32_t *__restrict__ ring_list, int nlist, int nside, int 
                const int32_t *__restrict__ mcut) {
     // cells per thread prefetched into registers for the next item (the rest are read in place): the Bluestein
     // instantiations need the registers for the fused filter pass (4 cells made them spill 66 VGPRs)
-    constexpr int MC = BLU ? (K5_MC > 2 ? 2 : K5_MC) : K5_MC;
+    constexpr int MC = BLU ? (NCH == 4 ? K5_MC_BLU4 : (K5_MC > 2 ? 2 : K5_MC)) : K5_MC;
     extern __shared__ __attribute__((aligned(16))) double2 sm[];  // [NCH][bstride], then the twiddle table
     const int tid = threadIdx.x, nt = blockDim.x;
     const int L = lmax + 1;
