@@ -115,14 +115,20 @@ legendre_adj_kernel(int lmax, int npair, int nring, int ncols, const double *__r
                 for (int par = 0; par < 2; par++)
 #pragma unroll
                     for (int t = 0; t < NCT; t++) acc[par][t] = (d4_t){0.0, 0.0, 0.0, 0.0};
+                // A operands are read one k-step AHEAD of the MFMAs that use them (the read of step s+1 is in flight
+                // behind the four MFMAs of step s; with the read inside the skip branch every group of MFMAs waited
+                // out a full LDS latency first).  Parities in separate halves of the row: each read is unit-stride over
+                // the 16 lanes of a k-slot (interleaved, the pair became one ds_read2_b64 whose 16-lane groups stride
+                // 4 dwords over 32 banks: 2-way conflicts, SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.25)
+                double ae_n = lamw[kq * LSTR + ri], ao_n = lamw[kq * LSTR + 16 + ri];
 #pragma unroll
                 for (int s = 0; s < 16; s++) {
+                    const double ae = ae_n, ao = ao_n;
+                    if (s + 1 < 16) {
+                        ae_n = lamw[(4 * (s + 1) + kq) * LSTR + ri];
+                        ao_n = lamw[(4 * (s + 1) + kq) * LSTR + 16 + ri];
+                    }
                     if (!((act >> (4 * s)) & 1ull)) continue;
-                    // parities in separate halves of the row: each read is unit-stride over the 16 lanes of a
-                    // k-slot (interleaved, the pair became one ds_read2_b64 whose 16-lane groups stride 4 dwords
-                    // over 32 banks: 2-way conflicts, SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.25)
-                    const double ae = lamw[(4 * s + kq) * LSTR + ri];
-                    const double ao = lamw[(4 * s + kq) * LSTR + 16 + ri];
 #pragma unroll
                     for (int t = 0; t < NCT; t++) {
                         acc[0][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(ae, ge[s][t], acc[0][t], 0, 0, 0);
