@@ -94,27 +94,36 @@ legendre_adj_kernel(int lmax, int npair, int nring, int ncols, const double *__r
             ls4 = min(ls4, __shfl_xor(ls4, 2));
             const double2 *cf = coef + base_m;
 
-            for (int lb = lb0; lb <= lmax; lb += LB) {
+            // one 32-l block: recurrence of this lane's ring -> transpose buffer -> MFMAs into `acc`
+            auto do_block = [&](const int lb, d4_t (&acc)[2][NCT]) __attribute__((always_inline)) {
                 const unsigned long long act = __ballot(ls4 <= lb + LB - 1);   // bit 4s: k-step s has a started ring
                 // lambda_{lb .. lb+31} of this lane's ring -> transpose buffer [ring][l - lb]
                 // (coefficients are read unconditionally - the table is padded by 32 entries - so that the scalar
                 // loads of a whole unrolled group are issued together; rows past lmax are discarded below)
+                // the seed injection (three selects and a compare per step) is only compiled into the blocks in
+                // which some ring of the wave actually starts: 4 instead of 11 VALU instructions per step elsewhere
+                if (__any(my_ls >= lb && my_ls < lb + LB)) {
 #pragma unroll 8
-                for (int j = 0; j < LB; j++) {
-                    const int l = lb + j;
-                    const double2 c = cf[l];
-                    double vv = fma(c.x * x, p1, -(c.y * p0));
-                    const bool inj = (l == my_ls);
-                    vv = inj ? sd.y : vv;
-                    p0 = inj ? sd.x : p1;
-                    p1 = vv;
-                    lamw[lane * LSTR + (j & 1) * 16 + (j >> 1)] = vv;   // row = [16 even l | 16 odd l]
+                    for (int j = 0; j < LB; j++) {
+                        const int l = lb + j;
+                        const double2 c = cf[l];
+                        double vv = fma(c.x * x, p1, -(c.y * p0));
+                        const bool inj = (l == my_ls);
+                        vv = inj ? sd.y : vv;
+                        p0 = inj ? sd.x : p1;
+                        p1 = vv;
+                        lamw[lane * LSTR + (j & 1) * 16 + (j >> 1)] = vv;   // row = [16 even l | 16 odd l]
+                    }
+                } else {
+#pragma unroll 8
+                    for (int j = 0; j < LB; j++) {
+                        const double2 c = cf[lb + j];
+                        const double vv = fma(c.x * x, p1, -(c.y * p0));
+                        p0 = p1;
+                        p1 = vv;
+                        lamw[lane * LSTR + (j & 1) * 16 + (j >> 1)] = vv;
+                    }
                 }
-                d4_t acc[2][NCT];
-#pragma unroll
-                for (int par = 0; par < 2; par++)
-#pragma unroll
-                    for (int t = 0; t < NCT; t++) acc[par][t] = (d4_t){0.0, 0.0, 0.0, 0.0};
                 // A operands are read one k-step AHEAD of the MFMAs that use them (the read of step s+1 is in flight
                 // behind the four MFMAs of step s; with the read inside the skip branch every group of MFMAs waited
                 // out a full LDS latency first).  Parities in separate halves of the row: each read is unit-stride over
@@ -135,6 +144,18 @@ legendre_adj_kernel(int lmax, int npair, int nring, int ncols, const double *__r
                         acc[1][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(ao, go[s][t], acc[1][t], 0, 0, 0);
                     }
                 }
+            };
+            // two blocks share one cross-wave reduction (half the barriers; the partial tiles of both fit the wave's
+            // transpose buffer exactly)
+            for (int lb = lb0; lb <= lmax; lb += 2 * LB) {
+                d4_t acc0[2][NCT], acc1[2][NCT];
+#pragma unroll
+                for (int par = 0; par < 2; par++)
+#pragma unroll
+                    for (int t = 0; t < NCT; t++) acc0[par][t] = acc1[par][t] = (d4_t){0.0, 0.0, 0.0, 0.0};
+                do_block(lb, acc0);
+                const bool two = lb + LB <= lmax;
+                if (two) do_block(lb + LB, acc1);
                 // ---- add the eight waves' partial tiles through LDS (the wave's transpose buffer is free now:
                 //      LDS operations of one wave are ordered)
 #pragma unroll
@@ -142,16 +163,20 @@ legendre_adj_kernel(int lmax, int npair, int nring, int ncols, const double *__r
 #pragma unroll
                     for (int t = 0; t < NCT; t++)
 #pragma unroll
-                        for (int r = 0; r < 4; r++) lamw[((par * NCT + t) * 4 + r) * 64 + lane] = acc[par][t][r];
+                        for (int r = 0; r < 4; r++) {
+                            lamw[((par * NCT + t) * 4 + r) * 64 + lane] = acc0[par][t][r];
+                            if (two) lamw[(((2 + par) * NCT + t) * 4 + r) * 64 + lane] = acc1[par][t][r];
+                        }
                 __syncthreads();
 #pragma unroll
-                for (int u = 0; u < NCT; u++) {
-                    const int e = tid + 512 * u;          // element (par, t, r, lane) of the reduced tile
+                for (int u = 0; u < 2 * NCT; u++) {
+                    if (u >= NCT && !two) break;
+                    const int e = tid + 512 * u;          // element (block, par, t, r, lane) of the reduced tiles
                     double sum = 0.0;
 #pragma unroll
                     for (int w = 0; w < ADJ_WAVES; w++) sum += lds[w * WREG + e];
-                    const int el = e & 63, r = (e >> 6) & 3, t = (e >> 8) % NCT, par = (e >> 8) / NCT;
-                    const int l = lb + 2 * ((el >> 4) + 4 * r) + par;
+                    const int el = e & 63, r = (e >> 6) & 3, q = e >> 8, t = q % NCT, par = (q / NCT) & 1, blk = q / (2 * NCT);
+                    const int l = lb + blk * LB + 2 * ((el >> 4) + 4 * r) + par;
                     if (l <= lmax) pout[(size_t)l * ncols + 16 * t + (el & 15)] = sum;
                 }
                 __syncthreads();
