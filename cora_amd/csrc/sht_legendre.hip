@@ -463,21 +463,36 @@ legendre_pol_kernel(int lmax, int npair, int nring, int ncols, const double *__r
                     const int lf = l0 + d;
                     // lambda at lf-1, lf (even l-m slot of this lane), lf+1 (odd slot); then 6 more steps
                     double lm1 = p1, le = 0.0, lo = 0.0;
+                    double lem1, lom1;
+                    if (__any(inj_l >= lf && inj_l < lf + 8)) {
 #pragma unroll
-                    for (int j = 0; j < 8; j++) {
-                        double vv = fma(c[j].x * x, p1, -(c[j].y * p0));
-                        const bool inj = (lf + j == inj_l);
-                        vv = inj ? sd.y : vv;
-                        p0 = inj ? sd.x : p1;
-                        p1 = vv;
-                        if (j == 0) {
-                            le = vv;
-                            lm1 = p0;      // lambda_{lf-1} as the recurrence sees it (the seed if injected here)
+                        for (int j = 0; j < 8; j++) {
+                            double vv = fma(c[j].x * x, p1, -(c[j].y * p0));
+                            const bool inj = (lf + j == inj_l);
+                            vv = inj ? sd.y : vv;
+                            p0 = inj ? sd.x : p1;
+                            p1 = vv;
+                            if (j == 0) {
+                                le = vv;
+                                lm1 = p0;      // lambda_{lf-1} as the recurrence sees it (the seed if injected here)
+                            }
+                            if (j == 1) lo = vv;
                         }
-                        if (j == 1) lo = vv;
+                        lem1 = lm1, lom1 = le;
+                        if (lf + 1 == inj_l) lom1 = sd.x;
+                    } else {
+                        // no ring of the wave starts inside this macro-step: plain recurrence (the compare and the
+                        // three 64-bit selects per step were two thirds of the VALU instructions of the loop)
+#pragma unroll
+                        for (int j = 0; j < 8; j++) {
+                            const double vv = fma(c[j].x * x, p1, -(c[j].y * p0));
+                            p0 = p1;
+                            p1 = vv;
+                            if (j == 0) le = vv;
+                            if (j == 1) lo = vv;
+                        }
+                        lem1 = lm1, lom1 = le;
                     }
-                    double lem1 = lm1, lom1 = le;
-                    if (lf + 1 == inj_l) lom1 = sd.x;
                     if (__all(ls_min > l0 + 7)) continue;
                     // W, X at the two l of this lane
                     const double4 ge = *reinterpret_cast<const double4 *>(sg + 4 * (8 * ms));
