@@ -248,16 +248,20 @@ draw_rng_kernel(const double *__restrict__ T, size_t t_ldl, int t_row0, const in
             if (pair_ok && kp < F) a = philox_normal_pair(seed, l, F, c_of, kp, mpair);
 #endif
             const int kl = 4 * kk + kq;          // k within the chunk
+            // all B operands of the k-step are read up front (one address + immediate offsets); with the read inside
+            // the triangular-skip branch every pair of MFMAs waited out an LDS latency first
+            double bv[NCT];
+            const double *brow = sb + ri * ROWD + 2 * ((kl >> 1) ^ ri) + (kl & 1);
+#pragma unroll
+            for (int t = 0; t < NCT; t++) bv[t] = brow[16 * t * ROWD];
 #pragma unroll
             for (int t = 0; t < NCT; t++) {
                 if (!dense && kbase > nu0 + col0 + 16 * t + 15) continue;
-                const int n = 16 * t + ri;
-                const double b = sb[n * ROWD + 2 * ((kl >> 1) ^ (n & 15)) + (kl & 1)];
 #if DRAW_ABLATE == 2   // diagnostic: no MFMA
-                asm volatile("" ::"v"(a.x), "v"(a.y), "v"(b));
+                asm volatile("" ::"v"(a.x), "v"(a.y), "v"(bv[t]));
 #else
-                acc0[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, b, acc0[t], 0, 0, 0);
-                acc1[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, b, acc1[t], 0, 0, 0);
+                acc0[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, bv[t], acc0[t], 0, 0, 0);
+                acc1[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, bv[t], acc1[t], 0, 0, 0);
 #endif
             }
         }
