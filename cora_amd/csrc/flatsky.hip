@@ -71,7 +71,7 @@ __device__ __host__ static inline int swz_bits(int x) {
 __device__ static inline int swz(int i) { return i ^ swz_bits(i >> 4); }
 // line t of a tile additionally rotates its slots by t (XOR of the low four bits): the lines of a tile are P apart,
 // i.e. in the same banks, and the commit / store of a strided axis touch T lines with consecutive lanes
-#define LINE_X(t) ((t) & 15 & (P - 1))   // (stays inside the line when P < 16)
+__device__ static inline int line_x(int t, int P) { return t & 15 & (P - 1); }   // (stays inside the line when P < 16)
 
 // e / d for 0 <= e < 2^23 with rcp = 1.0f / d: one float multiply and a +-1 correction instead of the
 // ~35-instruction integer division (the element loops below were 80 % integer division before)
@@ -92,7 +92,7 @@ __device__ __forceinline__ static void lds_dit(double2 *buf, int P, int logP, in
     if (logP & 1) {
         for (int w = threadIdx.x; w < lines * (P >> 1); w += FS_THREADS) {
             const int i = (2 * w) & (P - 1);                              // elements i, i + 1 share a bank row
-            const int sb = swz_bits(i >> 4) ^ LINE_X((2 * w) >> logP);
+            const int sb = swz_bits(i >> 4) ^ line_x((2 * w) >> logP, P);
             double2 *ln = buf + ((2 * w) & ~(P - 1));
             const double2 a = ln[i ^ sb], b = ln[(i + 1) ^ sb];
             ln[i ^ sb] = cadd(a, b);
@@ -109,7 +109,7 @@ __device__ __forceinline__ static void lds_dit(double2 *buf, int P, int logP, in
         for (int w = threadIdx.x; w < lines * q; w += FS_THREADS) {
             const int t = w >> lq, j = w & (q - 1);
             const int pos = j & (h - 1), grp = j >> lh;
-            const int i0 = ((grp << 2) << lh) + pos, s0 = swz_bits(i0 >> 4) ^ LINE_X(t);
+            const int i0 = ((grp << 2) << lh) + pos, s0 = swz_bits(i0 >> 4) ^ line_x(t, P);
             double2 *ln = buf + t * P;
             const int e0 = i0 ^ s0, e1 = (i0 + h) ^ s0 ^ c1s, e2 = (i0 + 2 * h) ^ s0 ^ c2s, e3 = (i0 + 3 * h) ^ s0 ^ c3s;
             const double2 w2 = tw[pos << ls2], w1 = cmul(w2, w2);
@@ -136,7 +136,7 @@ __device__ __forceinline__ static void lds_dif(double2 *buf, int P, int logP, in
         for (int w = threadIdx.x; w < lines * q; w += FS_THREADS) {
             const int t = w >> lq, j = w & (q - 1);
             const int pos = j & (h - 1), grp = j >> lh;
-            const int i0 = ((grp << 2) << lh) + pos, s0 = swz_bits(i0 >> 4) ^ LINE_X(t);
+            const int i0 = ((grp << 2) << lh) + pos, s0 = swz_bits(i0 >> 4) ^ line_x(t, P);
             double2 *ln = buf + t * P;
             const int e0 = i0 ^ s0, e1 = (i0 + h) ^ s0 ^ c1s, e2 = (i0 + 2 * h) ^ s0 ^ c2s, e3 = (i0 + 3 * h) ^ s0 ^ c3s;
             const double2 w2 = tw[pos << ls2], w1 = cmul(w2, w2);
@@ -153,7 +153,7 @@ __device__ __forceinline__ static void lds_dif(double2 *buf, int P, int logP, in
     if (logP & 1) {
         for (int w = threadIdx.x; w < lines * (P >> 1); w += FS_THREADS) {
             const int i = (2 * w) & (P - 1);                              // elements i, i + 1 share a bank row
-            const int sb = swz_bits(i >> 4) ^ LINE_X((2 * w) >> logP);
+            const int sb = swz_bits(i >> 4) ^ line_x((2 * w) >> logP, P);
             double2 *ln = buf + ((2 * w) & ~(P - 1));
             const double2 a = ln[i ^ sb], b = ln[(i + 1) ^ sb];
             ln[i ^ sb] = cadd(a, b);
@@ -257,7 +257,7 @@ __global__ void __launch_bounds__(FS_THREADS, FS_WG_PER_CU * FS_THREADS / 256) l
             for (int e = threadIdx.x; e < tl.teff * (P - n); e += FS_THREADS) {
                 int j;
                 const int t = fastdiv(e, P - n, rcp_z, j);
-                fs_lds[t * P + (swz(n + j) ^ LINE_X(t))] = make_double2(0.0, 0.0);
+                fs_lds[t * P + (swz(n + j) ^ line_x(t, P))] = make_double2(0.0, 0.0);
             }
         }
 #pragma unroll
@@ -272,25 +272,25 @@ __global__ void __launch_bounds__(FS_THREADS, FS_WG_PER_CU * FS_THREADS / 256) l
                     if (j == h)
                         xh[t] = v;
                     else
-                        fs_lds[t * P + (swz(j) ^ LINE_X(t))] = v;
+                        fs_lds[t * P + (swz(j) ^ line_x(t, P))] = v;
                 } else if (MODE == 1) {
                     if (j == 0 || 2 * j == n) v.y = 0.0;
                     // conj of the Hermitian extension: position j gets conj(c_j), position n-j gets c_j
                     const double2 lo = make_double2(v.x, -v.y);
                     const bool mirror = j > 0 && 2 * j < n;
                     if (A.blu) {
-                        fs_lds[t * P + (swz(j) ^ LINE_X(t))] = cmul(lo, A.chirp[j]);
-                        if (mirror) fs_lds[t * P + (swz(n - j) ^ LINE_X(t))] = cmul(v, A.chirp[n - j]);
+                        fs_lds[t * P + (swz(j) ^ line_x(t, P))] = cmul(lo, A.chirp[j]);
+                        if (mirror) fs_lds[t * P + (swz(n - j) ^ line_x(t, P))] = cmul(v, A.chirp[n - j]);
                     } else {
-                        fs_lds[t * P + (swz(brev_n(j, logP)) ^ LINE_X(t))] = lo;
-                        if (mirror) fs_lds[t * P + (swz(brev_n(n - j, logP)) ^ LINE_X(t))] = v;
+                        fs_lds[t * P + (swz(brev_n(j, logP)) ^ line_x(t, P))] = lo;
+                        if (mirror) fs_lds[t * P + (swz(brev_n(n - j, logP)) ^ line_x(t, P))] = v;
                     }
                 } else {
                     if (inv) v.y = -v.y;
                     if (A.blu)
-                        fs_lds[t * P + (swz(j) ^ LINE_X(t))] = cmul(v, A.chirp[j]);
+                        fs_lds[t * P + (swz(j) ^ line_x(t, P))] = cmul(v, A.chirp[j]);
                     else
-                        fs_lds[t * P + (swz(brev_n(j, logP)) ^ LINE_X(t))] = v;
+                        fs_lds[t * P + (swz(brev_n(j, logP)) ^ line_x(t, P))] = v;
                 }
             }
         }
@@ -330,7 +330,7 @@ __global__ void __launch_bounds__(FS_THREADS, FS_WG_PER_CU * FS_THREADS / 256) l
                 int k;
                 const int t = fastdiv(e, hp, rcp_hp, k), k2 = h - k;
                 double2 *ln = fs_lds + t * P;
-                const int pk = swz(k) ^ LINE_X(t), pk2 = swz(k2 < h ? k2 : 0) ^ LINE_X(t);
+                const int pk = swz(k) ^ line_x(t, P), pk2 = swz(k2 < h ? k2 : 0) ^ line_x(t, P);
                 double2 xk = ln[pk], xc = k == 0 ? xh[t] : ln[pk2];
                 if (k == 0) xk.y = 0.0, xc.y = 0.0;               // Im of the DC / Nyquist bins is ignored
                 const double2 E = make_double2(xk.x + xc.x, xk.y - xc.y);
@@ -353,7 +353,7 @@ __global__ void __launch_bounds__(FS_THREADS, FS_WG_PER_CU * FS_THREADS / 256) l
             else
                 lds_dif(fs_lds, P, logP, cur.teff, A.tw);
             for (int e = threadIdx.x; e < cur.teff * P; e += FS_THREADS) {
-                const int k = e & (P - 1), pe = (e - k) + (swz(k) ^ LINE_X(e >> logP));
+                const int k = e & (P - 1), pe = (e - k) + (swz(k) ^ line_x(e >> logP, P));
                 const double2 z = cmul(fs_lds[pe], A.filt[k]);
                 fs_lds[pe] = make_double2(z.x, -z.y);
             }
@@ -374,7 +374,7 @@ __global__ void __launch_bounds__(FS_THREADS, FS_WG_PER_CU * FS_THREADS / 256) l
         // ---- store ------------------------------------------------------------------------------
         // transform value Y_k of line t in natural order
         auto result = [&](int t, int k) {
-            double2 v = fs_lds[t * P + (swz((MODE == 3 && !A.blu) ? (int)brev_n(k, logP) : k) ^ LINE_X(t))];
+            double2 v = fs_lds[t * P + (swz((MODE == 3 && !A.blu) ? (int)brev_n(k, logP) : k) ^ line_x(t, P))];
             if (A.blu) v = cmul(make_double2(v.x, -v.y), A.chirp[k]);
             return v;
         };
