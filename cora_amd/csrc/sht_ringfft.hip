@@ -321,6 +321,27 @@ ringana_kernel(const int32_t *__restrict__ ring_list, int nlist, int nside, int 
     const int ngrp = (nnu + NCH - 1) / NCH;
     const int nitems = nlist * ngrp;
     const int nring = 4 * nside - 1;
+    // pixels of the NEXT item are loaded into registers behind the transform of the current one (one workgroup per
+    // CU: nothing else hides the HBM latency of the ring's pixels); ANA_PF double2 per channel and thread
+    constexpr int ANA_PF = 4;             // covers h <= ANA_PF * blockDim (2048 at 512 threads); longer rings read in place
+    double2 pf[NCH][ANA_PF];
+    auto prefetch = [&](int it) {
+        const int ring = ring_list[it / ngrp];
+        const int ch0 = (it % ngrp) * NCH;
+        const int h = nphi_a[ring] >> 1;
+        const long start = start_a[ring];
+#pragma unroll
+        for (int u = 0; u < ANA_PF; u++) {
+            const int j = tid + u * nt;
+#pragma unroll
+            for (int c = 0; c < NCH; c++) {
+                pf[c][u] = make_double2(0.0, 0.0);
+                if (j < h && ch0 + c < nvalid)
+                    pf[c][u] = *reinterpret_cast<const double2 *>(maps + (size_t)(ch0 + c) * npix + start + 2 * j);
+            }
+        }
+    };
+    if ((int)blockIdx.x < nitems) prefetch(blockIdx.x);
     for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
         const int ring = ring_list[item / ngrp];
         const int ch0 = (item % ngrp) * NCH;
@@ -342,7 +363,20 @@ ringana_kernel(const int32_t *__restrict__ ring_list, int nlist, int nside, int 
                 for (int c = 0; c < NCH; c++) sm[(size_t)c * bstride + fpad(j)] = make_double2(0.0, 0.0);
         }
         // ---- pixels -> packed complex (conjugated and chirped for the Bluestein path)
-        for (int j = tid; j < h; j += nt) {
+#pragma unroll
+        for (int u = 0; u < ANA_PF; u++) {
+            const int j = tid + u * nt;
+            if (j < h) {
+                const double2 bj = P ? bch[j] : make_double2(1.0, 0.0);
+#pragma unroll
+                for (int c = 0; c < NCH; c++) {
+                    double2 zv = pf[c][u];
+                    if (P) zv = cmul(make_double2(zv.x, -zv.y), bj);
+                    sm[(size_t)c * bstride + fpad(j)] = zv;
+                }
+            }
+        }
+        for (int j = tid + ANA_PF * nt; j < h; j += nt) {      // (rings longer than the prefetch window)
             const double2 bj = P ? bch[j] : make_double2(1.0, 0.0);
 #pragma unroll
             for (int c = 0; c < NCH; c++) {
@@ -352,6 +386,7 @@ ringana_kernel(const int32_t *__restrict__ ring_list, int nlist, int nside, int 
                 sm[(size_t)c * bstride + fpad(j)] = zv;
             }
         }
+        if (item + (int)gridDim.x < nitems) prefetch(item + gridDim.x);
         __syncthreads();
         double scaleZ = 1.0;
         if (P == 0) {
@@ -370,22 +405,33 @@ ringana_kernel(const int32_t *__restrict__ ring_list, int nlist, int nside, int 
         // ---- bins -> G_m cells
         const bool n_in_table = (pmax % n) == 0;
         double *cell0 = inter + ((size_t)ring * G + (ch0 >> 2)) * L * 8 + (ch0 & 3);
+        // phase e^{-i m phi0} and unpacking twiddle e^{-2 pi i m / n} of this thread's m = tid, tid + nt, ...: one
+        // sincospi each, then a rotation by the (exact-argument) step per iteration instead of two sincospi per m
+        // (at most ceil(L / nt) = 5 rotations, so the recurrence adds ~1e-16)
+        double2 phr, phs, wr_m, ws;
+        {
+            double sv, cv;
+            sincospi(fmod((double)tid * phi0_over_pi, 2.0), &sv, &cv);
+            phr = make_double2(cv, -sv);
+            sincospi(fmod((double)nt * phi0_over_pi, 2.0), &sv, &cv);
+            phs = make_double2(cv, -sv);
+            sincospi(2.0 * (double)(tid % n) / (double)n, &sv, &cv);
+            wr_m = make_double2(cv, -sv);
+            sincospi(2.0 * (double)(nt % n) / (double)n, &sv, &cv);
+            ws = make_double2(cv, -sv);
+        }
         for (int m = tid; m < Lr; m += nt) {
             const int k = m % n;
             const bool cj = k > h;
             const int kk = cj ? n - k : k;            // 0..h
             const int ka = kk == h ? 0 : kk;          // Z_h := Z_0
             const int kb = kk == 0 ? 0 : h - kk;      // partner h - kk (kk = 0 -> Z_h = Z_0)
-            double2 w;                                // e^{-2 pi i kk / n}
-            if (n_in_table) w = tw_get<-1>(tw, pmax, kk * (pmax / n));
-            else {
-                double sv, cv;
-                sincospi(2.0 * (double)kk / (double)n, &sv, &cv);
-                w = make_double2(cv, -sv);
-            }
-            double sp, cp;
-            sincospi(fmod((double)m * phi0_over_pi, 2.0), &sp, &cp);
-            const double2 ph = make_double2(cp * wr, -sp * wr);   // w_ring area e^{-i m phi0}
+            // e^{-2 pi i kk / n}: e^{-2 pi i m / n} has period n in m, and kk = n - k conjugates it
+            const double2 w = make_double2(wr_m.x, cj ? -wr_m.y : wr_m.y);
+            const double2 ph = make_double2(phr.x * wr, phr.y * wr);   // w_ring area e^{-i m phi0}
+            phr = cmul(phr, phs);
+            wr_m = cmul(wr_m, ws);
+            (void)n_in_table;
             double re[NCH], im[NCH];
 #pragma unroll
             for (int c = 0; c < NCH; c++) {
