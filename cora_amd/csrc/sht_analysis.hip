@@ -2,6 +2,10 @@
 // deterministic reduction over ring tiles.  See sht_internal.h.
 #include "sht_internal.h"
 
+#ifndef ADJ_CUNROLL
+#define ADJ_CUNROLL 8    // recurrence steps whose (scalar-loaded) coefficients are fetched together; measured 8 / 16 / 32: 25.1 / 26.9 / 25.5 ms
+#endif
+
 // K4^T  legendre_adj_kernel: a_lm(col) = sum_rings lambda_lm(ring) [G_m(north) + (-1)^{l+m} G_m(south)](col)
 // on FP64 MFMA with M = l, K = ring pairs, N = columns (channel re/im).  Work item = (m, 16 NCT columns,
 // tile of 512 ring pairs).  A wave owns 64 ring pairs: lane = ring steps the recurrence once per l (no
@@ -115,7 +119,7 @@ legendre_adj_kernel(int lmax, int npair, int nring, int ncols, const double *__r
                         lamw[lane * LSTR + (j & 1) * 16 + (j >> 1)] = vv;   // row = [16 even l | 16 odd l]
                     }
                 } else {
-#pragma unroll 8
+#pragma unroll ADJ_CUNROLL
                     for (int j = 0; j < LB; j++) {
                         const double2 c = cf[lb + j];
                         const double vv = fma(c.x * x, p1, -(c.y * p0));
