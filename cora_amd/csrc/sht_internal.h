@@ -104,6 +104,17 @@ __device__ static inline void glds16(const void *gsrc, unsigned lds_byte_addr) {
                  : "v"(gsrc), "s"(dst)
                  : "memory");
 }
+// same, with the source as a wave-uniform base (SGPR pair) + a 32-bit per-lane byte offset: the row address of an
+// a_lm piece is then pure scalar arithmetic (every instruction of K4's macro-step costs issue time)
+__device__ static inline void glds16_s(const void *sbase, unsigned lane_byte_off, unsigned lds_byte_addr) {
+    unsigned keep;
+    const unsigned dst = __builtin_amdgcn_readfirstlane(lds_byte_addr);
+    // (dropping the save / restore of M0 was measured: no gain)
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(lane_byte_off), "s"(sbase), "s"(dst)
+                 : "memory");
+}
 // ------------------------------------------------------------------------------------
 // K5: per-ring phase / fold / FFT
 // ------------------------------------------------------------------------------------

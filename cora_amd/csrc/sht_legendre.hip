@@ -53,6 +53,8 @@ legendre_kernel(int lmax, int npair, int nring, int ncols, const double *__restr
     struct item_t {
         int m, cg, rtile, l_begin, nstage;
         long base_m;
+        const double *src0;   // a_lm row (base_m + l_begin) of this column group (wave-uniform)
+        int row_limit;        // rows behind src0 that exist: the last m's stage overhang is clamped to the last row
     };
     auto decode = [&](int it) {
         item_t w;
@@ -67,6 +69,8 @@ legendre_kernel(int lmax, int npair, int nring, int ncols, const double *__restr
         w.l_begin = w.m + ((lmin - w.m) & ~7);
         w.nstage = lmin <= lmax ? (lmax - w.l_begin) / LEG_KT + 1 : 0;
         w.base_m = alm_idx(0, w.m, lmax);
+        w.src0 = alm + (size_t)w.cg * TCOLS + (size_t)(w.base_m + w.l_begin) * ncols;
+        w.row_limit = (int)(last_row - (w.base_m + w.l_begin));
         return w;
     };
     // LDS-DMA pieces: every wave issues exactly PIECES per stage (counted vmcnt): RPW a_lm rows (rows past
@@ -74,11 +78,12 @@ legendre_kernel(int lmax, int npair, int nring, int ncols, const double *__restr
     // the CROWS coefficient pairs (all waves write the same bytes).
     auto issue_row = [&](const item_t &w, int st, int rr) {
         const int row = wv + LEG_WAVES * rr;
-        long rowidx = w.base_m + w.l_begin + st * LEG_KT + row;
-        rowidx = rowidx < last_row ? rowidx : last_row;
-        const double *src = alm + (size_t)w.cg * TCOLS + (size_t)rowidx * ncols + 2 * lane;
+        int r = st * LEG_KT + row;
+        r = r < w.row_limit ? r : w.row_limit;
+        // wave-uniform: scalar address arithmetic only (the byte offset of a row fits 32 bits: < 2^12 rows of < 2^13 B... x 8)
+        const char *src = reinterpret_cast<const char *>(w.src0) + (unsigned)(r * ncols) * 8u;
         const unsigned dst = lds_base_bytes + (unsigned)(((st % LEG_NBUF) * STAGE + row * STRIDE) * sizeof(double));
-        if (lane < 8 * NT) glds16(src, dst);
+        if (lane < 8 * NT) glds16_s(src, 16u * lane, dst);
     };
     auto issue_coef = [&](const item_t &w, int st) {
         const int l = w.l_begin + st * LEG_KT + lane;
@@ -151,6 +156,18 @@ legendre_kernel(int lmax, int npair, int nring, int ncols, const double *__restr
                     inj_l[q] = 0x7fffffff;
                 }
             }
+            // wave-uniform bounds of the start rows: the skip tests of the macro-step loop become scalar compares
+            // (every vector instruction there costs issue time next to the MFMAs)
+            int ws_min = ls_min, ws_maxinj = -1;
+#pragma unroll
+            for (int q = 0; q < RT; q++) ws_maxinj = max(ws_maxinj, inj_l[q] == 0x7fffffff ? -1 : inj_l[q]);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                ws_min = min(ws_min, __shfl_xor(ws_min, o));
+                ws_maxinj = max(ws_maxinj, __shfl_xor(ws_maxinj, o));
+            }
+            ws_min = __builtin_amdgcn_readfirstlane(ws_min);
+            ws_maxinj = __builtin_amdgcn_readfirstlane(ws_maxinj);
 
             for (int st = 0; st < w.nstage; st++) {
                 // own pieces of stage st have landed when at most the pieces of the (up to LEG_NBUF-2) younger
@@ -175,7 +192,7 @@ legendre_kernel(int lmax, int npair, int nring, int ncols, const double *__restr
                     const int l0 = ls + 8 * ms;
                     if (l0 > lmax) continue;
                     // nothing of this wave starts before l0+14: skip the macro-step entirely
-                    if (__all(ls_min > l0 + 13)) continue;
+                    if (ws_min > l0 + 13) continue;
                     double ae[RT], ao[RT];
 #if LEG_ABLATE == 2  // diagnostic: no recurrence
 #pragma unroll
@@ -185,15 +202,17 @@ legendre_kernel(int lmax, int npair, int nring, int ncols, const double *__restr
                         asm volatile("" : "+v"(ae[q]), "+v"(ao[q]));
                     }
 #else
-                    __builtin_amdgcn_s_setprio(2);  // the short recurrence outranks the partner wave's MFMAs
                     double2 c[8];
 #pragma unroll
                     for (int j = 0; j < 8; j++) c[j] = sc[8 * ms + j];
                     const int lf = l0 + d;
                     bool any_inj = false;
+                    if (ws_maxinj >= l0) {   // (scalar) some ring of the wave may still start at or after this macro-step
 #pragma unroll
-                    for (int q = 0; q < RT; q++) any_inj |= (inj_l[q] >= lf && inj_l[q] < lf + 8);
-                    if (__any(any_inj)) {
+                        for (int q = 0; q < RT; q++) any_inj |= (inj_l[q] >= lf && inj_l[q] < lf + 8);
+                        any_inj = __any(any_inj);
+                    }
+                    if (any_inj) {
 #pragma unroll
                         for (int q = 0; q < RT; q++) {
 #pragma unroll
@@ -220,9 +239,24 @@ legendre_kernel(int lmax, int npair, int nring, int ncols, const double *__restr
                             }
                         }
                     }
-                    __builtin_amdgcn_s_setprio(0);
 #endif
-                    if (__all(ls_min > l0 + 7)) continue;  // all A operands of this macro-step are zero
+                    if (ws_min > l0 + 7) continue;  // all A operands of this macro-step are zero
+#if LEG_ABLATE == 5  // diagnostic: 16 extra INTEGER VALU instructions per macro-step (does non-matrix VALU issue hide behind MFMAs?)
+                    {
+                        unsigned dummy = (unsigned)l0;
+#pragma unroll
+                        for (int q = 0; q < 16; q++) asm volatile("v_add_u32 %0, %0, %1" : "+v"(dummy) : "v"(lane));
+                        asm volatile("" ::"v"(dummy));
+                    }
+#endif
+#if LEG_ABLATE == 6  // diagnostic: 16 extra SALU instructions per macro-step
+                    {
+                        unsigned sd0 = (unsigned)l0;
+#pragma unroll
+                        for (int q = 0; q < 16; q++) asm volatile("s_add_u32 %0, %0, 1" : "+s"(sd0));
+                        asm volatile("" ::"s"(sd0));
+                    }
+#endif
                     const double *be = sb + (8 * ms + d) * STRIDE + ri;
                     const double *bo = be + STRIDE;
 #if LEG_ABLATE == 1  // diagnostic: no MFMA (keep the operands alive)
