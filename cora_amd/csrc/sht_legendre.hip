@@ -2,6 +2,10 @@
 // spin-2 (legendre_pol_kernel) forms, and their launchers.  See sht_internal.h.
 #include "sht_internal.h"
 
+#ifndef LEG_MS_UNROLL
+#define LEG_MS_UNROLL 6   // (= LEG_KT / 8 at the shipped stage length) macro-step loop of a stage fully unrolled (loop counters and pointer increments become immediates): 71.0 -> 69.5 ms; factors 2 and 3: no change
+#endif
+
 // Lane roles (wave = 16 rings x 4 k-slots, the A operand of v_mfma_f64_16x16x4_f64):
 // lane (ri = lane&15, kq = lane>>4) runs the recurrence of ring ri STAGGERED by 2 kq steps, so that
 // at every macro-step (8 consecutive l, base l0) the first two values it produces are exactly the
@@ -181,7 +185,7 @@ legendre_kernel(int lmax, int npair, int nring, int ncols, const double *__restr
                 const int ls = w.l_begin + st * LEG_KT;
                 const double *sb = lds + (st % LEG_NBUF) * STAGE;
                 const double2 *sc = reinterpret_cast<const double2 *>(sb + LEG_KT * STRIDE) + d;
-#pragma unroll 1
+#pragma unroll LEG_MS_UNROLL
                 for (int ms = 0; ms < LEG_KT / 8; ms++) {
                     // one a_lm piece of the stage being refilled per macro-step: spreads the LDS-DMA issue
                     // over the MFMA work instead of an 8-wave burst behind the barrier (measured 7 % of time)
@@ -383,6 +387,8 @@ legendre_pol_kernel(int lmax, int npair, int nring, int ncols, const double *__r
     struct item_t {
         int m, cg, rtile, l_begin, nstage;
         long base_m;
+        const double *src0;   // a_lm row (base_m + l_begin) of this column group (wave-uniform)
+        int row_limit;        // rows behind src0 that exist
     };
     auto decode = [&](int it) {
         item_t w;
@@ -397,15 +403,17 @@ legendre_pol_kernel(int lmax, int npair, int nring, int ncols, const double *__r
         w.l_begin = w.m + ((lmin - w.m) & ~7);
         w.nstage = lmin <= lmax ? (lmax - w.l_begin) / KT + 1 : 0;
         w.base_m = alm_idx(0, w.m, lmax);
+        w.src0 = alm + (size_t)w.cg * TCOLS + (size_t)(w.base_m + w.l_begin) * ncols;
+        w.row_limit = (int)(last_row - (w.base_m + w.l_begin));
         return w;
     };
     auto issue_row = [&](const item_t &w, int st, int rr) {
         const int row = wv + LEG_WAVES * rr;
-        long rowidx = w.base_m + w.l_begin + st * KT + row;
-        rowidx = rowidx < last_row ? rowidx : last_row;
-        const double *src = alm + (size_t)w.cg * TCOLS + (size_t)rowidx * ncols + 2 * lane;
+        int r = st * KT + row;
+        r = r < w.row_limit ? r : w.row_limit;
+        const char *src = reinterpret_cast<const char *>(w.src0) + (unsigned)(r * ncols) * 8u;   // scalar arithmetic only
         const unsigned dst = lds_base_bytes + (unsigned)(((st % NBUF) * STAGE + row * STRIDE) * sizeof(double));
-        if (lane < 8 * NT) glds16(src, dst);
+        if (lane < 8 * NT) glds16_s(src, 16u * lane, dst);
     };
     // coefficient pieces of a stage: CROWS (A, B) pairs (16 B each) and CROWS (g1..g4) rows (32 B each = 2 CROWS
     // 16-byte chunks, contiguous in the table): 1 + 2 wave-instructions (CROWS = 40: 40 + 80 lanes)
@@ -459,7 +467,10 @@ legendre_pol_kernel(int lmax, int npair, int nring, int ncols, const double *__r
                 my_ls = lstart[o];
                 sd = seed[o];
             }
-            const int ls_min = my_ls;
+            int ls_min = my_ls;                  // wave-uniform below: the skip tests become scalar compares
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) ls_min = min(ls_min, __shfl_xor(ls_min, o));
+            ls_min = __builtin_amdgcn_readfirstlane(ls_min);
             int inj_l = my_ls;
             const double2 *cf = coef + w.base_m;
             {
@@ -486,11 +497,11 @@ legendre_pol_kernel(int lmax, int npair, int nring, int ncols, const double *__r
                 const double *sb = lds + (st % NBUF) * STAGE;
                 const double2 *sc = reinterpret_cast<const double2 *>(sb + KT * STRIDE) + d;
                 const double *sg = sb + KT * STRIDE + 2 * CROWS + 4 * d;
-#pragma unroll 1
+#pragma unroll
                 for (int ms = 0; ms < KT / 8; ms++) {
                     const int l0 = ls + 8 * ms;
                     if (l0 > lmax) continue;
-                    if (__all(ls_min > l0 + 13)) continue;
+                    if (ls_min > l0 + 13) continue;
                     double2 c[8];
 #pragma unroll
                     for (int j = 0; j < 8; j++) c[j] = sc[8 * ms + j];
@@ -527,7 +538,7 @@ legendre_pol_kernel(int lmax, int npair, int nring, int ncols, const double *__r
                         }
                         lem1 = lm1, lom1 = le;
                     }
-                    if (__all(ls_min > l0 + 7)) continue;
+                    if (ls_min > l0 + 7) continue;
                     // W, X at the two l of this lane
                     const double4 ge = *reinterpret_cast<const double4 *>(sg + 4 * (8 * ms));
                     const double4 go = *reinterpret_cast<const double4 *>(sg + 4 * (8 * ms + 1));
