@@ -53,6 +53,9 @@ __global__ void normals_kernel(uint64_t seed, int lmax, int F, double *__restric
 #ifndef DRAW_ABLATE
 #define DRAW_ABLATE 0  // diagnostic builds of the fused-RNG kernel: 1 no RNG, 2 no MFMA, 3 no a_lm stores, 4 no staging of T
 #endif
+#ifndef DRAW_KK_UNROLL
+#define DRAW_KK_UNROLL 1   // unroll factor of the k-step loop of a chunk in the fused-RNG kernel
+#endif
 #define DRAW_KC 32   // nu' per LDS stage
 #define DRAW_ROWS 64 // (c,m) rows per block (4 waves x 16)
 
@@ -236,7 +239,7 @@ draw_rng_kernel(const double *__restrict__ T, size_t t_ldl, int t_row0, const in
         if (!wave_has_rows) continue;
         const double *sb = lds + (c & 1) * BUF;
         const int k0 = c * DRAW_KC;
-#pragma unroll 1
+#pragma unroll DRAW_KK_UNROLL
         for (int kk = 0; kk < DRAW_KC / 4; kk++) {
             const int kbase = k0 + 4 * kk;
             if (kbase >= kmax) break;
