@@ -2,6 +2,9 @@
 // spin-2 (legendre_pol_kernel) forms, and their launchers.  See sht_internal.h.
 #include "sht_internal.h"
 
+#ifndef LEG_ST_UNROLL
+#define LEG_ST_UNROLL 1   // unroll factor of the stage loop (3 would make the LDS ring offsets immediates)
+#endif
 #ifndef LEG_MS_UNROLL
 #define LEG_MS_UNROLL 6   // (= LEG_KT / 8 at the shipped stage length) macro-step loop of a stage fully unrolled (loop counters and pointer increments become immediates): 71.0 -> 69.5 ms; factors 2 and 3: no change
 #endif
@@ -173,6 +176,7 @@ legendre_kernel(int lmax, int npair, int nring, int ncols, const double *__restr
             ws_min = __builtin_amdgcn_readfirstlane(ws_min);
             ws_maxinj = __builtin_amdgcn_readfirstlane(ws_maxinj);
 
+#pragma unroll LEG_ST_UNROLL
             for (int st = 0; st < w.nstage; st++) {
                 // own pieces of stage st have landed when at most the pieces of the (up to LEG_NBUF-2) younger
                 // stages are still in flight (anything younger than those only makes the wait stricter)
