@@ -176,117 +176,36 @@ legendre_kernel(int lmax, int npair, int nring, int ncols, const double *__restr
             ws_min = __builtin_amdgcn_readfirstlane(ws_min);
             ws_maxinj = __builtin_amdgcn_readfirstlane(ws_maxinj);
 
-#pragma unroll LEG_ST_UNROLL
-            for (int st = 0; st < w.nstage; st++) {
-                // own pieces of stage st have landed when at most the pieces of the (up to LEG_NBUF-2) younger
-                // stages are still in flight (anything younger than those only makes the wait stricter)
-                if (LEG_NBUF >= 4 && st + 2 < w.nstage) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PIECES) : "memory");
-                else if (LEG_NBUF >= 3 && st + 1 < w.nstage) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();  // everyone's pieces of stage st landed; everyone is done reading stage st-1
-                const bool refill = st + LEG_NBUF - 1 < w.nstage;
-                if (refill) issue_coef(w, st + LEG_NBUF - 1);
+            // Stage loop in three consecutive pieces (same body, leg_stage_body.inc): the head stages in which rings of
+            // the wave still start, the steady-state stages - every ring runs, none starts, every row <= lmax - whose
+            // macro-steps carry no tests at all and are fully unrolled (every scalar compare / branch / loop increment
+            // costs issue time next to the MFMAs), and the tail stage that overhangs lmax.
+            auto stage_clean = [&](int st) {
                 const int ls = w.l_begin + st * LEG_KT;
-                const double *sb = lds + (st % LEG_NBUF) * STAGE;
-                const double2 *sc = reinterpret_cast<const double2 *>(sb + LEG_KT * STRIDE) + d;
-#pragma unroll LEG_MS_UNROLL
-                for (int ms = 0; ms < LEG_KT / 8; ms++) {
-                    // one a_lm piece of the stage being refilled per macro-step: spreads the LDS-DMA issue
-                    // over the MFMA work instead of an 8-wave burst behind the barrier (measured 7 % of time)
-                    if (refill) {
-#pragma unroll
-                        for (int r = 0; r < RPM; r++) issue_row(w, st + LEG_NBUF - 1, ms * RPM + r);
-                    }
-                    const int l0 = ls + 8 * ms;
-                    if (l0 > lmax) continue;
-                    // nothing of this wave starts before l0+14: skip the macro-step entirely
-                    if (ws_min > l0 + 13) continue;
-                    double ae[RT], ao[RT];
-#if LEG_ABLATE == 2  // diagnostic: no recurrence
-#pragma unroll
-                    for (int q = 0; q < RT; q++) {
-                        ae[q] = x[q];
-                        ao[q] = x[q] + 1.0;
-                        asm volatile("" : "+v"(ae[q]), "+v"(ao[q]));
-                    }
-#else
-                    double2 c[8];
-#pragma unroll
-                    for (int j = 0; j < 8; j++) c[j] = sc[8 * ms + j];
-                    const int lf = l0 + d;
-                    bool any_inj = false;
-                    if (ws_maxinj >= l0) {   // (scalar) some ring of the wave may still start at or after this macro-step
-#pragma unroll
-                        for (int q = 0; q < RT; q++) any_inj |= (inj_l[q] >= lf && inj_l[q] < lf + 8);
-                        any_inj = __any(any_inj);
-                    }
-                    if (any_inj) {
-#pragma unroll
-                        for (int q = 0; q < RT; q++) {
-#pragma unroll
-                            for (int j = 0; j < 8; j++) {
-                                double vv = fma(c[j].x * x[q], p1[q], -(c[j].y * p0[q]));
-                                const bool inj = (lf + j == inj_l[q]);
-                                vv = inj ? sd[q].y : vv;
-                                p0[q] = inj ? sd[q].x : p1[q];
-                                p1[q] = vv;
-                                if (j == 0) ae[q] = vv;
-                                if (j == 1) ao[q] = vv;
-                            }
-                        }
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < 8; j++) {
-#pragma unroll
-                            for (int q = 0; q < RT; q++) {
-                                const double vv = fma(c[j].x * x[q], p1[q], -(c[j].y * p0[q]));
-                                p0[q] = p1[q];
-                                p1[q] = vv;
-                                if (j == 0) ae[q] = vv;
-                                if (j == 1) ao[q] = vv;
-                            }
-                        }
-                    }
-#endif
-                    if (ws_min > l0 + 7) continue;  // all A operands of this macro-step are zero
-#if LEG_ABLATE == 5  // diagnostic: 16 extra INTEGER VALU instructions per macro-step (does non-matrix VALU issue hide behind MFMAs?)
-                    {
-                        unsigned dummy = (unsigned)l0;
-#pragma unroll
-                        for (int q = 0; q < 16; q++) asm volatile("v_add_u32 %0, %0, %1" : "+v"(dummy) : "v"(lane));
-                        asm volatile("" ::"v"(dummy));
-                    }
-#endif
-#if LEG_ABLATE == 6  // diagnostic: 16 extra SALU instructions per macro-step
-                    {
-                        unsigned sd0 = (unsigned)l0;
-#pragma unroll
-                        for (int q = 0; q < 16; q++) asm volatile("s_add_u32 %0, %0, 1" : "+s"(sd0));
-                        asm volatile("" ::"s"(sd0));
-                    }
-#endif
-                    const double *be = sb + (8 * ms + d) * STRIDE + ri;
-                    const double *bo = be + STRIDE;
-#if LEG_ABLATE == 1  // diagnostic: no MFMA (keep the operands alive)
-                    asm volatile("" ::"v"(ae[0]), "v"(ao[0]), "v"(be), "v"(bo));
-#else
-#pragma unroll
-                    for (int t = 0; t < NT; t++) {
-#if LEG_ABLATE == 3  // diagnostic: no B operand reads from LDS
-                        const double bev = ae[0] + t, bov = ao[0] - t;
-                        asm volatile("" ::"v"(be), "v"(bo));
-#else
-                        const double bev = be[16 * t], bov = bo[16 * t];
-#endif
-#pragma unroll
-                        for (int q = 0; q < RT; q++) {
-                            acce[q][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(ae[q], bev, acce[q][t], 0, 0, 0);
-                            acco[q][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(ao[q], bov, acco[q][t], 0, 0, 0);
-                        }
-                    }
-#endif
-                }
+                return (ls + LEG_KT - 1 <= lmax) && (ws_min <= ls) && (ws_maxinj < ls);
+            };
+            int st = 0;
+#define LEG_CLEAN 0
+#define LEG_MS_PRAGMA _Pragma("unroll 1")
+            for (; st < w.nstage && !stage_clean(st); st++) {
+#include "leg_stage_body.inc"
             }
+#undef LEG_CLEAN
+#undef LEG_MS_PRAGMA
+#define LEG_CLEAN 1
+#define LEG_MS_PRAGMA _Pragma("unroll")
+            for (; st < w.nstage && stage_clean(st); st++) {
+#include "leg_stage_body.inc"
+            }
+#undef LEG_CLEAN
+#undef LEG_MS_PRAGMA
+#define LEG_CLEAN 0
+#define LEG_MS_PRAGMA _Pragma("unroll 1")
+            for (; st < w.nstage; st++) {
+#include "leg_stage_body.inc"
+            }
+#undef LEG_CLEAN
+#undef LEG_MS_PRAGMA
         }
 
         // ---- next item: start its first stages now, so they land behind this item's epilogue stores
