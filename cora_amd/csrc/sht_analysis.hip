@@ -134,18 +134,35 @@ legendre_adj_kernel(int lmax, int npair, int nring, int ncols, const double *__r
                 // the 16 lanes of a k-slot (interleaved, the pair became one ds_read2_b64 whose 16-lane groups stride
                 // 4 dwords over 32 banks: 2-way conflicts, SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.25)
                 double ae_n = lamw[kq * LSTR + ri], ao_n = lamw[kq * LSTR + 16 + ri];
+                if (act == ~0ull) {
+                    // every k-step has a started ring (all blocks but the first few of an item): no skip tests
 #pragma unroll
-                for (int s = 0; s < 16; s++) {
-                    const double ae = ae_n, ao = ao_n;
-                    if (s + 1 < 16) {
-                        ae_n = lamw[(4 * (s + 1) + kq) * LSTR + ri];
-                        ao_n = lamw[(4 * (s + 1) + kq) * LSTR + 16 + ri];
+                    for (int s = 0; s < 16; s++) {
+                        const double ae = ae_n, ao = ao_n;
+                        if (s + 1 < 16) {
+                            ae_n = lamw[(4 * (s + 1) + kq) * LSTR + ri];
+                            ao_n = lamw[(4 * (s + 1) + kq) * LSTR + 16 + ri];
+                        }
+#pragma unroll
+                        for (int t = 0; t < NCT; t++) {
+                            acc[0][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(ae, ge[s][t], acc[0][t], 0, 0, 0);
+                            acc[1][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(ao, go[s][t], acc[1][t], 0, 0, 0);
+                        }
                     }
-                    if (!((act >> (4 * s)) & 1ull)) continue;
+                } else {
 #pragma unroll
-                    for (int t = 0; t < NCT; t++) {
-                        acc[0][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(ae, ge[s][t], acc[0][t], 0, 0, 0);
-                        acc[1][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(ao, go[s][t], acc[1][t], 0, 0, 0);
+                    for (int s = 0; s < 16; s++) {
+                        const double ae = ae_n, ao = ao_n;
+                        if (s + 1 < 16) {
+                            ae_n = lamw[(4 * (s + 1) + kq) * LSTR + ri];
+                            ao_n = lamw[(4 * (s + 1) + kq) * LSTR + 16 + ri];
+                        }
+                        if (!((act >> (4 * s)) & 1ull)) continue;
+#pragma unroll
+                        for (int t = 0; t < NCT; t++) {
+                            acc[0][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(ae, ge[s][t], acc[0][t], 0, 0, 0);
+                            acc[1][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(ao, go[s][t], acc[1][t], 0, 0, 0);
+                        }
                     }
                 }
             };
