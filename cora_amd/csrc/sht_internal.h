@@ -80,7 +80,7 @@ static inline bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 #define LEG_ABLATE 0  // diagnostic builds only (make ablate): 1 no MFMA, 2 no recurrence, 3 no B reads, 4 no epilogue stores
 #endif
 #ifndef LEG_KT
-#define LEG_KT 48      // l rows per LDS stage (32 rows x 4 buffers: 75.6 ms; 48 x 3: 74.1 ms; 48 x 2 and 56 x 2: 74.2 ms; 64 needs > 64 coefficient lanes)
+#define LEG_KT 56     // rows of l per LDS stage (re-tuned after the instruction-count pass: 48 x 3 68.5, 56 x 2 67.7, 48 x 2 68.9, 40 x 3 72.1, 32 x 4 69.8 ms)
 #endif
 #ifndef LEG_WAVES
 #define LEG_WAVES 8
@@ -89,7 +89,7 @@ static inline bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 #define LMIN_RINGS 128              // granularity of the plan's per-(m, ring block) first-l table
 #define ADJ_WAVES 8                 // waves per workgroup of the analysis kernel
 #ifndef LEG_NBUF
-#define LEG_NBUF 3     // LDS stage ring: one being read + two in flight
+#define LEG_NBUF 2     // LDS stage ring: one being read + one in flight
 #endif
 
 // LDS-DMA issued from inline asm: hipcc does not count it, so it does not drain the DMA with a

@@ -6,7 +6,7 @@
 #define LEG_ST_UNROLL 1   // unroll factor of the stage loop (3 would make the LDS ring offsets immediates)
 #endif
 #ifndef LEG_MS_UNROLL
-#define LEG_MS_UNROLL 6   // (= LEG_KT / 8 at the shipped stage length) macro-step loop of a stage fully unrolled (loop counters and pointer increments become immediates): 71.0 -> 69.5 ms; factors 2 and 3: no change
+#define LEG_MS_UNROLL 7   // (= LEG_KT / 8 at the shipped stage length; only the rolled head / tail stages use it) macro-step loop of a stage fully unrolled (loop counters and pointer increments become immediates): 71.0 -> 69.5 ms; factors 2 and 3: no change
 #endif
 
 // Lane roles (wave = 16 rings x 4 k-slots, the A operand of v_mfma_f64_16x16x4_f64):
