@@ -194,7 +194,7 @@ legendre_kernel(int lmax, int npair, int nring, int ncols, const double *__restr
 #undef LEG_MS_PRAGMA
 #define LEG_CLEAN 1
 #define LEG_MS_PRAGMA _Pragma("unroll")
-            for (; st < w.nstage && stage_clean(st); st++) {
+            for (; st + LEG_NBUF - 1 < w.nstage && stage_clean(st); st++) {
 #include "leg_stage_body.inc"
             }
 #undef LEG_CLEAN
