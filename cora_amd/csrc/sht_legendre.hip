@@ -410,77 +410,36 @@ legendre_pol_kernel(int lmax, int npair, int nring, int ncols, const double *__r
                     inj_l = 0x7fffffff;
                 }
             }
-            for (int st = 0; st < w.nstage; st++) {
-                if (st + 1 < w.nstage) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
-                const bool refill = st + NBUF - 1 < w.nstage;
-                if (refill) issue_stage(w, st + NBUF - 1);
+            int ws_maxinj = inj_l == 0x7fffffff ? -1 : inj_l;   // wave-uniform: last row at which a ring of the wave starts
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) ws_maxinj = max(ws_maxinj, __shfl_xor(ws_maxinj, o));
+            ws_maxinj = __builtin_amdgcn_readfirstlane(ws_maxinj);
+            auto stage_clean = [&](int st) {
                 const int ls = w.l_begin + st * KT;
-                const double *sb = lds + (st % NBUF) * STAGE;
-                const double2 *sc = reinterpret_cast<const double2 *>(sb + KT * STRIDE) + d;
-                const double *sg = sb + KT * STRIDE + 2 * CROWS + 4 * d;
-#pragma unroll
-                for (int ms = 0; ms < KT / 8; ms++) {
-                    const int l0 = ls + 8 * ms;
-                    if (l0 > lmax) continue;
-                    if (ls_min > l0 + 13) continue;
-                    double2 c[8];
-#pragma unroll
-                    for (int j = 0; j < 8; j++) c[j] = sc[8 * ms + j];
-                    const int lf = l0 + d;
-                    // lambda at lf-1, lf (even l-m slot of this lane), lf+1 (odd slot); then 6 more steps
-                    double lm1 = p1, le = 0.0, lo = 0.0;
-                    double lem1, lom1;
-                    if (__any(inj_l >= lf && inj_l < lf + 8)) {
-#pragma unroll
-                        for (int j = 0; j < 8; j++) {
-                            double vv = fma(c[j].x * x, p1, -(c[j].y * p0));
-                            const bool inj = (lf + j == inj_l);
-                            vv = inj ? sd.y : vv;
-                            p0 = inj ? sd.x : p1;
-                            p1 = vv;
-                            if (j == 0) {
-                                le = vv;
-                                lm1 = p0;      // lambda_{lf-1} as the recurrence sees it (the seed if injected here)
-                            }
-                            if (j == 1) lo = vv;
-                        }
-                        lem1 = lm1, lom1 = le;
-                        if (lf + 1 == inj_l) lom1 = sd.x;
-                    } else {
-                        // no ring of the wave starts inside this macro-step: plain recurrence (the compare and the
-                        // three 64-bit selects per step were two thirds of the VALU instructions of the loop)
-#pragma unroll
-                        for (int j = 0; j < 8; j++) {
-                            const double vv = fma(c[j].x * x, p1, -(c[j].y * p0));
-                            p0 = p1;
-                            p1 = vv;
-                            if (j == 0) le = vv;
-                            if (j == 1) lo = vv;
-                        }
-                        lem1 = lm1, lom1 = le;
-                    }
-                    if (ls_min > l0 + 7) continue;
-                    // W, X at the two l of this lane
-                    const double4 ge = *reinterpret_cast<const double4 *>(sg + 4 * (8 * ms));
-                    const double4 go = *reinterpret_cast<const double4 *>(sg + 4 * (8 * ms + 1));
-                    const double We = fma(fma(ge.x, r1, ge.y), le, (ge.z * r2) * lem1);
-                    const double Xe = fma(ge.w * r2, le, -((mval * ge.z) * r1) * lem1);
-                    const double Wo = fma(fma(go.x, r1, go.y), lo, (go.z * r2) * lom1);
-                    const double Xo = fma(go.w * r2, lo, -((mval * go.z) * r1) * lom1);
-                    const double *be = sb + (8 * ms + d) * STRIDE + ri;
-                    const double *bo = be + STRIDE;
-#pragma unroll
-                    for (int t = 0; t < NT; t++) {
-                        const double bev = be[16 * t], bov = bo[16 * t];
-                        awe[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(We, bev, awe[t], 0, 0, 0);
-                        awo[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(Wo, bov, awo[t], 0, 0, 0);
-                        axe[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(Xe, bev, axe[t], 0, 0, 0);
-                        axo[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(Xo, bov, axo[t], 0, 0, 0);
-                    }
-                }
+                return (ls + KT - 1 <= lmax) && (ls_min <= ls) && (ws_maxinj < ls);
+            };
+            int st = 0;
+#define LEGP_CLEAN 0
+#define LEGP_MS_PRAGMA _Pragma("unroll 1")
+            for (; st < w.nstage && !stage_clean(st); st++) {
+#include "legpol_stage_body.inc"
             }
+#undef LEGP_CLEAN
+#undef LEGP_MS_PRAGMA
+#define LEGP_CLEAN 1
+#define LEGP_MS_PRAGMA _Pragma("unroll")
+            for (; st + NBUF - 1 < w.nstage && stage_clean(st); st++) {
+#include "legpol_stage_body.inc"
+            }
+#undef LEGP_CLEAN
+#undef LEGP_MS_PRAGMA
+#define LEGP_CLEAN 0
+#define LEGP_MS_PRAGMA _Pragma("unroll 1")
+            for (; st < w.nstage; st++) {
+#include "legpol_stage_body.inc"
+            }
+#undef LEGP_CLEAN
+#undef LEGP_MS_PRAGMA
         }
 
         const int cur_rtile = w.rtile, cur_cg = w.cg, cur_m = w.m, cur_nstage = w.nstage;
