@@ -2,6 +2,10 @@
 // FFT -> weighted, phased G_m cells), with their per-class launch loops.  The LDS FFT passes are in sht_internal.h.
 #include "sht_internal.h"
 
+#ifndef K5_XCD_PAIR
+#define K5_XCD_PAIR 1
+#endif
+
 // Persistent workgroups: each loops over work items (ring of the class, NCH consecutive channels),
 // all NCH channels transformed together in LDS.  The F_m cells of the NEXT item are fetched into
 // registers while the current item is in its FFT passes, so HBM reads overlap the FP64 work and the
@@ -86,9 +90,20 @@ ringfft_kernel(const int32_t *__restrict__ ring_list, int nlist, int nside, int 
     unsigned long long k5_last, t_zero = 0, t_fold = 0, t_z = 0, t_fft = 0, t_out = 0, t_pre = 0, t_mid = 0, t_dit = 0;
     { unsigned long long _t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)::"memory"); k5_last = _t; }
 #endif
-    int item = blockIdx.x;
-    if (item < nitems) prefetch(item);
-    for (; item < nitems; item += gridDim.x) {
+    // With NCH < 4 the 4 / NCH items of one ring that share every 64-byte cell are consecutive.  Round-robin dispatch
+    // puts consecutive workgroups on different XCDs, each L2 then fetches the cells for itself; workgroups b and
+    // b + 8 (same XCD, resident together) take such neighbours instead (K5_XCD_PAIR).
+    constexpr int SH = NCH == 2 ? 1 : (NCH == 1 ? 2 : 0);             // log2 of the items sharing a cell
+    const bool xcd_pair = K5_XCD_PAIR && SH > 0 && (nitems & ((8 << SH) - 1)) == 0 && (gridDim.x & ((8 << SH) - 1)) == 0;
+    auto remap = [&](int v) {
+        if (!xcd_pair) return v;
+        const int slot = v >> 3, xcd = v & 7;
+        return (((slot >> SH) * 8 + xcd) << SH) + (slot & ((1 << SH) - 1));
+    };
+    int vitem = blockIdx.x;
+    if (vitem < nitems) prefetch(remap(vitem));
+    for (; vitem < nitems; vitem += gridDim.x) {
+        const int item = remap(vitem);
         const int ring = ring_list[item / ngrp];
         const int ch0 = (item % ngrp) * NCH;
         const int n = nphi_a[ring];
@@ -166,7 +181,7 @@ ringfft_kernel(const int32_t *__restrict__ ring_list, int nlist, int nside, int 
             fold_one(m, load_cell(cell, m));
         }
         // the registers are free again: fetch the next item's cells behind the FFT passes
-        if (item + (int)gridDim.x < nitems) prefetch(item + gridDim.x);
+        if (vitem + (int)gridDim.x < nitems) prefetch(remap(vitem + gridDim.x));
         __syncthreads();
         K5STAMP(t_fold);
         // ---- Hermitian -> half-length complex: Z_k = (X_k + conj X_{h-k}) + i w^k (X_k - conj X_{h-k}),
