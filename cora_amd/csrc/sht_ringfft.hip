@@ -356,8 +356,17 @@ ringana_kernel(const int32_t *__restrict__ ring_list, int nlist, int nside, int 
             }
         }
     };
-    if ((int)blockIdx.x < nitems) prefetch(blockIdx.x);
-    for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+    // (K5_XCD_PAIR as in ringfft_kernel: the items writing the two halves of a 64-byte cell go to one XCD)
+    constexpr int SH = NCH == 2 ? 1 : (NCH == 1 ? 2 : 0);
+    const bool xcd_pair = K5_XCD_PAIR && SH > 0 && (nitems & ((8 << SH) - 1)) == 0 && (gridDim.x & ((8 << SH) - 1)) == 0;
+    auto remap = [&](int v) {
+        if (!xcd_pair) return v;
+        const int slot = v >> 3, xcd = v & 7;
+        return (((slot >> SH) * 8 + xcd) << SH) + (slot & ((1 << SH) - 1));
+    };
+    if ((int)blockIdx.x < nitems) prefetch(remap(blockIdx.x));
+    for (int vitem = blockIdx.x; vitem < nitems; vitem += gridDim.x) {
+        const int item = remap(vitem);
         const int ring = ring_list[item / ngrp];
         const int ch0 = (item % ngrp) * NCH;
         const int n = nphi_a[ring];
@@ -401,7 +410,7 @@ ringana_kernel(const int32_t *__restrict__ ring_list, int nlist, int nside, int 
                 sm[(size_t)c * bstride + fpad(j)] = zv;
             }
         }
-        if (item + (int)gridDim.x < nitems) prefetch(item + gridDim.x);
+        if (vitem + (int)gridDim.x < nitems) prefetch(remap(vitem + gridDim.x));
         __syncthreads();
         double scaleZ = 1.0;
         if (P == 0) {
