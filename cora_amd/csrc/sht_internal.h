@@ -310,6 +310,27 @@ __device__ __forceinline__ static void fft_pass(double2 *buf, int bstride, int n
 #pragma unroll
         for (int b = 1; b < NB; b++) wp[b] = cmul(wp[b - 1], wp[b - 1]);
         auto twiddle_all = [&]() {
+#if K5_TW_4X4
+            if (R == 16) {
+                // w^r = (w^4)^a w^c for r = 4a + c: 5 multiplies for (w^2, w^3, w^4, w^8, w^12) + 24 to apply them,
+                // instead of 3 squarings + 32 selected binary powers (6 complex multiplies fewer per butterfly)
+                const double2 w1 = wp[0], w2 = wp[1], w4 = wp[2], w8 = wp[3];
+                const double2 w3 = cmul(w2, w1), w12 = cmul(w8, w4);
+#pragma unroll
+                for (int a = 0; a < 4; a++) {
+                    x[(4 * a + 1) % R] = cmul(x[(4 * a + 1) % R], w1);
+                    x[(4 * a + 2) % R] = cmul(x[(4 * a + 2) % R], w2);
+                    x[(4 * a + 3) % R] = cmul(x[(4 * a + 3) % R], w3);
+                }
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    x[(4 + c) % R] = cmul(x[(4 + c) % R], w4);
+                    x[(8 + c) % R] = cmul(x[(8 + c) % R], w8);
+                    x[(12 + c) % R] = cmul(x[(12 + c) % R], w12);
+                }
+                return;
+            }
+#endif
 #pragma unroll
             for (int r = 1; r < R; r++) {
 #pragma unroll
@@ -330,6 +351,9 @@ __device__ __forceinline__ static void fft_pass(double2 *buf, int bstride, int n
     __syncthreads();
 }
 
+#ifndef K5_TW_4X4
+#define K5_TW_4X4 0   // 1: radix-16 twiddles as (w^4)^a w^c, 29 complex multiplies per butterfly instead of 35 - measured: no difference (the passes are latency-bound, two waves per SIMD)
+#endif
 #ifndef K5_RADIX
 #define K5_RADIX 16    // largest butterfly: 16 -> 512-thread workgroups; 8 -> 1024 threads (<= 128 VGPRs: measured 30 % slower, spills)
 #endif
