@@ -188,6 +188,7 @@ draw_rng_kernel(const double *__restrict__ T, size_t t_ldl, int t_row0, const in
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c_of = wave >> 1;
     const int ri = lane & 15, kq = lane >> 4;
+    if (mb * 64 >= lp1) return;                 // no m of this l in the block (half the [l][m-block] grid): uniform, before any barrier / DMA
     const int m0 = mb * 64 + (wave & 1) * 32;   // first m of this wave
     const int mpair = (m0 >> 1) + ri;           // this lane's m-pair: rows m = 2 mpair, 2 mpair + 1
     const bool pair_ok = 2 * mpair < lp1;

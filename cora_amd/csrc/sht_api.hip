@@ -50,10 +50,13 @@ extern "C" int corahip_alm2map(corahip_ctx *ctx, const corahip_sht_plan *p, cons
     // chunked: workspace holds [inter for chunk][alm slice for chunk]
     const size_t per8_inter = (size_t)p->nring * 2 * p->L * 8 * sizeof(double);
     const size_t per8_alm = (size_t)p->nalm * 16 * sizeof(double);
-    int nchunk8 = (int)(workspace_bytes / (per8_inter + per8_alm));
+    // K5's register prefetch over-reads up to K5_TAIL_PAD bytes behind the last F_m row: those bytes are the alm
+    // slice and, when the slice is smaller than the pad (small plans), the reserve kept free at the end
+    const size_t usable = workspace_bytes > K5_TAIL_PAD ? workspace_bytes - K5_TAIL_PAD : 0;
+    int nchunk8 = (int)(usable / (per8_inter + per8_alm));
     if (nchunk8 < 1) {
         corahip_set_error("alm2map workspace too small: %zu bytes, need at least %zu", workspace_bytes,
-                          per8_inter + per8_alm);
+                          per8_inter + per8_alm + K5_TAIL_PAD);
         return CORAHIP_ENOMEM;
     }
     // prefer chunks that are multiples of 64 channels (NT = 8 tiles)

@@ -148,10 +148,17 @@ class SkyShard:
         sp = self.plan
         self.nu0, self.nnu = sp.nu0, sp.nnu
         self.zint = zint = 2**zromb + 1 if zromb else 1
-        zhalf = abs(self.freq[1] - self.freq[0]) / 2.0 if F > 1 else 0.0
+        # channel half-width exactly as skysim.clarray takes it: from the two smallest sorted frequencies (skysim.py:41-45)
+        fsort = np.sort(self.freq)
+        zhalf = abs(fsort[1] - fsort[0]) / 2.0 if F > 1 else 0.0
         za = (self.freq[:, None] + np.linspace(-zhalf, zhalf, zint)[None, :]).ravel() if zromb else self.freq.copy()
         self.w = ctx.to_device(skysim.romberg_weights(zromb))
         cplan = model._clarray_plan(model.angular_powerspectrum)
+        if cplan is None:
+            raise NotImplementedError(
+                "SkyShard needs a model whose angular_powerspectrum is the library's table (21cm) or separable "
+                "(ForegroundSCK) form; %s overrides it - integrate C_l with skysim.clarray_device and use "
+                "skysim.mkfullsky_device(nu_range=...) instead" % type(model).__name__)
         nshard = max(world, self.emulate_world, 1)
         self.pair_sharded = (cplan["kind"] == "table21cm" and (self.distributed or self.emulate_world > 1)
                              and F % nshard == 0)

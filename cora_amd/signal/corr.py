@@ -244,7 +244,11 @@ class RedshiftCorrelation(object):
         return dict(kind="table21cm", prepare=prepare)
 
     def _clarray_plan(self, aps):
-        """Protocol used by ``skysim.clarray`` to recognise the table model."""
+        """Protocol used by ``skysim.clarray`` to recognise the table model: only the un-overridden flat-sky
+        method qualifies (``angular_powerspectrum`` is an alias of it); any other bound method - a subclass
+        override, ``angular_powerspectrum_full``, ... - goes down the generic host-callable path."""
+        if getattr(aps, "__func__", None) is not RedshiftCorrelation.angular_powerspectrum_fft:
+            return None
         return self._table_plan(lambda z: z)
 
     # ---- the aps callable ------------------------------------------------------------------

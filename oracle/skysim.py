@@ -15,9 +15,13 @@ import scipy.linalg as la
 from . import healpix, sht
 
 
-def clarray(aps, lmax, zarray, zromb=3, zwidth=None):
-    """skysim.py:10-69."""
+def clarray(aps, lmax, zarray, zromb=3, zwidth=None, rows=None):
+    """skysim.py:10-69.  ``rows`` (checker convenience, not in the reference): evaluate only these multipoles
+    (each l is independent in the reference's loop) and return ``[len(rows), F, F]``, the first channel axis
+    processed in blocks so that F = 1024, zromb = 3 fits in memory."""
     zarray = np.asarray(zarray, dtype=np.float64)
+    if rows is not None:
+        return _clarray_rows(aps, np.asarray(rows), zarray, zromb, zwidth)
     if zromb == 0:
         return aps(np.arange(lmax + 1)[:, np.newaxis, np.newaxis], zarray[np.newaxis, :, np.newaxis],
                    zarray[np.newaxis, np.newaxis, :])
@@ -35,6 +39,29 @@ def clarray(aps, lmax, zarray, zromb=3, zwidth=None):
         clt = si.romb(clt, dx=zspace, axis=4)
         clt = si.romb(clt, dx=zspace, axis=2)
         cla[lsec] = clt / (2 * zhalf) ** 2
+    return cla
+
+
+def _clarray_rows(aps, rows, zarray, zromb, zwidth, block=32):
+    """The body of clarray's l-section loop (skysim.py:56-67) for the multipoles ``rows`` only."""
+    lcol = rows.astype(np.int64)[:, np.newaxis, np.newaxis]
+    if zromb == 0:
+        return aps(lcol, zarray[np.newaxis, :, np.newaxis], zarray[np.newaxis, np.newaxis, :])
+    zsort = np.sort(zarray)
+    zhalf = np.abs(zsort[1] - zsort[0]) / 2.0 if zwidth is None else zwidth / 2.0
+    zlen = zarray.size
+    zint = 2**zromb + 1
+    zspace = 2.0 * zhalf / 2**zromb
+    za = (zarray[:, np.newaxis] + np.linspace(-zhalf, zhalf, zint)[np.newaxis, :]).flatten()
+    cla = np.zeros((len(rows), zlen, zlen), dtype=np.float64)
+    for i0 in range(0, zlen, block):
+        i1 = min(zlen, i0 + block)
+        zb = za[i0 * zint : i1 * zint]
+        clt = aps(lcol, zb[np.newaxis, :, np.newaxis], za[np.newaxis, np.newaxis, :])
+        clt = clt.reshape(-1, i1 - i0, zint, zlen, zint)
+        clt = si.romb(clt, dx=zspace, axis=4)
+        clt = si.romb(clt, dx=zspace, axis=2)
+        cla[:, i0:i1] = clt / (2 * zhalf) ** 2
     return cla
 
 

@@ -1,0 +1,285 @@
+"""Pixel- and element-level parity of the HIP path against the CPU oracle AT BASELINE SIZES (cfg 3: nside 1024,
+lmax 2048, 256 channels; cfg 5: nside 2048, lmax 4096, F = 1024).  The small-size tests of test_gpu_parity.py never
+reach the transform classes that carry these configurations (ring-FFT Bluestein lengths 2048 / 4096 / 8192, two
+channels or one channel per workgroup, the F = 256 / 1024 tiles of K1 - K3); the tests here compare them
+directly with the oracle on a few channels / multipoles of a full-size launch.  Run with -m gpu.
+
+Reference code the compared quantities come from: cora/util/hputil.py:369-391,500-531 (alm2map),
+cora/util/hputil.py:195-234 (map2alm), cora/core/skysim.py:41-67 (clarray), :114-121 (factor + draw).
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _ring_classes(nside):
+    """K5 transform class of every ring (0-based, north to south): 0 = direct power-of-two transform (belt and
+    the cap rings with 4i a power of two), else the Bluestein length (next power of two >= 2 h - 1, h = 2 i)."""
+    nring = 4 * nside - 1
+    cls = np.zeros(nring, dtype=np.int64)
+    for r in range(nring):
+        i = r + 1
+        icap = i if i < nside else (4 * nside - i if i > 3 * nside else 0)
+        if icap:
+            h = 2 * icap
+            if h & (h - 1):
+                P = 1
+                while P < 2 * h - 1:
+                    P *= 2
+                cls[r] = P
+    return cls
+
+
+def _per_class_error(dev_map, ref, nside, skip_polar=0):
+    """max |dev - ref| / rms(ref) per ring-FFT class -> dict {class: err}."""
+    from oracle import healpix
+
+    ri = healpix.ring_info(nside)
+    cls = _ring_classes(nside)
+    rms = ref.std()
+    d = np.abs(dev_map - ref)
+    out = {}
+    start, nphi = ri["start"], ri["nphi"]
+    ring_max = np.maximum.reduceat(d, start.astype(np.int64))
+    assert len(ring_max) == len(cls) and int(start[-1] + nphi[-1]) == d.size
+    if skip_polar:
+        # rings i <= skip_polar of both caps are reported under the key "polar" instead of their class
+        nring = len(cls)
+        i_cap = np.minimum(np.arange(nring) + 1, nring - np.arange(nring))
+        polar = i_cap <= skip_polar
+        out["polar"] = float(ring_max[polar].max() / rms)
+        cls = np.where(polar, -1, cls)
+    for c in np.unique(cls):
+        if c >= 0:
+            out[int(c)] = float(ring_max[cls == c].max() / rms)
+    return out
+
+
+def _packed_of(alm_dev, f):
+    """Channel f of an alm_dev tensor [nalm, G, 2, 4] as a packed complex128 numpy vector."""
+    g, v = divmod(f, 4)
+    return alm_dev[:, g, 0, v].cpu().numpy() + 1j * alm_dev[:, g, 1, v].cpu().numpy()
+
+
+def _red_alm(ctx, nalm_shape, lmax, seed):
+    import torch
+
+    L = lmax + 1
+    gen = torch.Generator(device=ctx.device).manual_seed(seed)
+    idx_l = torch.cat([torch.arange(m, L, device=ctx.device) for m in range(L)])
+    amp = 1.0 / (1.0 + idx_l.double())
+    a = torch.randn(nalm_shape, generator=gen, device=ctx.device, dtype=torch.float64)
+    return a * amp[:, None, None, None]
+
+
+# ------------------------------------------------------------------ a10: synthesis, cfg 3
+def test_cfg3_alm2map_pixel_parity_256_channel_launch(ctx):
+    """configs[2] geometry, ONE launch of all 256 channels; four channels (first, last, and lanes 1 / 2 of an
+    interior cell: both halves of the two-channel workgroups of the P = 4096 class) against the C/OpenMP oracle,
+    pixel by pixel, with the error reported per ring-FFT class."""
+    import torch
+    from oracle import sht
+
+    nside, lmax, F = 1024, 2048, 256
+    nalm = (lmax + 1) * (lmax + 2) // 2
+    alm = _red_alm(ctx, (nalm, F // 4, 2, 4), lmax, 31)
+    maps = ctx.alm2map(alm, nside, lmax, F)
+    worst = {}
+    for f in (0, 129, 130, 255):
+        ref = sht.alm2map(_packed_of(alm, f), nside, lmax)
+        err = _per_class_error(maps[f].cpu().numpy(), ref, nside)
+        for c, e in err.items():
+            worst[c] = max(worst.get(c, 0.0), e)
+    del maps, alm
+    torch.cuda.empty_cache()
+    print("cfg3 alm2map max|err|/rms per class (0 = direct, else Bluestein P):", worst)
+    assert set(worst) >= {0, 2048, 4096}, worst
+    assert max(worst.values()) <= 1e-11, worst
+
+
+def test_cfg5_alm2map_pixel_parity(ctx):
+    """configs[4] geometry (nside 2048, lmax 4096): an 8-channel launch, channels 0 and 5 against the oracle pixel
+    by pixel; classes here: belt h = 4096 (two channels per workgroup), Bluestein P = 8192 (one channel)."""
+    import torch
+    from oracle import sht
+
+    nside, lmax, nnu = 2048, 4096, 8
+    nalm = (lmax + 1) * (lmax + 2) // 2
+    alm = _red_alm(ctx, (nalm, 2, 2, 4), lmax, 32)
+    maps = ctx.alm2map(alm, nside, lmax, nnu)
+    worst = {}
+    for f in (0, 5):
+        ref = sht.alm2map(_packed_of(alm, f), nside, lmax)
+        for c, e in _per_class_error(maps[f].cpu().numpy(), ref, nside).items():
+            worst[c] = max(worst.get(c, 0.0), e)
+    del maps, alm
+    torch.cuda.empty_cache()
+    print("cfg5 alm2map max|err|/rms per class:", worst)
+    assert set(worst) >= {0, 4096, 8192}, worst
+    # l^2 eps growth of the fp64 three-term recurrence: 4x the cfg-3 bound at lmax = 4096
+    assert max(worst.values()) <= 4e-11, worst
+
+
+# ------------------------------------------------------------------ n1: analysis, cfg-3 geometry
+def test_cfg3_map2alm_quadrature_pass_vs_oracle(ctx):
+    """One unweighted quadrature pass (K5^T + K4^T) of 8 white-noise maps at nside 1024 / lmax 2048; channels 0
+    and 5 against oracle.sht.map2alm_adjoint element by element."""
+    import torch
+    from cora_amd.util import hputil
+    from oracle import sht
+
+    nside, lmax, nnu = 1024, 2048, 8
+    npix = 12 * nside * nside
+    gen = torch.Generator(device=ctx.device).manual_seed(33)
+    x = torch.randn((nnu, npix), generator=gen, device=ctx.device, dtype=torch.float64)
+    alm = ctx.map2alm(x, nside, lmax, None)
+    got = ctx.alm_dev_to_square(alm, lmax, nnu)
+    for k in (0, 5):
+        ref = hputil.unpack_alm(sht.map2alm_adjoint(x[k].cpu().numpy(), nside, lmax, None), lmax)
+        err = np.abs(got[k, 0].cpu().numpy() - ref).max() / np.abs(ref).max()
+        print("cfg3 map2alm channel", k, "max|err|/max|ref| =", err)
+        assert err <= 1e-12, (k, err)
+    del x, alm, got
+    torch.cuda.empty_cache()
+
+
+# ------------------------------------------------------------------ n4: spin-2 synthesis, cfg-3 geometry
+def test_cfg3_alm2map_spin2_pixel_parity(ctx):
+    """(E, B) -> (Q, U) at nside 1024 / lmax 2048, four frequencies (8 interleaved channels); the first and last
+    (Q, U) pair against the oracle pixel by pixel, per ring-FFT class."""
+    import torch
+    from oracle import sht
+
+    nside, lmax, nf = 1024, 2048, 4
+    L = lmax + 1
+    nalm = L * (L + 1) // 2
+    alm = _red_alm(ctx, (nalm, 2, 2, 4), lmax, 34)
+    alm[:L, :, 1, :] = 0.0                      # Im a_l0 = 0
+    l_of = torch.cat([torch.arange(m, L, device=ctx.device) for m in range(L)])
+    alm[l_of < 2] = 0.0                         # spin-2: l >= 2
+    maps = ctx.alm2map_spin2(alm, nside, lmax, 2 * nf)
+    worst = {}
+    for f in (0, nf - 1):
+        q, u = sht.alm2map_spin2(_packed_of(alm, 2 * f), _packed_of(alm, 2 * f + 1), nside, lmax)
+        for name, ref, dev in (("Q", q, maps[2 * f]), ("U", u, maps[2 * f + 1])):
+            for c, e in _per_class_error(dev.cpu().numpy(), ref, nside, skip_polar=8).items():
+                worst[c] = max(worst.get(c, 0.0), e)
+    del maps, alm
+    torch.cuda.empty_cache()
+    print("cfg3 spin-2 max|err|/rms per class:", worst)
+    # the spin-2 operands carry r1 = 1/sin^2(theta), r2 = cos/sin^2 (1.5e6 on the first ring of nside 1024): W and X
+    # are differences of terms that large, so the rounding of the scalar recurrence (l^2 eps) is amplified on the
+    # few rings next to the poles - in the oracle as much as on the device, with a different operation order
+    polar = worst.pop("polar")
+    assert polar <= 1e-9, polar
+    assert max(worst.values()) <= 1e-11, worst
+
+
+# ------------------------------------------------------------------ a1/a2/a3: C_l rows at F = 256 and F = 1024
+def _freqs(F):
+    return 400.0 + (np.arange(F) + 0.5) * (400.0 / F)
+
+
+def test_cfg3_clarray_rows_vs_oracle(model21):
+    """K1 at configs[2] size (F = 256, zromb 3, lmax 2048: the F = 256 tile mirroring, the l = 2048 table rows):
+    multipoles 0, 1, 2, 700, 2048 of the full launch against oracle.skysim.clarray, element by element."""
+    import torch
+    from cora_amd.core import skysim
+    from cora_amd.signal import corr21cm
+    from oracle import skysim as osk
+
+    F, lmax = 256, 2048
+    rows = [0, 1, 2, 700, 2048]
+    freq = _freqs(F)
+    C = skysim.clarray_device(corr21cm.Corr21cm().angular_powerspectrum, lmax, freq, zromb=3)
+    got = C[rows].cpu().numpy()
+    sym = (C - C.transpose(1, 2)).abs().max().item()
+    del C
+    torch.cuda.empty_cache()
+    ref = osk.clarray(model21.angular_powerspectrum, lmax, freq, zromb=3, rows=rows)
+    for k, l in enumerate(rows):
+        err = np.abs(got[k] - ref[k]).max() / np.abs(ref[k]).max()
+        print("cfg3 C_l row", l, "max|err|/max =", err)
+        assert err <= 1e-11, (l, err)
+    assert sym == 0.0
+
+
+@pytest.fixture(scope="module")
+def cfg5_cl(ctx):
+    """C_l of configs[4] (F = 1024, lmax 4096, zromb 3; 34.4 GB) integrated once on the device."""
+    import torch
+    from cora_amd.core import skysim
+    from cora_amd.signal import corr21cm
+
+    F, lmax = 1024, 4096
+    C = skysim.clarray_device(corr21cm.Corr21cm().angular_powerspectrum, lmax, _freqs(F), zromb=3)
+    yield C
+    del C
+    torch.cuda.empty_cache()
+
+
+def test_cfg5_clarray_rows_vs_oracle(cfg5_cl, model21):
+    """K1 at configs[4] size: multipoles 1 and 4096 of the F = 1024 launch against the oracle."""
+    from oracle import skysim as osk
+
+    rows = [1, 4096]
+    got = cfg5_cl[rows].cpu().numpy()
+    ref = osk.clarray(model21.angular_powerspectrum, 4096, _freqs(1024), zromb=3, rows=rows)
+    for k, l in enumerate(rows):
+        err = np.abs(got[k] - ref[k]).max() / np.abs(ref[k]).max()
+        print("cfg5 C_l row", l, "max|err|/max =", err)
+        assert err <= 1e-11, (l, err)
+        assert np.array_equal(got[k], got[k].T)
+
+
+def test_cfg5_factor_and_draw_F1024_vs_numpy(ctx, cfg5_cl):
+    """K2 + K3 at F = 1024 (1024 x 1024 Cholesky, 8 column groups in the draw): eight covariance blocks of the
+    configs[4] C_l are factored and drawn from as the l = 0..7 blocks of an lmax = 7 problem and compared with
+    numpy (scipy Cholesky of the jittered block, T g / sqrt 2 with the reference's normal order)."""
+    import scipy.linalg as la
+    import torch
+
+    F = 1024
+    ls = [1, 2, 100, 1000, 2048, 3000, 4000, 4096]
+    Csub = cfg5_cl[ls].contiguous()
+    T, info = ctx.factor_batched(Csub)                       # jitter 1e-14 max(diag) as skysim.py:116-117
+    assert int(info.abs().sum().item()) == 0
+    Th, Ch = T.cpu().numpy(), Csub.cpu().numpy()
+    lmax = len(ls) - 1
+    for k in range(len(ls)):
+        Cj = Ch[k] + np.eye(F) * Ch[k].diagonal().max() * 1e-14
+        ref = la.cholesky(Cj, lower=True)
+        err = np.abs(Th[k] - ref).max() / np.abs(ref).max()
+        res = np.abs(Th[k] @ Th[k].T - Cj).max() / np.abs(Cj).max()
+        print("F=1024 block l=%d: |T - chol|/max = %.2e, |T T^T - C|/max = %.2e" % (ls[k], err, res))
+        assert np.all(np.triu(Th[k], 1) == 0)
+        assert res <= 1e-13, (ls[k], res)
+        assert err <= 1e-9, (ls[k], err)                      # cond(C) ~ 1e3..1e5 at 0.39 MHz channels
+    rng = np.random.default_rng(1024)
+    nalm = (lmax + 1) * (lmax + 2) // 2
+    g = np.empty(2 * F * nalm)
+    o = 0
+    blocks = []
+    for l in range(lmax + 1):
+        re = rng.standard_normal((F, l + 1))
+        im = rng.standard_normal((F, l + 1))
+        blocks.append((re + 1j * im) / 2**0.5)
+        n = F * (l + 1)
+        g[o : o + n] = re.ravel()
+        g[o + n : o + 2 * n] = im.ravel()
+        o += 2 * n
+    alm = ctx.draw_alm(T, info, ctx.to_device(g), lmax, F)
+    sq = ctx.alm_dev_to_square(alm, lmax, F).cpu().numpy()
+    for l in range(lmax + 1):
+        ref = Th[l] @ blocks[l]
+        err = np.abs(sq[:, 0, l, : l + 1] - ref).max() / np.abs(ref).max()
+        assert err <= 1e-12, (l, err)
+    # the fused-RNG kernel on the same factors: equal to the materialised Philox stream
+    gp = ctx.normals_philox(77, lmax, F)
+    a = ctx.alm_dev_to_square(ctx.draw_alm(T, info, gp, lmax, F), lmax, F)
+    b = ctx.alm_dev_to_square(ctx.draw_alm_philox(T, info, 77, lmax, F), lmax, F)
+    assert (a - b).abs().max().item() <= 1e-13 * a.abs().max().item()
+    # and a frequency shard of it (the 128 channels one of eight ranks owns)
+    c = ctx.alm_dev_to_square(ctx.draw_alm_philox(T, info, 77, lmax, F, nu0=640, nnu=128), lmax, 128)
+    assert torch.equal(c, b[640:768])
