@@ -32,11 +32,18 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 WORKLOADS = {
-    # name: (model, F, nu_lower, nu_upper, nside, lmax, zromb)
-    "cfg3": ("21cm", 256, 400.0, 800.0, 1024, 2048, 3),
-    "cfg2": ("synchrotron", 32, 400.0, 800.0, 256, 512, 3),
-    "tiny": ("21cm", 16, 600.0, 625.0, 64, 128, 1),
+    # name: (components [(model, zromb)], F, nu_lower, nu_upper, nside, lmax)
+    "cfg3": ([("21cm", 3)], 256, 400.0, 800.0, 1024, 2048),
+    "cfg2": ([("synchrotron", 3)], 32, 400.0, 800.0, 256, 512),
+    # BASELINE configs[3]: three independent Gaussian components summed on one 512-channel grid
+    "cfg4": ([("21cm", 3), ("synchrotron", 0), ("pointsource", 0)], 512, 400.0, 800.0, 1024, 2048),
+    # BASELINE configs[4]: 412 GB of maps - an 8-GPU configuration; with fewer ranks the work of ONE of eight
+    # ranks is timed (--emulate-shard 8 is implied) and the line says so
+    "cfg5": ([("21cm", 3)], 1024, 400.0, 800.0, 2048, 4096),
+    "tiny": ([("21cm", 1)], 16, 600.0, 625.0, 64, 128),
+    "tiny3": ([("21cm", 1), ("synchrotron", 0), ("pointsource", 0)], 16, 600.0, 625.0, 64, 128),
 }
+MIN_RANKS = {"cfg5": 8}        # workloads that do not fit fewer GPUs: emulate one rank's share instead
 
 FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X vendor spec; profiles/mfma_f64_probe_r01.txt measures 77.4
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md
@@ -47,9 +54,34 @@ def build_model(name):
         from cora_amd.signal import corr21cm
 
         return corr21cm.Corr21cm()
+    if name == "pointsource":
+        from cora_amd.foreground import pointsource
+
+        return pointsource.CombinedPointSources._UnresolvedBackground()
     from cora_amd.foreground import galaxy
 
     return galaxy.FullSkySynchrotron()
+
+
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` from a plain shell: start the N ranks as a CHILD torch.distributed.run job - before
+    this process has imported torch or touched HIP (a process that initialised the GPU must never exec another
+    program) - relay rank 0's JSON line and return the child's exit code."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE)
+    line = [ln for ln in p.stdout.decode(errors="replace").splitlines() if ln.startswith("{")]
+    if line:
+        print(line[-1], flush=True)
+    return p.returncode if p.returncode or line else 1
 
 
 def main():
@@ -67,6 +99,9 @@ def main():
     ap.add_argument("--force-dist", action="store_true", help="take the multi-rank code path (process group, exchanges) even with 1 rank")
     ap.add_argument("--emulate-shard", type=int, default=0, help="time the work of the LAST rank of an N-rank job, no comm")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
 
     # stdout carries exactly ONE line (the JSON): native libraries print banners there (RCCL's version block
     # at communicator creation), so fd 1 is pointed at stderr for the run and the result goes to the saved fd
@@ -100,20 +135,30 @@ def main():
         else:
             dist.init_process_group(args.dist_backend)
 
-    model_name, F, nu_lo, nu_hi, nside, lmax, zromb = WORKLOADS[args.workload]
+    comps, F, nu_lo, nu_hi, nside, lmax = WORKLOADS[args.workload]
+    model_name = "+".join(c[0] for c in comps)
+    zromb = comps[0][1]
     L = lmax + 1
     nalm = L * (L + 1) // 2
     npix = 12 * nside * nside
-    from cora_amd.parallel import SkyShard
+    from cora_amd.parallel import SkyShard, SkySum
 
+    ranks_seen = dist.get_world_size() if dist is not None else 1
+    if world < MIN_RANKS.get(args.workload, 1) and args.emulate_shard <= 1:
+        if world != 1:
+            raise SystemExit("%s needs %d ranks (or 1 rank emulating one of them)" % (args.workload, MIN_RANKS[args.workload]))
+        args.emulate_shard = MIN_RANKS[args.workload]
     ctx = _lib.get_context(local_rank)
-    model = build_model(model_name)
     freq = nu_lo + (np.arange(F) + 0.5) * ((nu_hi - nu_lo) / F)
 
     # ---- untimed setup: everything the timed region reads is put in HBM (tables, plan, buffers) ----------
     t_setup = time.time()
-    shard = SkyShard(model, freq, nside, lmax, zromb=zromb, rank=rank, world=world, ctx=ctx, distributed=multi,
-                     emulate_world=args.emulate_shard)
+    if len(comps) == 1:
+        shard = SkyShard(build_model(comps[0][0]), freq, nside, lmax, zromb=zromb, rank=rank, world=world, ctx=ctx,
+                         distributed=multi, emulate_world=args.emulate_shard)
+    else:
+        shard = SkySum([(build_model(m), z) for m, z in comps], freq, nside, lmax, rank=rank, world=world, ctx=ctx,
+                       distributed=multi, emulate_world=args.emulate_shard)
     nnu, nu0 = shard.nnu, shard.nu0
     maps_buf = shard.maps_buf
     torch.cuda.synchronize()
@@ -195,7 +240,9 @@ def main():
     result = None
     if rank == 0:
         ms_step = dt / args.steps * 1e3
-        value = F * args.steps / dt
+        emu = args.emulate_shard if args.emulate_shard > 1 else 0
+        # emulated shard: only the nnu maps of that one rank were made
+        value = (nnu if emu else F) * args.steps / dt
         # dominant kernel: K4 Legendre contraction, FP64 MFMA bound
         leg = stages.get("legendre", {"ms_per_launch": float("nan")})
         flops_leg = 8.0 * nside * nalm * nnu          # per launch, SURVEY 8(d) / DESIGN.md
@@ -203,17 +250,21 @@ def main():
         alg_bytes = 8.0 * npix * nnu + 32.0 * nalm * nnu + 8.0 * L * F * F   # warm path, SURVEY 8(d)
         # HBM bytes of the dominant kernel from the PMC passes of the same command (collected separately
         # with rocprofv3 --pmc and committed under profiles/; bench.py cannot read counters itself)
-        traffic = None
-        pmc_file = os.path.join(ROOT, "profiles", "r01_k4_pmc.json")
-        if os.path.exists(pmc_file) and world == 1:
-            pmc = json.load(open(pmc_file))
-            if pmc.get("workload") == args.workload:
-                traffic = pmc["traffic_bytes_per_launch"]
+        traffic = traffic_source = None
+        for pmc_name in ("r02_k4_pmc.json", "r01_k4_pmc.json"):
+            pmc_file = os.path.join(ROOT, "profiles", pmc_name)
+            if os.path.exists(pmc_file) and world == 1 and not emu:
+                pmc = json.load(open(pmc_file))
+                if pmc.get("workload") == args.workload:
+                    traffic = pmc["traffic_bytes_per_launch"]
+                    traffic_source = "profiles/" + pmc_name + " (rocprofv3 --pmc passes of this command, not measured in this run)"
+                    break
         result = {
             "metric": "sky-maps/sec (nside=%d, lmax=%d, %d freq)" % (nside, lmax, F),
             "value": value,
             "unit": "maps/s",
             "n_gpus": world,
+            "ranks_seen": ranks_seen,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": ms_step,
@@ -223,9 +274,11 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": "%s: %s, %d channels %g-%g MHz, nside=%d, lmax=%d, zromb=%d, %s path, device Philox normals"
-                            % (args.workload, model_name, F, nu_lo, nu_hi, nside, lmax, zromb,
-                               "warm (cached factors)" if args.warm else "cold (C_l integration + factor + draw + synthesis)"),
+                "workload": "%s: %s, %d channels %g-%g MHz, nside=%d, lmax=%d, zromb=%s, %s path, device Philox normals%s"
+                            % (args.workload, model_name, F, nu_lo, nu_hi, nside, lmax, "/".join(str(c[1]) for c in comps),
+                               "warm (cached factors)" if args.warm else "cold (C_l integration + factor + draw + synthesis)",
+                               (" - ONE GPU doing the share of the most loaded of %d ranks (%d channels, no exchanges): "
+                                "value counts those maps only" % (emu, nnu)) if emu else ""),
                 "parallelism": "freq-shard x%d (pair-sharded C_l -> all-to-all -> l-sharded factor -> all-to-all of factor row blocks)" % world if world > 1 else "single GPU",
                 "realisations_per_s": args.steps / dt,
                 "warm_path": None if warm_ms is None else {"ms_per_step": warm_ms, "maps_per_s": F / (warm_ms * 1e-3)},
@@ -240,6 +293,7 @@ def main():
                 "unit": "TFLOP/s",
                 "frac": ach / FP64_MFMA_PEAK_TFLOPS,
                 "traffic": traffic,
+                "traffic_source": traffic_source,
                 "algorithmic_bytes": 16.0 * nalm * nnu + 16.0 * (4 * nside - 1) * L * nnu,
             },
             "hbm_roofline_whole_step": {
@@ -249,7 +303,7 @@ def main():
                 "frac": alg_bytes / 1e9 / (ms_step * 1e-3) / HBM_PEAK_GBS,
             },
         }
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and len(comps) == 1 and not emu:
             result["cpu_baseline"] = cpu_baseline(model_name, F, freq, nside, lmax, zromb)
             result["config"]["gpu_over_cpu"] = value / result["cpu_baseline"]["value"]
         os.write(json_fd, (json.dumps(result) + "\n").encode())

@@ -11,8 +11,7 @@ HIP kernels behind ``libcorahip.so``:
                K4  ring-pair Legendre contraction on FP64 MFMA
                K5  per-ring alias fold + FFT, RING-ordered pixels
 
-``mkconstrained`` (cora/core/skysim.py:139-201) needs the adjoint transform and is out of
-scope of this package.
+``mkconstrained`` (cora/core/skysim.py:139-201) is built on the analysis kernels (K5^T, K4^T).
 """
 import numpy as np
 import scipy.integrate as si
@@ -190,9 +189,23 @@ def mkfullsky(corr, nside, alms=False, rng=None):
     hpmaps : np.ndarray (numz, npix)
     """
     local = getattr(corr, "local_array", None)
-    if local is not None:  # caput MPIArray: only the single-rank case is supported here
-        if tuple(getattr(corr, "global_shape", local.shape)) != tuple(local.shape):
-            raise NotImplementedError("l-distributed MPIArray input: use cora_amd.parallel.mkfullsky_sharded")
+    if local is not None:  # caput MPIArray (skysim.py:97-103)
+        gshape = tuple(getattr(corr, "global_shape", local.shape))
+        if gshape != tuple(local.shape):
+            # l-distributed input: one process per GPU with torch.distributed initialised (the ranks of the MPI
+            # job); returns the rank's frequency shard, wrapped like the reference's return value (:132-134)
+            import torch.distributed as dist
+
+            if not (dist.is_available() and dist.is_initialized()):
+                raise NotImplementedError(
+                    "l-distributed MPIArray input needs an initialised torch.distributed process group "
+                    "(one process per GPU): see cora_amd.parallel.mkfullsky_sharded")
+            from .. import parallel
+
+            out, _ = parallel.mkfullsky_sharded(np.asarray(local), gshape, nside, rng=rng, alms=alms)
+            out = out.cpu().numpy()
+            wrap = getattr(type(corr), "wrap", None)
+            return wrap(out, axis=0) if wrap is not None else out
         corr = np.asarray(local)
     corr = np.asarray(corr, dtype=np.float64)
     if corr.shape[2] != corr.shape[1]:

@@ -124,7 +124,8 @@ class SkyShard:
         K2: rank 0's multipoles, K3-K5: the last channel shard, factors replaced by a random SPD stack).
     """
 
-    def __init__(self, model, freq, nside, lmax, zromb=3, rank=0, world=1, ctx=None, distributed=None, emulate_world=0):
+    def __init__(self, model, freq, nside, lmax, zromb=3, rank=0, world=1, ctx=None, distributed=None, emulate_world=0,
+                 alm_buf=None, maps_buf=None):
         import numpy as np
 
         from . import _lib
@@ -176,18 +177,28 @@ class SkyShard:
         nalm = L * (L + 1) // 2
         self.npix = 12 * self.nside * self.nside
         ctx.sht_plan(self.nside, self.lmax)
-        self.alm_buf = ctx.empty((nalm, (self.nnu + 3) // 4, 2, 4))
-        self.maps_buf = ctx.empty((self.nnu, self.npix))
+        # (a SkySum hands its components one shared pair of buffers)
+        self.alm_buf = alm_buf if alm_buf is not None else ctx.empty((nalm, (self.nnu + 3) // 4, 2, 4))
+        self.maps_buf = maps_buf if maps_buf is not None else ctx.empty((self.nnu, self.npix))
         ctx.workspace(ctx.alm2map_workspace_bytes(ctx.sht_plan(self.nside, self.lmax), self.nnu))
         self._emulated = None
         if self.emulate_world > 1:
             import torch
 
-            Cf = ctx.empty((L, F, F)).normal_()
-            Cf = Cf @ Cf.transpose(1, 2) + 0.1 * torch.eye(F, device=ctx.device, dtype=torch.float64)
-            Tf, inf = ctx.factor_batched(Cf)
-            self._emulated = ((Tf[:, self.nu0:self.nu0 + self.nnu, :].contiguous(), inf, True) if self.pair_sharded
-                              else (Tf, inf, False))
+            # stand-in factors of the right shape and structure (Cholesky factors of random SPD blocks), built in
+            # l-chunks so that F = 1024, L = 4097 (cfg 5) never holds more than one chunk of [*, F, F] temporaries
+            rows = self.pair_sharded
+            Tf = ctx.empty((L, self.nnu, F) if rows else (L, F, F))
+            inf = torch.empty((L,), dtype=torch.int32, device=ctx.device)
+            eye = 0.1 * torch.eye(F, device=ctx.device, dtype=torch.float64)
+            lc = max(1, min(L, (1 << 28) // (F * F)))
+            for l0 in range(0, L, lc):
+                Cc = ctx.empty((min(lc, L - l0), F, F)).normal_()
+                Tc, ic = ctx.factor_batched(Cc @ Cc.transpose(1, 2) + eye)
+                Tf[l0:l0 + Tc.shape[0]].copy_(Tc[:, self.nu0:self.nu0 + self.nnu, :] if rows else Tc)
+                inf[l0:l0 + Tc.shape[0]].copy_(ic)
+                del Cc, Tc, ic
+            self._emulated = (Tf, inf, rows)
 
     # -- K1 in its two shardings -----------------------------------------------------------
     def _clarray_local(self):
@@ -225,15 +236,70 @@ class SkyShard:
         Ta, ia = allgather_factors(T, info, sp)
         return Ta, ia, False
 
-    def realise(self, seed, factors=None):
-        """Maps ``[nnu, npix]`` (device tensor, reused between calls) of this rank's channels for ``seed``."""
+    def draw(self, seed, factors=None, out=None):
+        """a_lm of this rank's channels for ``seed`` (K3, device Philox stream) into ``out`` (default: the shard's
+        own a_lm buffer)."""
         ctx = self.ctx
+        out = self.alm_buf if out is None else out
         T, info, rows = factors if factors is not None else self.factors()
         if rows:
-            ctx.draw_alm_philox_rows(T, info, seed, self.lmax, self.F, self.nu0, self.nnu, out=self.alm_buf)
-        else:
-            ctx.draw_alm_philox(T, info, seed, self.lmax, self.F, nu0=self.nu0, nnu=self.nnu, out=self.alm_buf)
-        return ctx.alm2map(self.alm_buf, self.nside, self.lmax, self.nnu, out=self.maps_buf)
+            return ctx.draw_alm_philox_rows(T, info, seed, self.lmax, self.F, self.nu0, self.nnu, out=out)
+        return ctx.draw_alm_philox(T, info, seed, self.lmax, self.F, nu0=self.nu0, nnu=self.nnu, out=out)
+
+    def realise(self, seed, factors=None):
+        """Maps ``[nnu, npix]`` (device tensor, reused between calls) of this rank's channels for ``seed``."""
+        self.draw(seed, factors)
+        return self.ctx.alm2map(self.alm_buf, self.nside, self.lmax, self.nnu, out=self.maps_buf)
+
+
+class SkySum:
+    """Sum of independent Gaussian components on one channel grid - BASELINE configs[3]: 21cm (``Corr21cm``) +
+    galactic synchrotron (``FullSkySynchrotron``, cora/foreground/galaxy.py:20-27) + unresolved point sources
+    (``_UnresolvedBackground``, cora/foreground/pointsource.py:541-546).  The reference would make one
+    ``getsky()`` per component and add the maps; the synthesis is linear, so the a_lm of the components are
+    added instead and K4 + K5 (9/10 of a realisation) run ONCE per realisation.  Sharding, exchanges and the
+    ``factors()`` / ``realise(seed)`` protocol are those of :class:`SkyShard`, per component.
+
+    components : sequence of ``(model, zromb)``
+    """
+
+    _SEED_STRIDE = 0x9E3779B97F4A7C15      # component k draws with seed + k * stride (mod 2^64): disjoint Philox keys
+
+    def __init__(self, components, freq, nside, lmax, rank=0, world=1, ctx=None, distributed=None, emulate_world=0):
+        from . import _lib
+
+        self.ctx = ctx if ctx is not None else _lib.get_context()
+        self.shards = []
+        alm_buf = maps_buf = None
+        for model, zromb in components:
+            sh = SkyShard(model, freq, nside, lmax, zromb=zromb, rank=rank, world=world, ctx=self.ctx,
+                          distributed=distributed, emulate_world=emulate_world, alm_buf=alm_buf, maps_buf=maps_buf)
+            alm_buf, maps_buf = sh.alm_buf, sh.maps_buf
+            self.shards.append(sh)
+        s0 = self.shards[0]
+        self.alm_buf, self.maps_buf = alm_buf, maps_buf
+        self.nu0, self.nnu, self.F, self.nside, self.lmax, self.npix = s0.nu0, s0.nnu, s0.F, s0.nside, s0.lmax, s0.npix
+        self._tmp = self.ctx.empty(tuple(alm_buf.shape)) if len(self.shards) > 1 else None
+
+    def factors(self):
+        """Per-component factors (the cold part), in component order."""
+        return [sh.factors() for sh in self.shards]
+
+    def draw(self, seed, factors=None):
+        factors = factors if factors is not None else self.factors()
+        for k, (sh, fac) in enumerate(zip(self.shards, factors)):
+            sk = (int(seed) + k * self._SEED_STRIDE) & (2**64 - 1)
+            if k == 0:
+                sh.draw(sk, fac, out=self.alm_buf)
+            else:
+                sh.draw(sk, fac, out=self._tmp)
+                self.alm_buf.add_(self._tmp)
+        return self.alm_buf
+
+    def realise(self, seed, factors=None):
+        """Maps ``[nnu, npix]`` of the summed sky (device tensor, reused between calls)."""
+        self.draw(seed, factors)
+        return self.ctx.alm2map(self.alm_buf, self.nside, self.lmax, self.nnu, out=self.maps_buf)
 
 
 def getsky_shard(sky, seed, rank=0, world=1, lmax=None):
@@ -249,3 +315,83 @@ def getsky_shard(sky, seed, rank=0, world=1, lmax=None):
     freq = np.asarray(sky.nu_pixels, dtype=np.float64)[shard.nu0:shard.nu0 + shard.nnu]
     mean = shard.ctx.to_device(np.asarray(sky.mean_nu(freq), dtype=np.float64) * np.ones(shard.nnu))
     return maps + mean[:, None], shard.nu0
+
+
+def mkfullsky_sharded(corr_local, global_shape, nside, rng=None, alms=False, ctx=None):
+    """``skysim.mkfullsky`` for an l-DISTRIBUTED correlation array (cora/core/skysim.py:97-103,108-134: the reference
+    takes a caput ``MPIArray`` split over axis 0, draws its local multipoles, redistributes the a_lm over
+    frequency and returns ``MPIArray.wrap(sky, axis=0)``).
+
+    corr_local   : this rank's contiguous block of multipoles ``[n_local, F, F]`` (ndarray or device tensor); blocks
+                   are in rank order and cover ``global_shape[0]`` multipoles (caput's split or any other)
+    global_shape : ``(lmax + 1, F, F)``
+    rng          : ``DeviceRNG`` (same seed on every rank), a numpy ``Generator`` (identically seeded on every rank:
+                   every rank consumes the whole stream, so the result equals the single-process realisation of
+                   that seed - the reference's own multi-rank output is not a function of the seed alone, SURVEY
+                   App. B), or ``None`` (rank 0 draws a seed from numpy's legacy global state and broadcasts it)
+
+    Returns ``(out, nu0)``: the rank's channel shard - device maps ``[nnu, npix]`` or, with ``alms``,
+    ``[nnu, 1, L, L]`` complex - and its first channel (caput's axis-0 split of F).  Exchange: the factor ROW
+    blocks go by all-to-all when F divides evenly, else the factor stack is all-gathered; the a_lm are never
+    exchanged (every rank draws from the same global normal stream for its own channels).
+    """
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from . import _lib
+    from .core import skysim
+    from .util.nputil import DeviceRNG
+
+    ctx = ctx if ctx is not None else _lib.get_context()
+    world, rank = dist.get_world_size(), dist.get_rank()
+    L, F, F2 = (int(v) for v in global_shape)
+    if F2 != F:
+        raise Exception("Correlation matrix is incorrect shape.")
+    if not isinstance(corr_local, torch.Tensor):
+        corr_local = ctx.to_device(np.asarray(corr_local, dtype=np.float64))
+    n_local = int(corr_local.shape[0])
+    counts = [None] * world
+    dist.all_gather_object(counts, n_local)
+    if sum(counts) != L:
+        raise Exception("l blocks of the ranks do not add up to global_shape[0]")
+    lc = max(max(counts), 1)
+    sp = shard_plan(L, F, rank, world)
+    nu0, nnu = sp.nu0, sp.nnu
+    T_loc, i_loc = skysim.factor_device(corr_local) if n_local else (ctx.empty((0, F, F)), torch.empty(
+        (0,), dtype=torch.int32, device=ctx.device))
+    pad_T = torch.zeros((lc, F, F), dtype=torch.float64, device=ctx.device)
+    pad_i = torch.zeros((lc,), dtype=torch.int32, device=ctx.device)
+    pad_T[:n_local].copy_(T_loc)
+    pad_i[:n_local].copy_(i_loc)
+    i_all = torch.empty((world * lc,), dtype=torch.int32, device=ctx.device)
+    dist.all_gather_into_tensor(i_all, pad_i)
+    rows = F % world == 0
+    if rows:
+        send = pad_T.view(lc, world, nnu, F).permute(1, 0, 2, 3).contiguous()
+        recv = _all_to_all(send, world)                                   # [src, lc, nnu, F]
+    else:
+        recv = torch.empty((world * lc, F, F), dtype=torch.float64, device=ctx.device)
+        dist.all_gather_into_tensor(recv, pad_T)
+        recv = recv.view(world, lc, F, F)
+    T = torch.cat([recv[r, : counts[r]] for r in range(world)], dim=0).contiguous()
+    info = torch.cat([i_all[r * lc : r * lc + counts[r]] for r in range(world)]).contiguous()
+    lmax = L - 1
+    if rng is None:
+        box = [int(np.random.randint(0, 2**62)) if rank == 0 else 0]
+        dist.broadcast_object_list(box, src=0)
+        rng = DeviceRNG(box[0])
+    if isinstance(rng, DeviceRNG):
+        seed = rng.next_seed()
+        alm = (ctx.draw_alm_philox_rows(T, info, seed, lmax, F, nu0, nnu) if rows
+               else ctx.draw_alm_philox(T, info, seed, lmax, F, nu0=nu0, nnu=nnu))
+    else:
+        g = torch.from_numpy(skysim._host_normals(F, lmax, rng)).to(ctx.device)
+        if rows:   # the host-stream kernel takes full factors: embed the row block
+            Tf = torch.zeros((L, F, F), dtype=torch.float64, device=ctx.device)
+            Tf[:, nu0:nu0 + nnu, :] = T
+            T = Tf
+        alm = ctx.draw_alm(T, info, g, lmax, F, nu0=nu0, nnu=nnu)
+    if alms:
+        return ctx.alm_dev_to_square(alm, lmax, nnu), nu0
+    return ctx.alm2map(alm, int(nside), lmax, nnu), nu0

@@ -1,0 +1,56 @@
+"""Multi-rank paths on ONE GPU (ranks share cuda:0 and talk over gloo): bench.py's self-launching --gpus N, the
+three-component workload of BASELINE configs[3] through parallel.SkySum, and skysim.mkfullsky on an l-distributed
+MPIArray-like input (cora/core/skysim.py:97-134).  Run with -m gpu."""
+import json
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _plain_env():
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return env
+
+
+def _bench(args):
+    p = subprocess.run([sys.executable, "bench.py"] + args, cwd=ROOT, env=_plain_env(), capture_output=True, text=True,
+                       timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, p.stdout          # stdout carries exactly one line: the JSON
+    m = re.search(r"CHECKSUM (\w+)", p.stderr)
+    return json.loads(lines[0]), (m.group(1) if m else None)
+
+
+@pytest.mark.parametrize("workload", ["tiny", "tiny3"])
+def test_bench_launches_its_own_ranks(workload):
+    """`python bench.py --gpus 2` from a plain shell (no torch.distributed.run around it): the ranks are started as a
+    child job, one JSON line comes back, the process group really had 2 ranks, and the per-channel checksums of the
+    2-rank realisation equal the single-rank ones (tiny3: three summed components, parallel.SkySum)."""
+    common = ["--workload", workload, "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--checksum"]
+    one, c1 = _bench(common)
+    two, c2 = _bench(["--gpus", "2", "--dist-backend", "gloo", "--same-device"] + common)
+    assert one["n_gpus"] == 1 and one["ranks_seen"] == 1
+    assert two["n_gpus"] == 2 and two["ranks_seen"] == 2
+    assert c1 is not None and c1 == c2, (c1, c2)
+    assert two["value"] > 0 and two["metric"] == one["metric"]
+
+
+def test_mkfullsky_l_distributed_mpiarray():
+    """skysim.mkfullsky(MPIArray-like l-distributed corr): 2 and 3 ranks (uneven l blocks, F = 8 and 7) return the
+    frequency shards of the single-process realisation (DeviceRNG and identically seeded numpy Generators)."""
+    port = 29871
+    for n in (2, 3):
+        port += 1
+        p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+                            "--master-addr", "127.0.0.1", "--master-port", str(port),
+                            os.path.join("tests", "_mpiarray_worker.py")], cwd=ROOT, env=_plain_env(),
+                           capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0 and "MPIARRAY OK" in p.stderr, p.stderr[-3000:]

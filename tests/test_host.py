@@ -3,6 +3,7 @@ the C ABI library loads and exports every symbol of include/corahip.h."""
 import ctypes
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -318,3 +319,66 @@ def test_sinh_interpolater_matches_reference(golden):
     assert abs(sp(3.3) - float(sp(np.array([3.3]))[0])) < 1e-15
     kind, kx, ky, ky2, x_t, f_t = sp._device_spline()
     assert kind == 2 and x_t == 0.7 and f_t == 0.05 and kx.shape == ky.shape == ky2.shape == (12,)
+
+
+# ------------------------------------------------------------------ plan protocol / launcher (no GPU needed)
+def test_clarray_plan_only_for_unoverridden_methods():
+    """skysim.clarray takes the table / separable fast path only for the library's own aps methods: a subclass that
+    overrides angular_powerspectrum (or any other bound method) must fall through to the generic host-callable path
+    instead of being silently evaluated as the un-overridden model."""
+    from cora_amd.core import skysim
+    from cora_amd.foreground import galaxy
+    from cora_amd.signal import corr, corr21cm
+
+    class MyCorr(corr.RedshiftCorrelation):
+        def angular_powerspectrum(self, l, z1, z2):
+            return 2.0 * corr.RedshiftCorrelation.angular_powerspectrum_fft(self, l, z1, z2)
+
+    base = corr.RedshiftCorrelation.__new__(corr.RedshiftCorrelation)
+    sub = MyCorr.__new__(MyCorr)
+    assert skysim._plan_of(base.angular_powerspectrum)["kind"] == "table21cm"
+    assert skysim._plan_of(base.angular_powerspectrum_fft)["kind"] == "table21cm"
+    assert skysim._plan_of(sub.angular_powerspectrum) is None
+    assert skysim._plan_of(sub.angular_powerspectrum_fft)["kind"] == "table21cm"
+
+    class My21(corr21cm.Corr21cm):
+        def angular_powerspectrum(self, l, nu1, nu2):
+            return 0.0 * l
+
+    assert skysim._plan_of(My21.__new__(My21).angular_powerspectrum) is None
+
+    class MySync(galaxy.FullSkySynchrotron):
+        def angular_powerspectrum(self, l, nu1, nu2):
+            return 1.0 + 0.0 * l
+
+    assert skysim._plan_of(MySync().angular_powerspectrum) is None
+    assert skysim._plan_of(galaxy.FullSkySynchrotron().angular_powerspectrum)["kind"] == "separable"
+    assert skysim._plan_of(lambda l, a, b: l) is None
+
+
+def test_bench_self_launch_command(monkeypatch):
+    """bench.py --gpus N from a plain shell starts torch.distributed.run as a child (never an exec), hands the
+    arguments through and relays exactly the JSON line."""
+    import subprocess
+
+    sys.path.insert(0, ROOT)
+    import bench
+
+    seen = {}
+
+    class R:
+        returncode = 0
+        stdout = b"RCCL version banner\n{\"metric\": \"x\"}\n"
+
+    def fake(cmd, **kw):
+        seen["cmd"], seen["kw"] = cmd, kw
+        return R()
+
+    monkeypatch.setattr(subprocess, "run", fake)
+    assert bench.launch_ranks(4, ["--gpus", "4", "--steps", "2"]) == 0
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "4"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "4", "--steps", "2"]
+    assert seen["kw"]["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    for name in ("cfg3", "cfg4", "cfg5"):
+        assert name in bench.WORKLOADS
