@@ -54,10 +54,12 @@ struct corahip_sht_plan {
     int32_t *d_blu_P = nullptr;                           // [nside]: 0 = power-of-two ring
     int64_t *d_blu_boff = nullptr, *d_blu_foff = nullptr; // offsets into chirp / filter arrays
     double2 *d_bchirp = nullptr, *d_bfilt = nullptr;
+    double2 *d_bchirp2 = nullptr;                         // i e^{i pi j / h} b_j at the offsets of d_bchirp (compile-time kernels)
     int max_fft_len = 0;                                  // largest LDS FFT buffer (complex elems)
     // K5 launch classes: rings grouped by transform kind/length so each launch sizes its LDS
     struct ring_class {
         int P = 0;        // Bluestein length, 0 = direct power-of-two transform
+        int N = 0;        // direct classes: the half length h of the rings (all equal), 0 = mixed (run-time length)
         int nch = 4;      // channels transformed together per workgroup
         int threads = 0;  // workgroup size (0: K5_THREADS)
         int bstride = 0;  // complex elements per channel buffer in LDS
@@ -516,7 +518,8 @@ __device__ unsigned long long g_k5_stamps[8];
 static inline int nnu_pad_of(int nnu) { return (nnu + 7) & ~7; }
 // K5's register prefetch reads K5_MC * K5_THREADS cells from the start of a row without clamping: the last
 // row of the F_m buffer needs that much readable memory behind it
-#define K5_TAIL_PAD ((size_t)K5_MC * K5_THREADS * 64)
+// (the compile-time kernels of sht_ringfft_ct.hip prefetch up to 8 x 512 cells)
+#define K5_TAIL_PAD ((size_t)8 * 512 * 64)
 
 // ---- cross-translation-unit host functions -------------------------------------------------
 // K4: alm [nalm][ncols] -> F_m cells; the launch shape is chosen from the number of 16-column tiles
@@ -526,6 +529,10 @@ int sht_legendre_pol(corahip_ctx *ctx, corahip_sht_plan *p, int ncols, const dou
 // K5: F_m cells -> maps for nnu_valid channels (nnu_chunk_pad = channels in the cell layout)
 int sht_ringfft(corahip_ctx *ctx, const corahip_sht_plan *p, const double *inter, int nnu_chunk_pad, int nnu_valid,
                 double *maps);
+// K5 with compile-time transform shapes (sht_ringfft_ct.hip): returns 1 if it launched class c, 0 if the generic
+// kernel has to take it, < 0 or a hipError on failure
+int sht_ringfft_ct(corahip_ctx *ctx, const corahip_sht_plan *p, const corahip_sht_plan::ring_class &c, const double *inter,
+                   int G, int nnu, double *maps);
 // K5^T: maps -> weighted G_m cells for nnu_pad8 channels (nnu present in `maps`)
 int sht_ringana(corahip_ctx *ctx, const corahip_sht_plan *p, const double *maps, int nnu, int nnu_pad8,
                 const double *ring_w, double *inter);

@@ -499,6 +499,8 @@ int sht_ringfft(corahip_ctx *ctx, const corahip_sht_plan *p, const double *inter
                 (void)hipEventCreate(&ce1);
                 (void)hipEventRecord(ce0, ctx->stream);
             }
+            const int took = sht_ringfft_ct(ctx, p, c, inter, G, nnu_valid, maps);   // compile-time kernel for this class?
+            if (took < 0 || took > 1) return took;
             const size_t shm = sizeof(double2) * ((size_t)c.nch * c.bstride + TWL_ENTRIES(p->pmax));
             const long nitems = (long)c.count * ((nnu_valid + c.nch - 1) / c.nch);
             const int per_cu = std::max<int>(1, (int)((160 * 1024) / std::max<size_t>(shm, 1)));
@@ -511,7 +513,8 @@ int sht_ringfft(corahip_ctx *ctx, const corahip_sht_plan *p, const double *inter
                                                          p->d_nphi, p->d_start, p->d_phi0, inter, maps, p->d_tw, \
                                                          p->pmax, p->d_blu_P, p->d_blu_boff, p->d_blu_foff,      \
                                                          p->d_bchirp, p->d_bfilt, c.bstride, p->d_mcut)
-            if (c.P == 0) {
+            if (took) {
+            } else if (c.P == 0) {
                 if (c.nch == 4) { RINGFFT_LAUNCH(4, false); }
                 else if (c.nch == 2) { RINGFFT_LAUNCH(2, false); }
                 else { RINGFFT_LAUNCH(1, false); }

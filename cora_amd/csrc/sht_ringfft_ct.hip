@@ -1,0 +1,589 @@
+// sht_ringfft_ct.hip - K5 for the ring classes that carry the BASELINE configurations, with everything about the
+// transform fixed at compile time (length, pass radices, channels per workgroup):
+//   ringfft_direct_ct<N, NCH>  rings whose half length h = N is a power of two (the belt: N = 2 nside)
+//   ringfft_blu_ct<P, NCH>     cap rings through a Bluestein convolution of length P (power of two or 3 * 2^k)
+// The generic kernel of sht_ringfft.hip (run-time lengths) stays for every other class and is the reference
+// these are tested against (tests/test_gpu_fullsize.py compares both with the oracle pixel by pixel).
+//
+// What the fixed shapes buy, measured on the generic kernel's anatomy:
+//   * every LDS address of a butterfly is one per-thread base + immediate offsets: fpad(i0 + r q) = fpad(i0) +
+//     fpad(r q) whenever the bits of i0 and r q do not overlap, which the pass structure guarantees;
+//   * the twiddle a thread needs in a pass depends on tid only (j = tid mod q), not on the ring: the two
+//     twiddles of a three-pass transform live in registers for the whole persistent loop - no table load
+//     (L2 latency, and in-order vmcnt behind the next item's prefetch) inside any pass;
+//   * direct class: the Hermitian -> half-length-complex step is fused into the first pass (the butterfly reads
+//     its 16 inputs and their 16 mirror partners, one barrier, then writes) and the last pass stores pixels
+//     straight from registers (128-byte segments): four LDS write passes per item instead of five, no
+//     bank-conflicted digit-reversed read pass;
+//   * Bluestein class: chirp, i w^k chirp (plan-time table: no sincospi per item), filter and output-chirp
+//     values are requested one phase ahead of their use; the first forward pass reads only the non-zero half
+//     of the padded input and the last inverse pass forms only the h outputs that exist (so the upper half of
+//     the buffer is never zero-filled); last forward pass + filter + first inverse pass stay in registers.
+// LDS stores are the expensive operation of these kernels (ds_write_b128: 13 cycles per wave-instruction against
+// 4 for ds_read_b128, MI355X_MICROARCH.md section LDS), hence the count of write passes above.
+#include "sht_internal.h"
+
+static_assert(K5_SWZ == 0, "the compile-time kernels assume the padded LDS layout");
+#define CT_T 512
+
+__host__ __device__ constexpr int fpc(int i) { return i + (i >> 3) + ((i >> 7) << 3); }
+
+template <int N>
+struct Sch;   // DIF radices of a three-pass transform, largest stride first
+template <>
+struct Sch<1024> {
+    static constexpr int R0 = 16, R1 = 16, R2 = 4;
+};
+template <>
+struct Sch<2048> {
+    static constexpr int R0 = 16, R1 = 16, R2 = 8;
+};
+template <>
+struct Sch<4096> {
+    static constexpr int R0 = 16, R1 = 16, R2 = 16;
+};
+
+// e^{i pi r / 16}, r < 16 (indices are compile-time after unrolling: these fold into immediates)
+__device__ constexpr double kCos16[16] = {1.0, 0.98078528040323044913, 0.92387953251128675613, 0.83146961230254523708,
+                                          0.70710678118654752440, 0.55557023301960222474, 0.38268343236508977173, 0.19509032201612826785,
+                                          0.0, -0.19509032201612826785, -0.38268343236508977173, -0.55557023301960222474,
+                                          -0.70710678118654752440, -0.83146961230254523708, -0.92387953251128675613, -0.98078528040323044913};
+__device__ constexpr double kSin16[16] = {0.0, 0.19509032201612826785, 0.38268343236508977173, 0.55557023301960222474,
+                                          0.70710678118654752440, 0.83146961230254523708, 0.92387953251128675613, 0.98078528040323044913,
+                                          1.0, 0.98078528040323044913, 0.92387953251128675613, 0.83146961230254523708,
+                                          0.70710678118654752440, 0.55557023301960222474, 0.38268343236508977173, 0.19509032201612826785};
+
+__device__ __forceinline__ static double2 csqr(double2 a) {
+    return make_double2(fma(a.x, a.x, -(a.y * a.y)), 2.0 * a.x * a.y);
+}
+__device__ __forceinline__ static double2 cconj(double2 a) { return make_double2(a.x, -a.y); }
+
+// x[r] *= w^r, r = 1 .. R-1.  Powers of two by squaring (kept), every other power as w^(r - lowbit) * w^lowbit and
+// applied at once, so that besides w, w^2, w^4, w^8 only one or two products are live at a time (a table of all
+// powers cost 60 VGPRs and made the kernels spill).
+// The base twiddle is loop-invariant in the persistent item loop; without the empty asm the compiler hoists all 15
+// powers of every pass out of that loop and, having no registers for ~200 values, keeps them in scratch memory
+// (reloaded with vmcnt-ordered loads behind the prefetch).  Recomputing them costs 11 complex multiplies per butterfly.
+template <int R>
+__device__ __forceinline__ static void tw_apply(double2 (&x)[R], double2 w1) {
+    asm volatile("" : "+v"(w1.x), "+v"(w1.y));
+    double2 w[R];
+    w[1] = w1;
+    x[1] = cmul(x[1], w1);
+#pragma unroll
+    for (int r = 2; r < R; r++) {
+        const int lb = r & (-r);
+        w[r] = (lb == r) ? csqr(w[r >> 1]) : cmul(w[r - lb], w[lb]);
+        x[r] = cmul(x[r], w[r]);
+    }
+}
+
+// one in-LDS pass of a length-N transform on NCH channel buffers (channel c at sm + c BS), sub-length Ls, radix R.
+// DIT = false: DFT then twiddle (decimation in frequency); true: twiddle then DFT.  w1 = e^{+2 pi i j / Ls} of this
+// thread's j = tid mod (Ls / R) (the same for every butterfly the thread ever gets in this pass).
+template <int N, int NCH, int BS, int Ls, int R, int SIGN, bool DIT>
+__device__ __forceinline__ static void ct_pass(double2 *sm, const double2 w1) {
+    constexpr int NB = N / R, Q = Ls / R, TOT = NCH * NB;
+    constexpr int IT = (TOT + CT_T - 1) / CT_T;
+    const double2 w = make_double2(w1.x, SIGN > 0 ? w1.y : -w1.y);
+#pragma unroll
+    for (int it = 0; it < IT; it++) {
+        const int idx = threadIdx.x + it * CT_T;
+        if ((TOT % CT_T) != 0 && idx >= TOT) break;
+        const int ch = idx / NB, t = idx - ch * NB;
+        const int b = t / Q, j = t - b * Q;
+        double2 *p = sm + ch * BS + fpad(b * Ls + j);
+        double2 x[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) x[r] = p[fpc(r * Q)];
+        if (DIT && Q > 1) tw_apply<R>(x, w);
+        DftR<R, SIGN>::run(x);
+        if (!DIT && Q > 1) tw_apply<R>(x, w);
+#pragma unroll
+        for (int r = 0; r < R; r++) p[fpc(r * Q)] = x[r];
+    }
+}
+
+// ---- register prefetch of the F_m cells of one (ring, NCH channels) item ---------------------------------------
+template <int NCH>
+struct cell_ct {
+    double re[NCH], im[NCH];
+};
+template <int NCH>
+__device__ __forceinline__ static cell_ct<NCH> load_cell_ct(const double *__restrict__ cell, unsigned m) {
+    cell_ct<NCH> c;
+    if (NCH == 4) {
+        const double4 a = *reinterpret_cast<const double4 *>(cell + m * 8u);
+        const double4 b = *reinterpret_cast<const double4 *>(cell + m * 8u + 4u);
+        c.re[0] = a.x; c.re[1 % NCH] = a.y; c.re[2 % NCH] = a.z; c.re[3 % NCH] = a.w;
+        c.im[0] = b.x; c.im[1 % NCH] = b.y; c.im[2 % NCH] = b.z; c.im[3 % NCH] = b.w;
+    } else if (NCH == 2) {
+        const double2 a = *reinterpret_cast<const double2 *>(cell + m * 8u);
+        const double2 b = *reinterpret_cast<const double2 *>(cell + m * 8u + 4u);
+        c.re[0] = a.x; c.re[1 % NCH] = a.y;
+        c.im[0] = b.x; c.im[1 % NCH] = b.y;
+    } else {
+        c.re[0] = cell[m * 8u];
+        c.im[0] = cell[m * 8u + 4u];
+    }
+    return c;
+}
+
+// phase e^{i m phi0} and fold of one cell onto the bins 0..h of the Hermitian spectrum (see ringfft_kernel)
+template <int NCH, int BS>
+__device__ __forceinline__ static void fold_cell(double2 *sm, int m, int n, int h, bool noalias, const double2 ph,
+                                                 const cell_ct<NCH> &cv) {
+    double *smd = reinterpret_cast<double *>(sm);
+#pragma unroll
+    for (int c = 0; c < NCH; c++) {
+        const double2 val = cmul(make_double2(cv.re[c], cv.im[c]), ph);
+        double *bd = smd + (size_t)c * BS * 2;
+        if (noalias) {
+            if (m == 0) *reinterpret_cast<double2 *>(bd) = make_double2(val.x, 0.0);             // Re(c_0) only
+            else if (m < h) *reinterpret_cast<double2 *>(bd + 2 * fpad(m)) = val;
+            else *reinterpret_cast<double2 *>(bd + 2 * fpad(h)) = make_double2(2.0 * val.x, 0.0);  // m == h
+        } else {
+            const int k = m % n;
+            const int kc = (n - k) % n;
+            if (m == 0) atomicAdd(&bd[0], val.x);
+            else {
+                if (k <= h) {
+                    atomicAdd(&bd[2 * fpad(k)], val.x);
+                    atomicAdd(&bd[2 * fpad(k) + 1], val.y);
+                }
+                if (kc <= h) {
+                    atomicAdd(&bd[2 * fpad(kc)], val.x);
+                    atomicAdd(&bd[2 * fpad(kc) + 1], -val.y);
+                }
+            }
+        }
+    }
+}
+
+// shared front end of both kernels: zero / fold the ring spectrum of the current item from the prefetched
+// registers (cells m = tid + k CT_T, k < MC) and, behind it, cells read in place; then prefetch the next item.
+// Ends with a barrier.  X_k, k = 0..h, is then at sm[c BS + fpad(k)].
+// TAIL: one more register slot for the cell m = tid + MC CT_T, index clamped to the last cell of the row (the belt
+// has lmax + 1 = MC CT_T + 1 cells: read in place, that one cell exposed a whole memory latency per item).
+template <int NCH, int BS, int MC, bool TAIL>
+struct FrontEnd {
+    cell_ct<NCH> pf[MC + (TAIL ? 1 : 0)];
+    __device__ __forceinline__ void prefetch(const double *__restrict__ cell, int L) {
+#pragma unroll
+        for (int k = 0; k < MC; k++) pf[k] = load_cell_ct<NCH>(cell + (size_t)k * CT_T * 8, threadIdx.x);
+        if (TAIL) pf[MC] = load_cell_ct<NCH>(cell, (unsigned)min((int)threadIdx.x + MC * CT_T, L - 1));
+    }
+    __device__ __forceinline__ void fold(double2 *sm, const double *__restrict__ cell, int Lr, int n, double phi0_over_pi) {
+        const int tid = threadIdx.x;
+        const int h = n >> 1;
+        const bool noalias = Lr - 1 <= h;
+        if (noalias) {
+            for (int j = Lr + tid; j <= h; j += CT_T)
+#pragma unroll
+                for (int c = 0; c < NCH; c++) sm[c * BS + fpad(j)] = make_double2(0.0, 0.0);
+        } else {
+            for (int j = tid; j <= h; j += CT_T)
+#pragma unroll
+                for (int c = 0; c < NCH; c++) sm[c * BS + fpad(j)] = make_double2(0.0, 0.0);
+            __syncthreads();
+        }
+        double2 ph, phstep;
+        {
+            double s, c;
+            sincospi(fmod((double)tid * phi0_over_pi, 2.0), &s, &c);
+            ph = make_double2(c, s);
+            sincospi(fmod((double)CT_T * phi0_over_pi, 2.0), &s, &c);
+            phstep = make_double2(c, s);
+        }
+#pragma unroll
+        for (int k = 0; k < MC; k++) {
+            if (tid + k * CT_T < Lr) fold_cell<NCH, BS>(sm, tid + k * CT_T, n, h, noalias, ph, pf[k]);
+            ph = cmul(ph, phstep);
+        }
+        if (TAIL) {
+            if (tid + MC * CT_T < Lr) fold_cell<NCH, BS>(sm, tid + MC * CT_T, n, h, noalias, ph, pf[MC]);
+            ph = cmul(ph, phstep);
+        }
+        for (int m = tid + (MC + (TAIL ? 1 : 0)) * CT_T; m < Lr; m += CT_T) {   // cells beyond the prefetch window, read in place
+            fold_cell<NCH, BS>(sm, m, n, h, noalias, ph, load_cell_ct<NCH>(cell, m));
+            ph = cmul(ph, phstep);
+        }
+    }
+};
+
+// blockIdx -> item with the workgroups of one XCD taking the items that share 64-byte cells (K5_XCD_PAIR of
+// sht_ringfft.hip)
+template <int NCH>
+__device__ __forceinline__ static int ct_remap(int v, int nitems) {
+    constexpr int SH = NCH == 2 ? 1 : (NCH == 1 ? 2 : 0);
+    const bool on = SH > 0 && (nitems & ((8 << SH) - 1)) == 0 && (gridDim.x & ((8 << SH) - 1)) == 0;
+    if (!on) return v;
+    const int slot = v >> 3, xcd = v & 7;
+    return (((slot >> SH) * 8 + xcd) << SH) + (slot & ((1 << SH) - 1));
+}
+
+// ------------------------------------------------------------------------------------
+// direct class: h = N = 2^k (N >= 2048 so that the first-pass stride is a multiple of the 128-element padding period)
+// ------------------------------------------------------------------------------------
+template <int N, int NCH, int MC>
+__global__ void __launch_bounds__(CT_T)
+ringfft_direct_ct(const int32_t *__restrict__ ring_list, int nlist, int lmax, int G, int nnu, long npix,
+                  const int64_t *__restrict__ start_a, const double *__restrict__ phi0_a,
+                  const double *__restrict__ inter, double *__restrict__ maps, const int32_t *__restrict__ mcut) {
+    constexpr int R0 = Sch<N>::R0, R1 = Sch<N>::R1, R2 = Sch<N>::R2;
+    static_assert(R0 == 16 && R1 == 16, "digit map of the fused store assumes 16 x 16 x R2");
+    constexpr int Q0 = N / R0;              // stride of the first pass
+    static_assert(Q0 % 128 == 0, "first-pass stride must be a multiple of the padding period");
+    constexpr int BS = fpc(N) + 1 + K5_CH_SKEW;
+    constexpr int n = 2 * N, h = N;
+    extern __shared__ __attribute__((aligned(16))) double2 sm[];
+    const int tid = threadIdx.x;
+    const int L = lmax + 1;
+    const int ngrp = (nnu + NCH - 1) / NCH;
+    const int nitems = nlist * ngrp;
+
+    // per-thread twiddles, fixed for the whole kernel
+    double2 wH, wA, wB;     // e^{i pi j0 / N}, e^{2 pi i j0 / N}, e^{2 pi i j1 / (N / R0)}
+    {
+        const int j0 = tid & (Q0 - 1), j1 = tid & (Q0 / R1 - 1);
+        double s, c;
+        sincospi((double)j0 / (double)N, &s, &c);
+        wH = make_double2(c, s);
+        sincospi(2.0 * (double)j0 / (double)N, &s, &c);
+        wA = make_double2(c, s);
+        sincospi(2.0 * (double)j1 / (double)Q0, &s, &c);
+        wB = make_double2(c, s);
+    }
+    auto cell_ptr = [&](int item) {
+        const int ring = ring_list[item / ngrp];
+        const int ch0 = (item % ngrp) * NCH;
+        return inter + ((size_t)ring * G + (ch0 >> 2)) * L * 8 + (ch0 & 3);
+    };
+    FrontEnd<NCH, BS, MC, true> fe;
+    int vitem = blockIdx.x;
+    if (vitem < nitems) fe.prefetch(cell_ptr(ct_remap<NCH>(vitem, nitems)), L);
+    for (; vitem < nitems; vitem += gridDim.x) {
+        const int item = ct_remap<NCH>(vitem, nitems);
+        const int ring = ring_list[item / ngrp];
+        const int ch0 = (item % ngrp) * NCH;
+        const long start = start_a[ring];
+        const double phi0_over_pi = phi0_a[ring] / M_PI;
+        const int Lr = mcut[ring];
+        __syncthreads();                                  // previous item's LDS reads are done
+        fe.fold(sm, cell_ptr(item), Lr, n, phi0_over_pi);
+        if (vitem + (int)gridDim.x < nitems) fe.prefetch(cell_ptr(ct_remap<NCH>(vitem + gridDim.x, nitems)), L);
+        __syncthreads();
+        // ---- pass 1 with the Hermitian step: butterfly j0 of channel ch reads X_k, k = j0 + r Q0, and the mirror
+        //      partners X_{h-k} = element (Q0 - j0) + (R0 - 1 - r) Q0; Z_k = (X_k + conj X_{h-k}) + i w^k (X_k - conj X_{h-k}),
+        //      w^k = e^{i pi j0 / N} e^{i pi r / R0}
+        {
+            constexpr int TOT = NCH * Q0;
+            constexpr int IT = (TOT + CT_T - 1) / CT_T;
+            double2 x[IT][R0];
+            double2 wh = wH;
+            asm volatile("" : "+v"(wh.x), "+v"(wh.y));   // (keeps the 16 products below out of the loop-invariant set: see tw_apply)
+#pragma unroll
+            for (int it = 0; it < IT; it++) {
+                const int idx = tid + it * CT_T;
+                const int ch = idx / Q0, j0 = idx & (Q0 - 1);
+                const double2 *pa = sm + ch * BS + fpad(j0);
+                const double2 *pb = sm + ch * BS + fpad(Q0 - j0);
+#pragma unroll
+                for (int r = 0; r < R0; r++) {
+                    const double2 xa = pa[fpc(r * Q0)];
+                    const double2 xb = pb[fpc((R0 - 1 - r) * Q0)];
+                    const double2 w = cmul(wh, make_double2(kCos16[r], kSin16[r]));
+                    const double2 sum = make_double2(xa.x + xb.x, xa.y - xb.y);
+                    const double2 dif = make_double2(xa.x - xb.x, xa.y + xb.y);
+                    const double2 t = cmul(dif, w);
+                    x[it][r] = make_double2(sum.x - t.y, sum.y + t.x);
+                }
+            }
+            __syncthreads();                              // every raw X has been read
+#pragma unroll
+            for (int it = 0; it < IT; it++) {
+                const int idx = tid + it * CT_T;
+                const int ch = idx / Q0, j0 = idx & (Q0 - 1);
+                double2 *pa = sm + ch * BS + fpad(j0);
+                DftR<R0, 1>::run(x[it]);
+                tw_apply<R0>(x[it], wA);
+#pragma unroll
+                for (int r = 0; r < R0; r++) pa[fpc(r * Q0)] = x[it][r];
+            }
+        }
+        __syncthreads();
+        ct_pass<N, NCH, BS, Q0, R1, 1, false>(sm, wB);
+        __syncthreads();
+        // ---- last pass (radix R2 on contiguous elements, no twiddles) with the pixel store: butterfly t = 16 k0 + k1
+        //      holds the natural indices k0 + 16 k1 + 256 r.  Lane bits: 0-2 = k0 low, 3-5 = k1 low, 6 = k0 high,
+        //      7 = k1 high: eight consecutive lanes store 128 contiguous bytes; the LDS reads are 2-way conflicted.
+        {
+            constexpr int TOT = NCH * 256;
+            constexpr int IT = (TOT + CT_T - 1) / CT_T;
+#pragma unroll
+            for (int it = 0; it < IT; it++) {
+                const int idx = tid + it * CT_T;
+                if ((TOT % CT_T) != 0 && idx >= TOT) break;
+                const int ch = idx >> 8;
+                const int k0 = (idx & 7) | ((idx >> 3) & 8);
+                const int k1 = ((idx >> 3) & 7) | ((idx >> 4) & 8);
+                const double2 *p = sm + ch * BS + fpad((k0 * 16 + k1) * R2);
+                double2 x[R2];
+#pragma unroll
+                for (int r = 0; r < R2; r++) x[r] = p[fpc(r)];
+                DftR<R2, 1>::run(x);
+                if (ch0 + ch < nnu) {
+                    double *out = maps + (size_t)(ch0 + ch) * npix + start + 2 * (k0 + 16 * k1);
+#pragma unroll
+                    for (int r = 0; r < R2; r++) *reinterpret_cast<double2 *>(out + 512 * r) = x[r];
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// Bluestein class: cap rings, h = 2 i not a power of two, convolution length P >= 2 h - 1
+// ------------------------------------------------------------------------------------
+template <int P, int NCH, int MC>
+__global__ void __launch_bounds__(CT_T)
+ringfft_blu_ct(const int32_t *__restrict__ ring_list, int nlist, int nside, int lmax, int G, int nnu, long npix,
+               const int32_t *__restrict__ nphi_a, const int64_t *__restrict__ start_a,
+               const double *__restrict__ phi0_a, const double *__restrict__ inter, double *__restrict__ maps,
+               const int64_t *__restrict__ boff, const int64_t *__restrict__ foff, const double2 *__restrict__ chirp,
+               const double2 *__restrict__ chirp2, const double2 *__restrict__ filt, const int32_t *__restrict__ mcut) {
+    constexpr int R0 = Sch<P>::R0, R1 = Sch<P>::R1, R2 = Sch<P>::R2;
+    constexpr int Q0 = P / R0;
+    constexpr int BS = fpc(P) + K5_CH_SKEW;
+    constexpr int HALF = (R0 / 2) * Q0;          // the non-zero half of the padded input: h <= HALF
+    constexpr int U = (HALF / 2 + CT_T) / CT_T;  // pre-pass iterations: pairs k <= h / 2 <= HALF / 2
+    extern __shared__ __attribute__((aligned(16))) double2 sm[];
+    const int tid = threadIdx.x;
+    const int L = lmax + 1;
+    const int ngrp = (nnu + NCH - 1) / NCH;
+    const int nitems = nlist * ngrp;
+    const double invP = 1.0 / (double)P;
+
+    double2 wA, wB;     // e^{2 pi i j0 / P}, e^{2 pi i j1 / (P / R0)}
+    {
+        const int j0 = tid & (Q0 - 1), j1 = tid & (Q0 / R1 - 1);
+        double s, c;
+        sincospi(2.0 * (double)j0 / (double)P, &s, &c);
+        wA = make_double2(c, s);
+        sincospi(2.0 * (double)j1 / (double)Q0, &s, &c);
+        wB = make_double2(c, s);
+    }
+    auto cell_ptr = [&](int item) {
+        const int ring = ring_list[item / ngrp];
+        const int ch0 = (item % ngrp) * NCH;
+        return inter + ((size_t)ring * G + (ch0 >> 2)) * L * 8 + (ch0 & 3);
+    };
+    FrontEnd<NCH, BS, MC, false> fe;
+    int vitem = blockIdx.x;
+    if (vitem < nitems) fe.prefetch(cell_ptr(ct_remap<NCH>(vitem, nitems)), L);
+    for (; vitem < nitems; vitem += gridDim.x) {
+        const int item = ct_remap<NCH>(vitem, nitems);
+        const int ring = ring_list[item / ngrp];
+        const int ch0 = (item % ngrp) * NCH;
+        const int n = nphi_a[ring];
+        const int h = n >> 1;
+        const long start = start_a[ring];
+        const double phi0_over_pi = phi0_a[ring] / M_PI;
+        const int icap = ring + 1 < nside ? ring + 1 : 4 * nside - (ring + 1);
+        const int Lr = mcut[ring];
+        const double2 *bch = chirp + boff[icap - 1];
+        const double2 *bch2 = chirp2 + boff[icap - 1];
+        // chirp values of the pre-pass, requested before the fold (older than the next item's prefetch, so the
+        // in-order vmcnt wait in front of the pre-pass does not wait for that)
+        double2 cb[U][4];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int k = tid + u * CT_T;
+            const int ka = min(k, h - 1), kb = min(max(h - k, 0), h - 1);   // clamped: unused lanes load a valid slot
+            cb[u][0] = bch[ka];
+            cb[u][1] = bch2[ka];
+            cb[u][2] = bch[kb];
+            cb[u][3] = bch2[kb];
+        }
+        __syncthreads();                                  // previous item's LDS reads are done
+        fe.fold(sm, cell_ptr(item), Lr, n, phi0_over_pi);
+        if (vitem + (int)gridDim.x < nitems) fe.prefetch(cell_ptr(ct_remap<NCH>(vitem + gridDim.x, nitems)), L);
+        __syncthreads();
+        // ---- pre-pass: y_k = b_k (X_k + conj X_{h-k}) + (i w^k b_k) (X_k - conj X_{h-k}) for the pairs (k, h - k),
+        //      zeros on [h, HALF)
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int k = tid + u * CT_T;
+            if (2 * k <= h) {
+                const int k2 = h - k;
+#pragma unroll
+                for (int c = 0; c < NCH; c++) {
+                    double2 *bc = sm + c * BS;
+                    const double2 xa = bc[fpad(k)], xb = bc[fpad(k2)];
+                    const double2 s1 = make_double2(xa.x + xb.x, xa.y - xb.y), d1 = make_double2(xa.x - xb.x, xa.y + xb.y);
+                    const double2 s2 = make_double2(s1.x, -s1.y), d2 = make_double2(-d1.x, d1.y);  // (xb + conj xa), (xb - conj xa)
+                    const double2 zk = cadd(cmul(cb[u][0], s1), cmul(cb[u][1], d1));
+                    const double2 zk2 = cadd(cmul(cb[u][2], s2), cmul(cb[u][3], d2));
+                    bc[fpad(k)] = zk;
+                    if (k > 0) {
+                        if (k2 != k) bc[fpad(k2)] = zk2;
+                    } else {
+                        bc[fpad(h)] = make_double2(0.0, 0.0);
+                    }
+                }
+            }
+        }
+        for (int j = h + 1 + tid; j < HALF; j += CT_T)
+#pragma unroll
+            for (int c = 0; c < NCH; c++) sm[c * BS + fpad(j)] = make_double2(0.0, 0.0);
+        // filter values of the register-fused middle (storage positions t R2 + r; the same for every channel)
+        const double2 *f = filt + foff[icap - 1];
+        double2 fl[R2];
+        {
+            const int t = tid & (P / R2 - 1);
+#pragma unroll
+            for (int r = 0; r < R2; r++) fl[r] = f[t * R2 + r];
+        }
+        __syncthreads();
+        // ---- forward pass 1 (sign -), inputs r >= R0 / 2 are the zero padding and are not read
+        {
+            constexpr int TOT = NCH * Q0;
+            constexpr int IT = (TOT + CT_T - 1) / CT_T;
+            const double2 w = cconj(wA);
+#pragma unroll
+            for (int it = 0; it < IT; it++) {
+                const int idx = tid + it * CT_T;
+                if ((TOT % CT_T) != 0 && idx >= TOT) break;
+                const int ch = idx / Q0, j0 = idx & (Q0 - 1);
+                double2 *p = sm + ch * BS + fpad(j0);
+                double2 x[R0];
+#pragma unroll
+                for (int r = 0; r < R0 / 2; r++) x[r] = p[fpc(r * Q0)];
+#pragma unroll
+                for (int r = R0 / 2; r < R0; r++) x[r] = make_double2(0.0, 0.0);
+                DftR<R0, -1>::run(x);
+                tw_apply<R0>(x, w);
+#pragma unroll
+                for (int r = 0; r < R0; r++) p[fpc(r * Q0)] = x[r];
+            }
+        }
+        __syncthreads();
+        ct_pass<P, NCH, BS, Q0, R1, -1, false>(sm, wB);
+        __syncthreads();
+        // ---- last forward pass, filter, first inverse pass: R2 contiguous elements, no twiddles, in registers
+        {
+            constexpr int NB = P / R2, TOT = NCH * NB;
+            constexpr int IT = (TOT + CT_T - 1) / CT_T;
+#pragma unroll
+            for (int it = 0; it < IT; it++) {
+                const int idx = tid + it * CT_T;
+                if ((TOT % CT_T) != 0 && idx >= TOT) break;
+                const int ch = idx / NB, t = idx & (NB - 1);
+                double2 *p = sm + ch * BS + fpad(t * R2);
+                double2 x[R2];
+#pragma unroll
+                for (int r = 0; r < R2; r++) x[r] = p[fpc(r)];
+                DftR<R2, -1>::run(x);
+#pragma unroll
+                for (int r = 0; r < R2; r++) x[r] = cmul(x[r], fl[r]);
+                DftR<R2, 1>::run(x);
+#pragma unroll
+                for (int r = 0; r < R2; r++) p[fpc(r)] = x[r];
+            }
+        }
+        // chirp of the outputs this thread forms in the last pass: j0 + r Q0 < h, r < R0 / 2
+        double2 ob[R0 / 2];
+        {
+            const int j0 = tid & (Q0 - 1);
+#pragma unroll
+            for (int r = 0; r < R0 / 2; r++) ob[r] = bch[min(j0 + r * Q0, h - 1)];
+        }
+        __syncthreads();
+        ct_pass<P, NCH, BS, Q0, R1, 1, true>(sm, wB);
+        __syncthreads();
+        // ---- last inverse pass (sign +): only the outputs j0 + r Q0 < h exist; times b_j / P, pixel pairs to HBM
+        {
+            constexpr int TOT = NCH * Q0;
+            constexpr int IT = (TOT + CT_T - 1) / CT_T;
+#pragma unroll
+            for (int it = 0; it < IT; it++) {
+                const int idx = tid + it * CT_T;
+                if ((TOT % CT_T) != 0 && idx >= TOT) break;
+                const int ch = idx / Q0, j0 = idx & (Q0 - 1);
+                const double2 *p = sm + ch * BS + fpad(j0);
+                double2 x[R0];
+#pragma unroll
+                for (int r = 0; r < R0; r++) x[r] = p[fpc(r * Q0)];
+                tw_apply<R0>(x, wA);
+                DftR<R0, 1>::run(x);
+                if (ch0 + ch < nnu) {
+                    double *out = maps + (size_t)(ch0 + ch) * npix + start;
+#pragma unroll
+                    for (int r = 0; r < R0 / 2; r++) {
+                        const int jj = j0 + r * Q0;
+                        if (jj < h) {
+                            double2 zv = cmul(x[r], ob[r]);
+                            zv.x *= invP;
+                            zv.y *= invP;
+                            *reinterpret_cast<double2 *>(out + 2 * jj) = zv;
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// host side: launch one class with the compile-time kernel if there is one for it
+// ------------------------------------------------------------------------------------
+template <int N, int NCH, int MC>
+static int launch_direct(corahip_ctx *ctx, const corahip_sht_plan *p, const corahip_sht_plan::ring_class &c, const double *inter,
+                         int G, int nnu, double *maps) {
+    constexpr int BS = fpc(N) + 1 + K5_CH_SKEW;
+    const size_t shm = sizeof(double2) * (size_t)NCH * BS;
+    const long nitems = (long)c.count * ((nnu + NCH - 1) / NCH);
+    const int per_cu = std::max<int>(1, (int)((160 * 1024) / shm));
+    dim3 grid((unsigned)std::min<long>(nitems, (long)ctx->num_cu * per_cu));
+    HIP_TRY(hipFuncSetAttribute((const void *)ringfft_direct_ct<N, NCH, MC>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024));
+    ringfft_direct_ct<N, NCH, MC><<<grid, CT_T, shm, ctx->stream>>>(c.d_list, c.count, p->lmax, G, nnu, p->npix, p->d_start,
+                                                                  p->d_phi0, inter, maps, p->d_mcut);
+    LAUNCH_CHECK();
+    return 0;
+}
+template <int P, int NCH, int MC>
+static int launch_blu(corahip_ctx *ctx, const corahip_sht_plan *p, const corahip_sht_plan::ring_class &c, const double *inter,
+                      int G, int nnu, double *maps) {
+    constexpr int BS = fpc(P) + K5_CH_SKEW;
+    const size_t shm = sizeof(double2) * (size_t)NCH * BS;
+    const long nitems = (long)c.count * ((nnu + NCH - 1) / NCH);
+    const int per_cu = std::max<int>(1, (int)((160 * 1024) / shm));
+    dim3 grid((unsigned)std::min<long>(nitems, (long)ctx->num_cu * per_cu));
+    HIP_TRY(hipFuncSetAttribute((const void *)ringfft_blu_ct<P, NCH, MC>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024));
+    ringfft_blu_ct<P, NCH, MC><<<grid, CT_T, shm, ctx->stream>>>(c.d_list, c.count, p->nside, p->lmax, G, nnu, p->npix, p->d_nphi,
+                                                               p->d_start, p->d_phi0, inter, maps, p->d_blu_boff,
+                                                               p->d_blu_foff, p->d_bchirp, p->d_bchirp2, p->d_bfilt, p->d_mcut);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+// returns 1 if the class was launched here, 0 if the generic kernel has to take it, < 0 / hipError on failure
+int sht_ringfft_ct(corahip_ctx *ctx, const corahip_sht_plan *p, const corahip_sht_plan::ring_class &c, const double *inter,
+                   int G, int nnu, double *maps) {
+    static const bool off = getenv("CORAHIP_K5_GENERIC") != nullptr;   // diagnostics: force the generic kernel
+    if (off) return 0;
+    int rc = -1;
+    if (c.P == 0) {
+        if (c.N == 2048) rc = launch_direct<2048, 4, 4>(ctx, p, c, inter, G, nnu, maps);
+        else if (c.N == 4096) rc = launch_direct<4096, 2, 8>(ctx, p, c, inter, G, nnu, maps);
+        else return 0;
+    } else {
+        if (c.P == 4096) rc = launch_blu<4096, 2, 4>(ctx, p, c, inter, G, nnu, maps);
+        else if (c.P == 2048) rc = launch_blu<2048, 4, 2>(ctx, p, c, inter, G, nnu, maps);
+        else if (c.P == 1024) rc = launch_blu<1024, 4, 1>(ctx, p, c, inter, G, nnu, maps);
+        else return 0;
+    }
+    return rc ? rc : 1;
+}
