@@ -33,7 +33,16 @@ __device__ static inline void scaled_pow(double s, int n, double &mant, int &ex)
     ex = re;
 }
 
-#define SEED_MIN_EXP (-900)
+// Terms of the Legendre sums with |lambda_lm| < 2^SEED_MIN_EXP are dropped (K4 starts its recurrence at the first l
+// that reaches it; K4 neither writes nor K5 reads the F_m cells beyond the per-ring cut-off it implies).  2^-120 =
+// 7.5e-37: the sum of all 2e6 dropped terms of a channel stays below 1e-29 of an O(1) coefficient, 13 decades
+// under fp64 rounding; libsharp (the engine behind healpy.alm2map) truncates at m > lmax sin(theta) + max(100, lmax / 100),
+// which corresponds to about 2^-70 at lmax = 2048.  The first version used 2^-900 ("exactly zero"): with it the
+// rings 513..1023 of nside 1024 kept lmax + 1 > h + 1 cells, so their ring FFT took the aliased (LDS-atomic) fold
+// and read 20-45 % more cells.  The oracle keeps 2^-900.
+#ifndef SEED_MIN_EXP
+#define SEED_MIN_EXP (-120)
+#endif
 
 // lstart[m][r]: first l at which |lambda_lm(ring r)| >= 2^SEED_MIN_EXP, with the two
 // recurrence values there; terms below are < 1e-270 and are dropped (libsharp does the same).
@@ -103,7 +112,7 @@ __global__ void lambda_kernel(int lmax, int npair, int m, int r, const double *_
         out[l - m] = v;
     }
 }
-// per ring: mcut = number of m (from 0) whose lambda_lm reach 2^-900 for some l <= lmax; F_m of the ring
+// per ring: mcut = number of m (from 0) whose lambda_lm reach 2^SEED_MIN_EXP for some l <= lmax; F_m of the ring
 // is exactly zero beyond (lstart is monotone in m), so K4 need not write and K5 need not read those cells
 __global__ void mcut_kernel(int lmax, int npair, int nring, const int32_t *__restrict__ lstart,
                             int32_t *__restrict__ mcut) {

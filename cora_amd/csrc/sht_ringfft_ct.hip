@@ -25,6 +25,15 @@
 
 static_assert(K5_SWZ == 0, "the compile-time kernels assume the padded LDS layout");
 #define CT_T 512
+#ifndef CT_STAMPS
+#define CT_STAMPS 0   // diagnostic build (make k5ctstamps): s_memtime per phase of the Bluestein kernel, summed over waves
+#endif
+#if CT_STAMPS
+__device__ unsigned long long g_ct_stamps[12];
+#define CTSTAMP(k) { unsigned long long _t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)::"memory"); ct_acc[k] += _t - ct_last; ct_last = _t; }
+#else
+#define CTSTAMP(k)
+#endif
 
 __host__ __device__ constexpr int fpc(int i) { return i + (i >> 3) + ((i >> 7) << 3); }
 
@@ -82,13 +91,13 @@ __device__ __forceinline__ static void tw_apply(double2 (&x)[R], double2 w1) {
 // DIT = false: DFT then twiddle (decimation in frequency); true: twiddle then DFT.  w1 = e^{+2 pi i j / Ls} of this
 // thread's j = tid mod (Ls / R) (the same for every butterfly the thread ever gets in this pass).
 template <int N, int NCH, int BS, int Ls, int R, int SIGN, bool DIT>
-__device__ __forceinline__ static void ct_pass(double2 *sm, const double2 w1) {
+__device__ __forceinline__ static void ct_pass(double2 *sm, const double2 w1, const int tid) {
     constexpr int NB = N / R, Q = Ls / R, TOT = NCH * NB;
     constexpr int IT = (TOT + CT_T - 1) / CT_T;
     const double2 w = make_double2(w1.x, SIGN > 0 ? w1.y : -w1.y);
 #pragma unroll
     for (int it = 0; it < IT; it++) {
-        const int idx = threadIdx.x + it * CT_T;
+        const int idx = tid + it * CT_T;
         if ((TOT % CT_T) != 0 && idx >= TOT) break;
         const int ch = idx / NB, t = idx - ch * NB;
         const int b = t / Q, j = t - b * Q;
@@ -168,13 +177,22 @@ __device__ __forceinline__ static void fold_cell(double2 *sm, int m, int n, int 
 template <int NCH, int BS, int MC, bool TAIL>
 struct FrontEnd {
     cell_ct<NCH> pf[MC + (TAIL ? 1 : 0)];
-    __device__ __forceinline__ void prefetch(const double *__restrict__ cell, int L) {
+    __device__ __forceinline__ void prefetch(const double *__restrict__ cell, int L, int tid) {
 #pragma unroll
-        for (int k = 0; k < MC; k++) pf[k] = load_cell_ct<NCH>(cell + (size_t)k * CT_T * 8, threadIdx.x);
-        if (TAIL) pf[MC] = load_cell_ct<NCH>(cell, (unsigned)min((int)threadIdx.x + MC * CT_T, L - 1));
+        for (int k = 0; k < MC; k++) pf[k] = load_cell_ct<NCH>(cell + (size_t)k * CT_T * 8, tid);
+        if (TAIL) pf[MC] = load_cell_ct<NCH>(cell, (unsigned)min(tid + MC * CT_T, L - 1));
     }
-    __device__ __forceinline__ void fold(double2 *sm, const double *__restrict__ cell, int Lr, int n, double phi0_over_pi) {
-        const int tid = threadIdx.x;
+    // make the compiler wait for the prefetch HERE.  vmcnt completes in order and the pixel stores are conditional, so
+    // the compiler cannot count them: a wait for a prefetch register placed after the stores becomes vmcnt(0) and
+    // sits out the store acknowledgements of the whole previous item (measured: 7k cycles per item)
+    __device__ __forceinline__ void touch() const {
+#pragma unroll
+        for (int k = 0; k < MC + (TAIL ? 1 : 0); k++)
+#pragma unroll
+            for (int c = 0; c < NCH; c++) asm volatile("" ::"v"(pf[k].re[c]), "v"(pf[k].im[c]));
+    }
+    double2 ph0, ph1;   // e^{i m phi0} at m = tid and tid + CT_T (the Bluestein pre-pass derives e^{i pi k / h} from them)
+    __device__ __forceinline__ void fold(double2 *sm, const double *__restrict__ cell, int Lr, int n, double phi0_over_pi, const int tid) {
         const int h = n >> 1;
         const bool noalias = Lr - 1 <= h;
         if (noalias) {
@@ -190,11 +208,15 @@ struct FrontEnd {
         double2 ph, phstep;
         {
             double s, c;
-            sincospi(fmod((double)tid * phi0_over_pi, 2.0), &s, &c);
+            // (sincospi reduces its argument exactly; an fmod in front of it - the generic kernel has one - is a
+            //  slow library loop: the fold took 6.7k cycles per item with it)
+            sincospi((double)tid * phi0_over_pi, &s, &c);
             ph = make_double2(c, s);
-            sincospi(fmod((double)CT_T * phi0_over_pi, 2.0), &s, &c);
+            sincospi((double)CT_T * phi0_over_pi, &s, &c);
             phstep = make_double2(c, s);
         }
+        ph0 = ph;
+        ph1 = cmul(ph, phstep);
 #pragma unroll
         for (int k = 0; k < MC; k++) {
             if (tid + k * CT_T < Lr) fold_cell<NCH, BS>(sm, tid + k * CT_T, n, h, noalias, ph, pf[k]);
@@ -237,7 +259,7 @@ ringfft_direct_ct(const int32_t *__restrict__ ring_list, int nlist, int lmax, in
     constexpr int BS = fpc(N) + 1 + K5_CH_SKEW;
     constexpr int n = 2 * N, h = N;
     extern __shared__ __attribute__((aligned(16))) double2 sm[];
-    const int tid = threadIdx.x;
+    const int tid0 = threadIdx.x;
     const int L = lmax + 1;
     const int ngrp = (nnu + NCH - 1) / NCH;
     const int nitems = nlist * ngrp;
@@ -245,7 +267,7 @@ ringfft_direct_ct(const int32_t *__restrict__ ring_list, int nlist, int lmax, in
     // per-thread twiddles, fixed for the whole kernel
     double2 wH, wA, wB;     // e^{i pi j0 / N}, e^{2 pi i j0 / N}, e^{2 pi i j1 / (N / R0)}
     {
-        const int j0 = tid & (Q0 - 1), j1 = tid & (Q0 / R1 - 1);
+        const int j0 = tid0 & (Q0 - 1), j1 = tid0 & (Q0 / R1 - 1);
         double s, c;
         sincospi((double)j0 / (double)N, &s, &c);
         wH = make_double2(c, s);
@@ -261,8 +283,14 @@ ringfft_direct_ct(const int32_t *__restrict__ ring_list, int nlist, int lmax, in
     };
     FrontEnd<NCH, BS, MC, true> fe;
     int vitem = blockIdx.x;
-    if (vitem < nitems) fe.prefetch(cell_ptr(ct_remap<NCH>(vitem, nitems)), L);
+    if (vitem < nitems) fe.prefetch(cell_ptr(ct_remap<NCH>(vitem, nitems)), L, tid0);
+    fe.touch();   // (so that the prefetch is known to be complete on BOTH edges into the loop: no wait in the fold)
     for (; vitem < nitems; vitem += gridDim.x) {
+        // the thread index is made opaque once per item: otherwise every LDS / pixel address of every pass (all of them
+        // functions of tid only) is hoisted out of this loop as a loop invariant, ~60 registers of them spill, and a
+        // scratch reload - a vmcnt-ordered load - in the store pass waits for the whole prefetch of the next item
+        int tid = tid0;
+        asm volatile("" : "+v"(tid));
         const int item = ct_remap<NCH>(vitem, nitems);
         const int ring = ring_list[item / ngrp];
         const int ch0 = (item % ngrp) * NCH;
@@ -270,8 +298,11 @@ ringfft_direct_ct(const int32_t *__restrict__ ring_list, int nlist, int lmax, in
         const double phi0_over_pi = phi0_a[ring] / M_PI;
         const int Lr = mcut[ring];
         __syncthreads();                                  // previous item's LDS reads are done
-        fe.fold(sm, cell_ptr(item), Lr, n, phi0_over_pi);
-        if (vitem + (int)gridDim.x < nitems) fe.prefetch(cell_ptr(ct_remap<NCH>(vitem + gridDim.x, nitems)), L);
+        fe.fold(sm, cell_ptr(item), Lr, n, phi0_over_pi, tid);
+        // the next item's cells: two passes (~7k cycles) ahead of the store pass, in front of which they are waited for
+        // (unconditional - the last iteration re-reads an item - so that the compiler can COUNT these loads in its
+        //  vmcnt waits; behind an `if` it assumes they may be absent and waits for everything instead)
+        fe.prefetch(cell_ptr(ct_remap<NCH>(min(vitem + (int)gridDim.x, nitems - 1), nitems)), L, tid);
         __syncthreads();
         // ---- pass 1 with the Hermitian step: butterfly j0 of channel ch reads X_k, k = j0 + r Q0, and the mirror
         //      partners X_{h-k} = element (Q0 - j0) + (R0 - 1 - r) Q0; Z_k = (X_k + conj X_{h-k}) + i w^k (X_k - conj X_{h-k}),
@@ -312,7 +343,7 @@ ringfft_direct_ct(const int32_t *__restrict__ ring_list, int nlist, int lmax, in
             }
         }
         __syncthreads();
-        ct_pass<N, NCH, BS, Q0, R1, 1, false>(sm, wB);
+        ct_pass<N, NCH, BS, Q0, R1, 1, false>(sm, wB, tid);
         __syncthreads();
         // ---- last pass (radix R2 on contiguous elements, no twiddles) with the pixel store: butterfly t = 16 k0 + k1
         //      holds the natural indices k0 + 16 k1 + 256 r.  Lane bits: 0-2 = k0 low, 3-5 = k1 low, 6 = k0 high,
@@ -320,6 +351,7 @@ ringfft_direct_ct(const int32_t *__restrict__ ring_list, int nlist, int lmax, in
         {
             constexpr int TOT = NCH * 256;
             constexpr int IT = (TOT + CT_T - 1) / CT_T;
+            fe.touch();
 #pragma unroll
             for (int it = 0; it < IT; it++) {
                 const int idx = tid + it * CT_T;
@@ -349,16 +381,22 @@ template <int P, int NCH, int MC>
 __global__ void __launch_bounds__(CT_T)
 ringfft_blu_ct(const int32_t *__restrict__ ring_list, int nlist, int nside, int lmax, int G, int nnu, long npix,
                const int32_t *__restrict__ nphi_a, const int64_t *__restrict__ start_a,
-               const double *__restrict__ phi0_a, const double *__restrict__ inter, double *__restrict__ maps,
-               const int64_t *__restrict__ boff, const int64_t *__restrict__ foff, const double2 *__restrict__ chirp,
-               const double2 *__restrict__ chirp2, const double2 *__restrict__ filt, const int32_t *__restrict__ mcut) {
+               const double *__restrict__ phi0_a, const double *inter, double *maps,
+               const int64_t *__restrict__ boff, const int64_t *__restrict__ foff, const double2 *chirp,
+               const double2 *chirp2, const double2 *filt, const int32_t *__restrict__ mcut) {
+    // (inter, maps, chirp, filt are deliberately NOT __restrict__: the compiler then may not move their loads across the
+    //  barriers / pixel stores, and the places where this kernel requests them - one phase ahead of their use, and all
+    //  of them completed before the first store - are the places where they are issued; with __restrict__ the chirp
+    //  loads of the last pass were sunk to their use and waited out in full)
     constexpr int R0 = Sch<P>::R0, R1 = Sch<P>::R1, R2 = Sch<P>::R2;
     constexpr int Q0 = P / R0;
     constexpr int BS = fpc(P) + K5_CH_SKEW;
     constexpr int HALF = (R0 / 2) * Q0;          // the non-zero half of the padded input: h <= HALF
-    constexpr int U = (HALF / 2 + CT_T) / CT_T;  // pre-pass iterations: pairs k <= h / 2 <= HALF / 2
+    // pre-pass iterations over the pairs k <= h / 2: h <= HALF, and for a power-of-two P even h <= HALF - 2 (h = HALF
+    // is itself a power of two: direct class)
+    constexpr int U = (HALF / 2 + ((P & (P - 1)) ? 1 : 0) + CT_T - 1) / CT_T;
     extern __shared__ __attribute__((aligned(16))) double2 sm[];
-    const int tid = threadIdx.x;
+    const int tid0 = threadIdx.x;
     const int L = lmax + 1;
     const int ngrp = (nnu + NCH - 1) / NCH;
     const int nitems = nlist * ngrp;
@@ -366,7 +404,7 @@ ringfft_blu_ct(const int32_t *__restrict__ ring_list, int nlist, int nside, int 
 
     double2 wA, wB;     // e^{2 pi i j0 / P}, e^{2 pi i j1 / (P / R0)}
     {
-        const int j0 = tid & (Q0 - 1), j1 = tid & (Q0 / R1 - 1);
+        const int j0 = tid0 & (Q0 - 1), j1 = tid0 & (Q0 / R1 - 1);
         double s, c;
         sincospi(2.0 * (double)j0 / (double)P, &s, &c);
         wA = make_double2(c, s);
@@ -379,9 +417,30 @@ ringfft_blu_ct(const int32_t *__restrict__ ring_list, int nlist, int nside, int 
         return inter + ((size_t)ring * G + (ch0 >> 2)) * L * 8 + (ch0 & 3);
     };
     FrontEnd<NCH, BS, MC, false> fe;
+    double2 cbn[U];    // chirp b_k, k = tid + u CT_T, of the NEXT item (index clamped: unused lanes load a valid slot)
+    auto load_cbn = [&](int item, int t) {
+        const int ring = ring_list[item / ngrp];
+        const int ic = ring + 1 < nside ? ring + 1 : 4 * nside - (ring + 1);
+        const double2 *b = chirp + boff[ic - 1];
+        const int hh = nphi_a[ring] >> 1;
+#pragma unroll
+        for (int u = 0; u < U; u++) cbn[u] = b[min(t + u * CT_T, hh - 1)];
+    };
     int vitem = blockIdx.x;
-    if (vitem < nitems) fe.prefetch(cell_ptr(ct_remap<NCH>(vitem, nitems)), L);
+    if (vitem < nitems) {
+        fe.prefetch(cell_ptr(ct_remap<NCH>(vitem, nitems)), L, tid0);
+        load_cbn(ct_remap<NCH>(vitem, nitems), tid0);
+    }
+    fe.touch();   // complete on both edges into the loop (FrontEnd::touch)
+#pragma unroll
+    for (int u = 0; u < U; u++) asm volatile("" ::"v"(cbn[u].x), "v"(cbn[u].y));
+#if CT_STAMPS
+    unsigned long long ct_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, ct_last;
+    { unsigned long long _t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)::"memory"); ct_last = _t; }
+#endif
     for (; vitem < nitems; vitem += gridDim.x) {
+        int tid = tid0;                                   // opaque per item: see ringfft_direct_ct
+        asm volatile("" : "+v"(tid));
         const int item = ct_remap<NCH>(vitem, nitems);
         const int ring = ring_list[item / ngrp];
         const int ch0 = (item % ngrp) * NCH;
@@ -392,38 +451,48 @@ ringfft_blu_ct(const int32_t *__restrict__ ring_list, int nlist, int nside, int 
         const int icap = ring + 1 < nside ? ring + 1 : 4 * nside - (ring + 1);
         const int Lr = mcut[ring];
         const double2 *bch = chirp + boff[icap - 1];
-        const double2 *bch2 = chirp2 + boff[icap - 1];
-        // chirp values of the pre-pass, requested before the fold (older than the next item's prefetch, so the
-        // in-order vmcnt wait in front of the pre-pass does not wait for that)
-        double2 cb[U][4];
+        // filter values of the register-fused middle (storage positions t R2 + r; the same for every channel), requested
+        // first thing: vmcnt completes in order and the pixel stores of the previous item are ahead of these loads;
+        // by the middle pass they have long been acknowledged
+        const double2 *f = filt + foff[icap - 1];
+        double2 fl[R2];
+        {
+            const int t = tid & (P / R2 - 1);
 #pragma unroll
-        for (int u = 0; u < U; u++) {
-            const int k = tid + u * CT_T;
-            const int ka = min(k, h - 1), kb = min(max(h - k, 0), h - 1);   // clamped: unused lanes load a valid slot
-            cb[u][0] = bch[ka];
-            cb[u][1] = bch2[ka];
-            cb[u][2] = bch[kb];
-            cb[u][3] = bch2[kb];
+            for (int r = 0; r < R2; r++) fl[r] = f[t * R2 + r];
         }
+        // chirp b_k of the pre-pass pairs: fetched with the cells (one item ahead, before the previous item's stores)
+        double2 cb[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) cb[u] = cbn[u];
         __syncthreads();                                  // previous item's LDS reads are done
-        fe.fold(sm, cell_ptr(item), Lr, n, phi0_over_pi);
-        if (vitem + (int)gridDim.x < nitems) fe.prefetch(cell_ptr(ct_remap<NCH>(vitem + gridDim.x, nitems)), L);
+        CTSTAMP(0);
+        fe.fold(sm, cell_ptr(item), Lr, n, phi0_over_pi, tid);
+        CTSTAMP(1);
         __syncthreads();
-        // ---- pre-pass: y_k = b_k (X_k + conj X_{h-k}) + (i w^k b_k) (X_k - conj X_{h-k}) for the pairs (k, h - k),
+        CTSTAMP(2);
+        // ---- pre-pass for the pairs (k, h - k), with w = e^{2 pi i / n} and b_{h-k} = b_k, w^{h-k} = -conj(w^k) (h even):
+        //        y_k     = b_k [(X_k + conj X_{h-k}) + i w^k (X_k - conj X_{h-k})]
+        //        y_{h-k} = b_k [(X_{h-k} + conj X_k) - i conj(w^k) (X_{h-k} - conj X_k)]
+        //      w^k = e^{i pi k / h} is the square of the fold phase e^{i k phi0} (phi0 = pi / 2h on a cap ring);
         //      zeros on [h, HALF)
+        static_assert(U <= 2, "two fold phases are kept");
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const int k = tid + u * CT_T;
             if (2 * k <= h) {
                 const int k2 = h - k;
+                const double2 wk = csqr(u == 0 ? fe.ph0 : fe.ph1);
+                const double2 iw = make_double2(-wk.y, wk.x);                 // i w^k
+                const double2 miwc = make_double2(-wk.y, -wk.x);               // -i conj(w^k)
 #pragma unroll
                 for (int c = 0; c < NCH; c++) {
                     double2 *bc = sm + c * BS;
                     const double2 xa = bc[fpad(k)], xb = bc[fpad(k2)];
                     const double2 s1 = make_double2(xa.x + xb.x, xa.y - xb.y), d1 = make_double2(xa.x - xb.x, xa.y + xb.y);
                     const double2 s2 = make_double2(s1.x, -s1.y), d2 = make_double2(-d1.x, d1.y);  // (xb + conj xa), (xb - conj xa)
-                    const double2 zk = cadd(cmul(cb[u][0], s1), cmul(cb[u][1], d1));
-                    const double2 zk2 = cadd(cmul(cb[u][2], s2), cmul(cb[u][3], d2));
+                    const double2 zk = cmul(cb[u], cadd(s1, cmul(iw, d1)));
+                    const double2 zk2 = cmul(cb[u], cadd(s2, cmul(miwc, d2)));
                     bc[fpad(k)] = zk;
                     if (k > 0) {
                         if (k2 != k) bc[fpad(k2)] = zk2;
@@ -436,15 +505,8 @@ ringfft_blu_ct(const int32_t *__restrict__ ring_list, int nlist, int nside, int 
         for (int j = h + 1 + tid; j < HALF; j += CT_T)
 #pragma unroll
             for (int c = 0; c < NCH; c++) sm[c * BS + fpad(j)] = make_double2(0.0, 0.0);
-        // filter values of the register-fused middle (storage positions t R2 + r; the same for every channel)
-        const double2 *f = filt + foff[icap - 1];
-        double2 fl[R2];
-        {
-            const int t = tid & (P / R2 - 1);
-#pragma unroll
-            for (int r = 0; r < R2; r++) fl[r] = f[t * R2 + r];
-        }
         __syncthreads();
+        CTSTAMP(3);
         // ---- forward pass 1 (sign -), inputs r >= R0 / 2 are the zero padding and are not read
         {
             constexpr int TOT = NCH * Q0;
@@ -467,9 +529,20 @@ ringfft_blu_ct(const int32_t *__restrict__ ring_list, int nlist, int nside, int 
                 for (int r = 0; r < R0; r++) p[fpc(r * Q0)] = x[r];
             }
         }
+        // the next item's cells and pre-pass chirps: three passes ahead of the last pass, whose wait for its own
+        // (younger) chirp loads completes them before the first pixel store is issued - see FrontEnd::touch
+        // (unconditional, the last iteration re-reads an item: loads behind an `if` cannot be counted by the compiler's
+        //  vmcnt bookkeeping, and the wait for the filter values in the middle pass then waits for these as well)
+        {
+            const int nitem = ct_remap<NCH>(min(vitem + (int)gridDim.x, nitems - 1), nitems);
+            fe.prefetch(cell_ptr(nitem), L, tid);
+            load_cbn(nitem, tid);
+        }
         __syncthreads();
-        ct_pass<P, NCH, BS, Q0, R1, -1, false>(sm, wB);
+        CTSTAMP(4);
+        ct_pass<P, NCH, BS, Q0, R1, -1, false>(sm, wB, tid);
         __syncthreads();
+        CTSTAMP(5);
         // ---- last forward pass, filter, first inverse pass: R2 contiguous elements, no twiddles, in registers
         {
             constexpr int NB = P / R2, TOT = NCH * NB;
@@ -499,8 +572,10 @@ ringfft_blu_ct(const int32_t *__restrict__ ring_list, int nlist, int nside, int 
             for (int r = 0; r < R0 / 2; r++) ob[r] = bch[min(j0 + r * Q0, h - 1)];
         }
         __syncthreads();
-        ct_pass<P, NCH, BS, Q0, R1, 1, true>(sm, wB);
+        CTSTAMP(6);
+        ct_pass<P, NCH, BS, Q0, R1, 1, true>(sm, wB, tid);
         __syncthreads();
+        CTSTAMP(7);
         // ---- last inverse pass (sign +): only the outputs j0 + r Q0 < h exist; times b_j / P, pixel pairs to HBM
         {
             constexpr int TOT = NCH * Q0;
@@ -531,7 +606,12 @@ ringfft_blu_ct(const int32_t *__restrict__ ring_list, int nlist, int nside, int 
                 }
             }
         }
+        CTSTAMP(8);
     }
+#if CT_STAMPS
+    if ((tid0 & 63) == 0)
+        for (int k = 0; k < 9; k++) atomicAdd(&g_ct_stamps[k], ct_acc[k]);
+#endif
 }
 
 // ------------------------------------------------------------------------------------
@@ -566,6 +646,18 @@ static int launch_blu(corahip_ctx *ctx, const corahip_sht_plan *p, const corahip
                                                                p->d_start, p->d_phi0, inter, maps, p->d_blu_boff,
                                                                p->d_blu_foff, p->d_bchirp, p->d_bchirp2, p->d_bfilt, p->d_mcut);
     LAUNCH_CHECK();
+#if CT_STAMPS
+    {
+        unsigned long long hs[12], z[12] = {0};
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        HIP_TRY(hipMemcpyFromSymbol(hs, HIP_SYMBOL(g_ct_stamps), sizeof(hs)));
+        const double per = 1.0 / ((double)nitems * (CT_T / 64));   // cycles per item and wave
+        fprintf(stderr, "K5ct P=%d nch=%d items=%ld: cycles/item  top %.0f fold %.0f pf+bar %.0f pre %.0f F1 %.0f F2 %.0f mid %.0f I2 %.0f I3 %.0f\n",
+                P, NCH, nitems, hs[0] * per, hs[1] * per, hs[2] * per, hs[3] * per, hs[4] * per, hs[5] * per, hs[6] * per,
+                hs[7] * per, hs[8] * per);
+        HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_ct_stamps), z, sizeof(z)));
+    }
+#endif
     return 0;
 }
 
