@@ -119,7 +119,7 @@ struct cell_ct {
     double re[NCH], im[NCH];
 };
 template <int NCH>
-__device__ __forceinline__ static cell_ct<NCH> load_cell_ct(const double *__restrict__ cell, unsigned m) {
+__device__ __forceinline__ static cell_ct<NCH> load_cell_ct(const double *cell, unsigned m) {
     cell_ct<NCH> c;
     if (NCH == 4) {
         const double4 a = *reinterpret_cast<const double4 *>(cell + m * 8u);
@@ -177,10 +177,14 @@ __device__ __forceinline__ static void fold_cell(double2 *sm, int m, int n, int 
 template <int NCH, int BS, int MC, bool TAIL>
 struct FrontEnd {
     cell_ct<NCH> pf[MC + (TAIL ? 1 : 0)];
-    __device__ __forceinline__ void prefetch(const double *__restrict__ cell, int L, int tid) {
+    // PART 0 / 1: first / second half of the cells (the requests of one item are spread over two phases: a burst of all
+    // of them at once blocks every wave of the workgroup at the 64 B/clk of the vector memory path); -1: all
+    template <int PART = -1>
+    __device__ __forceinline__ void prefetch(const double *cell, int L, int tid) {
+        constexpr int K0 = PART == 1 ? (MC + 1) / 2 : 0, K1 = PART == 0 ? (MC + 1) / 2 : MC;
 #pragma unroll
-        for (int k = 0; k < MC; k++) pf[k] = load_cell_ct<NCH>(cell + (size_t)k * CT_T * 8, tid);
-        if (TAIL) pf[MC] = load_cell_ct<NCH>(cell, (unsigned)min(tid + MC * CT_T, L - 1));
+        for (int k = K0; k < K1; k++) pf[k] = load_cell_ct<NCH>(cell + (size_t)k * CT_T * 8, tid);
+        if (TAIL && PART != 0) pf[MC] = load_cell_ct<NCH>(cell, (unsigned)min(tid + MC * CT_T, L - 1));
     }
     // make the compiler wait for the prefetch HERE.  vmcnt completes in order and the pixel stores are conditional, so
     // the compiler cannot count them: a wait for a prefetch register placed after the stores becomes vmcnt(0) and
@@ -251,7 +255,7 @@ template <int N, int NCH, int MC>
 __global__ void __launch_bounds__(CT_T)
 ringfft_direct_ct(const int32_t *__restrict__ ring_list, int nlist, int lmax, int G, int nnu, long npix,
                   const int64_t *__restrict__ start_a, const double *__restrict__ phi0_a,
-                  const double *__restrict__ inter, double *__restrict__ maps, const int32_t *__restrict__ mcut) {
+                  const double *inter, double *maps, const int32_t *__restrict__ mcut) {   // (not __restrict__: see ringfft_blu_ct)
     constexpr int R0 = Sch<N>::R0, R1 = Sch<N>::R1, R2 = Sch<N>::R2;
     static_assert(R0 == 16 && R1 == 16, "digit map of the fused store assumes 16 x 16 x R2");
     constexpr int Q0 = N / R0;              // stride of the first pass
@@ -302,7 +306,8 @@ ringfft_direct_ct(const int32_t *__restrict__ ring_list, int nlist, int lmax, in
         // the next item's cells: two passes (~7k cycles) ahead of the store pass, in front of which they are waited for
         // (unconditional - the last iteration re-reads an item - so that the compiler can COUNT these loads in its
         //  vmcnt waits; behind an `if` it assumes they may be absent and waits for everything instead)
-        fe.prefetch(cell_ptr(ct_remap<NCH>(min(vitem + (int)gridDim.x, nitems - 1), nitems)), L, tid);
+        const double *ncell = cell_ptr(ct_remap<NCH>(min(vitem + (int)gridDim.x, nitems - 1), nitems));
+        fe.template prefetch<0>(ncell, L, tid);
         __syncthreads();
         // ---- pass 1 with the Hermitian step: butterfly j0 of channel ch reads X_k, k = j0 + r Q0, and the mirror
         //      partners X_{h-k} = element (Q0 - j0) + (R0 - 1 - r) Q0; Z_k = (X_k + conj X_{h-k}) + i w^k (X_k - conj X_{h-k}),
@@ -331,6 +336,7 @@ ringfft_direct_ct(const int32_t *__restrict__ ring_list, int nlist, int lmax, in
                 }
             }
             __syncthreads();                              // every raw X has been read
+            fe.template prefetch<1>(ncell, L, tid);
 #pragma unroll
             for (int it = 0; it < IT; it++) {
                 const int idx = tid + it * CT_T;
@@ -454,13 +460,10 @@ ringfft_blu_ct(const int32_t *__restrict__ ring_list, int nlist, int nside, int 
         // filter values of the register-fused middle (storage positions t R2 + r; the same for every channel), requested
         // first thing: vmcnt completes in order and the pixel stores of the previous item are ahead of these loads;
         // by the middle pass they have long been acknowledged
-        const double2 *f = filt + foff[icap - 1];
+        const double2 *f = filt + foff[icap - 1] + (size_t)(tid & (P / R2 - 1)) * R2;
         double2 fl[R2];
-        {
-            const int t = tid & (P / R2 - 1);
 #pragma unroll
-            for (int r = 0; r < R2; r++) fl[r] = f[t * R2 + r];
-        }
+        for (int r = 0; r < (R2 + 1) / 2; r++) fl[r] = f[r];     // (second half behind the fold: spread requests)
         // chirp b_k of the pre-pass pairs: fetched with the cells (one item ahead, before the previous item's stores)
         double2 cb[U];
 #pragma unroll
@@ -469,6 +472,8 @@ ringfft_blu_ct(const int32_t *__restrict__ ring_list, int nlist, int nside, int 
         CTSTAMP(0);
         fe.fold(sm, cell_ptr(item), Lr, n, phi0_over_pi, tid);
         CTSTAMP(1);
+#pragma unroll
+        for (int r = (R2 + 1) / 2; r < R2; r++) fl[r] = f[r];
         __syncthreads();
         CTSTAMP(2);
         // ---- pre-pass for the pairs (k, h - k), with w = e^{2 pi i / n} and b_{h-k} = b_k, w^{h-k} = -conj(w^k) (h even):
@@ -505,6 +510,13 @@ ringfft_blu_ct(const int32_t *__restrict__ ring_list, int nlist, int nside, int 
         for (int j = h + 1 + tid; j < HALF; j += CT_T)
 #pragma unroll
             for (int c = 0; c < NCH; c++) sm[c * BS + fpad(j)] = make_double2(0.0, 0.0);
+        // the next item's cells and pre-pass chirps, in two parts (here and behind forward pass 1): three passes ahead
+        // of the last pass, whose wait for its own (younger) chirp loads completes them before the first pixel store
+        // is issued - see FrontEnd::touch.  Unconditional (the last iteration re-reads an item): loads behind an `if`
+        // cannot be counted by the compiler's vmcnt bookkeeping, and the wait for the filter values in the middle
+        // pass would then wait for these as well.
+        const int nitem = ct_remap<NCH>(min(vitem + (int)gridDim.x, nitems - 1), nitems);
+        fe.template prefetch<0>(cell_ptr(nitem), L, tid);
         __syncthreads();
         CTSTAMP(3);
         // ---- forward pass 1 (sign -), inputs r >= R0 / 2 are the zero padding and are not read
@@ -529,15 +541,8 @@ ringfft_blu_ct(const int32_t *__restrict__ ring_list, int nlist, int nside, int 
                 for (int r = 0; r < R0; r++) p[fpc(r * Q0)] = x[r];
             }
         }
-        // the next item's cells and pre-pass chirps: three passes ahead of the last pass, whose wait for its own
-        // (younger) chirp loads completes them before the first pixel store is issued - see FrontEnd::touch
-        // (unconditional, the last iteration re-reads an item: loads behind an `if` cannot be counted by the compiler's
-        //  vmcnt bookkeeping, and the wait for the filter values in the middle pass then waits for these as well)
-        {
-            const int nitem = ct_remap<NCH>(min(vitem + (int)gridDim.x, nitems - 1), nitems);
-            fe.prefetch(cell_ptr(nitem), L, tid);
-            load_cbn(nitem, tid);
-        }
+        fe.template prefetch<1>(cell_ptr(nitem), L, tid);
+        load_cbn(nitem, tid);
         __syncthreads();
         CTSTAMP(4);
         ct_pass<P, NCH, BS, Q0, R1, -1, false>(sm, wB, tid);
