@@ -63,6 +63,10 @@ SIGNATURES = {
     "corahip_spin2_combine": (c_int, [c_void_p, c_void_p, PTR, c_int, c_int, PTR, c_int]),
     "corahip_xi_table_average": (c_int, [c_void_p, PTR, PTR, PTR, c_int, c_int, c_double, c_double, PTR, c_int, PTR, PTR,
                                          c_int, c_int, PTR]),
+    "corahip_ps_table21cm": (c_int, [c_void_p, PTR, PTR, PTR, c_int, c_int, c_double, PTR, c_int, PTR, c_int, c_double,
+                                     PTR, PTR, PTR, PTR]),
+    "corahip_dct1_workspace_bytes": (c_int, [ctypes.c_long, c_int, ctypes.POINTER(c_size_t)]),
+    "corahip_dct1_rows": (c_int, [c_void_p, PTR, ctypes.c_long, c_int, c_double, c_void_p, c_size_t]),
     "corahip_legendre_project": (c_int, [c_void_p, PTR, PTR, c_int, c_int, PTR, ctypes.c_long, PTR]),
     "corahip_fft_c2c": (c_int, [c_void_p, PTR, c_int, PTR, c_int, c_int]),
     "corahip_irfftn": (c_int, [c_void_p, PTR, c_int, PTR, c_int, PTR]),
@@ -250,6 +254,34 @@ class Context:
         out = self.empty((nl, F, F))
         _check(self.lib.corahip_romb_reduce(self.h, self._f64(clt), nl, F, zint, self._f64(w), self._f64(out)))
         return out
+
+    # -- K0 ---------------------------------------------------------------------------
+    def ps_table21cm(self, kperp, kpar, spline=None, kstar=0.0, freq_window=0.0, dd=None):
+        """(dd, dv, vv) device tables [nkperp, nkpar] BEFORE the DCT: from a spline description
+        ``spline = (loglog, x, y, y2)`` (device arrays) or from a host-evaluated ``dd`` (device array)."""
+        nkperp, nkpar = kperp.numel(), kpar.numel()
+        dv, vv = self.empty((nkperp, nkpar)), self.empty((nkperp, nkpar))
+        if dd is None:
+            loglog, kx, ky, ky2 = spline
+            dd = self.empty((nkperp, nkpar))
+            _check(self.lib.corahip_ps_table21cm(self.h, self._f64(kx), self._f64(ky), self._f64(ky2), kx.numel(),
+                                                 1 if loglog else 0, float(kstar), self._f64(kperp), nkperp,
+                                                 self._f64(kpar), nkpar, float(freq_window), None, self._f64(dd),
+                                                 self._f64(dv), self._f64(vv)))
+        else:
+            _check(self.lib.corahip_ps_table21cm(self.h, None, None, None, 0, 0, 0.0, self._f64(kperp), nkperp,
+                                                 self._f64(kpar), nkpar, 0.0, self._f64(dd), None, self._f64(dv),
+                                                 self._f64(vv)))
+        return dd, dv, vv
+
+    def dct1_rows(self, data, scale=1.0):
+        """In place: every row of the device array ``data`` [nrows, n] -> scipy.fftpack.dct(row, type=1) * scale."""
+        nrows, n = data.shape
+        b = c_size_t()
+        _check(self.lib.corahip_dct1_workspace_bytes(nrows, n, ctypes.byref(b)))
+        ws = self.workspace(int(b.value))
+        _check(self.lib.corahip_dct1_rows(self.h, self._f64(data), nrows, n, float(scale), self._p(ws), int(b.value)))
+        return data
 
     # -- K2 ---------------------------------------------------------------------------
     def factor_batched(self, C, jitter_rel=1e-14, eig_thresh=1e-16):

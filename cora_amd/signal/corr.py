@@ -18,7 +18,6 @@ are outside this package's scope.
 import math
 
 import numpy as np
-import scipy.fftpack
 
 from .. import _lib
 from ..core import gaussianfield
@@ -191,40 +190,72 @@ class RedshiftCorrelation(object):
         return acube
 
     # ---- table build / cache (corr.py:870-887, 909-942) ---------------------------------
-    def _build_tables(self):
-        kperp = np.logspace(np.log10(self.kperpmin), np.log10(self.kperpmax), self.nkperp)[:, np.newaxis]
-        kpar = np.linspace(0, self.kparmax, self.nkpar)[np.newaxis, :]
-        k = (kpar**2 + kperp**2) ** 0.5
-        mu2 = kpar**2 / k**2
-        window = np.sinc(kpar * self._freq_window / (2 * np.pi)) ** 2
-        dd = (self.ps_vv(k, kpar / k) if self.ps_2d else self.ps_vv(k)) * window
+    # K0: the tables are BUILT ON THE DEVICE (csrc/tables21.hip): P(k) on the 500 x 32768 grid - by the device spline
+    # evaluator when ps_vv is the library's own spline form (Corr21cm: exp(-k^2 / 2 k*^2) LogInterpolater), by one
+    # vectorised host call of the user's callable otherwise (it IS a Python callback) - then mu^2 / mu^4 and the
+    # DCT-I along k_par on the GPU.  They stay in HBM; the host copies (`_aps_dd` ...) are made only when asked for.
+    def _ps_spline_plan(self):
+        """(interpolater, kstar) when ``ps_vv`` is still the spline-form callable a subclass registered."""
+        plan = getattr(self, "_ps_plan", None)
+        if plan is None or self.ps_2d or self.ps_vv is not plan["callable"]:
+            return None
+        return plan["spline"], float(plan["kstar"]())
+
+    def _build_tables(self, ctx=None):
+        ctx = ctx if ctx is not None else _lib.get_context()
+        kperp = np.logspace(np.log10(self.kperpmin), np.log10(self.kperpmax), self.nkperp)
+        kpar = np.linspace(0, self.kparmax, self.nkpar)
+        kt_d, kp_d = ctx.to_device(kperp), ctx.to_device(kpar)
+        sp = self._ps_spline_plan()
+        kind = sp[0]._device_spline()[0] if sp is not None else None
+        if sp is not None and kind in (0, 1):
+            _, x, y, y2, _, _ = sp[0]._device_spline()
+            dd, dv, vv = ctx.ps_table21cm(kt_d, kp_d, spline=(kind == 1, ctx.to_device(x), ctx.to_device(y), ctx.to_device(y2)),
+                                          kstar=sp[1], freq_window=self._freq_window)
+        else:
+            kpar2, kperp2 = kpar[np.newaxis, :], kperp[:, np.newaxis]
+            k = (kpar2**2 + kperp2**2) ** 0.5
+            window = np.sinc(kpar2 * self._freq_window / (2 * np.pi)) ** 2
+            dd_h = (self.ps_vv(k, kpar2 / k) if self.ps_2d else self.ps_vv(k)) * window
+            dd, dv, vv = ctx.ps_table21cm(kt_d, kp_d, dd=ctx.to_device(np.ascontiguousarray(dd_h, dtype=np.float64)))
         norm = self.kparmax / (2 * self.nkpar)
-        self._aps_dd = scipy.fftpack.dct(dd, type=1) * norm
-        self._aps_dv = scipy.fftpack.dct(dd * mu2, type=1) * norm
-        self._aps_vv = scipy.fftpack.dct(dd * mu2**2, type=1) * norm
+        for t in (dd, dv, vv):
+            ctx.dct1_rows(t, norm)
+        self._dev_tables = {ctx.device.index: (dd, dv, vv)}
+        self._host_tables = None
         self._aps_cache = True
-        self._dev_tables = {}
+
+    def _host_copy(self, i):
+        if not self._aps_cache:
+            self._build_tables()
+        if getattr(self, "_host_tables", None) is None:
+            dev = next(iter(self._dev_tables.values()))
+            self._host_tables = tuple(t.cpu().numpy() for t in dev)
+        return self._host_tables[i]
+
+    _aps_dd = property(lambda self: self._host_copy(0))
+    _aps_dv = property(lambda self: self._host_copy(1))
+    _aps_vv = property(lambda self: self._host_copy(2))
 
     def save_fft_cache(self, fname):
         """Save the three lookup tables (corr.py:870-877)."""
-        if not self._aps_cache:
-            self._build_tables()
         np.savez(fname, dd=self._aps_dd, dv=self._aps_dv, vv=self._aps_vv)
 
     def load_fft_cache(self, fname):
         """Load lookup tables saved by :meth:`save_fft_cache` (corr.py:879-887)."""
         a = np.load(fname)
-        self._aps_dd, self._aps_dv, self._aps_vv = a["dd"], a["dv"], a["vv"]
-        self.nkperp, self.nkpar = self._aps_dd.shape
+        self._host_tables = (a["dd"], a["dv"], a["vv"])
+        self.nkperp, self.nkpar = self._host_tables[0].shape
         self._aps_cache = True
         self._dev_tables = {}
 
     def _tables_on(self, ctx):
-        if not self._aps_cache:
-            self._build_tables()
         key = ctx.device.index
         if key not in self._dev_tables:
-            self._dev_tables[key] = tuple(ctx.to_device(t) for t in (self._aps_dd, self._aps_dv, self._aps_vv))
+            if self._aps_cache and getattr(self, "_host_tables", None) is not None:
+                self._dev_tables[key] = tuple(ctx.to_device(t) for t in self._host_tables)   # loaded cache / other GPU
+            else:
+                self._build_tables(ctx)
         return self._dev_tables[key]
 
     # ---- per-redshift quantities (corr.py:944-951) --------------------------------------

@@ -26,6 +26,8 @@ class Corr21cm(corr.RedshiftCorrelation, maps.Sky3d):
             redshift = 1.5
             c1 = cs.LogInterpolater.fromfile(psfile)
             ps = lambda k: np.exp(-0.5 * k**2 / self._kstar**2) * c1(k)
+            # the same function in the form the device table build evaluates itself (csrc/tables21.hip)
+            self._ps_plan = dict(callable=ps, spline=c1, kstar=lambda: self._kstar)
         self._sigma_v = sigma_v
         corr.RedshiftCorrelation.__init__(self, ps_vv=ps, redshift=redshift)
 

@@ -210,6 +210,24 @@ int corahip_spin2_ring_scale(corahip_ctx *ctx, corahip_sht_plan *plan, const dou
 int corahip_spin2_combine(corahip_ctx *ctx, corahip_sht_plan *plan, const double *alm6_dev, int g6, int nfields,
                           double *alm_eb_dev, int gout);
 
+/* ---- K0: the 21cm lookup tables (SURVEY 8 row a4 / section 2a "K0") ------------------------------
+ * Replaces the one-off setup of RedshiftCorrelation.angular_powerspectrum_fft (cora/signal/corr.py:909-942)
+ * and the spline evaluation behind it (cora/util/cubicspline.pyx:126-175,254-288).
+ * ps_table21cm: dd, dv = dd mu^2, vv = dd mu^4 on the [nkperp][nkpar] grid (kperp, kpar: device arrays, as numpy's
+ *   logspace / linspace made them).  dd_in == NULL: dd = P(k) sinc^2(kpar freq_window / 2 pi) with P(k) a natural
+ *   cubic spline, knots (x, y, y'') [nknot] on the device - loglog != 0: exp(spline(log k)) (LogInterpolater) - times
+ *   exp(-k^2 / 2 kstar^2) when kstar > 0 (cora/signal/corr21cm.py:24-29).  dd_in != NULL: dd_in is dd as the host
+ *   evaluated it (any other ps_vv callable); only dv and vv are made (dd may be NULL).
+ * dct1_rows: scipy.fftpack.dct(x, type=1) * scale of every row of data [nrows][n], in place, as one complex DFT
+ *   of length n - 1 by the prime-factor (Good-Thomas) map: n - 1 must split into at most 6 pairwise coprime prime
+ *   powers <= 2048 (nkpar = 32768: 32767 = 7 * 31 * 151).  workspace: dct1_workspace_bytes(nrows, n). */
+int corahip_ps_table21cm(corahip_ctx *ctx, const double *knots_x, const double *knots_y, const double *knots_y2,
+                         int nknot, int loglog, double kstar, const double *kperp, int nkperp, const double *kpar,
+                         int nkpar, double freq_window, const double *dd_in, double *dd, double *dv, double *vv);
+int corahip_dct1_workspace_bytes(long nrows, int n, size_t *bytes);
+int corahip_dct1_rows(corahip_ctx *ctx, double *data, long nrows, int n, double scale, void *workspace,
+                      size_t workspace_bytes);
+
 /* ---- xi(r) -> C_l(chi, chi') ----------------------------------------------
  * Replaces corrfunc.corr_to_clarray (cora/signal/corrfunc.py:290-400).
  * xi_table_average: for every Gauss-Legendre node mu_m and channel pair (i, j) the radial-bin average

@@ -312,6 +312,64 @@ def _shared_corr21cm():
     return _CR["cr"]
 
 
+def test_21cm_tables_built_on_device(ctx, golden, model21):
+    """K0 (row a4): P(k) spline grid + mu^2 / mu^4 + DCT-I along k_par on the GPU (csrc/tables21.hip) against slices
+    of the reference's own tables, the full tables of the oracle, and - for a ps_vv callable the library does not
+    know - the host-evaluated P(k) route."""
+    import time
+
+    from cora_amd.signal import corr21cm
+
+    cr = corr21cm.Corr21cm()
+    t0 = time.time()
+    dev = cr._tables_on(ctx)
+    ctx.sync()
+    print("device table build: %.3f s" % (time.time() - t0))
+    ix = np.ix_(golden["tab_rows"], golden["tab_cols"])
+    for i, nm in enumerate(("dd", "dv", "vv")):
+        t = getattr(cr, "_aps_" + nm)
+        assert t.shape == (500, 32768)
+        assert np.abs(t[ix] - golden["tab_" + nm]).max() <= 1e-13 * np.abs(golden["tab_" + nm]).max(), nm
+        ref = model21.tables()[i]
+        err = np.abs(t - ref).max() / np.abs(ref).max()
+        print("table", nm, "device vs oracle (scipy DCT): %.2e" % err)
+        assert err <= 1e-13, (nm, err)
+    # a user-supplied power spectrum: evaluated on the host once, everything else on the device
+    cr2 = corr21cm.Corr21cm(ps=lambda k: 1.0 / (1.0 + k * k), redshift=1.5)
+    assert cr2._ps_spline_plan() is None
+    dd = cr2._aps_dd
+    kperp = np.logspace(-4, np.log10(40.0), 500)[:, None]
+    kpar = np.linspace(0, 20.0, 32768)[None, :]
+    import scipy.fftpack
+
+    ref = scipy.fftpack.dct(1.0 / (1.0 + kpar**2 + kperp**2), type=1) * (20.0 / (2 * 32768))
+    assert np.abs(dd - ref).max() <= 1e-13 * np.abs(ref).max()
+    # replacing ps_vv after construction drops the spline plan as well
+    cr.ps_vv = lambda k: k
+    assert cr._ps_spline_plan() is None
+
+
+@pytest.mark.parametrize("n", [4, 16, 106, 1156, 32768])
+def test_dct1_rows_vs_scipy(ctx, n):
+    """corahip_dct1_rows (prime-factor DFT of length n - 1) == scipy.fftpack.dct(type=1), several factorisations."""
+    import scipy.fftpack
+    import torch
+
+    rng = np.random.default_rng(n)
+    x = rng.standard_normal((5, n)) * np.exp(-np.arange(n) / (0.3 * n))
+    got = ctx.dct1_rows(torch.from_numpy(x.copy()).to(ctx.device), 0.25).cpu().numpy()
+    ref = scipy.fftpack.dct(x, type=1) * 0.25
+    assert np.abs(got - ref).max() <= 1e-13 * np.abs(ref).max()
+
+
+def test_dct1_rows_rejects_large_prime(ctx):
+    import torch
+    from cora_amd._lib import CoraHipError
+
+    with pytest.raises(CoraHipError):
+        ctx.dct1_rows(torch.zeros((1, 4099 + 1), dtype=torch.float64, device=ctx.device))   # 4099 is prime > 2048
+
+
 def test_clarray_21cm_many_channels(model21):
     """F = 40 channels (3 tiles of 16: exercises tile mirroring) vs the oracle."""
     from cora_amd.core import skysim

@@ -181,18 +181,6 @@ def test_corr21cm_host_quantities(golden):
     assert cr._clarray_plan(lambda l, a, b: 0) is None
 
 
-def test_21cm_table_build_matches_reference(golden):
-    """Host table build (P(k) spline grid + DCT-I) against slices of the reference's tables."""
-    from cora_amd.signal import corr21cm
-
-    cr = corr21cm.Corr21cm()
-    cr._build_tables()
-    ix = np.ix_(golden["tab_rows"], golden["tab_cols"])
-    for nm in ("dd", "dv", "vv"):
-        t = getattr(cr, "_aps_" + nm)
-        assert np.abs(t[ix] - golden["tab_" + nm]).max() <= 1e-13 * np.abs(golden["tab_" + nm]).max()
-
-
 # ------------------------------------------------------------------ cubic spline (mirrors tests/test_cubicspline.py)
 def test_cubicspline_usage_errors():
     from cora_amd.util import cubicspline as cs

@@ -1,16 +1,20 @@
 #!/bin/bash
-# Round profile: rocprofv3 kernel stats of the default bench + PMC passes for K4 (separate --pmc runs).
+# Round profile: rocprofv3 kernel stats of the default bench + PMC passes (separate --pmc runs, kernel-trace only)
+# for every kernel of the step: SQ pass, FETCH_SIZE pass, WRITE_SIZE pass.  tools/pmc_summary.py turns the CSVs into
+# profiles/<tag>_pmc.json (per-kernel HBM bytes per launch, GB/s, MFMA instructions).
 # usage (on the GPU box, from the repo root): bash tools/profile_round.sh <tag>
 export TMPDIR=/tmp
-TAG=${1:-r01}
+TAG=${1:-r02}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd $GRAFT_REPO_ROOT
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o stats -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/stats.err
 run() { n=$1; shift
-  rocprofv3 --kernel-trace --pmc "$@" --kernel-include-regex "legendre_kernel" --output-format csv -d $OUT -o $n -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline > /dev/null 2> $OUT/$n.err
+  rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT -o $n -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline > /dev/null 2> $OUT/$n.err
 }
 run sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_F64 SQ_WAVES
 run tcc2 FETCH_SIZE GRBM_GUI_ACTIVE
 run tcc3 WRITE_SIZE GRBM_GUI_ACTIVE
+python3 tools/pmc_summary.py $OUT $TAG > $OUT/${TAG}_pmc.json
+cat $OUT/${TAG}_pmc.json | head -80
 find $OUT -name "*.csv" | head -20
