@@ -92,6 +92,7 @@ def main():
     ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--warm", action="store_true", help="time the warm path only (factors cached)")
+    ap.add_argument("--no-host-delivered", action="store_true", help="skip the PCIe-inclusive (numpy-returning) leg")
     # test hooks (not used by the driver): run N ranks on ONE GPU over gloo and print per-channel checksums
     ap.add_argument("--dist-backend", default="nccl")
     ap.add_argument("--same-device", action="store_true")
@@ -215,6 +216,13 @@ def main():
         warm_ms = (time.time() - tw) / nw * 1e3
         del fac
 
+    # host-delivered rate: the reference's own signature returns numpy arrays (cora/core/skysim.py:130-136), i.e. every
+    # realisation crosses PCIe.  skysim.mkfullsky_stream double-buffers that copy (pinned memory, copy stream) behind the
+    # next realisation; measured after the timed region, reported next to the HBM-resident headline, never as `value`.
+    host_delivered = None
+    if rank == 0 and world == 1 and args.emulate_shard <= 1 and len(comps) == 1 and not args.no_host_delivered:
+        host_delivered = host_delivered_rate(ctx, shard, nside, F, npix)
+
     stages = {}
     for name in ("clarray", "factor", "normals", "draw", "legendre", "ringfft"):
         ms, n = ctx.profile_get(name)
@@ -283,6 +291,7 @@ def main():
                 "realisations_per_s": args.steps / dt,
                 "warm_path": None if warm_ms is None else {"ms_per_step": warm_ms, "maps_per_s": F / (warm_ms * 1e-3)},
                 "setup_s": t_setup,
+                "host_delivered": host_delivered,
             },
             "stages_ms": {k: round(v["ms_per_step"], 3) for k, v in stages.items()},
             "roofline": {
@@ -313,17 +322,63 @@ def main():
     return result
 
 
+def host_delivered_rate(ctx, shard, nside, F, npix, nrep=3):
+    """maps/s through skysim.mkfullsky_stream: realisations delivered to the host as numpy arrays (pinned memory,
+    D2H on the copy stream overlapped with the next realisation), factors cached.  Skipped when the host cannot hold
+    three realisations in RAM."""
+    import torch
+
+    from cora_amd.core import skysim
+    from cora_amd.util.nputil import DeviceRNG
+
+    need = 3.2 * F * npix * 8
+    try:
+        avail = [int(l.split()[1]) * 1024 for l in open("/proc/meminfo") if l.startswith("MemAvailable")][0]
+    except Exception:
+        avail = 0
+    if avail < need + 32e9:
+        return {"skipped": "host has %.0f GB available, the leg needs %.0f GB of pinned memory" % (avail / 1e9, need / 1e9)}
+    T, info, rows = shard.factors()
+    if rows:
+        return {"skipped": "row-sliced factors"}
+    t0 = time.time()
+    gen = skysim.mkfullsky_stream(None, nside, [DeviceRNG(7000 + i) for i in range(nrep + 2)], factors=(T, info))
+    first = next(gen)                      # pins the staging blocks (one-off)
+    chk = float(first[0, 0])
+    del first
+    t_first = time.time() - t0
+    t0 = time.time()
+    n = 0
+    for m in gen:
+        chk += float(m[-1, -1])
+        n += 1
+        del m
+    dt = time.time() - t0
+    torch.cuda.synchronize()
+    return {"maps_per_s": F * n / dt, "GB_per_s": F * n * npix * 8 / dt / 1e9, "realisations": n,
+            "first_call_s": t_first, "finite": bool(np.isfinite(chk)),
+            "path": "skysim.mkfullsky_stream: device Philox draw + synthesis, pinned double-buffered D2H on a copy stream"}
+
+
 def cpu_baseline(model_name, F, freq, nside, lmax, zromb):
-    """The oracle (a port of the reference's algorithm: numpy/scipy + C/OpenMP SHT) timed on
-    this box's host cores on a bounded sample of the same workload, scaled linearly."""
+    """The oracle (a port of the reference's algorithm) timed on this box's host cores on a bounded sample of the same
+    workload, each leg scaled linearly.  Legs and their threading:
+      C_l integration  numpy + C/OpenMP table lookups (bilinearmap.pyx's loop), l in sections of 5 as the reference
+                       (cora/core/skysim.py:51-67): numpy parts 1 thread, lookups `cores` threads
+      factor + draw    scipy Cholesky of the jittered block + numpy normals + ONE real GEMM [F,F] x [F, 2(l+1)] per l
+                       (the reference multiplies a complex array: twice the flops): BLAS threads = `cores`
+      synthesis        C/OpenMP Legendre recurrence + C/OpenMP ring stage (radix-2 / Bluestein FFT per ring) per channel,
+                       channels one after the other as hputil.py:525-529: `cores` threads
+    """
+    import scipy.integrate as si
+    import scipy.linalg as la
+
     from oracle import models
     from oracle import sht
-    from oracle import skysim as osk
 
     ncore = len(os.sched_getaffinity(0))
     L = lmax + 1
     rng = np.random.default_rng(0)
-    # K1 sample: nl_s multipoles spread over the range, all channels
     if model_name == "21cm":
         om = models.Corr21cm()
         t0 = time.time()
@@ -335,37 +390,37 @@ def cpu_baseline(model_name, F, freq, nside, lmax, zromb):
     zint = 2**zromb + 1
     zhalf = abs(freq[1] - freq[0]) / 2.0
     za = (freq[:, None] + np.linspace(-zhalf, zhalf, zint)[None, :]).ravel()
-    import scipy.integrate as si
-
-    nl_s = 16 if F > 64 else 20
-    lsec = np.linspace(1, lmax, nl_s).astype(int).astype(np.float64)
-    t0 = time.time()
+    # K1 sample: three sections of 5 multipoles spread over the range, all channels
+    nsec, per = 3, 5
+    secs = [np.arange(l0, l0 + per, dtype=np.float64) for l0 in np.linspace(1, lmax - per, nsec).astype(int)]
     zspace = 2.0 * zhalf / 2**zromb
-    cl_s = []
-    for l in lsec:
-        clt = om.angular_powerspectrum(np.array([l])[:, None, None], za[None, :, None], za[None, None, :])
+    t0 = time.time()
+    cl_s, l_s = [], []
+    for lsec in secs:
+        clt = om.angular_powerspectrum(lsec[:, None, None], za[None, :, None], za[None, None, :])
         clt = clt.reshape(-1, F, zint, F, zint)
         clt = si.romb(si.romb(clt, dx=zspace, axis=4), dx=zspace, axis=2) / (2 * zhalf) ** 2
-        cl_s.append(clt[0])
-    t_k1 = (time.time() - t0) * L / nl_s
+        cl_s.extend(list(clt))
+        l_s.extend(int(v) for v in lsec)
+    t_k1 = (time.time() - t0) * L / (nsec * per)
     # K2 + K3 sample: factor + draw for the sampled l
     t0 = time.time()
     nd = 0
-    for C, l in zip(cl_s, lsec):
-        l = int(l)
+    for C, l in zip(cl_s, l_s):
         cm = C + np.identity(F) * C.diagonal().max() * 1e-14
-        T = osk.matrix_root_manynull(cm, truncate=False)
-        gv = osk.complex_std_normal((F, l + 1), rng=rng)
-        np.dot(T, gv)
+        T = la.cholesky(cm, lower=True)
+        g = rng.standard_normal((F, 2 * (l + 1)))            # (re | im) blocks: one real GEMM
+        np.dot(T, g) * 0.7071067811865476
         nd += l + 1
     t_k23 = (time.time() - t0) * (L * (L + 1) / 2) / nd
     # K4 + K5 sample: nmap channels through the C/OpenMP synthesis
     nmap = 8 if nside >= 1024 else 4
     nalm = L * (L + 1) // 2
+    a = rng.standard_normal(nalm) + 1j * rng.standard_normal(nalm)
+    sht.alm2map(a, nside, lmax, rings_c=True)                 # (thread pool / page warm-up, not timed)
     t0 = time.time()
     for _ in range(nmap):
-        a = rng.standard_normal(nalm) + 1j * rng.standard_normal(nalm)
-        sht.alm2map(a, nside, lmax)
+        sht.alm2map(a, nside, lmax, rings_c=True)
     t_sht = (time.time() - t0) * F / nmap
     t_real = t_k1 + t_k23 + t_sht
     return {
@@ -373,10 +428,11 @@ def cpu_baseline(model_name, F, freq, nside, lmax, zromb):
         "unit": "maps/s",
         "cores": ncore,
         "kind": "port",
-        "sample": "C_l integration on %d of %d l (numpy + C/OpenMP table lookups, as cora/core/skysim.py:51-67 with bilinearmap.pyx), factor+normals+T@g on those l "
-                  "(scipy/numpy, scaled by nalm), C/OpenMP synthesis of %d of %d channels; each leg scaled linearly; "
-                  "per-realisation seconds: clarray %.1f, factor+draw %.1f, synthesis %.1f (one-off 21cm table build %.1f s "
-                  "not counted)" % (nl_s, L, nmap, F, t_k1, t_k23, t_sht, t_tables),
+        "sample": "C_l integration on %d of %d l in sections of 5 (numpy 1 thread + C/OpenMP table lookups %d threads), "
+                  "Cholesky + normals + one real GEMM per l on those l (BLAS %d threads, scaled by nalm), C/OpenMP Legendre + "
+                  "C/OpenMP ring FFTs of %d of %d channels (%d threads); each leg scaled linearly; per-realisation seconds: "
+                  "clarray %.1f, factor+draw %.1f, synthesis %.1f (one-off 21cm table build %.1f s not counted)"
+                  % (nsec * per, L, ncore, ncore, nmap, F, ncore, t_k1, t_k23, t_sht, t_tables),
     }
 
 

@@ -195,6 +195,44 @@ class Context:
         assert t.dtype == torch.float64 and t.device == self.device
         return self._p(t)
 
+    # -- host delivery ------------------------------------------------------------------
+    _PINNED_MIN_BYTES = 1 << 24     # below this a pageable copy is as fast as pinning a buffer
+
+    @property
+    def copy_stream(self):
+        """A second HIP stream for host <-> device copies that overlap the kernels of the library's stream."""
+        torch = _torch()
+        if getattr(self, "_copy_stream", None) is None:
+            self._copy_stream = torch.cuda.Stream(device=self.device)
+        return self._copy_stream
+
+    def to_host_async(self, t):
+        """Start the D2H copy of device tensor ``t`` into PINNED host memory on the copy stream (after everything
+        queued so far on the current stream); returns ``(host_tensor, event)``.  The pinned block comes from torch's
+        caching host allocator: the first buffer of a size is page-locked once (seconds for tens of GB), later ones of
+        that size are recycled as soon as the caller drops the array."""
+        torch = _torch()
+        host = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream(self.device))
+        cs = self.copy_stream
+        cs.wait_event(ready)
+        with torch.cuda.stream(cs):
+            host.copy_(t, non_blocking=True)
+            done = torch.cuda.Event()
+            done.record(cs)
+        t.record_stream(cs)
+        return host, done
+
+    def to_host(self, t):
+        """Device tensor -> numpy array.  Large arrays arrive through pinned memory at PCIe rate (the ndarray is a view
+        of the pinned block and keeps it alive); small ones by an ordinary pageable copy."""
+        if t.numel() * t.element_size() < self._PINNED_MIN_BYTES:
+            return t.cpu().numpy()
+        host, done = self.to_host_async(t)
+        done.synchronize()
+        return host.numpy()
+
     # -- K1 ---------------------------------------------------------------------------
     def clarray_table21cm(self, dd, dv, vv, kperpmin, kperpmax, kparmax, chi, pfd, f, b, F, zint, w, log10l):
         nl = log10l.numel()

@@ -125,6 +125,56 @@ def _host_normals(numz, maxl, rng):
     return g
 
 
+def _upload_host_normals(ctx, numz, maxl, rng):
+    """The reference's normal stream (see :func:`_host_normals`) as a device array, generated l by l on the host -
+    that order IS the seeded-parity contract - into two pinned staging buffers whose uploads (copy stream) overlap
+    the generation of the next block: the 8.6 GB of a cfg-3 realisation never exist on the host at once."""
+    import torch
+
+    nalm = (maxl + 1) * (maxl + 2) // 2
+    total = 2 * numz * nalm
+    chunk = 1 << 25                                   # doubles per staging buffer (256 MB)
+    if total <= chunk:
+        return torch.from_numpy(_host_normals(numz, maxl, rng)).to(ctx.device)
+    g = ctx.empty((total,))
+    bufs = [torch.empty((chunk,), dtype=torch.float64, pin_memory=True) for _ in range(2)]
+    views = [b.numpy() for b in bufs]
+    events = [None, None]
+    cs = ctx.copy_stream
+    sn = np.random.standard_normal if rng is None else rng.standard_normal
+    cur, fill, dev_off = 0, 0, 0
+
+    def flush():
+        nonlocal cur, fill, dev_off
+        if fill:
+            with torch.cuda.stream(cs):
+                g[dev_off:dev_off + fill].copy_(bufs[cur][:fill], non_blocking=True)
+                events[cur] = torch.cuda.Event()
+                events[cur].record(cs)
+            dev_off += fill
+        cur, fill = 1 - cur, 0
+        if events[cur] is not None:
+            events[cur].synchronize()                 # the buffer about to be refilled has left the host
+
+    for l in range(maxl + 1):
+        for _part in range(2):                        # real block, then imaginary block (nputil.py:121-125)
+            a = sn((numz, l + 1)).ravel()
+            o = 0
+            while o < a.size:
+                m = min(a.size - o, chunk - fill)
+                views[cur][fill:fill + m] = a[o:o + m]
+                fill += m
+                o += m
+                if fill == chunk:
+                    flush()
+    flush()
+    done = torch.cuda.Event()
+    done.record(cs)
+    torch.cuda.current_stream(ctx.device).wait_event(done)
+    g.record_stream(cs)
+    return g
+
+
 def factor_device(corr):
     """Per-l roots of the jittered covariance blocks (skysim.py:115-119) on the device."""
     ctx = _lib.get_context()
@@ -160,7 +210,7 @@ def mkfullsky_device(corr, nside, alms=False, rng=None, factors=None, nu_range=N
     if isinstance(rng, DeviceRNG):
         alm = ctx.draw_alm_philox(T, info, rng.next_seed(), maxl, numz, nu0=nu0, nnu=nnu)
     else:
-        g = torch.from_numpy(_host_normals(numz, maxl, rng)).to(ctx.device)
+        g = _upload_host_normals(ctx, numz, maxl, rng)
         alm = ctx.draw_alm(T, info, g, maxl, numz, nu0=nu0, nnu=nnu)
         del g
     if alms:
@@ -203,7 +253,7 @@ def mkfullsky(corr, nside, alms=False, rng=None):
             from .. import parallel
 
             out, _ = parallel.mkfullsky_sharded(np.asarray(local), gshape, nside, rng=rng, alms=alms)
-            out = out.cpu().numpy()
+            out = _lib.get_context().to_host(out)
             wrap = getattr(type(corr), "wrap", None)
             return wrap(out, axis=0) if wrap is not None else out
         corr = np.asarray(local)
@@ -211,7 +261,33 @@ def mkfullsky(corr, nside, alms=False, rng=None):
     if corr.shape[2] != corr.shape[1]:
         raise Exception("Correlation matrix is incorrect shape.")
     out = mkfullsky_device(corr, nside, alms=alms, rng=rng)
-    return out.cpu().numpy()
+    return _lib.get_context().to_host(out)
+
+
+def mkfullsky_stream(corr, nside, rngs, alms=False, factors=None):
+    """Generator over realisations of :func:`mkfullsky` delivered to the HOST as numpy arrays, one per entry of
+    ``rngs`` (numpy Generators, ``DeviceRNG`` instances or ``None``).  The factors are made once (what repeated seeds
+    amortise in the reference's pipelines, cora/signal/lss.py:424-478); the D2H copy of realisation i goes through
+    pinned memory on the copy stream while realisation i + 1 is drawn and synthesised, so a consumer that keeps up
+    sees the PCIe rate (25.8 GB per cfg-3 realisation), not copy + compute."""
+    ctx = _lib.get_context()
+    if factors is None:
+        corr = np.asarray(corr, dtype=np.float64) if not hasattr(corr, "device") else corr
+        if corr.shape[2] != corr.shape[1]:
+            raise Exception("Correlation matrix is incorrect shape.")
+        factors = factor_device(corr)
+    pending = None
+    for rng in rngs:
+        out = mkfullsky_device(None, nside, alms=alms, rng=rng, factors=factors)
+        nxt = ctx.to_host_async(out)                 # queued behind the kernels that make `out`
+        del out
+        if pending is not None:
+            pending[1].synchronize()
+            yield pending[0].numpy()
+        pending = nxt
+    if pending is not None:
+        pending[1].synchronize()
+        yield pending[0].numpy()
 
 
 def mkconstrained(corr, constraints, nside):

@@ -40,6 +40,9 @@ def _load():
         _lib.oracle_legendre_synth_spin2.restype = None
         _lib.oracle_bilinear_interp.argtypes = [dp, ctypes.c_long, ctypes.c_long, dp, dp, ctypes.c_long, dp]
         _lib.oracle_bilinear_interp.restype = None
+        _lib.oracle_ring_synth.argtypes = [ctypes.c_int, ctypes.c_int, dp, dp, ctypes.POINTER(ctypes.c_long),
+                                           ctypes.POINTER(ctypes.c_int), dp, dp]
+        _lib.oracle_ring_synth.restype = None
         _lib.oracle_num_threads.restype = ctypes.c_int
     return _lib
 
@@ -137,6 +140,23 @@ def ring_synthesis(fm, nphi, phi0):
     return np.fft.irfft(X[: nphi // 2 + 1], n=nphi) * nphi
 
 
+def synth_from_fm_c(fn, fs, nside):
+    """synth_from_fm in C/OpenMP (oracle_ring_synth in sht_ref.c: phase, alias fold, radix-2 / Bluestein inverse DFT per
+    ring, rings in parallel).  Same arithmetic; used where the oracle is TIMED (bench.py's cpu_baseline) so that the
+    baseline runs on every host core instead of a Python loop over 4 nside rings."""
+    ri = healpix.ring_info(nside)
+    lmax = fn.shape[1] - 1
+    out = np.empty(healpix.nside2npix(nside))
+    a = np.ascontiguousarray(fn, dtype=np.complex128).view(np.float64)
+    b = np.ascontiguousarray(fs, dtype=np.complex128).view(np.float64)
+    start = np.ascontiguousarray(ri["start"], dtype=np.int64)
+    nphi = np.ascontiguousarray(ri["nphi"], dtype=np.int32)
+    phi0 = np.ascontiguousarray(ri["phi0"], dtype=np.float64)
+    _load().oracle_ring_synth(nside, lmax, _dp(a), _dp(b), start.ctypes.data_as(ctypes.POINTER(ctypes.c_long)),
+                              nphi.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), _dp(phi0), _dp(out))
+    return out
+
+
 def synth_from_fm(fn, fs, nside):
     """Assemble the RING map from north/south F_m arrays ([2 nside][lmax+1])."""
     ri = healpix.ring_info(nside)
@@ -154,8 +174,9 @@ def synth_from_fm(fn, fs, nside):
     return out
 
 
-def alm2map(alm, nside, lmax=None, impl="c"):
-    """Packed (healpy-ordered) alm -> RING map, float64."""
+def alm2map(alm, nside, lmax=None, impl="c", rings_c=False):
+    """Packed (healpy-ordered) alm -> RING map, float64.  ``rings_c``: the ring stage in C/OpenMP too
+    (synth_from_fm_c) instead of the ring-by-ring numpy loop."""
     alm = np.asarray(alm, dtype=np.complex128)
     if lmax is None:
         # nalm = (lmax+1)(lmax+2)/2
@@ -165,7 +186,7 @@ def alm2map(alm, nside, lmax=None, impl="c"):
     npair = 2 * nside
     z, sth = ri["z"][:npair], ri["sth"][:npair]
     fn, fs = (_legendre_c if impl == "c" else _legendre_numpy)(lmax, z, sth, alm)
-    return synth_from_fm(fn, fs, nside)
+    return (synth_from_fm_c if rings_c else synth_from_fm)(fn, fs, nside)
 
 
 def alm2map_bruteforce(alm, nside, lmax):

@@ -317,6 +317,108 @@ void oracle_bilinear_interp(const double *arr, long nx, long ny, const double *x
     }
 }
 
+/* ------------------------------------------------------------------------------------
+ * Ring stage of the synthesis in C/OpenMP ("Ring FFT with aliasing"): per ring the phase
+ * e^{i m phi0}, the alias fold onto n = nphi bins and the length-n inverse DFT.  Same arithmetic as
+ * oracle/sht.py:ring_synthesis (which stays the readable definition and is what the tests compare this with);
+ * this version exists so that the oracle, where it is TIMED as the CPU baseline, runs on all host cores instead of
+ * a Python loop over 4 nside rings.  Lengths that are powers of two use an iterative radix-2 FFT, all others
+ * Bluestein's chirp convolution on top of it.
+ * ------------------------------------------------------------------------------------ */
+typedef struct { double re, im; } cplx;
+
+static void fft_pow2(cplx *a, int n, int sign, const cplx *tw /* e^{+2 pi i k/n}, k < n/2 */)
+{
+    for (int i = 1, j = 0; i < n; i++) {               /* bit reversal */
+        int bit = n >> 1;
+        for (; j & bit; bit >>= 1) j ^= bit;
+        j ^= bit;
+        if (i < j) { cplx t = a[i]; a[i] = a[j]; a[j] = t; }
+    }
+    for (int len = 2; len <= n; len <<= 1) {
+        int step = n / len;
+        for (int i = 0; i < n; i += len)
+            for (int k = 0; k < len / 2; k++) {
+                cplx w = tw[k * step];
+                if (sign < 0) w.im = -w.im;
+                cplx u = a[i + k], v = a[i + k + len / 2];
+                cplx t = { v.re * w.re - v.im * w.im, v.re * w.im + v.im * w.re };
+                a[i + k].re = u.re + t.re; a[i + k].im = u.im + t.im;
+                a[i + k + len / 2].re = u.re - t.re; a[i + k + len / 2].im = u.im - t.im;
+            }
+    }
+}
+
+/* fn, fs: [npair][L][2] F_m of the north rings and of their southern mirrors (oracle_legendre_synth);
+ * start, nphi, phi0: [nring] ring geometry; map: [npix] RING ordered output. */
+void oracle_ring_synth(int nside, int lmax, const double *fn, const double *fs, const long *start, const int *nphi,
+                       const double *phi0, double *map)
+{
+    const int L = lmax + 1, nring = 4 * nside - 1, npair = 2 * nside;
+    int pmax = 1;
+    while (pmax < 8 * nside) pmax <<= 1;                /* >= 2 n - 1 for every ring */
+    cplx *tw = (cplx *)malloc(sizeof(cplx) * (pmax / 2));
+    for (int k = 0; k < pmax / 2; k++) {
+        tw[k].re = cos(2.0 * M_PI * k / pmax);
+        tw[k].im = sin(2.0 * M_PI * k / pmax);
+    }
+#pragma omp parallel
+    {
+        cplx *X = (cplx *)malloc(sizeof(cplx) * pmax);
+        cplx *A = (cplx *)malloc(sizeof(cplx) * pmax);
+        cplx *B = (cplx *)malloc(sizeof(cplx) * pmax);
+        cplx *W = (cplx *)malloc(sizeof(cplx) * pmax);
+        cplx *twl = (cplx *)malloc(sizeof(cplx) * (pmax / 2));
+#pragma omp for schedule(dynamic, 4)
+        for (int r = 0; r < nring; r++) {
+            const int n = nphi[r];
+            const double *f = r < npair ? fn + 2 * (long)r * L : fs + 2 * (long)(nring - 1 - r) * L;
+            for (int k = 0; k < n; k++) X[k].re = X[k].im = 0.0;
+            for (int m = 0; m < L; m++) {
+                const double c = cos(m * phi0[r]), s = sin(m * phi0[r]);
+                const double cr = f[2 * m] * c - f[2 * m + 1] * s, ci = f[2 * m] * s + f[2 * m + 1] * c;
+                if (m == 0) { X[0].re += cr; continue; }
+                const int k = m % n, kc = (n - k) % n;
+                X[k].re += cr; X[k].im += ci;
+                X[kc].re += cr; X[kc].im -= ci;
+            }
+            double *out = map + start[r];
+            if ((n & (n - 1)) == 0) {                   /* power of two: T_j = sum_k X_k e^{+2 pi i jk/n} */
+                if (n == 1) { out[0] = X[0].re; continue; }
+                for (int k = 0; k < n / 2; k++) twl[k] = tw[k * (pmax / n)];
+                fft_pow2(X, n, +1, twl);
+                for (int j = 0; j < n; j++) out[j] = X[j].re;
+                continue;
+            }
+            /* Bluestein: jk = (j^2 + k^2 - (j-k)^2)/2, w_k = e^{i pi k^2/n} */
+            int P = 1;
+            while (P < 2 * n - 1) P <<= 1;
+            for (int k = 0; k < P / 2; k++) twl[k] = tw[k * (pmax / P)];
+            for (int k = 0; k < n; k++) {
+                const long q = ((long)k * k) % (2L * n);
+                W[k].re = cos(M_PI * q / n); W[k].im = sin(M_PI * q / n);
+            }
+            for (int k = 0; k < P; k++) A[k].re = A[k].im = B[k].re = B[k].im = 0.0;
+            for (int k = 0; k < n; k++) {
+                A[k].re = X[k].re * W[k].re - X[k].im * W[k].im;
+                A[k].im = X[k].re * W[k].im + X[k].im * W[k].re;
+                B[k].re = W[k].re; B[k].im = -W[k].im;
+                if (k) B[P - k] = B[k];
+            }
+            fft_pow2(A, P, -1, twl);
+            fft_pow2(B, P, -1, twl);
+            for (int k = 0; k < P; k++) {
+                const double re = A[k].re * B[k].re - A[k].im * B[k].im, im = A[k].re * B[k].im + A[k].im * B[k].re;
+                A[k].re = re; A[k].im = im;
+            }
+            fft_pow2(A, P, +1, twl);
+            for (int j = 0; j < n; j++) out[j] = (A[j].re * W[j].re - A[j].im * W[j].im) / P;
+        }
+        free(X); free(A); free(B); free(W); free(twl);
+    }
+    free(tw);
+}
+
 int oracle_num_threads(void)
 {
 #ifdef _OPENMP

@@ -1246,3 +1246,33 @@ def test_sphtrans_real_pol_round_trip_and_api(ctx):
     assert cplx.shape == (3, L, 2 * L - 1)
     ref = hputil._make_full_alm(back[:3]) + 1j * hputil._make_full_alm(hputil.sphtrans_real_pol(maps[:3][::-1], lmax=lmax))
     assert np.abs(cplx - ref).max() < 1e-12
+
+
+def test_host_delivery_paths(golden):
+    """The numpy-returning surface: mkfullsky through pinned memory, the l-block-wise upload of the host normal stream
+    (two staging buffers) and the double-buffered stream of realisations all give the arrays of the plain path."""
+    from cora_amd import _lib
+    from cora_amd.core import skysim
+    from cora_amd.util.nputil import DeviceRNG
+
+    ctx = _lib.get_context()
+    C = golden["cla_21cm_F8_l64_zromb3"]
+    nside = 128                                                    # 8 x 196608 doubles = 12.6 MB ... below the pinned threshold
+    ref = skysim.mkfullsky_device(C, nside, rng=np.random.default_rng(3)).cpu().numpy()
+    old = ctx._PINNED_MIN_BYTES
+    try:
+        type(ctx)._PINNED_MIN_BYTES = 1 << 10                      # force the pinned route
+        a = skysim.mkfullsky(C, nside, rng=np.random.default_rng(3))
+        assert isinstance(a, np.ndarray) and a.flags.writeable and np.array_equal(a, ref)
+        outs = list(skysim.mkfullsky_stream(C, nside, [DeviceRNG(s) for s in (5, 6, 7)]))
+        for s, o in zip((5, 6, 7), outs):
+            assert np.array_equal(o, skysim.mkfullsky_device(C, nside, rng=DeviceRNG(s)).cpu().numpy())
+        outs = list(skysim.mkfullsky_stream(C, nside, [np.random.default_rng(3), None]))
+        assert np.array_equal(outs[0], ref) and outs[1].shape == ref.shape
+    finally:
+        type(ctx)._PINNED_MIN_BYTES = old
+    # chunked upload of the host stream: more normals than one 256 MB staging buffer (F = 40, lmax = 1300 -> 68 M)
+    F, lmax = 40, 1300
+    g_ref = skysim._host_normals(F, lmax, np.random.default_rng(11))
+    g_dev = skysim._upload_host_normals(ctx, F, lmax, np.random.default_rng(11)).cpu().numpy()
+    assert g_ref.size > (1 << 25) and np.array_equal(g_dev, g_ref)

@@ -437,3 +437,17 @@ def test_spin2_analysis_oracle_definition_and_round_trip():
     # a pure-E sky analysed as (Q, U) -> (-U, Q) (45 degree rotation) comes back as pure B
     e4, b4 = sht.map2alm_spin2(-u, q, nside, lmax, True, 3)
     assert np.abs(e4 + b).max() < 1e-6 and np.abs(b4 - e).max() < 1e-6
+
+
+@pytest.mark.parametrize("nside,lmax", [(1, 2), (2, 5), (4, 11), (8, 23), (16, 32), (32, 95)])
+def test_c_ring_stage_equals_the_numpy_definition(nside, lmax):
+    """oracle_ring_synth (C/OpenMP: the ring stage of the timed CPU baseline) == oracle.sht.ring_synthesis ring by
+    ring - power-of-two rings (radix-2) and every other length (Bluestein), aliased (lmax >= nphi) and not."""
+    from oracle import sht
+
+    rng = np.random.default_rng(nside + lmax)
+    n = (lmax + 1) * (lmax + 2) // 2
+    a = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+    ref = sht.alm2map(a, nside, lmax)
+    got = sht.alm2map(a, nside, lmax, rings_c=True)
+    assert np.abs(got - ref).max() <= 1e-13 * ref.std()
