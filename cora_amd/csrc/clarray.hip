@@ -175,13 +175,18 @@ clarray21_kernel(const double *__restrict__ tt, int nkperp, int nkpar, double kp
 // scratch [slot][l] -> out [l][i][j] and its mirror [l][j][i].  Slot s holds canonical pair
 // p = (s % npl) * W + s / npl of the (i, j >= i) enumeration: W = 1, npl = npairs for a single GPU;
 // after the all-to-all of a W-rank run slab r = s / npl came from rank r, which integrated pairs r, r + W, ...
+// The canonical enumeration of the channel pairs runs DIAGONAL by diagonal: p = d F - d (d - 1) / 2 + i is the pair
+// (i, i + d).  Pairs of one diagonal have (nearly) the same radial separation, i.e. read the same few k_par columns of
+// the tables; with the row-major order the workgroups in flight spanned every separation at once and the profile
+// rows came from HBM again and again (rocprofv3: 21 GB of FETCH_SIZE for 0.4 GB of tables, profiles/r02_pmc.json).
 __device__ static inline int2 pair_of_index(long p, int F) {
-    // p = i F - i (i - 1) / 2 + (j - i), row i found from the quadratic, fixed up for rounding
-    int i = (int)(((2.0 * F + 1.0) - sqrt((2.0 * F + 1.0) * (2.0 * F + 1.0) - 8.0 * (double)p)) * 0.5);
-    i = max(0, min(i, F - 1));
-    while (i > 0 && (long)i * F - (long)i * (i - 1) / 2 > p) i--;
-    while ((long)(i + 1) * F - (long)(i + 1) * i / 2 <= p) i++;
-    return make_int2(i, i + (int)(p - ((long)i * F - (long)i * (i - 1) / 2)));
+    // diagonal d found from the quadratic, fixed up for rounding
+    int d = (int)(((2.0 * F + 1.0) - sqrt((2.0 * F + 1.0) * (2.0 * F + 1.0) - 8.0 * (double)p)) * 0.5);
+    d = max(0, min(d, F - 1));
+    while (d > 0 && (long)d * F - (long)d * (d - 1) / 2 > p) d--;
+    while ((long)(d + 1) * F - (long)(d + 1) * d / 2 <= p) d++;
+    const int i = (int)(p - ((long)d * F - (long)d * (d - 1) / 2));
+    return make_int2(i, i + d);
 }
 
 __global__ void cl_finish_kernel(const double *__restrict__ scratch, long npairs, int W, long npl, int lstride, int nl,
@@ -298,9 +303,9 @@ static int clarray21_pairs(corahip_ctx *ctx, const double *dd, const double *dv,
         // (re)build the pair list of this shard; it stays resident for the following calls
         std::vector<int2> pairs((size_t)npl_pad, make_int2(-1, -1));
         long p = 0, k = 0;
-        for (int i = 0; i < F; i++)
-            for (int j = i; j < F; j++, p++)
-                if (p >= pair_first && (p - pair_first) % pair_step == 0) pairs[(size_t)k++] = make_int2(i, j);
+        for (int d = 0; d < F; d++)          // canonical order: diagonal by diagonal (pair_of_index)
+            for (int i = 0; i + d < F; i++, p++)
+                if (p >= pair_first && (p - pair_first) % pair_step == 0) pairs[(size_t)k++] = make_int2(i, i + d);
         HIP_TRY(hipMemcpyAsync(dpairs, pairs.data(), sizeof(int2) * npl_pad, hipMemcpyHostToDevice, ctx->stream));
         HIP_TRY(hipStreamSynchronize(ctx->stream));  // `pairs` (host) must outlive the async copy
         memcpy(ctx->pairs_key, key, sizeof(key));

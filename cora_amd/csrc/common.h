@@ -35,6 +35,8 @@ struct corahip_linefft_plan {
 struct corahip_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;                 // second stream for kernels that run beside those of `stream` (K5 pair)
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipEvent_t t0 = nullptr, t1 = nullptr;
     bool profile = false;
     std::map<std::string, corahip_prof_entry> prof;

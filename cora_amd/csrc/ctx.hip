@@ -68,6 +68,12 @@ int corahip_ctx_destroy(corahip_ctx *ctx) {
     }
     (void)hipEventDestroy(ctx->t0);
     (void)hipEventDestroy(ctx->t1);
+    if (ctx->stream2) {
+        (void)hipStreamSynchronize(ctx->stream2);
+        (void)hipStreamDestroy(ctx->stream2);
+        (void)hipEventDestroy(ctx->ev_fork);
+        (void)hipEventDestroy(ctx->ev_join);
+    }
     for (int i = 0; i < 6; i++)
         if (ctx->scratch[i]) (void)hipFree(ctx->scratch[i]);
     for (auto &kv : ctx->linefft) {

@@ -533,6 +533,9 @@ int sht_ringfft(corahip_ctx *ctx, const corahip_sht_plan *p, const double *inter
 // kernel has to take it, < 0 or a hipError on failure
 int sht_ringfft_ct(corahip_ctx *ctx, const corahip_sht_plan *p, const corahip_sht_plan::ring_class &c, const double *inter,
                    int G, int nnu, double *maps);
+// belt + largest Bluestein class side by side on two streams (sht_ringfft_ct.hip): 1 = both launched
+int sht_ringfft_ct_pair(corahip_ctx *ctx, const corahip_sht_plan *p, const corahip_sht_plan::ring_class &belt,
+                        const corahip_sht_plan::ring_class &cap, const double *inter, int G, int nnu, double *maps);
 // K5^T: maps -> weighted G_m cells for nnu_pad8 channels (nnu present in `maps`)
 int sht_ringana(corahip_ctx *ctx, const corahip_sht_plan *p, const double *maps, int nnu, int nnu_pad8,
                 const double *ring_w, double *inter);

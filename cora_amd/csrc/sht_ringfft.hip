@@ -492,7 +492,19 @@ int sht_ringfft(corahip_ctx *ctx, const corahip_sht_plan *p, const double *inter
         StageTimer t(ctx, "ringfft");
         const int G = nnu_chunk_pad / 4;
         static const bool class_times = getenv("CORAHIP_K5_TIMES") != nullptr;   // diagnostics: per-class ms on stderr
+        // the belt and the largest Bluestein class run side by side (two streams, co-resident workgroups)
+        const corahip_sht_plan::ring_class *pb = nullptr, *pc = nullptr;
         for (const auto &c : p->classes) {
+            if (c.P == 0 && c.N > 0) pb = &c;
+            if (c.P == 4096) pc = &c;
+        }
+        int paired = 0;
+        if (pb && pc && !class_times) {
+            paired = sht_ringfft_ct_pair(ctx, p, *pb, *pc, inter, G, nnu_valid, maps);
+            if (paired < 0 || paired > 1) return paired;
+        }
+        for (const auto &c : p->classes) {
+            if (paired && (&c == pb || &c == pc)) continue;
             hipEvent_t ce0 = nullptr, ce1 = nullptr;
             if (class_times) {
                 (void)hipEventCreate(&ce0);

@@ -90,15 +90,15 @@ __device__ __forceinline__ static void tw_apply(double2 (&x)[R], double2 w1) {
 // one in-LDS pass of a length-N transform on NCH channel buffers (channel c at sm + c BS), sub-length Ls, radix R.
 // DIT = false: DFT then twiddle (decimation in frequency); true: twiddle then DFT.  w1 = e^{+2 pi i j / Ls} of this
 // thread's j = tid mod (Ls / R) (the same for every butterfly the thread ever gets in this pass).
-template <int N, int NCH, int BS, int Ls, int R, int SIGN, bool DIT>
+template <int N, int NCH, int BS, int Ls, int R, int SIGN, bool DIT, int T>
 __device__ __forceinline__ static void ct_pass(double2 *sm, const double2 w1, const int tid) {
     constexpr int NB = N / R, Q = Ls / R, TOT = NCH * NB;
-    constexpr int IT = (TOT + CT_T - 1) / CT_T;
+    constexpr int IT = (TOT + T - 1) / T;
     const double2 w = make_double2(w1.x, SIGN > 0 ? w1.y : -w1.y);
 #pragma unroll
     for (int it = 0; it < IT; it++) {
-        const int idx = tid + it * CT_T;
-        if ((TOT % CT_T) != 0 && idx >= TOT) break;
+        const int idx = tid + it * T;
+        if ((TOT % T) != 0 && idx >= TOT) break;
         const int ch = idx / NB, t = idx - ch * NB;
         const int b = t / Q, j = t - b * Q;
         double2 *p = sm + ch * BS + fpad(b * Ls + j);
@@ -174,7 +174,7 @@ __device__ __forceinline__ static void fold_cell(double2 *sm, int m, int n, int 
 // Ends with a barrier.  X_k, k = 0..h, is then at sm[c BS + fpad(k)].
 // TAIL: one more register slot for the cell m = tid + MC CT_T, index clamped to the last cell of the row (the belt
 // has lmax + 1 = MC CT_T + 1 cells: read in place, that one cell exposed a whole memory latency per item).
-template <int NCH, int BS, int MC, bool TAIL>
+template <int NCH, int BS, int MC, bool TAIL, int T>
 struct FrontEnd {
     cell_ct<NCH> pf[MC + (TAIL ? 1 : 0)];
     // PART 0 / 1: first / second half of the cells (the requests of one item are spread over two phases: a burst of all
@@ -183,8 +183,8 @@ struct FrontEnd {
     __device__ __forceinline__ void prefetch(const double *cell, int L, int tid) {
         constexpr int K0 = PART == 1 ? (MC + 1) / 2 : 0, K1 = PART == 0 ? (MC + 1) / 2 : MC;
 #pragma unroll
-        for (int k = K0; k < K1; k++) pf[k] = load_cell_ct<NCH>(cell + (size_t)k * CT_T * 8, tid);
-        if (TAIL && PART != 0) pf[MC] = load_cell_ct<NCH>(cell, (unsigned)min(tid + MC * CT_T, L - 1));
+        for (int k = K0; k < K1; k++) pf[k] = load_cell_ct<NCH>(cell + (size_t)k * T * 8, tid);
+        if (TAIL && PART != 0) pf[MC] = load_cell_ct<NCH>(cell, (unsigned)min(tid + MC * T, L - 1));
     }
     // make the compiler wait for the prefetch HERE.  vmcnt completes in order and the pixel stores are conditional, so
     // the compiler cannot count them: a wait for a prefetch register placed after the stores becomes vmcnt(0) and
@@ -195,16 +195,17 @@ struct FrontEnd {
 #pragma unroll
             for (int c = 0; c < NCH; c++) asm volatile("" ::"v"(pf[k].re[c]), "v"(pf[k].im[c]));
     }
-    double2 ph0, ph1;   // e^{i m phi0} at m = tid and tid + CT_T (the Bluestein pre-pass derives e^{i pi k / h} from them)
+    static constexpr int KP = 4;
+    double2 phk[KP];    // e^{i m phi0} at m = tid + k T, k < KP (the Bluestein pre-pass derives e^{i pi k / h} from them)
     __device__ __forceinline__ void fold(double2 *sm, const double *__restrict__ cell, int Lr, int n, double phi0_over_pi, const int tid) {
         const int h = n >> 1;
         const bool noalias = Lr - 1 <= h;
         if (noalias) {
-            for (int j = Lr + tid; j <= h; j += CT_T)
+            for (int j = Lr + tid; j <= h; j += T)
 #pragma unroll
                 for (int c = 0; c < NCH; c++) sm[c * BS + fpad(j)] = make_double2(0.0, 0.0);
         } else {
-            for (int j = tid; j <= h; j += CT_T)
+            for (int j = tid; j <= h; j += T)
 #pragma unroll
                 for (int c = 0; c < NCH; c++) sm[c * BS + fpad(j)] = make_double2(0.0, 0.0);
             __syncthreads();
@@ -216,21 +217,22 @@ struct FrontEnd {
             //  slow library loop: the fold took 6.7k cycles per item with it)
             sincospi((double)tid * phi0_over_pi, &s, &c);
             ph = make_double2(c, s);
-            sincospi((double)CT_T * phi0_over_pi, &s, &c);
+            sincospi((double)T * phi0_over_pi, &s, &c);
             phstep = make_double2(c, s);
         }
-        ph0 = ph;
-        ph1 = cmul(ph, phstep);
+        phk[0] = ph;
+#pragma unroll
+        for (int k = 1; k < KP; k++) phk[k] = cmul(phk[k - 1], phstep);
 #pragma unroll
         for (int k = 0; k < MC; k++) {
-            if (tid + k * CT_T < Lr) fold_cell<NCH, BS>(sm, tid + k * CT_T, n, h, noalias, ph, pf[k]);
+            if (tid + k * T < Lr) fold_cell<NCH, BS>(sm, tid + k * T, n, h, noalias, ph, pf[k]);
             ph = cmul(ph, phstep);
         }
         if (TAIL) {
-            if (tid + MC * CT_T < Lr) fold_cell<NCH, BS>(sm, tid + MC * CT_T, n, h, noalias, ph, pf[MC]);
+            if (tid + MC * T < Lr) fold_cell<NCH, BS>(sm, tid + MC * T, n, h, noalias, ph, pf[MC]);
             ph = cmul(ph, phstep);
         }
-        for (int m = tid + (MC + (TAIL ? 1 : 0)) * CT_T; m < Lr; m += CT_T) {   // cells beyond the prefetch window, read in place
+        for (int m = tid + (MC + (TAIL ? 1 : 0)) * T; m < Lr; m += T) {   // cells beyond the prefetch window, read in place
             fold_cell<NCH, BS>(sm, m, n, h, noalias, ph, load_cell_ct<NCH>(cell, m));
             ph = cmul(ph, phstep);
         }
@@ -251,8 +253,8 @@ __device__ __forceinline__ static int ct_remap(int v, int nitems) {
 // ------------------------------------------------------------------------------------
 // direct class: h = N = 2^k (N >= 2048 so that the first-pass stride is a multiple of the 128-element padding period)
 // ------------------------------------------------------------------------------------
-template <int N, int NCH, int MC>
-__global__ void __launch_bounds__(CT_T)
+template <int N, int NCH, int MC, int T>
+__global__ void __launch_bounds__(T)
 ringfft_direct_ct(const int32_t *__restrict__ ring_list, int nlist, int lmax, int G, int nnu, long npix,
                   const int64_t *__restrict__ start_a, const double *__restrict__ phi0_a,
                   const double *inter, double *maps, const int32_t *__restrict__ mcut) {   // (not __restrict__: see ringfft_blu_ct)
@@ -285,7 +287,7 @@ ringfft_direct_ct(const int32_t *__restrict__ ring_list, int nlist, int lmax, in
         const int ch0 = (item % ngrp) * NCH;
         return inter + ((size_t)ring * G + (ch0 >> 2)) * L * 8 + (ch0 & 3);
     };
-    FrontEnd<NCH, BS, MC, true> fe;
+    FrontEnd<NCH, BS, MC, true, T> fe;
     int vitem = blockIdx.x;
     if (vitem < nitems) fe.prefetch(cell_ptr(ct_remap<NCH>(vitem, nitems)), L, tid0);
     fe.touch();   // (so that the prefetch is known to be complete on BOTH edges into the loop: no wait in the fold)
@@ -314,13 +316,13 @@ ringfft_direct_ct(const int32_t *__restrict__ ring_list, int nlist, int lmax, in
         //      w^k = e^{i pi j0 / N} e^{i pi r / R0}
         {
             constexpr int TOT = NCH * Q0;
-            constexpr int IT = (TOT + CT_T - 1) / CT_T;
+            constexpr int IT = (TOT + T - 1) / T;
             double2 x[IT][R0];
             double2 wh = wH;
             asm volatile("" : "+v"(wh.x), "+v"(wh.y));   // (keeps the 16 products below out of the loop-invariant set: see tw_apply)
 #pragma unroll
             for (int it = 0; it < IT; it++) {
-                const int idx = tid + it * CT_T;
+                const int idx = tid + it * T;
                 const int ch = idx / Q0, j0 = idx & (Q0 - 1);
                 const double2 *pa = sm + ch * BS + fpad(j0);
                 const double2 *pb = sm + ch * BS + fpad(Q0 - j0);
@@ -339,7 +341,7 @@ ringfft_direct_ct(const int32_t *__restrict__ ring_list, int nlist, int lmax, in
             fe.template prefetch<1>(ncell, L, tid);
 #pragma unroll
             for (int it = 0; it < IT; it++) {
-                const int idx = tid + it * CT_T;
+                const int idx = tid + it * T;
                 const int ch = idx / Q0, j0 = idx & (Q0 - 1);
                 double2 *pa = sm + ch * BS + fpad(j0);
                 DftR<R0, 1>::run(x[it]);
@@ -349,19 +351,19 @@ ringfft_direct_ct(const int32_t *__restrict__ ring_list, int nlist, int lmax, in
             }
         }
         __syncthreads();
-        ct_pass<N, NCH, BS, Q0, R1, 1, false>(sm, wB, tid);
+        ct_pass<N, NCH, BS, Q0, R1, 1, false, T>(sm, wB, tid);
         __syncthreads();
         // ---- last pass (radix R2 on contiguous elements, no twiddles) with the pixel store: butterfly t = 16 k0 + k1
         //      holds the natural indices k0 + 16 k1 + 256 r.  Lane bits: 0-2 = k0 low, 3-5 = k1 low, 6 = k0 high,
         //      7 = k1 high: eight consecutive lanes store 128 contiguous bytes; the LDS reads are 2-way conflicted.
         {
             constexpr int TOT = NCH * 256;
-            constexpr int IT = (TOT + CT_T - 1) / CT_T;
+            constexpr int IT = (TOT + T - 1) / T;
             fe.touch();
 #pragma unroll
             for (int it = 0; it < IT; it++) {
-                const int idx = tid + it * CT_T;
-                if ((TOT % CT_T) != 0 && idx >= TOT) break;
+                const int idx = tid + it * T;
+                if ((TOT % T) != 0 && idx >= TOT) break;
                 const int ch = idx >> 8;
                 const int k0 = (idx & 7) | ((idx >> 3) & 8);
                 const int k1 = ((idx >> 3) & 7) | ((idx >> 4) & 8);
@@ -383,8 +385,8 @@ ringfft_direct_ct(const int32_t *__restrict__ ring_list, int nlist, int lmax, in
 // ------------------------------------------------------------------------------------
 // Bluestein class: cap rings, h = 2 i not a power of two, convolution length P >= 2 h - 1
 // ------------------------------------------------------------------------------------
-template <int P, int NCH, int MC>
-__global__ void __launch_bounds__(CT_T)
+template <int P, int NCH, int MC, int T>
+__global__ void __launch_bounds__(T)
 ringfft_blu_ct(const int32_t *__restrict__ ring_list, int nlist, int nside, int lmax, int G, int nnu, long npix,
                const int32_t *__restrict__ nphi_a, const int64_t *__restrict__ start_a,
                const double *__restrict__ phi0_a, const double *inter, double *maps,
@@ -400,7 +402,7 @@ ringfft_blu_ct(const int32_t *__restrict__ ring_list, int nlist, int nside, int 
     constexpr int HALF = (R0 / 2) * Q0;          // the non-zero half of the padded input: h <= HALF
     // pre-pass iterations over the pairs k <= h / 2: h <= HALF, and for a power-of-two P even h <= HALF - 2 (h = HALF
     // is itself a power of two: direct class)
-    constexpr int U = (HALF / 2 + ((P & (P - 1)) ? 1 : 0) + CT_T - 1) / CT_T;
+    constexpr int U = (HALF / 2 + ((P & (P - 1)) ? 1 : 0) + T - 1) / T;
     extern __shared__ __attribute__((aligned(16))) double2 sm[];
     const int tid0 = threadIdx.x;
     const int L = lmax + 1;
@@ -422,15 +424,15 @@ ringfft_blu_ct(const int32_t *__restrict__ ring_list, int nlist, int nside, int 
         const int ch0 = (item % ngrp) * NCH;
         return inter + ((size_t)ring * G + (ch0 >> 2)) * L * 8 + (ch0 & 3);
     };
-    FrontEnd<NCH, BS, MC, false> fe;
-    double2 cbn[U];    // chirp b_k, k = tid + u CT_T, of the NEXT item (index clamped: unused lanes load a valid slot)
+    FrontEnd<NCH, BS, MC, false, T> fe;
+    double2 cbn[U];    // chirp b_k, k = tid + u T, of the NEXT item (index clamped: unused lanes load a valid slot)
     auto load_cbn = [&](int item, int t) {
         const int ring = ring_list[item / ngrp];
         const int ic = ring + 1 < nside ? ring + 1 : 4 * nside - (ring + 1);
         const double2 *b = chirp + boff[ic - 1];
         const int hh = nphi_a[ring] >> 1;
 #pragma unroll
-        for (int u = 0; u < U; u++) cbn[u] = b[min(t + u * CT_T, hh - 1)];
+        for (int u = 0; u < U; u++) cbn[u] = b[min(t + u * T, hh - 1)];
     };
     int vitem = blockIdx.x;
     if (vitem < nitems) {
@@ -481,13 +483,13 @@ ringfft_blu_ct(const int32_t *__restrict__ ring_list, int nlist, int nside, int 
         //        y_{h-k} = b_k [(X_{h-k} + conj X_k) - i conj(w^k) (X_{h-k} - conj X_k)]
         //      w^k = e^{i pi k / h} is the square of the fold phase e^{i k phi0} (phi0 = pi / 2h on a cap ring);
         //      zeros on [h, HALF)
-        static_assert(U <= 2, "two fold phases are kept");
+        static_assert(U <= 4, "four fold phases are kept");
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            const int k = tid + u * CT_T;
+            const int k = tid + u * T;
             if (2 * k <= h) {
                 const int k2 = h - k;
-                const double2 wk = csqr(u == 0 ? fe.ph0 : fe.ph1);
+                const double2 wk = csqr(fe.phk[u]);
                 const double2 iw = make_double2(-wk.y, wk.x);                 // i w^k
                 const double2 miwc = make_double2(-wk.y, -wk.x);               // -i conj(w^k)
 #pragma unroll
@@ -507,7 +509,7 @@ ringfft_blu_ct(const int32_t *__restrict__ ring_list, int nlist, int nside, int 
                 }
             }
         }
-        for (int j = h + 1 + tid; j < HALF; j += CT_T)
+        for (int j = h + 1 + tid; j < HALF; j += T)
 #pragma unroll
             for (int c = 0; c < NCH; c++) sm[c * BS + fpad(j)] = make_double2(0.0, 0.0);
         // the next item's cells and pre-pass chirps, in two parts (here and behind forward pass 1): three passes ahead
@@ -522,12 +524,12 @@ ringfft_blu_ct(const int32_t *__restrict__ ring_list, int nlist, int nside, int 
         // ---- forward pass 1 (sign -), inputs r >= R0 / 2 are the zero padding and are not read
         {
             constexpr int TOT = NCH * Q0;
-            constexpr int IT = (TOT + CT_T - 1) / CT_T;
+            constexpr int IT = (TOT + T - 1) / T;
             const double2 w = cconj(wA);
 #pragma unroll
             for (int it = 0; it < IT; it++) {
-                const int idx = tid + it * CT_T;
-                if ((TOT % CT_T) != 0 && idx >= TOT) break;
+                const int idx = tid + it * T;
+                if ((TOT % T) != 0 && idx >= TOT) break;
                 const int ch = idx / Q0, j0 = idx & (Q0 - 1);
                 double2 *p = sm + ch * BS + fpad(j0);
                 double2 x[R0];
@@ -545,17 +547,17 @@ ringfft_blu_ct(const int32_t *__restrict__ ring_list, int nlist, int nside, int 
         load_cbn(nitem, tid);
         __syncthreads();
         CTSTAMP(4);
-        ct_pass<P, NCH, BS, Q0, R1, -1, false>(sm, wB, tid);
+        ct_pass<P, NCH, BS, Q0, R1, -1, false, T>(sm, wB, tid);
         __syncthreads();
         CTSTAMP(5);
         // ---- last forward pass, filter, first inverse pass: R2 contiguous elements, no twiddles, in registers
         {
             constexpr int NB = P / R2, TOT = NCH * NB;
-            constexpr int IT = (TOT + CT_T - 1) / CT_T;
+            constexpr int IT = (TOT + T - 1) / T;
 #pragma unroll
             for (int it = 0; it < IT; it++) {
-                const int idx = tid + it * CT_T;
-                if ((TOT % CT_T) != 0 && idx >= TOT) break;
+                const int idx = tid + it * T;
+                if ((TOT % T) != 0 && idx >= TOT) break;
                 const int ch = idx / NB, t = idx & (NB - 1);
                 double2 *p = sm + ch * BS + fpad(t * R2);
                 double2 x[R2];
@@ -578,17 +580,17 @@ ringfft_blu_ct(const int32_t *__restrict__ ring_list, int nlist, int nside, int 
         }
         __syncthreads();
         CTSTAMP(6);
-        ct_pass<P, NCH, BS, Q0, R1, 1, true>(sm, wB, tid);
+        ct_pass<P, NCH, BS, Q0, R1, 1, true, T>(sm, wB, tid);
         __syncthreads();
         CTSTAMP(7);
         // ---- last inverse pass (sign +): only the outputs j0 + r Q0 < h exist; times b_j / P, pixel pairs to HBM
         {
             constexpr int TOT = NCH * Q0;
-            constexpr int IT = (TOT + CT_T - 1) / CT_T;
+            constexpr int IT = (TOT + T - 1) / T;
 #pragma unroll
             for (int it = 0; it < IT; it++) {
-                const int idx = tid + it * CT_T;
-                if ((TOT % CT_T) != 0 && idx >= TOT) break;
+                const int idx = tid + it * T;
+                if ((TOT % T) != 0 && idx >= TOT) break;
                 const int ch = idx / Q0, j0 = idx & (Q0 - 1);
                 const double2 *p = sm + ch * BS + fpad(j0);
                 double2 x[R0];
@@ -622,41 +624,41 @@ ringfft_blu_ct(const int32_t *__restrict__ ring_list, int nlist, int nside, int 
 // ------------------------------------------------------------------------------------
 // host side: launch one class with the compile-time kernel if there is one for it
 // ------------------------------------------------------------------------------------
-template <int N, int NCH, int MC>
-static int launch_direct(corahip_ctx *ctx, const corahip_sht_plan *p, const corahip_sht_plan::ring_class &c, const double *inter,
-                         int G, int nnu, double *maps) {
+template <int N, int NCH, int MC, int T>
+static int launch_direct(corahip_ctx *ctx, hipStream_t stream, int wg_per_cu, const corahip_sht_plan *p,
+                         const corahip_sht_plan::ring_class &c, const double *inter, int G, int nnu, double *maps) {
     constexpr int BS = fpc(N) + 1 + K5_CH_SKEW;
     const size_t shm = sizeof(double2) * (size_t)NCH * BS;
     const long nitems = (long)c.count * ((nnu + NCH - 1) / NCH);
-    const int per_cu = std::max<int>(1, (int)((160 * 1024) / shm));
+    const int per_cu = wg_per_cu > 0 ? wg_per_cu : std::max<int>(1, (int)((160 * 1024) / shm));
     dim3 grid((unsigned)std::min<long>(nitems, (long)ctx->num_cu * per_cu));
-    HIP_TRY(hipFuncSetAttribute((const void *)ringfft_direct_ct<N, NCH, MC>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    HIP_TRY(hipFuncSetAttribute((const void *)ringfft_direct_ct<N, NCH, MC, T>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 160 * 1024));
-    ringfft_direct_ct<N, NCH, MC><<<grid, CT_T, shm, ctx->stream>>>(c.d_list, c.count, p->lmax, G, nnu, p->npix, p->d_start,
-                                                                  p->d_phi0, inter, maps, p->d_mcut);
+    ringfft_direct_ct<N, NCH, MC, T><<<grid, T, shm, stream>>>(c.d_list, c.count, p->lmax, G, nnu, p->npix, p->d_start,
+                                                               p->d_phi0, inter, maps, p->d_mcut);
     LAUNCH_CHECK();
     return 0;
 }
-template <int P, int NCH, int MC>
-static int launch_blu(corahip_ctx *ctx, const corahip_sht_plan *p, const corahip_sht_plan::ring_class &c, const double *inter,
-                      int G, int nnu, double *maps) {
+template <int P, int NCH, int MC, int T>
+static int launch_blu(corahip_ctx *ctx, hipStream_t stream, int wg_per_cu, const corahip_sht_plan *p,
+                      const corahip_sht_plan::ring_class &c, const double *inter, int G, int nnu, double *maps) {
     constexpr int BS = fpc(P) + K5_CH_SKEW;
     const size_t shm = sizeof(double2) * (size_t)NCH * BS;
     const long nitems = (long)c.count * ((nnu + NCH - 1) / NCH);
-    const int per_cu = std::max<int>(1, (int)((160 * 1024) / shm));
+    const int per_cu = wg_per_cu > 0 ? wg_per_cu : std::max<int>(1, (int)((160 * 1024) / shm));
     dim3 grid((unsigned)std::min<long>(nitems, (long)ctx->num_cu * per_cu));
-    HIP_TRY(hipFuncSetAttribute((const void *)ringfft_blu_ct<P, NCH, MC>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    HIP_TRY(hipFuncSetAttribute((const void *)ringfft_blu_ct<P, NCH, MC, T>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 160 * 1024));
-    ringfft_blu_ct<P, NCH, MC><<<grid, CT_T, shm, ctx->stream>>>(c.d_list, c.count, p->nside, p->lmax, G, nnu, p->npix, p->d_nphi,
-                                                               p->d_start, p->d_phi0, inter, maps, p->d_blu_boff,
-                                                               p->d_blu_foff, p->d_bchirp, p->d_bchirp2, p->d_bfilt, p->d_mcut);
+    ringfft_blu_ct<P, NCH, MC, T><<<grid, T, shm, stream>>>(c.d_list, c.count, p->nside, p->lmax, G, nnu, p->npix, p->d_nphi,
+                                                            p->d_start, p->d_phi0, inter, maps, p->d_blu_boff,
+                                                            p->d_blu_foff, p->d_bchirp, p->d_bchirp2, p->d_bfilt, p->d_mcut);
     LAUNCH_CHECK();
 #if CT_STAMPS
     {
         unsigned long long hs[12], z[12] = {0};
-        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        HIP_TRY(hipStreamSynchronize(stream));
         HIP_TRY(hipMemcpyFromSymbol(hs, HIP_SYMBOL(g_ct_stamps), sizeof(hs)));
-        const double per = 1.0 / ((double)nitems * (CT_T / 64));   // cycles per item and wave
+        const double per = 1.0 / ((double)nitems * (T / 64));   // cycles per item and wave
         fprintf(stderr, "K5ct P=%d nch=%d items=%ld: cycles/item  top %.0f fold %.0f pf+bar %.0f pre %.0f F1 %.0f F2 %.0f mid %.0f I2 %.0f I3 %.0f\n",
                 P, NCH, nitems, hs[0] * per, hs[1] * per, hs[2] * per, hs[3] * per, hs[4] * per, hs[5] * per, hs[6] * per,
                 hs[7] * per, hs[8] * per);
@@ -672,15 +674,44 @@ int sht_ringfft_ct(corahip_ctx *ctx, const corahip_sht_plan *p, const corahip_sh
     static const bool off = getenv("CORAHIP_K5_GENERIC") != nullptr;   // diagnostics: force the generic kernel
     if (off) return 0;
     int rc = -1;
+    hipStream_t st = ctx->stream;
     if (c.P == 0) {
-        if (c.N == 2048) rc = launch_direct<2048, 4, 4>(ctx, p, c, inter, G, nnu, maps);
-        else if (c.N == 4096) rc = launch_direct<4096, 2, 8>(ctx, p, c, inter, G, nnu, maps);
+        if (c.N == 2048) rc = launch_direct<2048, 4, 4, 512>(ctx, st, 0, p, c, inter, G, nnu, maps);
+        else if (c.N == 4096) rc = launch_direct<4096, 2, 8, 512>(ctx, st, 0, p, c, inter, G, nnu, maps);
         else return 0;
     } else {
-        if (c.P == 4096) rc = launch_blu<4096, 2, 4>(ctx, p, c, inter, G, nnu, maps);
-        else if (c.P == 2048) rc = launch_blu<2048, 4, 2>(ctx, p, c, inter, G, nnu, maps);
-        else if (c.P == 1024) rc = launch_blu<1024, 4, 1>(ctx, p, c, inter, G, nnu, maps);
+        if (c.P == 4096) rc = launch_blu<4096, 2, 4, 512>(ctx, st, 0, p, c, inter, G, nnu, maps);
+        else if (c.P == 2048) rc = launch_blu<2048, 4, 2, 512>(ctx, st, 0, p, c, inter, G, nnu, maps);
+        else if (c.P == 1024) rc = launch_blu<1024, 4, 1, 512>(ctx, st, 0, p, c, inter, G, nnu, maps);
         else return 0;
     }
     return rc ? rc : 1;
+}
+
+// The belt (HBM-bound: 2/3 of the pixels, little arithmetic) and the largest Bluestein class (LDS / FP64-bound, a third
+// of the traffic) run CONCURRENTLY: each as 256-thread workgroups with half the channels per item (78 KB of LDS), one
+// workgroup of each kernel per CU, launched on two streams - the compute-bound items of one kernel fill the memory
+// stalls of the other on every CU.  Returns 1 if it launched both classes (the caller then skips them), 0 if not
+// applicable.
+int sht_ringfft_ct_pair(corahip_ctx *ctx, const corahip_sht_plan *p, const corahip_sht_plan::ring_class &belt,
+                        const corahip_sht_plan::ring_class &cap, const double *inter, int G, int nnu, double *maps) {
+    // Measured at cfg 3 (one box, A/B): 18.6 ms paired against 17.0 ms with the two classes one after the other at
+    // full width - the half-width kernels lose more per item than the overlap returns - so the pairing is OFF unless
+    // CORAHIP_K5_PAIR is set; kept for the record and for other shapes.
+    static const bool on = getenv("CORAHIP_K5_PAIR") != nullptr && getenv("CORAHIP_K5_GENERIC") == nullptr;
+    if (!on || !(belt.P == 0 && belt.N == 2048 && cap.P == 4096)) return 0;
+    if (!ctx->stream2) {
+        HIP_TRY(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+    }
+    HIP_TRY(hipEventRecord(ctx->ev_fork, ctx->stream));
+    HIP_TRY(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
+    int rc = launch_blu<4096, 1, 8, 256>(ctx, ctx->stream2, 1, p, cap, inter, G, nnu, maps);
+    if (rc) return rc;
+    rc = launch_direct<2048, 2, 8, 256>(ctx, ctx->stream, 1, p, belt, inter, G, nnu, maps);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(ctx->ev_join, ctx->stream2));
+    HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+    return 1;
 }
