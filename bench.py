@@ -258,15 +258,17 @@ def main():
         alg_bytes = 8.0 * npix * nnu + 32.0 * nalm * nnu + 8.0 * L * F * F   # warm path, SURVEY 8(d)
         # HBM bytes of the dominant kernel from the PMC passes of the same command (collected separately
         # with rocprofv3 --pmc and committed under profiles/; bench.py cannot read counters itself)
-        traffic = traffic_source = None
-        for pmc_name in ("r02_k4_pmc.json", "r01_k4_pmc.json"):
-            pmc_file = os.path.join(ROOT, "profiles", pmc_name)
-            if os.path.exists(pmc_file) and world == 1 and not emu:
-                pmc = json.load(open(pmc_file))
-                if pmc.get("workload") == args.workload:
-                    traffic = pmc["traffic_bytes_per_launch"]
-                    traffic_source = "profiles/" + pmc_name + " (rocprofv3 --pmc passes of this command, not measured in this run)"
-                    break
+        traffic = traffic_source = executed = None
+        pmc_file = os.path.join(ROOT, "profiles", "r02_pmc.json")
+        if os.path.exists(pmc_file) and world == 1 and not emu and args.workload == "cfg3":
+            pmc = json.load(open(pmc_file)).get("kernels", {})
+            k4 = next((v for k, v in pmc.items() if k.startswith("legendre_kernel")), None)
+            if k4:
+                traffic = k4["hbm_bytes_per_launch"]
+                traffic_source = ("profiles/r02_pmc.json (rocprofv3 --pmc passes of this command, 2 x FETCH_SIZE + WRITE_SIZE; "
+                                  "not measured in this run)")
+                if k4.get("SQ_INSTS_VALU_MFMA_F64_per_launch"):
+                    executed = k4["SQ_INSTS_VALU_MFMA_F64_per_launch"] * 2048.0    # flop of a v_mfma_f64_16x16x4_f64
         result = {
             "metric": "sky-maps/sec (nside=%d, lmax=%d, %d freq)" % (nside, lmax, F),
             "value": value,
@@ -303,7 +305,20 @@ def main():
                 "frac": ach / FP64_MFMA_PEAK_TFLOPS,
                 "traffic": traffic,
                 "traffic_source": traffic_source,
+                # `achieved` counts the ALGORITHMIC flops of SURVEY 8(d); the kernel skips the terms below 2^-120 (as
+                # libsharp does), so the matrix pipe itself is busy for the EXECUTED flops only:
+                "executed_flops_per_launch": executed,
+                "executed_tflops": None if executed is None else executed / (leg["ms_per_launch"] * 1e-3) / 1e12,
+                "executed_frac": None if executed is None else executed / (leg["ms_per_launch"] * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS,
                 "algorithmic_bytes": 16.0 * nalm * nnu + 16.0 * (4 * nside - 1) * L * nnu,
+            },
+            "roofline_k5": {
+                "bound": "hbm",
+                "kernel": "ringfft_direct_ct / ringfft_blu_ct (K5)",
+                "achieved": (16.0 * (4 * nside - 1) * L * nnu + 8.0 * npix * nnu) / (stages.get("ringfft", {"ms_per_launch": float("nan")})["ms_per_launch"] * 1e-3) / 1e9,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": (16.0 * (4 * nside - 1) * L * nnu + 8.0 * npix * nnu) / (stages.get("ringfft", {"ms_per_launch": float("nan")})["ms_per_launch"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
             },
             "hbm_roofline_whole_step": {
                 "algorithmic_GB": alg_bytes / 1e9,

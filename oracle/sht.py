@@ -32,6 +32,8 @@ def _load():
         dp = ctypes.POINTER(ctypes.c_double)
         _lib.oracle_legendre_synth.argtypes = [ctypes.c_int, ctypes.c_int, dp, dp, dp, dp, dp]
         _lib.oracle_legendre_synth.restype = None
+        _lib.oracle_legendre_synth_blocked.argtypes = [ctypes.c_int, ctypes.c_int, dp, dp, dp, dp, dp]
+        _lib.oracle_legendre_synth_blocked.restype = None
         _lib.oracle_legendre_anal.argtypes = [ctypes.c_int, ctypes.c_int, dp, dp, dp, dp, dp]
         _lib.oracle_legendre_anal.restype = None
         _lib.oracle_lambda_lm.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_double, dp]
@@ -109,7 +111,7 @@ def _legendre_numpy(lmax, z, sth, alm):
     return fn, fs
 
 
-def _legendre_c(lmax, z, sth, alm):
+def _legendre_c(lmax, z, sth, alm, blocked=False):
     L = lmax + 1
     npair = len(z)
     a = np.ascontiguousarray(alm, dtype=np.complex128).view(np.float64)
@@ -117,8 +119,8 @@ def _legendre_c(lmax, z, sth, alm):
     fs = np.zeros((npair, L), dtype=np.complex128)
     zz = np.ascontiguousarray(z, dtype=np.float64)
     ss = np.ascontiguousarray(sth, dtype=np.float64)
-    _load().oracle_legendre_synth(lmax, npair, _dp(zz), _dp(ss), _dp(a), _dp(fn.view(np.float64)),
-                                  _dp(fs.view(np.float64)))
+    fun = _load().oracle_legendre_synth_blocked if blocked else _load().oracle_legendre_synth
+    fun(lmax, npair, _dp(zz), _dp(ss), _dp(a), _dp(fn.view(np.float64)), _dp(fs.view(np.float64)))
     return fn, fs
 
 
@@ -185,8 +187,11 @@ def alm2map(alm, nside, lmax=None, impl="c", rings_c=False):
     ri = healpix.ring_info(nside)
     npair = 2 * nside
     z, sth = ri["z"][:npair], ri["sth"][:npair]
+    if rings_c:      # the timed configuration: ring-blocked, vectorised Legendre + C ring stage
+        fn, fs = _legendre_c(lmax, z, sth, alm, blocked=True)
+        return synth_from_fm_c(fn, fs, nside)
     fn, fs = (_legendre_c if impl == "c" else _legendre_numpy)(lmax, z, sth, alm)
-    return (synth_from_fm_c if rings_c else synth_from_fm)(fn, fs, nside)
+    return synth_from_fm(fn, fs, nside)
 
 
 def alm2map_bruteforce(alm, nside, lmax):

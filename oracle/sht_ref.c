@@ -109,6 +109,108 @@ void oracle_legendre_synth(int lmax, int npair, const double *z, const double *s
 }
 
 
+/* The same sums as oracle_legendre_synth with the loops re-cut for the host CPU, used where the oracle is TIMED
+ * (bench.py's cpu_baseline): a block of RB consecutive ring pairs is taken through the l recurrence together, so that
+ * the coefficients alpha_lm and the a_lm of a multipole are loaded once per block instead of once per ring and the
+ * inner loop over the block's rings vectorises (the arrangement libsharp, healpy's engine, uses; target_clones
+ * selects AVX-512 / AVX2 / baseline code at load time).  Per ring and m the scaled phase 1 of oracle_legendre_synth
+ * finds the first l with |lambda| >= 2^-900 and the two recurrence values there; phase 2 starts every ring of the
+ * block at its own l by injecting those values.  Checked against oracle_legendre_synth in tests/test_oracle.py. */
+#define RB 8
+__attribute__((target_clones("avx512f", "avx2", "default")))
+void oracle_legendre_synth_blocked(int lmax, int npair, const double *z, const double *sth,
+                                   const double *alm, double *fn, double *fs)
+{
+    const int L = lmax + 1;
+    const long nalm = (long)L * (L + 1) / 2;
+    double *lp = (double *)malloc(sizeof(double) * L);
+    lp[0] = -0.5 * log2(4.0 * M_PI);
+    for (int m = 1; m < L; m++)
+        lp[m] = lp[m - 1] + 0.5 * log2((2.0 * m + 1.0) / (2.0 * m));
+    double *al = (double *)malloc(sizeof(double) * nalm);
+    double *ial = (double *)malloc(sizeof(double) * nalm);
+#pragma omp parallel for schedule(dynamic, 16)
+    for (int m = 0; m < L; m++) {
+        long base = (long)m * (2 * lmax + 1 - m) / 2;
+        const double m2 = (double)m * m;
+        al[base + m] = 0.0;
+        ial[base + m] = 0.0;
+        for (int l = m + 1; l < L; l++) {
+            double ll = l;
+            double a = sqrt((4.0 * ll * ll - 1.0) / (ll * ll - m2));
+            al[base + l] = a;
+            ial[base + l] = 1.0 / a;
+        }
+    }
+    const int nblk = (npair + RB - 1) / RB;
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int blk = 0; blk < nblk; blk++) {
+        const int r0 = blk * RB;
+        double x[RB], l2s[RB];
+        for (int q = 0; q < RB; q++) {
+            const int r = r0 + q < npair ? r0 + q : npair - 1;     /* (a padded lane repeats the last ring) */
+            x[q] = z[r];
+            l2s[q] = log2(sth[r]);
+        }
+        for (int m = 0; m < L; m++) {
+            const long base = (long)m * (2 * lmax + 1 - m) / 2;
+            const double *a = alm + 2 * base;
+            const double *A = al + base, *IA = ial + base;
+            int ls[RB];
+            double s0[RB], s1[RB];
+            int lmin = L;
+            for (int q = 0; q < RB; q++) {                          /* phase 1, scalar per ring */
+                double L2 = lp[m] + m * l2s[q];
+                int sc = (int)floor(L2);
+                double lam = exp2(L2 - sc);
+                if (m & 1) lam = -lam;
+                double lam_prev = 0.0;
+                int l = m;
+                while (l < L && sc + ilogb(lam) < -900) {
+                    double nxt = (l + 1 < L) ? A[l + 1] * (x[q] * lam - lam_prev * IA[l]) : 0.0;
+                    lam_prev = lam;
+                    lam = nxt;
+                    l++;
+                    if (fabs(lam) > 0x1p300) { lam *= 0x1p-300; lam_prev *= 0x1p-300; sc += 300; }
+                    if (lam == 0.0) break;
+                }
+                if (l < L && lam != 0.0) {
+                    ls[q] = l;
+                    s1[q] = ldexp(lam, sc);
+                    s0[q] = ldexp(lam_prev, sc);
+                } else {
+                    ls[q] = L;
+                    s0[q] = s1[q] = 0.0;
+                }
+                if (ls[q] < lmin) lmin = ls[q];
+            }
+            double lam[RB], lamp[RB], er[RB], ei[RB], orr[RB], oi[RB];
+            for (int q = 0; q < RB; q++) lam[q] = lamp[q] = er[q] = ei[q] = orr[q] = oi[q] = 0.0;
+            for (int l = lmin; l < L; l++) {                        /* phase 2, the block's rings together */
+                const double ar = a[2 * l], ai = a[2 * l + 1];
+                const double Anext = l + 1 < L ? A[l + 1] : 0.0, IAl = IA[l];
+                const int even = ((l - m) & 1) == 0;
+#pragma omp simd
+                for (int q = 0; q < RB; q++) {
+                    const int start = l == ls[q];
+                    const double lq = start ? s1[q] : lam[q];
+                    const double pq = start ? s0[q] : lamp[q];
+                    if (even) { er[q] += ar * lq; ei[q] += ai * lq; }
+                    else      { orr[q] += ar * lq; oi[q] += ai * lq; }
+                    lam[q] = Anext * (x[q] * lq - pq * IAl);
+                    lamp[q] = lq;
+                }
+            }
+            for (int q = 0; q < RB && r0 + q < npair; q++) {
+                long o = 2 * ((long)(r0 + q) * L + m);
+                fn[o] = er[q] + orr[q]; fn[o + 1] = ei[q] + oi[q];
+                fs[o] = er[q] - orr[q]; fs[o + 1] = ei[q] - oi[q];
+            }
+        }
+    }
+    free(lp); free(al); free(ial);
+}
+
 /* Adjoint of oracle_legendre_synth (the Legendre part of healpy.map2alm, which the reference
  * reaches through hputil.sphtrans_real, cora/util/hputil.py:195-234):
  *   a_lm = sum_rings lambda_lm(z_r) [G_m(north r) + (-1)^{l+m} G_m(south mirror of r)]
