@@ -136,10 +136,11 @@ clarray21_kernel(const double *__restrict__ tt, int nkperp, int nkpar, double kp
                 pb[x] = c0 * r0[x] + c1 * r1[x] + c2 * r0[tsz + x] + c3 * r1[tsz + x] + c4 * r0[2 * tsz + x] +
                         c5 * r1[2 * tsz + x];
 #endif
-            if (tid == 0) {
-                pb[nkperp] = 0.0;  // x1 = x0 + 1 is clamped to the last row below; slot kept finite
-                lxcs_s[b] = pp[6];
-            }
+            if (tid == 0) lxcs_s[b] = pp[6];
+            // slot nkperp repeats the last row: the interpolation reads (x0, x0 + 1) unclamped, which is then the
+            // clamped x1 = min(x0 + 1, nkperp - 1) of the reference's intent (the thread that wrote row nkperp - 1, if the
+            // profile reaches it, writes it; otherwise the slot is never read: x0 + 1 <= nx - 1 < nkperp)
+            if (nx == nkperp && tid == ((nkperp - 1 - x0r) & 255)) pb[nkperp] = pb[nkperp - 1];
         }
         __syncthreads();
         // ---- 1-D interpolation for this thread's multipoles
@@ -151,13 +152,15 @@ clarray21_kernel(const double *__restrict__ tt, int nkperp, int nkpar, double kp
             if (k >= kmax) break;  // uniform: l-sharded callers pass short l ranges
             double s = 0.0;
             for (int b = 0; b < zint; b++) {
+                // (instruction count matters here: 5.5e9 of these per cfg-3 launch bound the kernel.  fract instead of
+                //  int -> double -> subtract, one ds_read2_b64 for the unclamped row pair: 9 VALU + 1 LDS instead of 14 + 2)
                 double xx = lxs[k] - lxcs_s[b];
-                xx = xx < 0.0 ? 0.0 : (xx > ux ? ux : xx);
+                xx = fmin(fmax(xx, 0.0), ux);
                 const int x0 = (int)xx;
-                const double wx = xx - (double)x0;
-                const int xb = min(x0 + 1, nkperp - 1);
-                const double s0 = prof[b * PS + x0], s1 = prof[b * PS + xb];
-                s += s0 + wx * (s1 - s0);
+                const double wx = __builtin_amdgcn_fract(xx);
+                const double *pr = prof + b * PS + x0;
+                const double s0 = pr[0], s1 = pr[1];
+                s += fma(wx, s1 - s0, s0);
             }
             acc[k] += s;
         }
@@ -175,18 +178,42 @@ clarray21_kernel(const double *__restrict__ tt, int nkperp, int nkpar, double kp
 // scratch [slot][l] -> out [l][i][j] and its mirror [l][j][i].  Slot s holds canonical pair
 // p = (s % npl) * W + s / npl of the (i, j >= i) enumeration: W = 1, npl = npairs for a single GPU;
 // after the all-to-all of a W-rank run slab r = s / npl came from rank r, which integrated pairs r, r + W, ...
-// The canonical enumeration of the channel pairs runs DIAGONAL by diagonal: p = d F - d (d - 1) / 2 + i is the pair
-// (i, i + d).  Pairs of one diagonal have (nearly) the same radial separation, i.e. read the same few k_par columns of
-// the tables; with the row-major order the workgroups in flight spanned every separation at once and the profile
-// rows came from HBM again and again (rocprofv3: 21 GB of FETCH_SIZE for 0.4 GB of tables, profiles/r02_pmc.json).
-__device__ static inline int2 pair_of_index(long p, int F) {
-    // diagonal d found from the quadratic, fixed up for rounding
-    int d = (int)(((2.0 * F + 1.0) - sqrt((2.0 * F + 1.0) * (2.0 * F + 1.0) - 8.0 * (double)p)) * 0.5);
-    d = max(0, min(d, F - 1));
-    while (d > 0 && (long)d * F - (long)d * (d - 1) / 2 > p) d--;
-    while ((long)(d + 1) * F - (long)(d + 1) * d / 2 <= p) d++;
-    const int i = (int)(p - ((long)d * F - (long)d * (d - 1) / 2));
-    return make_int2(i, i + d);
+// The canonical enumeration of the channel pairs (i, j >= i) runs in BANDS of CL_BAND diagonals: band B holds the
+// separations d = j - i in [CL_BAND B, CL_BAND B + CL_BAND), enumerated i-major (for i: for d).  Pairs of nearby
+// diagonals have nearly the same radial separation, i.e. read the same few k_par columns of the tables: the ~800
+// workgroups in flight then share ~1 MB of table rows in L2 (with the row-major order they spanned every separation at
+// once and the rows came from HBM again and again: 43 GB of FETCH_SIZE per launch for 0.4 GB of tables, 28 GB with
+// this order, profiles/r02_pmc.json); and consecutive slots are consecutive j of one row i, so the transpose into
+// [l][i][j] writes contiguous segments (a plain diagonal-major order made every write an isolated 8 bytes).
+#define CL_BAND 32
+__host__ __device__ static inline long cl_band_count(int n) {   // pairs of a band that has n rows (n = F - CL_BAND B)
+    return n >= CL_BAND ? (long)CL_BAND * (n - (CL_BAND - 1)) + (long)(CL_BAND - 1) * CL_BAND / 2 : (long)n * (n + 1) / 2;
+}
+__host__ __device__ static inline int2 pair_of_index(long p, int F) {
+    int B = 0;
+    for (;; B++) {
+        const long c = cl_band_count(F - CL_BAND * B);
+        if (p < c) break;
+        p -= c;
+    }
+    const int n = F - CL_BAND * B;
+    const int nfull = n >= CL_BAND ? n - (CL_BAND - 1) : 0;         // rows with all CL_BAND separations
+    int i, dd;
+    if (p < (long)nfull * CL_BAND) {
+        i = (int)(p / CL_BAND);
+        dd = (int)(p % CL_BAND);
+    } else {
+        p -= (long)nfull * CL_BAND;
+        int e = n >= CL_BAND ? CL_BAND - 1 : n;                     // entries of the first tail row
+        i = nfull;
+        while (p >= e) {
+            p -= e;
+            e--;
+            i++;
+        }
+        dd = (int)p;
+    }
+    return make_int2(i, i + CL_BAND * B + dd);
 }
 
 __global__ void cl_finish_kernel(const double *__restrict__ scratch, long npairs, int W, long npl, int lstride, int nl,
@@ -303,9 +330,9 @@ static int clarray21_pairs(corahip_ctx *ctx, const double *dd, const double *dv,
         // (re)build the pair list of this shard; it stays resident for the following calls
         std::vector<int2> pairs((size_t)npl_pad, make_int2(-1, -1));
         long p = 0, k = 0;
-        for (int d = 0; d < F; d++)          // canonical order: diagonal by diagonal (pair_of_index)
-            for (int i = 0; i + d < F; i++, p++)
-                if (p >= pair_first && (p - pair_first) % pair_step == 0) pairs[(size_t)k++] = make_int2(i, i + d);
+        const long npairs_all = (long)F * (F + 1) / 2;
+        for (; p < npairs_all; p++)           // canonical order: bands of diagonals (pair_of_index)
+            if (p >= pair_first && (p - pair_first) % pair_step == 0) pairs[(size_t)k++] = pair_of_index(p, F);
         HIP_TRY(hipMemcpyAsync(dpairs, pairs.data(), sizeof(int2) * npl_pad, hipMemcpyHostToDevice, ctx->stream));
         HIP_TRY(hipStreamSynchronize(ctx->stream));  // `pairs` (host) must outlive the async copy
         memcpy(ctx->pairs_key, key, sizeof(key));

@@ -89,7 +89,7 @@ int corahip_clarray_table21cm(corahip_ctx *ctx, const double *dd, const double *
  * caput.mpiarray, skysim.py:97-103; the table lookups of a channel pair are shared by all l, so here
  * the PAIRS are sharded instead and the l-shards are assembled by one all-to-all):
  *   table21cm_pairs integrates, for all nl multipoles, the channel pairs p = pair_first + k pair_step
- *   (k = 0 .. npl-1, npl = ceil(F(F+1)/2 / pair_step); p enumerates the pairs (i, i + d) diagonal by diagonal, d = 0 first) and writes
+ *   (k = 0 .. npl-1, npl = ceil(F(F+1)/2 / pair_step); p enumerates the pairs (i, j >= i) in bands of 32 diagonals, i-major inside a band) and writes
  *   out_pairs [ceil(nl / l_block)][npl][l_block]: slab q is what the rank owning l in [q l_block, (q+1) l_block)
  *   receives.  pairs_finish takes the received slabs [nranks][npl][l_stride] (slab r from rank r) and
  *   scatters them into out [nl, F, F] and its mirror.                                              */
