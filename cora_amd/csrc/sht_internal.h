@@ -55,11 +55,17 @@ struct corahip_sht_plan {
     int64_t *d_blu_boff = nullptr, *d_blu_foff = nullptr; // offsets into chirp / filter arrays
     double2 *d_bchirp = nullptr, *d_bfilt = nullptr;
     double2 *d_bchirp2 = nullptr;                         // i e^{i pi j / h} b_j at the offsets of d_bchirp (compile-time kernels)
+    // second set of Bluestein filters for the rings whose 2 h - 1 also fits 3/4 of the power-of-two length (P3 = 1536 or
+    // 3072): used by the compile-time synthesis kernels only; everything else (analysis, run-time kernel) keeps blu_P
+    std::vector<int32_t> h_blu3_P;                        // [nside]: 0 = none
+    int64_t *d_blu3_foff = nullptr;
+    double2 *d_bfilt3 = nullptr;
     int max_fft_len = 0;                                  // largest LDS FFT buffer (complex elems)
     // K5 launch classes: rings grouped by transform kind/length so each launch sizes its LDS
     struct ring_class {
         int P = 0;        // Bluestein length, 0 = direct power-of-two transform
         int N = 0;        // direct classes: the half length h of the rings (all equal), 0 = mixed (run-time length)
+        int P3 = 0;       // 3 * 2^k Bluestein length all rings of the class also admit (0 = none): see d_bfilt3
         int nch = 4;      // channels transformed together per workgroup
         int threads = 0;  // workgroup size (0: K5_THREADS)
         int bstride = 0;  // complex elements per channel buffer in LDS
@@ -533,6 +539,10 @@ int sht_ringfft(corahip_ctx *ctx, const corahip_sht_plan *p, const double *inter
 // kernel has to take it, < 0 or a hipError on failure
 int sht_ringfft_ct(corahip_ctx *ctx, const corahip_sht_plan *p, const corahip_sht_plan::ring_class &c, const double *inter,
                    int G, int nnu, double *maps);
+// plan time: filters of the 3 * 2^k Bluestein lengths (fills p->d_bfilt3; h_blu3_P / d_blu3_foff / d_bchirp must be set)
+int sht_blu3_tables(corahip_ctx *ctx, corahip_sht_plan *p, int64_t total);
+// creates ctx->stream2 and the fork / join events on first use
+int sht_second_stream(corahip_ctx *ctx);
 // belt + largest Bluestein class side by side on two streams (sht_ringfft_ct.hip): 1 = both launched
 int sht_ringfft_ct_pair(corahip_ctx *ctx, const corahip_sht_plan *p, const corahip_sht_plan::ring_class &belt,
                         const corahip_sht_plan::ring_class &cap, const double *inter, int G, int nnu, double *maps);

@@ -208,6 +208,8 @@ int corahip_sht_plan_destroy(corahip_ctx *ctx, corahip_sht_plan *p) {
     (void)hipFree(p->d_blu_boff);
     (void)hipFree(p->d_blu_foff);
     (void)hipFree(p->d_bchirp2);
+    (void)hipFree(p->d_blu3_foff);
+    (void)hipFree(p->d_bfilt3);
     (void)hipFree(p->d_bchirp);
     (void)hipFree(p->d_bfilt);
     for (auto &c : p->classes) (void)hipFree(c.d_list);
@@ -381,6 +383,27 @@ int corahip_sht_plan_create(corahip_ctx *ctx, int nside, int lmax, corahip_sht_p
             LAUNCH_CHECK();
         }
     }
+    // 3 * 2^k Bluestein lengths for the compile-time synthesis kernels: 3 P / 4 where it still holds 2 h - 1
+    {
+        p->h_blu3_P.assign(nside, 0);
+        std::vector<int64_t> fo3(nside, 0);
+        int64_t nf3 = 0;
+        for (int i = 1; i < nside; i++) {
+            const int h = 2 * i;
+            if (is_pow2(h)) continue;
+            int P = 1;
+            while (P < 2 * h - 1) P <<= 1;
+            const int P3 = 3 * (P / 4);
+            if ((P3 == 1536 || P3 == 3072) && P3 >= 2 * h - 1) {
+                p->h_blu3_P[i - 1] = P3;
+                fo3[i - 1] = nf3;
+                nf3 += P3;
+            }
+        }
+        if ((rc = dev_upload(&p->d_blu3_foff, fo3, s))) return rc;
+        HIP_TRY(hipMalloc((void **)&p->d_bfilt3, sizeof(double2) * std::max<int64_t>(1, nf3)));
+        if (nf3 && (rc = sht_blu3_tables(ctx, p, nf3))) return rc;
+    }
     // K5 ring classes
     {
         // key: Bluestein length P, or -h for the belt (direct transform of the one length 2 nside: its own class so
@@ -397,6 +420,7 @@ int corahip_sht_plan_create(corahip_ctx *ctx, int nside, int lmax, corahip_sht_p
                 if (!is_pow2(h)) {
                     P = 1;
                     while (P < 2 * h - 1) P <<= 1;
+                    P = 4 * P + (p->h_blu3_P[icap - 1] ? 1 : 0);   // rings that also admit 3 P / 4: a class of their own
                 }
             }
             by_len[P].push_back(r);
@@ -405,7 +429,8 @@ int corahip_sht_plan_create(corahip_ctx *ctx, int nside, int lmax, corahip_sht_p
         if (getenv("CORAHIP_K5_LDS_KB")) lds_budget = (size_t)atoi(getenv("CORAHIP_K5_LDS_KB")) * 1024;
         for (auto &kv : by_len) {
             corahip_sht_plan::ring_class c;
-            c.P = std::max(kv.first, 0);
+            c.P = kv.first > 0 ? kv.first / 4 : 0;
+            c.P3 = (kv.first > 0 && (kv.first & 1)) ? 3 * (c.P / 4) : 0;
             c.N = kv.first < 0 ? -kv.first : 0;
             c.bstride = fpad_len(c.P ? c.P : 2 * nside + 1) + K5_CH_SKEW;
             c.nch = 4;

@@ -503,8 +503,28 @@ int sht_ringfft(corahip_ctx *ctx, const corahip_sht_plan *p, const double *inter
             paired = sht_ringfft_ct_pair(ctx, p, *pb, *pc, inter, G, nnu_valid, maps);
             if (paired < 0 || paired > 1) return paired;
         }
+        // The class launches alternate between two streams: every class is a persistent grid that fills the chip, so the
+        // two kernels in flight run one after the other EXCEPT for their tails - the workgroups of the next class start on
+        // the CUs the finishing one frees (12 launches, 0.1-0.3 ms of tail each on one stream).  CORAHIP_K5_ONE_STREAM=1
+        // or the per-class timing switch keep everything on the context's stream.
+        static const bool one_stream = getenv("CORAHIP_K5_ONE_STREAM") != nullptr;
+        const bool two = !one_stream && !class_times && !K5_STAMPS && p->classes.size() > 1;
+        hipStream_t const main_stream = ctx->stream;
+        struct Restore {          // ctx->stream is switched per launch below: back to the caller's on every exit path
+            corahip_ctx *c;
+            hipStream_t s;
+            ~Restore() { c->stream = s; }
+        } restore{ctx, main_stream};
+        if (two) {
+            int rc2 = sht_second_stream(ctx);
+            if (rc2) return rc2;
+            HIP_TRY(hipEventRecord(ctx->ev_fork, main_stream));
+            HIP_TRY(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
+        }
+        int launch_no = 0;
         for (const auto &c : p->classes) {
             if (paired && (&c == pb || &c == pc)) continue;
+            if (two) ctx->stream = (launch_no++ & 1) ? ctx->stream2 : main_stream;   // (restored below; every launch of the loop uses ctx->stream)
             hipEvent_t ce0 = nullptr, ce1 = nullptr;
             if (class_times) {
                 (void)hipEventCreate(&ce0);
@@ -512,7 +532,10 @@ int sht_ringfft(corahip_ctx *ctx, const corahip_sht_plan *p, const double *inter
                 (void)hipEventRecord(ce0, ctx->stream);
             }
             const int took = sht_ringfft_ct(ctx, p, c, inter, G, nnu_valid, maps);   // compile-time kernel for this class?
-            if (took < 0 || took > 1) return took;
+            if (took < 0 || took > 1) {
+                ctx->stream = main_stream;
+                return took;
+            }
             const size_t shm = sizeof(double2) * ((size_t)c.nch * c.bstride + TWL_ENTRIES(p->pmax));
             const long nitems = (long)c.count * ((nnu_valid + c.nch - 1) / c.nch);
             const int per_cu = std::max<int>(1, (int)((160 * 1024) / std::max<size_t>(shm, 1)));
@@ -557,6 +580,11 @@ int sht_ringfft(corahip_ctx *ctx, const corahip_sht_plan *p, const double *inter
                 HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_k5_stamps), z8, sizeof(z8)));
             }
 #endif
+        }
+        ctx->stream = main_stream;
+        if (two) {
+            HIP_TRY(hipEventRecord(ctx->ev_join, ctx->stream2));
+            HIP_TRY(hipStreamWaitEvent(main_stream, ctx->ev_join, 0));
         }
     }
     return 0;

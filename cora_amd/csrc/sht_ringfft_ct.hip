@@ -51,6 +51,48 @@ template <>
 struct Sch<4096> {
     static constexpr int R0 = 16, R1 = 16, R2 = 16;
 };
+// 3 * 2^k: the factor 3 sits in the first pass (radix 12), whose stride P / 12 is a power of two, so every
+// butterfly address is still base + immediates; the Bluestein length of a ring is then at most 1.5 (not 2) times
+// 2 h - 1
+template <>
+struct Sch<3072> {
+    static constexpr int R0 = 12, R1 = 16, R2 = 16;
+};
+template <>
+struct Sch<1536> {
+    static constexpr int R0 = 12, R1 = 16, R2 = 8;
+};
+
+// 12-point DFT, natural order in and out: n = 3 a + c, k = k1 + 4 k2: DFT4 over a, twiddle w12^{c k1}, DFT3 over c
+template <int SIGN>
+struct DftR<12, SIGN> {
+    __device__ __forceinline__ static void run(double2 (&x)[12]) {
+        const double h3 = 0.86602540378443864676;   // sqrt(3) / 2
+#pragma unroll
+        for (int c = 0; c < 3; c++) dft4<SIGN>(x[c], x[3 + c], x[6 + c], x[9 + c]);
+        // now x[3 k1 + c] = t_c[k1]; twiddles w12^{c k1}: c = 1: w1, w2, w3 = SIGN i;  c = 2: w2, w4, w6 = -1
+        const double2 w1 = make_double2(h3, SIGN * 0.5), w2 = make_double2(0.5, SIGN * h3), w4 = make_double2(-0.5, SIGN * h3);
+        x[3 + 1] = cmul(x[3 + 1], w1);
+        x[6 + 1] = cmul(x[6 + 1], w2);
+        x[9 + 1] = cmuli<SIGN>(x[9 + 1]);
+        x[3 + 2] = cmul(x[3 + 2], w2);
+        x[6 + 2] = cmul(x[6 + 2], w4);
+        x[9 + 2] = make_double2(-x[9 + 2].x, -x[9 + 2].y);
+        double2 y[12];
+#pragma unroll
+        for (int k1 = 0; k1 < 4; k1++) {
+            const double2 a = x[3 * k1], b = x[3 * k1 + 1], c = x[3 * k1 + 2];
+            const double2 sm = cadd(b, c), d = csub(b, c);
+            const double2 m = make_double2(a.x - 0.5 * sm.x, a.y - 0.5 * sm.y);
+            const double2 n = cmuli<SIGN>(make_double2(h3 * d.x, h3 * d.y));
+            y[k1] = cadd(a, sm);
+            y[k1 + 4] = cadd(m, n);
+            y[k1 + 8] = csub(m, n);
+        }
+#pragma unroll
+        for (int k = 0; k < 12; k++) x[k] = y[k];
+    }
+};
 
 // e^{i pi r / 16}, r < 16 (indices are compile-time after unrolling: these fold into immediates)
 __device__ constexpr double kCos16[16] = {1.0, 0.98078528040323044913, 0.92387953251128675613, 0.83146961230254523708,
@@ -462,7 +504,7 @@ ringfft_blu_ct(const int32_t *__restrict__ ring_list, int nlist, int nside, int 
         // filter values of the register-fused middle (storage positions t R2 + r; the same for every channel), requested
         // first thing: vmcnt completes in order and the pixel stores of the previous item are ahead of these loads;
         // by the middle pass they have long been acknowledged
-        const double2 *f = filt + foff[icap - 1] + (size_t)(tid & (P / R2 - 1)) * R2;
+        const double2 *f = filt + foff[icap - 1] + (size_t)(tid % (P / R2)) * R2;
         double2 fl[R2];
 #pragma unroll
         for (int r = 0; r < (R2 + 1) / 2; r++) fl[r] = f[r];     // (second half behind the fold: spread requests)
@@ -552,13 +594,15 @@ ringfft_blu_ct(const int32_t *__restrict__ ring_list, int nlist, int nside, int 
         CTSTAMP(5);
         // ---- last forward pass, filter, first inverse pass: R2 contiguous elements, no twiddles, in registers
         {
-            constexpr int NB = P / R2, TOT = NCH * NB;
-            constexpr int IT = (TOT + T - 1) / T;
+            // thread -> (channel, butterfly t) with t = tid mod NB in EVERY iteration (the filter registers fl[] belong to
+            // that t): CPI whole channels per iteration, threads beyond CPI NB idle (NB = 192 for the 3 * 2^k lengths)
+            constexpr int NB = P / R2, CPI = T / NB, IT = (NCH + CPI - 1) / CPI;
+            static_assert(CPI >= 1, "a channel's butterflies must fit one iteration");
 #pragma unroll
             for (int it = 0; it < IT; it++) {
-                const int idx = tid + it * T;
-                if ((TOT % T) != 0 && idx >= TOT) break;
-                const int ch = idx / NB, t = idx & (NB - 1);
+                const int chl = tid / NB, t = tid - chl * NB;
+                const int ch = it * CPI + chl;
+                if (chl >= CPI || ch >= NCH) break;
                 double2 *p = sm + ch * BS + fpad(t * R2);
                 double2 x[R2];
 #pragma unroll
@@ -641,7 +685,12 @@ static int launch_direct(corahip_ctx *ctx, hipStream_t stream, int wg_per_cu, co
 }
 template <int P, int NCH, int MC, int T>
 static int launch_blu(corahip_ctx *ctx, hipStream_t stream, int wg_per_cu, const corahip_sht_plan *p,
-                      const corahip_sht_plan::ring_class &c, const double *inter, int G, int nnu, double *maps) {
+                      const corahip_sht_plan::ring_class &c, const double *inter, int G, int nnu, double *maps,
+                      const int64_t *d_foff = nullptr, const double2 *d_filt = nullptr) {
+    if (!d_foff) {
+        d_foff = p->d_blu_foff;
+        d_filt = p->d_bfilt;
+    }
     constexpr int BS = fpc(P) + K5_CH_SKEW;
     const size_t shm = sizeof(double2) * (size_t)NCH * BS;
     const long nitems = (long)c.count * ((nnu + NCH - 1) / NCH);
@@ -651,7 +700,7 @@ static int launch_blu(corahip_ctx *ctx, hipStream_t stream, int wg_per_cu, const
                                 160 * 1024));
     ringfft_blu_ct<P, NCH, MC, T><<<grid, T, shm, stream>>>(c.d_list, c.count, p->nside, p->lmax, G, nnu, p->npix, p->d_nphi,
                                                             p->d_start, p->d_phi0, inter, maps, p->d_blu_boff,
-                                                            p->d_blu_foff, p->d_bchirp, p->d_bchirp2, p->d_bfilt, p->d_mcut);
+                                                            d_foff, p->d_bchirp, p->d_bchirp2, d_filt, p->d_mcut);
     LAUNCH_CHECK();
 #if CT_STAMPS
     {
@@ -680,12 +729,24 @@ int sht_ringfft_ct(corahip_ctx *ctx, const corahip_sht_plan *p, const corahip_sh
         else if (c.N == 4096) rc = launch_direct<4096, 2, 8, 512>(ctx, st, 0, p, c, inter, G, nnu, maps);
         else return 0;
     } else {
-        if (c.P == 4096) rc = launch_blu<4096, 2, 4, 512>(ctx, st, 0, p, c, inter, G, nnu, maps);
+        static const bool no3 = getenv("CORAHIP_K5_NO3") != nullptr;   // diagnostics: power-of-two lengths only
+        if (c.P3 == 3072 && !no3) rc = launch_blu<3072, 2, 4, 512>(ctx, st, 0, p, c, inter, G, nnu, maps, p->d_blu3_foff, p->d_bfilt3);
+        else if (c.P3 == 1536 && !no3) rc = launch_blu<1536, 4, 2, 512>(ctx, st, 0, p, c, inter, G, nnu, maps, p->d_blu3_foff, p->d_bfilt3);
+        else if (c.P == 4096) rc = launch_blu<4096, 2, 4, 512>(ctx, st, 0, p, c, inter, G, nnu, maps);
         else if (c.P == 2048) rc = launch_blu<2048, 4, 2, 512>(ctx, st, 0, p, c, inter, G, nnu, maps);
         else if (c.P == 1024) rc = launch_blu<1024, 4, 1, 512>(ctx, st, 0, p, c, inter, G, nnu, maps);
         else return 0;
     }
     return rc ? rc : 1;
+}
+
+int sht_second_stream(corahip_ctx *ctx) {
+    if (!ctx->stream2) {
+        HIP_TRY(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+    }
+    return 0;
 }
 
 // The belt (HBM-bound: 2/3 of the pixels, little arithmetic) and the largest Bluestein class (LDS / FP64-bound, a third
@@ -700,11 +761,8 @@ int sht_ringfft_ct_pair(corahip_ctx *ctx, const corahip_sht_plan *p, const corah
     // CORAHIP_K5_PAIR is set; kept for the record and for other shapes.
     static const bool on = getenv("CORAHIP_K5_PAIR") != nullptr && getenv("CORAHIP_K5_GENERIC") == nullptr;
     if (!on || !(belt.P == 0 && belt.N == 2048 && cap.P == 4096)) return 0;
-    if (!ctx->stream2) {
-        HIP_TRY(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
-        HIP_TRY(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
-    }
+    int rcs = sht_second_stream(ctx);
+    if (rcs) return rcs;
     HIP_TRY(hipEventRecord(ctx->ev_fork, ctx->stream));
     HIP_TRY(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
     int rc = launch_blu<4096, 1, 8, 256>(ctx, ctx->stream2, 1, p, cap, inter, G, nnu, maps);
@@ -714,4 +772,65 @@ int sht_ringfft_ct_pair(corahip_ctx *ctx, const corahip_sht_plan *p, const corah
     HIP_TRY(hipEventRecord(ctx->ev_join, ctx->stream2));
     HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
     return 1;
+}
+
+// ------------------------------------------------------------------------------------
+// plan time: Bluestein filters of the 3 * 2^k lengths, in the storage order of the forward passes above
+// ------------------------------------------------------------------------------------
+template <int P>
+__global__ void __launch_bounds__(CT_T)
+blu3_filter_kernel(int nside, const int32_t *__restrict__ p3_of, const int64_t *__restrict__ boff, const int64_t *__restrict__ foff3,
+                   const double2 *__restrict__ chirp, double2 *__restrict__ filt3) {
+    constexpr int R0 = Sch<P>::R0, R1 = Sch<P>::R1, R2 = Sch<P>::R2;
+    constexpr int Q0 = P / R0, BS = fpc(P) + K5_CH_SKEW;
+    extern __shared__ __attribute__((aligned(16))) double2 sm[];
+    const int i = blockIdx.x + 1;
+    if (p3_of[i - 1] != P) return;
+    const int tid = threadIdx.x;
+    const int h = 2 * i;
+    const double2 *b = chirp + boff[i - 1];
+    for (int j = tid; j < P; j += CT_T) {          // conj chirp, wrapped: f_j = conj b_j (j < h), f_{P-j} = conj b_j (0 < j < h)
+        double2 v = make_double2(0.0, 0.0);
+        if (j < h) v = cconj(b[j]);
+        else if (P - j < h) v = cconj(b[P - j]);
+        sm[fpad(j)] = v;
+    }
+    __syncthreads();
+    double2 wA, wB;
+    {
+        double sv, cv;
+        sincospi(2.0 * (double)(tid & (Q0 - 1)) / (double)P, &sv, &cv);
+        wA = make_double2(cv, sv);
+        sincospi(2.0 * (double)(tid & (Q0 / R1 - 1)) / (double)Q0, &sv, &cv);
+        wB = make_double2(cv, sv);
+    }
+    ct_pass<P, 1, BS, P, R0, -1, false, CT_T>(sm, wA, tid);
+    __syncthreads();
+    ct_pass<P, 1, BS, Q0, R1, -1, false, CT_T>(sm, wB, tid);
+    __syncthreads();
+    ct_pass<P, 1, BS, Q0 / R1, R2, -1, false, CT_T>(sm, wB, tid);   // (stride 1: no twiddles)
+    __syncthreads();
+    double2 *f = filt3 + foff3[i - 1];
+    for (int j = tid; j < P; j += CT_T) f[j] = sm[fpad(j)];
+}
+
+int sht_blu3_tables(corahip_ctx *ctx, corahip_sht_plan *p, int64_t total) {
+    (void)total;
+    int32_t *d_p3 = nullptr;
+    HIP_TRY(hipMalloc((void **)&d_p3, sizeof(int32_t) * p->h_blu3_P.size()));
+    HIP_TRY(hipMemcpyAsync(d_p3, p->h_blu3_P.data(), sizeof(int32_t) * p->h_blu3_P.size(), hipMemcpyHostToDevice, ctx->stream));
+    const int nb = p->nside - 1;
+#define BLU3_LAUNCH(PP)                                                                                                   \
+    {                                                                                                                     \
+        const size_t shm = sizeof(double2) * (size_t)(fpc(PP) + K5_CH_SKEW);                                              \
+        HIP_TRY(hipFuncSetAttribute((const void *)blu3_filter_kernel<PP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+        blu3_filter_kernel<PP><<<nb, CT_T, shm, ctx->stream>>>(p->nside, d_p3, p->d_blu_boff, p->d_blu3_foff, p->d_bchirp, p->d_bfilt3); \
+        LAUNCH_CHECK();                                                                                                   \
+    }
+    BLU3_LAUNCH(1536)
+    BLU3_LAUNCH(3072)
+#undef BLU3_LAUNCH
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    (void)hipFree(d_p3);
+    return 0;
 }
