@@ -19,13 +19,14 @@
 // A value depends only on (seed, l, c, nu', m): the same for any number of GPUs, and the same whether it is
 // materialised in HBM (normals_kernel, stream-order layout) or generated inside K3.  oracle/philox.py
 // restates the stream in numpy.
-__device__ static inline double2 philox_normal_pair(uint64_t seed, int l, int F, int c, int nup, int mpair) {
+__device__ static inline double2 philox_normal_pair(uint64_t seed, int l, int F, int c, int nup, int mpair,
+                                                    const double2 *log_tab = LOG_TAB) {
     uint32_t r[4];
     const uint64_t ctr = ((uint64_t)((uint32_t)l * 2u * (uint32_t)F + (uint32_t)(c * F + nup)) << 32) | (uint32_t)mpair;
     philox4x32_10(ctr, seed, r);
     const double u1 = ((double)(((uint64_t)r[0] << 21) | (r[1] >> 11)) + 0.5) * 0x1p-53;
     const double u2 = ((double)(((uint64_t)r[2] << 21) | (r[3] >> 11)) + 0.5) * 0x1p-53;
-    const double rad = fast_sqrt_pos(-2.0 * fast_log01(u1));
+    const double rad = fast_sqrt_pos(-2.0 * fast_log01(u1, log_tab));
     double sn, cs;
     fast_sincos2pi(u2, sn, cs);
     return make_double2(rad * cs, rad * sn);
@@ -165,6 +166,16 @@ __device__ static inline void draw_glds16(const void *gsrc, unsigned lds_byte_ad
                  : "memory");
 }
 
+#ifndef DRAW_STAMPS
+#define DRAW_STAMPS 0   // diagnostic build (make k3stamps): s_memtime per phase, summed over the waves that have rows
+#endif
+#if DRAW_STAMPS
+__device__ unsigned long long g_draw_stamps[8];
+#define DSTAMP(k) { unsigned long long _t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)::"memory"); d_acc[k] += _t - d_last; d_last = _t; }
+#else
+#define DSTAMP(k)
+#endif
+
 template <int NCT>
 __global__ void __launch_bounds__(256, 2)
 draw_rng_kernel(const double *__restrict__ T, size_t t_ldl, int t_row0, const int32_t *__restrict__ info,
@@ -176,6 +187,7 @@ draw_rng_kernel(const double *__restrict__ T, size_t t_ldl, int t_row0, const in
     // Bs[n][slot' = slot ^ (n & 15)][2]: the 16-byte slots of a row are XOR-swizzled with the row number
     // (applied on the DMA source address), so that 16 rows read at the same k hit 16 distinct slots
     extern __shared__ __attribute__((aligned(16))) double lds[];  // [2][NC][ROWD]
+    __shared__ double2 log_tab_s[47];      // LDS copy of the log table of the Box-Muller radius (see fast_log01)
 
     // workgroup = 64 values of m x (re, im): waves 0,1 draw the real parts, waves 2,3 the imaginary parts of the
     // SAME m, so that both halves of every 64-byte a_lm cell ([re x4 | im x4]) are written by one workgroup within
@@ -189,6 +201,10 @@ draw_rng_kernel(const double *__restrict__ T, size_t t_ldl, int t_row0, const in
     const int c_of = wave >> 1;
     const int ri = lane & 15, kq = lane >> 4;
     if (mb * 64 >= lp1) return;                 // no m of this l in the block (half the [l][m-block] grid): uniform, before any barrier / DMA
+#if DRAW_STAMPS
+    unsigned long long d_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, d_last;
+    { unsigned long long _t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)::"memory"); d_last = _t; }
+#endif
     const int m0 = mb * 64 + (wave & 1) * 32;   // first m of this wave
     const int mpair = (m0 >> 1) + ri;           // this lane's m-pair: rows m = 2 mpair, 2 mpair + 1
     const bool pair_ok = 2 * mpair < lp1;
@@ -224,6 +240,8 @@ draw_rng_kernel(const double *__restrict__ T, size_t t_ldl, int t_row0, const in
             const double *src = zeros;  // F is even on this path (host wrapper), so k + 1 < F whenever k < F
             if (col0 + n < nnu && nu < F && k + 1 < F) src = Tl + (size_t)nu * F + k;
 #if DRAW_ABLATE != 4   // diagnostic 4: no staging of T
+            // (LDS-DMA moves only ~10 B/clk per CU - MI355X_MICROARCH.md "ldsdma-fill" - but staging through registers,
+            //  global_load_dwordx4 + ds_write_b128 committed before the next barrier, was slower still: 14.0 vs 10.1 ms)
             draw_glds16(src, lds_base + (unsigned)(((c & 1) * BUF + 4 * rq * ROWD) * sizeof(double)));
 #else
             (void)src;
@@ -232,11 +250,15 @@ draw_rng_kernel(const double *__restrict__ T, size_t t_ldl, int t_row0, const in
     };
     (void)full_k;
 
+    if (threadIdx.x < 47) log_tab_s[threadIdx.x] = LOG_TAB[threadIdx.x];   // (visible after the first chunk's barrier)
     stage(0);
+    DSTAMP(0);                           // prologue + first stage issue
     for (int c = 0; c < nchunk; c++) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                 // chunk c landed; everyone is done with chunk c-1
+        DSTAMP(1);                       // wait for the stage + barrier
         if (c + 1 < nchunk) stage(c + 1);
+        DSTAMP(2);                       // issue of the next stage
         if (!wave_has_rows) continue;
         const double *sb = lds + (c & 1) * BUF;
         const int k0 = c * DRAW_KC;
@@ -249,7 +271,11 @@ draw_rng_kernel(const double *__restrict__ T, size_t t_ldl, int t_row0, const in
 #if DRAW_ABLATE == 1   // diagnostic: no RNG
             if (pair_ok && kp < F) a = make_double2(1.0 + kp, 0.5 * mpair);
 #else
-            if (pair_ok && kp < F) a = philox_normal_pair(seed, l, F, c_of, kp, mpair);
+            if (pair_ok && kp < F) a = philox_normal_pair(seed, l, F, c_of, kp, mpair, log_tab_s);
+#endif
+#if DRAW_STAMPS
+            asm volatile("" ::"v"(a.x), "v"(a.y));
+            DSTAMP(3);                   // normals of the k-step
 #endif
             const int kl = 4 * kk + kq;          // k within the chunk
             // all B operands of the k-step are read up front (one address + immediate offsets); with the read inside
@@ -268,6 +294,7 @@ draw_rng_kernel(const double *__restrict__ T, size_t t_ldl, int t_row0, const in
                 acc1[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, bv[t], acc1[t], 0, 0, 0);
 #endif
             }
+            DSTAMP(4);                   // B reads + MFMA issue of the k-step
         }
     }
     if (!wave_has_rows) return;
@@ -294,6 +321,13 @@ draw_rng_kernel(const double *__restrict__ T, size_t t_ldl, int t_row0, const in
             }
         }
     }
+#if DRAW_STAMPS
+    DSTAMP(5);                           // epilogue (scale + a_lm stores issued)
+    if (lane == 0) {
+        for (int k = 0; k < 6; k++) atomicAdd(&g_draw_stamps[k], d_acc[k]);
+        atomicAdd(&g_draw_stamps[7], 1ull);
+    }
+#endif
 }
 
 template <int NCT>
@@ -311,6 +345,17 @@ static int launch_draw_rng(corahip_ctx *ctx, const double *T, size_t t_ldl, int 
     draw_rng_kernel<NCT><<<grid, 256, shm, ctx->stream>>>(T, t_ldl, t_row0, info, zeros, seed, lmax, F, nu0, nnu, Gout,
                                                           alm);
     LAUNCH_CHECK();
+#if DRAW_STAMPS
+    {
+        unsigned long long hs[8], z[8] = {0};
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        HIP_TRY(hipMemcpyFromSymbol(hs, HIP_SYMBOL(g_draw_stamps), sizeof(hs)));
+        const double per = 1.0 / (double)std::max<unsigned long long>(hs[7], 1);
+        fprintf(stderr, "K3 NCT=%d waves=%llu: cycles/wave  prologue %.0f wait+barrier %.0f stage-issue %.0f rng %.0f reads+mfma %.0f epilogue %.0f\n",
+                NCT, hs[7], hs[0] * per, hs[1] * per, hs[2] * per, hs[3] * per, hs[4] * per, hs[5] * per);
+        HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_draw_stamps), z, sizeof(z)));
+    }
+#endif
     return 0;
 }
 

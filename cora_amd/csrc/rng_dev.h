@@ -49,14 +49,16 @@ __device__ static const double2 LOG_TAB[47] = {
 #include "log_tab.inc"
 };
 
-__device__ static inline double fast_log01(double x) {  // x in (0, 1]
+// `tab`: the 47-entry table, LOG_TAB itself or a copy of it in LDS (K3: a look-up in global memory is a dependent
+// vmcnt-ordered load on the critical path of every normal pair - and waits for the LDS-DMA stage issued before it)
+__device__ static inline double fast_log01(double x, const double2 *tab = LOG_TAB) {  // x in (0, 1]
     double m = __builtin_amdgcn_frexp_mant(x);           // [0.5, 1)
     int e = __builtin_amdgcn_frexp_exp(x);
     const bool lo = m < 0.70710678118654752440;
     m = lo ? m + m : m;                                  // [1/sqrt2, sqrt2)
     e = lo ? e - 1 : e;
     const int i = (int)__builtin_rint(m * 64.0);         // 45 .. 91
-    const double2 tc = LOG_TAB[i - 45];
+    const double2 tc = tab[i - 45];
     const double r = fma(m, tc.x, -1.0);
     double p = -1.0 / 8.0;
     p = fma(p, r, 1.0 / 7.0);

@@ -173,7 +173,7 @@ class SkyShard:
             self._sep = None
         else:
             al, bcov = cplan["prepare"](larr.copy(), za)
-            self._sep = (ctx.to_device(al[sp.l_lo:sp.l_hi]), ctx.to_device(bcov))
+            self._sep = (ctx.to_device(al[sp.l_lo:sp.l_hi]), ctx.to_device(bcov), ctx.to_device(al))
         nalm = L * (L + 1) // 2
         self.npix = 12 * self.nside * self.nside
         ctx.sht_plan(self.nside, self.lmax)
@@ -207,6 +207,25 @@ class SkyShard:
             return ctx.clarray_separable(self._sep[0], self._sep[1], self.F, self.zint, self.w)
         return ctx.clarray_table21cm(*self._tabs, *self._k1, self.F, self.zint, self.w, self._lx)
 
+    def _separable_factors(self):
+        """Separable model C_l = A_l B (ForegroundSCK, cora/foreground/gaussianfg.py:107-130): the reference factors
+        every jittered block C_l + 1e-14 max(diag C_l) I = A_l (B + 1e-14 max(diag B) I) on its own (skysim.py:115-119);
+        that root is sqrt(A_l) root(B + 1e-14 max(diag B) I) for every l, so ONE factorisation serves all multipoles
+        (SURVEY 8 a6).  Every rank makes it for itself - an F x F Cholesky - and keeps the rows of its own channels:
+        no C_l stack, no exchange.  A_l = 0 (l = 0) gives the zero root the reference's eigen branch returns.  (With
+        cond(B) ~ 1e19 the factor of a scaled block differs from the scaled factor at the 1e-7 level; T T^T = C_l
+        holds to rounding either way: the near-singular contract of SURVEY 8 a8.)"""
+        import torch
+
+        ctx = self.ctx
+        one = torch.ones((1,), dtype=torch.float64, device=ctx.device)
+        bbar = ctx.clarray_separable(one, self._sep[1], self.F, self.zint, self.w)          # channel-averaged B [1, F, F]
+        tb, ib = ctx.factor_batched(bbar)
+        rows = tb[0, self.nu0:self.nu0 + self.nnu, :]
+        T = torch.sqrt(self._sep[2])[:, None, None] * rows[None, :, :]                       # [L, nnu, F]
+        info = ib.expand(self.L).contiguous()
+        return T.contiguous(), info, True
+
     def _clarray_pairs(self, first, step):
         return self.ctx.clarray_table21cm_pairs(*self._tabs, *self._k1, self.F, self.zint, self.w, self._lx, first, step,
                                                 self.plan.l_shard, nblocks=step)
@@ -215,6 +234,8 @@ class SkyShard:
         """(T, info, rows): the factors this rank's draw needs; ``rows`` tells whether T holds only the rank's row
         blocks ``[L, nnu, F]`` (pair-sharded path) or the full ``[L, F, F]`` stack."""
         ctx, sp = self.ctx, self.plan
+        if self._sep is not None:          # (also under emulate_world: this IS the rank's whole cold part)
+            return self._separable_factors()
         if self.emulate_world > 1:
             N = self.emulate_world
             if self.pair_sharded:
