@@ -298,26 +298,36 @@ draw_rng_kernel(const double *__restrict__ T, size_t t_ldl, int t_row0, const in
         }
     }
     if (!wave_has_rows) return;
-    // epilogue: C row i of tile0 is m = m0 + 2 i, of tile1 m = m0 + 2 i + 1; 1/sqrt(2) of complex_std_normal
+    // epilogue: C row i of tile0 is m = m0 + 2 i, of tile1 m = m0 + 2 i + 1; 1/sqrt(2) of complex_std_normal.
+    // Lanes (ri, ri ^ 1) hold adjacent channels of the same rows: the even lane takes the m-even row of BOTH channels, the
+    // odd lane the m-odd row (one DPP swap per value), so every store is 16 bytes instead of 8 - the a_lm stores are
+    // issue-bound (~7 B/clk per CU for 8-byte lanes: 13 % of the kernel's wave cycles by the phase stamps).
     const double sc = 0.70710678118654752440;
+    const bool odd = ri & 1;
+    auto swap1 = [](double v) {            // value of lane ^ 1 (quad_perm [1, 0, 3, 2])
+        int lo = __double2loint(v), hi = __double2hiint(v);
+        lo = __builtin_amdgcn_update_dpp(lo, lo, 0xB1, 0xF, 0xF, false);
+        hi = __builtin_amdgcn_update_dpp(hi, hi, 0xB1, 0xF, 0xF, false);
+        return __hiloint2double(hi, lo);
+    };
 #pragma unroll
     for (int t = 0; t < NCT; t++) {
-        const int col = col0 + 16 * t + ri;
-        if (col >= 4 * Gout) continue;
+        const int col = col0 + 16 * t + (ri & ~1);          // first channel of the lane pair
+        const bool col_ok = col < 4 * Gout;                 // (4 Gout is a multiple of 4: both channels or none)
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             const int i = kq + 4 * r;
-#pragma unroll
-            for (int par = 0; par < 2; par++) {
-                const int m = m0 + 2 * i + par;
-                if (m < lp1) {
-                    const long idx = (long)m * (2 * lmax + 1 - m) / 2 + l;
+            const double mine = (odd ? acc1[t][r] : acc0[t][r]) * sc;      // this lane's channel of the row it stores
+            const double give = (odd ? acc0[t][r] : acc1[t][r]) * sc;      // the partner's row
+            const double got = swap1(give);                                  // the partner's channel of MY row
+            const int m = m0 + 2 * i + (odd ? 1 : 0);
+            if (col_ok && m < lp1) {
+                const long idx = (long)m * (2 * lmax + 1 - m) / 2 + l;
 #if DRAW_ABLATE == 3   // diagnostic: no a_lm stores
-                    if (acc0[t][r] == 1.2345e300)
+                if (mine == 1.2345e300)
 #endif
-                    alm[((size_t)idx * Gout + (col >> 2)) * 8 + c_of * 4 + (col & 3)] =
-                        (par ? acc1[t][r] : acc0[t][r]) * sc;
-                }
+                *reinterpret_cast<double2 *>(alm + ((size_t)idx * Gout + (col >> 2)) * 8 + c_of * 4 + (col & 3)) =
+                    odd ? make_double2(got, mine) : make_double2(mine, got);
             }
         }
     }
