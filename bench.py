@@ -354,7 +354,7 @@ def host_delivered_rate(ctx, shard, nside, F, npix, nrep=4):
     if avail < need + 32e9:
         return {"skipped": "host has %.0f GB available, the leg needs %.0f GB of pinned memory" % (avail / 1e9, need / 1e9)}
     T, info, rows = shard.factors()
-    if rows:
+    if rows and T.shape[1] != T.shape[2]:
         return {"skipped": "row-sliced factors"}
     t0 = time.time()
     nwarm = 3                              # three pinned blocks rotate (in flight, delivered, being filled): page-locked once
