@@ -283,3 +283,26 @@ def test_cfg5_factor_and_draw_F1024_vs_numpy(ctx, cfg5_cl):
     # and a frequency shard of it (the 128 channels one of eight ranks owns)
     c = ctx.alm_dev_to_square(ctx.draw_alm_philox(T, info, 77, lmax, F, nu0=640, nnu=128), lmax, 128)
     assert torch.equal(c, b[640:768])
+
+
+def test_default_lmax_aliased_rings_pixel_parity(ctx):
+    """The reference's own default, lmax = 3 nside - 1 (cora/core/maps.py:230), at nside 1024: lmax = 3071 exceeds
+    half the ring length on EVERY ring, so the fold of the ring FFT aliases everywhere (belt included) and the cell
+    rows are longer than the prefetch window of the compile-time kernels - paths the lmax = 2 nside configurations
+    never take.  Channels 0 and 6 of an 8-channel launch against the oracle, per ring-FFT class."""
+    import torch
+    from oracle import sht
+
+    nside, lmax, nnu = 1024, 3071, 8
+    nalm = (lmax + 1) * (lmax + 2) // 2
+    alm = _red_alm(ctx, (nalm, 2, 2, 4), lmax, 35)
+    maps = ctx.alm2map(alm, nside, lmax, nnu)
+    worst = {}
+    for f in (0, 6):
+        ref = sht.alm2map(_packed_of(alm, f), nside, lmax)
+        for c, e in _per_class_error(maps[f].cpu().numpy(), ref, nside).items():
+            worst[c] = max(worst.get(c, 0.0), e)
+    del maps, alm
+    torch.cuda.empty_cache()
+    print("nside 1024 / lmax 3071 alm2map max|err|/rms per class:", worst)
+    assert max(worst.values()) <= 2e-11, worst
