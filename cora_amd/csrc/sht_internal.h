@@ -54,7 +54,6 @@ struct corahip_sht_plan {
     int32_t *d_blu_P = nullptr;                           // [nside]: 0 = power-of-two ring
     int64_t *d_blu_boff = nullptr, *d_blu_foff = nullptr; // offsets into chirp / filter arrays
     double2 *d_bchirp = nullptr, *d_bfilt = nullptr;
-    double2 *d_bchirp2 = nullptr;                         // i e^{i pi j / h} b_j at the offsets of d_bchirp (compile-time kernels)
     // second set of Bluestein filters for the rings whose 2 h - 1 also fits 3/4 of the power-of-two length (P3 = 1536 or
     // 3072): used by the compile-time synthesis kernels only; everything else (analysis, run-time kernel) keeps blu_P
     std::vector<int32_t> h_blu3_P;                        // [nside]: 0 = none

@@ -138,7 +138,7 @@ __global__ void lmin_kernel(int lmax, int npair, int ntile, const int32_t *__res
 // and filt = FFT_P(conj chirp wrapped), stored in the digit-reversed order fft_dif produces.
 __global__ void __launch_bounds__(256)
 bluestein_table_kernel(const int32_t *__restrict__ blu_P, const int64_t *__restrict__ boff,
-                       const int64_t *__restrict__ foff, double2 *__restrict__ chirp, double2 *__restrict__ chirp2,
+                       const int64_t *__restrict__ foff, double2 *__restrict__ chirp,
                        double2 *__restrict__ filt, const double2 *__restrict__ tw, int pmax, int tl_off) {
     extern __shared__ __attribute__((aligned(16))) double2 fbuf[];   // [fpad_len(maxlen) + 1] then the twiddle table
     const int i = blockIdx.x + 1;
@@ -159,12 +159,6 @@ bluestein_table_kernel(const int32_t *__restrict__ blu_P, const int64_t *__restr
         double s, c;
         sincospi((double)q / (double)h, &s, &c);
         b[j] = make_double2(c, s);
-        {   // i w^j b_j, w = e^{2 pi i / n}, n = 2 h: phase (j^2 + j) / h, reduced exactly
-            const long q2 = ((long)j * j + j) % (2 * h);
-            double s2, c2;
-            sincospi((double)q2 / (double)h, &s2, &c2);
-            chirp2[boff[i - 1] + j] = make_double2(-s2, c2);
-        }
         fbuf[fpad(j)] = make_double2(c, -s);
         if (j > 0) fbuf[fpad(P - j)] = make_double2(c, -s);
     }
@@ -207,7 +201,6 @@ int corahip_sht_plan_destroy(corahip_ctx *ctx, corahip_sht_plan *p) {
     (void)hipFree(p->d_blu_P);
     (void)hipFree(p->d_blu_boff);
     (void)hipFree(p->d_blu_foff);
-    (void)hipFree(p->d_bchirp2);
     (void)hipFree(p->d_blu3_foff);
     (void)hipFree(p->d_bfilt3);
     (void)hipFree(p->d_bchirp);
@@ -371,7 +364,6 @@ int corahip_sht_plan_create(corahip_ctx *ctx, int nside, int lmax, corahip_sht_p
         if ((rc = dev_upload(&p->d_blu_boff, bo, s))) return rc;
         if ((rc = dev_upload(&p->d_blu_foff, fo, s))) return rc;
         HIP_TRY(hipMalloc((void **)&p->d_bchirp, sizeof(double2) * std::max<int64_t>(1, nb)));
-        HIP_TRY(hipMalloc((void **)&p->d_bchirp2, sizeof(double2) * std::max<int64_t>(1, nb)));
         HIP_TRY(hipMalloc((void **)&p->d_bfilt, sizeof(double2) * std::max<int64_t>(1, nf)));
         if (nside > 1) {
             const int tl_off = fpad_len(maxlen) + 1;
@@ -379,7 +371,7 @@ int corahip_sht_plan_create(corahip_ctx *ctx, int nside, int lmax, corahip_sht_p
             HIP_TRY(hipFuncSetAttribute((const void *)bluestein_table_kernel,
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
             bluestein_table_kernel<<<nside - 1, 256, shm, s>>>(p->d_blu_P, p->d_blu_boff, p->d_blu_foff,
-                                                                p->d_bchirp, p->d_bchirp2, p->d_bfilt, p->d_tw, p->pmax, tl_off);
+                                                                p->d_bchirp, p->d_bfilt, p->d_tw, p->pmax, tl_off);
             LAUNCH_CHECK();
         }
     }

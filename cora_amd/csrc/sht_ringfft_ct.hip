@@ -15,8 +15,8 @@
 //     its 16 inputs and their 16 mirror partners, one barrier, then writes) and the last pass stores pixels
 //     straight from registers (128-byte segments): four LDS write passes per item instead of five, no
 //     bank-conflicted digit-reversed read pass;
-//   * Bluestein class: chirp, i w^k chirp (plan-time table: no sincospi per item), filter and output-chirp
-//     values are requested one phase ahead of their use; the first forward pass reads only the non-zero half
+//   * Bluestein class: chirp (w^k of the pre-pass is the square of the fold phase: no table, no sincospi), filter and
+//     output-chirp values are requested ahead of their use; the first forward pass reads only the non-zero half
 //     of the padded input and the last inverse pass forms only the h outputs that exist (so the upper half of
 //     the buffer is never zero-filled); last forward pass + filter + first inverse pass stay in registers.
 // LDS stores are the expensive operation of these kernels (ds_write_b128: 13 cycles per wave-instruction against
@@ -433,7 +433,7 @@ ringfft_blu_ct(const int32_t *__restrict__ ring_list, int nlist, int nside, int 
                const int32_t *__restrict__ nphi_a, const int64_t *__restrict__ start_a,
                const double *__restrict__ phi0_a, const double *inter, double *maps,
                const int64_t *__restrict__ boff, const int64_t *__restrict__ foff, const double2 *chirp,
-               const double2 *chirp2, const double2 *filt, const int32_t *__restrict__ mcut) {
+               const double2 *filt, const int32_t *__restrict__ mcut) {
     // (inter, maps, chirp, filt are deliberately NOT __restrict__: the compiler then may not move their loads across the
     //  barriers / pixel stores, and the places where this kernel requests them - one phase ahead of their use, and all
     //  of them completed before the first store - are the places where they are issued; with __restrict__ the chirp
@@ -700,7 +700,7 @@ static int launch_blu(corahip_ctx *ctx, hipStream_t stream, int wg_per_cu, const
                                 160 * 1024));
     ringfft_blu_ct<P, NCH, MC, T><<<grid, T, shm, stream>>>(c.d_list, c.count, p->nside, p->lmax, G, nnu, p->npix, p->d_nphi,
                                                             p->d_start, p->d_phi0, inter, maps, p->d_blu_boff,
-                                                            d_foff, p->d_bchirp, p->d_bchirp2, d_filt, p->d_mcut);
+                                                            d_foff, p->d_bchirp, d_filt, p->d_mcut);
     LAUNCH_CHECK();
 #if CT_STAMPS
     {

@@ -10,7 +10,7 @@ import torch  # noqa: E402
 
 from cora_amd import _lib  # noqa: E402
 
-nside, lmax, nnu = 1024, 2048, int(os.environ.get("NNU", "256"))
+nside, lmax, nnu = int(os.environ.get("NSIDE", "1024")), int(os.environ.get("LMAX", "2048")), int(os.environ.get("NNU", "256"))
 ctx = _lib.get_context()
 nalm = (lmax + 1) * (lmax + 2) // 2
 alm = ctx.empty((nalm, nnu // 4, 2, 4)).normal_()
