@@ -6,6 +6,7 @@ kernels through :mod:`cora_amd.core.skysim`.
 """
 import numpy as np
 
+from .. import _lib
 from ..util import constants
 from . import skysim
 
@@ -146,9 +147,12 @@ class Sky3d(Map3d):
         nu = self._channels()
         cl = skysim.clarray_device(self.angular_powerspectrum, self._lmax(), nu,
                                    zromb=self.oversample)
-        fluct = skysim.mkfullsky_device(cl, self.nside, rng=rng).cpu().numpy()
-        fluct += self.mean_nu(nu)[:, np.newaxis]
-        return fluct
+        fluct = skysim.mkfullsky_device(cl, self.nside, rng=rng)
+        ctx = _lib.get_context()
+        mean = np.asarray(self.mean_nu(nu), dtype=np.float64) * np.ones(nu.shape)
+        if np.any(mean != 0.0):          # added on the device: a pass over 25.8 GB of host memory is seconds
+            fluct += ctx.to_device(mean)[:, None]
+        return ctx.to_host(fluct)        # pinned memory: PCIe-rate copy
 
     def getpolsky(self, rng=None):
         """``[nfreq, 4, npix]`` Stokes cube with only I populated (maps.py:239-247)."""
@@ -161,4 +165,4 @@ class Sky3d(Map3d):
     def getalms(self, lmax, rng=None):
         """Harmonic coefficients ``[nfreq, 1, lmax+1, lmax+1]`` (maps.py:249-252)."""
         cl = skysim.clarray_device(self.angular_powerspectrum, lmax, self._channels())
-        return skysim.mkfullsky_device(cl, self.nside, alms=True, rng=rng).cpu().numpy()
+        return _lib.get_context().to_host(skysim.mkfullsky_device(cl, self.nside, alms=True, rng=rng))

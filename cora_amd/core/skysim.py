@@ -107,7 +107,7 @@ def clarray(aps, lmax, zarray, zromb=3, zwidth=None):
     -------
     aps : np.ndarray[lmax+1, len(zarray), len(zarray)]
     """
-    return clarray_device(aps, lmax, zarray, zromb=zromb, zwidth=zwidth).cpu().numpy()
+    return _lib.get_context().to_host(clarray_device(aps, lmax, zarray, zromb=zromb, zwidth=zwidth))
 
 
 def _host_normals(numz, maxl, rng):

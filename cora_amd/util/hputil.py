@@ -152,7 +152,7 @@ def _synth(alm_list, nside):
 
     alm_dev = ctx.alm_packed_to_dev(torch.from_numpy(np.ascontiguousarray(packed)).to(ctx.device), lmax)
     maps = ctx.alm2map(alm_dev, int(nside), lmax, n)
-    return maps.cpu().numpy()
+    return _lib.get_context().to_host(maps)
 
 
 def sphtrans_inv_real(alm, nside):
