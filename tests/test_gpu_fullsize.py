@@ -306,3 +306,27 @@ def test_default_lmax_aliased_rings_pixel_parity(ctx):
     torch.cuda.empty_cache()
     print("nside 1024 / lmax 3071 alm2map max|err|/rms per class:", worst)
     assert max(worst.values()) <= 2e-11, worst
+
+
+@pytest.mark.parametrize("nside,lmax,nnu", [(1024, 700, 5), (1024, 1500, 8), (512, 1024, 12), (2048, 2048, 3)])
+def test_compile_time_ring_kernels_other_shapes(ctx, nside, lmax, nnu):
+    """The compile-time ring-FFT kernels away from lmax = 2 nside and from whole channel groups: short cell rows (the
+    register prefetch window reaches past the row), ragged channel counts (3, 5, 12: padding lanes of the 4- and
+    2-channel workgroups), nside 512 (Bluestein classes 2048 / 1536 / 1024 compile-time, belt run-time) and nside
+    2048 at lmax = nside.  First and last channel against the oracle, per class."""
+    import torch
+    from oracle import sht
+
+    nalm = (lmax + 1) * (lmax + 2) // 2
+    G = (nnu + 3) // 4
+    alm = _red_alm(ctx, (nalm, G, 2, 4), lmax, 36 + nnu)
+    maps = ctx.alm2map(alm, nside, lmax, nnu)
+    worst = {}
+    for f in (0, nnu - 1):
+        ref = sht.alm2map(_packed_of(alm, f), nside, lmax)
+        for c, e in _per_class_error(maps[f].cpu().numpy(), ref, nside).items():
+            worst[c] = max(worst.get(c, 0.0), e)
+    del maps, alm
+    torch.cuda.empty_cache()
+    print("nside %d lmax %d nnu %d: max|err|/rms per class: %s" % (nside, lmax, nnu, worst))
+    assert max(worst.values()) <= 2e-11, worst
