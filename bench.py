@@ -324,6 +324,8 @@ def main():
                 "unit": "GB/s",
                 "frac": (16.0 * (4 * nside - 1) * L * nnu + 8.0 * npix * nnu) / (stages.get("ringfft", {"ms_per_launch": float("nan")})["ms_per_launch"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
             },
+            # every stage against the roof that bounds it (algorithmic work of SURVEY 8(d) / DESIGN section 3 per launch)
+            "stage_rooflines": stage_rooflines(stages, nside, lmax, F, nnu, zromb),
             "hbm_roofline_whole_step": {
                 "algorithmic_GB": alg_bytes / 1e9,
                 "achieved_GBs": alg_bytes / 1e9 / (ms_step * 1e-3),
@@ -339,6 +341,30 @@ def main():
     if dist is not None:
         dist.destroy_process_group()
     return result
+
+
+def stage_rooflines(stages, nside, lmax, F, nnu, zromb):
+    L = lmax + 1
+    nalm = L * (L + 1) // 2
+    npix = 12 * nside * nside
+    zint = 2**zromb + 1 if zromb else 1
+    work = {
+        # name: (bound, algorithmic flops, algorithmic bytes)
+        "clarray": ("valu", 60.0 * L * (F * zint) ** 2 / 2, 8.0 * L * F * F),
+        "factor": ("valu", L * F**3 / 3.0, 16.0 * L * F * F),
+        "draw": ("mfma", 2.0 * F * nnu * nalm, 8.0 * L * F * nnu + 16.0 * nalm * nnu),
+        "legendre": ("mfma", 8.0 * nside * nalm * nnu, 16.0 * nalm * nnu + 16.0 * (4 * nside - 1) * L * nnu),
+        "ringfft": ("hbm", 2.5 * npix * np.log2(4 * nside) * nnu, 16.0 * (4 * nside - 1) * L * nnu + 8.0 * npix * nnu),
+    }
+    out = {}
+    for k, (bound, flops, nbytes) in work.items():
+        if k not in stages:
+            continue
+        sec = stages[k]["ms_per_launch"] * 1e-3
+        e = {"ms": stages[k]["ms_per_launch"], "bound": bound, "TFLOPs": flops / sec / 1e12, "GBs": nbytes / sec / 1e9}
+        e["frac"] = e["GBs"] / HBM_PEAK_GBS if bound == "hbm" else e["TFLOPs"] / FP64_MFMA_PEAK_TFLOPS
+        out[k] = e
+    return out
 
 
 def host_delivered_rate(ctx, shard, nside, F, npix, nrep=4):
