@@ -232,6 +232,10 @@ draw_rng_kernel(const double *__restrict__ T, size_t t_ldl, int t_row0, const in
         for (int it = 0; it < NC / 16; it++) {      // NC/4 row-quads over 4 waves
             const int rq = wave + 4 * it;           // row quad index
             if (rq >= NC / 4) break;
+            // triangular factors: a 16-row tile whose rows all have nu < k0 is zero in this chunk and its MFMAs are
+            // skipped below (the same test at kbase >= k0), so its four quads need not be staged at all (a third of the
+            // LDS-DMA volume); tile granularity, not quad: a partly-zero tile is still multiplied as a whole
+            if (!dense && k0 > nu0 + col0 + 16 * (rq >> 2) + 15) continue;
             const int n = 4 * rq + (lane >> 4);     // row of this lane
             const int slot_dst = lane & 15;
             const int slot_src = slot_dst ^ (n & 15);
