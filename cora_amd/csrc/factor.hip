@@ -123,17 +123,32 @@ chol_kernel(const double *__restrict__ C, int F, double jitter_rel, double *__re
         }
         __syncthreads();  // panel visible to the whole workgroup (same CU, write-through L1)
         // ---- 3. trailing update A22 -= X X^T (lower triangle), 64x64 tiles, 4x4 per thread
+        // (the kernel is latency-bound: one workgroup per matrix, every tile a load -> barrier -> compute -> read-modify-
+        //  write -> barrier chain against L2.  The row panel PA is loaded once per tile row, and the A22 elements the
+        //  thread will update are requested BEFORE the product is formed, so their L2 latency hides behind it.)
         const int nt = (F - r0 + 63) / 64;
         for (int ti = 0; ti < nt; ti++) {
+            const int i0 = r0 + ti * 64;
+            for (int q = tid; q < 64 * CH_NB; q += 256) {
+                const int rr = q / CH_NB, cc = q % CH_NB;
+                PA[rr * (CH_NB + 1) + cc] = (i0 + rr < F && cc < nb) ? Tl[(size_t)(i0 + rr) * F + kb + cc] : 0.0;
+            }
             for (int tj = 0; tj <= ti; tj++) {
-                const int i0 = r0 + ti * 64, j0 = r0 + tj * 64;
+                const int j0 = r0 + tj * 64;
                 for (int q = tid; q < 64 * CH_NB; q += 256) {
                     const int rr = q / CH_NB, cc = q % CH_NB;
-                    PA[rr * (CH_NB + 1) + cc] = (i0 + rr < F && cc < nb) ? Tl[(size_t)(i0 + rr) * F + kb + cc] : 0.0;
                     PB[rr * (CH_NB + 1) + cc] = (j0 + rr < F && cc < nb) ? Tl[(size_t)(j0 + rr) * F + kb + cc] : 0.0;
                 }
-                __syncthreads();
                 const int ty = tid >> 4, tx = tid & 15;  // 16 x 16 threads, each a 4x4 micro tile
+                double old[4][4];
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+#pragma unroll
+                    for (int w = 0; w < 4; w++) {
+                        const int i = i0 + ty + 16 * u, j = j0 + tx + 16 * w;
+                        old[u][w] = (i < F && j <= i) ? Tl[(size_t)i * F + j] : 0.0;
+                    }
+                __syncthreads();
                 double acc[4][4] = {};
                 for (int p = 0; p < CH_NB; p++) {
                     double a[4], b[4];
@@ -152,7 +167,7 @@ chol_kernel(const double *__restrict__ C, int F, double jitter_rel, double *__re
 #pragma unroll
                     for (int w = 0; w < 4; w++) {
                         const int i = i0 + ty + 16 * u, j = j0 + tx + 16 * w;
-                        if (i < F && j <= i) Tl[(size_t)i * F + j] -= acc[u][w];
+                        if (i < F && j <= i) Tl[(size_t)i * F + j] = old[u][w] - acc[u][w];
                     }
                 __syncthreads();
             }
