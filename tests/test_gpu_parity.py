@@ -608,7 +608,8 @@ def test_config3_full_size_properties(ctx):
 
 
 def test_frequency_sharded_pipeline_matches_single_gpu():
-    """bench.py's N-rank paths, run as 2, 4 (and 8) ranks sharing this one GPU over gloo, give the same per-channel
+    """bench.py's N-rank paths, run as 2 and 3 ranks sharing this one GPU over gloo (the GPU boxes allow at most 6
+    processes on the card: this process + the launcher + the ranks), give the same per-channel
     map statistics as 1 rank: cfg2 (separable model: l-sharded C_l/factor -> all-gather) and a small 21cm
     case (pair-sharded C_l -> all-to-all -> l-sharded factor -> all-to-all of factor rows).  The RCCL
     calls themselves are exercised with a 1-rank nccl group (--force-dist)."""
@@ -629,7 +630,7 @@ def test_frequency_sharded_pipeline_matches_single_gpu():
     for workload in ("cfg2", "tiny"):
         common = ["--workload", workload, "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--checksum"]
         ref = run([sys.executable, "bench.py"] + common)
-        for n in ((2, 4, 8) if workload == "tiny" else (2, 4)):
+        for n in (2, 3):   # 3 does not divide F: the l-shard + all-gather fall-back of the row exchange
             port += 1
             got = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
                        "--master-addr", "127.0.0.1", "--master-port", str(port), "bench.py", "--gpus", str(n),
