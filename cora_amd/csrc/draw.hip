@@ -10,26 +10,20 @@
 // from the stream-ordered buffer (each element is used by exactly one wave).
 #include "common.h"
 
+#include <type_traits>
+
 #include "rng_dev.h"
 
-// The device stream: the normals of (l, c = re/im, nu', m) and (.., m+1), m even, are the two
-// Box-Muller outputs of Philox counter {lo = m/2, hi = l*2F + c*F + nu'} under key = seed:
-//   u1 = (k1 + 0.5) 2^-53, u2 = (k2 + 0.5) 2^-53 with k1 = r0 << 21 | r1 >> 11, k2 = r2 << 21 | r3 >> 11;
-//   (sqrt(-2 ln u1) cos(2 pi u2), sqrt(-2 ln u1) sin(2 pi u2)).
+// The device stream: the normals of (l, c = re/im, nu', m) and (.., m+1), m even, are the two Box-Muller outputs
+// of Philox counter {lo = m/2, hi = l*2F + c*F + nu'} under key = seed, built from the four output words as
+// rng_dev.h describes (u1 from 52 bits of (r0, r1), the angle from 60 bits of (r2, r3)).
 // A value depends only on (seed, l, c, nu', m): the same for any number of GPUs, and the same whether it is
 // materialised in HBM (normals_kernel, stream-order layout) or generated inside K3.  oracle/philox.py
 // restates the stream in numpy.
 __device__ static inline double2 philox_normal_pair(uint64_t seed, int l, int F, int c, int nup, int mpair,
-                                                    const double2 *log_tab = LOG_TAB) {
-    uint32_t r[4];
+                                                    const double2 *lg = RNG_LOG_TAB, const double2 *sc = RNG_SC_TAB) {
     const uint64_t ctr = ((uint64_t)((uint32_t)l * 2u * (uint32_t)F + (uint32_t)(c * F + nup)) << 32) | (uint32_t)mpair;
-    philox4x32_10(ctr, seed, r);
-    const double u1 = ((double)(((uint64_t)r[0] << 21) | (r[1] >> 11)) + 0.5) * 0x1p-53;
-    const double u2 = ((double)(((uint64_t)r[2] << 21) | (r[3] >> 11)) + 0.5) * 0x1p-53;
-    const double rad = fast_sqrt_pos(-2.0 * fast_log01(u1, log_tab));
-    double sn, cs;
-    fast_sincos2pi(u2, sn, cs);
-    return make_double2(rad * cs, rad * sn);
+    return philox_boxmuller(ctr, seed, lg, sc);
 }
 
 // one thread per (l, c, nu', m-pair): writes the stream-order buffer  g[F l(l+1) + c F(l+1) + nu'(l+1) + m]
@@ -56,6 +50,9 @@ __global__ void normals_kernel(uint64_t seed, int lmax, int F, double *__restric
 #endif
 #ifndef DRAW_KK_UNROLL
 #define DRAW_KK_UNROLL 1   // unroll factor of the k-step loop of a chunk in the fused-RNG kernel
+#endif
+#ifndef DRAW_BEARLY
+#define DRAW_BEARLY 0  // 1: B-operand LDS reads of a k-step issued before its generator chain
 #endif
 #define DRAW_KC 32   // nu' per LDS stage
 #define DRAW_ROWS 64 // (c,m) rows per block (4 waves x 16)
@@ -176,6 +173,15 @@ __device__ unsigned long long g_draw_stamps[8];
 #define DSTAMP(k)
 #endif
 
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>), in order
+template <int N, int J = 0, class Fn>
+__device__ static inline void draw_static_for(Fn &&f) {
+    if constexpr (J < N) {
+        f(std::integral_constant<int, J>{});
+        draw_static_for<N, J + 1>(f);
+    }
+}
+
 template <int NCT>
 __global__ void __launch_bounds__(256, 2)
 draw_rng_kernel(const double *__restrict__ T, size_t t_ldl, int t_row0, const int32_t *__restrict__ info,
@@ -187,7 +193,7 @@ draw_rng_kernel(const double *__restrict__ T, size_t t_ldl, int t_row0, const in
     // Bs[n][slot' = slot ^ (n & 15)][2]: the 16-byte slots of a row are XOR-swizzled with the row number
     // (applied on the DMA source address), so that 16 rows read at the same k hit 16 distinct slots
     extern __shared__ __attribute__((aligned(16))) double lds[];  // [2][NC][ROWD]
-    __shared__ double2 log_tab_s[47];      // LDS copy of the log table of the Box-Muller radius (see fast_log01)
+    __shared__ double2 lg_s[257], sc_s[256];   // LDS copies of the Box-Muller tables (rng_dev.h): 8 KB
 
     // workgroup = 64 values of m x (re, im): waves 0,1 draw the real parts, waves 2,3 the imaginary parts of the
     // SAME m, so that both halves of every 64-byte a_lm cell ([re x4 | im x4]) are written by one workgroup within
@@ -207,7 +213,6 @@ draw_rng_kernel(const double *__restrict__ T, size_t t_ldl, int t_row0, const in
 #endif
     const int m0 = mb * 64 + (wave & 1) * 32;   // first m of this wave
     const int mpair = (m0 >> 1) + ri;           // this lane's m-pair: rows m = 2 mpair, 2 mpair + 1
-    const bool pair_ok = 2 * mpair < lp1;
 
     const double *Tl = T + (size_t)l * t_ldl - (size_t)t_row0 * F;  // row nu of T_l at Tl + nu F (rows < t_row0 never read)
     const bool dense = (info == nullptr) || (info[l] != 0);
@@ -219,8 +224,10 @@ draw_rng_kernel(const double *__restrict__ T, size_t t_ldl, int t_row0, const in
         acc0[t] = (d4_t){0.0, 0.0, 0.0, 0.0};
         acc1[t] = (d4_t){0.0, 0.0, 0.0, 0.0};
     }
-    const int kmax = dense ? F : min(F, nu0 + col0 + NC);
+    const int base0 = nu0 + col0;                // first channel of the block
+    const int kmax = dense ? F : min(F, base0 + NC);
     const int nchunk = (kmax + DRAW_KC - 1) / DRAW_KC;
+    const bool tri_tail = !dense && (base0 % DRAW_KC) == 0;   // the chunks across the block's own channels drop tiles (below)
     const bool wave_has_rows = m0 < lp1;
     const bool full_k = (F % DRAW_KC) == 0;      // rows of T_l are whole 256-byte runs
 
@@ -235,7 +242,7 @@ draw_rng_kernel(const double *__restrict__ T, size_t t_ldl, int t_row0, const in
             // triangular factors: a 16-row tile whose rows all have nu < k0 is zero in this chunk and its MFMAs are
             // skipped below (the same test at kbase >= k0), so its four quads need not be staged at all (a third of the
             // LDS-DMA volume); tile granularity, not quad: a partly-zero tile is still multiplied as a whole
-            if (!dense && k0 > nu0 + col0 + 16 * (rq >> 2) + 15) continue;
+            if (tri_tail && k0 > base0 + 16 * (rq >> 2) + 15) continue;
             const int n = 4 * rq + (lane >> 4);     // row of this lane
             const int slot_dst = lane & 15;
             const int slot_src = slot_dst ^ (n & 15);
@@ -254,43 +261,41 @@ draw_rng_kernel(const double *__restrict__ T, size_t t_ldl, int t_row0, const in
     };
     (void)full_k;
 
-    if (threadIdx.x < 47) log_tab_s[threadIdx.x] = LOG_TAB[threadIdx.x];   // (visible after the first chunk's barrier)
-    stage(0);
-    DSTAMP(0);                           // prologue + first stage issue
-    for (int c = 0; c < nchunk; c++) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();                 // chunk c landed; everyone is done with chunk c-1
-        DSTAMP(1);                       // wait for the stage + barrier
-        if (c + 1 < nchunk) stage(c + 1);
-        DSTAMP(2);                       // issue of the next stage
-        if (!wave_has_rows) continue;
-        const double *sb = lds + (c & 1) * BUF;
-        const int k0 = c * DRAW_KC;
+    lg_s[threadIdx.x] = RNG_LOG_TAB[threadIdx.x];                          // (visible after the first chunk's barrier)
+    sc_s[threadIdx.x] = RNG_SC_TAB[threadIdx.x];
+    if (threadIdx.x == 0) lg_s[256] = RNG_LOG_TAB[256];
+    // k-steps of one half (16 nu' = 4 k-steps) of the chunk in buffer `sb`, multiplying the tiles TMIN .. NCT-1
+    auto half_steps = [&](auto tmin_c, const double *sb, int k0, int half) {
+        constexpr int TMIN = decltype(tmin_c)::value;
 #pragma unroll DRAW_KK_UNROLL
-        for (int kk = 0; kk < DRAW_KC / 4; kk++) {
-            const int kbase = k0 + 4 * kk;
-            if (kbase >= kmax) break;
-            const int kp = kbase + kq;
-            double2 a = make_double2(0.0, 0.0);
+        for (int kk = 4 * half; kk < 4 * half + 4; kk++) {
+            const int kp = k0 + 4 * kk + kq;
+            const int kl = 4 * kk + kq;          // k within the chunk
+            // all B operands of the k-step are read up front (one address + immediate offsets)
+            double bv[NCT];
+            const double *brow = sb + ri * ROWD + 2 * ((kl >> 1) ^ ri) + (kl & 1);
+#if DRAW_BEARLY        // the reads in front of the generator chain (their latency behind it), pinned by a scheduling barrier
+#pragma unroll
+            for (int t = TMIN; t < NCT; t++) bv[t] = brow[16 * t * ROWD];
+            __builtin_amdgcn_sched_barrier(0);
+#endif
 #if DRAW_ABLATE == 1   // diagnostic: no RNG
-            if (pair_ok && kp < F) a = make_double2(1.0 + kp, 0.5 * mpair);
+            double2 a = make_double2(1.0 + kp, 0.5 * mpair);
 #else
-            if (pair_ok && kp < F) a = philox_normal_pair(seed, l, F, c_of, kp, mpair, log_tab_s);
+            // (rows past l and nu' >= F are generated like any other: their products meet staged zeros or are never
+            //  stored - no exec masking around the chain)
+            double2 a = philox_normal_pair(seed, l, F, c_of, kp, mpair, lg_s, sc_s);
 #endif
 #if DRAW_STAMPS
             asm volatile("" ::"v"(a.x), "v"(a.y));
             DSTAMP(3);                   // normals of the k-step
 #endif
-            const int kl = 4 * kk + kq;          // k within the chunk
-            // all B operands of the k-step are read up front (one address + immediate offsets); with the read inside
-            // the triangular-skip branch every pair of MFMAs waited out an LDS latency first
-            double bv[NCT];
-            const double *brow = sb + ri * ROWD + 2 * ((kl >> 1) ^ ri) + (kl & 1);
+#if !DRAW_BEARLY
 #pragma unroll
-            for (int t = 0; t < NCT; t++) bv[t] = brow[16 * t * ROWD];
+            for (int t = TMIN; t < NCT; t++) bv[t] = brow[16 * t * ROWD];
+#endif
 #pragma unroll
-            for (int t = 0; t < NCT; t++) {
-                if (!dense && kbase > nu0 + col0 + 16 * t + 15) continue;
+            for (int t = TMIN; t < NCT; t++) {
 #if DRAW_ABLATE == 2   // diagnostic: no MFMA
                 asm volatile("" ::"v"(a.x), "v"(a.y), "v"(bv[t]));
 #else
@@ -300,7 +305,45 @@ draw_rng_kernel(const double *__restrict__ T, size_t t_ldl, int t_row0, const in
             }
             DSTAMP(4);                   // B reads + MFMA issue of the k-step
         }
+    };
+    auto chunk_begin = [&](int c) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                 // chunk c landed; everyone is done with chunk c-1
+        DSTAMP(1);                       // wait for the stage + barrier
+        if (c + 1 < nchunk) stage(c + 1);
+        DSTAMP(2);                       // issue of the next stage
+    };
+
+    stage(0);
+    DSTAMP(0);                           // prologue + first stage issue
+    // Tile t (channels base0 + 16 t .. + 15) of a triangular factor is zero for nu' > base0 + 16 t + 15.  With base0 a
+    // multiple of the chunk length the chunks below the block's own channels take every tile and the chunks across them
+    // drop one tile per half: that tail is unrolled so that every half knows its tiles at compile time (the per-tile
+    // tests inside the k-steps were 45 scalar instructions per k-step, issue time next to the MFMAs; a run-time
+    // dispatch per half made the register allocator copy the accumulators between the cases).  A tile that is kept is
+    // multiplied as a whole: the entries above the diagonal are stored zeros.  Any other base0 (uneven channel shards)
+    // takes every tile up to kmax - correct for the same reason, just not minimal.
+    const int c_full = tri_tail ? min(nchunk, base0 / DRAW_KC) : nchunk;
+    int c = 0;
+    for (; c < c_full; c++) {
+        chunk_begin(c);
+        if (!wave_has_rows) continue;
+        const double *sb = lds + (c & 1) * BUF;
+        half_steps(std::integral_constant<int, 0>{}, sb, c * DRAW_KC, 0);
+        if (c * DRAW_KC + 16 < kmax) half_steps(std::integral_constant<int, 0>{}, sb, c * DRAW_KC, 1);
     }
+    draw_static_for<(NC + DRAW_KC - 1) / DRAW_KC>([&](auto jc) {
+        constexpr int J = decltype(jc)::value;
+        if (c >= nchunk) return;         // (uniform; also the dense / unaligned case, where c == nchunk here)
+        chunk_begin(c);
+        if (wave_has_rows) {
+            const double *sb = lds + (c & 1) * BUF;
+            half_steps(std::integral_constant<int, (2 * J < NCT ? 2 * J : NCT)>{}, sb, c * DRAW_KC, 0);
+            if (2 * J + 1 < NCT && c * DRAW_KC + 16 < kmax)
+                half_steps(std::integral_constant<int, (2 * J + 1 < NCT ? 2 * J + 1 : NCT)>{}, sb, c * DRAW_KC, 1);
+        }
+        c++;
+    });
     if (!wave_has_rows) return;
     // epilogue: C row i of tile0 is m = m0 + 2 i, of tile1 m = m0 + 2 i + 1; 1/sqrt(2) of complex_std_normal.
     // Lanes (ri, ri ^ 1) hold adjacent channels of the same rows: the even lane takes the m-even row of BOTH channels, the

@@ -9,9 +9,11 @@ This file is the specification of that stream, checked against the kernels in te
 
   Philox4x32-10 (Salmon et al., SC'11; known-answer vectors of Random123 in tests/test_oracle.py)
   counter = (m // 2, l * 2F + c * F + nu', 0, 0),  key = (seed & 0xffffffff, seed >> 32)
-  k1 = r0 << 21 | r1 >> 11,  k2 = r2 << 21 | r3 >> 11        (two 53-bit integers)
-  u1 = (k1 + 0.5) 2^-53,     u2 = (k2 + 0.5) 2^-53            (IEEE double arithmetic)
-  normal(l, c, nu', m even) = sqrt(-2 ln u1) cos(2 pi u2),  normal(.., m + 1) = sqrt(-2 ln u1) sin(2 pi u2)
+  k = r0 << 20 | r1 >> 12                       (52 bits)   u1 = (k + 1/2) 2^-52        (exact in a double)
+  j = r2 >> 24,  w = (r2 & 0xffffff) << 28 | r3 >> 4   (8 + 52 bits)   theta = 2 pi (j + (w + 1/2) 2^-52) / 256
+  normal(l, c, nu', m even) = sqrt(-2 ln u1) cos(theta),  normal(.., m + 1) = sqrt(-2 ln u1) sin(theta)
+(the uniforms are defined on their bits so that the kernels build them without integer -> double conversions:
+cora_amd/csrc/rng_dev.h; mathematically evaluated here, in extended precision for the angle)
 
 laid out in the reference's stream order: for l: F*(l+1) reals [nu'][m], then F*(l+1) imags.
 """
@@ -46,22 +48,28 @@ def philox4x32_10(c0, c1, c2, c3, k0, k1):
 def boxmuller_counter(seed, lo, hi):
     """The two normals of Philox counter (lo, hi, 0, 0) under key = seed (broadcasts over arrays)."""
     r0, r1, r2, r3 = philox4x32_10(lo, hi, 0, 0, seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
-    k1 = (r0.astype(np.uint64) << np.uint64(21)) | (r1.astype(np.uint64) >> np.uint64(11))
-    k2 = (r2.astype(np.uint64) << np.uint64(21)) | (r3.astype(np.uint64) >> np.uint64(11))
-    u1 = (k1.astype(np.float64) + 0.5) * 2.0**-53
-    u2 = (k2.astype(np.float64) + 0.5) * 2.0**-53
-    rad = np.sqrt(-2.0 * np.log(u1))
-    # octant-exact angle reduction (u2 * 8 is exact) so that the restatement itself is good to ~1e-16
-    a = 8.0 * u2
-    q = np.floor(a).astype(np.int64)
-    f = a - q
-    g = np.where(q & 1, 1.0 - f, f) * (np.pi / 4)
-    s, co = np.sin(g), np.cos(g)
-    swap = ((q + 1) >> 1) & 1
-    cc = np.where(swap, s, co)
-    ss = np.where(swap, co, s)
-    cs = np.where(((q + 2) >> 2) & 1, -cc, cc)
-    sn = np.where(q & 4, -ss, ss)
+    r0, r1, r2, r3 = (v.astype(np.uint64) for v in (r0, r1, r2, r3))
+    k = (r0 << np.uint64(20)) | (r1 >> np.uint64(12))
+    u1 = (k.astype(np.float64) + 0.5) * 2.0**-52                  # exact: 2k + 1 < 2^53
+    rad = np.sqrt(-2.0 * np.log1p(-(1.0 - u1)))                   # (1 - u1 exact; log1p keeps u1 -> 1 accurate)
+    j = r2 >> np.uint64(24)
+    w = ((r2 & np.uint64(0xFFFFFF)) << np.uint64(28)) | (r3 >> np.uint64(4))
+    # sector-exact reduction: theta = centre of sector j + x, x = ((w + 1/2) 2^-52 - 1/2) 2 pi / 256 (the offset is
+    # exact in a double; cos / sin of the centre and of x in long double, combined there, rounded once at the end)
+    ld = np.longdouble
+    two_pi = 2 * ld(np.pi) + ld(2.4492935982947064e-16)           # 2 pi to ~1e-32 (pi = double(pi) + 1.2246e-16)
+    tw = (w.astype(np.float64) * 2.0**-52 - 0.5) + 2.0**-53       # exact
+    x = tw.astype(ld) * (two_pi / 256)
+    # octant-exact evaluation of the centre angle (a multiple of pi/256: reduce the integer, not the float)
+    jj = (2 * j.astype(np.int64) + 1)                             # centre = jj * pi / 256, jj odd in [1, 511]
+    q = jj // 128                                                 # quadrant of the centre (0..3), remainder < pi/2
+    rem = (jj - 128 * q).astype(ld) * (two_pi / 512)
+    cr, sr = np.cos(rem), np.sin(rem)
+    c0 = np.where(q == 0, cr, np.where(q == 1, -sr, np.where(q == 2, -cr, sr)))
+    s0 = np.where(q == 0, sr, np.where(q == 1, cr, np.where(q == 2, -sr, -cr)))
+    cx, sx = np.cos(x), np.sin(x)
+    cs = (c0 * cx - s0 * sx).astype(np.float64)
+    sn = (s0 * cx + c0 * sx).astype(np.float64)
     return rad * cs, rad * sn
 
 

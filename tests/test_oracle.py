@@ -288,6 +288,69 @@ def test_device_stream_oracle_layout_and_moments():
     assert abs(g.mean()) < 5 / np.sqrt(g.size) and abs(g.var() - 1) < 5 * np.sqrt(2 / g.size)
 
 
+def _device_boxmuller_model(r0, r1, r2, r3):
+    """numpy model of rng_boxmuller_bits (cora_amd/csrc/rng_dev.h): the same bit constructions, table look-ups
+    (tables parsed from rng_tab.inc) and polynomials, plain double arithmetic (no fma)."""
+    import os
+    import re
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    txt = open(os.path.join(root, "cora_amd", "csrc", "rng_tab.inc")).read()
+    pairs = re.findall(r"\{(-?0x[0-9a-f.]+p[+-]\d+), (-?0x[0-9a-f.]+p[+-]\d+)\}", txt)
+    tab = np.array([[float.fromhex(a), float.fromhex(b)] for a, b in pairs])
+    assert tab.shape == (257 + 256, 2)
+    lg, sc = tab[:257], tab[257:]
+    U = np.uint64
+    r0, r1, r2, r3 = (v.astype(U) for v in (r0, r1, r2, r3))
+    k = (r0 << U(20)) | (r1 >> U(12))
+    u1 = ((U(0x3FF) << U(52)) | k).view(np.float64) - (1.0 - 2.0**-53)
+    ub = u1.view(U)
+    uh = ub >> U(32)
+    mh = uh & U(0xFFFFF)
+    idx = ((mh + U(0x800)) >> U(12)).astype(np.int64)
+    m = (((mh | U(0x3FF00000)) << U(32)) | (ub & U(0xFFFFFFFF))).view(np.float64)
+    e = (uh >> U(20)).astype(np.int64) - 1023 + (idx > 106)
+    rr = m * lg[idx, 0] - 1.0
+    q = rr * (-2 / 5) + 0.5
+    q = q * rr - 2 / 3
+    q = q * rr + 1.0
+    t = e * (-2 * 0.69314718055994530942) + ((rr * rr) * q + (rr * -2.0 + lg[idx, 1]))
+    rad = np.sqrt(t)
+    j = (r2 >> U(24)).astype(np.int64)
+    w = ((r2 & U(0xFFFFFF)) << U(28)) | (r3 >> U(4))
+    tw = ((U(0x3FF) << U(52)) | w).view(np.float64) - 1.5
+    c = 2 * np.pi / 256
+    x = tw * c + 2.0**-53 * c
+    z = x * x
+    sx = (x * z) * (z * (1 / 120) - 1 / 6) + x
+    cx = z * ((z * (-1 / 720) + 1 / 24) * z - 0.5) + 1.0
+    a, b = rad * sc[j, 0], rad * sc[j, 1]
+    return a * cx - b * sx, a * sx + b * cx
+
+
+def test_device_boxmuller_algorithm_matches_stream_spec(monkeypatch):
+    """The bit-level Box-Muller of the kernels (tables of rng_tab.inc, split of the mantissa at ~sqrt2, sector
+    rotation) evaluates the stream that oracle/philox.py specifies: random words plus the corner cases of the
+    mantissa split, u1 -> 0, u1 -> 1 and the table's last entries."""
+    from oracle import philox
+
+    rng = np.random.default_rng(1)
+    n = 400000
+    r = [rng.integers(0, 2**32, n, dtype=np.uint64).astype(np.uint32) for _ in range(4)]
+    r[0][:10] = [0, 0, 0xFFFFFFFF, 0xFFFFFFFF, 0x80000000, 0x7FFFFFFF, 0x6A09E667, 0x6A09E668, 0x6A000000, 0x6AFFFFFF]
+    r[1][:10] = [0, 0xFFFFFFFF, 0xFFFFFFFF, 0, 0, 0xFFFFFFFF, 0xF3BCC908, 0, 0, 0xFFFFFFFF]
+    r[2][:4] = [0, 0xFFFFFFFF, 0x00FFFFFF, 0x01000000]
+    r[3][:4] = [0, 0xFFFFFFFF, 0xFFFFFFFF, 0]
+    a, b = _device_boxmuller_model(*r)
+    monkeypatch.setattr(philox, "philox4x32_10", lambda *args: tuple(r))
+    oa, ob = philox.boxmuller_counter(0, 0, 0)
+    # without fma the model's r = m / c - 1 carries 1e-16 absolute, i.e. 1e-16 / radius in the normal: 4e-15 here
+    assert np.abs(a - oa).max() < 4e-15 and np.abs(b - ob).max() < 4e-15, (np.abs(a - oa).max(), np.abs(b - ob).max())
+    # the radius is accurate RELATIVE to itself where u1 -> 1 (words 2, 3 of the corner cases)
+    for i in (2, 3):
+        assert abs(np.hypot(a[i], b[i]) / np.hypot(oa[i], ob[i]) - 1) < 1e-14
+
+
 def test_map2alm_oracle_against_bruteforce_and_adjointness():
     """The analysis oracle (n1: healpy.map2alm restated) vs an independent scipy Y_lm quadrature,
     <S a, x> = <a, A x> adjointness with the synthesis oracle, and convergence of the Jacobi iterations."""
