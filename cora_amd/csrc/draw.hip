@@ -14,31 +14,30 @@
 
 #include "rng_dev.h"
 
-// The device stream: the normals of (l, c = re/im, nu', m) and (.., m+1), m even, are the two Box-Muller outputs
-// of Philox counter {lo = m/2, hi = l*2F + c*F + nu'} under key = seed, built from the four output words as
-// rng_dev.h describes (u1 from 52 bits of (r0, r1), the angle from 60 bits of (r2, r3)).
-// A value depends only on (seed, l, c, nu', m): the same for any number of GPUs, and the same whether it is
+// The device stream: the real and the imaginary normal of (l, nu', m) are the two Box-Muller outputs of Philox
+// counter {lo = m, hi = l F + nu'} under key = seed, built from the four output words as rng_dev.h describes
+// (u1 from 52 bits of (r0, r1), the angle from 60 bits of (r2, r3)).
+// A value depends only on (seed, l, nu', m, re/im): the same for any number of GPUs, and the same whether it is
 // materialised in HBM (normals_kernel, stream-order layout) or generated inside K3.  oracle/philox.py
 // restates the stream in numpy.
-__device__ static inline double2 philox_normal_pair(uint64_t seed, int l, int F, int c, int nup, int mpair,
+__device__ static inline double2 philox_normal_pair(uint64_t seed, int l, int F, int nup, int m,
                                                     const double2 *lg = RNG_LOG_TAB, const double2 *sc = RNG_SC_TAB) {
-    const uint64_t ctr = ((uint64_t)((uint32_t)l * 2u * (uint32_t)F + (uint32_t)(c * F + nup)) << 32) | (uint32_t)mpair;
+    const uint64_t ctr = ((uint64_t)((uint32_t)l * (uint32_t)F + (uint32_t)nup) << 32) | (uint32_t)m;
     return philox_boxmuller(ctr, seed, lg, sc);
 }
 
-// one thread per (l, c, nu', m-pair): writes the stream-order buffer  g[F l(l+1) + c F(l+1) + nu'(l+1) + m]
+// one thread per (l, nu', m): writes the stream-order buffer  g[F l(l+1) + c F(l+1) + nu'(l+1) + m], c = 0 (re), 1 (im)
 __global__ void normals_kernel(uint64_t seed, int lmax, int F, double *__restrict__ g) {
     const int l = blockIdx.y;
-    const int lp1 = l + 1, npair = (lp1 + 1) >> 1;
-    const long n = 2L * F * npair;
+    const int lp1 = l + 1;
+    const long n = (long)F * lp1;
     double *gl = g + (size_t)F * l * lp1;
     for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (long)gridDim.x * blockDim.x) {
-        const int mp = (int)(q % npair);
-        const int cn = (int)(q / npair);  // c*F + nu'
-        const double2 v = philox_normal_pair(seed, l, F, cn / F, cn % F, mp);
-        double *dst = gl + (size_t)cn * lp1 + 2 * mp;
-        dst[0] = v.x;
-        if (2 * mp + 1 < lp1) dst[1] = v.y;
+        const int m = (int)(q % lp1);
+        const int nup = (int)(q / lp1);
+        const double2 v = philox_normal_pair(seed, l, F, nup, m);
+        gl[q] = v.x;
+        gl[n + q] = v.y;
     }
 }
 
@@ -148,9 +147,17 @@ draw_kernel(const double *__restrict__ T, size_t t_ldl, int t_row0, const int32_
 }
 
 // ------------------------------------------------------------------------------------
-// K3 with the normals generated in registers (device-RNG mode): no 8.6 GB normal buffer is written or
-// read.  Wave tile = 32 rows (16 m-pairs of one c: the two Box-Muller outputs feed the even-m and the
-// odd-m row tile) x 16*NCT channels; workgroup = 4 waves = 128 rows.
+// K3 with the normals generated in registers (device-RNG mode): no 8.6 GB normal buffer is written or read.
+//
+// Work item = (l, block of 128 m, column group of 16 NCT channels); persistent workgroups of 8 waves pull items
+// from an atomic queue (heavy column groups first).  Wave tile = 16 m x (re, im) x 16 NCT channels: the two
+// Box-Muller outputs of one Philox block are the real and the imaginary normal of the SAME (l, m, nu'), so a wave
+// owns whole 64-byte a_lm cells ([re x4 | im x4]) and stores them as full lines (16 bytes per lane after a quad
+// exchange).  T_l is staged by LDS-DMA through a ring of three 32-nu' stages that runs on across items: the first
+// two stages of the next item are requested before the epilogue stores of the current one.
+// Round-2 form, for the record (stamps, `make k3stamps`): 4-wave workgroups of one (l, 64 m, column group) each
+// spent 13 % of their wave cycles in the prologue (tables, first stage), 30 % issuing / waiting for the LDS-DMA of
+// T_l - every 64 m re-staged the same 256 KB - and 28 % in an epilogue of half-line (32-byte) stores.
 // ------------------------------------------------------------------------------------
 // LDS-DMA of 16 bytes per lane from inline asm (see sht_internal.h: hipcc would drain a builtin DMA with
 // vmcnt(0) before every later ds_read); lane i's bytes land at lds_byte_addr + 16 i.
@@ -164,7 +171,7 @@ __device__ static inline void draw_glds16(const void *gsrc, unsigned lds_byte_ad
 }
 
 #ifndef DRAW_STAMPS
-#define DRAW_STAMPS 0   // diagnostic build (make k3stamps): s_memtime per phase, summed over the waves that have rows
+#define DRAW_STAMPS 0   // diagnostic build (make k3stamps): s_memtime per phase, summed over all waves
 #endif
 #if DRAW_STAMPS
 __device__ unsigned long long g_draw_stamps[8];
@@ -182,204 +189,252 @@ __device__ static inline void draw_static_for(Fn &&f) {
     }
 }
 
+#define DRAW_WAVES 8                 // waves per workgroup of the fused-RNG kernel
+#define DRAW_MB (16 * DRAW_WAVES)    // m per work item
+#define DRAW_NBUF 3                  // stages in the LDS ring
+
+// number of (l, m-block) slots: l in band j = l >> 7 has j + 1 blocks of 128 m
+static inline long draw_slots(int lmax) {
+    long n = 0;
+    for (int l = 0; l <= lmax; l++) n += (l / DRAW_MB) + 1;
+    return n;
+}
+
 template <int NCT>
-__global__ void __launch_bounds__(256, 2)
+__global__ void __launch_bounds__(64 * DRAW_WAVES, 2)
 draw_rng_kernel(const double *__restrict__ T, size_t t_ldl, int t_row0, const int32_t *__restrict__ info,
                 const double *__restrict__ zeros, uint64_t seed, int lmax, int F, int nu0, int nnu, int Gout,
-                double *__restrict__ alm) {
+                int nslots, int ncg, double *__restrict__ alm, unsigned *__restrict__ queue) {
     constexpr int NC = 16 * NCT;
     constexpr int ROWD = DRAW_KC;            // doubles per channel row in LDS: 256 B, unpadded (DMA is lane-linear)
     constexpr int BUF = NC * ROWD;           // doubles per stage
+    constexpr int QPW = (NC / 4 + DRAW_WAVES - 1) / DRAW_WAVES;   // row quads (= DMA instructions) a staging wave issues per stage
+    static_assert(QPW * DRAW_WAVES == NC / 4 || NC / 4 < DRAW_WAVES, "every staging wave issues the same number of pieces");
     // Bs[n][slot' = slot ^ (n & 15)][2]: the 16-byte slots of a row are XOR-swizzled with the row number
     // (applied on the DMA source address), so that 16 rows read at the same k hit 16 distinct slots
-    extern __shared__ __attribute__((aligned(16))) double lds[];  // [2][NC][ROWD]
+    extern __shared__ __attribute__((aligned(16))) double lds[];  // [DRAW_NBUF][NC][ROWD]
     __shared__ double2 lg_s[257], sc_s[256];   // LDS copies of the Box-Muller tables (rng_dev.h): 8 KB
+    __shared__ int s_next[2];                  // next work item, double-buffered (written one item ahead)
 
-    // workgroup = 64 values of m x (re, im): waves 0,1 draw the real parts, waves 2,3 the imaginary parts of the
-    // SAME m, so that both halves of every 64-byte a_lm cell ([re x4 | im x4]) are written by one workgroup within
-    // a short time and merge in L2 (with re and im in different workgroups every cell reached HBM as two 32-byte
-    // partial writes: the kernel was bound by that, not by the RNG or the MFMAs - make DRAW_ABLATE builds)
-    const int l = blockIdx.x;
-    const int lp1 = l + 1;
-    const int mb = blockIdx.y;
-    const int col0 = blockIdx.z * NC;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int c_of = wave >> 1;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ri = lane & 15, kq = lane >> 4;
-    if (mb * 64 >= lp1) return;                 // no m of this l in the block (half the [l][m-block] grid): uniform, before any barrier / DMA
+    const int nitems = nslots * ncg;
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) double *)lds;
 #if DRAW_STAMPS
     unsigned long long d_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, d_last;
     { unsigned long long _t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)::"memory"); d_last = _t; }
 #endif
-    const int m0 = mb * 64 + (wave & 1) * 32;   // first m of this wave
-    const int mpair = (m0 >> 1) + ri;           // this lane's m-pair: rows m = 2 mpair, 2 mpair + 1
 
-    const double *Tl = T + (size_t)l * t_ldl - (size_t)t_row0 * F;  // row nu of T_l at Tl + nu F (rows < t_row0 never read)
-    const bool dense = (info == nullptr) || (info[l] != 0);
-    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) double *)lds;
-
-    d4_t acc0[NCT], acc1[NCT];
-#pragma unroll
-    for (int t = 0; t < NCT; t++) {
-        acc0[t] = (d4_t){0.0, 0.0, 0.0, 0.0};
-        acc1[t] = (d4_t){0.0, 0.0, 0.0, 0.0};
-    }
-    const int base0 = nu0 + col0;                // first channel of the block
-    const int kmax = dense ? F : min(F, base0 + NC);
-    const int nchunk = (kmax + DRAW_KC - 1) / DRAW_KC;
-    const bool tri_tail = !dense && (base0 % DRAW_KC) == 0;   // the chunks across the block's own channels drop tiles (below)
-    const bool wave_has_rows = m0 < lp1;
-    const bool full_k = (F % DRAW_KC) == 0;      // rows of T_l are whole 256-byte runs
-
-    // stage chunk c of T_l (rows nu0+col0 .. +NC-1, k in [c KC, c KC + KC)) into buffer c & 1:
-    // each wave-instruction moves 4 rows x 16 slots
-    auto stage = [&](int c) {
+    struct item_t {
+        int l, mb, base0, kmax, nchunk, c_full;
+        bool tri_tail;
+        const double *Tl;        // row nu of T_l at Tl + nu F (rows < t_row0 never read)
+    };
+    auto decode = [&](int it) {
+        item_t w;
+        const int cg = ncg - 1 - it / nslots;          // the column groups with the longest nu' range first
+        int s = it - (it / nslots) * nslots;
+        int l = 0, mb = 0;
+        for (int j = lmax / DRAW_MB; j >= 0; j--) {    // bands of l from the top: j + 1 blocks of m per l
+            const int lhi = min(lmax, DRAW_MB * j + DRAW_MB - 1);
+            const int cnt = (lhi - DRAW_MB * j + 1) * (j + 1);
+            if (s < cnt) {
+                l = lhi - s / (j + 1);
+                mb = s - (s / (j + 1)) * (j + 1);
+                break;
+            }
+            s -= cnt;
+        }
+        w.l = l;
+        w.mb = mb;
+        w.base0 = nu0 + cg * NC;                       // first channel of the item
+        const bool dense = (info == nullptr) || (info[l] != 0);
+        // lower-triangular T: channel nu only needs nu' <= nu
+        w.kmax = dense ? F : min(F, w.base0 + NC);
+        w.nchunk = (w.kmax + DRAW_KC - 1) / DRAW_KC;
+        // Tile t (channels base0 + 16 t .. + 15) of a triangular factor is zero for nu' > base0 + 16 t + 15.  With base0 a
+        // multiple of the chunk length the chunks below the item's own channels take every tile and the chunks across
+        // them drop one tile per half: that tail is unrolled so that every half knows its tiles at compile time (per-tile
+        // tests inside the k-steps were 45 scalar instructions per k-step, issue time next to the MFMAs; a run-time
+        // dispatch per half made the register allocator copy the accumulators between the cases).  A tile that is kept
+        // is multiplied as a whole: the entries above the diagonal are stored zeros.  Any other base0 (uneven channel
+        // shards) takes every tile up to kmax - correct for the same reason, just not minimal.
+        w.tri_tail = !dense && (w.base0 % DRAW_KC) == 0;
+        w.c_full = w.tri_tail ? min(w.nchunk, w.base0 / DRAW_KC) : w.nchunk;
+        w.Tl = T + (size_t)l * t_ldl - (size_t)t_row0 * F;
+        return w;
+    };
+    // stage chunk c of the item (rows base0 .. base0+NC-1 of T_l, nu' in [c KC, c KC + KC)) into ring slot `slot`:
+    // each wave-instruction moves 4 rows x 16 slots; every row is staged (zeros past nnu / F), so that every
+    // staging wave issues exactly QPW pieces per stage and the waits below can count them
+    auto stage = [&](const item_t &w, int c, int slot) {
         const int k0 = c * DRAW_KC;
 #pragma unroll
-        for (int it = 0; it < NC / 16; it++) {      // NC/4 row-quads over 4 waves
-            const int rq = wave + 4 * it;           // row quad index
+        for (int it = 0; it < QPW; it++) {
+            const int rq = wave + DRAW_WAVES * it;  // row quad index
             if (rq >= NC / 4) break;
-            // triangular factors: a 16-row tile whose rows all have nu < k0 is zero in this chunk and its MFMAs are
-            // skipped below (the same test at kbase >= k0), so its four quads need not be staged at all (a third of the
-            // LDS-DMA volume); tile granularity, not quad: a partly-zero tile is still multiplied as a whole
-            if (tri_tail && k0 > base0 + 16 * (rq >> 2) + 15) continue;
             const int n = 4 * rq + (lane >> 4);     // row of this lane
             const int slot_dst = lane & 15;
             const int slot_src = slot_dst ^ (n & 15);
-            const int nu = nu0 + col0 + n;
+            const int nu = w.base0 + n;
             const int k = k0 + 2 * slot_src;
             const double *src = zeros;  // F is even on this path (host wrapper), so k + 1 < F whenever k < F
-            if (col0 + n < nnu && nu < F && k + 1 < F) src = Tl + (size_t)nu * F + k;
+            if (nu - nu0 < nnu && nu < F && k + 1 < F) src = w.Tl + (size_t)nu * F + k;
 #if DRAW_ABLATE != 4   // diagnostic 4: no staging of T
-            // (LDS-DMA moves only ~10 B/clk per CU - MI355X_MICROARCH.md "ldsdma-fill" - but staging through registers,
-            //  global_load_dwordx4 + ds_write_b128 committed before the next barrier, was slower still: 14.0 vs 10.1 ms)
-            draw_glds16(src, lds_base + (unsigned)(((c & 1) * BUF + 4 * rq * ROWD) * sizeof(double)));
+            draw_glds16(src, lds_base + (unsigned)((slot * BUF + 4 * rq * ROWD) * sizeof(double)));
 #else
             (void)src;
 #endif
         }
     };
-    (void)full_k;
 
-    lg_s[threadIdx.x] = RNG_LOG_TAB[threadIdx.x];                          // (visible after the first chunk's barrier)
-    sc_s[threadIdx.x] = RNG_SC_TAB[threadIdx.x];
-    if (threadIdx.x == 0) lg_s[256] = RNG_LOG_TAB[256];
-    // k-steps of one half (16 nu' = 4 k-steps) of the chunk in buffer `sb`, multiplying the tiles TMIN .. NCT-1
-    auto half_steps = [&](auto tmin_c, const double *sb, int k0, int half) {
-        constexpr int TMIN = decltype(tmin_c)::value;
+    for (int i = tid; i < 257; i += 64 * DRAW_WAVES) lg_s[i] = RNG_LOG_TAB[i];   // (visible after the first barrier)
+    for (int i = tid; i < 256; i += 64 * DRAW_WAVES) sc_s[i] = RNG_SC_TAB[i];
+
+    int item = blockIdx.x;      // the first gridDim.x items are pre-assigned; the queue starts behind them
+    if (item >= nitems) return;
+    item_t w = decode(item);
+    int ring = 0, par = 0;
+    stage(w, 0, 0);
+    if (w.nchunk > 1) stage(w, 1, 1);
+    DSTAMP(0);                           // prologue + first stages issued
+
+    for (;;) {
+        if (tid == 0) s_next[par] = (int)(gridDim.x + atomicAdd(queue, 1u));   // latency hidden behind this item
+        const int l = w.l, lp1 = w.l + 1;
+        const int mw = w.mb * DRAW_MB + 16 * wave;     // first m of this wave
+        const bool wave_has_rows = mw < lp1;
+        const int m_lane = mw + ri;                    // the A-operand row of this lane
+        const int kmax = w.kmax, nchunk = w.nchunk;
+        d4_t acc0[NCT], acc1[NCT];                     // real / imaginary part of a_lm: rows m = mw + kq + 4 r, channel 16 t + ri
+#pragma unroll
+        for (int t = 0; t < NCT; t++) {
+            acc0[t] = (d4_t){0.0, 0.0, 0.0, 0.0};
+            acc1[t] = (d4_t){0.0, 0.0, 0.0, 0.0};
+        }
+        // k-steps of one half (16 nu' = 4 k-steps) of the chunk in buffer `sb`, multiplying the tiles TMIN .. NCT-1
+        auto half_steps = [&](auto tmin_c, const double *sb, int k0, int half) {
+            constexpr int TMIN = decltype(tmin_c)::value;
 #pragma unroll DRAW_KK_UNROLL
-        for (int kk = 4 * half; kk < 4 * half + 4; kk++) {
-            const int kp = k0 + 4 * kk + kq;
-            const int kl = 4 * kk + kq;          // k within the chunk
-            // all B operands of the k-step are read up front (one address + immediate offsets)
-            double bv[NCT];
-            const double *brow = sb + ri * ROWD + 2 * ((kl >> 1) ^ ri) + (kl & 1);
-#if DRAW_BEARLY        // the reads in front of the generator chain (their latency behind it), pinned by a scheduling barrier
+            for (int kk = 4 * half; kk < 4 * half + 4; kk++) {
+                const int kp = k0 + 4 * kk + kq;
+                const int kl = 4 * kk + kq;          // k within the chunk
+                // all B operands of the k-step are read up front (one address + immediate offsets)
+                double bv[NCT];
+                const double *brow = sb + ri * ROWD + 2 * ((kl >> 1) ^ ri) + (kl & 1);
 #pragma unroll
-            for (int t = TMIN; t < NCT; t++) bv[t] = brow[16 * t * ROWD];
-            __builtin_amdgcn_sched_barrier(0);
-#endif
+                for (int t = TMIN; t < NCT; t++) bv[t] = brow[16 * t * ROWD];
 #if DRAW_ABLATE == 1   // diagnostic: no RNG
-            double2 a = make_double2(1.0 + kp, 0.5 * mpair);
+                double2 a = make_double2(1.0 + kp, 0.5 * m_lane);
 #else
-            // (rows past l and nu' >= F are generated like any other: their products meet staged zeros or are never
-            //  stored - no exec masking around the chain)
-            double2 a = philox_normal_pair(seed, l, F, c_of, kp, mpair, lg_s, sc_s);
-#endif
-#if DRAW_STAMPS
-            asm volatile("" ::"v"(a.x), "v"(a.y));
-            DSTAMP(3);                   // normals of the k-step
-#endif
-#if !DRAW_BEARLY
-#pragma unroll
-            for (int t = TMIN; t < NCT; t++) bv[t] = brow[16 * t * ROWD];
+                // (rows past l and nu' >= F are generated like any other: their products meet staged zeros or are
+                //  never stored - no exec masking around the chain)
+                double2 a = philox_normal_pair(seed, l, F, kp, m_lane, lg_s, sc_s);
 #endif
 #pragma unroll
-            for (int t = TMIN; t < NCT; t++) {
+                for (int t = TMIN; t < NCT; t++) {
 #if DRAW_ABLATE == 2   // diagnostic: no MFMA
-                asm volatile("" ::"v"(a.x), "v"(a.y), "v"(bv[t]));
+                    asm volatile("" ::"v"(a.x), "v"(a.y), "v"(bv[t]));
 #else
-                acc0[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, bv[t], acc0[t], 0, 0, 0);
-                acc1[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, bv[t], acc1[t], 0, 0, 0);
+                    acc0[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, bv[t], acc0[t], 0, 0, 0);
+                    acc1[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, bv[t], acc1[t], 0, 0, 0);
 #endif
+                }
             }
-            DSTAMP(4);                   // B reads + MFMA issue of the k-step
+        };
+        // Stage c of the item sits in ring slot (ring + c) % NBUF.  On entry stages 0 and 1 have been requested (before
+        // the previous item's stores): the first wait drains everything; later waits leave the QPW pieces of the
+        // younger stage in flight.  After the barrier of chunk c every wave has finished chunk c - 1, whose slot
+        // takes stage c + 2.
+        auto chunk_begin = [&](int c) {
+            if (c == 0 || c + 1 >= nchunk) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(QPW) : "memory");
+            __syncthreads();
+            DSTAMP(1);                       // wait for the stage + barrier
+            if (c + 2 < nchunk) stage(w, c + 2, (ring + c + 2) % DRAW_NBUF);
+            DSTAMP(2);                       // issue of the stage after next
+        };
+        int c = 0;
+        for (; c < w.c_full; c++) {
+            chunk_begin(c);
+            if (!wave_has_rows) continue;
+            const double *sb = lds + ((ring + c) % DRAW_NBUF) * BUF;
+            half_steps(std::integral_constant<int, 0>{}, sb, c * DRAW_KC, 0);
+            if (c * DRAW_KC + 16 < kmax) half_steps(std::integral_constant<int, 0>{}, sb, c * DRAW_KC, 1);
+            DSTAMP(3);                       // generator + MFMAs of the chunk
         }
-    };
-    auto chunk_begin = [&](int c) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();                 // chunk c landed; everyone is done with chunk c-1
-        DSTAMP(1);                       // wait for the stage + barrier
-        if (c + 1 < nchunk) stage(c + 1);
-        DSTAMP(2);                       // issue of the next stage
-    };
+        draw_static_for<(NC + DRAW_KC - 1) / DRAW_KC>([&](auto jc) {
+            constexpr int J = decltype(jc)::value;
+            if (c >= nchunk) return;         // (uniform; also the dense / unaligned case, where c == nchunk here)
+            chunk_begin(c);
+            if (wave_has_rows) {
+                const double *sb = lds + ((ring + c) % DRAW_NBUF) * BUF;
+                half_steps(std::integral_constant<int, (2 * J < NCT ? 2 * J : NCT)>{}, sb, c * DRAW_KC, 0);
+                if (2 * J + 1 < NCT && c * DRAW_KC + 16 < kmax)
+                    half_steps(std::integral_constant<int, (2 * J + 1 < NCT ? 2 * J + 1 : NCT)>{}, sb, c * DRAW_KC, 1);
+                DSTAMP(3);
+            }
+            c++;
+        });
 
-    stage(0);
-    DSTAMP(0);                           // prologue + first stage issue
-    // Tile t (channels base0 + 16 t .. + 15) of a triangular factor is zero for nu' > base0 + 16 t + 15.  With base0 a
-    // multiple of the chunk length the chunks below the block's own channels take every tile and the chunks across them
-    // drop one tile per half: that tail is unrolled so that every half knows its tiles at compile time (the per-tile
-    // tests inside the k-steps were 45 scalar instructions per k-step, issue time next to the MFMAs; a run-time
-    // dispatch per half made the register allocator copy the accumulators between the cases).  A tile that is kept is
-    // multiplied as a whole: the entries above the diagonal are stored zeros.  Any other base0 (uneven channel shards)
-    // takes every tile up to kmax - correct for the same reason, just not minimal.
-    const int c_full = tri_tail ? min(nchunk, base0 / DRAW_KC) : nchunk;
-    int c = 0;
-    for (; c < c_full; c++) {
-        chunk_begin(c);
-        if (!wave_has_rows) continue;
-        const double *sb = lds + (c & 1) * BUF;
-        half_steps(std::integral_constant<int, 0>{}, sb, c * DRAW_KC, 0);
-        if (c * DRAW_KC + 16 < kmax) half_steps(std::integral_constant<int, 0>{}, sb, c * DRAW_KC, 1);
-    }
-    draw_static_for<(NC + DRAW_KC - 1) / DRAW_KC>([&](auto jc) {
-        constexpr int J = decltype(jc)::value;
-        if (c >= nchunk) return;         // (uniform; also the dense / unaligned case, where c == nchunk here)
-        chunk_begin(c);
-        if (wave_has_rows) {
-            const double *sb = lds + (c & 1) * BUF;
-            half_steps(std::integral_constant<int, (2 * J < NCT ? 2 * J : NCT)>{}, sb, c * DRAW_KC, 0);
-            if (2 * J + 1 < NCT && c * DRAW_KC + 16 < kmax)
-                half_steps(std::integral_constant<int, (2 * J + 1 < NCT ? 2 * J + 1 : NCT)>{}, sb, c * DRAW_KC, 1);
+        // ---- next item: its first two stages are requested now, ahead of this item's stores.  Only the slot of the
+        //      last chunk can still be in use by a slower wave, and the ring moves on past it.
+        ring = (ring + nchunk) % DRAW_NBUF;
+        const int cur_base0 = w.base0;
+        item = __builtin_amdgcn_readfirstlane(s_next[par]);   // (written before this item's first barrier)
+        par ^= 1;
+        const bool have_next = item < nitems;
+        if (have_next) {
+            w = decode(item);
+            stage(w, 0, ring);
+            if (w.nchunk > 1) stage(w, 1, (ring + 1) % DRAW_NBUF);
         }
-        c++;
-    });
-    if (!wave_has_rows) return;
-    // epilogue: C row i of tile0 is m = m0 + 2 i, of tile1 m = m0 + 2 i + 1; 1/sqrt(2) of complex_std_normal.
-    // Lanes (ri, ri ^ 1) hold adjacent channels of the same rows: the even lane takes the m-even row of BOTH channels, the
-    // odd lane the m-odd row (one DPP swap per value), so every store is 16 bytes instead of 8 - the a_lm stores are
-    // issue-bound (~7 B/clk per CU for 8-byte lanes: 13 % of the kernel's wave cycles by the phase stamps).
-    const double sc = 0.70710678118654752440;
-    const bool odd = ri & 1;
-    auto swap1 = [](double v) {            // value of lane ^ 1 (quad_perm [1, 0, 3, 2])
-        int lo = __double2loint(v), hi = __double2hiint(v);
-        lo = __builtin_amdgcn_update_dpp(lo, lo, 0xB1, 0xF, 0xF, false);
-        hi = __builtin_amdgcn_update_dpp(hi, hi, 0xB1, 0xF, 0xF, false);
-        return __hiloint2double(hi, lo);
-    };
+        DSTAMP(4);                           // next item decoded, its first stages issued
+
+        // ---- epilogue: 1/sqrt(2) of complex_std_normal; lane (ri, kq) holds re and im of rows m = mw + kq + 4 r, channel
+        //      16 t + ri.  The four lanes of a quad hold one 64-byte cell [re x4 | im x4]: lane q of the quad stores its
+        //      16-byte quarter - (re0, re1), (re2, re3), (im0, im1), (im2, im3) - after a quad exchange (DPP), so every
+        //      store instruction writes 16 full lines.
+        if (wave_has_rows) {
+            const double sc = 0.70710678118654752440;
+            const int q = ri & 3;
+            const bool upper = q >= 2;                 // this lane stores imaginary parts
+            auto quad = [](double v, auto ctrl_c) {    // v of the quad lane selected by the quad_perm pattern
+                constexpr int CTRL = decltype(ctrl_c)::value;
+                int lo = __double2loint(v), hi = __double2hiint(v);
+                lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
+                hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
+                return __hiloint2double(hi, lo);
+            };
 #pragma unroll
-    for (int t = 0; t < NCT; t++) {
-        const int col = col0 + 16 * t + (ri & ~1);          // first channel of the lane pair
-        const bool col_ok = col < 4 * Gout;                 // (4 Gout is a multiple of 4: both channels or none)
+            for (int t = 0; t < NCT; t++) {
+                const int col = cur_base0 - nu0 + 16 * t + (ri & ~3);    // first (local) channel of the quad's cell
+                const bool col_ok = col < 4 * Gout;                       // (4 Gout is a multiple of 4: the whole cell or none)
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const int i = kq + 4 * r;
-            const double mine = (odd ? acc1[t][r] : acc0[t][r]) * sc;      // this lane's channel of the row it stores
-            const double give = (odd ? acc0[t][r] : acc1[t][r]) * sc;      // the partner's row
-            const double got = swap1(give);                                  // the partner's channel of MY row
-            const int m = m0 + 2 * i + (odd ? 1 : 0);
-            if (col_ok && m < lp1) {
-                const long idx = (long)m * (2 * lmax + 1 - m) / 2 + l;
+                for (int r = 0; r < 4; r++) {
+                    const double re = acc0[t][r] * sc, im = acc1[t][r] * sc;
+                    // quarter 0 / 2 takes the values of quad lanes (0, 1), quarter 1 / 3 those of lanes (2, 3)
+                    const double re_a = quad(re, std::integral_constant<int, 0x88>{});   // from lanes [0, 2, 0, 2]
+                    const double im_a = quad(im, std::integral_constant<int, 0x88>{});
+                    const double re_b = quad(re, std::integral_constant<int, 0xDD>{});   // from lanes [1, 3, 1, 3]
+                    const double im_b = quad(im, std::integral_constant<int, 0xDD>{});
+                    const int m = mw + kq + 4 * r;
+                    if (col_ok && m < lp1) {
+                        const long idx = (long)m * (2 * lmax + 1 - m) / 2 + l;
 #if DRAW_ABLATE == 3   // diagnostic: no a_lm stores
-                if (mine == 1.2345e300)
+                        if (re == 1.2345e300)
 #endif
-                *reinterpret_cast<double2 *>(alm + ((size_t)idx * Gout + (col >> 2)) * 8 + c_of * 4 + (col & 3)) =
-                    odd ? make_double2(got, mine) : make_double2(mine, got);
+                        *reinterpret_cast<double2 *>(alm + ((size_t)idx * Gout + (col >> 2)) * 8 + 2 * q) =
+                            upper ? make_double2(im_a, im_b) : make_double2(re_a, re_b);
+                    }
+                }
             }
         }
+        DSTAMP(5);                           // epilogue (scale, exchange, a_lm stores issued)
+        if (!have_next) break;
     }
 #if DRAW_STAMPS
-    DSTAMP(5);                           // epilogue (scale + a_lm stores issued)
     if (lane == 0) {
         for (int k = 0; k < 6; k++) atomicAdd(&g_draw_stamps[k], d_acc[k]);
         atomicAdd(&g_draw_stamps[7], 1ull);
@@ -391,16 +446,24 @@ template <int NCT>
 static int launch_draw_rng(corahip_ctx *ctx, const double *T, size_t t_ldl, int t_row0, const int32_t *info,
                            uint64_t seed, int lmax, int F, int nu0, int nnu, int Gout, double *alm) {
     constexpr int NC = 16 * NCT;
-    const size_t shm = sizeof(double) * 2 * NC * DRAW_KC;
+    const size_t shm = sizeof(double) * DRAW_NBUF * NC * DRAW_KC;
     HIP_TRY(hipFuncSetAttribute((const void *)draw_rng_kernel<NCT>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)shm));
-    double *zeros = nullptr;
-    int rc = corahip_ctx_scratch(ctx, 3, 4096, (void **)&zeros);
+    // scratch slot 3: 4096 bytes of zeros (DMA source of padded rows) + the work queue counter behind them
+    char *zq = nullptr;
+    int rc = corahip_ctx_scratch(ctx, 3, 8192, (void **)&zq);
     if (rc) return rc;
-    HIP_TRY(hipMemsetAsync(zeros, 0, 4096, ctx->stream));
-    dim3 grid(lmax + 1, (lmax + 1 + 63) / 64, (4 * Gout + NC - 1) / NC);
-    draw_rng_kernel<NCT><<<grid, 256, shm, ctx->stream>>>(T, t_ldl, t_row0, info, zeros, seed, lmax, F, nu0, nnu, Gout,
-                                                          alm);
+    HIP_TRY(hipMemsetAsync(zq, 0, 8192, ctx->stream));
+    const int ncg = (4 * Gout + NC - 1) / NC;
+    const long nslots = draw_slots(lmax);
+    const long nitems = nslots * ncg;
+    ARG_CHECK(nitems < (1L << 30));
+    // persistent: one workgroup per CU for the 128-channel shape (106 KB of LDS), two for the narrower ones
+    const int per_cu = (shm + 8300 > 80 * 1024) ? 1 : 2;
+    dim3 grid((unsigned)std::min<long>(nitems, (long)ctx->num_cu * per_cu));
+    draw_rng_kernel<NCT><<<grid, 64 * DRAW_WAVES, shm, ctx->stream>>>(T, t_ldl, t_row0, info, (const double *)zq, seed, lmax,
+                                                                      F, nu0, nnu, Gout, (int)nslots, ncg, alm,
+                                                                      (unsigned *)(zq + 4096));
     LAUNCH_CHECK();
 #if DRAW_STAMPS
     {
@@ -408,7 +471,7 @@ static int launch_draw_rng(corahip_ctx *ctx, const double *T, size_t t_ldl, int 
         HIP_TRY(hipStreamSynchronize(ctx->stream));
         HIP_TRY(hipMemcpyFromSymbol(hs, HIP_SYMBOL(g_draw_stamps), sizeof(hs)));
         const double per = 1.0 / (double)std::max<unsigned long long>(hs[7], 1);
-        fprintf(stderr, "K3 NCT=%d waves=%llu: cycles/wave  prologue %.0f wait+barrier %.0f stage-issue %.0f rng %.0f reads+mfma %.0f epilogue %.0f\n",
+        fprintf(stderr, "K3 NCT=%d waves=%llu: cycles/wave  prologue %.0f wait+barrier %.0f stage-issue %.0f rng+mfma %.0f next-item %.0f epilogue %.0f\n",
                 NCT, hs[7], hs[0] * per, hs[1] * per, hs[2] * per, hs[3] * per, hs[4] * per, hs[5] * per);
         HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_draw_stamps), z, sizeof(z)));
     }
@@ -472,7 +535,7 @@ extern "C" {
 int corahip_normals_philox(corahip_ctx *ctx, uint64_t seed, int lmax, int F, double *g) {
     ARG_CHECK(ctx != nullptr && g != nullptr && lmax >= 0 && F >= 1);
     StageTimer t(ctx, "normals");
-    dim3 grid(std::max(1, std::min(64, (F * (lmax + 2) / 2 + 255) / 256)), lmax + 1);
+    dim3 grid(std::max(1, std::min(64, (F * (lmax + 1) + 255) / 256)), lmax + 1);
     normals_kernel<<<grid, 256, 0, ctx->stream>>>(seed, lmax, F, g);
     LAUNCH_CHECK();
     return 0;

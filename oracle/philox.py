@@ -8,10 +8,10 @@ for any number of GPUs ("device counter-based RNG keyed by (seed, l
 This file is the specification of that stream, checked against the kernels in tests/:
 
   Philox4x32-10 (Salmon et al., SC'11; known-answer vectors of Random123 in tests/test_oracle.py)
-  counter = (m // 2, l * 2F + c * F + nu', 0, 0),  key = (seed & 0xffffffff, seed >> 32)
+  counter = (m, l * F + nu', 0, 0),  key = (seed & 0xffffffff, seed >> 32)
   k = r0 << 20 | r1 >> 12                       (52 bits)   u1 = (k + 1/2) 2^-52        (exact in a double)
   j = r2 >> 24,  w = (r2 & 0xffffff) << 28 | r3 >> 4   (8 + 52 bits)   theta = 2 pi (j + (w + 1/2) 2^-52) / 256
-  normal(l, c, nu', m even) = sqrt(-2 ln u1) cos(theta),  normal(.., m + 1) = sqrt(-2 ln u1) sin(theta)
+  Re-normal(l, nu', m) = sqrt(-2 ln u1) cos(theta),  Im-normal(l, nu', m) = sqrt(-2 ln u1) sin(theta)
 (the uniforms are defined on their bits so that the kernels build them without integer -> double conversions:
 cora_amd/csrc/rng_dev.h; mathematically evaluated here, in extended precision for the angle)
 
@@ -73,23 +73,18 @@ def boxmuller_counter(seed, lo, hi):
     return rad * cs, rad * sn
 
 
-def normal_pairs(seed, l, F, c, nup, mpair):
-    """The two normals of counter (mpair, l*2F + c*F + nup) - broadcasting over array arguments."""
-    hi = (np.asarray(l, dtype=np.uint64) * np.uint64(2 * F) + np.asarray(c, dtype=np.uint64) * np.uint64(F)
-          + np.asarray(nup, dtype=np.uint64)) & _MASK
-    return boxmuller_counter(seed, mpair, hi)
+def normal_pairs(seed, l, F, nup, m):
+    """(real, imaginary) normal of (l, nu', m): counter (m, l*F + nup) - broadcasting over array arguments."""
+    hi = (np.asarray(l, dtype=np.uint64) * np.uint64(F) + np.asarray(nup, dtype=np.uint64)) & _MASK
+    return boxmuller_counter(seed, m, hi)
 
 
 def device_normals(seed, lmax, F):
     """The whole device stream in the reference's stream order (2 F nalm doubles)."""
     out = []
     for l in range(lmax + 1):
-        lp1 = l + 1
-        npair = (lp1 + 1) // 2
-        blk = np.empty((2, F, 2 * npair))
-        cc, nn, mm = np.meshgrid(np.arange(2), np.arange(F), np.arange(npair), indexing="ij")
-        a, b = normal_pairs(seed, l, F, cc, nn, mm)
-        blk[:, :, 0::2] = a
-        blk[:, :, 1::2] = b
-        out.append(blk[:, :, :lp1].reshape(-1))
+        nn, mm = np.meshgrid(np.arange(F), np.arange(l + 1), indexing="ij")
+        re, im = normal_pairs(seed, l, F, nn, mm)
+        out.append(re.reshape(-1))
+        out.append(im.reshape(-1))
     return np.concatenate(out)

@@ -283,8 +283,8 @@ def test_device_stream_oracle_layout_and_moments():
     assert g.size == 2 * F * (lmax + 1) * (lmax + 2) // 2
     # element (l, c, nu', m) sits at F l (l+1) + c F (l+1) + nu' (l+1) + m
     l, c, nu, m = 17, 1, 4, 9
-    a, b = philox.normal_pairs(12345, l, F, c, nu, m // 2)
-    assert g[F * l * (l + 1) + c * F * (l + 1) + nu * (l + 1) + m] == (b if m & 1 else a)
+    a, b = philox.normal_pairs(12345, l, F, nu, m)
+    assert g[F * l * (l + 1) + c * F * (l + 1) + nu * (l + 1) + m] == (b if c else a)
     assert abs(g.mean()) < 5 / np.sqrt(g.size) and abs(g.var() - 1) < 5 * np.sqrt(2 / g.size)
 
 
