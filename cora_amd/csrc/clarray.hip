@@ -51,12 +51,17 @@ __global__ void cl_transpose_kernel(const double *__restrict__ dd, const double 
 // the three-table combination (corr.py:980-982) hoisted out of the l loop: 12x fewer table reads.
 // Results go to a [pair][l] scratch (coalesced); cl_finish_kernel scatters them into [l][i][j].
 // Pairs with i < 0 (padding of a multi-GPU pair shard) are skipped.
+// ZINT > 0: the sub-sample count as a compile-time constant (9 = the default oversample of Sky3d): the zint
+// interpolations of a multipole are then independent straight-line code whose LDS reads are all in flight together
+// (with a run-time trip count every interpolation waited out its own LDS latency); ZINT = 0: any zint.
+template <int ZINT>
 __global__ void __launch_bounds__(256)
 clarray21_kernel(const double *__restrict__ tt, int nkperp, int nkpar, double kperpmin, double xscale, double yscale,
                  const double *__restrict__ chi, const double *__restrict__ pfd, const double *__restrict__ fz,
-                 const double *__restrict__ bz, int F, int zint, const double *__restrict__ w,
+                 const double *__restrict__ bz, int F, int zint_rt, const double *__restrict__ w,
                  const double *__restrict__ log10l, int nl, int l_base, const int2 *__restrict__ pairs,
                  double *__restrict__ scratch, int nl_total, int l_block) {
+    const int zint = ZINT > 0 ? ZINT : zint_rt;
     extern __shared__ __attribute__((aligned(16))) double sm[];
     double *prof = sm;                       // [zint][CL_XS + 2]
     double *lxcs_s = sm + zint * (CL_XS + 2);   // [zint]
@@ -144,25 +149,37 @@ clarray21_kernel(const double *__restrict__ tt, int nkperp, int nkpar, double kp
         }
         __syncthreads();
         // ---- 1-D interpolation for this thread's multipoles
+        double lxc_r[ZINT > 0 ? ZINT : 1];
+        if constexpr (ZINT > 0) {
+#pragma unroll
+            for (int b = 0; b < ZINT; b++) lxc_r[b] = lxcs_s[b];
+        }
+        // (instruction count matters here: 5.5e9 of these per cfg-3 launch bound the kernel.  fract instead of
+        //  int -> double -> subtract, one ds_read2_b64 for the unclamped row pair: 9 VALU + 1 LDS instead of 14 + 2)
+        auto interp = [&](int b, double lx, double lxc) {
+            double xx = lx - lxc;
+            xx = fmin(fmax(xx, 0.0), ux);
+            const int x0 = (int)xx;
+            const double wx = __builtin_amdgcn_fract(xx);
+            const double *pr = prof + b * PS + x0;
+            const double s0 = pr[0], s1 = pr[1];
+            return fma(wx, s1 - s0, s0);
+        };
 #pragma unroll
         for (int k = 0; k < CL_LPT; k++) {
 #if CL_ABLATE == 2   // diagnostic: no interpolation phase
-            if (k >= 1) break;
+            if (k >= 1) continue;
 #endif
-            if (k >= kmax) break;  // uniform: l-sharded callers pass short l ranges
-            double s = 0.0;
-            for (int b = 0; b < zint; b++) {
-                // (instruction count matters here: 5.5e9 of these per cfg-3 launch bound the kernel.  fract instead of
-                //  int -> double -> subtract, one ds_read2_b64 for the unclamped row pair: 9 VALU + 1 LDS instead of 14 + 2)
-                double xx = lxs[k] - lxcs_s[b];
-                xx = fmin(fmax(xx, 0.0), ux);
-                const int x0 = (int)xx;
-                const double wx = __builtin_amdgcn_fract(xx);
-                const double *pr = prof + b * PS + x0;
-                const double s0 = pr[0], s1 = pr[1];
-                s += fma(wx, s1 - s0, s0);
+            if (k < kmax) {  // uniform: l-sharded callers pass short l ranges
+                double s = 0.0;
+                if constexpr (ZINT > 0) {
+#pragma unroll
+                    for (int b = 0; b < ZINT; b++) s += interp(b, lxs[k], lxc_r[b]);
+                } else {
+                    for (int b = 0; b < zint; b++) s += interp(b, lxs[k], lxcs_s[b]);
+                }
+                acc[k] += s;
             }
-            acc[k] += s;
         }
     }
 #pragma unroll
@@ -346,11 +363,11 @@ static int clarray21_pairs(corahip_ctx *ctx, const double *dd, const double *dv,
     const double xscale = (double)(nkperp - 1) / log10(kperpmax / kperpmin);
     const double yscale = kparmax / M_PI;
     const size_t shm = sizeof(double) * ((size_t)zint * (CL_XS + 2) + zint + (size_t)zint * zint * 10);
-    HIP_TRY(hipFuncSetAttribute((const void *)clarray21_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+    auto kern = zint == 9 ? clarray21_kernel<9> : (zint == 5 ? clarray21_kernel<5> : (zint == 3 ? clarray21_kernel<3> : clarray21_kernel<0>));
+    HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
     for (int l_base = 0; l_base < nl; l_base += 256 * CL_LPT) {
-        clarray21_kernel<<<(unsigned)npl_pad, 256, shm, ctx->stream>>>(tt, nkperp, nkpar, kperpmin, xscale, yscale, chi, pfd,
-                                                                      f, b, F, zint, w, log10l, nl, l_base, dpairs,
-                                                                      out_pairs, nl, l_block);
+        kern<<<(unsigned)npl_pad, 256, shm, ctx->stream>>>(tt, nkperp, nkpar, kperpmin, xscale, yscale, chi, pfd, f, b, F, zint, w,
+                                                          log10l, nl, l_base, dpairs, out_pairs, nl, l_block);
         LAUNCH_CHECK();
     }
     return 0;
