@@ -254,11 +254,42 @@ __global__ void cl_finish_kernel(const double *__restrict__ scratch, long npairs
     for (int r = ty; r < 32; r += 8) {
         const int l = l0 + r;
         if (l < nl) {
-            const double v = tile[tx][r];
-            out[((size_t)l * F + ij.x) * F + ij.y] = v;
-            out[((size_t)l * F + ij.y) * F + ij.x] = v;
+            out[((size_t)l * F + ij.x) * F + ij.y] = tile[tx][r];   // upper triangle (j >= i): consecutive slots, consecutive j
         }
     }
+}
+
+// out[l][j][i] = out[l][i][j] for j > i, in 32 x 32 tiles through LDS: both the read of the upper and the write of the
+// lower triangle are 256-byte rows (cl_finish_kernel used to write the mirror element by element, F doubles apart:
+// 2.9 GB of WRITE_SIZE for 1.07 GB of C_l, profiles/r02_pmc.json).  grid = (upper tiles, l)
+__global__ void cl_mirror_kernel(double *__restrict__ out, int F) {
+    __shared__ double tile[32][33];
+    const int nt = (F + 31) / 32;
+    // upper-triangular tile index -> (ti, tj >= ti)
+    int ti = 0, rem = blockIdx.x;
+    while (rem >= nt - ti) {
+        rem -= nt - ti;
+        ti++;
+    }
+    const int tj = ti + rem;
+    double *o = out + (size_t)blockIdx.y * F * F;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    for (int r = ty; r < 32; r += 8) {
+        const int i = ti * 32 + r, j = tj * 32 + tx;
+        tile[r][tx] = (i < F && j < F) ? o[(size_t)i * F + j] : 0.0;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int j = tj * 32 + r, i = ti * 32 + tx;       // element (j, i) of the lower triangle
+        if (j < F && i < F && j > i) o[(size_t)j * F + i] = tile[tx][r];
+    }
+}
+static int launch_mirror(corahip_ctx *ctx, double *out, int nl, int F) {
+    const int nt = (F + 31) / 32;
+    dim3 grid((unsigned)(nt * (nt + 1) / 2), (unsigned)nl);
+    cl_mirror_kernel<<<grid, 256, 0, ctx->stream>>>(out, F);
+    LAUNCH_CHECK();
+    return 0;
 }
 
 // separable model: Bavg[i][j] = sum_ab w_a w_b bcov[i zint + a][j zint + b]; out[l][i][j] = al[l] Bavg[i][j]
@@ -391,7 +422,7 @@ int corahip_clarray_table21cm(corahip_ctx *ctx, const double *dd, const double *
     dim3 grid((unsigned)((npairs + 31) / 32), (nl + 31) / 32);
     cl_finish_kernel<<<grid, 256, 0, ctx->stream>>>(scratch, npairs, 1, npairs, nl, nl, F, out);
     LAUNCH_CHECK();
-    return 0;
+    return launch_mirror(ctx, out, nl, F);
 }
 
 int corahip_clarray_table21cm_pairs(corahip_ctx *ctx, const double *dd, const double *dv, const double *vv, int nkperp,
@@ -419,7 +450,7 @@ int corahip_clarray_pairs_finish(corahip_ctx *ctx, const double *pairs_in, int F
     dim3 grid((unsigned)((npl * nranks + 31) / 32), (nl + 31) / 32);
     cl_finish_kernel<<<grid, 256, 0, ctx->stream>>>(pairs_in, npairs, nranks, npl, l_stride, nl, F, out);
     LAUNCH_CHECK();
-    return 0;
+    return launch_mirror(ctx, out, nl, F);
 }
 
 int corahip_clarray_separable(corahip_ctx *ctx, const double *al, int nl, const double *bcov, int F, int zint,

@@ -5,6 +5,9 @@
 #ifndef LEG_ST_UNROLL
 #define LEG_ST_UNROLL 1   // unroll factor of the stage loop (3 would make the LDS ring offsets immediates)
 #endif
+#ifndef LEG_XCD_PAIR
+#define LEG_XCD_PAIR 0    // 1: the two ring tiles (2k, 2k+1) of an a_lm slice are taken by workgroups of ONE XCD (see map_item); measured neutral in time, +12 % FETCH_SIZE: off
+#endif
 #ifndef LEG_MS_UNROLL
 #define LEG_MS_UNROLL 7   // (= LEG_KT / 8 at the shipped stage length; only the rolled head / tail stages use it) macro-step loop of a stage fully unrolled (loop counters and pointer increments become immediates): 71.0 -> 69.5 ms; factors 2 and 3: no change
 #endif
@@ -105,8 +108,28 @@ legendre_kernel(int lmax, int npair, int nring, int ncols, const double *__restr
     };
 
     // dynamic work queue (one atomic per item, fetched one item ahead): items differ a lot in length
-    // (polar ring tiles start late, large m is short), a static assignment left ~10 % on the table
-    int item = blockIdx.x;  // the first gridDim.x items are pre-assigned; the queue starts behind them
+    // (polar ring tiles start late, large m is short), a static assignment left ~10 % on the table.
+    // LEG_XCD_PAIR: one queue per XCD (workgroups with equal blockIdx % 8 share an XCD under round-robin placement - a
+    // matter of speed only).  The pairs of ring tiles (2k, 2k+1) of all slices are dealt over the eight queues -
+    // pair q to queue (q + q / 8) % 8: the eight pairs of a block go to eight different XCDs and the rotation lets every
+    // XCD see polar and equatorial tiles alike - and the two tiles of a pair are consecutive entries of their queue:
+    // two workgroups of the XCD stream the same a_lm rows at the same time, so that L2 fetches the slice once
+    // for both.  Measured (round 2, cfg 3): 56.8 ms either way and FETCH_SIZE 85 GB against 76 GB with the global queue -
+    // the partner's rows have left the 4 MB L2 (32 workgroups x two 57 KB stages + the F_m stores) before it asks for
+    // them; the re-reads of a slice are absorbed by the 256 MB Infinity Cache, which FETCH_SIZE counts as fetches
+    // (MI355X_MICROARCH.md).  All eight tiles of a slice on one XCD had been 24 % slower (L2-channel hot-spotting).
+    const bool xcd_pair = LEG_XCD_PAIR && (ntile % 2 == 0) && (gridDim.x % 8 == 0);
+    const int xcd = blockIdx.x & 7;
+    const int nwg_q = xcd_pair ? (int)(gridDim.x >> 3) : (int)gridDim.x;      // workgroups feeding from this queue
+    unsigned *const my_queue = queue + (xcd_pair ? 32 * xcd : 0);
+    auto map_item = [&](int t) {       // t-th entry of this workgroup's queue -> item index (nitems: the queue is exhausted)
+        if (!xcd_pair) return t;
+        const int s = t >> 1;
+        const long q = 8L * s + ((xcd - s) & 7);                             // pair index: (slice group, tile pair)
+        const long it = q * 2 + (t & 1);                                     // = gidx * ntile + 2 kp + half  (ntile even)
+        return it < nitems ? (int)it : nitems;
+    };
+    int item = map_item(xcd_pair ? (int)(blockIdx.x >> 3) : (int)blockIdx.x);  // the first entries are pre-assigned; the queue starts behind them
     if (item >= nitems) return;
     item_t w = decode(item);
 #pragma unroll
@@ -115,7 +138,7 @@ legendre_kernel(int lmax, int npair, int nring, int ncols, const double *__restr
 
     for (;;) {
         const int m = w.m;
-        if (tid == 0) s_next = (int)(gridDim.x + atomicAdd(queue, 1u));  // latency hidden behind this item
+        if (tid == 0) s_next = map_item((int)(nwg_q + atomicAdd(my_queue, 1u)));  // latency hidden behind this item
         d4_t acce[RT][NT], acco[RT][NT];
 #pragma unroll
         for (int q = 0; q < RT; q++)
@@ -489,7 +512,7 @@ static int launch_legendre(corahip_ctx *ctx, const corahip_sht_plan *p, int ncol
     // persistent: as many workgroups as fit (LDS-limited: one per CU for NT = 8)
     const int per_cu = std::max<int>(1, std::min<int>(2, (int)((160 * 1024) / shm)));
     dim3 grid((unsigned)std::min<long>(nitems, (long)ctx->num_cu * per_cu));
-    HIP_TRY(hipMemsetAsync(p->d_queue, 0, 64, ctx->stream));
+    HIP_TRY(hipMemsetAsync(p->d_queue, 0, 1024, ctx->stream));
     legendre_kernel<NT, RT><<<grid, 64 * LEG_WAVES, shm, ctx->stream>>>(p->lmax, p->npair, p->nring, ncols, p->d_z,
                                                                        p->d_coef, p->d_lstart, p->d_seed, p->d_lmin,
                                                                        alm, p->d_zeros, inter, p->d_queue);

@@ -318,7 +318,7 @@ int corahip_sht_plan_create(corahip_ctx *ctx, int nside, int lmax, corahip_sht_p
     }
     {
         const int ntile = (p->npair + LMIN_RINGS - 1) / LMIN_RINGS;
-        HIP_TRY(hipMalloc((void **)&p->d_queue, 64));
+        HIP_TRY(hipMalloc((void **)&p->d_queue, 1024));   // 8 queue heads, 128 bytes apart
         HIP_TRY(hipMalloc((void **)&p->d_mcut, sizeof(int32_t) * (size_t)p->nring));
         mcut_kernel<<<(p->npair + 63) / 64, 64, 0, s>>>(lmax, p->npair, p->nring, p->d_lstart, p->d_mcut);
         LAUNCH_CHECK();

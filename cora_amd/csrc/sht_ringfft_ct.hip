@@ -730,7 +730,10 @@ int sht_ringfft_ct(corahip_ctx *ctx, const corahip_sht_plan *p, const corahip_sh
         else return 0;
     } else {
         static const bool no3 = getenv("CORAHIP_K5_NO3") != nullptr;   // diagnostics: power-of-two lengths only
-        if (c.P3 == 3072 && !no3) rc = launch_blu<3072, 2, 4, 512>(ctx, st, 0, p, c, inter, G, nnu, maps, p->d_blu3_foff, p->d_bfilt3);
+        static const bool half = getenv("CORAHIP_K5_HALF") != nullptr;   // A/B: 256-thread workgroups of one channel, two per CU
+        if (half && c.P3 == 3072 && !no3) rc = launch_blu<3072, 1, 8, 256>(ctx, st, 0, p, c, inter, G, nnu, maps, p->d_blu3_foff, p->d_bfilt3);
+        else if (half && c.P3 != 1536 && c.P == 4096) rc = launch_blu<4096, 1, 8, 256>(ctx, st, 0, p, c, inter, G, nnu, maps);
+        else if (c.P3 == 3072 && !no3) rc = launch_blu<3072, 2, 4, 512>(ctx, st, 0, p, c, inter, G, nnu, maps, p->d_blu3_foff, p->d_bfilt3);
         else if (c.P3 == 1536 && !no3) rc = launch_blu<1536, 4, 2, 512>(ctx, st, 0, p, c, inter, G, nnu, maps, p->d_blu3_foff, p->d_bfilt3);
         else if (c.P == 4096) rc = launch_blu<4096, 2, 4, 512>(ctx, st, 0, p, c, inter, G, nnu, maps);
         else if (c.P == 2048) rc = launch_blu<2048, 4, 2, 512>(ctx, st, 0, p, c, inter, G, nnu, maps);
