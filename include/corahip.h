@@ -133,8 +133,9 @@ int corahip_factor_batched(corahip_ctx *ctx, const double *C, int nl, int F, dou
  * Normal stream layout ("stream order"; nputil.py:104-125 called from
  * skysim.py:120): for l = 0..lmax: F*(l+1) reals [nu'][m] then F*(l+1) imags [nu'][m];
  * total 2*F*nalm doubles.  The 1/sqrt(2) of complex_std_normal is applied by draw_alm.
- * normals_philox fills that buffer with the device stream: element (l, c, nu', m) is a Box-Muller output
- * of Philox4x32-10 counter {m/2, l*2F + c*F + nu'} under key `seed` (independent of the GPU count). */
+ * normals_philox fills that buffer with the device stream: the elements (l, c = 0 / 1, nu', m) are the two Box-Muller
+ * outputs of Philox4x32-10 counter {m, l*F + nu'} under key `seed` (independent of the GPU count; the mapping of the
+ * four output words to the pair is specified in oracle/philox.py and cora_amd/csrc/rng_dev.h). */
 int corahip_normals_philox(corahip_ctx *ctx, uint64_t seed, int lmax, int F, double *g);
 
 /* a_lm(nu) = sum_nu' T_l[nu,nu'] g_lm(nu')  (skysim.py:121) for channels nu0 <= nu < nu0+nnu.
