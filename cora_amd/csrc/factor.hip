@@ -177,26 +177,34 @@ chol_kernel(const double *__restrict__ C, int F, double jitter_rel, double *__re
 }
 
 // ------------------------------------------------------------------------------------
-// The same blocked right-looking Cholesky with the trailing update on FP64 MFMA (even F >= 64; chol_kernel above
-// keeps the odd and the small sizes).  What changed, and why (rocprofv3 + PMC of chol_kernel at F = 256: 2.45 ms for
-// 1.15e10 flop, 6.8 GB of HBM-side traffic for 2.1 GB of matrices - a latency chain, not a bandwidth or flop bound):
-//  * the update A22 -= X X^T is dealt in 32 x 32 tiles to the four WAVES, which work on their own: a wave stages the
-//    two 32 x 32 panel blocks of its tile in a wave-private piece of LDS (256-byte row loads, no workgroup barrier),
-//    reads them as v_mfma_f64_16x16x4_f64 operands (row stride 34 doubles: conflict-free for half-waves) and
-//    accumulates onto the old tile loaded in the MFMA's own C layout (A operand negated: new = old + (-X_i) X_j^T);
-//    the workgroup meets at TWO barriers per panel (panel solved / update done) where the VALU version met at two per
-//    64 x 64 tile;
-//  * the next tile's panel block and old values are requested before the MFMAs of the current tile.
-// Diagonal block (one wave, v_readlane broadcast) and panel solve (one row per thread) are those of chol_kernel.
+// LEFT-LOOKING blocked Cholesky on FP64 MFMA (even F >= 64; chol_kernel above keeps the odd and the small sizes).
+// chol_kernel is a latency chain against L2 at F = 256 (2.45 ms for 1.15e10 flop) and HBM-bound beyond: a right-looking
+// update re-reads and re-writes the whole trailing matrix for every panel - F^3 / 96 doubles each way per matrix, 23 GB
+// per cfg-4 step (F = 512), 92 GB for a cfg-5 rank (F = 1024) - and the matrices in flight (two per CU) do not fit any
+// cache.  Left-looking, block column j (32 wide) is formed once: every 32 x 32 tile (i >= j, j) starts from the INPUT
+// block (there is no copy-in pass), subtracts L_ik L_jk^T for k < j with the accumulators resident in registers
+// (v_mfma_f64_16x16x4_f64, the tile in the MFMA's C layout), and is written once; the factors read are final.  HBM
+// traffic: the input lower triangle + the output + F^3 / 192 doubles of factor blocks per matrix.
+//  * the tiles of a block column are dealt to the four WAVES, which work on their own: a wave stages the two 32 x 32
+//    factor blocks of a k-step in a wave-private piece of LDS (256-byte row loads, no workgroup barrier; the next
+//    k-step's blocks are requested before the MFMAs of the current one) and reads them as MFMA operands (row stride 34
+//    doubles: conflict-free for half-waves); A operand negated: acc += (-L_ik) L_jk^T;
+//  * the diagonal tile goes to LDS and is factored by one wave, row i in the registers of lane i, broadcasts by
+//    v_readlane, 1 / sqrt(d) by v_rsq_f64 + two Newton steps (the ds_bpermute of __shfl and sqrt + division cost 0.3 ms
+//    of the 2.1 ms of a right-looking MFMA version of this kernel); 1 / L_jj is kept for the solve;
+//  * the off-diagonal tiles are written as they are and solved in place, one row per thread, against the LDS block;
+//  * three barriers per block column.
+// Ablations of the right-looking MFMA version (F = 256, 2.11 ms): diagonal blocks 0.50, panel solve 0.35, trailing update
+// 0.62, copy-in 0.5 ms.
 // ------------------------------------------------------------------------------------
-#define CHM_S 34    // doubles per staged panel row
+#define CHM_S 34    // doubles per staged block row
 #ifndef CHM_ABLATE
-#define CHM_ABLATE 0   // diagnostic builds (wrong results): 1 no diagonal-block factorisation, 2 no panel solve, 3 no trailing update, 4 no copy-in
+#define CHM_ABLATE 0   // diagnostic builds (wrong results): 1 no diagonal-block factorisation, 2 no panel solve, 3 no MFMA updates
 #endif
 
 __global__ void __launch_bounds__(256)
-chol_mfma_kernel(const double *__restrict__ C, int F, double jitter_rel, double *__restrict__ T,
-                 int32_t *__restrict__ info) {
+chol_ll_kernel(const double *__restrict__ C, int F, double jitter_rel, double *__restrict__ T,
+               int32_t *__restrict__ info) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double *D = lds;                                   // [32][33] diagonal block
     double *red = lds + CH_NB * (CH_NB + 1);           // [256] reduction scratch
@@ -223,35 +231,100 @@ chol_mfma_kernel(const double *__restrict__ C, int F, double jitter_rel, double 
     }
     const double jit = red[0] * jitter_rel;
     __syncthreads();
-    // copy lower triangle (+jitter), zero the upper: 16 bytes per thread (F even)
-    for (long q = 2L * tid; q < (long)F * F && CHM_ABLATE != 4; q += 512) {
-        const int i = (int)(q / F), j = (int)(q % F);
-        double2 v = make_double2(0.0, 0.0);
-        if (j <= i) {
-            v = *reinterpret_cast<const double2 *>(A + q);
-            if (j == i) {
-                v.x += jit;
-                v.y = 0.0;
-            } else if (j + 1 == i) {
-                v.y += jit;
+
+    const int nblk = (F + 31) / 32;
+    // this lane's part of a 32 x 32 block moved as rows: half a row (16 doubles) = row (lane >> 1), columns 16 (lane & 1) ..
+    const int srow = lane >> 1, scol = 16 * (lane & 1);
+    // (the loads are unconditional - a row past the end reads row 0 and is zeroed by the sign when it is staged: with the
+    //  zeroing at the load the compiler waited for the prefetched values right behind their request)
+    auto load_block = [&](int row0, int col0, double2 (&v)[8]) {   // rows row0 .. + 31, columns col0 .. + 31 of the factor
+        const double *src = Tl + (size_t)(row0 + srow < F ? row0 + srow : 0) * F + col0 + scol;
+#pragma unroll
+        for (int q = 0; q < 8; q++) v[q] = *reinterpret_cast<const double2 *>(src + 2 * q);
+    };
+    auto store_block = [&](double *P, const double2 (&v)[8], double sign, int row0) {
+        const double sg = row0 + srow < F ? sign : 0.0;
+#pragma unroll
+        for (int q = 0; q < 8; q++)
+            *reinterpret_cast<double2 *>(P + srow * CHM_S + scol + 2 * q) = make_double2(sg * v[q].x, sg * v[q].y);
+    };
+
+    for (int j = 0; j < nblk; j++) {
+        const int kb = 32 * j;
+        const int nb = min(CH_NB, F - kb);
+        // ---- A. the tiles (i >= j, j) of the block column: input block minus the products of the factor blocks to the left.
+        //         Tile (a, b), register r of the accumulators <-> row i0 + 16 a + kq + 4 r, column kb + 16 b + ri.
+        for (int i = j + wave; i < nblk; i += 4) {
+            const int i0 = 32 * i;
+            d4_t acc[2][2];
+#pragma unroll
+            for (int a = 0; a < 2; a++)
+#pragma unroll
+                for (int b = 0; b < 2; b++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const int row = i0 + 16 * a + kq + 4 * r, col = kb + 16 * b + ri;
+                        double v = 0.0;
+                        if (row < F && col <= row) v = A[(size_t)row * F + col] + (row == col ? jit : 0.0);
+                        acc[a][b][r] = v;
+                    }
+            if (j > 0 && CHM_ABLATE != 3) {
+                double2 va[8], vb[8];
+                load_block(i0, 0, va);
+                load_block(kb, 0, vb);
+                for (int k = 0; k < j; k++) {
+                    store_block(PA, va, -1.0, i0);
+                    store_block(PB, vb, 1.0, kb);
+                    if (k + 1 < j) {          // the next k-step's blocks, in flight during the MFMAs below
+                        load_block(i0, 32 * (k + 1), va);
+                        load_block(kb, 32 * (k + 1), vb);
+                    }
+                    // (wave-private LDS: the ds_writes above complete before the reads below, and these before the next
+                    //  k-step's writes - one wave, in order)
+#pragma unroll
+                    for (int s = 0; s < 8; s++) {
+                        double af[2], bf[2];
+#pragma unroll
+                        for (int a = 0; a < 2; a++) {
+                            af[a] = PA[(16 * a + ri) * CHM_S + 4 * s + kq];
+                            bf[a] = PB[(16 * a + ri) * CHM_S + 4 * s + kq];
+                        }
+#pragma unroll
+                        for (int a = 0; a < 2; a++)
+#pragma unroll
+                            for (int b = 0; b < 2; b++)
+                                acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[a], bf[b], acc[a][b], 0, 0, 0);
+                    }
+                }
+            }
+            if (i == j) {      // (wave 0) the diagonal tile goes to LDS
+#pragma unroll
+                for (int a = 0; a < 2; a++)
+#pragma unroll
+                    for (int b = 0; b < 2; b++)
+#pragma unroll
+                        for (int r = 0; r < 4; r++) D[(16 * a + kq + 4 * r) * (CH_NB + 1) + 16 * b + ri] = acc[a][b][r];
+            } else {           // an off-diagonal tile is stored for the solve; its mirror tile of the upper triangle is zeroed
+#pragma unroll
+                for (int a = 0; a < 2; a++)
+#pragma unroll
+                    for (int b = 0; b < 2; b++)
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            const int row = i0 + 16 * a + kq + 4 * r, col = kb + 16 * b + ri;
+                            if (row < F && col < F) Tl[(size_t)row * F + col] = acc[a][b][r];
+                        }
+                if (kb + srow < F) {
+                    double *z = Tl + (size_t)(kb + srow) * F + i0 + scol;
+#pragma unroll
+                    for (int q = 0; q < 8; q++)
+                        if (i0 + scol + 2 * q < F) *reinterpret_cast<double2 *>(z + 2 * q) = make_double2(0.0, 0.0);
+                }
             }
         }
-        *reinterpret_cast<double2 *>(Tl + q) = v;
-    }
-    __syncthreads();
-
-    for (int kb = 0; kb < F; kb += CH_NB) {
-        const int nb = min(CH_NB, F - kb);
-        // ---- 1. diagonal block into LDS and factor it (one wave, row i in the registers of lane i)
-        for (int q = tid; q < nb * nb; q += 256) {
-            const int i = q / nb, j = q % nb;
-            D[i * (CH_NB + 1) + j] = (j <= i) ? Tl[(size_t)(kb + i) * F + kb + j] : 0.0;
-        }
         __syncthreads();
+        // ---- B. factor the diagonal block with ONE wave, row i of the block in the registers of lane i
         if (tid < 64 && CHM_ABLATE != 1) {
-            // (broadcasts by v_readlane into scalar registers - the ds_bpermute of __shfl cost 1056 LDS-crossbar round trips
-            //  per panel on the one chain of the kernel that nothing else overlaps - and 1 / sqrt(d) by v_rsq_f64 + two
-            //  Newton steps instead of a square root followed by a division; 1 / L_jj is kept for the panel solve)
             auto bcast = [](double v, int src) {
                 const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
                 const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
@@ -262,9 +335,9 @@ chol_mfma_kernel(const double *__restrict__ C, int F, double jitter_rel, double 
             for (int k = 0; k < CH_NB; k++) row[k] = (lane < nb && k <= lane) ? D[lane * (CH_NB + 1) + k] : 0.0;
             bool bad = false;
 #pragma unroll
-            for (int j = 0; j < CH_NB; j++) {
-                if (j < nb && !bad) {
-                    const double d = bcast(row[j], j);
+            for (int jj = 0; jj < CH_NB; jj++) {
+                if (jj < nb && !bad) {
+                    const double d = bcast(row[jj], jj);
                     if (!(d > 0.0)) {  // also catches NaN: LAPACK potrf "not positive definite"
                         bad = true;
                     } else {
@@ -272,11 +345,11 @@ chol_mfma_kernel(const double *__restrict__ C, int F, double jitter_rel, double 
                         const double hd = 0.5 * d;
                         y = fma(y, fma(-hd * y, y, 0.5), y);
                         y = fma(y, fma(-hd * y, y, 0.5), y);       // 1 / sqrt(d)
-                        const double lij = row[j] * y;             // lane j: sqrt(d); lanes above j: unused garbage
-                        row[j] = lij;
-                        if (lane == j) rdiag[j] = y;
+                        const double lij = row[jj] * y;            // lane jj: sqrt(d); lanes above jj: unused garbage
+                        row[jj] = lij;
+                        if (lane == jj) rdiag[jj] = y;
 #pragma unroll
-                        for (int k = j + 1; k < CH_NB; k++) row[k] = fma(-lij, bcast(lij, k), row[k]);
+                        for (int k = jj + 1; k < CH_NB; k++) row[k] = fma(-lij, bcast(lij, k), row[k]);
                     }
                 }
             }
@@ -287,136 +360,37 @@ chol_mfma_kernel(const double *__restrict__ C, int F, double jitter_rel, double 
         }
         __syncthreads();
         if (*flag) break;
-        for (int q = tid; q < nb * nb; q += 256) {
-            const int i = q / nb, j = q % nb;
-            if (j <= i) Tl[(size_t)(kb + i) * F + kb + j] = D[i * (CH_NB + 1) + j];
+        for (int q = tid; q < nb * nb; q += 256) {      // L_jj and the zeros above its diagonal
+            const int i = q / nb, jj = q % nb;
+            Tl[(size_t)(kb + i) * F + kb + jj] = (jj <= i) ? D[i * (CH_NB + 1) + jj] : 0.0;
         }
         const int r0 = kb + nb;
-        if (r0 >= F) break;
-        // ---- 2. panel: rows r0..F-1, X = A21 * L11^{-T}; one row per thread (nb == 32 here)
+        // ---- C. the tiles below: X = S L_jj^{-T}, one row per thread, in place (nb == 32 whenever there are rows below)
         for (int r = r0 + tid; r < F && CHM_ABLATE != 2; r += 256) {
             double x[CH_NB];
             double *row = Tl + (size_t)r * F + kb;
 #pragma unroll
-            for (int j = 0; j < CH_NB; j += 2) {
-                const double2 v = *reinterpret_cast<const double2 *>(row + j);
-                x[j] = v.x;
-                x[j + 1] = v.y;
+            for (int jj = 0; jj < CH_NB; jj += 2) {
+                const double2 v = *reinterpret_cast<const double2 *>(row + jj);
+                x[jj] = v.x;
+                x[jj + 1] = v.y;
             }
             // (the run-time test on nb keeps the 528 reads of D inside the row loop: without it they are hoisted in
             //  front of it as loop invariants - into 1000 registers, i.e. scratch)
 #pragma unroll
-            for (int j = 0; j < CH_NB; j++) {
-                if (j < nb) {
-                    double s = x[j];
+            for (int jj = 0; jj < CH_NB; jj++) {
+                if (jj < nb) {
+                    double s = x[jj];
 #pragma unroll
                     for (int p = 0; p < CH_NB; p++)
-                        if (p < j) s -= x[p] * D[j * (CH_NB + 1) + p];
-                    x[j] = s * rdiag[j];
+                        if (p < jj) s -= x[p] * D[jj * (CH_NB + 1) + p];
+                    x[jj] = s * rdiag[jj];
                 }
             }
 #pragma unroll
-            for (int j = 0; j < CH_NB; j += 2) *reinterpret_cast<double2 *>(row + j) = make_double2(x[j], x[j + 1]);
+            for (int jj = 0; jj < CH_NB; jj += 2) *reinterpret_cast<double2 *>(row + jj) = make_double2(x[jj], x[jj + 1]);
         }
-        __syncthreads();  // panel visible to the whole workgroup (same CU, write-through L1)
-        // ---- 3. trailing update A22 -= X X^T, lower triangle, 32 x 32 tiles dealt to the waves (tile rows interleaved so
-        //         that every wave gets long and short rows); (r0 is a multiple of 32 here: nb == 32 whenever r0 < F)
-        const int nt = (F - r0 + 31) / 32;
-        // this lane's part of a 32-row panel block: half a row (16 doubles) = row (lane >> 1), columns 16 (lane & 1) ..
-        const int srow = lane >> 1, scol = 16 * (lane & 1);
-        auto load_block = [&](int i0, double2 (&v)[8]) {          // rows i0 .. i0 + 31 of the panel, columns kb .. kb + 31
-            const bool ok = i0 + srow < F;
-            const double *src = Tl + (size_t)(ok ? i0 + srow : r0) * F + kb + scol;
-#pragma unroll
-            for (int q = 0; q < 8; q++) {
-                v[q] = *reinterpret_cast<const double2 *>(src + 2 * q);
-                if (!ok) v[q] = make_double2(0.0, 0.0);
-            }
-        };
-        auto store_block = [&](double *P, const double2 (&v)[8], double sign) {
-#pragma unroll
-            for (int q = 0; q < 8; q++)
-                *reinterpret_cast<double2 *>(P + srow * CHM_S + scol + 2 * q) = make_double2(sign * v[q].x, sign * v[q].y);
-        };
-        // old values of tile (i0, j0) in the C layout of the MFMA: tile (a, b), register r <-> row i0 + 16 a + kq + 4 r,
-        // column j0 + 16 b + ri
-        auto load_old = [&](int i0, int j0, d4_t (&acc)[2][2]) {
-#pragma unroll
-            for (int a = 0; a < 2; a++)
-#pragma unroll
-                for (int b = 0; b < 2; b++)
-#pragma unroll
-                    for (int r = 0; r < 4; r++) {
-                        const int i = i0 + 16 * a + kq + 4 * r, j = j0 + 16 * b + ri;
-                        acc[a][b][r] = (i < F && j <= i) ? Tl[(size_t)i * F + j] : 0.0;
-                    }
-        };
-        // tiles of this wave: (ti, tj <= ti) for ti = wave, wave + 4, ...; flattened into one sequence so that the next
-        // tile's loads can be in flight during the current tile's MFMAs
-        int ti = wave, tj = 0;
-        bool have = ti < nt && CHM_ABLATE != 3;
-        double2 vb[8];
-        d4_t acc[2][2], nxt[2][2];
-        if (have) {
-            double2 va[8];
-            load_block(r0 + 32 * ti, va);
-            load_block(r0 + 32 * tj, vb);
-            load_old(r0 + 32 * ti, r0 + 32 * tj, acc);
-            store_block(PA, va, -1.0);
-        }
-        while (have) {
-            const int i0 = r0 + 32 * ti, j0 = r0 + 32 * tj;
-            store_block(PB, vb, 1.0);
-            // next tile of this wave
-            int nti = ti, ntj = tj + 1;
-            if (ntj > nti) {
-                nti += 4;
-                ntj = 0;
-            }
-            const bool have_next = nti < nt;
-            const bool new_row = have_next && nti != ti;
-            double2 va[8];
-            if (have_next) {
-                load_block(r0 + 32 * ntj, vb);
-                if (new_row) load_block(r0 + 32 * nti, va);
-                load_old(r0 + 32 * nti, r0 + 32 * ntj, nxt);
-            }
-            // (wave-private LDS: the ds_writes above are complete before the reads below issue - same wave, in order)
-#pragma unroll
-            for (int s = 0; s < 8; s++) {
-                double af[2], bf[2];
-#pragma unroll
-                for (int a = 0; a < 2; a++) {
-                    af[a] = PA[(16 * a + ri) * CHM_S + 4 * s + kq];
-                    bf[a] = PB[(16 * a + ri) * CHM_S + 4 * s + kq];
-                }
-#pragma unroll
-                for (int a = 0; a < 2; a++)
-#pragma unroll
-                    for (int b = 0; b < 2; b++)
-                        acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[a], bf[b], acc[a][b], 0, 0, 0);
-            }
-#pragma unroll
-            for (int a = 0; a < 2; a++)
-#pragma unroll
-                for (int b = 0; b < 2; b++)
-#pragma unroll
-                    for (int r = 0; r < 4; r++) {
-                        const int i = i0 + 16 * a + kq + 4 * r, j = j0 + 16 * b + ri;
-                        if (i < F && j <= i) Tl[(size_t)i * F + j] = acc[a][b][r];
-                    }
-            if (have_next) {
-                if (new_row) store_block(PA, va, -1.0);   // (every read of PA for the old row has been issued: in order)
-#pragma unroll
-                for (int a = 0; a < 2; a++)
-#pragma unroll
-                    for (int b = 0; b < 2; b++) acc[a][b] = nxt[a][b];
-            }
-            ti = nti;
-            tj = ntj;
-            have = have_next;
-        }
-        __syncthreads();   // the update is complete before the next diagonal block is read
+        __syncthreads();  // the block column is final and visible to the whole workgroup (same CU, write-through L1)
     }
     if (tid == 0) info[blockIdx.x] = *flag;
 }
@@ -589,8 +563,8 @@ extern "C" int corahip_factor_batched(corahip_ctx *ctx, const double *C, int nl,
     static const bool no_mfma = getenv("CORAHIP_K2_VALU") != nullptr;   // A/B: the VALU kernel for every size
     if (F >= 64 && (F % 2) == 0 && !no_mfma) {
         const size_t shm = sizeof(double) * (CH_NB * (CH_NB + 1) + 256 + 2 + CH_NB + 4 * 2 * 32 * CHM_S) + 16;
-        HIP_TRY(hipFuncSetAttribute((const void *)chol_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-        chol_mfma_kernel<<<nl, 256, shm, ctx->stream>>>(C, F, jitter_rel, T, info);
+        HIP_TRY(hipFuncSetAttribute((const void *)chol_ll_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+        chol_ll_kernel<<<nl, 256, shm, ctx->stream>>>(C, F, jitter_rel, T, info);
         LAUNCH_CHECK();
     } else {
         const size_t shm = sizeof(double) * (CH_NB * (CH_NB + 1) + 2 * 64 * (CH_NB + 1) + 256) + 16;
