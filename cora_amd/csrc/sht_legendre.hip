@@ -8,6 +8,9 @@
 #ifndef LEG_XCD_PAIR
 #define LEG_XCD_PAIR 0    // 1: the two ring tiles (2k, 2k+1) of an a_lm slice are taken by workgroups of ONE XCD (see map_item); measured neutral in time, +12 % FETCH_SIZE: off
 #endif
+#ifndef LEG_RING_BLOCKS
+#define LEG_RING_BLOCKS 0   // (measured neutral: 56.6 vs 56.5 ms, off) 1: a wave takes CONSECUTIVE rings of the tile (its own first contributing l), the two waves of a SIMD complementary blocks; 0: rings interleaved over the waves
+#endif
 #ifndef LEG_MS_UNROLL
 #define LEG_MS_UNROLL 7   // (= LEG_KT / 8 at the shipped stage length; only the rolled head / tail stages use it) macro-step loop of a stage fully unrolled (loop counters and pointer increments become immediates): 71.0 -> 69.5 ms; factors 2 and 3: no change
 #endif
@@ -56,6 +59,15 @@ legendre_kernel(int lmax, int npair, int nring, int ncols, const double *__restr
     const unsigned lds_base_bytes = (unsigned)(size_t)(__attribute__((address_space(3))) double *)lds;
     const bool odd_lane = lane & 1;
 
+    // Rings of a tile -> waves.  Interleaved (ring = 8 j + wave, round 1) every wave sees the tile's whole range of first
+    // contributing l, i.e. every wave starts at the tile's EARLIEST ring and multiplies zeros for the others.  With
+    // consecutive blocks a wave starts at its own block's first l (its skip tests are per wave); so that the SIMDs
+    // still finish a stage together, the two waves of a SIMD (waves w and w + 4) take complementary blocks (b, 7 - b):
+    // the first l grows monotonically over the tile, so every SIMD gets the same total.
+    auto ring_in_tile = [&](int j) {     // j-th ring (0 .. 16 RT - 1) of this wave
+        if (LEG_RING_BLOCKS && LEG_WAVES == 8) return (wave < 4 ? wave : 11 - wave) * (16 * RT) + j;
+        return j * LEG_WAVES + wave;
+    };
     // Persistent workgroups.  Work item = (m, column group, ring tile); consecutive items are the ring
     // tiles of one a_lm slice, so the workgroups running at the same time share slices in L2 (they are
     // dealt over all 8 XCDs; packing a slice group onto ONE XCD was measured 24 % slower: every resident
@@ -157,7 +169,7 @@ legendre_kernel(int lmax, int npair, int nring, int ncols, const double *__restr
             int ls_min = lmax + 1;
 #pragma unroll
             for (int q = 0; q < RT; q++) {
-                const int ring = w.rtile * TRINGS + (ri + 16 * q) * LEG_WAVES + wave;
+                const int ring = w.rtile * TRINGS + ring_in_tile(ri + 16 * q);
                 x[q] = 0.0;
                 my_ls[q] = lmax + 1;
                 sd[q] = make_double2(0.0, 0.0);
@@ -262,7 +274,7 @@ legendre_kernel(int lmax, int npair, int nring, int ncols, const double *__restr
                         const double nrecv = __shfl_xor(odd_lane ? n0 : n1, 1);
                         const double srecv = __shfl_xor(odd_lane ? s0 : s1, 1);
                         const int rr = odd_lane ? r1 : r0;
-                        const int ro = cur_rtile * TRINGS + (kq + 4 * rr + 16 * q) * LEG_WAVES + wave;
+                        const int ro = cur_rtile * TRINGS + ring_in_tile(kq + 4 * rr + 16 * q);
 #if LEG_ABLATE == 4  // diagnostic: no epilogue stores (unless a value is absurd: keeps the arithmetic alive)
                         if (ro < npair && n0 == 1.2345e300) {
 #else
