@@ -121,7 +121,7 @@ class SkyShard:
     freq  : all F channel centres (MHz);  zromb : Romberg order of the channel average (``oversample``)
     distributed : run the exchanges (default: world > 1);  emulate_world : measurement hook - do the work of the most
         loaded rank of an ``emulate_world``-rank job on this GPU without any communication (K1: last pair shard,
-        K2: rank 0's multipoles, K3-K5: the last channel shard, factors replaced by a random SPD stack).
+        K2: rank 0's multipoles on random SPD blocks, K3-K5: the last channel shard, factors those of a random SPD stack).
     """
 
     def __init__(self, model, freq, nside, lmax, zromb=3, rank=0, world=1, ctx=None, distributed=None, emulate_world=0,
@@ -199,6 +199,14 @@ class SkyShard:
                 inf[l0:l0 + Tc.shape[0]].copy_(ic)
                 del Cc, Tc, ic
             self._emulated = (Tf, inf, rows)
+            # stand-in input of the rank's K2 (rank 0's multipoles): random SPD blocks - the emulated K1 only fills its own
+            # pair shard, and an incomplete (or zero) block would time the failure path of the factorisation, not K2
+            nl0 = sp.l_hi - sp.l_lo
+            self._emu_C = ctx.empty((nl0, F, F))
+            for l0 in range(0, nl0, lc):
+                Cc = ctx.empty((min(lc, nl0 - l0), F, F)).normal_()
+                self._emu_C[l0:l0 + Cc.shape[0]].copy_(Cc @ Cc.transpose(1, 2) + eye)
+                del Cc
 
     # -- K1 in its two shardings -----------------------------------------------------------
     def _clarray_local(self):
@@ -241,9 +249,10 @@ class SkyShard:
             if self.pair_sharded:
                 slab = self._clarray_pairs(N - 1, N)
                 C = ctx.clarray_pairs_finish(slab.new_zeros((N,) + tuple(slab.shape[1:])), self.F, sp.l_hi - sp.l_lo)
+                del C
             else:
-                C = self._clarray_local()
-            ctx.factor_batched(C)
+                self._clarray_local()
+            ctx.factor_batched(self._emu_C)
             return self._emulated
         if not self.distributed:
             T, info = ctx.factor_batched(self._clarray_local())
