@@ -7,9 +7,9 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
 
 // KIND: which instruction; 8 independent chains so that latency is hidden even with one wave per SIMD
-enum { K_MAD64 = 0, K_XOR, K_BITOP3, K_FMA64, K_CVT_U32, K_LDEXP, K_RSQ, K_MOV64, K_CNDMASK, K_MULHI, K_MULLO, K_ADD64, K_FREXP, K_RNDNE, K_ALIGNBIT, K_N };
+enum { K_MAD64 = 0, K_XOR, K_BITOP3, K_FMA64, K_CVT_U32, K_LDEXP, K_RSQ, K_MOV64, K_CNDMASK, K_MULHI, K_MULLO, K_ADD64, K_FREXP, K_RNDNE, K_ALIGNBIT, K_PL32SWAP, K_PL16SWAP, K_FMA64_CHAIN, K_N };
 static const char *names[K_N] = {"v_mad_u64_u32", "v_xor_b32", "v_bitop3_b32", "v_fma_f64", "v_cvt_f64_u32", "v_ldexp_f64", "v_rsq_f64",
-                                 "v_mov_b64", "v_cndmask_b32", "v_mul_hi_u32", "v_mul_lo_u32", "v_add_f64", "v_frexp_mant_f64", "v_rndne_f64", "v_alignbit_b32"};
+                                 "v_mov_b64", "v_cndmask_b32", "v_mul_hi_u32", "v_mul_lo_u32", "v_add_f64", "v_frexp_mant_f64", "v_rndne_f64", "v_alignbit_b32", "v_permlane32_swap", "v_permlane16_swap", "v_fma_f64 (one dependent chain)"};
 
 template <int KIND, int NMFMA>
 __global__ void __launch_bounds__(256) probe(double *out, int iters, unsigned long long *stamps) {
@@ -48,6 +48,9 @@ __global__ void __launch_bounds__(256) probe(double *out, int iters, unsigned lo
                 if (KIND == K_FREXP) asm volatile("v_frexp_mant_f64 %0, %1" : "=v"(d[i]) : "v"(d[i]));
                 if (KIND == K_RNDNE) asm volatile("v_rndne_f64 %0, %1" : "=v"(d[i]) : "v"(d[i]));
                 if (KIND == K_ALIGNBIT) asm volatile("v_alignbit_b32 %0, %1, %2, 12" : "=v"(u[i]) : "v"(u[i]), "v"(m0));
+                if (KIND == K_PL32SWAP) asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(u[i]), "+v"(u[(i + 1) & 7]));
+                if (KIND == K_PL16SWAP) asm volatile("v_permlane16_swap_b32 %0, %1" : "+v"(u[i]), "+v"(u[(i + 1) & 7]));
+                if (KIND == K_FMA64_CHAIN) asm volatile("v_fma_f64 %0, %1, %2, %3" : "=v"(d[0]) : "v"(d[0]), "v"(ma), "v"(mb));
             }
     }
     unsigned long long c1 = __builtin_amdgcn_s_memtime();
@@ -106,5 +109,8 @@ int main() {
     all<K_FREXP>();
     all<K_RNDNE>();
     all<K_RSQ>();
+    all<K_PL32SWAP>();
+    all<K_PL16SWAP>();
+    all<K_FMA64_CHAIN>();
     return 0;
 }
