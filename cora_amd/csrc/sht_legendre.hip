@@ -210,6 +210,12 @@ legendre_kernel(int lmax, int npair, int nring, int ncols, const double *__restr
             }
             ws_min = __builtin_amdgcn_readfirstlane(ws_min);
             ws_maxinj = __builtin_amdgcn_readfirstlane(ws_maxinj);
+            // The ring's loads (z, first row, seed pair) are CONSUMED here.  Left to the compiler, the wait for the seed pair
+            // lands at its only use - the injection branch inside the macro-step loop - and where its registers are
+            // reused in the epilogue, as an s_waitcnt vmcnt(0): vmcnt is in order, so that wait also drains every LDS-DMA
+            // piece in flight (the stage being refilled; in the epilogue the next item's first stages, just requested).
+#pragma unroll
+            for (int q = 0; q < RT; q++) asm volatile("" ::"v"(x[q]), "v"(sd[q].x), "v"(sd[q].y), "v"(my_ls[q]));
 
             // Stage loop in three consecutive pieces (same body, leg_stage_body.inc): the head stages in which rings of
             // the wave still start, the steady-state stages - every ring runs, none starts, every row <= lmax - whose
@@ -449,6 +455,7 @@ legendre_pol_kernel(int lmax, int npair, int nring, int ncols, const double *__r
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) ws_maxinj = max(ws_maxinj, __shfl_xor(ws_maxinj, o));
             ws_maxinj = __builtin_amdgcn_readfirstlane(ws_maxinj);
+            asm volatile("" ::"v"(x), "v"(sd.x), "v"(sd.y), "v"(my_ls), "v"(r1), "v"(r2));   // (the ring's loads are consumed here: see legendre_kernel)
             auto stage_clean = [&](int st) {
                 const int ls = w.l_begin + st * KT;
                 return (ls + KT - 1 <= lmax) && (ls_min <= ls) && (ws_maxinj < ls);
