@@ -145,6 +145,41 @@ def test_factor_eigen_branch(ctx, golden):
     assert np.abs(T[2] @ T[2].T - psd).max() <= 1e-13 * np.abs(psd).max()
 
 
+def test_factor_mfma_kernel_failure_path_and_ragged_sizes(ctx):
+    """The left-looking MFMA Cholesky (even F >= 64): a block that is not positive definite is flagged and handed to the
+    eigen branch (at a late pivot, a first pivot, and the zero matrix), its neighbours in the batch are untouched; sizes
+    that are not multiples of the 32-column blocks; the upper triangle comes back exactly zero."""
+    rng = np.random.default_rng(64)
+    F = 96
+    A = rng.standard_normal((4, F, F + 5))
+    C = A @ A.transpose(0, 2, 1) + 0.1 * np.eye(F)
+    ev, evec = np.linalg.eigh(C[1])
+    ev[3] = -0.5                                        # indefinite: the Cholesky fails somewhere in the middle
+    C[1] = (evec * ev) @ evec.T
+    C[1] = 0.5 * (C[1] + C[1].T)
+    C[2] = 0.0                                          # zero block: first pivot
+    T, info = ctx.factor_batched(ctx.to_device(C), jitter_rel=0.0)
+    T, info = T.cpu().numpy(), info.cpu().numpy()
+    assert list(info) == [0, 1, 1, 0]
+    for k in (0, 3):
+        ref = np.linalg.cholesky(C[k])
+        assert np.abs(T[k] - ref).max() <= 1e-12 * np.abs(ref).max()
+        assert np.all(np.triu(T[k], 1) == 0)
+    e1, v1 = np.linalg.eigh(C[1])
+    psd = (v1 * np.where(e1 < e1.max() * 1e-16, 0.0, e1)) @ v1.T
+    assert np.abs(T[1] @ T[1].T - psd).max() <= 1e-12 * np.abs(psd).max()
+    assert np.all(T[2] == 0)
+    for F in (64, 66, 94, 130, 200):
+        A = rng.standard_normal((2, F, F + 2))
+        C = A @ A.transpose(0, 2, 1) + 0.05 * np.eye(F)
+        T, info = ctx.factor_batched(ctx.to_device(C))   # (with the reference's jitter)
+        T = T.cpu().numpy()
+        ref = np.linalg.cholesky(C + 1e-14 * np.einsum("lii->li", C).max(axis=1)[:, None, None] * np.eye(F))
+        assert np.all(info.cpu().numpy() == 0)
+        assert np.abs(T - ref).max() <= 1e-12 * np.abs(ref).max(), F
+        assert np.all(np.triu(T, 1) == 0)
+
+
 def test_matrix_root_manynull_api(golden):
     from cora_amd.util import nputil
 
