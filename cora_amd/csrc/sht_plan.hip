@@ -434,6 +434,11 @@ int corahip_sht_plan_create(corahip_ctx *ctx, int nside, int lmax, corahip_sht_p
             }
             // (measured and rejected for the P = 4096 class: one channel per 4-wave workgroup, two workgroups per CU,
             //  so that LDS and FP64 phases of different workgroups overlap: 12.8 -> 13.6 ms, the cells are read 4x)
+            // The short Bluestein classes (P <= 512: 0.5 % of the pixels at nside 1024, but six launches in a row) run
+            // workgroups of 64 / 128 threads instead of 512: a 512-point transform of four channels has 128 radix-16
+            // butterflies per pass - most of a 512-thread workgroup only attended the barriers (P = 512 0.41 -> 0.19 ms,
+            // P = 256 0.19 -> 0.05 ms, K5 -0.5 ms at cfg 3).
+            if (c.P > 0 && c.P <= 512) c.threads = c.P >= 512 ? 128 : 64;
             c.count = (int)kv.second.size();
             if ((rc = dev_upload(&c.d_list, kv.second, s))) return rc;
             p->classes.push_back(c);

@@ -540,7 +540,8 @@ int sht_ringfft(corahip_ctx *ctx, const corahip_sht_plan *p, const double *inter
             const long nitems = (long)c.count * ((nnu_valid + c.nch - 1) / c.nch);
             const int per_cu = std::max<int>(1, (int)((160 * 1024) / std::max<size_t>(shm, 1)));
             const int k5_threads = c.threads ? c.threads : K5_THREADS;
-            dim3 grid((unsigned)std::min<long>(nitems, (long)ctx->num_cu * std::min(per_cu, 4)));
+            // (the short classes run narrow workgroups - see the plan - and more of them per CU)
+            dim3 grid((unsigned)std::min<long>(nitems, (long)ctx->num_cu * std::min(per_cu, k5_threads <= 128 ? 8 : 4)));
 #define RINGFFT_LAUNCH(NCH, BLU)                                                                                     \
     HIP_TRY(hipFuncSetAttribute((const void *)ringfft_kernel<NCH, BLU>, hipFuncAttributeMaxDynamicSharedMemorySize,  \
                                 160 * 1024));                                                                   \
