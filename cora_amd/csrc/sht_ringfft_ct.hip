@@ -737,7 +737,7 @@ int sht_ringfft_ct(corahip_ctx *ctx, const corahip_sht_plan *p, const corahip_sh
         else if (c.P3 == 1536 && !no3) rc = launch_blu<1536, 4, 2, 512>(ctx, st, 0, p, c, inter, G, nnu, maps, p->d_blu3_foff, p->d_bfilt3);
         else if (c.P == 4096) rc = launch_blu<4096, 2, 4, 512>(ctx, st, 0, p, c, inter, G, nnu, maps);
         else if (c.P == 2048) rc = launch_blu<2048, 4, 2, 512>(ctx, st, 0, p, c, inter, G, nnu, maps);
-        else if (c.P == 1024) rc = launch_blu<1024, 4, 1, 512>(ctx, st, 0, p, c, inter, G, nnu, maps);
+        else if (c.P == 1024) rc = launch_blu<1024, 4, 2, 256>(ctx, st, 0, p, c, inter, G, nnu, maps);   // (256 threads, two workgroups per CU: 0.61 -> 0.54 ms)
         else return 0;
     }
     return rc ? rc : 1;
