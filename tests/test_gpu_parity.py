@@ -297,6 +297,37 @@ def test_draw_more_than_128_columns(ctx):
         assert (a - d).abs().max().item() <= 1e-13 * a.abs().max().item()
 
 
+def test_fused_draw_random_shapes(ctx):
+    """The persistent fused-RNG draw against the materialised stream over random shapes: channel counts that are not
+    multiples of 4 / 16 / 32, channel ranges starting anywhere (aligned and unaligned column groups), lmax below and
+    above one 128-m block, triangular and dense factors, row-sliced factors."""
+    import torch
+
+    rng = np.random.default_rng(2026)
+    for trial in range(14):
+        F = int(rng.choice([6, 10, 18, 34, 66, 96, 130, 160, 258]))
+        lmax = int(rng.choice([0, 3, 17, 100, 127, 128, 150, 260]))
+        if F * lmax > 30000:
+            lmax = 30000 // F
+        A = rng.standard_normal((lmax + 1, F, F + 3))
+        C = A @ A.transpose(0, 2, 1) + 0.05 * np.eye(F)
+        T, info = ctx.factor_batched(ctx.to_device(C))
+        if trial % 3 == 2:
+            info = torch.ones_like(info)                 # dense: every nu' contributes (the upper part is stored zeros)
+        seed = 1000 + trial
+        g = ctx.normals_philox(seed, lmax, F)
+        nu0 = int(rng.integers(0, F))
+        nnu = int(rng.integers(1, F - nu0 + 1))
+        for (a0, n) in ((0, F), (nu0, nnu)):
+            a = ctx.alm_dev_to_square(ctx.draw_alm(T, info, g, lmax, F, nu0=a0, nnu=n), lmax, n)
+            b = ctx.alm_dev_to_square(ctx.draw_alm_philox(T, info, seed, lmax, F, nu0=a0, nnu=n), lmax, n)
+            assert torch.isfinite(b).all()
+            assert (a - b).abs().max().item() <= 1e-13 * a.abs().max().item(), (trial, F, lmax, a0, n)
+            rows = T[:, a0:a0 + n, :].contiguous()
+            c = ctx.alm_dev_to_square(ctx.draw_alm_philox_rows(rows, info, seed, lmax, F, a0, n), lmax, n)
+            assert torch.equal(b, c), (trial, F, lmax, a0, n)
+
+
 def test_philox_normals_match_stream_oracle(ctx):
     """normals_philox (fast in-kernel log / sqrt / sincos) == numpy restatement of the device stream."""
     from oracle import philox
