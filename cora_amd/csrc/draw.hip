@@ -48,7 +48,7 @@ __global__ void normals_kernel(uint64_t seed, int lmax, int F, double *__restric
 #define DRAW_ABLATE 0  // diagnostic builds of the fused-RNG kernel: 1 no RNG, 2 no MFMA, 3 no a_lm stores, 4 no staging of T
 #endif
 #ifndef DRAW_KK_UNROLL
-#define DRAW_KK_UNROLL 1   // unroll factor of the k-step loop of a chunk in the fused-RNG kernel
+#define DRAW_KK_UNROLL 2   // unroll factor of the k-step loop of a chunk in the fused-RNG kernel (two generator chains interleaved: 7.58 -> 7.45 ms; 4: the same)
 #endif
 #ifndef DRAW_BEARLY
 #define DRAW_BEARLY 0  // 1: B-operand LDS reads of a k-step issued before its generator chain
