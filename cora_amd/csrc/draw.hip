@@ -351,7 +351,10 @@ draw_rng_kernel(const double *__restrict__ T, size_t t_ldl, int t_row0, const in
             if (c == 0 || c + 1 >= nchunk) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(QPW) : "memory");
             __syncthreads();
-            DSTAMP(1);                       // wait for the stage + barrier
+#if DRAW_STAMPS
+            if (c == 0) { DSTAMP(6); } else
+#endif
+            DSTAMP(1);                       // wait for the stage + barrier (stamp 6: the first chunk of an item, which also waits for the previous item's stores)
             if (c + 2 < nchunk) stage(w, c + 2, (ring + c + 2) % DRAW_NBUF);
             DSTAMP(2);                       // issue of the stage after next
         };
@@ -436,7 +439,7 @@ draw_rng_kernel(const double *__restrict__ T, size_t t_ldl, int t_row0, const in
     }
 #if DRAW_STAMPS
     if (lane == 0) {
-        for (int k = 0; k < 6; k++) atomicAdd(&g_draw_stamps[k], d_acc[k]);
+        for (int k = 0; k < 7; k++) atomicAdd(&g_draw_stamps[k], d_acc[k]);
         atomicAdd(&g_draw_stamps[7], 1ull);
     }
 #endif
@@ -471,8 +474,8 @@ static int launch_draw_rng(corahip_ctx *ctx, const double *T, size_t t_ldl, int 
         HIP_TRY(hipStreamSynchronize(ctx->stream));
         HIP_TRY(hipMemcpyFromSymbol(hs, HIP_SYMBOL(g_draw_stamps), sizeof(hs)));
         const double per = 1.0 / (double)std::max<unsigned long long>(hs[7], 1);
-        fprintf(stderr, "K3 NCT=%d waves=%llu: cycles/wave  prologue %.0f wait+barrier %.0f stage-issue %.0f rng+mfma %.0f next-item %.0f epilogue %.0f\n",
-                NCT, hs[7], hs[0] * per, hs[1] * per, hs[2] * per, hs[3] * per, hs[4] * per, hs[5] * per);
+        fprintf(stderr, "K3 NCT=%d waves=%llu: cycles/wave  prologue %.0f wait+barrier %.0f (first chunk of an item %.0f) stage-issue %.0f rng+mfma %.0f next-item %.0f epilogue %.0f\n",
+                NCT, hs[7], hs[0] * per, hs[1] * per, hs[6] * per, hs[2] * per, hs[3] * per, hs[4] * per, hs[5] * per);
         HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_draw_stamps), z, sizeof(z)));
     }
 #endif
