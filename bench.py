@@ -309,7 +309,7 @@ def main():
                 "frac": ach / FP64_MFMA_PEAK_TFLOPS,
                 "traffic": traffic,
                 "traffic_source": traffic_source,
-                # `achieved` counts the ALGORITHMIC flops of SURVEY 8(d); the kernel skips the terms below 2^-120 (as
+                # `achieved` counts the ALGORITHMIC flops of SURVEY 8(d); the kernel skips the terms below 2^-80 (as
                 # libsharp does), so the matrix pipe itself is busy for the EXECUTED flops only:
                 "executed_flops_per_launch": executed,
                 "executed_tflops": None if executed is None else executed / (leg["ms_per_launch"] * 1e-3) / 1e12,

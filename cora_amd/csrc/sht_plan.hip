@@ -34,14 +34,15 @@ __device__ static inline void scaled_pow(double s, int n, double &mant, int &ex)
 }
 
 // Terms of the Legendre sums with |lambda_lm| < 2^SEED_MIN_EXP are dropped (K4 starts its recurrence at the first l
-// that reaches it; K4 neither writes nor K5 reads the F_m cells beyond the per-ring cut-off it implies).  2^-120 =
-// 7.5e-37: the sum of all 2e6 dropped terms of a channel stays below 1e-29 of an O(1) coefficient, 13 decades
+// that reaches it; K4 neither writes nor K5 reads the F_m cells beyond the per-ring cut-off it implies).  2^-80 =
+// 8.3e-25: the sum of all 2e6 dropped terms of a channel stays below 2e-18 of an O(1) coefficient, two decades
 // under fp64 rounding; libsharp (the engine behind healpy.alm2map) truncates at m > lmax sin(theta) + max(100, lmax / 100),
-// which corresponds to about 2^-70 at lmax = 2048.  The first version used 2^-900 ("exactly zero"): with it the
-// rings 513..1023 of nside 1024 kept lmax + 1 > h + 1 cells, so their ring FFT took the aliased (LDS-atomic) fold
-// and read 20-45 % more cells.  The oracle keeps 2^-900.
+// which corresponds to about 2^-70 at lmax = 2048, i.e. is LOOSER.  The first version used 2^-900 ("exactly zero"):
+// with it the rings 513..1023 of nside 1024 kept lmax + 1 > h + 1 cells, so their ring FFT took the aliased
+// (LDS-atomic) fold and read 20-45 % more cells; 2^-120 followed (K4 66.2 -> 58.3 ms), 2^-80 took another 1.1 ms off
+// K4 (56.4 -> 55.3 ms at cfg 3) with no change in any printed digit of the full-size comparisons.  The oracle keeps 2^-900.
 #ifndef SEED_MIN_EXP
-#define SEED_MIN_EXP (-120)
+#define SEED_MIN_EXP (-80)
 #endif
 
 // lstart[m][r]: first l at which |lambda_lm(ring r)| >= 2^SEED_MIN_EXP, with the two
