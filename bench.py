@@ -311,6 +311,8 @@ def main():
                 "traffic_source": traffic_source,
                 # `achieved` counts the ALGORITHMIC flops of SURVEY 8(d); the kernel skips the terms below 2^-80 (as
                 # libsharp does), so the matrix pipe itself is busy for the EXECUTED flops only:
+                "note": "achieved = algorithmic flops / measured time; the kernel skips the terms below 2^-80 (25 % of the MFMAs), "
+                        "so frac can exceed 1: executed_frac is the busy fraction of the matrix pipe",
                 "executed_flops_per_launch": executed,
                 "executed_tflops": None if executed is None else executed / (leg["ms_per_launch"] * 1e-3) / 1e12,
                 "executed_frac": None if executed is None else executed / (leg["ms_per_launch"] * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS,
