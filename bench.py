@@ -255,24 +255,32 @@ def main():
         emu = args.emulate_shard if args.emulate_shard > 1 else 0
         # emulated shard: only the nnu maps of that one rank were made
         value = (nnu if emu else F) * args.steps / dt
-        # dominant kernel: K4 Legendre contraction, FP64 MFMA bound
+        # dominant kernel: K4 Legendre contraction, FP64 MFMA bound.  `achieved` prices the flops the kernel EXECUTES:
+        # the plan counts, from its first-contributing-l tables, the v_mfma_f64_16x16x4_f64 instructions (2048 flop
+        # each) this launch issues (corahip_sht_plan_k4_mfma_count - the number SQ_INSTS_VALU_MFMA_F64 reads, checked
+        # against the committed PMC profile by tests/test_gpu_fullsize.py).  The algorithmic 8 nside nalm F of SURVEY
+        # 8(d) counts Legendre terms below the plan's 2^-80 cut that nobody has to compute (libsharp, the engine
+        # behind healpy.alm2map, drops them too): it is reported as `algorithmic_tflops`, never as a fraction of peak.
         leg = stages.get("legendre", {"ms_per_launch": float("nan")})
-        flops_leg = 8.0 * nside * nalm * nnu          # per launch, SURVEY 8(d) / DESIGN.md
-        ach = flops_leg / (leg["ms_per_launch"] * 1e-3) / 1e12
+        flops_alg = 8.0 * nside * nalm * nnu           # per launch, SURVEY 8(d) / DESIGN.md
+        mfma_insts = ctx.k4_mfma_count(nside, lmax, nnu)
+        flops_exec = 2048.0 * mfma_insts
+        ach = flops_exec / (leg["ms_per_launch"] * 1e-3) / 1e12
         alg_bytes = 8.0 * npix * nnu + 32.0 * nalm * nnu + 8.0 * L * F * F   # warm path, SURVEY 8(d)
         # HBM bytes of the dominant kernel from the PMC passes of the same command (collected separately
         # with rocprofv3 --pmc and committed under profiles/; bench.py cannot read counters itself)
-        traffic = traffic_source = executed = None
-        pmc_file = os.path.join(ROOT, "profiles", "r02_pmc.json")
-        if os.path.exists(pmc_file) and world == 1 and not emu and args.workload == "cfg3":
-            pmc = json.load(open(pmc_file)).get("kernels", {})
-            k4 = next((v for k, v in pmc.items() if k.startswith("legendre_kernel")), None)
-            if k4:
-                traffic = k4["hbm_bytes_per_launch"]
-                traffic_source = ("profiles/r02_pmc.json (rocprofv3 --pmc passes of this command, 2 x FETCH_SIZE + WRITE_SIZE; "
-                                  "not measured in this run)")
-                if k4.get("SQ_INSTS_VALU_MFMA_F64_per_launch"):
-                    executed = k4["SQ_INSTS_VALU_MFMA_F64_per_launch"] * 2048.0    # flop of a v_mfma_f64_16x16x4_f64
+        traffic = traffic_source = pmc_mfma = None
+        for pmc_name in ("r03_pmc.json", "r02_pmc.json"):
+            pmc_file = os.path.join(ROOT, "profiles", pmc_name)
+            if os.path.exists(pmc_file) and world == 1 and not emu and args.workload == "cfg3":
+                pmc = json.load(open(pmc_file)).get("kernels", {})
+                k4 = next((v for k, v in pmc.items() if k.startswith("legendre_kernel")), None)
+                if k4:
+                    traffic = k4["hbm_bytes_per_launch"]
+                    traffic_source = ("profiles/%s (rocprofv3 --pmc passes of this command, 2 x FETCH_SIZE + WRITE_SIZE; "
+                                      "not measured in this run)" % pmc_name)
+                    pmc_mfma = k4.get("SQ_INSTS_VALU_MFMA_F64_per_launch")
+                    break
         result = {
             "metric": "sky-maps/sec (nside=%d, lmax=%d, %d freq)" % (nside, lmax, F),
             "value": value,
@@ -309,13 +317,14 @@ def main():
                 "frac": ach / FP64_MFMA_PEAK_TFLOPS,
                 "traffic": traffic,
                 "traffic_source": traffic_source,
-                # `achieved` counts the ALGORITHMIC flops of SURVEY 8(d); the kernel skips the terms below 2^-80 (as
-                # libsharp does), so the matrix pipe itself is busy for the EXECUTED flops only:
-                "note": "achieved = algorithmic flops / measured time; the kernel skips the terms below 2^-80 (25 % of the MFMAs), "
-                        "so frac can exceed 1: executed_frac is the busy fraction of the matrix pipe",
-                "executed_flops_per_launch": executed,
-                "executed_tflops": None if executed is None else executed / (leg["ms_per_launch"] * 1e-3) / 1e12,
-                "executed_frac": None if executed is None else executed / (leg["ms_per_launch"] * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS,
+                "note": "achieved = EXECUTED flops / measured time: 2048 x the FP64 MFMA instructions this launch issues, counted "
+                        "in this run from the plan's first-contributing-l tables (= SQ_INSTS_VALU_MFMA_F64); Legendre terms "
+                        "below 2^-80 are skipped (as libsharp does), so the algorithmic count of SURVEY 8(d) is larger",
+                "executed_mfma_instructions_per_launch": mfma_insts,
+                "executed_flops_per_launch": flops_exec,
+                "pmc_mfma_instructions_per_launch": pmc_mfma,
+                "algorithmic_flops_per_launch": flops_alg,
+                "algorithmic_tflops": flops_alg / (leg["ms_per_launch"] * 1e-3) / 1e12,
                 "algorithmic_bytes": 16.0 * nalm * nnu + 16.0 * (4 * nside - 1) * L * nnu,
             },
             "roofline_k5": {
@@ -327,7 +336,7 @@ def main():
                 "frac": (16.0 * (4 * nside - 1) * L * nnu + 8.0 * npix * nnu) / (stages.get("ringfft", {"ms_per_launch": float("nan")})["ms_per_launch"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
             },
             # every stage against the roof that bounds it (algorithmic work of SURVEY 8(d) / DESIGN section 3 per launch)
-            "stage_rooflines": stage_rooflines(stages, nside, lmax, F, nnu, zromb),
+            "stage_rooflines": stage_rooflines(stages, nside, lmax, F, nnu, zromb, flops_exec),
             "hbm_roofline_whole_step": {
                 "algorithmic_GB": alg_bytes / 1e9,
                 "achieved_GBs": alg_bytes / 1e9 / (ms_step * 1e-3),
@@ -345,7 +354,7 @@ def main():
     return result
 
 
-def stage_rooflines(stages, nside, lmax, F, nnu, zromb):
+def stage_rooflines(stages, nside, lmax, F, nnu, zromb, legendre_executed_flops):
     L = lmax + 1
     nalm = L * (L + 1) // 2
     npix = 12 * nside * nside
@@ -355,7 +364,8 @@ def stage_rooflines(stages, nside, lmax, F, nnu, zromb):
         "clarray": ("valu", 60.0 * L * (F * zint) ** 2 / 2, 8.0 * L * F * F),
         "factor": ("valu", L * F**3 / 3.0, 16.0 * L * F * F),
         "draw": ("mfma", 2.0 * F * nnu * nalm, 8.0 * L * F * nnu + 16.0 * nalm * nnu),
-        "legendre": ("mfma", 8.0 * nside * nalm * nnu, 16.0 * nalm * nnu + 16.0 * (4 * nside - 1) * L * nnu),
+        # (executed flops: the plan's MFMA count, see `roofline`)
+        "legendre": ("mfma", legendre_executed_flops, 16.0 * nalm * nnu + 16.0 * (4 * nside - 1) * L * nnu),
         "ringfft": ("hbm", 2.5 * npix * np.log2(4 * nside) * nnu, 16.0 * (4 * nside - 1) * L * nnu + 8.0 * npix * nnu),
     }
     out = {}

@@ -53,6 +53,9 @@ SIGNATURES = {
     "corahip_alm_dev_to_square": (c_int, [c_void_p, PTR, c_int, c_int, PTR]),
     "corahip_alm_packed_to_dev": (c_int, [c_void_p, PTR, c_int, c_int, PTR]),
     "corahip_sht_plan_create": (c_int, [c_void_p, c_int, c_int, ctypes.POINTER(c_void_p)]),
+    "corahip_sht_plan_create_ex": (c_int, [c_void_p, c_int, c_int, c_int, ctypes.POINTER(c_void_p)]),
+    "corahip_sht_plan_cut_exp": (c_int, [c_void_p, ctypes.POINTER(c_int)]),
+    "corahip_sht_plan_k4_mfma_count": (c_int, [c_void_p, c_void_p, c_int, ctypes.POINTER(c_u64)]),
     "corahip_sht_plan_destroy": (c_int, [c_void_p, c_void_p]),
     "corahip_alm2map_workspace_bytes": (c_int, [c_void_p, c_int, ctypes.POINTER(c_size_t)]),
     "corahip_alm2map": (c_int, [c_void_p, c_void_p, PTR, c_int, PTR, c_void_p, c_size_t]),
@@ -78,6 +81,7 @@ SIGNATURES = {
     "corahip_raytrace_slices": (c_int, [c_void_p, PTR, c_int, c_int, c_int, PTR, PTR, PTR, PTR, c_double, c_double,
                                         c_int, c_int, c_int, PTR]),
     "corahip_sht_plan_rings": (c_int, [c_void_p, PTR, PTR, PTR, PTR]),
+    "corahip_sht_plan_ring_classes": (c_int, [c_void_p, PTR]),
     "corahip_sht_lambda": (c_int, [c_void_p, c_void_p, c_int, c_int, PTR]),
 }
 
@@ -385,13 +389,27 @@ class Context:
         return alm
 
     # -- K4/K5 ------------------------------------------------------------------------
-    def sht_plan(self, nside, lmax):
-        key = (int(nside), int(lmax))
+    # truncation exponent of the Legendre sums used by plans made without an explicit one (0 = the library's
+    # default, 2^-80); `Context.sht_cut_exp = -900` before the first transform keeps every representable term
+    sht_cut_exp = 0
+
+    def sht_plan(self, nside, lmax, cut_exp=None):
+        """The (nside, lmax) transform plan; terms of the Legendre sums below 2^cut_exp are dropped (pixel error
+        <= 2 sum |a_lm| 2^cut_exp; default -80, see corahip_sht_plan_create_ex)."""
+        cut = int(self.sht_cut_exp if cut_exp is None else cut_exp)
+        key = (int(nside), int(lmax)) if cut == 0 else (int(nside), int(lmax), cut)
         if key not in self._plans:
             h = c_void_p()
-            _check(self.lib.corahip_sht_plan_create(self.h, key[0], key[1], ctypes.byref(h)))
+            _check(self.lib.corahip_sht_plan_create_ex(self.h, key[0], key[1], cut, ctypes.byref(h)))
             self._plans[key] = h
         return self._plans[key]
+
+    def k4_mfma_count(self, nside, lmax, nnu, cut_exp=None):
+        """FP64 MFMA instructions (v_mfma_f64_16x16x4_f64, 2048 flop each) the Legendre kernel issues for one
+        alm2map pass over ``nnu`` channels - from the plan's tables, equal to the SQ_INSTS_VALU_MFMA_F64 counter."""
+        n = c_u64()
+        _check(self.lib.corahip_sht_plan_k4_mfma_count(self.h, self.sht_plan(nside, lmax, cut_exp), int(nnu), ctypes.byref(n)))
+        return int(n.value)
 
     def alm2map_workspace_bytes(self, plan, nnu):
         b = c_size_t()
@@ -405,8 +423,8 @@ class Context:
             self._workspace = torch.empty((nbytes,), dtype=torch.uint8, device=self.device)
         return self._workspace
 
-    def alm2map(self, alm, nside, lmax, nnu, out=None, max_workspace_bytes=None):
-        plan = self.sht_plan(nside, lmax)
+    def alm2map(self, alm, nside, lmax, nnu, out=None, max_workspace_bytes=None, cut_exp=None):
+        plan = self.sht_plan(nside, lmax, cut_exp)
         npix = 12 * nside * nside
         maps = out if out is not None else self.empty((nnu, npix))
         need = self.alm2map_workspace_bytes(plan, nnu)
@@ -587,6 +605,13 @@ class Context:
         _check(self.lib.corahip_sht_plan_rings(plan, start.ctypes.data_as(c_void_p), nphi.ctypes.data_as(c_void_p),
                                                z.ctypes.data_as(c_void_p), phi0.ctypes.data_as(c_void_p)))
         return dict(start=start, nphi=nphi, z=z, phi0=phi0)
+
+    def sht_ring_classes(self, nside, lmax):
+        """Ring-FFT class of every ring as the synthesis kernels take it: 0 = direct transform, else the Bluestein
+        length (a power of two or 3 * 2^k)."""
+        cls = np.zeros(4 * nside - 1, dtype=np.int32)
+        _check(self.lib.corahip_sht_plan_ring_classes(self.sht_plan(nside, lmax), cls.ctypes.data_as(c_void_p)))
+        return cls
 
     def sht_lambda(self, nside, lmax, m, ring_pair):
         plan = self.sht_plan(nside, lmax)

@@ -141,6 +141,9 @@ def _upload_host_normals(ctx, numz, maxl, rng):
     views = [b.numpy() for b in bufs]
     events = [None, None]
     cs = ctx.copy_stream
+    # `g` may be the recycled block of the previous realisation's normals, whose draw is still queued on the compute
+    # stream: the copies must not start before that stream has reached this point
+    cs.wait_stream(torch.cuda.current_stream(ctx.device))
     sn = np.random.standard_normal if rng is None else rng.standard_normal
     cur, fill, dev_off = 0, 0, 0
 
@@ -253,6 +256,10 @@ def mkfullsky(corr, nside, alms=False, rng=None):
             from .. import parallel
 
             out, _ = parallel.mkfullsky_sharded(np.asarray(local), gshape, nside, rng=rng, alms=alms)
+            if alms:
+                # the reference returns ``alm_array.allgather()`` here (skysim.py:123-125): the FULL [numz, 1, L, L]
+                # array on every rank, as a plain ndarray - not a wrapped frequency shard
+                return _lib.get_context().to_host(parallel.allgather_channels(out, gshape[1]))
             out = _lib.get_context().to_host(out)
             wrap = getattr(type(corr), "wrap", None)
             return wrap(out, axis=0) if wrap is not None else out

@@ -31,6 +31,8 @@
 // ------------------------------------------------------------------------------------
 struct corahip_sht_plan {
     int nside = 0, lmax = 0, L = 0, npair = 0, nring = 0;
+    int cut_exp = 0;                                      // terms of the Legendre sums with |lambda_lm| < 2^cut_exp are dropped
+    std::map<int, uint64_t> k4_macro_steps;               // by RT: macro-steps legendre_kernel executes per column group (lazy)
     long npix = 0, nalm = 0;
     std::vector<int64_t> h_start;
     std::vector<int32_t> h_nphi;
@@ -70,6 +72,7 @@ struct corahip_sht_plan {
         int bstride = 0;  // complex elements per channel buffer in LDS
         int count = 0;
         int32_t *d_list = nullptr;
+        std::vector<int32_t> h_list;   // host copy of the ring list (corahip_sht_plan_ring_classes)
     };
     std::vector<ring_class> classes;
 };
@@ -534,17 +537,17 @@ int sht_legendre_pol(corahip_ctx *ctx, corahip_sht_plan *p, int ncols, const dou
 // K5: F_m cells -> maps for nnu_valid channels (nnu_chunk_pad = channels in the cell layout)
 int sht_ringfft(corahip_ctx *ctx, const corahip_sht_plan *p, const double *inter, int nnu_chunk_pad, int nnu_valid,
                 double *maps);
-// K5 with compile-time transform shapes (sht_ringfft_ct.hip): returns 1 if it launched class c, 0 if the generic
-// kernel has to take it, < 0 or a hipError on failure
+// K5 with compile-time transform shapes (sht_ringfft_ct.hip): *took = it launched class c (false: the generic kernel
+// has to take it); the return value is the error status only (0, CORAHIP_E* or a hipError_t)
 int sht_ringfft_ct(corahip_ctx *ctx, const corahip_sht_plan *p, const corahip_sht_plan::ring_class &c, const double *inter,
-                   int G, int nnu, double *maps);
+                   int G, int nnu, double *maps, bool *took);
 // plan time: filters of the 3 * 2^k Bluestein lengths (fills p->d_bfilt3; h_blu3_P / d_blu3_foff / d_bchirp must be set)
 int sht_blu3_tables(corahip_ctx *ctx, corahip_sht_plan *p, int64_t total);
 // creates ctx->stream2 and the fork / join events on first use
 int sht_second_stream(corahip_ctx *ctx);
-// belt + largest Bluestein class side by side on two streams (sht_ringfft_ct.hip): 1 = both launched
+// belt + largest Bluestein class side by side on two streams (sht_ringfft_ct.hip): *took = both launched
 int sht_ringfft_ct_pair(corahip_ctx *ctx, const corahip_sht_plan *p, const corahip_sht_plan::ring_class &belt,
-                        const corahip_sht_plan::ring_class &cap, const double *inter, int G, int nnu, double *maps);
+                        const corahip_sht_plan::ring_class &cap, const double *inter, int G, int nnu, double *maps, bool *took);
 // K5^T: maps -> weighted G_m cells for nnu_pad8 channels (nnu present in `maps`)
 int sht_ringana(corahip_ctx *ctx, const corahip_sht_plan *p, const double *maps, int nnu, int nnu_pad8,
                 const double *ring_w, double *inter);

@@ -37,7 +37,9 @@ __device__ static inline void scaled_pow(double s, int n, double &mant, int &ex)
 // that reaches it; K4 neither writes nor K5 reads the F_m cells beyond the per-ring cut-off it implies).  2^-80 =
 // 8.3e-25: the sum of all 2e6 dropped terms of a channel stays below 2e-18 of an O(1) coefficient, two decades
 // under fp64 rounding; libsharp (the engine behind healpy.alm2map) truncates at m > lmax sin(theta) + max(100, lmax / 100),
-// which corresponds to about 2^-70 at lmax = 2048, i.e. is LOOSER.  The first version used 2^-900 ("exactly zero"):
+// which corresponds to about 2^-70 at lmax = 2048, i.e. is LOOSER.  The exponent is a PLAN parameter
+// (corahip_sht_plan_create_ex, default SEED_MIN_EXP): the error of a pixel is bounded by sum_lm |a_lm| 2^cut, so a
+// caller with a_lm of extreme dynamic range lowers it (-900 = the oracle's "exactly zero").  The first version used 2^-900:
 // with it the rings 513..1023 of nside 1024 kept lmax + 1 > h + 1 cells, so their ring FFT took the aliased
 // (LDS-atomic) fold and read 20-45 % more cells; 2^-120 followed (K4 66.2 -> 58.3 ms), 2^-80 took another 1.1 ms off
 // K4 (56.4 -> 55.3 ms at cfg 3) with no change in any printed digit of the full-size comparisons.  The oracle keeps 2^-900.
@@ -45,9 +47,9 @@ __device__ static inline void scaled_pow(double s, int n, double &mant, int &ex)
 #define SEED_MIN_EXP (-80)
 #endif
 
-// lstart[m][r]: first l at which |lambda_lm(ring r)| >= 2^SEED_MIN_EXP, with the two
-// recurrence values there; terms below are < 1e-270 and are dropped (libsharp does the same).
-__global__ void seed_kernel(int lmax, int npair, const double *__restrict__ z, const double *__restrict__ sth,
+// lstart[m][r]: first l at which |lambda_lm(ring r)| >= 2^min_exp (the plan's cut, default SEED_MIN_EXP = -80), with
+// the two recurrence values there; terms below (< 8.3e-25 at the default) are dropped (libsharp does the same).
+__global__ void seed_kernel(int lmax, int npair, int min_exp, const double *__restrict__ z, const double *__restrict__ sth,
                             const double *__restrict__ pref, const double2 *__restrict__ coef,
                             int32_t *__restrict__ lstart, double2 *__restrict__ seed) {
     int r = blockIdx.x * blockDim.x + threadIdx.x;
@@ -62,7 +64,7 @@ __global__ void seed_kernel(int lmax, int npair, const double *__restrict__ z, c
     int sc = pe + t;
     if (m & 1) mant = -mant;
     long o = (long)m * npair + r;
-    if (sc >= SEED_MIN_EXP) {
+    if (sc >= min_exp) {
         lstart[o] = m;
         seed[o] = make_double2(0.0, ldexp(mant, sc));
         return;
@@ -81,7 +83,7 @@ __global__ void seed_kernel(int lmax, int npair, const double *__restrict__ z, c
             p1 *= 0x1p-100;
             sc += 100;
         }
-        if (p1 != 0.0 && sc + ilogb(p1) >= SEED_MIN_EXP) {
+        if (p1 != 0.0 && sc + ilogb(p1) >= min_exp) {
             found = l;
             s0 = ldexp(p0, sc);
             s1 = ldexp(p1, sc);
@@ -113,7 +115,7 @@ __global__ void lambda_kernel(int lmax, int npair, int m, int r, const double *_
         out[l - m] = v;
     }
 }
-// per ring: mcut = number of m (from 0) whose lambda_lm reach 2^SEED_MIN_EXP for some l <= lmax; F_m of the ring
+// per ring: mcut = number of m (from 0) whose lambda_lm reach the plan's cut for some l <= lmax; F_m of the ring
 // is exactly zero beyond (lstart is monotone in m), so K4 need not write and K5 need not read those cells
 __global__ void mcut_kernel(int lmax, int npair, int nring, const int32_t *__restrict__ lstart,
                             int32_t *__restrict__ mcut) {
@@ -134,6 +136,47 @@ __global__ void lmin_kernel(int lmax, int npair, int ntile, const int32_t *__res
     int v = lmax + 1;
     for (int r = t * LMIN_RINGS; r < min((t + 1) * LMIN_RINGS, npair); r++) v = min(v, lstart[(long)m * npair + r]);
     lmin_tab[m * ntile + t] = v;
+}
+// FP64 MFMA instructions legendre_kernel<NT, RT> ISSUES for one column group, summed over (m, ring tile, wave): the
+// kernel's own skip logic restated (sht_legendre.hip / leg_stage_body.inc) - an item starts at
+// l_begin = m + ((lmin - m) & ~7) with lmin the tile's first contributing l; wave w of the workgroup owns the rings
+// tile * 128 RT + 8 j + w (j < 16 RT) and executes the 2 NT RT MFMAs of the macro-step at l0 = l_begin + 8 k iff
+// l0 <= lmax and ws_min <= l0 + 7 (ws_min = first contributing l of the wave's rings).  Thread = (m, tile, wave);
+// out accumulates the number of executed macro-steps.  The count is what SQ_INSTS_VALU_MFMA_F64 reads for the
+// launch (tests/test_gpu_fullsize.py checks it against the committed PMC profile): the roofline fraction of K4 is
+// priced on it, not on the algorithmic 8 nside nalm F of SURVEY 8(d), which counts terms nobody has to compute.
+__global__ void k4_count_kernel(int lmax, int npair, int rt, const int32_t *__restrict__ lstart,
+                                const int32_t *__restrict__ lmin_tab, unsigned long long *__restrict__ out) {
+    const int trings = LEG_RINGS * rt;
+    const int ntile = (npair + trings - 1) / trings;
+    const int ntile128 = (npair + LMIN_RINGS - 1) / LMIN_RINGS;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = (long)(lmax + 1) * ntile * LEG_WAVES;
+    unsigned long long n = 0;
+    if (idx < total) {
+        const int wave = (int)(idx % LEG_WAVES);
+        const int tile = (int)((idx / LEG_WAVES) % ntile);
+        const int m = (int)(idx / ((long)LEG_WAVES * ntile));
+        int lmin = lmax + 1;
+        const int t_first = (tile * trings) / LMIN_RINGS;
+        const int t_last = min((tile * trings + trings - 1) / LMIN_RINGS, ntile128 - 1);
+        for (int t = t_first; t <= t_last; t++) lmin = min(lmin, lmin_tab[m * ntile128 + t]);
+        if (lmin <= lmax) {
+            int ws_min = lmax + 1;
+            for (int j = 0; j < 16 * rt; j++) {
+                const int ring = tile * trings + j * LEG_WAVES + wave;
+                if (ring < npair) ws_min = min(ws_min, lstart[(long)m * npair + ring]);
+            }
+            const int l_begin = m + ((lmin - m) & ~7);
+            const int k_max = (lmax - l_begin) / 8;
+            const int need = ws_min - 7 - l_begin;                 // l0 >= ws_min - 7
+            const int k_min = need > 0 ? (need + 7) / 8 : 0;
+            if (k_max >= k_min) n = (unsigned long long)(k_max - k_min + 1);
+        }
+    }
+    // wave-level sum, one atomic per wave
+    for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o);
+    if ((threadIdx.x & 63) == 0 && n) atomicAdd(out, n);
 }
 // Bluestein tables for cap ring i (h = 2i not a power of two): chirp b_j = e^{i pi j^2/h}, j < h,
 // and filt = FFT_P(conj chirp wrapped), stored in the digit-reversed order fft_dif produces.
@@ -212,9 +255,47 @@ int corahip_sht_plan_destroy(corahip_ctx *ctx, corahip_sht_plan *p) {
 }
 
 int corahip_sht_plan_create(corahip_ctx *ctx, int nside, int lmax, corahip_sht_plan **out) {
+    return corahip_sht_plan_create_ex(ctx, nside, lmax, 0, out);
+}
+
+int corahip_sht_plan_cut_exp(const corahip_sht_plan *p, int *cut_exp) {
+    ARG_CHECK(p != nullptr && cut_exp != nullptr);
+    *cut_exp = p->cut_exp;
+    return 0;
+}
+
+int corahip_sht_plan_k4_mfma_count(corahip_ctx *ctx, const corahip_sht_plan *p, int nnu, uint64_t *mfma_instructions) {
+    ARG_CHECK(ctx != nullptr && p != nullptr && mfma_instructions != nullptr && nnu >= 1);
+    // the launch shape sht_legendre picks for this many channels (16-column tiles: 8 channels x re/im)
+    const int ncols = 2 * nnu_pad_of(nnu);
+    const int nt16 = ncols / 16;
+    const int NT = nt16 % 8 == 0 ? 8 : (nt16 % 4 == 0 ? 4 : (nt16 % 2 == 0 ? 2 : 1));
+    const int RT = NT == 8 ? 1 : 2;
+    auto it = p->k4_macro_steps.find(RT);
+    if (it == p->k4_macro_steps.end()) {
+        HIP_TRY(hipSetDevice(ctx->device));
+        unsigned long long *d_n = nullptr, h_n = 0;
+        HIP_TRY(hipMalloc((void **)&d_n, sizeof(h_n)));
+        HIP_TRY(hipMemsetAsync(d_n, 0, sizeof(h_n), ctx->stream));
+        const int ntile = (p->npair + LEG_RINGS * RT - 1) / (LEG_RINGS * RT);
+        const long total = (long)p->L * ntile * LEG_WAVES;
+        k4_count_kernel<<<(unsigned)((total + 255) / 256), 256, 0, ctx->stream>>>(p->lmax, p->npair, RT, p->d_lstart, p->d_lmin, d_n);
+        LAUNCH_CHECK();
+        HIP_TRY(hipMemcpyAsync(&h_n, d_n, sizeof(h_n), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        (void)hipFree(d_n);
+        it = const_cast<corahip_sht_plan *>(p)->k4_macro_steps.emplace(RT, (uint64_t)h_n).first;
+    }
+    *mfma_instructions = it->second * (uint64_t)(2 * NT * RT) * (uint64_t)(ncols / (16 * NT));
+    return 0;
+}
+
+int corahip_sht_plan_create_ex(corahip_ctx *ctx, int nside, int lmax, int cut_exp, corahip_sht_plan **out) {
     ARG_CHECK(ctx != nullptr && out != nullptr);
     ARG_CHECK(nside >= 1 && is_pow2(nside) && nside <= 8192);
     ARG_CHECK(lmax >= 0 && lmax <= 16384);
+    ARG_CHECK(cut_exp <= 0 && cut_exp >= -1000);
+    if (cut_exp == 0) cut_exp = SEED_MIN_EXP;
     HIP_TRY(hipSetDevice(ctx->device));
     corahip_sht_plan *p = new corahip_sht_plan();
     // every early return below (HIP_TRY / rc checks) releases what was allocated so far
@@ -226,6 +307,7 @@ int corahip_sht_plan_create(corahip_ctx *ctx, int nside, int lmax, corahip_sht_p
     } guard{p};
     p->nside = nside;
     p->lmax = lmax;
+    p->cut_exp = cut_exp;
     p->L = lmax + 1;
     p->npair = 2 * nside;
     p->nring = 4 * nside - 1;
@@ -314,7 +396,7 @@ int corahip_sht_plan_create(corahip_ctx *ctx, int nside, int lmax, corahip_sht_p
     HIP_TRY(hipMalloc((void **)&p->d_seed, sizeof(double2) * (size_t)p->L * p->npair));
     {
         dim3 grid((p->npair + 63) / 64, p->L);
-        seed_kernel<<<grid, 64, 0, s>>>(lmax, p->npair, p->d_z, p->d_sth, d_pref, p->d_coef, p->d_lstart, p->d_seed);
+        seed_kernel<<<grid, 64, 0, s>>>(lmax, p->npair, cut_exp, p->d_z, p->d_sth, d_pref, p->d_coef, p->d_lstart, p->d_seed);
         LAUNCH_CHECK();
     }
     {
@@ -441,6 +523,7 @@ int corahip_sht_plan_create(corahip_ctx *ctx, int nside, int lmax, corahip_sht_p
             // P = 256 0.19 -> 0.05 ms, K5 -0.5 ms at cfg 3).
             if (c.P > 0 && c.P <= 512) c.threads = c.P >= 512 ? 128 : 64;
             c.count = (int)kv.second.size();
+            c.h_list = kv.second;
             if ((rc = dev_upload(&c.d_list, kv.second, s))) return rc;
             p->classes.push_back(c);
         }
@@ -460,6 +543,13 @@ int corahip_sht_plan_rings(const corahip_sht_plan *p, int64_t *host_start, int32
         if (host_z) host_z[r] = p->h_z[r];
         if (host_phi0) host_phi0[r] = p->h_phi0[r];
     }
+    return 0;
+}
+
+int corahip_sht_plan_ring_classes(const corahip_sht_plan *p, int32_t *host_len) {
+    ARG_CHECK(p != nullptr && host_len != nullptr);
+    for (const auto &c : p->classes)
+        for (int32_t r : c.h_list) host_len[r] = c.P3 ? c.P3 : c.P;   // (the 3 * 2^k kernels take the classes that admit them)
     return 0;
 }
 

@@ -498,10 +498,10 @@ int sht_ringfft(corahip_ctx *ctx, const corahip_sht_plan *p, const double *inter
             if (c.P == 0 && c.N > 0) pb = &c;
             if (c.P == 4096) pc = &c;
         }
-        int paired = 0;
+        bool paired = false;
         if (pb && pc && !class_times) {
-            paired = sht_ringfft_ct_pair(ctx, p, *pb, *pc, inter, G, nnu_valid, maps);
-            if (paired < 0 || paired > 1) return paired;
+            const int rcp = sht_ringfft_ct_pair(ctx, p, *pb, *pc, inter, G, nnu_valid, maps, &paired);
+            if (rcp) return rcp;
         }
         // The class launches alternate between two streams: every class is a persistent grid that fills the chip, so the
         // two kernels in flight run one after the other EXCEPT for their tails - the workgroups of the next class start on
@@ -531,11 +531,9 @@ int sht_ringfft(corahip_ctx *ctx, const corahip_sht_plan *p, const double *inter
                 (void)hipEventCreate(&ce1);
                 (void)hipEventRecord(ce0, ctx->stream);
             }
-            const int took = sht_ringfft_ct(ctx, p, c, inter, G, nnu_valid, maps);   // compile-time kernel for this class?
-            if (took < 0 || took > 1) {
-                ctx->stream = main_stream;
-                return took;
-            }
+            bool took = false;   // compile-time kernel for this class?
+            const int rct = sht_ringfft_ct(ctx, p, c, inter, G, nnu_valid, maps, &took);
+            if (rct) return rct;   // (Restore puts the caller's stream back)
             const size_t shm = sizeof(double2) * ((size_t)c.nch * c.bstride + TWL_ENTRIES(p->pmax));
             const long nitems = (long)c.count * ((nnu_valid + c.nch - 1) / c.nch);
             const int per_cu = std::max<int>(1, (int)((160 * 1024) / std::max<size_t>(shm, 1)));

@@ -717,10 +717,13 @@ static int launch_blu(corahip_ctx *ctx, hipStream_t stream, int wg_per_cu, const
     return 0;
 }
 
-// returns 1 if the class was launched here, 0 if the generic kernel has to take it, < 0 / hipError on failure
+// *took = true if the class was launched here, false if the generic kernel has to take it; the return value is the
+// error status only (0 = OK, CORAHIP_E* < 0 or a positive hipError_t): hipErrorInvalidValue is 1, so "launched" must
+// never share the int with the status
 int sht_ringfft_ct(corahip_ctx *ctx, const corahip_sht_plan *p, const corahip_sht_plan::ring_class &c, const double *inter,
-                   int G, int nnu, double *maps) {
+                   int G, int nnu, double *maps, bool *took) {
     static const bool off = getenv("CORAHIP_K5_GENERIC") != nullptr;   // diagnostics: force the generic kernel
+    *took = false;
     if (off) return 0;
     int rc = -1;
     hipStream_t st = ctx->stream;
@@ -740,7 +743,9 @@ int sht_ringfft_ct(corahip_ctx *ctx, const corahip_sht_plan *p, const corahip_sh
         else if (c.P == 1024) rc = launch_blu<1024, 4, 2, 256>(ctx, st, 0, p, c, inter, G, nnu, maps);   // (256 threads, two workgroups per CU: 0.61 -> 0.54 ms)
         else return 0;
     }
-    return rc ? rc : 1;
+    if (rc) return rc;
+    *took = true;
+    return 0;
 }
 
 int sht_second_stream(corahip_ctx *ctx) {
@@ -755,10 +760,11 @@ int sht_second_stream(corahip_ctx *ctx) {
 // The belt (HBM-bound: 2/3 of the pixels, little arithmetic) and the largest Bluestein class (LDS / FP64-bound, a third
 // of the traffic) run CONCURRENTLY: each as 256-thread workgroups with half the channels per item (78 KB of LDS), one
 // workgroup of each kernel per CU, launched on two streams - the compute-bound items of one kernel fill the memory
-// stalls of the other on every CU.  Returns 1 if it launched both classes (the caller then skips them), 0 if not
-// applicable.
+// stalls of the other on every CU.  *took = true if it launched both classes (the caller then skips them); the return
+// value is the error status only.
 int sht_ringfft_ct_pair(corahip_ctx *ctx, const corahip_sht_plan *p, const corahip_sht_plan::ring_class &belt,
-                        const corahip_sht_plan::ring_class &cap, const double *inter, int G, int nnu, double *maps) {
+                        const corahip_sht_plan::ring_class &cap, const double *inter, int G, int nnu, double *maps, bool *took) {
+    *took = false;
     // Measured at cfg 3 (one box, A/B): 18.6 ms paired against 17.0 ms with the two classes one after the other at
     // full width - the half-width kernels lose more per item than the overlap returns - so the pairing is OFF unless
     // CORAHIP_K5_PAIR is set; kept for the record and for other shapes.
@@ -774,7 +780,8 @@ int sht_ringfft_ct_pair(corahip_ctx *ctx, const corahip_sht_plan *p, const corah
     if (rc) return rc;
     HIP_TRY(hipEventRecord(ctx->ev_join, ctx->stream2));
     HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
-    return 1;
+    *took = true;
+    return 0;
 }
 
 // ------------------------------------------------------------------------------------

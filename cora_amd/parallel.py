@@ -62,6 +62,25 @@ def allgather_factors(T_local, info_local, plan):
     return T_all[: plan.L], i_all[: plan.L]
 
 
+def allgather_channels(shard, F):
+    """Channel shards [nnu_r, ...] of all ranks (the axis-0 split of :func:`shard_plan`, uneven when F % world != 0) ->
+    the full [F, ...] tensor on every rank (the reference's ``alm_array.allgather()``, cora/core/skysim.py:123-125)."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size()
+    nmax = (F + world - 1) // world
+    pad = torch.zeros((nmax,) + tuple(shard.shape[1:]), dtype=shard.dtype, device=shard.device)
+    pad[: shard.shape[0]].copy_(shard)
+    full = torch.empty((world * nmax,) + tuple(shard.shape[1:]), dtype=shard.dtype, device=shard.device)
+    dist.all_gather_into_tensor(full, pad)
+    parts = []
+    for r in range(world):
+        sp = shard_plan(1, F, r, world)
+        parts.append(full[r * nmax : r * nmax + sp.nnu])
+    return torch.cat(parts, dim=0)
+
+
 def _all_to_all(send, world):
     """send [world, ...] -> recv [world, ...] (slab q goes to rank q).  RCCL all_to_all_single; backends
     without it for device tensors (gloo, used by the single-GPU test hooks) go through an all-gather."""

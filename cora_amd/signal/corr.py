@@ -221,7 +221,10 @@ class RedshiftCorrelation(object):
         norm = self.kparmax / (2 * self.nkpar)
         for t in (dd, dv, vv):
             ctx.dct1_rows(t, norm)
-        self._dev_tables = {ctx.device.index: (dd, dv, vv)}
+        # (the other devices' copies stay: a second context must not evict the first one's tables)
+        if getattr(self, "_dev_tables", None) is None:
+            self._dev_tables = {}
+        self._dev_tables[ctx.device.index] = (dd, dv, vv)
         self._host_tables = None
         self._aps_cache = True
 
@@ -233,9 +236,21 @@ class RedshiftCorrelation(object):
             self._host_tables = tuple(t.cpu().numpy() for t in dev)
         return self._host_tables[i]
 
-    _aps_dd = property(lambda self: self._host_copy(0))
-    _aps_dv = property(lambda self: self._host_copy(1))
-    _aps_vv = property(lambda self: self._host_copy(2))
+    def _set_host_table(self, i, value):
+        """Assigning a table (what the reference's load_fft_cache does, corr.py:879-887, and user subclasses may):
+        it becomes the host copy; the device copies are dropped and re-uploaded on next use."""
+        cur = list(self._host_tables) if getattr(self, "_host_tables", None) is not None else (
+            [self._host_copy(k) if k != i else None for k in range(3)] if self._aps_cache else [None, None, None])
+        cur[i] = np.ascontiguousarray(value, dtype=np.float64)
+        self._host_tables = tuple(cur)
+        self._dev_tables = {}
+        if all(t is not None for t in cur):
+            self.nkperp, self.nkpar = cur[0].shape
+            self._aps_cache = True
+
+    _aps_dd = property(lambda self: self._host_copy(0), lambda self, v: self._set_host_table(0, v))
+    _aps_dv = property(lambda self: self._host_copy(1), lambda self, v: self._set_host_table(1, v))
+    _aps_vv = property(lambda self: self._host_copy(2), lambda self, v: self._set_host_table(2, v))
 
     def save_fft_cache(self, fname):
         """Save the three lookup tables (corr.py:870-877)."""
@@ -252,8 +267,12 @@ class RedshiftCorrelation(object):
     def _tables_on(self, ctx):
         key = ctx.device.index
         if key not in self._dev_tables:
-            if self._aps_cache and getattr(self, "_host_tables", None) is not None:
-                self._dev_tables[key] = tuple(ctx.to_device(t) for t in self._host_tables)   # loaded cache / other GPU
+            ht = getattr(self, "_host_tables", None)
+            if self._aps_cache and ht is not None and all(t is not None for t in ht):
+                self._dev_tables[key] = tuple(ctx.to_device(t) for t in ht)   # loaded cache
+            elif self._aps_cache and self._dev_tables:
+                src = next(iter(self._dev_tables.values()))                   # another GPU holds them: device-to-device
+                self._dev_tables[key] = tuple(t.to(ctx.device) for t in src)
             else:
                 self._build_tables(ctx)
         return self._dev_tables[key]

@@ -167,7 +167,19 @@ int corahip_alm_packed_to_dev(corahip_ctx *ctx, const double *packed, int lmax, 
  * Replaces hputil.sphtrans_inv_sky / sphtrans_inv_real -> healpy.alm2map
  * (cora/util/hputil.py:369-391,500-531) for nnu channels at once.                   */
 int corahip_sht_plan_create(corahip_ctx *ctx, int nside, int lmax, corahip_sht_plan **plan);
+/* ... with the truncation of the Legendre sums as a parameter: terms with |lambda_lm(theta)| < 2^cut_exp are dropped
+ * (-1000 <= cut_exp < 0; 0 = the default, -80).  The error this leaves in a pixel is bounded by
+ * 2 sum_lm |a_lm| 2^cut_exp (1.7e-24 per unit coefficient at the default; libsharp, the engine behind
+ * healpy.alm2map - cora/util/hputil.py:388-391 - cuts at about 2^-70 for lmax = 2048): lower it for a_lm whose
+ * dynamic range exceeds ~1e13; -900 keeps every term fp64 can represent (what the oracle does). */
+int corahip_sht_plan_create_ex(corahip_ctx *ctx, int nside, int lmax, int cut_exp, corahip_sht_plan **plan);
+int corahip_sht_plan_cut_exp(const corahip_sht_plan *plan, int *cut_exp);
 int corahip_sht_plan_destroy(corahip_ctx *ctx, corahip_sht_plan *plan);
+/* number of v_mfma_f64_16x16x4_f64 instructions (2048 flop each) the Legendre kernel of corahip_alm2map ISSUES
+ * for one pass over nnu channels with this plan - computed from the plan's first-contributing-l tables, i.e. what
+ * the SQ_INSTS_VALU_MFMA_F64 counter reads for the launch.  bench.py prices K4's roofline fraction on it. */
+int corahip_sht_plan_k4_mfma_count(corahip_ctx *ctx, const corahip_sht_plan *plan, int nnu,
+                                   uint64_t *mfma_instructions);
 /* bytes of scratch alm2map needs to process `nnu` channels in one pass */
 int corahip_alm2map_workspace_bytes(const corahip_sht_plan *plan, int nnu, size_t *bytes);
 /* alm_dev [nalm][nnu_pad/4][2][4] -> maps [nnu, 12 nside^2] RING order.
@@ -287,6 +299,10 @@ int corahip_raytrace_slices(corahip_ctx *ctx, const double *cube, int n0, int n1
 /* ring geometry of the plan (host arrays of length 4 nside - 1), for tests */
 int corahip_sht_plan_rings(const corahip_sht_plan *plan, int64_t *host_start, int32_t *host_nphi,
                            double *host_z, double *host_phi0);
+/* ring-FFT class of every ring (host array of length 4 nside - 1), for tests and per-class reports: 0 = direct
+ * transform (belt, power-of-two cap rings), else the Bluestein length the synthesis kernel of that ring runs
+ * (a power of two, or 3 * 2^k for the rings whose 2 h - 1 fits it) */
+int corahip_sht_plan_ring_classes(const corahip_sht_plan *plan, int32_t *host_len);
 /* normalised associated Legendre values lambda_lm(cos theta_ring) the synthesis uses
  * (device recurrence incl. the polar seed table), l = m..lmax -> out [lmax-m+1] (device) */
 int corahip_sht_lambda(corahip_ctx *ctx, const corahip_sht_plan *plan, int m, int ring_pair, double *out);

@@ -13,30 +13,32 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def _ring_classes(nside):
-    """K5 transform class of every ring (0-based, north to south): 0 = direct power-of-two transform (belt and
-    the cap rings with 4i a power of two), else the Bluestein length (next power of two >= 2 h - 1, h = 2 i)."""
-    nring = 4 * nside - 1
-    cls = np.zeros(nring, dtype=np.int64)
-    for r in range(nring):
+def _ring_classes(nside, lmax):
+    """K5 transform class of every ring (0-based, north to south) AS THE PLAN LAUNCHES IT
+    (corahip_sht_plan_ring_classes): 0 = direct transform (belt and the cap rings with 4i a power of two), else the
+    Bluestein length of the kernel that takes the ring - a power of two >= 2 h - 1 (h = 2 i) or, for the rings whose
+    2 h - 1 fits it, 3 * 2^k (ringfft_blu_ct<3072> / <1536>)."""
+    from cora_amd import _lib
+
+    cls = _lib.get_context().sht_ring_classes(nside, lmax).astype(np.int64)
+    # the plan's classes against the rule they implement
+    for r in range(4 * nside - 1):
         i = r + 1
         icap = i if i < nside else (4 * nside - i if i > 3 * nside else 0)
-        if icap:
-            h = 2 * icap
-            if h & (h - 1):
-                P = 1
-                while P < 2 * h - 1:
-                    P *= 2
-                cls[r] = P
+        h = 2 * icap
+        if icap == 0 or h & (h - 1) == 0:
+            assert cls[r] == 0, (r, cls[r])
+        else:
+            assert cls[r] >= 2 * h - 1 and (cls[r] & (cls[r] - 1) == 0 or (cls[r] % 3 == 0 and cls[r] // 3 & (cls[r] // 3 - 1) == 0)), (r, cls[r])
     return cls
 
 
-def _per_class_error(dev_map, ref, nside, skip_polar=0):
+def _per_class_error(dev_map, ref, nside, lmax, skip_polar=0):
     """max |dev - ref| / rms(ref) per ring-FFT class -> dict {class: err}."""
     from oracle import healpix
 
     ri = healpix.ring_info(nside)
-    cls = _ring_classes(nside)
+    cls = _ring_classes(nside, lmax)
     rms = ref.std()
     d = np.abs(dev_map - ref)
     out = {}
@@ -88,13 +90,15 @@ def test_cfg3_alm2map_pixel_parity_256_channel_launch(ctx):
     worst = {}
     for f in (0, 129, 130, 255):
         ref = sht.alm2map(_packed_of(alm, f), nside, lmax)
-        err = _per_class_error(maps[f].cpu().numpy(), ref, nside)
+        err = _per_class_error(maps[f].cpu().numpy(), ref, nside, lmax)
         for c, e in err.items():
             worst[c] = max(worst.get(c, 0.0), e)
     del maps, alm
     torch.cuda.empty_cache()
     print("cfg3 alm2map max|err|/rms per class (0 = direct, else Bluestein P):", worst)
-    assert set(worst) >= {0, 2048, 4096}, worst
+    # every kernel class of the cfg-3 step must have been compared: belt + power-of-two caps (0), ringfft_blu_ct of
+    # the lengths 4096, 3072, 2048, 1536, 1024 and the run-time kernel's short classes
+    assert set(worst) >= {0, 1024, 1536, 2048, 3072, 4096}, worst
     assert max(worst.values()) <= 1e-11, worst
 
 
@@ -111,7 +115,7 @@ def test_cfg5_alm2map_pixel_parity(ctx):
     worst = {}
     for f in (0, 5):
         ref = sht.alm2map(_packed_of(alm, f), nside, lmax)
-        for c, e in _per_class_error(maps[f].cpu().numpy(), ref, nside).items():
+        for c, e in _per_class_error(maps[f].cpu().numpy(), ref, nside, lmax).items():
             worst[c] = max(worst.get(c, 0.0), e)
     del maps, alm
     torch.cuda.empty_cache()
@@ -163,7 +167,7 @@ def test_cfg3_alm2map_spin2_pixel_parity(ctx):
     for f in (0, nf - 1):
         q, u = sht.alm2map_spin2(_packed_of(alm, 2 * f), _packed_of(alm, 2 * f + 1), nside, lmax)
         for name, ref, dev in (("Q", q, maps[2 * f]), ("U", u, maps[2 * f + 1])):
-            for c, e in _per_class_error(dev.cpu().numpy(), ref, nside, skip_polar=8).items():
+            for c, e in _per_class_error(dev.cpu().numpy(), ref, nside, lmax, skip_polar=8).items():
                 worst[c] = max(worst.get(c, 0.0), e)
     del maps, alm
     torch.cuda.empty_cache()
@@ -300,7 +304,7 @@ def test_default_lmax_aliased_rings_pixel_parity(ctx):
     worst = {}
     for f in (0, 6):
         ref = sht.alm2map(_packed_of(alm, f), nside, lmax)
-        for c, e in _per_class_error(maps[f].cpu().numpy(), ref, nside).items():
+        for c, e in _per_class_error(maps[f].cpu().numpy(), ref, nside, lmax).items():
             worst[c] = max(worst.get(c, 0.0), e)
     del maps, alm
     torch.cuda.empty_cache()
@@ -308,12 +312,15 @@ def test_default_lmax_aliased_rings_pixel_parity(ctx):
     assert max(worst.values()) <= 2e-11, worst
 
 
-@pytest.mark.parametrize("nside,lmax,nnu", [(1024, 700, 5), (1024, 1500, 8), (512, 1024, 12), (2048, 2048, 3)])
+@pytest.mark.parametrize("nside,lmax,nnu", [(1024, 700, 5), (1024, 1500, 8), (512, 1024, 12), (2048, 2048, 3),
+                                            (1024, 2048, 32), (1024, 2048, 16)])
 def test_compile_time_ring_kernels_other_shapes(ctx, nside, lmax, nnu):
     """The compile-time ring-FFT kernels away from lmax = 2 nside and from whole channel groups: short cell rows (the
     register prefetch window reaches past the row), ragged channel counts (3, 5, 12: padding lanes of the 4- and
     2-channel workgroups), nside 512 (Bluestein classes 2048 / 1536 / 1024 compile-time, belt run-time) and nside
-    2048 at lmax = nside.  First and last channel against the oracle, per class."""
+    2048 at lmax = nside.  (1024, 2048, 32) and (1024, 2048, 16) are what one rank of an 8- / 16-way frequency shard
+    of cfg 3 launches: legendre_kernel<4, 2> / <2, 2> (64 / 32 columns, two recurrences per lane) and the ring-FFT
+    grids of 8 / 4 channel groups.  First and last channel against the oracle, per class."""
     import torch
     from oracle import sht
 
@@ -324,9 +331,91 @@ def test_compile_time_ring_kernels_other_shapes(ctx, nside, lmax, nnu):
     worst = {}
     for f in (0, nnu - 1):
         ref = sht.alm2map(_packed_of(alm, f), nside, lmax)
-        for c, e in _per_class_error(maps[f].cpu().numpy(), ref, nside).items():
+        for c, e in _per_class_error(maps[f].cpu().numpy(), ref, nside, lmax).items():
             worst[c] = max(worst.get(c, 0.0), e)
     del maps, alm
     torch.cuda.empty_cache()
     print("nside %d lmax %d nnu %d: max|err|/rms per class: %s" % (nside, lmax, nnu, worst))
     assert max(worst.values()) <= 2e-11, worst
+
+
+# ------------------------------------------------------------------ (d): the executed-flop count behind roofline.frac
+def test_k4_mfma_count_matches_pmc_profile(ctx):
+    """bench.py prices K4's roofline on the FP64 MFMA instructions the launch ISSUES, counted at run time from the
+    plan's first-contributing-l tables (corahip_sht_plan_k4_mfma_count).  That count must be what the hardware
+    counter read for the same launch: SQ_INSTS_VALU_MFMA_F64 of legendre_kernel<8, 1> in the committed rocprofv3
+    --pmc profile of `bench.py` (cfg 3: nside 1024, lmax 2048, 256 channels), within 1 %."""
+    import json
+    import os
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pmc = None
+    for name in ("r03_pmc.json", "r02_pmc.json"):
+        f = os.path.join(root, "profiles", name)
+        if os.path.exists(f):
+            k = json.load(open(f))["kernels"]
+            pmc = next(v["SQ_INSTS_VALU_MFMA_F64_per_launch"] for n, v in k.items() if n.startswith("legendre_kernel<8, 1>"))
+            break
+    assert pmc, "no committed PMC profile with the K4 MFMA counter"
+    n = ctx.k4_mfma_count(1024, 2048, 256)
+    alg = 8.0 * 1024 * (2049 * 2050 // 2) * 256 / 2048.0       # SURVEY 8(d) count in MFMA instructions
+    print("K4 MFMA instructions per cfg-3 launch: plan %d, PMC %.0f (ratio %.4f); algorithmic %.4g -> executed share %.3f"
+          % (n, pmc, n / pmc, alg, n / alg))
+    assert abs(n / pmc - 1.0) <= 0.01, (n, pmc)
+    assert n < alg
+    # shard shapes: per-channel count is the same for the wide shape at any multiple of 64 channels, and the
+    # 64 / 32-column shapes (<4, 2>, <2, 2>: 256-ring tiles) execute a little more per channel
+    assert ctx.k4_mfma_count(1024, 2048, 64) * 4 == n
+    n32 = ctx.k4_mfma_count(1024, 2048, 32)
+    assert n / 8 <= n32 <= 1.1 * n / 8, (n32, n / 8)
+    # a plan without truncation executes (nearly) the algorithmic count
+    n900 = ctx.k4_mfma_count(1024, 2048, 256, cut_exp=-900)
+    print("cut 2^-900: %d MFMA instructions (%.3f of algorithmic)" % (n900, n900 / alg))
+    assert n < n900 <= 1.02 * alg
+
+
+def test_legendre_cut_is_a_plan_parameter(ctx):
+    """corahip_sht_plan_create_ex: the truncation exponent of the Legendre sums is chosen per plan.  With the cut
+    the oracle uses (2^-900) the device maps equal the oracle's to the digits the default plan (2^-80) gives - the
+    default drops nothing that matters for O(1) coefficients - and coefficients of extreme dynamic range, where
+    the documented bound sum |a_lm| 2^cut says the default is NOT enough, are reproduced only by the lower cut."""
+    from oracle import sht
+
+    nside, lmax, nnu = 256, 512, 8
+    nalm = (lmax + 1) * (lmax + 2) // 2
+    alm = _red_alm(ctx, (nalm, 2, 2, 4), lmax, 77)
+    ref = sht.alm2map(_packed_of(alm, 3), nside, lmax)
+    e80 = np.abs(ctx.alm2map(alm, nside, lmax, nnu)[3].cpu().numpy() - ref).max() / ref.std()
+    e900 = np.abs(ctx.alm2map(alm, nside, lmax, nnu, cut_exp=-900)[3].cpu().numpy() - ref).max() / ref.std()
+    print("nside 256 / lmax 512: max|err|/rms with cut 2^-80: %.2e, with 2^-900: %.2e" % (e80, e900))
+    assert e80 <= 1e-11 and e900 <= 1e-11
+    # one huge coefficient at high m next to an O(1) sky: on the polar rings lambda_lm of that mode is below 2^-80
+    # but 1e40 x it is not negligible - the bound sum |a_lm| 2^cut = 1e40 x 8e-25 tells the caller so
+    m0 = 500
+    idx = m0 * (2 * lmax + 1 - m0) // 2 + lmax
+    alm2 = alm.clone()
+    alm2[idx, 0, 0, 3] = 1e40
+    ref2 = sht.alm2map(_packed_of(alm2, 3), nside, lmax)
+    from oracle import healpix
+
+    start = healpix.ring_info(nside)["start"].astype(np.int64)
+    ring_of = lambda x: np.maximum.reduceat(x, start)            # noqa: E731  (per-ring maximum)
+    rmax = ring_of(np.abs(ref2))
+    d80 = np.abs(ctx.alm2map(alm2, nside, lmax, nnu)[3].cpu().numpy() - ref2)
+    d900 = np.abs(ctx.alm2map(alm2, nside, lmax, nnu, cut_exp=-900)[3].cpu().numpy() - ref2)
+    rel80, rel900 = (ring_of(d80) / rmax).max(), (ring_of(d900) / rmax).max()
+    bound = 2.0 * 1e40 * 2.0**-80                                # 2 sum |a_lm| 2^cut (c_m = 2 for m > 0)
+    print("1e40 coefficient: worst ring error / ring max with cut 2^-80: %.2e, with 2^-900: %.2e; max abs error of the "
+          "default plan on the rings it truncates %.3e <= bound %.3e" % (rel80, rel900, ring_of(d80)[ring_of(d80) > 1e-6 * rmax].max(), bound))
+    assert rel900 <= 1e-7, rel900                    # (l^2 eps of the recurrence relative to the ring's own scale)
+    assert rel80 >= 1e-3, rel80                      # the default cut visibly drops the mode where it is < 2^-80 ...
+    assert np.all(ring_of(d80) <= bound * 1.01 + 1e-7 * rmax)     # ... and never more than the documented bound
+    cut = ctypes_int()
+    assert ctx.lib.corahip_sht_plan_cut_exp(ctx.sht_plan(nside, lmax, -900), cut) == 0 and cut.value == -900
+    assert ctx.lib.corahip_sht_plan_cut_exp(ctx.sht_plan(nside, lmax), cut) == 0 and cut.value == -80
+
+
+def ctypes_int():
+    import ctypes
+
+    return ctypes.c_int()

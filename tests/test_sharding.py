@@ -103,3 +103,41 @@ def test_all_to_all_exchanges_gloo_world2():
     for p in procs:
         p.join(timeout=60)
     assert sorted(res) == [(0, True), (1, True)]
+
+
+def _worker_chan(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+
+    sys.path.insert(0, ROOT)
+    from cora_amd.parallel import allgather_channels, shard_plan
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ok = True
+    for F in (8, 7, 2):                      # even split, uneven split, fewer channels than... ranks + 0 (world 3: one empty)
+        full = torch.arange(F * 1 * 3 * 3, dtype=torch.float64).reshape(F, 1, 3, 3)
+        p = shard_plan(5, F, rank, world)
+        got = allgather_channels(full[p.nu0:p.nu0 + p.nnu].clone(), F)
+        ok = ok and bool(torch.equal(got, full))
+    q.put((rank, ok))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_allgather_channels_gloo(world):
+    """alms=True on the l-distributed path returns the full a_lm array on every rank (cora/core/skysim.py:123-125):
+    channel shards of uneven length are padded, all-gathered and re-assembled."""
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + os.getpid() % 2000 + world
+    procs = [ctx.Process(target=_worker_chan, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(r, True) for r in range(world)]
