@@ -50,6 +50,9 @@ SIGNATURES = {
     "corahip_draw_alm_philox": (c_int, [c_void_p, PTR, PTR, c_u64, c_int, c_int, c_int, c_int, PTR]),
     "corahip_draw_alm_philox_rows": (c_int, [c_void_p, PTR, PTR, c_u64, c_int, c_int, c_int, c_int, PTR]),
     "corahip_draw_alm": (c_int, [c_void_p, PTR, PTR, PTR, c_int, c_int, c_int, c_int, PTR]),
+    "corahip_shard_plan": (c_int, [c_int, c_int, c_int, c_int, PTR]),
+    "corahip_factor_rows_pack": (c_int, [c_void_p, PTR, c_int, c_int, c_int, c_int, PTR]),
+    "corahip_factor_rows_unpack": (c_int, [c_void_p, PTR, PTR, c_int, c_int, c_int, c_int, PTR]),
     "corahip_alm_dev_to_square": (c_int, [c_void_p, PTR, c_int, c_int, PTR]),
     "corahip_alm_packed_to_dev": (c_int, [c_void_p, PTR, c_int, c_int, PTR]),
     "corahip_sht_plan_create": (c_int, [c_void_p, c_int, c_int, ctypes.POINTER(c_void_p)]),
@@ -371,6 +374,25 @@ class Context:
         _check(self.lib.corahip_draw_alm_philox_rows(self.h, self._f64(T_rows), self._p(info) if info is not None else None,
                                                      c_u64(int(seed) & (2**64 - 1)), lmax, F, nu0, nnu, self._f64(alm)))
         return alm
+
+    # -- frequency sharding: the data movements around the factor row-block all-to-all ---------
+    def factor_rows_pack(self, T_local, l_stride, world):
+        """[n_local, F, F] l-sharded factors -> send [world, l_stride, F / world, F] (slab q = rows of rank q's
+        channels, l rows past n_local zero)."""
+        n_local, F, _ = T_local.shape
+        send = self.empty((world, l_stride, F // world, F))
+        _check(self.lib.corahip_factor_rows_pack(self.h, self._f64(T_local) if n_local else None, n_local, l_stride, F,
+                                                 world, self._f64(send)))
+        return send
+
+    def factor_rows_unpack(self, recv, counts):
+        """recv [world, l_stride, nnu, F] (slab r from rank r) + the multipoles each rank holds -> T_rows
+        [sum(counts), nnu, F], the l blocks in rank order."""
+        world, l_stride, nnu, F = recv.shape
+        cnt = (ctypes.c_int32 * world)(*[int(c) for c in counts])
+        out = self.empty((int(sum(counts)), nnu, F))
+        _check(self.lib.corahip_factor_rows_unpack(self.h, self._f64(recv), cnt, world, l_stride, nnu, F, self._f64(out)))
+        return out
 
     def alm_dev_to_square(self, alm, lmax, nnu):
         torch = _torch()

@@ -32,6 +32,7 @@ struct corahip_linefft_plan {
     double2 *rtw = nullptr;    // [n/2 + 1]  e^{+2 pi i k / 2n}: (un)packing of a real transform of length 2n
 };
 
+#define CORAHIP_NSCRATCH 6
 struct corahip_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -45,8 +46,8 @@ struct corahip_ctx {
     // grow-only device scratch slots owned by the context (freed by ctx_destroy)
     // slots: 0 K1 transposed tables, 1 K1 pair results / odd-F normal stream, 2 K1 pair list, 3 zeros,
     //        4 Legendre matrix of legendre_project, 5 its zero-padded operand
-    void *scratch[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    size_t scratch_bytes[6] = {0, 0, 0, 0, 0, 0};
+    void *scratch[CORAHIP_NSCRATCH] = {};
+    size_t scratch_bytes[CORAHIP_NSCRATCH] = {};
     // K1 pair list resident in scratch slot 2: (F, first, step, slots, device pointer it was written to)
     long pairs_key[4] = {-1, -1, -1, -1};
     void *pairs_ptr = nullptr;

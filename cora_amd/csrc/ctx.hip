@@ -74,7 +74,7 @@ int corahip_ctx_destroy(corahip_ctx *ctx) {
         (void)hipEventDestroy(ctx->ev_fork);
         (void)hipEventDestroy(ctx->ev_join);
     }
-    for (int i = 0; i < 6; i++)
+    for (int i = 0; i < CORAHIP_NSCRATCH; i++)
         if (ctx->scratch[i]) (void)hipFree(ctx->scratch[i]);
     for (auto &kv : ctx->linefft) {
         if (kv.second.tw) (void)hipFree(kv.second.tw);

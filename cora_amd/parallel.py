@@ -107,9 +107,37 @@ def exchange_pair_slabs(slabs, plan):
     return _all_to_all(slabs, plan.world)
 
 
+def _rows_pack(T_local, l_stride, world):
+    """[n, F, F] -> [world, l_stride, F / world, F]: corahip_factor_rows_pack on the device; for the CPU tensors of
+    the gloo tests of the exchange pattern (tests/test_sharding.py) the same permutation in torch."""
+    import torch
+
+    if T_local.is_cuda:
+        from . import _lib
+
+        return _lib.get_context(T_local.device.index).factor_rows_pack(T_local.contiguous(), l_stride, world)
+    n, F, _ = T_local.shape
+    pad = torch.zeros((l_stride, F, F), dtype=T_local.dtype)
+    pad[:n].copy_(T_local)
+    return pad.view(l_stride, world, F // world, F).permute(1, 0, 2, 3).contiguous()
+
+
+def _rows_unpack(recv, counts):
+    """[world, l_stride, nnu, F] + per-rank l counts -> [sum counts, nnu, F] (corahip_factor_rows_unpack on the device)."""
+    import torch
+
+    if recv.is_cuda:
+        from . import _lib
+
+        return _lib.get_context(recv.device.index).factor_rows_unpack(recv, counts)
+    return torch.cat([recv[r, : counts[r]] for r in range(recv.shape[0])], dim=0).contiguous()
+
+
 def exchange_factor_rows(T_local, info_local, plan):
     """l-sharded factors [l_hi - l_lo, F, F] -> (T_rows [L, nnu, F], info [L]): every rank ends up with the
-    rows of ALL T_l that its own channels need.  Requires F % world == 0 (equal row blocks)."""
+    rows of ALL T_l that its own channels need.  Requires F % world == 0 (equal row blocks).  The pack / unpack
+    around the all-to-all are the C entry points a caput / mpi4py caller would use (include/corahip.h,
+    INTEGRATION.md section 3)."""
     import torch
     import torch.distributed as dist
 
@@ -117,16 +145,14 @@ def exchange_factor_rows(T_local, info_local, plan):
     W = plan.world
     assert F % W == 0 and plan.nnu == F // W
     n = plan.l_hi - plan.l_lo
-    pad_T = torch.zeros((plan.l_shard, F, F), dtype=T_local.dtype, device=T_local.device)
     pad_i = torch.zeros((plan.l_shard,), dtype=info_local.dtype, device=info_local.device)
-    pad_T[:n].copy_(T_local)
     pad_i[:n].copy_(info_local)
-    # [l, (dst, row), k] -> [dst, l, row, k]
-    send = pad_T.view(plan.l_shard, W, plan.nnu, F).permute(1, 0, 2, 3).contiguous()
-    recv = _all_to_all(send, W)                     # [src, l_shard, nnu, F] = [L_pad, nnu, F]
+    send = _rows_pack(T_local, plan.l_shard, W)     # [dst, l, row, k]
+    recv = _all_to_all(send, W)                     # [src, l_shard, nnu, F]
     i_all = torch.empty((plan.l_pad,), dtype=info_local.dtype, device=info_local.device)
     dist.all_gather_into_tensor(i_all, pad_i)
-    return recv.view(plan.l_pad, plan.nnu, F)[: plan.L], i_all[: plan.L]
+    counts = [max(0, min(plan.L, (r + 1) * plan.l_shard) - min(plan.L, r * plan.l_shard)) for r in range(W)]
+    return _rows_unpack(recv, counts), i_all[: plan.L]
 
 
 class SkyShard:
@@ -417,13 +443,13 @@ def mkfullsky_sharded(corr_local, global_shape, nside, rng=None, alms=False, ctx
     dist.all_gather_into_tensor(i_all, pad_i)
     rows = F % world == 0
     if rows:
-        send = pad_T.view(lc, world, nnu, F).permute(1, 0, 2, 3).contiguous()
-        recv = _all_to_all(send, world)                                   # [src, lc, nnu, F]
+        recv = _all_to_all(_rows_pack(T_loc, lc, world), world)           # [src, lc, nnu, F]
+        T = _rows_unpack(recv, counts)
     else:
         recv = torch.empty((world * lc, F, F), dtype=torch.float64, device=ctx.device)
         dist.all_gather_into_tensor(recv, pad_T)
         recv = recv.view(world, lc, F, F)
-    T = torch.cat([recv[r, : counts[r]] for r in range(world)], dim=0).contiguous()
+        T = torch.cat([recv[r, : counts[r]] for r in range(world)], dim=0).contiguous()
     info = torch.cat([i_all[r * lc : r * lc + counts[r]] for r in range(world)]).contiguous()
     lmax = L - 1
     if rng is None:

@@ -157,6 +157,37 @@ int corahip_draw_alm_philox(corahip_ctx *ctx, const double *T, const int32_t *in
 int corahip_draw_alm_philox_rows(corahip_ctx *ctx, const double *T_rows, const int32_t *info, uint64_t seed,
                                  int lmax, int F, int nu0, int nnu, double *alm_dev);
 
+/* ---- frequency sharding for callers that pass the messages themselves -----------------------------
+ * The reference distributes this path with caput.mpiarray over MPI (cora/core/skysim.py:97-110: C_l and the a_lm
+ * buffer split over l; :125-134: allgather / redistribute to a frequency split).  These entry points give such a
+ * caller the sharded path without torch.distributed: the only exchange is ONE all-to-all of factor row blocks.
+ *   shard_plan        the split both sides use: multipoles [l_lo, l_hi) (contiguous blocks of l_shard, the last
+ *                     ones shorter / empty), channels [nu0, nu0 + nnu); rows_exchange = 1 iff F % world == 0 (the
+ *                     row-block all-to-all applies; otherwise all-gather the [L, F, F] factor stack instead).
+ *                     Pure host arithmetic - any other contiguous l split (caput's) works with pack / unpack too.
+ *   factor_rows_pack  T_local [n_local, F, F] (this rank's factors, corahip_factor_batched of its C_l block) ->
+ *                     send [world][l_stride][F / world][F]: slab q = the rows of rank q's channels, l rows
+ *                     n_local .. l_stride - 1 zero (l_stride = the largest block of any rank: equal slabs)
+ *   (caller)          all-to-all: slab q of every rank goes to rank q -> recv [world][l_stride][nnu][F], slab r
+ *                     from rank r; all-gather of the info flags (int32 [n_local] each)
+ *   factor_rows_unpack recv + host_counts [world <= 64] (multipoles each rank holds, in rank order) ->
+ *                     T_rows [sum counts][nnu][F]: what corahip_draw_alm_philox_rows consumes
+ * then corahip_draw_alm_philox_rows(T_rows, info_all, seed, lmax, F, nu0, nnu) and corahip_alm2map: every rank
+ * draws from the same counter-based stream for its own channels, the a_lm are never exchanged, the maps stay
+ * frequency-sharded (the reference's MPIArray.wrap(sky, axis=0), skysim.py:132-134). */
+typedef struct corahip_shard {
+    int32_t l_lo, l_hi;      /* this rank integrates / factors multipoles [l_lo, l_hi) */
+    int32_t l_shard, l_pad;  /* padded block length (equal on all ranks), l_shard * world >= L */
+    int32_t nu0, nnu;        /* this rank draws and synthesises channels [nu0, nu0 + nnu) */
+    int32_t rows_exchange;   /* 1: F % world == 0, factor row blocks go by all-to-all */
+    int32_t L;
+} corahip_shard;
+int corahip_shard_plan(int L, int F, int rank, int world, corahip_shard *out);
+int corahip_factor_rows_pack(corahip_ctx *ctx, const double *T_local, int n_local, int l_stride, int F, int world,
+                             double *send);
+int corahip_factor_rows_unpack(corahip_ctx *ctx, const double *recv, const int32_t *host_counts, int world,
+                               int l_stride, int nnu, int F, double *T_rows);
+
 /* layout converters between alm_dev and the reference's arrays:
  *   square  [nnu, 1, L, L] complex128 as returned by mkfullsky(alms=True) (skysim.py:108-125)
  *   packed  [nnu, nalm]   complex128 healpy order, as pack_alm produces (hputil.py:124-152)  */

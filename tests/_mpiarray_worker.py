@@ -28,9 +28,16 @@ def main():
     import torch
     import torch.distributed as dist
 
-    dist.init_process_group("gloo")
+    # default: all ranks share GPU 0 and talk over gloo (the 1-GPU boxes of the pool); CORA_TEST_BACKEND=nccl: one
+    # device per rank over RCCL (parallel._all_to_all's all_to_all_single branch with world > 1)
+    backend = os.environ.get("CORA_TEST_BACKEND", "gloo")
+    if backend == "nccl":
+        torch.cuda.set_device(int(os.environ["LOCAL_RANK"]))
+        dist.init_process_group("nccl", device_id=torch.device("cuda", int(os.environ["LOCAL_RANK"])))
+    else:
+        dist.init_process_group("gloo")
+        torch.cuda.set_device(0)
     rank, world = dist.get_rank(), dist.get_world_size()
-    torch.cuda.set_device(0)
     from cora_amd.core import skysim
     from cora_amd.util.nputil import DeviceRNG
 

@@ -54,3 +54,35 @@ def test_mkfullsky_l_distributed_mpiarray():
                             os.path.join("tests", "_mpiarray_worker.py")], cwd=ROOT, env=_plain_env(),
                            capture_output=True, text=True, timeout=600)
         assert p.returncode == 0 and "MPIARRAY OK" in p.stderr, p.stderr[-3000:]
+
+
+def _ngpu():
+    import torch
+
+    return torch.cuda.device_count()      # (does not initialise the GPU in this process)
+
+
+@pytest.mark.skipif(_ngpu() < 2, reason="needs two GPUs: RCCL with world > 1")
+@pytest.mark.parametrize("workload", ["tiny", "tiny3"])
+def test_bench_two_devices_over_rccl(workload):
+    """bench.py --gpus 2 as the driver's scaling tier runs it: one rank per DEVICE over RCCL (backend nccl) -
+    parallel._all_to_all's all_to_all_single branch with world > 1, the pair-slab and factor-row exchanges over xGMI.
+    The per-channel checksums must equal the single-GPU ones.  Skips on the 1-GPU boxes of this pool and runs the
+    first time a multi-GPU node executes the suite, i.e. before the SCALE bench does."""
+    common = ["--workload", workload, "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--checksum"]
+    one, c1 = _bench(common)
+    two, c2 = _bench(["--gpus", "2"] + common)
+    assert two["n_gpus"] == 2 and two["ranks_seen"] == 2
+    assert c1 is not None and c1 == c2, (c1, c2)
+
+
+@pytest.mark.skipif(_ngpu() < 2, reason="needs two GPUs: RCCL with world > 1")
+def test_mkfullsky_l_distributed_mpiarray_over_rccl():
+    """skysim.mkfullsky on an l-distributed MPIArray-like input with one rank per device over RCCL (2 ranks)."""
+    env = _plain_env()
+    env["CORA_TEST_BACKEND"] = "nccl"
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29891",
+                        os.path.join("tests", "_mpiarray_worker.py")], cwd=ROOT, env=env, capture_output=True, text=True,
+                       timeout=600)
+    assert p.returncode == 0 and "MPIARRAY OK" in p.stderr, p.stderr[-3000:]

@@ -1082,6 +1082,51 @@ def test_c_abi_with_ctypes_only_no_torch(tmp_path, golden):
         assert np.abs(got - a1).max() <= 1e-12 * np.abs(a1).max()
 
 
+def test_c_abi_sharded_mkfullsky_two_processes_no_torch(tmp_path, golden):
+    """The sharded path through the C ABI alone (corahip_shard_plan, corahip_factor_rows_pack / _unpack,
+    corahip_draw_alm_philox_rows): tools/abi_shard_demo.py runs mkfullsky on an
+    l-distributed C_l (cora/core/skysim.py:97-110,125-134) as 2 and 3 ctypes-only processes that exchange the factor
+    row blocks through files - what a caput / mpi4py caller would do with MPI_Alltoall - and their frequency shards
+    must equal the single-process realisation of the same seed; that one is checked against the oracle's synthesis
+    of its own a_lm and against T g computed in numpy from the device Philox stream's specification."""
+    import os
+    import subprocess
+    import sys
+
+    from oracle import philox
+    from oracle import sht
+    from oracle import skysim as osk
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    key, nside, seed = "cla_21cm_F8_l64_zromb3", 16, 11
+    # F = 8: world 2 and 4 divide it (row-block exchange); L = 65 splits unevenly over both
+    for world in (2, 4):
+        d = str(tmp_path / ("w%d" % world))
+        os.makedirs(d)
+        p = subprocess.run([sys.executable, os.path.join(root, "tools", "abi_shard_demo.py"), key, str(nside), str(seed),
+                            str(world), "launch", d], capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0 and "ABI_SHARD ok" in p.stdout and p.stdout.strip().endswith("False"), p.stdout + p.stderr
+        em, ea = (float(v) for v in p.stdout.split("ABI_SHARD ok")[1].split()[:2])
+        assert em <= 1e-13 and ea <= 1e-13, (world, em, ea)
+    r = np.load(os.path.join(d, "single.npz"))
+    C = golden[key]
+    L, F, _ = C.shape
+    lmax = L - 1
+    # the single-process result itself: a_lm = T g with g the specified Philox stream, maps = synthesis of those a_lm
+    g = philox.device_normals(seed, lmax, F)
+    o = 0
+    for l in range(L):
+        n = F * (l + 1)
+        re, im = g[o:o + n].reshape(F, l + 1), g[o + n:o + 2 * n].reshape(F, l + 1)
+        o += 2 * n
+        T = osk.matrix_root_manynull(C[l] + np.identity(F) * C[l].diagonal().max() * 1e-14, truncate=False)
+        ref = T @ ((re + 1j * im) / 2**0.5)
+        assert np.abs(r["alm"][:, 0, l, : l + 1] - ref).max() <= 1e-12 * np.abs(ref).max(), l
+    for i in (0, 7):
+        m = sht.alm2map(osk.pack_alm(r["alm"][i, 0]), nside, lmax)
+        assert np.abs(r["maps"][i] - m).max() <= 1e-11 * m.std()
+
+
 def test_complex_transform_family(ctx):
     """hputil.sphtrans_inv_complex / sphtrans_complex (cora/util/hputil.py:237-263,435-457): a complex field from
     a_lm with both signs of m equals the oracle synthesis of its real/imaginary projections, and transforms back."""

@@ -26,6 +26,27 @@ def test_library_exports_every_declared_symbol():
     assert isinstance(lib.corahip_last_error(), bytes)
 
 
+def test_c_shard_plan_matches_python_plan():
+    """corahip_shard_plan (what a caput / mpi4py caller of the C ABI uses, cora/core/skysim.py:97-110) and
+    cora_amd.parallel.shard_plan (what the torch.distributed path uses) are the same split: host arithmetic only."""
+    from cora_amd import _lib
+    from cora_amd.parallel import shard_plan
+
+    class Shard(ctypes.Structure):
+        _fields_ = [(n, ctypes.c_int32) for n in ("l_lo", "l_hi", "l_shard", "l_pad", "nu0", "nnu", "rows_exchange", "L")]
+
+    lib = _lib.load()
+    for L, F, world in ((2049, 256, 8), (4097, 1024, 8), (129, 16, 2), (65, 8, 3), (10, 7, 3), (3, 2, 4)):
+        for r in range(world):
+            c = Shard()
+            assert lib.corahip_shard_plan(L, F, r, world, ctypes.byref(c)) == 0
+            p = shard_plan(L, F, r, world)
+            assert (c.l_lo, c.l_hi, c.l_shard, c.l_pad, c.nu0, c.nnu, c.L) == (p.l_lo, p.l_hi, p.l_shard, p.l_pad, p.nu0, p.nnu, L)
+            assert c.rows_exchange == (1 if F % world == 0 else 0)
+    assert lib.corahip_shard_plan(10, 4, 2, 2, ctypes.byref(Shard())) == -1        # rank >= world: CORAHIP_EINVAL
+    assert b"invalid argument" in lib.corahip_last_error()
+
+
 def test_no_gpu_fails_loudly():
     """Without a GPU the compute entry points raise; they never fall back to a CPU path."""
     import torch
