@@ -25,6 +25,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <type_traits>
 #include <cstdlib>
 #include <map>
 
@@ -96,6 +97,7 @@ static inline bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 #define LEG_WAVES 8
 #endif
 #define LEG_RINGS (16 * LEG_WAVES)  // ring pairs per workgroup (x RT)
+#define LEG_RPM (8 / LEG_WAVES)     // a_lm pieces each wave issues per macro-step (= RPW / (LEG_KT / 8))
 #define LMIN_RINGS 128              // granularity of the plan's per-(m, ring block) first-l table
 #define ADJ_WAVES 8                 // waves per workgroup of the analysis kernel
 #ifndef LEG_NBUF

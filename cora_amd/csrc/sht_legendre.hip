@@ -40,7 +40,7 @@ legendre_kernel(int lmax, int npair, int nring, int ncols, const double *__restr
     constexpr int PIECES = RPW + 1;                     // LDS-DMA pieces per wave per stage (+ coefficients)
     constexpr int TRINGS = LEG_RINGS * RT;              // ring pairs per workgroup
     constexpr int RPM = RPW / (LEG_KT / 8);             // a_lm pieces each wave issues per macro-step
-    static_assert(RPM * (LEG_KT / 8) == RPW && RPM >= 1, "whole a_lm pieces per macro-step");
+    static_assert(RPM * (LEG_KT / 8) == RPW && RPM >= 1 && RPM == LEG_RPM, "whole a_lm pieces per macro-step");
     extern __shared__ __attribute__((aligned(16))) double lds[];
     int &s_next = *reinterpret_cast<int *>(lds + LEG_NBUF * STAGE);  // next work item (carved after the ring)
 
@@ -106,6 +106,28 @@ legendre_kernel(int lmax, int npair, int nring, int ncols, const double *__restr
         const char *src = reinterpret_cast<const char *>(w.src0) + (unsigned)(r * ncols) * 8u;
         const unsigned dst = lds_base_bytes + (unsigned)(((st % LEG_NBUF) * STAGE + row * STRIDE) * sizeof(double));
         if (lane < 8 * NT) glds16_s(src, 16u * lane, dst);
+    };
+    // The a_lm pieces of the steady-state stages ("fast" form: 3 instructions instead of 13).  Every instruction of
+    // the macro-step loop costs issue time next to the MFMAs: the generic issue_row spends 8 scalar
+    // instructions on the row address (clamp, multiply, 64-bit add, LDS offset) and 4 on saving / setting / restoring
+    // M0.  Here the source is a per-STAGE scalar base + a per-lane byte offset that lives in a VGPR for the whole
+    // kernel (one per piece of a stage: voff[p] = 16 lane + 8 p ncols LEG_WAVES), the LDS destination a per-stage
+    // scalar + an immediate, written straight into M0 (nothing else in this kernel reads M0: the other LDS-DMA
+    // helpers set it themselves and the compiler does not use it on gfx950; checked in the ISA).  Only taken when
+    // every row of the refilled stage exists (no clamping): the stage loop's `refill_clean`.
+    unsigned voff[RPW];
+#pragma unroll
+    for (int p = 0; p < RPW; p++) voff[p] = 16u * lane + (unsigned)(p * LEG_WAVES * ncols) * 8u;
+    auto issue_row_fast = [&](const char *rsrc, unsigned rdst, auto pc) {
+        constexpr int P = decltype(pc)::value;
+        constexpr int IMM = P * LEG_WAVES * STRIDE * 8;
+        const unsigned vo = voff[P];     // (asm operands inside a generic lambda do not capture: name a local)
+        const bool on = NT == 8 || lane < 8 * NT;
+        if (on)
+            asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                         :
+                         : "v"(vo), "s"(rsrc), "s"(rdst), "n"(IMM)
+                         : "memory", "scc");     // (s_add_u32 writes SCC: undeclared, it ate the stage loop's compare)
     };
     auto issue_coef = [&](const item_t &w, int st) {
         const int l = w.l_begin + st * LEG_KT + lane;
@@ -221,21 +243,28 @@ legendre_kernel(int lmax, int npair, int nring, int ncols, const double *__restr
             // the wave still start, the steady-state stages - every ring runs, none starts, every row <= lmax - whose
             // macro-steps carry no tests at all and are fully unrolled (every scalar compare / branch / loop increment
             // costs issue time next to the MFMAs), and the tail stage that overhangs lmax.
-            auto stage_clean = [&](int st) {
+            // A stage is "clean" when (lo) every ring of the wave already runs and none starts in it - true from some
+            // stage on - and (hi) all its rows are <= lmax, it refills the ring and every row of the stage it refills
+            // exists (the fast pieces do not clamp) - true up to some stage.  Both bounds are found once per item, so
+            // the steady-state loop's own condition is one scalar compare.
+            auto stage_lo = [&](int st) {
                 const int ls = w.l_begin + st * LEG_KT;
-                return (ls + LEG_KT - 1 <= lmax) && (ws_min <= ls) && (ws_maxinj < ls);
+                return (ws_min <= ls) && (ws_maxinj < ls);
             };
+            int st_hi = min(min((lmax - w.l_begin + 1) / LEG_KT, (w.row_limit + 1) / LEG_KT - LEG_NBUF + 1),
+                            w.nstage - LEG_NBUF + 1);
+            st_hi = __builtin_amdgcn_readfirstlane(st_hi);
             int st = 0;
 #define LEG_CLEAN 0
 #define LEG_MS_PRAGMA _Pragma("unroll 1")
-            for (; st < w.nstage && !stage_clean(st); st++) {
+            for (; st < w.nstage && !(stage_lo(st) && st < st_hi); st++) {
 #include "leg_stage_body.inc"
             }
 #undef LEG_CLEAN
 #undef LEG_MS_PRAGMA
 #define LEG_CLEAN 1
 #define LEG_MS_PRAGMA _Pragma("unroll")
-            for (; st + LEG_NBUF - 1 < w.nstage && stage_clean(st); st++) {
+            for (; st < st_hi; st++) {
 #include "leg_stage_body.inc"
             }
 #undef LEG_CLEAN

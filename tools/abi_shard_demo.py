@@ -69,7 +69,7 @@ def _put(path, arr):
     os.replace(tmp, path)
 
 
-def _get(path, timeout=300.0):
+def _get(path, timeout=90.0):
     t0 = time.time()
     while not os.path.exists(path):
         if time.time() - t0 > timeout:
@@ -139,12 +139,34 @@ def run_rank(key, nside, seed, world, rank, scratch):
 def launch(key, nside, seed, world, scratch):
     def start(w, r, d):
         os.makedirs(d, exist_ok=True)
-        return subprocess.Popen([sys.executable, os.path.abspath(__file__), key, str(nside), str(seed), str(w), str(r), d])
+        err = open(os.path.join(d, "rank%d.err" % r), "w")
+        return subprocess.Popen([sys.executable, os.path.abspath(__file__), key, str(nside), str(seed), str(w), str(r), d],
+                                stderr=err), err
+
+    def run_all(w, d):
+        """Start the w ranks, wait for all; the first failure ends the others (they would only time out on its files)."""
+        procs = [start(w, r, d) for r in range(w)]
+        t0 = time.time()
+        bad = None
+        while bad is None and any(p.poll() is None for p, _ in procs):
+            bad = next((r for r, (p, _) in enumerate(procs) if p.poll() not in (None, 0)), None)
+            if time.time() - t0 > 300:
+                bad = -1
+            time.sleep(0.05)
+        bad = bad if bad is not None else next((r for r, (p, _) in enumerate(procs) if p.returncode != 0), None)
+        for p, e in procs:
+            if p.poll() is None:
+                p.kill()
+            p.wait()
+            e.close()
+        if bad is not None:
+            for r in range(w):
+                sys.stderr.write("---- rank %d of %d ----\n%s\n" % (r, w, open(os.path.join(d, "rank%d.err" % r)).read()[-2000:]))
+            raise SystemExit("ABI_SHARD failed: rank %s of %d" % (bad, w))
 
     d1, dw = os.path.join(scratch, "w1"), os.path.join(scratch, "w%d" % world)
-    procs = [start(1, 0, d1)] + [start(world, r, dw) for r in range(world)]
-    rcs = [p.wait(timeout=600) for p in procs]
-    assert not any(rcs), rcs
+    run_all(1, d1)          # the single-process realisation first, then the ranks (never more than `world` on the GPU)
+    run_all(world, dw)
     one = np.load(os.path.join(d1, "rank0_of1.npz"))
     parts = sorted((np.load(os.path.join(dw, "rank%d_of%d.npz" % (r, world))) for r in range(world)), key=lambda z: int(z["nu0"]))
     maps = np.concatenate([z["maps"] for z in parts])
