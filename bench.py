@@ -99,6 +99,8 @@ def main():
     ap.add_argument("--checksum", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="take the multi-rank code path (process group, exchanges) even with 1 rank")
     ap.add_argument("--emulate-shard", type=int, default=0, help="time the work of the LAST rank of an N-rank job, no comm")
+    ap.add_argument("--sum-mode", default="joint", choices=["joint", "separate"],
+                    help="multi-component workloads (cfg4): one factorisation + draw of the summed covariance, or one per component")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -159,7 +161,7 @@ def main():
                          distributed=multi, emulate_world=args.emulate_shard)
     else:
         shard = SkySum([(build_model(m), z) for m, z in comps], freq, nside, lmax, rank=rank, world=world, ctx=ctx,
-                       distributed=multi, emulate_world=args.emulate_shard)
+                       distributed=multi, emulate_world=args.emulate_shard, mode=args.sum_mode)
     nnu, nu0 = shard.nnu, shard.nu0
     maps_buf = shard.maps_buf
     torch.cuda.synchronize()
@@ -296,9 +298,11 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": "%s: %s, %d channels %g-%g MHz, nside=%d, lmax=%d, zromb=%s, %s path, device Philox normals%s"
+                "workload": "%s: %s, %d channels %g-%g MHz, nside=%d, lmax=%d, zromb=%s, %s path, device Philox normals%s%s"
                             % (args.workload, model_name, F, nu_lo, nu_hi, nside, lmax, "/".join(str(c[1]) for c in comps),
                                "warm (cached factors)" if args.warm else "cold (C_l integration + factor + draw + synthesis)",
+                               "" if len(comps) == 1 else (", components summed as ONE Gaussian field (covariances added, one factorisation + one draw)"
+                                                           if args.sum_mode == "joint" else ", one draw per component, a_lm added"),
                                (" - ONE GPU doing the share of the most loaded of %d ranks (%d channels, no exchanges): "
                                 "value counts those maps only" % (emu, nnu)) if emu else ""),
                 "parallelism": "freq-shard x%d (pair-sharded C_l -> all-to-all -> l-sharded factor -> all-to-all of factor row blocks)" % world if world > 1 else "single GPU",

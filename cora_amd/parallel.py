@@ -283,6 +283,36 @@ class SkyShard:
         return self.ctx.clarray_table21cm_pairs(*self._tabs, *self._k1, self.F, self.zint, self.w, self._lx, first, step,
                                                 self.plan.l_shard, nblocks=step)
 
+    def covariance_shard(self):
+        """C_l of this rank's multipoles ``[l_hi - l_lo, F, F]`` (all of them when not distributed) - the cold
+        part up to, not including, the factorisation: K1 and, when it is pair-sharded, all-to-all #1.  Under
+        ``emulate_world`` the rank's K1 work is done and a stand-in stack of the right shape returned."""
+        ctx, sp = self.ctx, self.plan
+        if self.emulate_world > 1:
+            N = self.emulate_world
+            if self._sep is None and self.pair_sharded:
+                slab = self._clarray_pairs(N - 1, N)
+                ctx.clarray_pairs_finish(slab.new_zeros((N,) + tuple(slab.shape[1:])), self.F, sp.l_hi - sp.l_lo)
+            else:
+                self._clarray_local()
+            return self._emu_C
+        if self.distributed and self._sep is None and self.pair_sharded:
+            mine = exchange_pair_slabs(self._clarray_pairs(self.rank, self.world), sp)   # all-to-all #1
+            return ctx.clarray_pairs_finish(mine, self.F, sp.l_hi - sp.l_lo)
+        return self._clarray_local()
+
+    def share_factors(self, T, info):
+        """l-sharded factors of this rank -> (T, info, rows) as the draw takes them: the row-block all-to-all (#2)
+        when F divides over the ranks, else the all-gather of the stack; a single rank keeps what it has."""
+        sp = self.plan
+        if not self.distributed:
+            return T, info, False
+        if self.F % max(self.world, 1) == 0:
+            Tr, ia = exchange_factor_rows(T, info, sp)
+            return Tr, ia, True
+        Ta, ia = allgather_factors(T, info, sp)
+        return Ta, ia, False
+
     def factors(self):
         """(T, info, rows): the factors this rank's draw needs; ``rows`` tells whether T holds only the rank's row
         blocks ``[L, nnu, F]`` (pair-sharded path) or the full ``[L, F, F]`` stack."""
@@ -331,18 +361,33 @@ class SkySum:
     """Sum of independent Gaussian components on one channel grid - BASELINE configs[3]: 21cm (``Corr21cm``) +
     galactic synchrotron (``FullSkySynchrotron``, cora/foreground/galaxy.py:20-27) + unresolved point sources
     (``_UnresolvedBackground``, cora/foreground/pointsource.py:541-546).  The reference would make one
-    ``getsky()`` per component and add the maps; the synthesis is linear, so the a_lm of the components are
-    added instead and K4 + K5 (9/10 of a realisation) run ONCE per realisation.  Sharding, exchanges and the
-    ``factors()`` / ``realise(seed)`` protocol are those of :class:`SkyShard`, per component.
+    ``getsky()`` per component and add the maps.  Two forms, both behind the ``factors()`` / ``realise(seed)`` protocol
+    of :class:`SkyShard`:
+
+    ``mode="separate"``  every component is factored and drawn on its own (its own Philox key) and the a_lm are
+        ADDED before one synthesis - the transform is linear, so K4 + K5 run once per realisation; the
+        per-component a_lm exist (``draw`` leaves the sum in ``alm_buf``).
+    ``mode="joint"`` (default)  the sum of independent zero-mean Gaussian fields with covariances C_l^(c) IS a
+        Gaussian field with covariance sum_c C_l^(c): the component C_l stacks are added - each with the
+        ``1e-14 max(diag)`` jitter mkfullsky gives it (cora/core/skysim.py:115-117), so the summed covariance is
+        exactly that of the reference's summed maps - and ONE factorisation and ONE draw per realisation replace
+        one per component (cfg 4: K3 77 -> 26 ms, K2 9 -> 7 ms).  Same distribution, not the same numbers as
+        "separate" for a given seed; the device stream is statistical mode either way (seed parity with numpy needs
+        the host stream and per-component draws: ``skysim.mkfullsky``).  The foreground blocks alone have
+        cond ~ 1e19; their sum with the 21cm block is better conditioned than they are.
 
     components : sequence of ``(model, zromb)``
     """
 
     _SEED_STRIDE = 0x9E3779B97F4A7C15      # component k draws with seed + k * stride (mod 2^64): disjoint Philox keys
 
-    def __init__(self, components, freq, nside, lmax, rank=0, world=1, ctx=None, distributed=None, emulate_world=0):
+    def __init__(self, components, freq, nside, lmax, rank=0, world=1, ctx=None, distributed=None, emulate_world=0,
+                 mode="joint"):
         from . import _lib
 
+        if mode not in ("joint", "separate"):
+            raise ValueError("mode must be 'joint' or 'separate'")
+        self.mode = mode
         self.ctx = ctx if ctx is not None else _lib.get_context()
         self.shards = []
         alm_buf = maps_buf = None
@@ -354,14 +399,42 @@ class SkySum:
         s0 = self.shards[0]
         self.alm_buf, self.maps_buf = alm_buf, maps_buf
         self.nu0, self.nnu, self.F, self.nside, self.lmax, self.npix = s0.nu0, s0.nnu, s0.F, s0.nside, s0.lmax, s0.npix
-        self._tmp = self.ctx.empty(tuple(alm_buf.shape)) if len(self.shards) > 1 else None
+        self._tmp = self.ctx.empty(tuple(alm_buf.shape)) if (len(self.shards) > 1 and mode == "separate") else None
+
+    def covariance_shard(self):
+        """sum_c (C_l^(c) + 1e-14 max(diag C_l^(c)) I) for this rank's multipoles: the covariance of the summed
+        field exactly as the reference's per-component mkfullsky calls imply it."""
+        total = None
+        for sh in self.shards:
+            C = sh.covariance_shard()
+            if sh.emulate_world > 1:            # (stand-in stack shared by the components: timing only)
+                total = C
+                continue
+            jit = C.diagonal(dim1=1, dim2=2).amax(dim=1) * 1e-14
+            if total is None:
+                total = C
+            else:
+                total.add_(C)
+                del C
+            total.diagonal(dim1=1, dim2=2).add_(jit[:, None])
+        return total
 
     def factors(self):
-        """Per-component factors (the cold part), in component order."""
-        return [sh.factors() for sh in self.shards]
+        """Per-component factors (the cold part), in component order; one entry in joint mode."""
+        if self.mode == "separate":
+            return [sh.factors() for sh in self.shards]
+        s0 = self.shards[0]
+        C = self.covariance_shard()
+        T, info = self.ctx.factor_batched(C, jitter_rel=0.0)       # (the jitters are in C already)
+        del C
+        if s0.emulate_world > 1:
+            return [s0._emulated]
+        return [s0.share_factors(T, info)]
 
     def draw(self, seed, factors=None):
         factors = factors if factors is not None else self.factors()
+        if self.mode == "joint":
+            return self.shards[0].draw(int(seed), factors[0], out=self.alm_buf)
         for k, (sh, fac) in enumerate(zip(self.shards, factors)):
             sk = (int(seed) + k * self._SEED_STRIDE) & (2**64 - 1)
             if k == 0:

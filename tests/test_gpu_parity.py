@@ -1024,6 +1024,88 @@ def test_config4_three_components_frequency_shard(ctx):
     torch.cuda.empty_cache()
 
 
+def test_config4_skysum_full_size_factors_and_synthesis(ctx):
+    """configs[3] through the product object (parallel.SkySum; 512 channels, nside 1024, lmax 2048 on one GPU), both
+    forms.  (i) The near-singular F = 512 foreground blocks (cond ~ 1e19): Cholesky branch for every l >= 1
+    (info = 0; the all-zero l = 0 block gives the zero root the reference's eigen branch returns) and
+    |T T^T - (C_l + jitter)| <= 1e-13 max C_l at six multipoles; (ii) the joint factor reproduces
+    sum_c (C_l^(c) + jitter_c) to the same bound; (iii) two channels of the realised maps equal the ORACLE synthesis
+    of the a_lm SkySum drew and summed, pixel by pixel; (iv) the joint draw's spectrum matches the diagonal of the
+    summed covariance (cora/core/skysim.py:114-121 run once instead of three times)."""
+    import torch
+    from cora_amd.core import skysim
+    from cora_amd.foreground import galaxy, pointsource
+    from cora_amd.parallel import SkySum
+    from cora_amd.signal import corr21cm
+    from oracle import sht
+
+    nside, lmax, F = 1024, 2048, 512
+    L = lmax + 1
+    freq = 400.0 + (np.arange(F) + 0.5) * (400.0 / F)
+    mk = lambda: [(corr21cm.Corr21cm(), 3), (galaxy.FullSkySynchrotron(), 0),      # noqa: E731
+                  (pointsource.CombinedPointSources._UnresolvedBackground(), 0)]
+    ls = [0, 1, 2, 100, 1000, 2048]
+    eye = torch.eye(F, device=ctx.device, dtype=torch.float64)
+
+    def packed(alm, f):
+        g, v = divmod(f, 4)
+        return alm[:, g, 0, v].cpu().numpy() + 1j * alm[:, g, 1, v].cpu().numpy()
+
+    def check_maps(obj, tag):
+        maps = obj.realise(4040, fac)
+        for f in (0, F - 1):
+            ref = sht.alm2map(packed(obj.alm_buf, f), nside, lmax)
+            err = np.abs(maps[f].cpu().numpy() - ref).max() / ref.std()
+            print("cfg4 SkySum(%s) channel %d: max|err|/rms = %.2e" % (tag, f, err))
+            assert err <= 1e-11, (tag, f, err)
+
+    # ---- separate form
+    sky = SkySum(mk(), freq, nside, lmax, mode="separate")
+    fac = sky.factors()
+    Csum = None
+    for k, (model, zromb) in enumerate(mk()):
+        C = skysim.clarray_device(model.angular_powerspectrum, lmax, freq, zromb=zromb)[ls]
+        jit = C.diagonal(dim1=1, dim2=2).amax(dim=1) * 1e-14
+        Cj = C + jit[:, None, None] * eye
+        Csum = Cj if Csum is None else Csum + Cj
+        T, info, rows = fac[k]
+        if k > 0:                                  # the separable foreground components: one factor serves every l
+            assert rows and tuple(T.shape) == (L, F, F) and int(info.abs().sum().item()) == 0
+            Tl = T[ls]
+            res = (Tl @ Tl.transpose(1, 2) - Cj).abs().amax(dim=(1, 2)) / Cj.abs().amax(dim=(1, 2)).clamp_min(1e-300)
+            print("cfg4 component %d: |T T^T - C|/max C at l = %s: %s" % (k, ls, ["%.1e" % v for v in res.tolist()]))
+            assert res[1:].max().item() <= 1e-13 and float(Tl[0].abs().max().item()) == 0.0
+            assert torch.equal(Tl.triu(1), torch.zeros_like(Tl))          # lower triangular: the Cholesky branch
+        del C
+    check_maps(sky, "separate")
+    del sky, fac, T, Tl
+    torch.cuda.empty_cache()
+
+    # ---- joint form
+    sky = SkySum(mk(), freq, nside, lmax, mode="joint")
+    fac = sky.factors()
+    assert len(fac) == 1
+    T, info, rows = fac[0]
+    assert not rows and int(info.abs().sum().item()) == 0                 # every block of the sum is positive definite
+    Tl = T[ls]
+    res = (Tl @ Tl.transpose(1, 2) - Csum).abs().amax(dim=(1, 2)) / Csum.abs().amax(dim=(1, 2))
+    print("cfg4 joint: |T T^T - sum_c (C + jitter)|/max at l = %s: %s" % (ls, ["%.1e" % v for v in res.tolist()]))
+    assert res.max().item() <= 1e-13
+    check_maps(sky, "joint")
+    # spectrum of the joint draw against the diagonal of the summed covariance (m = 0 quirk: (2l + 1/2) / (2l + 1))
+    l = torch.arange(L, device=ctx.device, dtype=torch.float64)
+    ps = _alm_power(sky.alm_buf, lmax)                                      # [F, L]
+    diag = None
+    for model, zromb in mk():
+        d = torch.diagonal(skysim.clarray_device(model.angular_powerspectrum, lmax, freq, zromb=zromb), dim1=1, dim2=2).T.clone()
+        diag = d if diag is None else diag + d
+    expect = diag * (2 * l + 0.5) / (2 * l + 1)
+    z = ((ps - expect) / (expect * torch.sqrt(2.0 / (2 * l + 1))))[:, 2:]
+    assert z[:, 30:].abs().max().item() < 6.5 and abs(z.mean().item()) < 0.1, (z[:, 30:].abs().max().item(), z.mean().item())
+    del sky, fac, T, Tl, ps, diag
+    torch.cuda.empty_cache()
+
+
 def test_config5_geometry_synthesis_properties(ctx):
     """configs[4] geometry (nside 2048, lmax 4096; one 8-channel slice of a rank's 128): the largest plan -
     ring FFTs of 8192 pixels (two channels per workgroup), Bluestein length 8192, 8.4 M a_lm per channel.
