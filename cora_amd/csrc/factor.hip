@@ -202,6 +202,14 @@ chol_kernel(const double *__restrict__ C, int F, double jitter_rel, double *__re
 #define CHM_ABLATE 0   // diagnostic builds (wrong results): 1 no diagonal-block factorisation, 2 no panel solve, 3 no MFMA updates
 #endif
 
+// TALL = true (F >= 384): the wave tiles of step A are 64 rows x 32 columns (two block rows) and the factor block
+// L_jk of a k-step - the operand every tile of the block column shares - is staged ONCE per workgroup (each wave loads
+// a quarter of it; double-buffered, one barrier per k-step) instead of once per tile.  At F = 512 / 1024 a matrix
+// (2 / 8 MB, two per CU in flight) lives in no cache and the 32 x 32 form re-read 16 KB of factor blocks per 32 MFMAs -
+// 87 MB per F = 1024 matrix, 3 TB/s for the whole launch: the kernel was bound by that traffic, not by its 2.3 ms of
+// MFMA work.  The tall form moves 16 KB + 2 KB per 64 MFMAs (49 MB per matrix).  At F = 256 the matrices sit in L2,
+// the per-k-step barrier costs more than the traffic: the 32 x 32 form stays.
+template <bool TALL>
 __global__ void __launch_bounds__(256)
 chol_ll_kernel(const double *__restrict__ C, int F, double jitter_rel, double *__restrict__ T,
                int32_t *__restrict__ info) {
@@ -217,7 +225,9 @@ chol_ll_kernel(const double *__restrict__ C, int F, double jitter_rel, double *_
     const size_t off = (size_t)blockIdx.x * F * F;
     const double *A = C + off;
     double *Tl = T + off;
-    double *PA = stage + (size_t)wave * 2 * 32 * CHM_S, *PB = PA + 32 * CHM_S;
+    // 32 x 32 form: per wave an A and a B block; tall form: per wave an A block, then the shared B block twice
+    double *PA = stage + (size_t)wave * (TALL ? 1 : 2) * 32 * CHM_S, *PB = PA + 32 * CHM_S;
+    double *PBS = stage + 4 * 32 * CHM_S;              // (tall) [2][32][CHM_S]
 
     // jitter = max(diag) * jitter_rel
     double dmax = -INFINITY;
@@ -254,6 +264,122 @@ chol_ll_kernel(const double *__restrict__ C, int F, double jitter_rel, double *_
         const int nb = min(CH_NB, F - kb);
         // ---- A. the tiles (i >= j, j) of the block column: input block minus the products of the factor blocks to the left.
         //         Tile (a, b), register r of the accumulators <-> row i0 + 16 a + kq + 4 r, column kb + 16 b + ri.
+        if (TALL) {
+            const int ntile = (nblk - j + 1) / 2;          // tiles of two block rows: (j, j+1), (j+2, j+3), ...
+            const int nround = (ntile + 3) / 4;
+            // this wave's quarter of a shared block: row 8 wave + (lane >> 3), columns 4 (lane & 7) .. + 3
+            const int brow = 8 * wave + (lane >> 3), bcol = 4 * (lane & 7);
+            auto load_bq = [&](int col0, double2 (&v)[2]) {
+                const double *src = Tl + (size_t)(kb + brow < F ? kb + brow : 0) * F + col0 + bcol;
+                v[0] = *reinterpret_cast<const double2 *>(src);
+                v[1] = *reinterpret_cast<const double2 *>(src + 2);
+            };
+            auto store_bq = [&](double *P, const double2 (&v)[2]) {
+                const double sg = kb + brow < F ? 1.0 : 0.0;
+                *reinterpret_cast<double2 *>(P + brow * CHM_S + bcol) = make_double2(sg * v[0].x, sg * v[0].y);
+                *reinterpret_cast<double2 *>(P + brow * CHM_S + bcol + 2) = make_double2(sg * v[1].x, sg * v[1].y);
+            };
+            for (int u = 0; u < nround; u++) {
+                const int t = wave + 4 * u;
+                const bool has = t < ntile;
+                const int i0 = 32 * (j + 2 * t);           // first row of the tile
+                d4_t acc[4][2];
+#pragma unroll
+                for (int a = 0; a < 4; a++)
+#pragma unroll
+                    for (int b = 0; b < 2; b++)
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            const int row = i0 + 16 * a + kq + 4 * r, col = kb + 16 * b + ri;
+                            double v = 0.0;
+                            if (has && row < F && col <= row) v = A[(size_t)row * F + col] + (row == col ? jit : 0.0);
+                            acc[a][b][r] = v;
+                        }
+                if (j > 0 && CHM_ABLATE != 3) {
+                    double2 va0[8], va1[8], vb[2];
+                    if (has) {
+                        load_block(i0, 0, va0);
+                        load_block(i0 + 32, 0, va1);
+                    }
+                    load_bq(0, vb);
+                    for (int k = 0; k < j; k++) {
+                        double *PBc = PBS + (k & 1) * 32 * CHM_S;
+                        store_bq(PBc, vb);
+                        __syncthreads();     // block (j, k) complete; every wave is done with step k - 1 (the other buffer)
+                        if (k + 1 < j) load_bq(32 * (k + 1), vb);
+                        if (has) {
+                            // rows 0..31 of the tile through the wave-private A buffer, then rows 32..63 through the same
+                            // buffer (one wave, LDS in order: the reads of a half complete before the next half's writes)
+                            store_block(PA, va0, -1.0, i0);
+                            if (k + 1 < j) load_block(i0, 32 * (k + 1), va0);
+#pragma unroll
+                            for (int s = 0; s < 8; s++) {
+                                double af[2], bf[2];
+#pragma unroll
+                                for (int a = 0; a < 2; a++) {
+                                    af[a] = PA[(16 * a + ri) * CHM_S + 4 * s + kq];
+                                    bf[a] = PBc[(16 * a + ri) * CHM_S + 4 * s + kq];
+                                }
+#pragma unroll
+                                for (int a = 0; a < 2; a++)
+#pragma unroll
+                                    for (int b = 0; b < 2; b++)
+                                        acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[a], bf[b], acc[a][b], 0, 0, 0);
+                            }
+                            store_block(PA, va1, -1.0, i0 + 32);
+                            if (k + 1 < j) load_block(i0 + 32, 32 * (k + 1), va1);
+#pragma unroll
+                            for (int s = 0; s < 8; s++) {
+                                double af[2], bf[2];
+#pragma unroll
+                                for (int a = 0; a < 2; a++) {
+                                    af[a] = PA[(16 * a + ri) * CHM_S + 4 * s + kq];
+                                    bf[a] = PBc[(16 * a + ri) * CHM_S + 4 * s + kq];
+                                }
+#pragma unroll
+                                for (int a = 0; a < 2; a++)
+#pragma unroll
+                                    for (int b = 0; b < 2; b++)
+                                        acc[2 + a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[a], bf[b], acc[2 + a][b], 0, 0, 0);
+                            }
+                        }
+                    }
+                    __syncthreads();         // the last step's reads of the shared buffers, before the next round refills them
+                }
+                if (has) {
+#pragma unroll
+                    for (int hb = 0; hb < 2; hb++) {       // the two block rows of the tile
+                        const int r0b = i0 + 32 * hb;
+                        if (r0b >= F) continue;
+                        if (t == 0 && hb == 0) {            // the diagonal block goes to LDS
+#pragma unroll
+                            for (int a = 0; a < 2; a++)
+#pragma unroll
+                                for (int b = 0; b < 2; b++)
+#pragma unroll
+                                    for (int r = 0; r < 4; r++)
+                                        D[(16 * a + kq + 4 * r) * (CH_NB + 1) + 16 * b + ri] = acc[a][b][r];
+                        } else {                            // stored for the solve; its mirror block of the upper triangle zeroed
+#pragma unroll
+                            for (int a = 0; a < 2; a++)
+#pragma unroll
+                                for (int b = 0; b < 2; b++)
+#pragma unroll
+                                    for (int r = 0; r < 4; r++) {
+                                        const int row = r0b + 16 * a + kq + 4 * r, col = kb + 16 * b + ri;
+                                        if (row < F && col < F) Tl[(size_t)row * F + col] = acc[2 * hb + a][b][r];
+                                    }
+                            if (kb + srow < F) {
+                                double *z = Tl + (size_t)(kb + srow) * F + r0b + scol;
+#pragma unroll
+                                for (int q = 0; q < 8; q++)
+                                    if (r0b + scol + 2 * q < F) *reinterpret_cast<double2 *>(z + 2 * q) = make_double2(0.0, 0.0);
+                            }
+                        }
+                    }
+                }
+            }
+        } else
         for (int i = j + wave; i < nblk; i += 4) {
             const int i0 = 32 * i;
             d4_t acc[2][2];
@@ -377,14 +503,16 @@ chol_ll_kernel(const double *__restrict__ C, int F, double jitter_rel, double *_
             }
             // (the run-time test on nb keeps the 528 reads of D inside the row loop: without it they are hoisted in
             //  front of it as loop invariants - into 1000 registers, i.e. scratch)
+            // four partial sums per dot product: the 496 multiply-adds of a row are otherwise ONE dependent chain (8 cycles
+            // per link, nothing to overlap it with at one or two waves per SIMD)
 #pragma unroll
             for (int jj = 0; jj < CH_NB; jj++) {
                 if (jj < nb) {
-                    double s = x[jj];
+                    double s[4] = {x[jj], 0.0, 0.0, 0.0};
 #pragma unroll
                     for (int p = 0; p < CH_NB; p++)
-                        if (p < jj) s -= x[p] * D[jj * (CH_NB + 1) + p];
-                    x[jj] = s * rdiag[jj];
+                        if (p < jj) s[p & 3] = fma(-x[p], D[jj * (CH_NB + 1) + p], s[p & 3]);
+                    x[jj] = ((s[0] + s[1]) + (s[2] + s[3])) * rdiag[jj];
                 }
             }
 #pragma unroll
@@ -562,9 +690,17 @@ extern "C" int corahip_factor_batched(corahip_ctx *ctx, const double *C, int nl,
     StageTimer t(ctx, "factor");
     static const bool no_mfma = getenv("CORAHIP_K2_VALU") != nullptr;   // A/B: the VALU kernel for every size
     if (F >= 64 && (F % 2) == 0 && !no_mfma) {
-        const size_t shm = sizeof(double) * (CH_NB * (CH_NB + 1) + 256 + 2 + CH_NB + 4 * 2 * 32 * CHM_S) + 16;
-        HIP_TRY(hipFuncSetAttribute((const void *)chol_ll_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-        chol_ll_kernel<<<nl, 256, shm, ctx->stream>>>(C, F, jitter_rel, T, info);
+        // tall tiles + shared L_jk from F = 384 on (CORAHIP_K2_TALL=0 / 1 forces one form: A/B runs)
+        static const char *tall_env = getenv("CORAHIP_K2_TALL");
+        const bool tall = tall_env ? atoi(tall_env) != 0 : F >= 384;
+        const size_t shm = sizeof(double) * (CH_NB * (CH_NB + 1) + 256 + 2 + CH_NB + (tall ? 6 : 8) * 32 * CHM_S) + 16;
+        if (tall) {
+            HIP_TRY(hipFuncSetAttribute((const void *)chol_ll_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+            chol_ll_kernel<true><<<nl, 256, shm, ctx->stream>>>(C, F, jitter_rel, T, info);
+        } else {
+            HIP_TRY(hipFuncSetAttribute((const void *)chol_ll_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+            chol_ll_kernel<false><<<nl, 256, shm, ctx->stream>>>(C, F, jitter_rel, T, info);
+        }
         LAUNCH_CHECK();
     } else {
         const size_t shm = sizeof(double) * (CH_NB * (CH_NB + 1) + 2 * 64 * (CH_NB + 1) + 256) + 16;

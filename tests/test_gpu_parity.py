@@ -169,7 +169,26 @@ def test_factor_mfma_kernel_failure_path_and_ragged_sizes(ctx):
     psd = (v1 * np.where(e1 < e1.max() * 1e-16, 0.0, e1)) @ v1.T
     assert np.abs(T[1] @ T[1].T - psd).max() <= 1e-12 * np.abs(psd).max()
     assert np.all(T[2] == 0)
-    for F in (64, 66, 94, 130, 200):
+    # from F = 384 on the kernel takes its tall form (64-row wave tiles, the shared factor block staged once per
+    # workgroup): sizes with a partial last block row / an odd number of block rows, and its failure path
+    F = 400
+    A = rng.standard_normal((3, F, F + 5))
+    C = A @ A.transpose(0, 2, 1) + 0.1 * np.eye(F)
+    ev, evec = np.linalg.eigh(C[1])
+    ev[200] = -0.5
+    C[1] = (evec * ev) @ evec.T
+    C[1] = 0.5 * (C[1] + C[1].T)
+    T, info = ctx.factor_batched(ctx.to_device(C), jitter_rel=0.0)
+    T, info = T.cpu().numpy(), info.cpu().numpy()
+    assert list(info) == [0, 1, 0]
+    for k in (0, 2):
+        ref = np.linalg.cholesky(C[k])
+        assert np.abs(T[k] - ref).max() <= 1e-12 * np.abs(ref).max()
+        assert np.all(np.triu(T[k], 1) == 0)
+    e1, v1 = np.linalg.eigh(C[1])
+    psd = (v1 * np.where(e1 < e1.max() * 1e-16, 0.0, e1)) @ v1.T
+    assert np.abs(T[1] @ T[1].T - psd).max() <= 1e-11 * np.abs(psd).max()
+    for F in (64, 66, 94, 130, 200, 384, 390, 418, 450, 520):
         A = rng.standard_normal((2, F, F + 2))
         C = A @ A.transpose(0, 2, 1) + 0.05 * np.eye(F)
         T, info = ctx.factor_batched(ctx.to_device(C))   # (with the reference's jitter)
