@@ -62,6 +62,9 @@ struct corahip_sht_plan {
     std::vector<int32_t> h_blu3_P;                        // [nside]: 0 = none
     int64_t *d_blu3_foff = nullptr;
     double2 *d_bfilt3 = nullptr;
+    // fold phases of the cap rings for the compile-time Bluestein kernels: e^{i t phi0(ring)}, t < 512, and the steps
+    // e^{i 256 phi0}, e^{i 512 phi0}, by north-cap ring number i - 1
+    double2 *d_foldph = nullptr, *d_foldstep = nullptr;
     int max_fft_len = 0;                                  // largest LDS FFT buffer (complex elems)
     // K5 launch classes: rings grouped by transform kind/length so each launch sizes its LDS
     struct ring_class {

@@ -178,6 +178,19 @@ __global__ void k4_count_kernel(int lmax, int npair, int rt, const int32_t *__re
     for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o);
     if ((threadIdx.x & 63) == 0 && n) atomicAdd(out, n);
 }
+// e^{i t phi0} of north-cap ring blockIdx.x, t < 512, and the steps e^{i 256 phi0}, e^{i 512 phi0}: the expression
+// FrontEnd::fold (sht_ringfft_ct.hip) evaluated per item - phi0 / pi as the kernels form it, then sincospi
+__global__ void fold_phase_kernel(const double *__restrict__ phi0, double2 *__restrict__ ph, double2 *__restrict__ step) {
+    const int r = blockIdx.x, t = threadIdx.x;
+    const double pop = phi0[r] / M_PI;
+    double s, c;
+    sincospi((double)t * pop, &s, &c);
+    ph[(size_t)r * 512 + t] = make_double2(c, s);
+    if (t < 2) {
+        sincospi((double)(256 << t) * pop, &s, &c);
+        step[r * 2 + t] = make_double2(c, s);
+    }
+}
 // Bluestein tables for cap ring i (h = 2i not a power of two): chirp b_j = e^{i pi j^2/h}, j < h,
 // and filt = FFT_P(conj chirp wrapped), stored in the digit-reversed order fft_dif produces.
 __global__ void __launch_bounds__(256)
@@ -249,6 +262,8 @@ int corahip_sht_plan_destroy(corahip_ctx *ctx, corahip_sht_plan *p) {
     (void)hipFree(p->d_bfilt3);
     (void)hipFree(p->d_bchirp);
     (void)hipFree(p->d_bfilt);
+    (void)hipFree(p->d_foldph);
+    (void)hipFree(p->d_foldstep);
     for (auto &c : p->classes) (void)hipFree(c.d_list);
     delete p;
     return 0;
@@ -457,6 +472,12 @@ int corahip_sht_plan_create_ex(corahip_ctx *ctx, int nside, int lmax, int cut_ex
                                                                 p->d_bchirp, p->d_bfilt, p->d_tw, p->pmax, tl_off);
             LAUNCH_CHECK();
         }
+    }
+    HIP_TRY(hipMalloc((void **)&p->d_foldph, sizeof(double2) * 512 * (size_t)nside));
+    HIP_TRY(hipMalloc((void **)&p->d_foldstep, sizeof(double2) * 2 * (size_t)nside));
+    if (nside > 1) {
+        fold_phase_kernel<<<nside - 1, 512, 0, s>>>(p->d_phi0, p->d_foldph, p->d_foldstep);
+        LAUNCH_CHECK();
     }
     // 3 * 2^k Bluestein lengths for the compile-time synthesis kernels: 3 P / 4 where it still holds 2 h - 1
     {

@@ -239,7 +239,19 @@ struct FrontEnd {
     }
     static constexpr int KP = 4;
     double2 phk[KP];    // e^{i m phi0} at m = tid + k T, k < KP (the Bluestein pre-pass derives e^{i pi k / h} from them)
+    // fold with the phase computed here (two sincospi per thread and item: ~150 DP instructions)
     __device__ __forceinline__ void fold(double2 *sm, const double *__restrict__ cell, int Lr, int n, double phi0_over_pi, const int tid) {
+        double s, c;
+        // (sincospi reduces its argument exactly; an fmod in front of it - the generic kernel has one - is a
+        //  slow library loop: the fold took 6.7k cycles per item with it)
+        sincospi((double)tid * phi0_over_pi, &s, &c);
+        const double2 ph0 = make_double2(c, s);
+        sincospi((double)T * phi0_over_pi, &s, &c);
+        fold(sm, cell, Lr, n, ph0, make_double2(c, s), tid);
+    }
+    // fold with ph0 = e^{i tid phi0} and phstep = e^{i T phi0} given: a per-thread constant for the belt (phi0 takes two
+    // values there), a plan table for the cap rings (sht_plan.hip: fold_phase_kernel evaluates the same expression)
+    __device__ __forceinline__ void fold(double2 *sm, const double *__restrict__ cell, int Lr, int n, const double2 ph0, const double2 phstep, const int tid) {
         const int h = n >> 1;
         const bool noalias = Lr - 1 <= h;
         if (noalias) {
@@ -252,16 +264,7 @@ struct FrontEnd {
                 for (int c = 0; c < NCH; c++) sm[c * BS + fpad(j)] = make_double2(0.0, 0.0);
             __syncthreads();
         }
-        double2 ph, phstep;
-        {
-            double s, c;
-            // (sincospi reduces its argument exactly; an fmod in front of it - the generic kernel has one - is a
-            //  slow library loop: the fold took 6.7k cycles per item with it)
-            sincospi((double)tid * phi0_over_pi, &s, &c);
-            ph = make_double2(c, s);
-            sincospi((double)T * phi0_over_pi, &s, &c);
-            phstep = make_double2(c, s);
-        }
+        double2 ph = ph0;
         phk[0] = ph;
 #pragma unroll
         for (int k = 1; k < KP; k++) phk[k] = cmul(phk[k - 1], phstep);
@@ -330,6 +333,18 @@ ringfft_direct_ct(const int32_t *__restrict__ ring_list, int nlist, int lmax, in
         return inter + ((size_t)ring * G + (ch0 >> 2)) * L * 8 + (ch0 & 3);
     };
     FrontEnd<NCH, BS, MC, true, T> fe;
+    // fold phases e^{i m phi0}: phi0 of a belt ring is 0 or pi / (4 nside) = pi / (2 N) (sht_plan.hip), so e^{i tid phi0}
+    // and the step e^{i T phi0} are per-thread constants of the kernel (the same expressions FrontEnd::fold evaluates
+    // per item - two sincospi, ~150 DP instructions per thread and item, 7 % of the belt's cycles)
+    double2 phS, phstepS;
+    {
+        const double phs = (M_PI / (2.0 * N)) / M_PI;
+        double s, c;
+        sincospi((double)tid0 * phs, &s, &c);
+        phS = make_double2(c, s);
+        sincospi((double)T * phs, &s, &c);
+        phstepS = make_double2(c, s);
+    }
     int vitem = blockIdx.x;
     if (vitem < nitems) fe.prefetch(cell_ptr(ct_remap<NCH>(vitem, nitems)), L, tid0);
     fe.touch();   // (so that the prefetch is known to be complete on BOTH edges into the loop: no wait in the fold)
@@ -343,10 +358,14 @@ ringfft_direct_ct(const int32_t *__restrict__ ring_list, int nlist, int lmax, in
         const int ring = ring_list[item / ngrp];
         const int ch0 = (item % ngrp) * NCH;
         const long start = start_a[ring];
-        const double phi0_over_pi = phi0_a[ring] / M_PI;
+        const bool shifted = phi0_a[ring] != 0.0;         // (uniform) the ring starts at pi / (4 nside)
         const int Lr = mcut[ring];
         __syncthreads();                                  // previous item's LDS reads are done
-        fe.fold(sm, cell_ptr(item), Lr, n, phi0_over_pi, tid);
+        {
+            double2 p0 = shifted ? phS : make_double2(1.0, 0.0), p1 = shifted ? phstepS : make_double2(1.0, 0.0);
+            asm volatile("" : "+v"(p0.x), "+v"(p0.y), "+v"(p1.x), "+v"(p1.y));   // (not loop invariants: see tw_apply)
+            fe.fold(sm, cell_ptr(item), Lr, n, p0, p1, tid);
+        }
         // the next item's cells: two passes (~7k cycles) ahead of the store pass, in front of which they are waited for
         // (unconditional - the last iteration re-reads an item - so that the compiler can COUNT these loads in its
         //  vmcnt waits; behind an `if` it assumes they may be absent and waits for everything instead)
@@ -433,7 +452,7 @@ ringfft_blu_ct(const int32_t *__restrict__ ring_list, int nlist, int nside, int 
                const int32_t *__restrict__ nphi_a, const int64_t *__restrict__ start_a,
                const double *__restrict__ phi0_a, const double *inter, double *maps,
                const int64_t *__restrict__ boff, const int64_t *__restrict__ foff, const double2 *chirp,
-               const double2 *filt, const int32_t *__restrict__ mcut) {
+               const double2 *filt, const int32_t *__restrict__ mcut, const double2 *foldph, const double2 *foldstep) {
     // (inter, maps, chirp, filt are deliberately NOT __restrict__: the compiler then may not move their loads across the
     //  barriers / pixel stores, and the places where this kernel requests them - one phase ahead of their use, and all
     //  of them completed before the first store - are the places where they are issued; with __restrict__ the chirp
@@ -497,7 +516,6 @@ ringfft_blu_ct(const int32_t *__restrict__ ring_list, int nlist, int nside, int 
         const int n = nphi_a[ring];
         const int h = n >> 1;
         const long start = start_a[ring];
-        const double phi0_over_pi = phi0_a[ring] / M_PI;
         const int icap = ring + 1 < nside ? ring + 1 : 4 * nside - (ring + 1);
         const int Lr = mcut[ring];
         const double2 *bch = chirp + boff[icap - 1];
@@ -508,13 +526,17 @@ ringfft_blu_ct(const int32_t *__restrict__ ring_list, int nlist, int nside, int 
         double2 fl[R2];
 #pragma unroll
         for (int r = 0; r < (R2 + 1) / 2; r++) fl[r] = f[r];     // (second half behind the fold: spread requests)
+        // fold phases e^{i tid phi0}, e^{i T phi0} of this cap ring from the plan's table (the two sincospi they replace
+        // were ~150 DP instructions per thread and item); requested here, consumed behind the barrier
+        const double2 fph0 = foldph[(size_t)(icap - 1) * 512 + tid];
+        const double2 fphs = foldstep[(icap - 1) * 2 + (T == 512 ? 1 : 0)];
         // chirp b_k of the pre-pass pairs: fetched with the cells (one item ahead, before the previous item's stores)
         double2 cb[U];
 #pragma unroll
         for (int u = 0; u < U; u++) cb[u] = cbn[u];
         __syncthreads();                                  // previous item's LDS reads are done
         CTSTAMP(0);
-        fe.fold(sm, cell_ptr(item), Lr, n, phi0_over_pi, tid);
+        fe.fold(sm, cell_ptr(item), Lr, n, fph0, fphs, tid);
         CTSTAMP(1);
 #pragma unroll
         for (int r = (R2 + 1) / 2; r < R2; r++) fl[r] = f[r];
@@ -676,6 +698,10 @@ static int launch_direct(corahip_ctx *ctx, hipStream_t stream, int wg_per_cu, co
     const long nitems = (long)c.count * ((nnu + NCH - 1) / NCH);
     const int per_cu = wg_per_cu > 0 ? wg_per_cu : std::max<int>(1, (int)((160 * 1024) / shm));
     dim3 grid((unsigned)std::min<long>(nitems, (long)ctx->num_cu * per_cu));
+    // diagnostics (overlap table): the belt on fewer workgroups than CUs - it is HBM-bound, how many
+    // CUs does it need to stream at its rate?
+    static const char *belt_wgs = getenv("CORAHIP_K5_BELT_WGS");
+    if (belt_wgs && atoi(belt_wgs) > 0) grid.x = (unsigned)std::min<long>(grid.x, atol(belt_wgs));
     HIP_TRY(hipFuncSetAttribute((const void *)ringfft_direct_ct<N, NCH, MC, T>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 160 * 1024));
     ringfft_direct_ct<N, NCH, MC, T><<<grid, T, shm, stream>>>(c.d_list, c.count, p->lmax, G, nnu, p->npix, p->d_start,
@@ -700,7 +726,7 @@ static int launch_blu(corahip_ctx *ctx, hipStream_t stream, int wg_per_cu, const
                                 160 * 1024));
     ringfft_blu_ct<P, NCH, MC, T><<<grid, T, shm, stream>>>(c.d_list, c.count, p->nside, p->lmax, G, nnu, p->npix, p->d_nphi,
                                                             p->d_start, p->d_phi0, inter, maps, p->d_blu_boff,
-                                                            d_foff, p->d_bchirp, d_filt, p->d_mcut);
+                                                            d_foff, p->d_bchirp, d_filt, p->d_mcut, p->d_foldph, p->d_foldstep);
     LAUNCH_CHECK();
 #if CT_STAMPS
     {
