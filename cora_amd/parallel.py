@@ -9,7 +9,9 @@ a node of MI355X GPUs:
                   the rank's contiguous l range
   exchange        all-to-all of factor ROW blocks: rank r receives T_l[nu in its channels, :] for all
                   l - 1/N of the traffic and memory of an all-gather of the [L, F, F] stack
-                  (all-gather is kept for separable models and for F not divisible by N)
+                  (the all-gather is kept for F not divisible by N; separable models factor their one
+                  F x F block on every rank and exchange nothing); pack / unpack around the exchange are
+                  the C entry points of csrc/shard.hip, the same an MPI caller of the ABI uses
   stage B (warm)  nu-sharded: every rank generates the same global normal stream (counter-based,
                   so it is a function of (seed, position) only), draws a_lm for its own channels
                   and synthesises them; maps stay on the rank that made them (the reference's
