@@ -754,7 +754,10 @@ int sht_ringfft_ct(corahip_ctx *ctx, const corahip_sht_plan *p, const corahip_sh
     int rc = -1;
     hipStream_t st = ctx->stream;
     if (c.P == 0) {
-        if (c.N == 2048) rc = launch_direct<2048, 4, 4, 512>(ctx, st, 0, p, c, inter, G, nnu, maps);
+        // A/B: the belt as 2-channel items of 256 threads, TWO workgroups (78 KB each) per CU
+        static const bool belt2 = getenv("CORAHIP_K5_BELT2") != nullptr;
+        if (c.N == 2048 && belt2) rc = launch_direct<2048, 2, 8, 256>(ctx, st, 2, p, c, inter, G, nnu, maps);
+        else if (c.N == 2048) rc = launch_direct<2048, 4, 4, 512>(ctx, st, 0, p, c, inter, G, nnu, maps);
         else if (c.N == 4096) rc = launch_direct<4096, 2, 8, 512>(ctx, st, 0, p, c, inter, G, nnu, maps);
         else return 0;
     } else {
@@ -765,6 +768,7 @@ int sht_ringfft_ct(corahip_ctx *ctx, const corahip_sht_plan *p, const corahip_sh
         else if (c.P3 == 3072 && !no3) rc = launch_blu<3072, 2, 4, 512>(ctx, st, 0, p, c, inter, G, nnu, maps, p->d_blu3_foff, p->d_bfilt3);
         else if (c.P3 == 1536 && !no3) rc = launch_blu<1536, 4, 2, 512>(ctx, st, 0, p, c, inter, G, nnu, maps, p->d_blu3_foff, p->d_bfilt3);
         else if (c.P == 4096) rc = launch_blu<4096, 2, 4, 512>(ctx, st, 0, p, c, inter, G, nnu, maps);
+        else if (c.P == 2048 && half) rc = launch_blu<2048, 2, 4, 256>(ctx, st, 2, p, c, inter, G, nnu, maps);   // A/B: 2-channel items, two per CU
         else if (c.P == 2048) rc = launch_blu<2048, 4, 2, 512>(ctx, st, 0, p, c, inter, G, nnu, maps);
         else if (c.P == 1024) rc = launch_blu<1024, 4, 2, 256>(ctx, st, 0, p, c, inter, G, nnu, maps);   // (256 threads, two workgroups per CU: 0.61 -> 0.54 ms)
         else return 0;
