@@ -340,7 +340,7 @@ def main():
                 "frac": (16.0 * (4 * nside - 1) * L * nnu + 8.0 * npix * nnu) / (stages.get("ringfft", {"ms_per_launch": float("nan")})["ms_per_launch"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
             },
             # every stage against the roof that bounds it (algorithmic work of SURVEY 8(d) / DESIGN section 3 per launch)
-            "stage_rooflines": stage_rooflines(stages, nside, lmax, F, nnu, zromb, flops_exec),
+            "stage_rooflines": stage_rooflines(stages, nside, lmax, F, nnu, zromb, flops_exec, nu0),
             "hbm_roofline_whole_step": {
                 "algorithmic_GB": alg_bytes / 1e9,
                 "achieved_GBs": alg_bytes / 1e9 / (ms_step * 1e-3),
@@ -358,7 +358,7 @@ def main():
     return result
 
 
-def stage_rooflines(stages, nside, lmax, F, nnu, zromb, legendre_executed_flops):
+def stage_rooflines(stages, nside, lmax, F, nnu, zromb, legendre_executed_flops, nu0=0):
     L = lmax + 1
     nalm = L * (L + 1) // 2
     npix = 12 * nside * nside
@@ -367,7 +367,9 @@ def stage_rooflines(stages, nside, lmax, F, nnu, zromb, legendre_executed_flops)
         # name: (bound, algorithmic flops, algorithmic bytes)
         "clarray": ("valu", 60.0 * L * (F * zint) ** 2 / 2, 8.0 * L * F * F),
         "factor": ("valu", L * F**3 / 3.0, 16.0 * L * F * F),
-        "draw": ("mfma", 2.0 * F * nnu * nalm, 8.0 * L * F * nnu + 16.0 * nalm * nnu),
+        # triangular factors: channel nu takes nu + 1 columns, re and im: 4 nalm sum_{nu in the shard} (nu + 1) flop
+        # (2 F^2 nalm for all channels; the LAST rank of a frequency shard has nearly full rows - twice the average)
+        "draw": ("mfma", 4.0 * nalm * nnu * (nu0 + 0.5 * (nnu + 1)), 8.0 * L * F * nnu + 16.0 * nalm * nnu),
         # (executed flops: the plan's MFMA count, see `roofline`)
         "legendre": ("mfma", legendre_executed_flops, 16.0 * nalm * nnu + 16.0 * (4 * nside - 1) * L * nnu),
         "ringfft": ("hbm", 2.5 * npix * np.log2(4 * nside) * nnu, 16.0 * (4 * nside - 1) * L * nnu + 8.0 * npix * nnu),
