@@ -134,6 +134,11 @@ legendre_kernel(int lmax, int npair, int nring, int ncols, const double *__restr
         const double *src = (l <= lmax) ? reinterpret_cast<const double *>(coef + w.base_m + l) : zeros;
         const unsigned dst = lds_base_bytes + (unsigned)(((st % LEG_NBUF) * STAGE + LEG_KT * STRIDE) * sizeof(double));
         if (lane < CROWS) glds16(src, dst);
+        if constexpr (CROWS > 64) {            // (stages of 64 rows: the 72 coefficient rows take a second instruction)
+            const int l2 = l + 64;
+            const double *src2 = (l2 <= lmax) ? reinterpret_cast<const double *>(coef + w.base_m + l2) : zeros;
+            if (lane < CROWS - 64) glds16(src2, dst + 64 * 16);
+        }
     };
     auto issue_stage = [&](const item_t &w, int st) {
         issue_coef(w, st);
