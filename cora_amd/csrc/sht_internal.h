@@ -46,6 +46,11 @@ struct corahip_sht_plan {
     double2 *d_coef = nullptr;                            // [nalm]: (A_l, B_l) at alm_idx(l,m)
     int32_t *d_lstart = nullptr;                          // [L][npair]
     double2 *d_seed = nullptr;                            // [L][npair]: (lambda_{lstart-1}, lambda_{lstart})
+    // the scalar synthesis kernel runs the recurrence in its two-instruction form mu_l = (alpha_l x) mu_{l-1} - mu_{l-2},
+    // lambda_l = s_l mu_l (s_m = s_{m+1} = 1, s_l = B_l s_{l-2}, alpha_l = A_l s_{l-1} / s_l): its own coefficient and
+    // seed tables (the spin-2 and the analysis kernels keep the (A, B) form)
+    double2 *d_coefmu = nullptr;                          // [nalm]: (alpha_l, s_l) at alm_idx(l,m)
+    double2 *d_seedmu = nullptr;                          // [L][npair]: (mu_{lstart-1}, mu_{lstart})
     int32_t *d_lmin = nullptr;                            // [L][ntile] first l per (m, ring tile)
     unsigned *d_queue = nullptr;                          // K4 work-queue head
     int32_t *d_mcut = nullptr;                            // [nring] number of m with any non-negligible lambda_lm

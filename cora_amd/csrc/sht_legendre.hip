@@ -22,6 +22,11 @@
 // (odd).  No cross-lane movement, no selects; the price is that the recurrence coefficients are
 // no longer wave-uniform (4 distinct rows per step) - they are staged through LDS with the a_lm
 // rows and read with one broadcast ds_read_b128 per step.
+// The recurrence runs in its SCALED two-instruction form (round 3): lambda_l = s_l mu_l with s_m = s_{m+1} = 1,
+// s_l = B_l s_{l-2}, so that  mu_l = (alpha_l x) mu_{l-1} - mu_{l-2},  alpha_l = A_l s_{l-1} / s_l  - a multiply and an
+// fma per step instead of two multiplies and an fma - and only the two values a lane feeds to the MFMAs are scaled back
+// (lambda = s mu): 18 instead of 24 DP instructions per macro-step.  `coef` holds (alpha_l, s_l), `seed` the mu pair at
+// the first contributing l (sht_plan.hip: d_coefmu, d_seedmu); rows past lmax are zeros: s = 0 makes their A operand 0.
 // NT = 16-column tiles per wave, RT = 16-ring row tiles per wave (RT x NT x 2 parities = 16 accumulator
 // tiles = 128 VGPRs in both shipped shapes: <8,1> for >= 128 columns, <4,2> for 64-column shards, where a
 // second, independent recurrence per lane keeps the recurrence : MFMA ratio of the wide shape).
@@ -218,7 +223,7 @@ legendre_kernel(int lmax, int npair, int nring, int ncols, const double *__restr
                     p1[q] = sd[q].y;
                     for (int l = my_ls[q] + 1; l < lf; l++) {
                         const double2 c = (l <= lmax) ? cf[l] : make_double2(0.0, 0.0);
-                        const double vv = fma(c.x * x[q], p1[q], -(c.y * p0[q]));
+                        const double vv = fma(c.x * x[q], p1[q], -p0[q]);        // scaled form: see the lane-role note
                         p0[q] = p1[q];
                         p1[q] = vv;
                     }
@@ -567,7 +572,7 @@ static int launch_legendre(corahip_ctx *ctx, const corahip_sht_plan *p, int ncol
     dim3 grid((unsigned)std::min<long>(nitems, (long)ctx->num_cu * per_cu));
     HIP_TRY(hipMemsetAsync(p->d_queue, 0, 1024, ctx->stream));
     legendre_kernel<NT, RT><<<grid, 64 * LEG_WAVES, shm, ctx->stream>>>(p->lmax, p->npair, p->nring, ncols, p->d_z,
-                                                                       p->d_coef, p->d_lstart, p->d_seed, p->d_lmin,
+                                                                       p->d_coefmu, p->d_lstart, p->d_seedmu, p->d_lmin,
                                                                        alm, p->d_zeros, inter, p->d_queue);
     LAUNCH_CHECK();
     return 0;

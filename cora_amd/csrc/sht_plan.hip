@@ -51,7 +51,8 @@ __device__ static inline void scaled_pow(double s, int n, double &mant, int &ex)
 // the two recurrence values there; terms below (< 8.3e-25 at the default) are dropped (libsharp does the same).
 __global__ void seed_kernel(int lmax, int npair, int min_exp, const double *__restrict__ z, const double *__restrict__ sth,
                             const double *__restrict__ pref, const double2 *__restrict__ coef,
-                            int32_t *__restrict__ lstart, double2 *__restrict__ seed) {
+                            const double2 *__restrict__ coefmu, int32_t *__restrict__ lstart, double2 *__restrict__ seed,
+                            double2 *__restrict__ seedmu) {
     int r = blockIdx.x * blockDim.x + threadIdx.x;
     int m = blockIdx.y;
     if (r >= npair) return;
@@ -67,6 +68,7 @@ __global__ void seed_kernel(int lmax, int npair, int min_exp, const double *__re
     if (sc >= min_exp) {
         lstart[o] = m;
         seed[o] = make_double2(0.0, ldexp(mant, sc));
+        seedmu[o] = make_double2(0.0, ldexp(mant, sc));     // s_m = 1
         return;
     }
     const double2 *cf = coef + alm_idx(0, m, lmax);
@@ -92,27 +94,31 @@ __global__ void seed_kernel(int lmax, int npair, int min_exp, const double *__re
     }
     lstart[o] = found;
     seed[o] = make_double2(s0, s1);
+    // the same pair in the scaled form of the synthesis kernel: mu_l = lambda_l / s_l
+    const double2 *cm = coefmu + alm_idx(0, m, lmax);
+    seedmu[o] = found <= lmax ? make_double2(s0 / cm[found - 1].y, s1 / cm[found].y) : make_double2(0.0, 0.0);
 }
 
-// test hook: lambda_lm for one (m, ring pair), l = m..lmax
+// test hook: lambda_lm for one (m, ring pair), l = m..lmax, as the synthesis kernel forms them: the scaled recurrence
+// mu_l = (alpha_l x) mu_{l-1} - mu_{l-2} from the mu seeds, lambda_l = s_l mu_l
 __global__ void lambda_kernel(int lmax, int npair, int m, int r, const double *__restrict__ z,
-                              const double2 *__restrict__ coef, const int32_t *__restrict__ lstart,
-                              const double2 *__restrict__ seed, double *__restrict__ out) {
+                              const double2 *__restrict__ coefmu, const int32_t *__restrict__ lstart,
+                              const double2 *__restrict__ seedmu, double *__restrict__ out) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     double x = z[r];
     long o = (long)m * npair + r;
     int ls = lstart[o];
-    double2 sd = seed[o];
-    const double2 *cf = coef + alm_idx(0, m, lmax);
+    double2 sd = seedmu[o];
+    const double2 *cf = coefmu + alm_idx(0, m, lmax);
     double p0 = 0.0, p1 = 0.0;
     for (int l = m; l <= lmax; l++) {
         double2 c = cf[l];
-        double v = fma(c.x * x, p1, -(c.y * p0));
+        double v = fma(c.x * x, p1, -p0);
         bool inj = (l == ls);
         v = inj ? sd.y : v;
         p0 = inj ? sd.x : p1;
         p1 = v;
-        out[l - m] = v;
+        out[l - m] = l >= ls ? v * c.y : 0.0;
     }
 }
 // per ring: mcut = number of m (from 0) whose lambda_lm reach the plan's cut for some l <= lmax; F_m of the ring
@@ -249,6 +255,8 @@ int corahip_sht_plan_destroy(corahip_ctx *ctx, corahip_sht_plan *p) {
     (void)hipFree(p->d_coef);
     (void)hipFree(p->d_lstart);
     (void)hipFree(p->d_seed);
+    (void)hipFree(p->d_coefmu);
+    (void)hipFree(p->d_seedmu);
     (void)hipFree(p->d_tw);
     (void)hipFree(p->d_zeros);
     (void)hipFree(p->d_lmin);
@@ -394,6 +402,27 @@ int corahip_sht_plan_create_ex(corahip_ctx *ctx, int nside, int lmax, int cut_ex
             }
         }
         if ((rc = dev_upload(&p->d_coef, coef, s))) return rc;
+        // scaled form: s_m = s_{m+1} = 1, s_l = B_l s_{l-2}; alpha_l = A_l s_{l-1} / s_l (alpha_m = 0: never used, the
+        // recurrence starts from the seed at l >= m).  s_l stays within [~0.15, 1] (it tends to sqrt(A_inf / A_{m+1})).
+        std::vector<double2> cmu(p->nalm + 32, make_double2(0.0, 0.0));
+        for (int m = 0; m <= lmax; m++) {
+            long double aprev = 0.0L, s1 = 1.0L, s2 = 1.0L;    // A_{l-1}, s_{l-1}, s_{l-2}
+            for (int l = m; l <= lmax; l++) {
+                const long o = alm_idx(l, m, lmax);
+                if (l == m) {
+                    cmu[o] = make_double2(0.0, 1.0);
+                    continue;
+                }
+                const long double ll = l, mm = m;
+                const long double al = sqrtl((4.0L * ll * ll - 1.0L) / (ll * ll - mm * mm));
+                const long double sl = l == m + 1 ? 1.0L : (al / aprev) * s2;
+                cmu[o] = make_double2((double)(al * s1 / sl), (double)sl);
+                aprev = al;
+                s2 = s1;
+                s1 = sl;
+            }
+        }
+        if ((rc = dev_upload(&p->d_coefmu, cmu, s))) return rc;
     }
     // |lambda_mm| prefactor sqrt((2m+1)!!/(4 pi (2m)!!))
     double *d_pref = nullptr;
@@ -409,9 +438,11 @@ int corahip_sht_plan_create_ex(corahip_ctx *ctx, int nside, int lmax, int cut_ex
     }
     HIP_TRY(hipMalloc((void **)&p->d_lstart, sizeof(int32_t) * (size_t)p->L * p->npair));
     HIP_TRY(hipMalloc((void **)&p->d_seed, sizeof(double2) * (size_t)p->L * p->npair));
+    HIP_TRY(hipMalloc((void **)&p->d_seedmu, sizeof(double2) * (size_t)p->L * p->npair));
     {
         dim3 grid((p->npair + 63) / 64, p->L);
-        seed_kernel<<<grid, 64, 0, s>>>(lmax, p->npair, cut_exp, p->d_z, p->d_sth, d_pref, p->d_coef, p->d_lstart, p->d_seed);
+        seed_kernel<<<grid, 64, 0, s>>>(lmax, p->npair, cut_exp, p->d_z, p->d_sth, d_pref, p->d_coef, p->d_coefmu, p->d_lstart,
+                                        p->d_seed, p->d_seedmu);
         LAUNCH_CHECK();
     }
     {
@@ -577,8 +608,8 @@ int corahip_sht_plan_ring_classes(const corahip_sht_plan *p, int32_t *host_len) 
 int corahip_sht_lambda(corahip_ctx *ctx, const corahip_sht_plan *p, int m, int ring_pair, double *out) {
     ARG_CHECK(ctx != nullptr && p != nullptr && out != nullptr);
     ARG_CHECK(m >= 0 && m <= p->lmax && ring_pair >= 0 && ring_pair < p->npair);
-    lambda_kernel<<<1, 64, 0, ctx->stream>>>(p->lmax, p->npair, m, ring_pair, p->d_z, p->d_coef, p->d_lstart,
-                                             p->d_seed, out);
+    lambda_kernel<<<1, 64, 0, ctx->stream>>>(p->lmax, p->npair, m, ring_pair, p->d_z, p->d_coefmu, p->d_lstart,
+                                             p->d_seedmu, out);
     LAUNCH_CHECK();
     return 0;
 }
