@@ -152,7 +152,8 @@ __global__ void lmin_kernel(int lmax, int npair, int ntile, const int32_t *__res
 // launch (tests/test_gpu_fullsize.py checks it against the committed PMC profile): the roofline fraction of K4 is
 // priced on it, not on the algorithmic 8 nside nalm F of SURVEY 8(d), which counts terms nobody has to compute.
 __global__ void k4_count_kernel(int lmax, int npair, int rt, const int32_t *__restrict__ lstart,
-                                const int32_t *__restrict__ lmin_tab, unsigned long long *__restrict__ out) {
+                                const int32_t *__restrict__ lmin_tab, unsigned long long *__restrict__ out,
+                                unsigned long long *__restrict__ out_clean) {
     const int trings = LEG_RINGS * rt;
     const int ntile = (npair + trings - 1) / trings;
     const int ntile128 = (npair + LMIN_RINGS - 1) / LMIN_RINGS;
@@ -178,6 +179,28 @@ __global__ void k4_count_kernel(int lmax, int npair, int rt, const int32_t *__re
             const int need = ws_min - 7 - l_begin;                 // l0 >= ws_min - 7
             const int k_min = need > 0 ? (need + 7) / 8 : 0;
             if (k_max >= k_min) n = (unsigned long long)(k_max - k_min + 1);
+            if (out_clean) {
+                // macro-steps of this wave that run in the test-free steady-state stages (sht_legendre.hip: stage_lo && st < st_hi);
+                // row_limit is not restated: it only matters for the last m's
+                const int KT = LEG_KT;
+                const int nstage = (lmax - l_begin) / KT + 1;
+                const int st_hi = min((lmax - l_begin + 1) / KT, nstage - LEG_NBUF + 1);
+                // ws_maxinj: the last first-contributing l of the wave's rings that lies at or after l_begin + (stagger): bound it by the max lstart <= lmax
+                int ws_max = -1;
+                for (int j = 0; j < 16 * rt; j++) {
+                    const int ring = tile * trings + j * LEG_WAVES + wave;
+                    if (ring < npair) {
+                        const int ls = lstart[(long)m * npair + ring];
+                        if (ls <= lmax) ws_max = max(ws_max, ls);
+                    }
+                }
+                unsigned long long nc = 0;
+                for (int st = 0; st < st_hi; st++) {
+                    const int ls0 = l_begin + st * KT;
+                    if (ws_min <= ls0 && ws_max < ls0) nc += KT / 8;
+                }
+                if (nc) atomicAdd(out_clean, nc);     // (diagnostics only: one atomic per thread, divergent code - no wave reduction here)
+            }
         }
     }
     // wave-level sum, one atomic per wave
@@ -298,14 +321,21 @@ int corahip_sht_plan_k4_mfma_count(corahip_ctx *ctx, const corahip_sht_plan *p, 
     if (it == p->k4_macro_steps.end()) {
         HIP_TRY(hipSetDevice(ctx->device));
         unsigned long long *d_n = nullptr, h_n = 0;
-        HIP_TRY(hipMalloc((void **)&d_n, sizeof(h_n)));
-        HIP_TRY(hipMemsetAsync(d_n, 0, sizeof(h_n), ctx->stream));
+        HIP_TRY(hipMalloc((void **)&d_n, 2 * sizeof(h_n)));
+        HIP_TRY(hipMemsetAsync(d_n, 0, 2 * sizeof(h_n), ctx->stream));
+        static const bool dbg = getenv("CORAHIP_K4_COUNT_DEBUG") != nullptr;   // diagnostics: share of the steady-state stages
         const int ntile = (p->npair + LEG_RINGS * RT - 1) / (LEG_RINGS * RT);
         const long total = (long)p->L * ntile * LEG_WAVES;
-        k4_count_kernel<<<(unsigned)((total + 255) / 256), 256, 0, ctx->stream>>>(p->lmax, p->npair, RT, p->d_lstart, p->d_lmin, d_n);
+        k4_count_kernel<<<(unsigned)((total + 255) / 256), 256, 0, ctx->stream>>>(p->lmax, p->npair, RT, p->d_lstart, p->d_lmin, d_n, dbg ? d_n + 1 : nullptr);
         LAUNCH_CHECK();
         HIP_TRY(hipMemcpyAsync(&h_n, d_n, sizeof(h_n), hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(hipStreamSynchronize(ctx->stream));
+        if (dbg) {
+            unsigned long long h_c = 0;
+            HIP_TRY(hipMemcpy(&h_c, d_n + 1, sizeof(h_c), hipMemcpyDeviceToHost));
+            fprintf(stderr, "K4 macro-steps per column group (RT %d): %llu executed, %llu of them in steady-state stages (%.3f)\n", RT,
+                    h_n, h_c, (double)h_c / (double)std::max<unsigned long long>(h_n, 1));
+        }
         (void)hipFree(d_n);
         it = const_cast<corahip_sht_plan *>(p)->k4_macro_steps.emplace(RT, (uint64_t)h_n).first;
     }
