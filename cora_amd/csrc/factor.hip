@@ -198,6 +198,15 @@ chol_kernel(const double *__restrict__ C, int F, double jitter_rel, double *__re
 // 0.62, copy-in 0.5 ms.
 // ------------------------------------------------------------------------------------
 #define CHM_S 34    // doubles per staged block row
+#ifndef CHM_STAMPS
+#define CHM_STAMPS 0   // diagnostic build (make k2stamps): s_memtime per phase of chol_ll_kernel, summed over the waves
+#endif
+#if CHM_STAMPS
+__device__ unsigned long long g_chm_stamps[8];
+#define CSTAMP(k) { unsigned long long _t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)::"memory"); c_acc[k] += _t - c_last; c_last = _t; }
+#else
+#define CSTAMP(k)
+#endif
 #ifndef CHM_ABLATE
 #define CHM_ABLATE 0   // diagnostic builds (wrong results): 1 no diagonal-block factorisation, 2 no panel solve, 3 no MFMA updates
 #endif
@@ -242,6 +251,10 @@ chol_ll_kernel(const double *__restrict__ C, int F, double jitter_rel, double *_
     const double jit = red[0] * jitter_rel;
     __syncthreads();
 
+#if CHM_STAMPS
+    unsigned long long c_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, c_last;
+    { unsigned long long _t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)::"memory"); c_last = _t; }
+#endif
     const int nblk = (F + 31) / 32;
     // this lane's part of a 32 x 32 block moved as rows: half a row (16 doubles) = row (lane >> 1), columns 16 (lane & 1) ..
     const int srow = lane >> 1, scol = 16 * (lane & 1);
@@ -406,7 +419,8 @@ chol_ll_kernel(const double *__restrict__ C, int F, double jitter_rel, double *_
                         load_block(kb, 32 * (k + 1), vb);
                     }
                     // (wave-private LDS: the ds_writes above complete before the reads below, and these before the next
-                    //  k-step's writes - one wave, in order)
+                    //  k-step's writes - one wave, in order.  Requesting the blocks TWO k-steps ahead - two register sets,
+                    //  248 VGPRs - was measured: 14.6 / 7.36 / 1.73 against 14.4 / 7.32 / 1.70 ms, nothing)
 #pragma unroll
                     for (int s = 0; s < 8; s++) {
                         double af[2], bf[2];
@@ -448,7 +462,9 @@ chol_ll_kernel(const double *__restrict__ C, int F, double jitter_rel, double *_
                 }
             }
         }
+        CSTAMP(0);           // A: tile initialisation, update loop, tile stores
         __syncthreads();
+        CSTAMP(1);           // barrier behind A
         // ---- B. factor the diagonal block with ONE wave, row i of the block in the registers of lane i
         if (tid < 64 && CHM_ABLATE != 1) {
             auto bcast = [](double v, int src) {
@@ -484,7 +500,9 @@ chol_ll_kernel(const double *__restrict__ C, int F, double jitter_rel, double *_
                 if (lane < nb && k <= lane) D[lane * (CH_NB + 1) + k] = row[k];
             if (bad && lane == 0) *flag = 1;
         }
+        CSTAMP(2);           // B (one wave; the others arrive at once)
         __syncthreads();
+        CSTAMP(3);           // barrier behind B = the three idle waves' wait for the diagonal block
         if (*flag) break;
         for (int q = tid; q < nb * nb; q += 256) {      // L_jj and the zeros above its diagonal
             const int i = q / nb, jj = q % nb;
@@ -518,9 +536,17 @@ chol_ll_kernel(const double *__restrict__ C, int F, double jitter_rel, double *_
 #pragma unroll
             for (int jj = 0; jj < CH_NB; jj += 2) *reinterpret_cast<double2 *>(row + jj) = make_double2(x[jj], x[jj + 1]);
         }
+        CSTAMP(4);           // C: diagonal block store + panel solve
         __syncthreads();  // the block column is final and visible to the whole workgroup (same CU, write-through L1)
+        CSTAMP(5);           // barrier behind C
     }
     if (tid == 0) info[blockIdx.x] = *flag;
+#if CHM_STAMPS
+    if (lane == 0) {
+        for (int k = 0; k < 6; k++) atomicAdd(&g_chm_stamps[k], c_acc[k]);
+        atomicAdd(&g_chm_stamps[7], 1ull);
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------
@@ -702,6 +728,17 @@ extern "C" int corahip_factor_batched(corahip_ctx *ctx, const double *C, int nl,
             chol_ll_kernel<false><<<nl, 256, shm, ctx->stream>>>(C, F, jitter_rel, T, info);
         }
         LAUNCH_CHECK();
+#if CHM_STAMPS
+        {
+            unsigned long long hs[8], z[8] = {0};
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
+            HIP_TRY(hipMemcpyFromSymbol(hs, HIP_SYMBOL(g_chm_stamps), sizeof(hs)));
+            const double per = 1.0 / (double)std::max<unsigned long long>(hs[7], 1);
+            fprintf(stderr, "K2 F=%d nl=%d tall=%d: cycles/wave  A %.0f  bar %.0f  B %.0f  bar %.0f  C %.0f  bar %.0f\n", F, nl, (int)tall,
+                    hs[0] * per, hs[1] * per, hs[2] * per, hs[3] * per, hs[4] * per, hs[5] * per);
+            HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_chm_stamps), z, sizeof(z)));
+        }
+#endif
     } else {
         const size_t shm = sizeof(double) * (CH_NB * (CH_NB + 1) + 2 * 64 * (CH_NB + 1) + 256) + 16;
         chol_kernel<<<nl, 256, shm, ctx->stream>>>(C, F, jitter_rel, T, info);
