@@ -1183,6 +1183,29 @@ def test_c_abi_with_ctypes_only_no_torch(tmp_path, golden):
         assert np.abs(got - a1).max() <= 1e-12 * np.abs(a1).max()
 
 
+def test_factor_rows_pack_unpack_kernels(ctx):
+    """corahip_factor_rows_pack / _unpack (csrc/shard.hip) against the permutation they implement, including an
+    empty l block (a rank with no multipoles), uneven blocks and an odd row length."""
+    import torch
+
+    for F, world, counts in ((8, 2, [3, 2]), (12, 4, [2, 0, 3, 1]), (6, 3, [1, 1, 1]), (10, 5, [4, 4, 0, 0, 1])):
+        nnu, l_stride, L = F // world, max(max(counts), 1), sum(counts)
+        gen = torch.Generator(device=ctx.device).manual_seed(F)
+        blocks = [torch.randn((c, F, F), generator=gen, device=ctx.device, dtype=torch.float64) for c in counts]
+        sends = [ctx.factor_rows_pack(b, l_stride, world) for b in blocks]            # what every rank would send
+        for r, (b, sd) in enumerate(zip(blocks, sends)):
+            want = torch.zeros((world, l_stride, nnu, F), device=ctx.device, dtype=torch.float64)
+            for q in range(world):
+                want[q, : counts[r]] = b[:, q * nnu:(q + 1) * nnu, :]
+            assert torch.equal(sd, want), (F, world, r)
+        full = torch.cat(blocks, dim=0)                                                 # [L, F, F]
+        for q in range(world):                                                          # what rank q receives: slab q of every rank
+            recv = torch.stack([sd[q] for sd in sends]).contiguous()
+            T_rows = ctx.factor_rows_unpack(recv, counts)
+            assert tuple(T_rows.shape) == (L, nnu, F)
+            assert torch.equal(T_rows, full[:, q * nnu:(q + 1) * nnu, :]), (F, world, q)
+
+
 def test_c_abi_sharded_mkfullsky_two_processes_no_torch(tmp_path, golden):
     """The sharded path through the C ABI alone (corahip_shard_plan, corahip_factor_rows_pack / _unpack,
     corahip_draw_alm_philox_rows): tools/abi_shard_demo.py runs mkfullsky on an
