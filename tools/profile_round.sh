@@ -4,7 +4,7 @@
 # profiles/<tag>_pmc.json (per-kernel HBM bytes per launch, GB/s, MFMA instructions).
 # usage (on the GPU box, from the repo root): bash tools/profile_round.sh <tag>
 export TMPDIR=/tmp
-TAG=${1:-r02}
+TAG=${1:-r03}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd $GRAFT_REPO_ROOT
