@@ -70,6 +70,8 @@ def allgather_channels(shard, F):
     import torch
     import torch.distributed as dist
 
+    if shard.is_complex():     # (the collectives move real numbers: RCCL has no complex type)
+        return torch.view_as_complex(allgather_channels(torch.view_as_real(shard).contiguous(), F))
     world = dist.get_world_size()
     nmax = (F + world - 1) // world
     pad = torch.zeros((nmax,) + tuple(shard.shape[1:]), dtype=shard.dtype, device=shard.device)

@@ -121,6 +121,9 @@ def _worker_chan(rank, world, port, q):
         p = shard_plan(5, F, rank, world)
         got = allgather_channels(full[p.nu0:p.nu0 + p.nnu].clone(), F)
         ok = ok and bool(torch.equal(got, full))
+        cfull = torch.complex(full, -2.0 * full)       # the a_lm squares are complex128
+        got = allgather_channels(cfull[p.nu0:p.nu0 + p.nnu].clone(), F)
+        ok = ok and bool(torch.equal(got, cfull))
     q.put((rank, ok))
     dist.destroy_process_group()
 
