@@ -41,6 +41,7 @@ SIGNATURES = {
                                                 PTR, PTR, PTR, PTR, c_int, c_int, PTR, PTR, c_int, c_int, c_int, c_int,
                                                 PTR]),
     "corahip_clarray_pairs_finish": (c_int, [c_void_p, PTR, c_int, c_int, c_int, c_int, PTR]),
+    "corahip_clarray_tables_pin": (c_int, [c_void_p, PTR, PTR, PTR, c_u64]),
     "corahip_aps_table21cm_points": (c_int, [c_void_p, PTR, PTR, PTR, c_int, c_int, c_double, c_double, c_double,
                                              ctypes.c_long, PTR, PTR, PTR, PTR, PTR, PTR, PTR]),
     "corahip_clarray_separable": (c_int, [c_void_p, PTR, c_int, PTR, c_int, c_int, PTR, PTR]),
@@ -241,6 +242,11 @@ class Context:
         return host.numpy()
 
     # -- K1 ---------------------------------------------------------------------------
+    def pin_tables(self, dd, dv, vv, generation):
+        """The 21cm tables (dd, dv, vv) stay as they are under this generation number: K1 keeps its transposed copy
+        of them between calls (corahip_clarray_tables_pin).  The model that owns the tables calls this."""
+        _check(self.lib.corahip_clarray_tables_pin(self.h, self._f64(dd), self._f64(dv), self._f64(vv), c_u64(int(generation))))
+
     def clarray_table21cm(self, dd, dv, vv, kperpmin, kperpmax, kparmax, chi, pfd, f, b, F, zint, w, log10l):
         nl = log10l.numel()
         out = self.empty((nl, F, F))

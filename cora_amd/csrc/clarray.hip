@@ -386,10 +386,14 @@ static int clarray21_pairs(corahip_ctx *ctx, const double *dd, const double *dv,
         memcpy(ctx->pairs_key, key, sizeof(key));
         ctx->pairs_ptr = (void *)dpairs;
     }
-    {
+    // the x-contiguous copy of the tables: made on every call unless the caller has pinned exactly these tables
+    // (corahip_clarray_tables_pin) and the copy of that generation is still the one in the scratch slot
+    const bool pinned = ctx->tt_pinned && ctx->tt_pin[0] == dd && ctx->tt_pin[1] == dv && ctx->tt_pin[2] == vv;
+    if (!(pinned && ctx->tt_valid && ctx->scratch_bytes[0] == tt_bytes)) {
         dim3 grid((nkpar + 31) / 32, CL_XS / 32, 3);
         cl_transpose_kernel<<<grid, 256, 0, ctx->stream>>>(dd, dv, vv, nkperp, nkpar, tt);
         LAUNCH_CHECK();
+        ctx->tt_valid = pinned;
     }
     const double xscale = (double)(nkperp - 1) / log10(kperpmax / kperpmin);
     const double yscale = kparmax / M_PI;
@@ -401,6 +405,20 @@ static int clarray21_pairs(corahip_ctx *ctx, const double *dd, const double *dv,
                                                           log10l, nl, l_base, dpairs, out_pairs, nl, l_block);
         LAUNCH_CHECK();
     }
+    return 0;
+}
+
+int corahip_clarray_tables_pin(corahip_ctx *ctx, const double *dd, const double *dv, const double *vv, uint64_t generation) {
+    ARG_CHECK(ctx != nullptr);
+    const bool same = ctx->tt_pinned && dd && ctx->tt_pin[0] == dd && ctx->tt_pin[1] == dv && ctx->tt_pin[2] == vv &&
+                      ctx->tt_pin_gen == generation;
+    if (same) return 0;
+    ctx->tt_pin[0] = dd;
+    ctx->tt_pin[1] = dv;
+    ctx->tt_pin[2] = vv;
+    ctx->tt_pin_gen = generation;
+    ctx->tt_pinned = dd != nullptr;
+    ctx->tt_valid = false;
     return 0;
 }
 

@@ -48,6 +48,11 @@ struct corahip_ctx {
     //        4 Legendre matrix of legendre_project, 5 its zero-padded operand
     void *scratch[CORAHIP_NSCRATCH] = {};
     size_t scratch_bytes[CORAHIP_NSCRATCH] = {};
+    // K1 transposed tables resident in scratch slot 0: valid for the pinned (dd, dv, vv, generation) only
+    // (corahip_clarray_tables_pin: the caller vouches that the tables do not change under that generation)
+    const void *tt_pin[3] = {nullptr, nullptr, nullptr};
+    uint64_t tt_pin_gen = 0;
+    bool tt_pinned = false, tt_valid = false;
     // K1 pair list resident in scratch slot 2: (F, first, step, slots, device pointer it was written to)
     long pairs_key[4] = {-1, -1, -1, -1};
     void *pairs_ptr = nullptr;

@@ -264,7 +264,21 @@ class RedshiftCorrelation(object):
         self._aps_cache = True
         self._dev_tables = {}
 
+    _table_generation = [0]      # process-wide counter: every (re)built / uploaded table set gets its own number
+
     def _tables_on(self, ctx):
+        dd_dv_vv = self._tables_on_unpinned(ctx)
+        # K1 may keep its transposed copy of these tables between calls: they are this instance's cache and change only
+        # through _build_tables / load_fft_cache / the _aps_* setters, each of which makes a new entry with a new number
+        gens = self.__dict__.setdefault("_dev_table_gen", {})
+        key = ctx.device.index
+        if gens.get(key, (None, None))[0] is not dd_dv_vv:
+            RedshiftCorrelation._table_generation[0] += 1
+            gens[key] = (dd_dv_vv, RedshiftCorrelation._table_generation[0])
+        ctx.pin_tables(*dd_dv_vv, gens[key][1])
+        return dd_dv_vv
+
+    def _tables_on_unpinned(self, ctx):
         key = ctx.device.index
         if key not in self._dev_tables:
             ht = getattr(self, "_host_tables", None)

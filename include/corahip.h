@@ -101,6 +101,14 @@ int corahip_clarray_table21cm_pairs(corahip_ctx *ctx, const double *dd, const do
 int corahip_clarray_pairs_finish(corahip_ctx *ctx, const double *pairs_in, int F, int nranks, int l_stride,
                                  int nl, double *out);
 
+/* The table integrators work from an x-contiguous copy of (dd, dv, vv) that they make on every call (0.15 ms at
+ * 500 x 32768).  A caller that keeps the tables unchanged between calls - they are the per-model cache of the reference,
+ * cora/signal/corr.py:909-942 - pins them: the copy made by the next call is then reused as long as the SAME pointers
+ * are passed and no other pin is made.  `generation` distinguishes table sets that happen to reuse device addresses
+ * (increment it whenever the tables are rebuilt or rewritten); dd = NULL removes the pin. */
+int corahip_clarray_tables_pin(corahip_ctx *ctx, const double *dd, const double *dv, const double *vv,
+                               uint64_t generation);
+
 /* the bare aps callable at n independent points (corr.py:953-982): lx = log10(l), chi1, chi2,
  * and the coefficient triples b1 b2 P, (f1 b2 + f2 b1) P, f1 f2 P with P = D1 D2 pf1 pf2
  * (the 1/(xc^2 pi) factor is applied by the kernel).  All arrays [n]. */

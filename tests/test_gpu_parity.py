@@ -1183,6 +1183,28 @@ def test_c_abi_with_ctypes_only_no_torch(tmp_path, golden):
         assert np.abs(got - a1).max() <= 1e-12 * np.abs(a1).max()
 
 
+def test_pinned_tables_follow_table_changes(ctx):
+    """K1 keeps its transposed copy of the 21cm tables between calls while the model has them pinned
+    (corahip_clarray_tables_pin); assigning new tables (the setters the reference's load_fft_cache uses,
+    cora/signal/corr.py:879-887) must not leave a stale copy behind: C_l of the doubled tables is exactly 2 C_l."""
+    from cora_amd.core import skysim
+    from cora_amd.signal import corr21cm
+
+    m = corr21cm.Corr21cm()
+    freq = 600.0 + 2.0 * np.arange(6)
+    C1 = skysim.clarray(m.angular_powerspectrum, 40, freq, zromb=1)
+    C1b = skysim.clarray(m.angular_powerspectrum, 40, freq, zromb=1)      # second call: the pinned copy is reused
+    assert np.array_equal(C1, C1b)
+    dd, dv, vv = m._aps_dd.copy(), m._aps_dv.copy(), m._aps_vv.copy()
+    m._aps_dd, m._aps_dv, m._aps_vv = 2.0 * dd, 2.0 * dv, 2.0 * vv
+    C2 = skysim.clarray(m.angular_powerspectrum, 40, freq, zromb=1)
+    assert np.array_equal(C2, 2.0 * C1)
+    other = corr21cm.Corr21cm()                                            # a second model on the same context, then back
+    C3 = skysim.clarray(other.angular_powerspectrum, 40, freq, zromb=1)
+    assert np.array_equal(C3, C1)
+    assert np.array_equal(skysim.clarray(m.angular_powerspectrum, 40, freq, zromb=1), C2)
+
+
 def test_factor_rows_pack_unpack_kernels(ctx):
     """corahip_factor_rows_pack / _unpack (csrc/shard.hip) against the permutation they implement, including an
     empty l block (a rank with no multipoles), uneven blocks and an odd row length."""
