@@ -14,6 +14,7 @@
 #include "common.h"
 
 #include <cstring>
+#include <type_traits>
 
 #ifndef CL_ABLATE
 #define CL_ABLATE 0  // diagnostic builds: 1 no table loads in the profile build, 2 interpolation for one multipole per thread only
@@ -88,6 +89,7 @@ clarray21_kernel(const double *__restrict__ tt, int nkperp, int nkpar, double kp
 
     // ---- parameters of the zint^2 sub-sample pairs, computed ONCE per workgroup (one thread each) instead of by
     //      every thread in front of every profile: the log10 / divisions were the largest part of the kernel
+    int noclamp = 1;
     for (int t = tid; t < zint * zint; t += 256) {
         const int a = t / zint, b = t - a * zint;
         const int za = i * zint + a, zb = j * zint + b;
@@ -120,8 +122,14 @@ clarray21_kernel(const double *__restrict__ tt, int nkperp, int nkpar, double kp
         ipar[t * 4 + 0] = y0;
         ipar[t * 4 + 1] = (int)xlo;                       // first row needed
         ipar[t * 4 + 2] = min((int)xhi + 2, nkperp);      // rows x0 .. nx-1 are needed
+        // does any multipole of this launch other than its FIRST entry (which may be the l = 0 sentinel, 1e-10) need the
+        // clamps of bilinearmap.interp?  (x is monotone in l: the second and the last entry bound the rest)
+        const double x2nd = (l_base + 1 < l_end ? log10l[l_base + 1] * xscale : lx_hi) - lxc;
+        if (!(x2nd >= 0.0 && lx_hi - lxc <= ux)) noclamp = 0;
     }
-    __syncthreads();
+    // uniform over the workgroup: every sub-sample pair can skip the clamps (true for every configuration cora's
+    // frequency ranges produce: 0 <= x <= ~390 of 500 rows for l >= 1)
+    const bool all_fast = __syncthreads_and(noclamp) != 0;
 
     for (int a = 0; a < zint; a++) {
         __syncthreads();
@@ -156,31 +164,40 @@ clarray21_kernel(const double *__restrict__ tt, int nkperp, int nkpar, double kp
         }
         // (instruction count matters here: 5.5e9 of these per cfg-3 launch bound the kernel.  fract instead of
         //  int -> double -> subtract, one ds_read2_b64 for the unclamped row pair: 9 VALU + 1 LDS instead of 14 + 2)
-        auto interp = [&](int b, double lx, double lxc) {
+        // (the clamps are two of the nine VALU instructions of an interpolation: when no multipole of the launch needs
+        //  them - all_fast - only the thread that holds the launch's first entry, the possible l = 0, keeps them)
+        auto interp = [&](int b, double lx, double lxc, bool clamp) {
             double xx = lx - lxc;
-            xx = fmin(fmax(xx, 0.0), ux);
+            if (clamp) xx = fmin(fmax(xx, 0.0), ux);
             const int x0 = (int)xx;
             const double wx = __builtin_amdgcn_fract(xx);
             const double *pr = prof + b * PS + x0;
             const double s0 = pr[0], s1 = pr[1];
             return fma(wx, s1 - s0, s0);
         };
+        auto interp_all = [&](auto fast_c) {
+            constexpr bool FAST = decltype(fast_c)::value;
 #pragma unroll
-        for (int k = 0; k < CL_LPT; k++) {
+            for (int k = 0; k < CL_LPT; k++) {
 #if CL_ABLATE == 2   // diagnostic: no interpolation phase
-            if (k >= 1) continue;
+                if (k >= 1) continue;
 #endif
-            if (k < kmax) {  // uniform: l-sharded callers pass short l ranges
-                double s = 0.0;
-                if constexpr (ZINT > 0) {
+                if (k < kmax) {  // uniform: l-sharded callers pass short l ranges
+                    // (FAST: only the first entry of the launch - thread 0, k = 0 - is clamped)
+                    const bool clamp = !FAST || (k == 0 && tid == 0);
+                    double s = 0.0;
+                    if constexpr (ZINT > 0) {
 #pragma unroll
-                    for (int b = 0; b < ZINT; b++) s += interp(b, lxs[k], lxc_r[b]);
-                } else {
-                    for (int b = 0; b < zint; b++) s += interp(b, lxs[k], lxcs_s[b]);
+                        for (int b = 0; b < ZINT; b++) s += interp(b, lxs[k], lxc_r[b], clamp);
+                    } else {
+                        for (int b = 0; b < zint; b++) s += interp(b, lxs[k], lxcs_s[b], clamp);
+                    }
+                    acc[k] += s;
                 }
-                acc[k] += s;
             }
-        }
+        };
+        if (all_fast) interp_all(std::true_type{});
+        else interp_all(std::false_type{});
     }
 #pragma unroll
     for (int k = 0; k < CL_LPT; k++) {
