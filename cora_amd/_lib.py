@@ -48,6 +48,9 @@ SIGNATURES = {
     "corahip_romb_reduce": (c_int, [c_void_p, PTR, c_int, c_int, c_int, PTR, PTR]),
     "corahip_factor_batched": (c_int, [c_void_p, PTR, c_int, c_int, c_double, c_double, PTR, PTR]),
     "corahip_normals_philox": (c_int, [c_void_p, c_u64, c_int, c_int, PTR]),
+    "corahip_normals_pcg64": (c_int, [c_void_p, ctypes.POINTER(c_u64), ctypes.POINTER(c_u64), ctypes.c_int64, PTR,
+                                      ctypes.POINTER(c_u64)]),
+    "corahip_pcg64_advance": (c_int, [ctypes.POINTER(c_u64), ctypes.POINTER(c_u64), c_u64, ctypes.POINTER(c_u64)]),
     "corahip_draw_alm_philox": (c_int, [c_void_p, PTR, PTR, c_u64, c_int, c_int, c_int, c_int, PTR]),
     "corahip_draw_alm_philox_rows": (c_int, [c_void_p, PTR, PTR, c_u64, c_int, c_int, c_int, c_int, PTR]),
     "corahip_draw_alm": (c_int, [c_void_p, PTR, PTR, PTR, c_int, c_int, c_int, c_int, PTR]),
@@ -122,6 +125,17 @@ def load():
             raise ImportError("cora_amd: ABI version mismatch in %s" % LIB_PATH)
         _lib = lib
     return _lib
+
+
+def pcg64_advance(state, inc, delta):
+    """PCG64 state (python int) after ``delta`` steps - numpy's ``bit_generator.advance`` as host arithmetic of the
+    library (no GPU needed)."""
+    M = 2**64 - 1
+    st = (c_u64 * 2)((int(state) >> 64) & M, int(state) & M)
+    ic = (c_u64 * 2)((int(inc) >> 64) & M, int(inc) & M)
+    out = (c_u64 * 2)()
+    _check(load().corahip_pcg64_advance(st, ic, c_u64(int(delta)), out))
+    return (int(out[0]) << 64) | int(out[1])
 
 
 def _check(rc):
@@ -352,6 +366,19 @@ class Context:
         assert g.numel() >= n
         _check(self.lib.corahip_normals_philox(self.h, c_u64(int(seed) & (2**64 - 1)), lmax, F, self._f64(g)))
         return g
+
+    def normals_pcg64(self, state, inc, n, out=None):
+        """The next ``n`` values of numpy's ``Generator(PCG64).standard_normal`` from bit-generator ``state`` / ``inc``
+        (python ints, 128 bits), generated on the device; returns (g, n_raw): the normals and the number of raw 64-bit
+        draws they consumed (see :func:`pcg64_advance`)."""
+        g = out if out is not None else self.empty((n,))
+        assert g.numel() >= n
+        M = 2**64 - 1
+        st = (c_u64 * 2)((int(state) >> 64) & M, int(state) & M)
+        ic = (c_u64 * 2)((int(inc) >> 64) & M, int(inc) & M)
+        nraw = c_u64(0)
+        _check(self.lib.corahip_normals_pcg64(self.h, st, ic, int(n), self._f64(g), ctypes.byref(nraw)))
+        return g, int(nraw.value)
 
     def draw_alm(self, T, info, g, lmax, F, nu0=0, nnu=None, out=None):
         nnu = F if nnu is None else nnu

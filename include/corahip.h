@@ -32,6 +32,7 @@ extern "C" {
 #endif
 
 #define CORAHIP_ABI_VERSION 1
+#define CORAHIP_ABI_MINOR 1      /* additions since version 1: 1 = normals_pcg64, pcg64_advance */
 
 #define CORAHIP_EINVAL (-1)   /* bad argument / shape */
 #define CORAHIP_ENOMEM (-2)   /* workspace too small / allocation refused */
@@ -145,6 +146,24 @@ int corahip_factor_batched(corahip_ctx *ctx, const double *C, int nl, int F, dou
  * outputs of Philox4x32-10 counter {m, l*F + nu'} under key `seed` (independent of the GPU count; the mapping of the
  * four output words to the pair is specified in oracle/philox.py and cora_amd/csrc/rng_dev.h). */
 int corahip_normals_philox(corahip_ctx *ctx, uint64_t seed, int lmax, int F, double *g);
+
+/* The REFERENCE's own seeded stream on the device: the next n values of
+ * numpy.random.Generator(PCG64).standard_normal - what `rng.standard_normal(shape)` of cora/util/nputil.py:121-125
+ * returns for the `rng = default_rng(seed)` of cora/signal/lss.py:449-450 - bit for bit (fast-path and wedge samples
+ * are one exact multiply; tail samples use glibc's log1p restated operation by operation), written to g[0..n) in draw
+ * order: with n = 2*F*nalm the "stream order" buffer draw_alm consumes.
+ *   state, inc   host: the 128-bit PCG64 state and increment as {high 64 bits, low 64 bits}
+ *                (rng.bit_generator.state["state"]["state" | "inc"])
+ *   n_raw        host, out: the number of raw 64-bit draws the n normals consumed (1.0215 n on average: the ziggurat
+ *                takes a data-dependent number per sample); corahip_pcg64_advance(state, inc, *n_raw) is the state
+ *                numpy would be left in.
+ * Synchronises the context's stream (n_raw is read back).  numpy's algorithm: PCG64 = pcg_setseq_128_xsl_rr_64,
+ * 256-strip ziggurat of numpy/random/src/distributions/distributions.c; restated in oracle/npnormal.py. */
+int corahip_normals_pcg64(corahip_ctx *ctx, const uint64_t host_state[2], const uint64_t host_inc[2], int64_t n,
+                          double *g, uint64_t *host_n_raw);
+/* host arithmetic: the PCG64 state after `delta` steps (numpy's bit_generator.advance) */
+int corahip_pcg64_advance(const uint64_t host_state[2], const uint64_t host_inc[2], uint64_t delta,
+                          uint64_t host_out_state[2]);
 
 /* a_lm(nu) = sum_nu' T_l[nu,nu'] g_lm(nu')  (skysim.py:121) for channels nu0 <= nu < nu0+nnu.
  *   T [lmax+1, F, F], info [lmax+1] (from factor_batched; NULL = treat all as dense),

@@ -1,0 +1,139 @@
+"""Oracle (test infrastructure only): restatement of numpy's seeded normal stream, ``Generator(PCG64).standard_normal``.
+
+The reference draws every normal of ``mkfullsky`` from the caller's ``numpy.random.Generator``
+(cora/util/nputil.py:121-125, called per l from cora/core/skysim.py:120; built by ``default_rng(seed)`` in
+cora/signal/lss.py:449-450).  numpy is a third-party dependency of the reference (absent from /root/reference; numpy
+2.2.6 in this image, ``numpy>=1.24`` in pyproject.toml) - what is restated here is its PUBLISHED algorithm:
+
+  bit generator  PCG64 = pcg_setseq_128_xsl_rr_64 (O'Neill, "PCG: A Family of Simple Fast Space-Efficient
+                 Statistically Good Algorithms for Random Number Generation", 2014; numpy/random/src/pcg64/pcg64.h):
+                     state <- state * M + inc  (mod 2^128),  M = 0x2360ED051FC65DA44385DF649FCCF645
+                     output = rotr64(hi ^ lo, hi >> 58)       (step first, then output)
+  sampler        the 256-strip ziggurat of numpy/random/src/distributions/distributions.c
+                 (``random_standard_normal``; Marsaglia & Tsang 2000 in Doornik's ZIGNOR form), tables ki / wi / fi
+                 (cora_amd/csrc/zig_tab.inc, read out of numpy's own compiled library by tools/gen_zig_tabs.py):
+                     r = next64; idx = r & 0xff; r >>= 8; sign = r & 1; rabs = (r >> 1) & (2^52 - 1)
+                     x = rabs * wi[idx] (negated if sign);  rabs < ki[idx] -> return x            (99.3 %)
+                     idx == 0: tail  loop  xx = -log1p(-U)/R, yy = -log1p(-U);  yy + yy > xx xx -> +-(R + xx),
+                               sign bit = (rabs >> 8) & 1
+                     else wedge: (fi[idx-1] - fi[idx]) U + fi[idx] < exp(-x x / 2) -> return x, else start again
+                     U = (next64 >> 11) 2^-53
+
+PINNED by numpy itself, which is present here and on the GPU box: tests/test_oracle.py compares this restatement with
+``np.random.Generator(np.random.PCG64(seed)).standard_normal`` value by value (wedge and tail samples included), the
+consumed raw count with the generator's own state afterwards, and ``advance`` with ``bit_generator.advance``.  The device
+stream (cora_amd/csrc/npnormal.hip) is compared with numpy directly and with the counts of this file.
+"""
+import math
+import os
+import re
+
+import numpy as np
+
+PCG_MULT = (2549297995355413924 << 64) + 4865540595714422341
+MASK128 = (1 << 128) - 1
+MASK64 = (1 << 64) - 1
+ZIG_R = 3.6541528853610087963519472518
+ZIG_INV_R = 0.27366123732975827203338247596
+
+
+def tables():
+    """(ki, wi, fi) parsed from the generated include file the kernels are compiled with."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "cora_amd", "csrc", "zig_tab.inc")
+    txt = open(path).read()
+    ki = [int(t, 16) for t in re.findall(r"0x([0-9a-f]{16})ull", txt)]
+    fl = [float.fromhex(t) for t in re.findall(r"(-?0x[01]\.[0-9a-f]+p[+-]?\d+),", txt)]
+    assert len(ki) == 256 and len(fl) == 512
+    return ki, fl[:256], fl[256:]
+
+
+def state_of(rng):
+    """(state, inc) of a numpy Generator / BitGenerator built on PCG64."""
+    bg = getattr(rng, "bit_generator", rng)
+    st = bg.state
+    assert st["bit_generator"] == "PCG64"
+    return int(st["state"]["state"]), int(st["state"]["inc"])
+
+
+def step(state, inc):
+    return (state * PCG_MULT + inc) & MASK128
+
+
+def output(state):
+    hi, lo = state >> 64, state & MASK64
+    x = hi ^ lo
+    rot = hi >> 58
+    return ((x >> rot) | (x << ((64 - rot) & 63))) & MASK64 if rot else x
+
+
+def advance(state, inc, delta):
+    """state after ``delta`` steps: f^n(s) = M^n s + inc (M^n - 1)/(M - 1), by square-and-multiply on (mult, plus)
+    (Brown, "Random number generation with arbitrary strides"; numpy's pcg_advance_lcg_128)."""
+    acc_mult, acc_plus = 1, 0
+    cur_mult, cur_plus = PCG_MULT, inc
+    while delta > 0:
+        if delta & 1:
+            acc_mult = (acc_mult * cur_mult) & MASK128
+            acc_plus = (acc_plus * cur_mult + cur_plus) & MASK128
+        cur_plus = ((cur_mult + 1) * cur_plus) & MASK128
+        cur_mult = (cur_mult * cur_mult) & MASK128
+        delta >>= 1
+    return (acc_mult * state + acc_plus) & MASK128
+
+
+def raw_stream(state, inc, n):
+    """The next n 64-bit outputs as a uint64 array (python-int loop: small n only) and the state after them."""
+    out = np.empty(n, dtype=np.uint64)
+    for i in range(n):
+        state = step(state, inc)
+        out[i] = output(state)
+    return out, state
+
+
+def standard_normal(state, inc, n, stats=None):
+    """The next n values of ``standard_normal`` and the number of raw 64-bit draws they consume."""
+    ki, wi, fi = tables()
+    vals = np.empty(n, dtype=np.float64)
+    nraw = 0
+
+    def nxt():
+        nonlocal state, nraw
+        state = step(state, inc)
+        nraw += 1
+        return output(state)
+
+    def nxt_double():
+        return (nxt() >> 11) * (1.0 / 9007199254740992.0)
+
+    kinds = {"fast": 0, "wedge_accept": 0, "wedge_reject": 0, "tail": 0, "tail_reject": 0}
+    for k in range(n):
+        while True:
+            r = nxt()
+            idx = r & 0xFF
+            r >>= 8
+            sign = r & 1
+            rabs = (r >> 1) & 0x000FFFFFFFFFFFFF
+            x = rabs * wi[idx]
+            if sign:
+                x = -x
+            if rabs < ki[idx]:
+                kinds["fast"] += 1
+                break
+            if idx == 0:
+                while True:
+                    xx = -ZIG_INV_R * math.log1p(-nxt_double())
+                    yy = -math.log1p(-nxt_double())
+                    if yy + yy > xx * xx:
+                        break
+                    kinds["tail_reject"] += 1
+                x = -(ZIG_R + xx) if (rabs >> 8) & 1 else ZIG_R + xx
+                kinds["tail"] += 1
+                break
+            if (fi[idx - 1] - fi[idx]) * nxt_double() + fi[idx] < math.exp(-0.5 * x * x):
+                kinds["wedge_accept"] += 1
+                break
+            kinds["wedge_reject"] += 1
+        vals[k] = x
+    if stats is not None:
+        stats.update(kinds)
+    return vals, nraw
