@@ -178,6 +178,32 @@ def _upload_host_normals(ctx, numz, maxl, rng):
     return g
 
 
+def _is_pcg64_generator(rng):
+    """True for a ``numpy.random.Generator`` on the ``PCG64`` bit generator - what ``default_rng(seed)`` builds and
+    what cora's callers pass (cora/signal/lss.py:449-450)."""
+    return isinstance(rng, np.random.Generator) and type(rng.bit_generator) is np.random.PCG64
+
+
+def stream_normals(ctx, numz, maxl, rng):
+    """The normal stream of one realisation in the reference's draw order (:func:`_host_normals`) as a device array.
+
+    A ``Generator`` on PCG64 is continued ON THE DEVICE (``corahip_normals_pcg64``: the same PCG64 + ziggurat
+    sequence, bit for bit) and left exactly where ``rng.standard_normal`` would have left it: its state is advanced by
+    the number of raw draws the normals consumed.  Any other generator (``rng=None`` = numpy's legacy global MT19937 +
+    polar method, other bit generators) is consumed on the host and uploaded (:func:`_upload_host_normals`)."""
+    if not _is_pcg64_generator(rng):
+        return _upload_host_normals(ctx, numz, maxl, rng)
+    n = 2 * numz * ((maxl + 1) * (maxl + 2) // 2)
+    bg = rng.bit_generator
+    with bg.lock:                                          # the lock numpy's own draws hold
+        st = bg.state
+        s, inc = int(st["state"]["state"]), int(st["state"]["inc"])
+        g, nraw = ctx.normals_pcg64(s, inc, n)
+        st["state"]["state"] = _lib.pcg64_advance(s, inc, nraw)
+        bg.state = st                                      # (has_uint32 / uinteger untouched, as standard_normal leaves them)
+    return g
+
+
 def factor_device(corr):
     """Per-l roots of the jittered covariance blocks (skysim.py:115-119) on the device."""
     ctx = _lib.get_context()
@@ -213,7 +239,7 @@ def mkfullsky_device(corr, nside, alms=False, rng=None, factors=None, nu_range=N
     if isinstance(rng, DeviceRNG):
         alm = ctx.draw_alm_philox(T, info, rng.next_seed(), maxl, numz, nu0=nu0, nnu=nnu)
     else:
-        g = _upload_host_normals(ctx, numz, maxl, rng)
+        g = stream_normals(ctx, numz, maxl, rng)
         alm = ctx.draw_alm(T, info, g, maxl, numz, nu0=nu0, nnu=nnu)
         del g
     if alms:
@@ -233,9 +259,11 @@ def mkfullsky(corr, nside, alms=False, rng=None):
     alms : boolean, optional
         If True return the alms ``[numz, 1, lmax+1, lmax+1]`` instead of the sky maps.
     rng : numpy Generator, :class:`cora_amd.DeviceRNG`, optional
-        Seeded generator.  A numpy Generator (or None = numpy's legacy global state) is
-        consumed on the host in exactly the reference's order, so the same seed gives the
-        same realisation as cora; a ``DeviceRNG`` keeps the draw on the GPU.
+        Seeded generator.  A numpy ``Generator`` on PCG64 (``default_rng(seed)``) is continued
+        on the GPU - the same values cora draws, in the reference's order, and the generator
+        is left in the state cora would leave it in; ``None`` (numpy's legacy global state)
+        and other bit generators are consumed on the host in that order; a ``DeviceRNG``
+        is the library's own counter-based stream (not numpy's numbers).
 
     Returns
     -------

@@ -15,32 +15,37 @@
 // "Which raw position starts a sample" is a prefix problem; oracle/npnormal_model.py states the decomposition in python
 // (checked against numpy on the CPU), this is the same thing on the device:
 //
-//   chunk  R consecutive positions per thread, classified AS IF each started a sample: nf (not fast), z (tail class),
-//          wacc (wedge test of (p, p + 1) passes).  Entered with k positions already consumed by an earlier sample,
-//          position p >= k starts a sample iff it is not the second draw of a wedge sample: inside a maximal run of nf
-//          positions the starts alternate from the run's first position - found for all positions at once with an
-//          integer add (the carry runs through a run of ones; simdjson's odd-backslash scan).  A tail-class start is
-//          resolved by its owner reading on past its chunk, like the wedge draw of a chunk's last position: the state
-//          at a chunk boundary is just k = positions of the next chunk(s) already consumed.
-//   block  256 chunks; k of thread t + 1 = k_out of thread t, by fixed-point iteration from k = 0 (a fast position ends
-//          every dependency chain: 2-3 iterations).
-//   grid   zig_count_kernel: every block's (k_out, count) for block entry k in {0, 1}; a block that hands k >= 2 to its
-//          successor (a tail sample across the boundary, 6e-4 of the blocks) evaluates the successor for that k itself
-//          and appends the result to a patch list.  zig_scan_kernel (one workgroup) composes the block functions and
-//          gives every block its true (k, first ordinal).  zig_emit_kernel re-runs every block with them and writes the
-//          normals at their ordinals through an LDS staging buffer (coalesced stores).
+//   row    64 consecutive positions, one per lane (lane p of row j of a block holds position 64 j + p; its LCG steps by
+//          64: s <- M^64 s + inc G_64), classified AS IF each started a sample: nf (not fast), z (tail class), w (wedge
+//          test of (p, p + 1) passes).  The compares that classify ARE the row's 64-bit masks (v_cmp writes a scalar
+//          pair), so everything below is scalar code, once per wave.  With `pos` = the next position that starts a
+//          sample, position p >= pos of the row starts one iff it is not the second draw of a wedge sample: inside a
+//          maximal run of nf positions the starts alternate from the run's first position - found for all 64 at once
+//          with an integer add (the carry runs through a run of ones; simdjson's odd-backslash scan).  A tail-class
+//          start is walked where it is met (2 draws per iteration, wave-uniform), past the end of the block if need be,
+//          like the wedge draw of a block's last position: the state at a block boundary is just k = positions of the
+//          next block(s) already consumed.  The wedge tests (15 per block) are gathered in LDS and run 64 at a time.
+//   block  16 rows = 1024 positions = one wave, rows in sequence (the scalar chain carries pos from row to row).
+//   grid   zig_count_kernel: every block's (k_out, count) for block entry k in {0, 1} and the classes of its rows; a
+//          block that hands k >= 2 to its successor (a tail sample across the boundary, 1.5e-4 of the blocks) evaluates
+//          the successor for that k itself and appends the result to a patch list.  zig_tile / zig_top / zig_entry
+//          compose the block functions (tiles of 512 blocks; inside a tile and across tiles by fixed-point iteration
+//          from k = 0: almost every block maps 0 and 1 to the same k_out) and give every block its true
+//          (k, first ordinal).  zig_emit_kernel re-runs the generator of every block with them and the stored classes:
+//          the samples of a row leave as one store instruction at ordinal + mbcnt - consecutive addresses, no staging.
 #include "common.h"
 
 #include <algorithm>
+#include <cstdlib>
 
 #define ZIG_TAB_Q __device__ static const
 #include "zig_tab.inc"
 
 typedef unsigned __int128 u128;
 
-#define ZIG_R_CHUNK 16      // positions per thread
-#define ZIG_T 256           // threads per block
-#define ZIG_BLK (ZIG_R_CHUNK * ZIG_T)
+#define ZIG_ROWS 16         // rows of 64 consecutive positions per block: lane p of row j holds position 64 j + p
+#define ZIG_BLK (64 * ZIG_ROWS)
+#define ZIG_WG 256          // threads per workgroup of the count / emit kernels (independent waves, one block each)
 
 namespace {
 
@@ -65,23 +70,20 @@ constexpr jump_tab<64> make_pow2() {
     }
     return t;
 }
-// n = t R: the offset of thread t's chunk inside its block
-template <int R, int T>
-constexpr jump_tab<T> make_thr() {
-    jump_tab<T> t{};
-    u128 m = 1, g = 0;
-    for (int i = 0; i < T; i++) {
+// n = l + 1: from the state before a block's first position to the state that outputs position l
+constexpr jump_tab<64> make_lane() {
+    jump_tab<64> t{};
+    u128 m = PCG_MULT, g = 1;
+    for (int i = 0; i < 64; i++) {
         t.v[i] = jump_t{(uint64_t)(m >> 64), (uint64_t)m, (uint64_t)(g >> 64), (uint64_t)g};
-        for (int r = 0; r < R; r++) {
-            g = g * PCG_MULT + 1;
-            m = m * PCG_MULT;
-        }
+        g = g * PCG_MULT + 1;
+        m = m * PCG_MULT;
     }
     return t;
 }
 constexpr jump_tab<64> H_POW2 = make_pow2();
 __device__ const jump_tab<64> ZIG_POW2 = make_pow2();
-__device__ const jump_tab<ZIG_T> ZIG_THR = make_thr<ZIG_R_CHUNK, ZIG_T>();
+__device__ const jump_tab<64> ZIG_LANE = make_lane();
 
 __host__ __device__ inline u128 jump_apply(const jump_t &j, u128 s, u128 inc) {
     return mk128(j.mhi, j.mlo) * s + inc * mk128(j.ghi, j.glo);
@@ -105,7 +107,7 @@ constexpr uint64_t M52 = 0x000fffffffffffffull;
 
 // glibc's log1p (sysdeps/ieee754/dbl-64/s_log1p.c: fdlibm's algorithm, polynomial in glibc's split evaluation order),
 // for -1 < x <= 0, operation by operation in IEEE double without contraction: bit-identical to the libm numpy calls
-// (tools/log1p_probe.py compares the same restatement with math.log1p on the host).
+// (oracle/npnormal.py holds the same restatement; tests/test_oracle.py compares it with math.log1p on the host).
 __device__ __attribute__((noinline)) double glibc_log1p_neg(double x) {
 #pragma clang fp contract(off)
     const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
@@ -191,48 +193,46 @@ struct zig_status {
 
 #define ZIG_TAIL_CAP 4096   // iterations of one tail loop before the status word is flagged (rejection rate 8 %)
 
-template <int R>
-struct chunk_t {
-    uint64_t raw[R + 1];
-    u128 s0;               // state before the chunk's first position
-    unsigned nf, z, wacc;
-};
-
-template <int R>
-__device__ inline void chunk_build(chunk_t<R> &c, u128 s, u128 inc, const uint64_t *ki, const double *wi,
-                                   const double *fi) {
-    c.s0 = s;
-#pragma unroll
-    for (int j = 0; j <= R; j++) {
-        s = pcg_step(s, inc);
-        c.raw[j] = pcg_out(s);
-    }
-    unsigned nf = 0, z = 0;
-#pragma unroll
-    for (int p = 0; p < R; p++) {
-        const uint64_t r = c.raw[p];
-        const unsigned idx = (unsigned)(r & 0xff);
-        const bool slow = ((r >> 9) & M52) >= ki[idx];
-        nf |= (slow ? 1u : 0u) << p;
-        z |= ((slow && idx == 0) ? 1u : 0u) << p;
-    }
-    unsigned wacc = 0;
-    const unsigned w = nf & ~z;
-    if (w) {
-#pragma unroll
-        for (int p = 0; p < R; p++)
-            if ((w >> p) & 1) wacc |= (zig_wedge_accept(c.raw[p], c.raw[p + 1], wi, fi) ? 1u : 0u) << p;
-    }
-    c.nf = nf;
-    c.z = z;
-    c.wacc = wacc;
+// ---- wave-level primitives ---------------------------------------------------------------------------------------
+// (the builtins return int: without the casts the low word sign-extends over the high one)
+__device__ inline unsigned uni32(unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane(v); }
+__device__ inline uint64_t uni64(uint64_t v) { return ((uint64_t)uni32((unsigned)(v >> 32)) << 32) | uni32((unsigned)v); }
+__device__ inline unsigned readlane32(unsigned v, int l) { return (unsigned)__builtin_amdgcn_readlane(v, l); }
+// number of set bits of m below this lane
+__device__ inline unsigned mbcnt64(uint64_t m) {
+    return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+}
+__device__ inline uint64_t readlane64(uint64_t v, int l) {
+    return ((uint64_t)readlane32((unsigned)(v >> 32), l) << 32) | readlane32((unsigned)v, l);
+}
+__device__ inline void wave_lds_fence() {      // LDS serves a wave's instructions in order; this stops the compiler
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
 }
 
-// tail sample started at position p of the chunk (r_p its draw): value, and the positions consumed after p
-__device__ __attribute__((noinline)) void zig_tail_walk(u128 s, u128 inc, int p, uint64_t r_p, double &val, unsigned &consumed,
+// the 64-bit class masks of the 16 rows of a block, row j in lane j of each word ("columns"): wave-uniform values
+// without spending 6 x 16 scalar registers
+struct cols_t {
+    unsigned nf_lo = 0, nf_hi = 0, z_lo = 0, z_hi = 0, w_lo = 0, w_hi = 0;
+};
+__device__ inline void col_set(unsigned &lo, unsigned &hi, int j, uint64_t m) {
+    const bool mine = (int)(threadIdx.x & 63) == j;           // (m is wave-uniform: two selects against scalars)
+    lo = mine ? (unsigned)m : lo;
+    hi = mine ? (unsigned)(m >> 32) : hi;
+}
+__device__ inline uint64_t col_get(unsigned lo, unsigned hi, int j) {
+    return ((uint64_t)readlane32(hi, j) << 32) | readlane32(lo, j);
+}
+
+// tail sample started at position q of the block (wave-uniform; every lane computes the same): the value up to its
+// sign, and the positions consumed after q
+__device__ __attribute__((noinline)) void zig_tail_walk(u128 s_blk, u128 inc, unsigned q, double &val, unsigned &consumed,
                                                         unsigned *err) {
 #pragma clang fp contract(off)
-    for (int i = 0; i <= p; i++) s = pcg_step(s, inc);
+    u128 s = s_blk;                              // state before the block's first position -> after position q
+    const unsigned n = q + 1;
+    for (int i = 0; i < 32 && (n >> i); i++)
+        if ((n >> i) & 1) s = jump_apply(ZIG_POW2.v[i], s, inc);
     unsigned c = 0;
     double xx = 0.0;
     for (int it = 0;; it++) {
@@ -249,118 +249,70 @@ __device__ __attribute__((noinline)) void zig_tail_walk(u128 s, u128 inc, int p,
             break;
         }
     }
-    const bool neg = (((r_p >> 9) & M52) >> 8) & 1;
-    val = neg ? -(ZIG_NOR_R + xx) : ZIG_NOR_R + xx;
+    val = ZIG_NOR_R + xx;
     consumed = c;
 }
 
-struct emit_ctx {
-    double *stage;                 // LDS staging buffer of the block (padded index)
-    unsigned obase;                // ordinal of the thread's first sample relative to the block
-    unsigned long long blk_ord;    // ordinal of the block's first sample
-    unsigned long long n;          // samples wanted in all
-    unsigned long long pos;        // absolute position of the chunk's first draw
-    unsigned long long *n_raw;
+// ---- the run scan ------------------------------------------------------------------------------------------------
+// One row = 64 consecutive positions, bit p of a mask = position p.  `pos` = the next position of the BLOCK that starts a
+// sample (everything below it is consumed).  Returns for row j: e_fast / e_wedge = the fast-path / accepted-wedge
+// samples of the row up to its first tail-class start, tl_bit = that start (64 = none), and moves pos on past the row
+// or past what the row's samples up to there consume.  All values are wave-uniform: this is scalar code.
+struct row_eval_t {
+    uint64_t e_fast, e_wedge;
+    int tl_bit;
 };
-__device__ inline unsigned stage_pad(unsigned i) { return i + (i >> 4); }
-
-// (k_out, count) of a chunk entered with k positions consumed; EMIT: also writes the values at their ordinals
-template <int R, bool EMIT>
-__device__ inline void chain_eval(const chunk_t<R> &c, u128 inc, unsigned k, unsigned &kout, unsigned &cnt,
-                                  const double *wi, unsigned *err, const emit_ctx *ec) {
-    constexpr unsigned FULL = (R == 32) ? 0xffffffffu : ((1u << R) - 1u);
-    constexpr unsigned EVEN = 0x55555555u;
-    static_assert(R <= 31, "the run scan needs a spare bit for the carry");
-    unsigned n = 0;
-    for (;;) {
-        if (k >= (unsigned)R) {
-            kout = k - R;
-            cnt = n;
-            return;
-        }
-        const unsigned low = (1u << k) - 1u;
-        const unsigned nf = c.nf & ~low;
-        const unsigned starts = nf & ~(nf << 1);
-        const unsigned re = nf & ~(nf + (starts & EVEN));       // runs whose first position is even
-        const unsigned ro = nf & ~(nf + (starts & ~EVEN));      // ... odd
-        const unsigned sn = ((re & EVEN) | (ro & ~EVEN)) & FULL; // sample starts that are not fast
-        const unsigned S = ~(sn << 1);                           // sample starts
-        const unsigned valid = FULL & ~low;
-        const unsigned tl = S & c.z & valid;                     // tail-class starts
-        const unsigned upto = tl ? (valid & ((tl & (0u - tl)) - 1u)) : valid;
-        const unsigned e_fast = S & ~nf & upto;
-        const unsigned e_wedge = sn & ~c.z & c.wacc & upto;
-        const unsigned e = e_fast | e_wedge;
-        if constexpr (EMIT) {
-#pragma unroll
-            for (int p = 0; p < R; p++) {
-                if ((e >> p) & 1) {
-                    const unsigned o = ec->obase + n + __builtin_popcount(e & ((1u << p) - 1u));
-                    ec->stage[stage_pad(o)] = zig_value(c.raw[p], wi);
-                    if (ec->blk_ord + o + 1 == ec->n) *ec->n_raw = ec->pos + p + 1 + ((e_wedge >> p) & 1);
-                }
-            }
-        }
-        n += __builtin_popcount(e);
-        if (!tl) {
-            kout = (sn >> (R - 1)) & 1u;
-            cnt = n;
-            return;
-        }
-        const int p = __builtin_ctz(tl);
-        // (the draw of position p by a select chain: raw[] lives in registers)
-        uint64_t rp = 0;
-#pragma unroll
-        for (int q = 0; q < R; q++) rp = (q == p) ? c.raw[q] : rp;
-        double v;
-        unsigned consumed;
-        zig_tail_walk(c.s0, inc, p, rp, v, consumed, err);
-        if constexpr (EMIT) {
-            const unsigned o = ec->obase + n;
-            ec->stage[stage_pad(o)] = v;
-            if (ec->blk_ord + o + 1 == ec->n) *ec->n_raw = ec->pos + p + 1 + consumed;
-        }
-        n += 1;
-        k = p + 1 + consumed;
-    }
+__device__ inline row_eval_t row_eval(uint64_t nf_j, uint64_t z_j, uint64_t w_j, int j, unsigned &pos) {
+    constexpr uint64_t EVEN = 0x5555555555555555ull;
+    const unsigned lowk = pos - 64u * j;                                 // < 64 (the caller skips consumed rows)
+    const uint64_t low = (1ull << lowk) - 1ull;
+    const uint64_t nf = nf_j & ~low;
+    const uint64_t starts = nf & ~(nf << 1);
+    const uint64_t re = nf & ~(nf + (starts & EVEN));                    // runs whose first position is even
+    const uint64_t ro = nf & ~(nf + (starts & ~EVEN));                   // ... odd
+    const uint64_t sn = (re & EVEN) | (ro & ~EVEN);                      // sample starts that are not fast
+    const uint64_t S = ~(sn << 1);                                       // sample starts
+    const uint64_t valid = ~low;
+    const uint64_t tl = S & z_j & valid;
+    row_eval_t r;
+    r.tl_bit = tl ? __builtin_ctzll(tl) : 64;
+    const uint64_t upto = tl ? (valid & ((tl & (0ull - tl)) - 1ull)) : valid;
+    r.e_fast = S & ~nf & upto;
+    r.e_wedge = sn & ~z_j & w_j & upto;
+    if (!tl) pos = 64u * (j + 1) + (unsigned)(sn >> 63);                 // a wedge sample at bit 63 takes the next row's first draw
+    return r;
 }
 
-// fixed point of the thread entries of one block: every thread leaves with its own (kin, kout, cnt)
-template <int R, int T>
-__device__ inline void block_resolve(const chunk_t<R> &c, u128 inc, unsigned k_block, unsigned *lds_k /* [T + 1] */,
-                                     const double *wi, unsigned *err, unsigned &kin, unsigned &kout, unsigned &cnt) {
-    const int t = threadIdx.x;
-    kin = t == 0 ? k_block : 0u;
-    for (int it = 0; it <= T; it++) {
-        chain_eval<R, false>(c, inc, kin, kout, cnt, wi, err, nullptr);
-        lds_k[t + 1] = kout;
-        __syncthreads();
-        const unsigned nk = t == 0 ? k_block : lds_k[t];
-        const int changed = nk != kin;
-        kin = nk;
-        if (!__syncthreads_or(changed)) break;
+// (k_out, count) of a block entered with k positions consumed (pass 1: no values)
+__device__ inline void block_chain(const cols_t &c, u128 s_blk, u128 inc, unsigned k, unsigned &kout, unsigned &cnt,
+                                   unsigned &pos_row0, unsigned &cnt_row0, int rows, unsigned *err) {
+    unsigned pos = k, n = 0;
+    for (int j = 0; j < ZIG_ROWS; j++) {
+        if (j == 1) {
+            pos_row0 = pos;
+            cnt_row0 = n;
+            if (rows == 1) break;
+        }
+        if (pos >= 64u * (j + 1)) continue;
+        const uint64_t nf_j = col_get(c.nf_lo, c.nf_hi, j), z_j = col_get(c.z_lo, c.z_hi, j), w_j = col_get(c.w_lo, c.w_hi, j);
+        while (pos < 64u * (j + 1)) {
+            const row_eval_t r = row_eval(nf_j, z_j, w_j, j, pos);
+            n += __builtin_popcountll(r.e_fast | r.e_wedge);
+            if (r.tl_bit == 64) break;
+            double v;
+            unsigned consumed;
+            zig_tail_walk(s_blk, inc, 64u * j + r.tl_bit, v, consumed, err);
+            n += 1;
+            pos = 64u * j + r.tl_bit + 1 + consumed;
+        }
     }
-}
-
-// sum over the block (every thread gets it); red: [T / 64 + 1] words of LDS
-template <int T>
-__device__ inline unsigned block_sum(unsigned v, unsigned *red) {
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    const int t = threadIdx.x;
-    __syncthreads();
-    if ((t & 63) == 0) red[t >> 6] = v;
-    __syncthreads();
-    unsigned s = 0;
-#pragma unroll
-    for (int w = 0; w < T / 64; w++) s += red[w];
-    return s;
+    kout = pos > ZIG_BLK ? pos - ZIG_BLK : 0u;
+    cnt = n;
 }
 
 struct zig_lds {
     uint64_t ki[256];
     double wi[256], fi[256];
-    unsigned k[ZIG_T + 1];
-    unsigned red[ZIG_T / 64 + 4];
 };
 __device__ inline void zig_lds_fill(zig_lds &L) {
     for (int i = threadIdx.x; i < 256; i += blockDim.x) {
@@ -384,57 +336,138 @@ __global__ void zig_seek_kernel(uint64_t s_hi, uint64_t s_lo, uint64_t i_hi, uin
     blk_state[b] = make_ulonglong2((uint64_t)(s >> 64), (uint64_t)s);
 }
 
-__device__ inline u128 thread_state(const ulonglong2 *blk_state, long b, u128 inc) {
-    const ulonglong2 bs = blk_state[b];
-    return jump_apply(ZIG_THR.v[threadIdx.x], mk128(bs.x, bs.y), inc);
+// wave-private LDS of the wedge tests: 1.45 % of the positions are wedge class (15 of a block's 1024); tested where
+// they stand they cost a full instruction stream each, so the (draw, next draw) pairs of a block are gathered and
+// tested 64 at a time, the verdicts coming back as bits of the rows' masks
+#define ZIG_WCAP 128
+struct zig_wlds {
+    ulonglong2 cand[ZIG_WCAP];
+    unsigned short where[ZIG_WCAP];     // position in the block
+    unsigned wmask[2 * ZIG_ROWS];       // accepted-wedge masks, row j in words 2 j, 2 j + 1
+};
+
+__device__ inline void wedge_flush(zig_wlds *W, unsigned ncand, const double *wi, const double *fi) {
+    const int lane = threadIdx.x & 63;
+    wave_lds_fence();
+    for (unsigned i = lane; i < ncand; i += 64) {
+        const ulonglong2 pr = W->cand[i];
+        const unsigned q = W->where[i];
+        if (zig_wedge_accept(pr.x, pr.y, wi, fi)) atomicOr(&W->wmask[q >> 5], 1u << (q & 31));
+    }
+    wave_lds_fence();
 }
 
-// pass 1: fun[2 b + e] = k_out << 16 | count of block b entered with e in {0, 1} positions consumed; successors that
-// will be entered with k >= 2 are evaluated here and appended to the patch list (key = b << 16 | k, value as fun)
-__global__ void __launch_bounds__(ZIG_T)
+// rows 0 .. 15 of block b: the class masks of every row (columns) - pass 1's vector work
+__device__ inline void block_classify(cols_t &c, u128 s_blk, u128 lane_m, u128 lane_c, u128 c64, const zig_lds &L,
+                                      zig_wlds *W) {
+    const int lane = threadIdx.x & 63;
+    constexpr u128 M64 = mk128(H_POW2.v[6].mhi, H_POW2.v[6].mlo);
+    u128 s = lane_m * s_blk + lane_c;                            // state after position `lane` of row 0
+    uint64_t raw_cur = pcg_out(s);
+    if (lane < 2 * ZIG_ROWS) W->wmask[lane] = 0;
+    unsigned ncand = 0;
+#pragma unroll
+    for (int j = 0; j < ZIG_ROWS; j++) {
+        s = s * M64 + c64;
+        const uint64_t raw_next = pcg_out(s);                    // row j + 1 (row 16: the next block's first row)
+        const unsigned idx = (unsigned)(raw_cur & 0xff);
+        const bool slow = ((raw_cur >> 9) & M52) >= L.ki[idx];
+        const uint64_t NF = __ballot(slow), Z = __ballot(slow && idx == 0);
+        const uint64_t Wm = NF & ~Z;
+        if (Wm) {
+            // the wedge draw of position p is the draw of position p + 1: the next lane, or lane 0 of the next row
+            uint64_t r1 = __shfl_down(raw_cur, 1);
+            const uint64_t first_next = readlane64(raw_next, 0);
+            if (lane == 63) r1 = first_next;
+            const unsigned add = __builtin_popcountll(Wm);
+            if (ncand + add > ZIG_WCAP) {
+                wedge_flush(W, ncand, L.wi, L.fi);
+                ncand = 0;
+            }
+            if ((Wm >> lane) & 1) {
+                const unsigned slot = ncand + mbcnt64(Wm);
+                W->cand[slot] = make_ulonglong2(raw_cur, r1);
+                W->where[slot] = (unsigned short)(64 * j + lane);
+            }
+            ncand += add;
+        }
+        col_set(c.nf_lo, c.nf_hi, j, NF);
+        col_set(c.z_lo, c.z_hi, j, Z);
+        raw_cur = raw_next;
+    }
+    wedge_flush(W, ncand, L.wi, L.fi);
+    c.w_lo = lane < ZIG_ROWS ? W->wmask[2 * lane] : 0u;
+    c.w_hi = lane < ZIG_ROWS ? W->wmask[2 * lane + 1] : 0u;
+    wave_lds_fence();
+}
+
+// pass 1: fun[2 b + e] = k_out << 16 | count of block b entered with e in {0, 1} positions consumed; classes[b][j] =
+// (A, B) of row j with A = wedge class, B = accepted wedge | tail class; successors that will be entered with k >= 2
+// are evaluated here and appended to the patch list (key = b << 16 | k, value as fun).
+// One wave per block; the waves of a workgroup share nothing but the tables.
+__global__ void __launch_bounds__(ZIG_WG)
 zig_count_kernel(const ulonglong2 *__restrict__ blk_state, uint64_t i_hi, uint64_t i_lo, long nblk,
-                 unsigned *__restrict__ fun, ulonglong2 *__restrict__ patch, unsigned patch_cap, zig_status *st) {
-    constexpr int R = ZIG_R_CHUNK, T = ZIG_T;
+                 unsigned *__restrict__ fun, ulonglong2 *__restrict__ classes, ulonglong2 *__restrict__ patch,
+                 unsigned patch_cap, zig_status *st) {
     __shared__ zig_lds L;
+    __shared__ zig_wlds Wall[ZIG_WG / 64];
+    zig_wlds *W = &Wall[threadIdx.x >> 6];
     zig_lds_fill(L);
     const u128 inc = mk128(i_hi, i_lo);
-    const int t = threadIdx.x;
-    for (long b = blockIdx.x; b < nblk; b += gridDim.x) {
-        chunk_t<R> c;
-        chunk_build<R>(c, thread_state(blk_state, b, inc), inc, L.ki, L.wi, L.fi);
-        unsigned kfwd[2];
-        for (int e = 0; e < 2; e++) {
-            unsigned kin, kout, cnt;
-            block_resolve<R, T>(c, inc, (unsigned)e, L.k, L.wi, &st->error, kin, kout, cnt);
-            const unsigned total = block_sum<T>(cnt, L.red);
-            const unsigned kb = L.k[T];                  // k_out of the last thread
-            if (t == 0) fun[2 * b + e] = (kb << 16) | total;
-            kfwd[e] = kb;
-            __syncthreads();
+    const u128 c64 = inc * mk128(H_POW2.v[6].ghi, H_POW2.v[6].glo);
+    const int lane = threadIdx.x & 63;
+    // from the state before a block's first position to the one that outputs position `lane`: s -> lane_m s + lane_c
+    const jump_t lj = ZIG_LANE.v[lane];
+    const u128 lane_m = mk128(lj.mhi, lj.mlo), lane_c = inc * mk128(lj.ghi, lj.glo);
+    const long wave0 = (long)blockIdx.x * (ZIG_WG / 64) + (threadIdx.x >> 6), nwave = (long)gridDim.x * (ZIG_WG / 64);
+    for (long b = wave0; b < nblk; b += nwave) {
+        const ulonglong2 bs = blk_state[b];
+        const u128 s_blk = mk128(uni64(bs.x), uni64(bs.y));
+        cols_t c;
+        block_classify(c, s_blk, lane_m, lane_c, c64, L, W);
+        if (lane < ZIG_ROWS) {
+            const uint64_t nf = ((uint64_t)c.nf_hi << 32) | c.nf_lo, z = ((uint64_t)c.z_hi << 32) | c.z_lo,
+                           w = ((uint64_t)c.w_hi << 32) | c.w_lo;
+            classes[b * ZIG_ROWS + lane] = make_ulonglong2(nf & ~z, w | z);
         }
+        unsigned kb0, total0, p0, c0, kb1, total1, p1, c1;
+        block_chain(c, s_blk, inc, 0u, kb0, total0, p0, c0, ZIG_ROWS, &st->error);
+        // entry 1 changes row 0 only, unless the row hands on a different position
+        block_chain(c, s_blk, inc, 1u, kb1, total1, p1, c1, 1, &st->error);
+        if (p1 == p0) {
+            kb1 = kb0;
+            total1 = total0 - c0 + c1;
+        } else {
+            block_chain(c, s_blk, inc, 1u, kb1, total1, p1, c1, ZIG_ROWS, &st->error);
+        }
+        if (lane == 0) *reinterpret_cast<uint2 *>(fun + 2 * b) = make_uint2((kb0 << 16) | total0, (kb1 << 16) | total1);
         // rare: a tail sample (or several) reaches across the end of the block
         for (int e = 0; e < 2; e++) {
-            unsigned k = kfwd[e];
-            if (e == 1 && k == kfwd[0]) break;
+            unsigned k = e ? kb1 : kb0;
+            if (e == 1 && kb1 == kb0) break;
             for (long bb = b + 1; k >= 2 && bb < nblk; bb++) {
-                chunk_t<R> c2;
-                chunk_build<R>(c2, thread_state(blk_state, bb, inc), inc, L.ki, L.wi, L.fi);
-                unsigned kin, kout, cnt;
-                block_resolve<R, T>(c2, inc, k, L.k, L.wi, &st->error, kin, kout, cnt);
-                const unsigned total = block_sum<T>(cnt, L.red);
-                const unsigned kb = L.k[T];
-                if (t == 0) {
+                const ulonglong2 bs2 = blk_state[bb];
+                const u128 s2 = mk128(uni64(bs2.x), uni64(bs2.y));
+                cols_t c2;
+                block_classify(c2, s2, lane_m, lane_c, c64, L, W);
+                unsigned kb, total, pp, cc;
+                block_chain(c2, s2, inc, k, kb, total, pp, cc, ZIG_ROWS, &st->error);
+                if (lane == 0) {
                     const unsigned slot = atomicAdd(&st->npatch, 1u);
                     if (slot < patch_cap) patch[slot] = make_ulonglong2(((unsigned long long)bb << 16) | k, (kb << 16) | total);
                     else atomicOr(&st->error, 2u);
                 }
                 k = kb;
-                __syncthreads();
             }
         }
     }
 }
 
+// ---- the scan over the block functions ---------------------------------------------------------------------------
+// Three small kernels: (1) every tile of 64 x 8 consecutive blocks (one wave; lane = 8 blocks) reduced to its function
+// on {0, 1}; (2) one workgroup composes the tile functions and gives every tile its (k, ordinal); (3) every tile
+// writes the (k, ordinal) of its blocks.  Inside a tile the lane entries come from the same fixed-point iteration
+// from k = 0: almost every block maps 0 and 1 to the same k_out, which ends the dependency.
 __device__ inline unsigned patch_lookup(const ulonglong2 *patch, unsigned npatch, long b, unsigned k, unsigned *err) {
     const unsigned long long key = ((unsigned long long)b << 16) | k;
     for (unsigned i = 0; i < npatch; i++)
@@ -442,31 +475,109 @@ __device__ inline unsigned patch_lookup(const ulonglong2 *patch, unsigned npatch
     atomicOr(err, 4u);
     return 0u;
 }
+__device__ inline void fun_step(long b, uint2 w2, unsigned &k, unsigned &cnt, const ulonglong2 *patch, unsigned npatch,
+                                unsigned *err) {
+    const unsigned w = k < 2 ? (k ? w2.y : w2.x) : patch_lookup(patch, npatch, b, k, err);
+    k = w >> 16;
+    cnt += w & 0xffffu;
+}
+#define ZIG_SEG 8                       // blocks per lane
+#define ZIG_TILE (64 * ZIG_SEG)         // blocks per tile
+struct tile_t {
+    uint2 w2[ZIG_SEG];
+    long b0;                            // first block of the lane
+    int nv;                             // blocks of the lane that exist
+};
+__device__ inline void tile_load(tile_t &t, const unsigned *fun, long tile, long nblk) {
+    const int lane = threadIdx.x & 63;
+    t.b0 = tile * ZIG_TILE + (long)lane * ZIG_SEG;
+    t.nv = (int)std::max<long>(0, std::min<long>(ZIG_SEG, nblk - t.b0));
+    const uint2 *f2 = reinterpret_cast<const uint2 *>(fun);
+#pragma unroll
+    for (int j = 0; j < ZIG_SEG; j++) t.w2[j] = j < t.nv ? f2[t.b0 + j] : make_uint2(0u, 0u);
+}
+__device__ inline void seg_eval(const tile_t &t, unsigned k, unsigned &kout, unsigned &cnt, const ulonglong2 *patch,
+                                unsigned npatch, unsigned *err) {
+    unsigned c = 0;
+#pragma unroll
+    for (int j = 0; j < ZIG_SEG; j++)
+        if (j < t.nv) fun_step(t.b0 + j, t.w2[j], k, c, patch, npatch, err);
+    kout = k;
+    cnt = c;
+}
+// lane entries of a tile entered with k_tile; returns the tile's k_out, every lane keeps its (kin, cnt)
+__device__ inline unsigned tile_resolve(const tile_t &t, unsigned k_tile, unsigned &kin, unsigned &cnt,
+                                        const ulonglong2 *patch, unsigned npatch, unsigned *err) {
+    const int lane = threadIdx.x & 63;
+    kin = lane == 0 ? k_tile : 0u;
+    unsigned assumed = 0, kout = 0;
+    for (int it = 0; it <= 64; it++) {
+        seg_eval(t, kin, kout, cnt, patch, npatch, err);
+        const bool changed = lane != 63 && kout != assumed;
+        assumed = kout;
+        if (!__any(changed)) break;
+        const unsigned up = __shfl_up(kout, 1);
+        kin = lane == 0 ? k_tile : up;
+    }
+    return __shfl(kout, 63);
+}
+__device__ inline unsigned wave_sum(unsigned v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
 
-// one workgroup: composes the block functions, entry[b] = (k, first ordinal) of every block
-__global__ void __launch_bounds__(ZIG_T)
-zig_scan_kernel(long nblk, const unsigned *__restrict__ fun, const ulonglong2 *__restrict__ patch, unsigned patch_cap,
-                unsigned long long ord0, ulonglong2 *__restrict__ entry, zig_status *st) {
-    constexpr int T = ZIG_T;
+__global__ void __launch_bounds__(256)
+zig_tile_kernel(long nblk, long ntile, const unsigned *__restrict__ fun, const ulonglong2 *__restrict__ patch,
+                unsigned patch_cap, uint4 *__restrict__ tile_fun, zig_status *st) {
+    const long tile = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tile >= ntile) return;
+    const unsigned npatch = min(st->npatch, patch_cap);
+    tile_t t;
+    tile_load(t, fun, tile, nblk);
+    unsigned kin, cnt;
+    const unsigned k0 = tile_resolve(t, 0u, kin, cnt, patch, npatch, &st->error);
+    const unsigned c0 = wave_sum(cnt);
+    const unsigned k1 = tile_resolve(t, 1u, kin, cnt, patch, npatch, &st->error);
+    const unsigned c1 = wave_sum(cnt);
+    if ((threadIdx.x & 63) == 0) tile_fun[tile] = make_uint4(k0, c0, k1, c1);
+}
+
+// one workgroup: tile_entry[t] = (k, ordinal) of every tile; a tile entered with k >= 2 (a tail sample across a tile
+// boundary) is walked block by block here
+#define ZIG_TOP_T 1024
+__global__ void __launch_bounds__(ZIG_TOP_T)
+zig_top_kernel(long nblk, long ntile, const unsigned *__restrict__ fun, const ulonglong2 *__restrict__ patch,
+               unsigned patch_cap, const uint4 *__restrict__ tile_fun, unsigned long long ord0,
+               ulonglong2 *__restrict__ tile_entry, zig_status *st) {
+    constexpr int T = ZIG_TOP_T;
     __shared__ unsigned g_k[T][2];
     __shared__ unsigned long long g_c[T][2];
-    __shared__ unsigned s_k[T + 1];
-    __shared__ unsigned long long s_o[T + 1];
+    __shared__ unsigned s_k[T];
+    __shared__ unsigned long long s_o[T];
     const int t = threadIdx.x;
     const unsigned npatch = min(st->npatch, patch_cap);
-    const long seg = (nblk + T - 1) / T;
-    const long b0 = std::min<long>(nblk, t * seg), b1 = std::min<long>(nblk, b0 + seg);
-    auto walk = [&](unsigned k, unsigned long long o, bool write, unsigned &k_end, unsigned long long &o_end) {
-        for (long b = b0; b < b1; b++) {
-            if (write) entry[b] = make_ulonglong2(k, o);
-            const unsigned w = k < 2 ? fun[2 * b + k] : patch_lookup(patch, npatch, b, k, &st->error);
-            k = w >> 16;
-            o += w & 0xffffu;
+    const long seg = (ntile + T - 1) / T;
+    const long t0 = std::min<long>(ntile, t * seg), t1 = std::min<long>(ntile, t0 + seg);
+    auto tile_step = [&](long tile, unsigned &k, unsigned long long &o) {
+        if (k < 2) {
+            const uint4 f = tile_fun[tile];
+            o += k ? f.w : f.y;
+            k = k ? f.z : f.x;
+        } else {
+            const uint2 *f2 = reinterpret_cast<const uint2 *>(fun);
+            const long c0 = tile * ZIG_TILE, c1 = std::min<long>(nblk, c0 + ZIG_TILE);
+            unsigned c = 0;
+            for (long b = c0; b < c1; b++) fun_step(b, f2[b], k, c, patch, npatch, &st->error);
+            o += c;
         }
-        k_end = k;
-        o_end = o;
     };
-    for (int e = 0; e < 2; e++) walk((unsigned)e, 0ull, false, g_k[t][e], g_c[t][e]);
+    for (int e = 0; e < 2; e++) {
+        unsigned k = e;
+        unsigned long long o = 0;
+        for (long tile = t0; tile < t1; tile++) tile_step(tile, k, o);
+        g_k[t][e] = k;
+        g_c[t][e] = o;
+    }
     __syncthreads();
     if (t == 0) {
         unsigned k = 0;
@@ -478,74 +589,130 @@ zig_scan_kernel(long nblk, const unsigned *__restrict__ fun, const ulonglong2 *_
                 o += g_c[i][k];
                 k = g_k[i][k];
             } else {
-                // a tail sample across a segment boundary: this segment is walked here (its owner starts from k < 2)
-                const long c0 = std::min<long>(nblk, i * seg), c1 = std::min<long>(nblk, c0 + seg);
-                for (long b = c0; b < c1; b++) {
-                    const unsigned w = k < 2 ? fun[2 * b + k] : patch_lookup(patch, npatch, b, k, &st->error);
-                    k = w >> 16;
-                    o += w & 0xffffu;
-                }
+                const long a0 = std::min<long>(ntile, i * seg), a1 = std::min<long>(ntile, a0 + seg);
+                for (long tile = a0; tile < a1; tile++) tile_step(tile, k, o);
             }
         }
-        s_k[T] = k;
-        s_o[T] = o;
         st->total = o;
         st->k_last = k;
     }
     __syncthreads();
-    unsigned ke;
-    unsigned long long oe;
-    walk(s_k[t], s_o[t], true, ke, oe);
+    unsigned k = s_k[t];
+    unsigned long long o = s_o[t];
+    for (long tile = t0; tile < t1; tile++) {
+        tile_entry[tile] = make_ulonglong2(k, o);
+        tile_step(tile, k, o);
+    }
 }
 
-// pass 2: every block with its true entry; the normals go to g[ordinal] for ordinal < n
-__global__ void __launch_bounds__(ZIG_T)
+__global__ void __launch_bounds__(256)
+zig_entry_kernel(long nblk, long ntile, const unsigned *__restrict__ fun, const ulonglong2 *__restrict__ patch,
+                 unsigned patch_cap, const ulonglong2 *__restrict__ tile_entry, ulonglong2 *__restrict__ entry,
+                 zig_status *st) {
+    const long tile = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tile >= ntile) return;
+    const int lane = threadIdx.x & 63;
+    const unsigned npatch = min(st->npatch, patch_cap);
+    tile_t t;
+    tile_load(t, fun, tile, nblk);
+    const ulonglong2 te = tile_entry[tile];
+    unsigned kin, cnt;
+    tile_resolve(t, (unsigned)te.x, kin, cnt, patch, npatch, &st->error);
+    unsigned incl = cnt;
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned v = __shfl_up(incl, o);
+        if (lane >= o) incl += v;
+    }
+    unsigned k = kin;
+    unsigned long long o = te.y + (incl - cnt);
+#pragma unroll
+    for (int j = 0; j < ZIG_SEG; j++) {
+        if (j < t.nv) {
+            entry[t.b0 + j] = make_ulonglong2(k, o);
+            unsigned c = 0;
+            fun_step(t.b0 + j, t.w2[j], k, c, patch, npatch, &st->error);
+            o += c;
+        }
+    }
+}
+
+// pass 2: every block with its true entry; the normals go to g[ordinal] for ordinal < n.  Lane p of row j holds position
+// 64 j + p: the samples of a row leave as one store instruction to consecutive addresses.
+__global__ void __launch_bounds__(ZIG_WG)
 zig_emit_kernel(const ulonglong2 *__restrict__ blk_state, uint64_t i_hi, uint64_t i_lo, long nblk,
-                const ulonglong2 *__restrict__ entry, unsigned long long pos0, unsigned long long n,
-                double *__restrict__ g, zig_status *st) {
-    constexpr int R = ZIG_R_CHUNK, T = ZIG_T;
+                const ulonglong2 *__restrict__ entry, const ulonglong2 *__restrict__ classes, unsigned long long pos0,
+                unsigned long long n, double *__restrict__ g, zig_status *st) {
     __shared__ zig_lds L;
-    __shared__ double stage[ZIG_BLK + ZIG_BLK / 16 + 2];
-    __shared__ unsigned wsum[T / 64];
     zig_lds_fill(L);
     const u128 inc = mk128(i_hi, i_lo);
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    for (long b = blockIdx.x; b < nblk; b += gridDim.x) {
+    const u128 c64 = inc * mk128(H_POW2.v[6].ghi, H_POW2.v[6].glo);
+    constexpr u128 M64 = mk128(H_POW2.v[6].mhi, H_POW2.v[6].mlo);
+    const int lane = threadIdx.x & 63;
+    const jump_t lj = ZIG_LANE.v[lane];
+    const u128 lane_m = mk128(lj.mhi, lj.mlo), lane_c = inc * mk128(lj.ghi, lj.glo);
+    const long wave0 = (long)blockIdx.x * (ZIG_WG / 64) + (threadIdx.x >> 6), nwave = (long)gridDim.x * (ZIG_WG / 64);
+    for (long b = wave0; b < nblk; b += nwave) {
         const ulonglong2 en = entry[b];
-        if (en.y >= n) break;                               // (blocks are in ordinal order: nothing left to write)
-        chunk_t<R> c;
-        chunk_build<R>(c, thread_state(blk_state, b, inc), inc, L.ki, L.wi, L.fi);
-        unsigned kin, kout, cnt;
-        block_resolve<R, T>(c, inc, (unsigned)en.x, L.k, L.wi, &st->error, kin, kout, cnt);
-        // exclusive prefix of the counts over the block
-        unsigned incl = cnt;
-        for (int o = 1; o < 64; o <<= 1) {
-            const unsigned v = __shfl_up(incl, o);
-            if (lane >= o) incl += v;
-        }
-        if (lane == 63) wsum[wave] = incl;
-        __syncthreads();
-        unsigned wbase = 0, total = 0;
+        const unsigned long long ord_blk = uni64(en.y);
+        if (ord_blk >= n) break;                            // (blocks are in ordinal order: nothing left to write)
+        const ulonglong2 bs = blk_state[b];
+        const u128 s_blk = mk128(uni64(bs.x), uni64(bs.y));
+        // classes of the 16 rows, row j in lane j
+        ulonglong2 cl = make_ulonglong2(0ull, 0ull);
+        if (lane < ZIG_ROWS) cl = classes[b * ZIG_ROWS + lane];
+        const uint64_t z_col = cl.y & ~cl.x, w_col = cl.y & cl.x, nf_col = cl.x | z_col;
+        u128 s = lane_m * s_blk + lane_c;                    // state after position `lane` of row 0
+        unsigned pos = uni32((unsigned)en.x);
+        unsigned long long ord = ord_blk;                    // ordinal of the next sample
+        const unsigned long long blk_pos = pos0 + (unsigned long long)b * ZIG_BLK;
 #pragma unroll
-        for (int w = 0; w < T / 64; w++) {
-            if (w < wave) wbase += wsum[w];
-            total += wsum[w];
+        for (int j = 0; j < ZIG_ROWS; j++) {
+            const uint64_t raw = pcg_out(s);
+            s = s * M64 + c64;
+            if (pos >= 64u * (j + 1)) continue;
+            const uint64_t nf_j = readlane64(nf_col, j), z_j = readlane64(z_col, j), w_j = readlane64(w_col, j);
+            while (pos < 64u * (j + 1)) {
+                const row_eval_t r = row_eval(nf_j, z_j, w_j, j, pos);
+                const uint64_t e = r.e_fast | r.e_wedge;
+                if ((e >> lane) & 1) {
+                    const unsigned long long o = ord + mbcnt64(e);
+                    if (o < n) {
+                        g[o] = zig_value(raw, L.wi);
+                        if (o + 1 == n) st->n_raw = blk_pos + 64u * j + lane + 1 + ((r.e_wedge >> lane) & 1);
+                    }
+                }
+                ord += __builtin_popcountll(e);
+                if (r.tl_bit == 64) break;
+                double v;
+                unsigned consumed;
+                zig_tail_walk(s_blk, inc, 64u * j + r.tl_bit, v, consumed, &st->error);
+                const uint64_t rq = readlane64(raw, r.tl_bit);
+                if ((((rq >> 9) & M52) >> 8) & 1) v = -v;
+                if (lane == 0 && ord < n) {
+                    g[ord] = v;
+                    if (ord + 1 == n) st->n_raw = blk_pos + 64u * j + r.tl_bit + 1 + consumed;
+                }
+                ord += 1;
+                pos = 64u * j + r.tl_bit + 1 + consumed;
+            }
         }
-        emit_ctx ec;
-        ec.stage = stage;
-        ec.obase = wbase + incl - cnt;
-        ec.blk_ord = en.y;
-        ec.n = n;
-        ec.pos = pos0 + (unsigned long long)b * ZIG_BLK + (unsigned long long)t * R;
-        ec.n_raw = &st->n_raw;
-        unsigned k2, c2;
-        chain_eval<R, true>(c, inc, kin, k2, c2, L.wi, &st->error, &ec);
-        __syncthreads();
-        const unsigned long long room = n - en.y;
-        const unsigned m = (unsigned)std::min<unsigned long long>(total, room);
-        for (unsigned i = t; i < m; i += T) g[en.y + i] = stage[stage_pad(i)];
-        __syncthreads();
     }
+}
+
+__global__ void zig_debug_kernel(const ulonglong2 *blk_state, uint64_t i_hi, uint64_t i_lo, long b, uint64_t *out) {
+    const u128 inc = mk128(i_hi, i_lo);
+    const int lane = threadIdx.x & 63;
+    const jump_t lj = ZIG_LANE.v[lane];
+    const u128 lane_m = mk128(lj.mhi, lj.mlo), lane_c = inc * mk128(lj.ghi, lj.glo);
+    const ulonglong2 bs = blk_state[b];
+    const u128 s_blk = mk128(uni64(bs.x), uni64(bs.y));
+    const u128 s = lane_m * s_blk + lane_c;
+    out[lane] = pcg_out(s);
+    const u128 s2 = jump_apply(ZIG_LANE.v[lane], mk128(bs.x, bs.y), inc);
+    out[64 + lane] = pcg_out(s2);
+    constexpr u128 M64 = mk128(H_POW2.v[6].mhi, H_POW2.v[6].mlo);
+    const u128 c64 = inc * mk128(H_POW2.v[6].ghi, H_POW2.v[6].glo);
+    out[128 + lane] = pcg_out(s2 * M64 + c64);
 }
 
 }  // namespace
@@ -573,10 +740,14 @@ int corahip_normals_pcg64(corahip_ctx *ctx, const uint64_t state[2], const uint6
         // 1.02145 raw draws per normal on average; the margin covers 200 sigma, and a short round is followed by another
         const long nblk = (long)((want + want / 44 + 2 * ZIG_BLK) / ZIG_BLK) + 1;
         const unsigned patch_cap = (unsigned)(nblk / 64 + 1024);
+        const long ntile = (nblk + ZIG_TILE - 1) / ZIG_TILE;
         const size_t off_fun = sizeof(ulonglong2) * (size_t)nblk;
         const size_t off_entry = off_fun + sizeof(unsigned) * 2 * (size_t)nblk;
         const size_t off_patch = off_entry + sizeof(ulonglong2) * (size_t)nblk;
-        const size_t off_st = off_patch + sizeof(ulonglong2) * patch_cap;
+        const size_t off_cls = off_patch + sizeof(ulonglong2) * patch_cap;
+        const size_t off_tf = off_cls + sizeof(ulonglong2) * ZIG_ROWS * (size_t)nblk;
+        const size_t off_te = off_tf + sizeof(uint4) * (size_t)ntile;
+        const size_t off_st = off_te + sizeof(ulonglong2) * (size_t)ntile;
         char *ws = nullptr;
         int rc = corahip_ctx_scratch(ctx, 6, off_st + sizeof(zig_status), (void **)&ws);
         if (rc) return rc;
@@ -584,22 +755,71 @@ int corahip_normals_pcg64(corahip_ctx *ctx, const uint64_t state[2], const uint6
         unsigned *fun = (unsigned *)(ws + off_fun);
         ulonglong2 *entry = (ulonglong2 *)(ws + off_entry);
         ulonglong2 *patch = (ulonglong2 *)(ws + off_patch);
+        ulonglong2 *classes = (ulonglong2 *)(ws + off_cls);
+        uint4 *tile_fun = (uint4 *)(ws + off_tf);
+        ulonglong2 *tile_entry = (ulonglong2 *)(ws + off_te);
         zig_status *st = (zig_status *)(ws + off_st);
         HIP_TRY(hipMemsetAsync(st, 0, sizeof(zig_status), ctx->stream));
-        zig_seek_kernel<<<(unsigned)((nblk + 255) / 256), 256, 0, ctx->stream>>>(state[0], state[1], inc[0], inc[1], pos0, nblk,
-                                                                                blk_state);
-        LAUNCH_CHECK();
-        const unsigned grid = (unsigned)std::min<long>(nblk, (long)ctx->num_cu * 8);
-        zig_count_kernel<<<grid, ZIG_T, 0, ctx->stream>>>(blk_state, inc[0], inc[1], nblk, fun, patch, patch_cap, st);
-        LAUNCH_CHECK();
-        zig_scan_kernel<<<1, ZIG_T, 0, ctx->stream>>>(nblk, fun, patch, patch_cap, ord0, entry, st);
-        LAUNCH_CHECK();
-        zig_emit_kernel<<<grid, ZIG_T, 0, ctx->stream>>>(blk_state, inc[0], inc[1], nblk, entry, pos0, (unsigned long long)n, g,
-                                                         st);
-        LAUNCH_CHECK();
+        {
+            StageTimer t0(ctx, "zig_seek");
+            zig_seek_kernel<<<(unsigned)((nblk + 255) / 256), 256, 0, ctx->stream>>>(state[0], state[1], inc[0], inc[1], pos0,
+                                                                                    nblk, blk_state);
+            LAUNCH_CHECK();
+        }
+        const unsigned grid = (unsigned)std::min<long>((nblk + ZIG_WG / 64 - 1) / (ZIG_WG / 64), (long)ctx->num_cu * 32);
+        {
+            StageTimer t1(ctx, "zig_count");
+            zig_count_kernel<<<grid, ZIG_WG, 0, ctx->stream>>>(blk_state, inc[0], inc[1], nblk, fun, classes, patch, patch_cap,
+                                                              st);
+            LAUNCH_CHECK();
+        }
+        {
+            StageTimer t2(ctx, "zig_scan");
+            const unsigned tgrid = (unsigned)((ntile + 3) / 4);
+            zig_tile_kernel<<<tgrid, 256, 0, ctx->stream>>>(nblk, ntile, fun, patch, patch_cap, tile_fun, st);
+            LAUNCH_CHECK();
+            zig_top_kernel<<<1, ZIG_TOP_T, 0, ctx->stream>>>(nblk, ntile, fun, patch, patch_cap, tile_fun, ord0, tile_entry, st);
+            LAUNCH_CHECK();
+            zig_entry_kernel<<<tgrid, 256, 0, ctx->stream>>>(nblk, ntile, fun, patch, patch_cap, tile_entry, entry, st);
+            LAUNCH_CHECK();
+        }
+        {
+            StageTimer t3(ctx, "zig_emit");
+            zig_emit_kernel<<<grid, ZIG_WG, 0, ctx->stream>>>(blk_state, inc[0], inc[1], nblk, entry, classes, pos0,
+                                                             (unsigned long long)n, g, st);
+            LAUNCH_CHECK();
+        }
         zig_status hs;
         HIP_TRY(hipMemcpyAsync(&hs, st, sizeof(hs), hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(hipStreamSynchronize(ctx->stream));
+        if (getenv("CORAHIP_ZIG_DEBUG")) {
+            const long nb = std::min<long>(nblk, 8);
+            std::vector<unsigned> hf(2 * nb);
+            std::vector<ulonglong2> he(nb), hb(nb);
+            uint4 tf;
+            ulonglong2 te;
+            (void)hipMemcpy(hf.data(), fun, sizeof(unsigned) * 2 * nb, hipMemcpyDeviceToHost);
+            (void)hipMemcpy(he.data(), entry, sizeof(ulonglong2) * nb, hipMemcpyDeviceToHost);
+            (void)hipMemcpy(hb.data(), blk_state, sizeof(ulonglong2) * nb, hipMemcpyDeviceToHost);
+            (void)hipMemcpy(&tf, tile_fun, sizeof(tf), hipMemcpyDeviceToHost);
+            (void)hipMemcpy(&te, tile_entry, sizeof(te), hipMemcpyDeviceToHost);
+            fprintf(stderr, "zig debug: nblk %ld ntile %ld total %llu k_last %u npatch %u err %u n_raw %llu | tile0 fun (%u %u %u %u) entry (%llu %llu)\n",
+                    nblk, ntile, hs.total, hs.k_last, hs.npatch, hs.error, hs.n_raw, tf.x, tf.y, tf.z, tf.w, te.x, te.y);
+            {
+                uint64_t *dbg = nullptr, h[192];
+                (void)hipMalloc(&dbg, sizeof(h));
+                zig_debug_kernel<<<1, 64, 0, ctx->stream>>>(blk_state, inc[0], inc[1], 1, dbg);
+                (void)hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost);
+                (void)hipFree(dbg);
+                fprintf(stderr, "  blk 1 raws: hoisted %016llx %016llx %016llx | table %016llx %016llx %016llx | row 1 %016llx %016llx\n",
+                        (unsigned long long)h[0], (unsigned long long)h[1], (unsigned long long)h[63], (unsigned long long)h[64],
+                        (unsigned long long)h[65], (unsigned long long)h[127], (unsigned long long)h[128], (unsigned long long)h[129]);
+            }
+            for (long i = 0; i < nb; i++)
+                fprintf(stderr, "  blk %ld: state %016llx%016llx fun0 (k %u cnt %u) fun1 (k %u cnt %u) entry (k %llu ord %llu)\n", i,
+                        hb[i].x, hb[i].y, hf[2 * i] >> 16, hf[2 * i] & 0xffff, hf[2 * i + 1] >> 16, hf[2 * i + 1] & 0xffff,
+                        he[i].x, he[i].y);
+        }
         if (hs.error) {
             corahip_set_error("normals_pcg64: device status %u (1 tail loop cap, 2 patch list full, 4 patch missing)", hs.error);
             return CORAHIP_ESTATE;

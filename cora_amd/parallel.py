@@ -538,7 +538,7 @@ def mkfullsky_sharded(corr_local, global_shape, nside, rng=None, alms=False, ctx
         alm = (ctx.draw_alm_philox_rows(T, info, seed, lmax, F, nu0, nnu) if rows
                else ctx.draw_alm_philox(T, info, seed, lmax, F, nu0=nu0, nnu=nnu))
     else:
-        g = torch.from_numpy(skysim._host_normals(F, lmax, rng)).to(ctx.device)
+        g = skysim.stream_normals(ctx, F, lmax, rng)
         if rows:   # the host-stream kernel takes full factors: embed the row block
             Tf = torch.zeros((L, F, F), dtype=torch.float64, device=ctx.device)
             Tf[:, nu0:nu0 + nnu, :] = T

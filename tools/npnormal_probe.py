@@ -55,7 +55,14 @@ def main():
         ctx.normals_pcg64(st["state"], st["inc"], n, out=g)
         torch.cuda.synchronize()
         print("cfg-3 stream (%.3e normals): %.2f ms" % (n, 1e3 * (time.perf_counter() - t0)))
-    ctx.profile_enable(True) if hasattr(ctx, "profile_enable") else None
+    ctx.profile_enable(True)
+    ctx.profile_reset()
+    reps = 5
+    for _ in range(reps):
+        ctx.normals_pcg64(st["state"], st["inc"], n, out=g)
+    print("  per kernel (ms): " + ", ".join("%s %.3f" % (k, ctx.profile_get(k)[0] / reps)
+                                          for k in ("zig_seek", "zig_count", "zig_scan", "zig_emit", "normals_pcg64")))
+    ctx.profile_enable(False)
     print("ALL OK" if ok else "FAILED")
     return 0 if ok else 1
 
