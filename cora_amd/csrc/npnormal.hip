@@ -46,6 +46,9 @@ typedef unsigned __int128 u128;
 #define ZIG_ROWS 16         // rows of 64 consecutive positions per block: lane p of row j holds position 64 j + p
 #define ZIG_BLK (64 * ZIG_ROWS)
 #define ZIG_WG 256          // threads per workgroup of the count / emit kernels (independent waves, one block each)
+#ifndef ZIG_ABLATE
+#define ZIG_ABLATE 0        // diagnostic builds (make zigablate; wrong results, timing only): 1 no wedge gather / tests,
+#endif                      //   2 also no classification (generator only), 3 no chain in pass 1, 4 pass 2 without stores
 
 namespace {
 
@@ -224,15 +227,11 @@ __device__ inline uint64_t col_get(unsigned lo, unsigned hi, int j) {
     return ((uint64_t)readlane32(hi, j) << 32) | readlane32(lo, j);
 }
 
-// tail sample started at position q of the block (wave-uniform; every lane computes the same): the value up to its
-// sign, and the positions consumed after q
-__device__ __attribute__((noinline)) void zig_tail_walk(u128 s_blk, u128 inc, unsigned q, double &val, unsigned &consumed,
-                                                        unsigned *err) {
+// tail sample whose first draw came out of state `s` (wave-uniform; every lane computes the same): the value with its
+// sign, and the draws consumed after that first one
+__device__ __attribute__((noinline)) void zig_tail_from(u128 s, u128 inc, double &val, unsigned &consumed, unsigned *err) {
 #pragma clang fp contract(off)
-    u128 s = s_blk;                              // state before the block's first position -> after position q
-    const unsigned n = q + 1;
-    for (int i = 0; i < 32 && (n >> i); i++)
-        if ((n >> i) & 1) s = jump_apply(ZIG_POW2.v[i], s, inc);
+    const uint64_t r0 = pcg_out(s);
     unsigned c = 0;
     double xx = 0.0;
     for (int it = 0;; it++) {
@@ -249,8 +248,41 @@ __device__ __attribute__((noinline)) void zig_tail_walk(u128 s_blk, u128 inc, un
             break;
         }
     }
-    val = ZIG_NOR_R + xx;
+    const bool neg = (((r0 >> 9) & M52) >> 8) & 1;
+    val = neg ? -(ZIG_NOR_R + xx) : ZIG_NOR_R + xx;
     consumed = c;
+}
+// the same for position q of a block, from the state before the block's first position (a jump of q + 1 steps)
+__device__ inline void zig_tail_walk(u128 s_blk, u128 inc, unsigned q, double &val, unsigned &consumed, unsigned *err) {
+    u128 s = s_blk;
+    const unsigned n = q + 1;
+    for (int i = 0; i < 32 && (n >> i); i++)
+        if ((n >> i) & 1) s = jump_apply(ZIG_POW2.v[i], s, inc);
+    zig_tail_from(s, inc, val, consumed, err);
+}
+__device__ inline u128 bcast128(u128 s, int l) {
+    const uint64_t hi = (uint64_t)(s >> 64), lo = (uint64_t)s;
+    return mk128(readlane64(hi, l), readlane64(lo, l));
+}
+
+// The tail-class positions of a block with what a sample started there consumes: up to four 16-bit entries
+// q | (consumed / 2) << 10 (never 0: a tail sample consumes at least two draws); bit 63 = more than fits - the block
+// then takes the sequential scalar chain.  Pass 1 makes the table where the row's generator state is live, pass 2
+// reads it back.
+#define ZIG_TT_OVER (1ull << 63)
+__device__ inline uint64_t ttab_add(uint64_t tt, unsigned ntail, unsigned q, unsigned consumed) {
+    if (ntail >= 4 || (consumed >> 1) >= 32) return tt | ZIG_TT_OVER;
+    return tt | ((uint64_t)(q | ((consumed >> 1) << 10)) << (16 * ntail));
+}
+// draws consumed by the tail sample started at position q (0: not in the table)
+__device__ inline unsigned ttab_lookup(uint64_t tt, unsigned q) {
+    unsigned c = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const unsigned en = (unsigned)(tt >> (16 * i)) & 0x7fffu;
+        if (en != 0 && (en & 0x3ffu) == q) c = (en >> 10) << 1;
+    }
+    return c;
 }
 
 // ---- the run scan ------------------------------------------------------------------------------------------------
@@ -310,6 +342,84 @@ __device__ inline void block_chain(const cols_t &c, u128 s_blk, u128 inc, unsign
     cnt = n;
 }
 
+// ---- the run scan of all 16 rows at once (lanes 0..15 = rows, 64-bit VALU) -------------------------------------------
+// Row j evaluated for both possible carries in (0: its first position starts a sample, 1: it is the wedge draw of the
+// previous row's last position); the 16 carries follow from the rows' (carry out | carry in) pairs with one integer add
+// (generate = out for carry 0, propagate = out only for carry 1).  A tail-class START anywhere on the chosen path
+// (a quarter of the blocks) sends the block to the sequential scalar chain instead.
+struct vrow_t {
+    uint64_t e, ew, t;      // samples of the row: fast | accepted wedge, the accepted wedges among them, tail samples
+    unsigned cout;          // positions of the next row the row's samples consume (0 / 1; more: `big`)
+    bool big;
+};
+__device__ inline vrow_t row_eval_vec(uint64_t nf_j, uint64_t z_j, uint64_t w_j, unsigned cin, uint64_t tt, unsigned q0) {
+    constexpr uint64_t EVEN = 0x5555555555555555ull;
+    vrow_t r;
+    r.e = r.ew = r.t = 0;
+    r.cout = 0;
+    r.big = false;
+    uint64_t low = cin;                                   // positions of the row already consumed
+    for (int it = 0; it < 6; it++) {
+        const uint64_t nf = nf_j & ~low;
+        const uint64_t starts = nf & ~(nf << 1);
+        const uint64_t re = nf & ~(nf + (starts & EVEN));
+        const uint64_t ro = nf & ~(nf + (starts & ~EVEN));
+        const uint64_t sn = (re & EVEN) | (ro & ~EVEN);
+        const uint64_t S = ~(sn << 1);
+        const uint64_t valid = ~low;
+        const uint64_t tl = S & z_j & valid;
+        const uint64_t upto = tl ? (valid & ((tl & (0ull - tl)) - 1ull)) : valid;
+        const uint64_t ew = sn & ~z_j & w_j & upto;
+        r.e |= (S & ~nf & upto) | ew;
+        r.ew |= ew;
+        if (!tl) {
+            r.cout = (unsigned)(sn >> 63);
+            return r;
+        }
+        const unsigned p = (unsigned)__builtin_ctzll(tl);
+        r.t |= 1ull << p;
+        const unsigned nxt = p + 1 + ttab_lookup(tt, q0 + p);
+        if (nxt >= 64) {
+            r.cout = nxt - 64;
+            r.big = r.cout > 1;
+            return r;
+        }
+        low = (1ull << nxt) - 1ull;
+    }
+    r.big = true;                                          // (more tail samples in one row than the loop allows)
+    return r;
+}
+// carries into rows 0..16 (bit j = row j's carry in; bit 16 = the block's carry out) for block entry k in {0, 1}
+__device__ inline unsigned row_carries(unsigned G, unsigned C1, unsigned k) {
+    if ((G & ~C1) == 0) {                       // no row inverts its carry: generate / propagate, one add
+        const unsigned sum = C1 + G + k;
+        return (sum ^ C1 ^ G) & 0x1ffffu;
+    }
+    unsigned c = k, cins = 0;
+    for (int j = 0; j < ZIG_ROWS; j++) {
+        cins |= c << j;
+        c = c ? (C1 >> j) & 1u : (G >> j) & 1u;
+    }
+    return cins | (c << 16);
+}
+// sum over lanes 0..15 (DPP row shifts; lanes 16.. must hold 0 or are ignored): the total, wave-uniform
+__device__ inline unsigned row16_sum(unsigned v) {
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);   // row_shr:8
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);   // row_shr:4
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);   // row_shr:2
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);   // row_shr:1
+    return readlane32(v, 15);
+}
+// inclusive prefix over lanes 0..15
+__device__ inline unsigned row16_scan(unsigned v) {
+    unsigned t;
+    t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true); v += t;
+    t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true); v += t;
+    t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true); v += t;
+    t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true); v += t;
+    return v;
+}
+
 struct zig_lds {
     uint64_t ki[256];
     double wi[256], fi[256];
@@ -358,22 +468,32 @@ __device__ inline void wedge_flush(zig_wlds *W, unsigned ncand, const double *wi
 }
 
 // rows 0 .. 15 of block b: the class masks of every row (columns) - pass 1's vector work
-__device__ inline void block_classify(cols_t &c, u128 s_blk, u128 lane_m, u128 lane_c, u128 c64, const zig_lds &L,
-                                      zig_wlds *W) {
+__device__ inline uint64_t block_classify(cols_t &c, u128 s_blk, u128 inc, u128 lane_m, u128 lane_c, u128 c64,
+                                          const zig_lds &L, zig_wlds *W, unsigned *err) {
     const int lane = threadIdx.x & 63;
     constexpr u128 M64 = mk128(H_POW2.v[6].mhi, H_POW2.v[6].mlo);
     u128 s = lane_m * s_blk + lane_c;                            // state after position `lane` of row 0
     uint64_t raw_cur = pcg_out(s);
     if (lane < 2 * ZIG_ROWS) W->wmask[lane] = 0;
-    unsigned ncand = 0;
+    unsigned ncand = 0, ntail = 0;
+    uint64_t tt = 0;
 #pragma unroll
     for (int j = 0; j < ZIG_ROWS; j++) {
+        const u128 s_row = s;                                    // the states that put out row j
         s = s * M64 + c64;
         const uint64_t raw_next = pcg_out(s);                    // row j + 1 (row 16: the next block's first row)
         const unsigned idx = (unsigned)(raw_cur & 0xff);
+#if ZIG_ABLATE == 2
+        const bool slow = (raw_cur >> 9) == 12345;
+#else
         const bool slow = ((raw_cur >> 9) & M52) >= L.ki[idx];
+#endif
         const uint64_t NF = __ballot(slow), Z = __ballot(slow && idx == 0);
+#if ZIG_ABLATE == 1 || ZIG_ABLATE == 2
+        const uint64_t Wm = 0;
+#else
         const uint64_t Wm = NF & ~Z;
+#endif
         if (Wm) {
             // the wedge draw of position p is the draw of position p + 1: the next lane, or lane 0 of the next row
             uint64_t r1 = __shfl_down(raw_cur, 1);
@@ -391,6 +511,15 @@ __device__ inline void block_classify(cols_t &c, u128 s_blk, u128 lane_m, u128 l
             }
             ncand += add;
         }
+        if (Z) {                                                 // 1.6 % of the rows: what a sample started there would consume
+            for (uint64_t zz = Z; zz; zz &= zz - 1) {
+                const int pz = __builtin_ctzll(zz);
+                double v;
+                unsigned consumed;
+                zig_tail_from(bcast128(s_row, pz), inc, v, consumed, err);
+                tt = ttab_add(tt, ntail++, 64u * j + pz, consumed);
+            }
+        }
         col_set(c.nf_lo, c.nf_hi, j, NF);
         col_set(c.z_lo, c.z_hi, j, Z);
         raw_cur = raw_next;
@@ -399,6 +528,7 @@ __device__ inline void block_classify(cols_t &c, u128 s_blk, u128 lane_m, u128 l
     c.w_lo = lane < ZIG_ROWS ? W->wmask[2 * lane] : 0u;
     c.w_hi = lane < ZIG_ROWS ? W->wmask[2 * lane + 1] : 0u;
     wave_lds_fence();
+    return tt;
 }
 
 // pass 1: fun[2 b + e] = k_out << 16 | count of block b entered with e in {0, 1} positions consumed; classes[b][j] =
@@ -407,8 +537,8 @@ __device__ inline void block_classify(cols_t &c, u128 s_blk, u128 lane_m, u128 l
 // One wave per block; the waves of a workgroup share nothing but the tables.
 __global__ void __launch_bounds__(ZIG_WG)
 zig_count_kernel(const ulonglong2 *__restrict__ blk_state, uint64_t i_hi, uint64_t i_lo, long nblk,
-                 unsigned *__restrict__ fun, ulonglong2 *__restrict__ classes, ulonglong2 *__restrict__ patch,
-                 unsigned patch_cap, zig_status *st) {
+                 unsigned *__restrict__ fun, ulonglong2 *__restrict__ classes, unsigned long long *__restrict__ tails,
+                 ulonglong2 *__restrict__ patch, unsigned patch_cap, zig_status *st) {
     __shared__ zig_lds L;
     __shared__ zig_wlds Wall[ZIG_WG / 64];
     zig_wlds *W = &Wall[threadIdx.x >> 6];
@@ -424,22 +554,47 @@ zig_count_kernel(const ulonglong2 *__restrict__ blk_state, uint64_t i_hi, uint64
         const ulonglong2 bs = blk_state[b];
         const u128 s_blk = mk128(uni64(bs.x), uni64(bs.y));
         cols_t c;
-        block_classify(c, s_blk, lane_m, lane_c, c64, L, W);
+        const uint64_t tt = block_classify(c, s_blk, inc, lane_m, lane_c, c64, L, W, &st->error);
         if (lane < ZIG_ROWS) {
             const uint64_t nf = ((uint64_t)c.nf_hi << 32) | c.nf_lo, z = ((uint64_t)c.z_hi << 32) | c.z_lo,
                            w = ((uint64_t)c.w_hi << 32) | c.w_lo;
             classes[b * ZIG_ROWS + lane] = make_ulonglong2(nf & ~z, w | z);
         }
-        unsigned kb0, total0, p0, c0, kb1, total1, p1, c1;
-        block_chain(c, s_blk, inc, 0u, kb0, total0, p0, c0, ZIG_ROWS, &st->error);
-        // entry 1 changes row 0 only, unless the row hands on a different position
-        block_chain(c, s_blk, inc, 1u, kb1, total1, p1, c1, 1, &st->error);
-        if (p1 == p0) {
-            kb1 = kb0;
-            total1 = total0 - c0 + c1;
-        } else {
-            block_chain(c, s_blk, inc, 1u, kb1, total1, p1, c1, ZIG_ROWS, &st->error);
+        if (lane == 0) tails[b] = tt;
+        unsigned kb0, total0, kb1, total1;
+#if ZIG_ABLATE == 3
+        kb0 = kb1 = 0;
+        total0 = total1 = 1000 + (c.nf_lo & 1);
+#else
+        {
+            const bool row = lane < ZIG_ROWS;
+            const uint64_t nf = ((uint64_t)c.nf_hi << 32) | c.nf_lo, z = ((uint64_t)c.z_hi << 32) | c.z_lo,
+                           w = ((uint64_t)c.w_hi << 32) | c.w_lo;
+            const vrow_t v0 = row_eval_vec(nf, z, w, 0u, tt, 64u * lane), v1 = row_eval_vec(nf, z, w, 1u, tt, 64u * lane);
+            const unsigned G = (unsigned)__ballot(row && v0.cout), C1 = (unsigned)__ballot(row && v1.cout);
+            const unsigned p0 = row ? __builtin_popcountll(v0.e | v0.t) : 0u;
+            const unsigned p1 = row ? __builtin_popcountll(v1.e | v1.t) : 0u;
+            const unsigned sum0 = row16_sum(p0);
+            const bool over = (tt & ZIG_TT_OVER) != 0;
+            unsigned kk[2], tt_[2];
+            for (unsigned e = 0; e < 2; e++) {
+                const unsigned cins = row_carries(G, C1, e);
+                const bool c1 = (cins >> lane) & 1u;
+                const bool slow = over || __ballot(row && (c1 ? v1.big : v0.big)) != 0;
+                if (!slow) {
+                    kk[e] = cins >> 16;
+                    tt_[e] = sum0 + row16_sum(c1 && row ? p1 - p0 : 0u);
+                } else {
+                    unsigned pp, cc;
+                    block_chain(c, s_blk, inc, e, kk[e], tt_[e], pp, cc, ZIG_ROWS, &st->error);
+                }
+            }
+            kb0 = kk[0];
+            total0 = tt_[0];
+            kb1 = kk[1];
+            total1 = tt_[1];
         }
+#endif
         if (lane == 0) *reinterpret_cast<uint2 *>(fun + 2 * b) = make_uint2((kb0 << 16) | total0, (kb1 << 16) | total1);
         // rare: a tail sample (or several) reaches across the end of the block
         for (int e = 0; e < 2; e++) {
@@ -449,7 +604,7 @@ zig_count_kernel(const ulonglong2 *__restrict__ blk_state, uint64_t i_hi, uint64
                 const ulonglong2 bs2 = blk_state[bb];
                 const u128 s2 = mk128(uni64(bs2.x), uni64(bs2.y));
                 cols_t c2;
-                block_classify(c2, s2, lane_m, lane_c, c64, L, W);
+                block_classify(c2, s2, inc, lane_m, lane_c, c64, L, W, &st->error);
                 unsigned kb, total, pp, cc;
                 block_chain(c2, s2, inc, k, kb, total, pp, cc, ZIG_ROWS, &st->error);
                 if (lane == 0) {
@@ -640,8 +795,9 @@ zig_entry_kernel(long nblk, long ntile, const unsigned *__restrict__ fun, const 
 // 64 j + p: the samples of a row leave as one store instruction to consecutive addresses.
 __global__ void __launch_bounds__(ZIG_WG)
 zig_emit_kernel(const ulonglong2 *__restrict__ blk_state, uint64_t i_hi, uint64_t i_lo, long nblk,
-                const ulonglong2 *__restrict__ entry, const ulonglong2 *__restrict__ classes, unsigned long long pos0,
-                unsigned long long n, double *__restrict__ g, zig_status *st) {
+                const ulonglong2 *__restrict__ entry, const ulonglong2 *__restrict__ classes,
+                const unsigned long long *__restrict__ tails, unsigned long long pos0, unsigned long long n,
+                double *__restrict__ g, zig_status *st) {
     __shared__ zig_lds L;
     zig_lds_fill(L);
     const u128 inc = mk128(i_hi, i_lo);
@@ -663,8 +819,65 @@ zig_emit_kernel(const ulonglong2 *__restrict__ blk_state, uint64_t i_hi, uint64_
         const uint64_t z_col = cl.y & ~cl.x, w_col = cl.y & cl.x, nf_col = cl.x | z_col;
         u128 s = lane_m * s_blk + lane_c;                    // state after position `lane` of row 0
         unsigned pos = uni32((unsigned)en.x);
-        unsigned long long ord = ord_blk;                    // ordinal of the next sample
         const unsigned long long blk_pos = pos0 + (unsigned long long)b * ZIG_BLK;
+        // fast path (entry 0 or 1): all rows evaluated at once in lanes 0..15
+        const uint64_t tt = uni64(tails[b]);
+        if (pos < 2 && !(tt & ZIG_TT_OVER)) {
+            const bool row = lane < ZIG_ROWS;
+            const vrow_t v0 = row_eval_vec(nf_col, z_col, w_col, 0u, tt, 64u * lane),
+                         v1 = row_eval_vec(nf_col, z_col, w_col, 1u, tt, 64u * lane);
+            const unsigned G = (unsigned)__ballot(row && v0.cout), C1 = (unsigned)__ballot(row && v1.cout);
+            const unsigned cins = row_carries(G, C1, pos);
+            const bool c1 = (cins >> lane) & 1u;
+            if (__ballot(row && (c1 ? v1.big : v0.big)) == 0) {
+                const uint64_t ew_col = row ? (c1 ? v1.ew : v0.ew) : 0ull;
+                const uint64_t t_col = row ? (c1 ? v1.t : v0.t) : 0ull;
+                const uint64_t e_col = row ? (c1 ? v1.e : v0.e) : 0ull;
+                const unsigned pc = __builtin_popcountll(e_col | t_col);
+                const unsigned base_col = row16_scan(pc) - pc;          // samples of the block before row `lane`
+                const unsigned trows = (unsigned)__ballot(t_col != 0);  // rows with a tail sample
+#pragma unroll
+                for (int j = 0; j < ZIG_ROWS; j++) {
+                    const uint64_t raw = pcg_out(s);
+                    const uint64_t e = readlane64(e_col, j);
+                    if ((trows >> j) & 1) {
+                        const uint64_t tj = readlane64(t_col, j), all = e | tj;
+                        for (uint64_t zz = tj; zz; zz &= zz - 1) {
+                            const int pz = __builtin_ctzll(zz);
+                            double v;
+                            unsigned consumed;
+                            zig_tail_from(bcast128(s, pz), inc, v, consumed, &st->error);
+                            const unsigned long long o = ord_blk + readlane32(base_col, j) +
+                                                         __builtin_popcountll(all & ((1ull << pz) - 1ull));
+                            if (lane == 0 && o < n) {
+                                g[o] = v;
+                                if (o + 1 == n) st->n_raw = blk_pos + 64u * j + pz + 1 + consumed;
+                            }
+                        }
+                        if ((e >> lane) & 1) {
+                            const unsigned long long o = ord_blk + readlane32(base_col, j) + mbcnt64(all);
+                            if (o < n) {
+                                g[o] = zig_value(raw, L.wi);
+                                if (o + 1 == n) st->n_raw = blk_pos + 64u * j + lane + 1 + ((readlane64(ew_col, j) >> lane) & 1);
+                            }
+                        }
+                    } else if ((e >> lane) & 1) {
+                        const unsigned long long o = ord_blk + readlane32(base_col, j) + mbcnt64(e);
+#if ZIG_ABLATE == 4
+                        if (o < n && raw == 12345) {
+#else
+                        if (o < n) {
+#endif
+                            g[o] = zig_value(raw, L.wi);
+                            if (o + 1 == n) st->n_raw = blk_pos + 64u * j + lane + 1 + ((readlane64(ew_col, j) >> lane) & 1);
+                        }
+                    }
+                    s = s * M64 + c64;
+                }
+                continue;
+            }
+        }
+        unsigned long long ord = ord_blk;                    // ordinal of the next sample
 #pragma unroll
         for (int j = 0; j < ZIG_ROWS; j++) {
             const uint64_t raw = pcg_out(s);
@@ -686,8 +899,6 @@ zig_emit_kernel(const ulonglong2 *__restrict__ blk_state, uint64_t i_hi, uint64_
                 double v;
                 unsigned consumed;
                 zig_tail_walk(s_blk, inc, 64u * j + r.tl_bit, v, consumed, &st->error);
-                const uint64_t rq = readlane64(raw, r.tl_bit);
-                if ((((rq >> 9) & M52) >> 8) & 1) v = -v;
                 if (lane == 0 && ord < n) {
                     g[ord] = v;
                     if (ord + 1 == n) st->n_raw = blk_pos + 64u * j + r.tl_bit + 1 + consumed;
@@ -745,7 +956,8 @@ int corahip_normals_pcg64(corahip_ctx *ctx, const uint64_t state[2], const uint6
         const size_t off_entry = off_fun + sizeof(unsigned) * 2 * (size_t)nblk;
         const size_t off_patch = off_entry + sizeof(ulonglong2) * (size_t)nblk;
         const size_t off_cls = off_patch + sizeof(ulonglong2) * patch_cap;
-        const size_t off_tf = off_cls + sizeof(ulonglong2) * ZIG_ROWS * (size_t)nblk;
+        const size_t off_tt = off_cls + sizeof(ulonglong2) * ZIG_ROWS * (size_t)nblk;
+        const size_t off_tf = off_tt + sizeof(unsigned long long) * (size_t)nblk;
         const size_t off_te = off_tf + sizeof(uint4) * (size_t)ntile;
         const size_t off_st = off_te + sizeof(ulonglong2) * (size_t)ntile;
         char *ws = nullptr;
@@ -756,6 +968,7 @@ int corahip_normals_pcg64(corahip_ctx *ctx, const uint64_t state[2], const uint6
         ulonglong2 *entry = (ulonglong2 *)(ws + off_entry);
         ulonglong2 *patch = (ulonglong2 *)(ws + off_patch);
         ulonglong2 *classes = (ulonglong2 *)(ws + off_cls);
+        unsigned long long *tails = (unsigned long long *)(ws + off_tt);
         uint4 *tile_fun = (uint4 *)(ws + off_tf);
         ulonglong2 *tile_entry = (ulonglong2 *)(ws + off_te);
         zig_status *st = (zig_status *)(ws + off_st);
@@ -769,8 +982,8 @@ int corahip_normals_pcg64(corahip_ctx *ctx, const uint64_t state[2], const uint6
         const unsigned grid = (unsigned)std::min<long>((nblk + ZIG_WG / 64 - 1) / (ZIG_WG / 64), (long)ctx->num_cu * 32);
         {
             StageTimer t1(ctx, "zig_count");
-            zig_count_kernel<<<grid, ZIG_WG, 0, ctx->stream>>>(blk_state, inc[0], inc[1], nblk, fun, classes, patch, patch_cap,
-                                                              st);
+            zig_count_kernel<<<grid, ZIG_WG, 0, ctx->stream>>>(blk_state, inc[0], inc[1], nblk, fun, classes, tails, patch,
+                                                              patch_cap, st);
             LAUNCH_CHECK();
         }
         {
@@ -785,7 +998,7 @@ int corahip_normals_pcg64(corahip_ctx *ctx, const uint64_t state[2], const uint6
         }
         {
             StageTimer t3(ctx, "zig_emit");
-            zig_emit_kernel<<<grid, ZIG_WG, 0, ctx->stream>>>(blk_state, inc[0], inc[1], nblk, entry, classes, pos0,
+            zig_emit_kernel<<<grid, ZIG_WG, 0, ctx->stream>>>(blk_state, inc[0], inc[1], nblk, entry, classes, tails, pos0,
                                                              (unsigned long long)n, g, st);
             LAUNCH_CHECK();
         }
