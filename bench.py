@@ -93,6 +93,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--warm", action="store_true", help="time the warm path only (factors cached)")
     ap.add_argument("--no-host-delivered", action="store_true", help="skip the PCIe-inclusive (numpy-returning) leg")
+    ap.add_argument("--no-seeded-modes", action="store_true", help="skip the numpy-seeded / legacy-RNG legs")
     # test hooks (not used by the driver): run N ranks on ONE GPU over gloo and print per-channel checksums
     ap.add_argument("--dist-backend", default="nccl")
     ap.add_argument("--same-device", action="store_true")
@@ -203,6 +204,12 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
+    stages = {}
+    for name in ("clarray", "factor", "normals", "draw", "legendre", "ringfft"):
+        ms, n = ctx.profile_get(name)
+        if n:
+            stages[name] = {"ms_per_launch": ms / n, "launches": n, "ms_per_step": ms / args.steps}
+
     # warm path (factors cached: draw + synthesis only - what repeated seeds amortise, cora/signal/lss.py:424-478),
     # measured after the timed region and reported next to the headline (cold) number
     warm_ms = None
@@ -218,6 +225,14 @@ def main():
         warm_ms = (time.time() - tw) / nw * 1e3
         del fac
 
+    # the REFERENCE's seeded call (rng = numpy Generator, cora/core/skysim.py:72,120; cora/signal/lss.py:449-450): the same
+    # cold step with numpy's PCG64 + ziggurat stream generated on the device (bit-identical to numpy, the generator left
+    # where numpy would leave it) instead of the library's Philox stream; and the legacy mode (rng=None: numpy's global
+    # MT19937 + polar method), whose normals are host-generated - measured on a bounded sample and extrapolated
+    seeded_numpy = legacy_rng = None
+    if rank == 0 and world == 1 and args.emulate_shard <= 1 and len(comps) == 1 and not args.no_seeded_modes:
+        seeded_numpy, legacy_rng = seeded_modes(ctx, shard, cold_factors, F, lmax, barrier, args.steps)
+
     # host-delivered rate: the reference's own signature returns numpy arrays (cora/core/skysim.py:130-136), i.e. every
     # realisation crosses PCIe.  skysim.mkfullsky_stream double-buffers that copy (pinned memory, copy stream) behind the
     # next realisation; measured after the timed region, reported next to the HBM-resident headline, never as `value`.
@@ -228,12 +243,6 @@ def main():
         except Exception as e:      # (e.g. a box that cannot page-lock 80 GB): the leg is extra, the headline must not die with it
             host_delivered = {"skipped": "%s: %s" % (type(e).__name__, e)}
             torch.cuda.synchronize()
-
-    stages = {}
-    for name in ("clarray", "factor", "normals", "draw", "legendre", "ringfft"):
-        ms, n = ctx.profile_get(name)
-        if n:
-            stages[name] = {"ms_per_launch": ms / n, "launches": n, "ms_per_step": ms / args.steps}
 
     # sanity: the maps of the last step are finite and have the expected variance scale
     chk = float(maps_buf[0, ::4097].std().item())
@@ -310,6 +319,8 @@ def main():
                 "warm_path": None if warm_ms is None else {"ms_per_step": warm_ms, "maps_per_s": F / (warm_ms * 1e-3)},
                 "setup_s": t_setup,
                 "host_delivered": host_delivered,
+                "seeded_numpy_mode": seeded_numpy,
+                "legacy_rng_mode": legacy_rng,
             },
             "stages_ms": {k: round(v["ms_per_step"], 3) for k, v in stages.items()},
             "roofline": {
@@ -383,6 +394,53 @@ def stage_rooflines(stages, nside, lmax, F, nnu, zromb, legendre_executed_flops,
         e["frac"] = e["GBs"] / HBM_PEAK_GBS if bound == "hbm" else e["TFLOPs"] / FP64_MFMA_PEAK_TFLOPS
         out[k] = e
     return out
+
+
+def seeded_modes(ctx, shard, cold_factors, F, lmax, barrier, steps):
+    """(seeded_numpy_mode, legacy_rng_mode) of the bench line.
+
+    seeded_numpy_mode: HBM-resident ms per COLD step when the caller passes ``rng = numpy.random.default_rng(seed)`` as
+    cora's callers do - the normals are numpy's own PCG64 + ziggurat sequence, generated on the device.
+    legacy_rng_mode: ``rng=None`` (numpy's global MT19937 + polar method, cora/util/nputil.py:121-123) - that stream is
+    generated by numpy on the host; its rate is measured on a bounded sample (3e7 normals) and the step time is that
+    extrapolated to the 2 F nalm normals of a realisation (the upload overlaps the generation; the device part of the
+    step is the measured seeded step without its generator)."""
+    import torch
+
+    nrep = max(1, min(3, steps))
+    rng = np.random.default_rng(2024)
+    shard.realise_numpy(rng, cold_factors())                  # (workspace growth, not timed)
+    barrier()
+    ctx.profile_reset()
+    ctx.profile_enable(True)
+    t0 = time.time()
+    for _ in range(nrep):
+        shard.realise_numpy(rng, cold_factors())
+    barrier()
+    ms = (time.time() - t0) / nrep * 1e3
+    ctx.profile_enable(False)
+    st = {}
+    for name in ("normals_pcg64", "zig_count", "zig_scan", "zig_emit", "draw"):
+        t, n = ctx.profile_get(name)
+        if n:
+            st[name] = round(t / nrep, 3)
+    nnorm = 2 * F * ((lmax + 1) * (lmax + 2) // 2)
+    seeded = {"ms_per_step": ms, "maps_per_s": F / (ms * 1e-3), "stages_ms": st, "normals_per_step": nnorm,
+              "rng": "numpy.random.default_rng(seed): PCG64 + ziggurat standard_normal continued on the device "
+                     "(corahip_normals_pcg64), bit-identical to numpy; the Generator's state is advanced as numpy would"}
+    nsample = 30_000_000
+    np.random.seed(12345)
+    t0 = time.time()
+    np.random.standard_normal(nsample)
+    rate = nsample / (time.time() - t0)
+    host_s = nnorm / rate
+    dev_ms = ms - st.get("normals_pcg64", 0.0)
+    legacy = {"ms_per_step_estimated": max(host_s * 1e3, dev_ms) + 0.0, "maps_per_s_estimated": F / max(host_s, dev_ms * 1e-3),
+              "host_normals_per_s": rate, "host_generation_s_per_step": host_s, "sample": "%d legacy normals timed, scaled to %d" % (nsample, nnorm),
+              "rng": "rng=None: numpy's legacy global MT19937 + polar method, generated on the host in the reference's order "
+                     "and uploaded through pinned staging (skysim._upload_host_normals); single thread, as numpy"}
+    torch.cuda.synchronize()
+    return seeded, legacy
 
 
 def host_delivered_rate(ctx, shard, nside, F, npix, nrep=4):

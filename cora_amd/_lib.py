@@ -54,6 +54,7 @@ SIGNATURES = {
     "corahip_draw_alm_philox": (c_int, [c_void_p, PTR, PTR, c_u64, c_int, c_int, c_int, c_int, PTR]),
     "corahip_draw_alm_philox_rows": (c_int, [c_void_p, PTR, PTR, c_u64, c_int, c_int, c_int, c_int, PTR]),
     "corahip_draw_alm": (c_int, [c_void_p, PTR, PTR, PTR, c_int, c_int, c_int, c_int, PTR]),
+    "corahip_draw_alm_rows": (c_int, [c_void_p, PTR, PTR, PTR, c_int, c_int, c_int, c_int, PTR]),
     "corahip_shard_plan": (c_int, [c_int, c_int, c_int, c_int, PTR]),
     "corahip_factor_rows_pack": (c_int, [c_void_p, PTR, c_int, c_int, c_int, c_int, PTR]),
     "corahip_factor_rows_unpack": (c_int, [c_void_p, PTR, PTR, c_int, c_int, c_int, c_int, PTR]),
@@ -387,6 +388,16 @@ class Context:
         alm = out if out is not None else self.empty((nalm, G, 2, 4))
         _check(self.lib.corahip_draw_alm(self.h, self._f64(T), self._p(info) if info is not None else None,
                                          self._f64(g), lmax, F, nu0, nnu, self._f64(alm)))
+        return alm
+
+    def draw_alm_rows(self, T_rows, info, g, lmax, F, nu0, nnu, out=None):
+        """draw_alm with T_rows [lmax+1, nnu, F] = rows nu0..nu0+nnu-1 of every factor."""
+        assert tuple(T_rows.shape) == (lmax + 1, nnu, F), T_rows.shape
+        nalm = (lmax + 1) * (lmax + 2) // 2
+        G = (nnu + 3) // 4
+        alm = out if out is not None else self.empty((nalm, G, 2, 4))
+        _check(self.lib.corahip_draw_alm_rows(self.h, self._f64(T_rows), self._p(info) if info is not None else None,
+                                              self._f64(g), lmax, F, nu0, nnu, self._f64(alm)))
         return alm
 
     def draw_alm_philox(self, T, info, seed, lmax, F, nu0=0, nnu=None, out=None):

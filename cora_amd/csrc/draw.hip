@@ -10,6 +10,7 @@
 // from the stream-ordered buffer (each element is used by exactly one wave).
 #include "common.h"
 
+#include <cstdlib>
 #include <type_traits>
 
 #include "rng_dev.h"
@@ -200,11 +201,16 @@ static inline long draw_slots(int lmax) {
     return n;
 }
 
-template <int NCT>
+// FROMG: the normals come from a stream-order buffer `gsrc` (the caller's numpy stream: uploaded, or generated on the
+// device by corahip_normals_pcg64) instead of the Philox chain.  The A operands of a chunk (8 k-steps x (re, im) = 16
+// doubles per lane) are requested one chunk ahead by asm loads that take their place in the counted vmcnt scheme of the
+// staging: after the barrier of chunk c a wave issues the loads of chunk c + 1, THEN the DMA pieces of stage c + 2, so
+// the wait that leaves those QPW pieces in flight covers the loads as well.
+template <int NCT, bool FROMG = false>
 __global__ void __launch_bounds__(64 * DRAW_WAVES, 2)
 draw_rng_kernel(const double *__restrict__ T, size_t t_ldl, int t_row0, const int32_t *__restrict__ info,
-                const double *__restrict__ zeros, uint64_t seed, int lmax, int F, int nu0, int nnu, int Gout,
-                int nslots, int ncg, double *__restrict__ alm, unsigned *__restrict__ queue) {
+                const double *__restrict__ zeros, uint64_t seed, const double *__restrict__ gsrc, int lmax, int F, int nu0,
+                int nnu, int Gout, int nslots, int ncg, double *__restrict__ alm, unsigned *__restrict__ queue) {
     constexpr int NC = 16 * NCT;
     constexpr int ROWD = DRAW_KC;            // doubles per channel row in LDS: 256 B, unpadded (DMA is lane-linear)
     constexpr int BUF = NC * ROWD;           // doubles per stage
@@ -289,8 +295,36 @@ draw_rng_kernel(const double *__restrict__ T, size_t t_ldl, int t_row0, const in
         }
     };
 
-    for (int i = tid; i < 257; i += 64 * DRAW_WAVES) lg_s[i] = RNG_LOG_TAB[i];   // (visible after the first barrier)
-    for (int i = tid; i < 256; i += 64 * DRAW_WAVES) sc_s[i] = RNG_SC_TAB[i];
+    if constexpr (!FROMG) {
+        for (int i = tid; i < 257; i += 64 * DRAW_WAVES) lg_s[i] = RNG_LOG_TAB[i];   // (visible after the first barrier)
+        for (int i = tid; i < 256; i += 64 * DRAW_WAVES) sc_s[i] = RNG_SC_TAB[i];
+    }
+
+    // FROMG: A operands by HALF chunks (4 k-steps x (re, im) = 8 doubles per lane): a_x holds the first half of a chunk,
+    // a_y the second; each is requested half a chunk before its use
+    double a_x[8], a_y[8];
+    // requests half `half` of chunk c of item `w` for this wave's rows: element (l, c, nu', m) of the stream-order buffer
+    // sits at F l (l + 1) + c F (l + 1) + nu' (l + 1) + m; rows past l and nu' past F - 1 are read from the clamped
+    // address (finite values: their products meet staged zeros or are never stored)
+    auto issue_a = [&](const item_t &w, int c, int half, double (&dst)[8]) {
+        const int lp1 = w.l + 1;
+        const int m = min(w.mb * DRAW_MB + 16 * wave + ri, w.l);
+        const double *gre = gsrc + (size_t)F * w.l * lp1 + m;
+        const size_t im_off = (size_t)F * lp1;
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) {
+            const int kp = min(c * DRAW_KC + 16 * half + 4 * kk + kq, F - 1);
+            const double *pr = gre + (size_t)kp * lp1;
+            const double *pi = pr + im_off;
+            asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(dst[2 * kk]) : "v"(pr) : "memory");
+            asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(dst[2 * kk + 1]) : "v"(pi) : "memory");
+        }
+    };
+    // behind the wait that covers them: ties the later uses of the values to this point
+    auto pin_a = [&](double (&dst)[8]) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) asm volatile("" : "+v"(dst[i]));
+    };
 
     int item = blockIdx.x;      // the first gridDim.x items are pre-assigned; the queue starts behind them
     if (item >= nitems) return;
@@ -298,6 +332,9 @@ draw_rng_kernel(const double *__restrict__ T, size_t t_ldl, int t_row0, const in
     int ring = 0, par = 0;
     stage(w, 0, 0);
     if (w.nchunk > 1) stage(w, 1, 1);
+    if constexpr (FROMG) {
+        if (w.mb * DRAW_MB + 16 * wave < w.l + 1) issue_a(w, 0, 0, a_x);
+    }
     DSTAMP(0);                           // prologue + first stages issued
 
     for (;;) {
@@ -314,9 +351,10 @@ draw_rng_kernel(const double *__restrict__ T, size_t t_ldl, int t_row0, const in
             acc1[t] = (d4_t){0.0, 0.0, 0.0, 0.0};
         }
         // k-steps of one half (16 nu' = 4 k-steps) of the chunk in buffer `sb`, multiplying the tiles TMIN .. NCT-1
-        auto half_steps = [&](auto tmin_c, const double *sb, int k0, int half) {
+        auto half_steps = [&](auto tmin_c, const double *sb, int k0, auto half_c) {
             constexpr int TMIN = decltype(tmin_c)::value;
-#pragma unroll DRAW_KK_UNROLL
+            constexpr int half = decltype(half_c)::value;
+#pragma unroll(FROMG ? 4 : DRAW_KK_UNROLL)
             for (int kk = 4 * half; kk < 4 * half + 4; kk++) {
                 const int kp = k0 + 4 * kk + kq;
                 const int kl = 4 * kk + kq;          // k within the chunk
@@ -330,7 +368,10 @@ draw_rng_kernel(const double *__restrict__ T, size_t t_ldl, int t_row0, const in
 #else
                 // (rows past l and nu' >= F are generated like any other: their products meet staged zeros or are
                 //  never stored - no exec masking around the chain)
-                double2 a = philox_normal_pair(seed, l, F, kp, m_lane, lg_s, sc_s);
+                double2 a;
+                if constexpr (FROMG) a = half ? make_double2(a_y[2 * (kk - 4 * half)], a_y[2 * (kk - 4 * half) + 1])
+                                              : make_double2(a_x[2 * (kk - 4 * half)], a_x[2 * (kk - 4 * half) + 1]);
+                else a = philox_normal_pair(seed, l, F, kp, m_lane, lg_s, sc_s);
 #endif
 #pragma unroll
                 for (int t = TMIN; t < NCT; t++) {
@@ -347,14 +388,31 @@ draw_rng_kernel(const double *__restrict__ T, size_t t_ldl, int t_row0, const in
         // the previous item's stores): the first wait drains everything; later waits leave the QPW pieces of the
         // younger stage in flight.  After the barrier of chunk c every wave has finished chunk c - 1, whose slot
         // takes stage c + 2.
+        // FROMG, in front of the second half of chunk c: its operands are older than the stage requested at the chunk's
+        // start; then the first half of the next chunk is requested (a_x is free: the first half is done)
+        auto mid_chunk = [&](int c) {
+            if constexpr (FROMG) {
+                if (c + 2 < nchunk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(QPW) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                pin_a(a_y);
+                if (c + 1 < nchunk) issue_a(w, c + 1, 0, a_x);
+            }
+        };
         auto chunk_begin = [&](int c) {
             if (c == 0 || c + 1 >= nchunk) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(QPW) : "memory");
+            if constexpr (FROMG) {
+                if (wave_has_rows) pin_a(a_x);
+            }
             __syncthreads();
 #if DRAW_STAMPS
             if (c == 0) { DSTAMP(6); } else
 #endif
             DSTAMP(1);                       // wait for the stage + barrier (stamp 6: the first chunk of an item, which also waits for the previous item's stores)
+            if constexpr (FROMG) {
+                // second half of this chunk: ahead of the DMA pieces, so that the wait in front of the half leaves them
+                if (wave_has_rows && c * DRAW_KC + 16 < kmax) issue_a(w, c, 1, a_y);
+            }
             if (c + 2 < nchunk) stage(w, c + 2, (ring + c + 2) % DRAW_NBUF);
             DSTAMP(2);                       // issue of the stage after next
         };
@@ -363,8 +421,11 @@ draw_rng_kernel(const double *__restrict__ T, size_t t_ldl, int t_row0, const in
             chunk_begin(c);
             if (!wave_has_rows) continue;
             const double *sb = lds + ((ring + c) % DRAW_NBUF) * BUF;
-            half_steps(std::integral_constant<int, 0>{}, sb, c * DRAW_KC, 0);
-            if (c * DRAW_KC + 16 < kmax) half_steps(std::integral_constant<int, 0>{}, sb, c * DRAW_KC, 1);
+            half_steps(std::integral_constant<int, 0>{}, sb, c * DRAW_KC, std::integral_constant<int, 0>{});
+            if (c * DRAW_KC + 16 < kmax) {
+                mid_chunk(c);
+                half_steps(std::integral_constant<int, 0>{}, sb, c * DRAW_KC, std::integral_constant<int, 1>{});
+            }
             DSTAMP(3);                       // generator + MFMAs of the chunk
         }
         draw_static_for<(NC + DRAW_KC - 1) / DRAW_KC>([&](auto jc) {
@@ -373,9 +434,13 @@ draw_rng_kernel(const double *__restrict__ T, size_t t_ldl, int t_row0, const in
             chunk_begin(c);
             if (wave_has_rows) {
                 const double *sb = lds + ((ring + c) % DRAW_NBUF) * BUF;
-                half_steps(std::integral_constant<int, (2 * J < NCT ? 2 * J : NCT)>{}, sb, c * DRAW_KC, 0);
-                if (2 * J + 1 < NCT && c * DRAW_KC + 16 < kmax)
-                    half_steps(std::integral_constant<int, (2 * J + 1 < NCT ? 2 * J + 1 : NCT)>{}, sb, c * DRAW_KC, 1);
+                half_steps(std::integral_constant<int, (2 * J < NCT ? 2 * J : NCT)>{}, sb, c * DRAW_KC, std::integral_constant<int, 0>{});
+                if (c * DRAW_KC + 16 < kmax) {
+                    mid_chunk(c);
+                    if constexpr (2 * J + 1 < NCT)
+                        half_steps(std::integral_constant<int, (2 * J + 1 < NCT ? 2 * J + 1 : NCT)>{}, sb, c * DRAW_KC,
+                                   std::integral_constant<int, 1>{});
+                }
                 DSTAMP(3);
             }
             c++;
@@ -392,6 +457,9 @@ draw_rng_kernel(const double *__restrict__ T, size_t t_ldl, int t_row0, const in
             w = decode(item);
             stage(w, 0, ring);
             if (w.nchunk > 1) stage(w, 1, (ring + 1) % DRAW_NBUF);
+            if constexpr (FROMG) {
+                if (w.mb * DRAW_MB + 16 * wave < w.l + 1) issue_a(w, 0, 0, a_x);
+            }
         }
         DSTAMP(4);                           // next item decoded, its first stages issued
 
@@ -445,12 +513,12 @@ draw_rng_kernel(const double *__restrict__ T, size_t t_ldl, int t_row0, const in
 #endif
 }
 
-template <int NCT>
+template <int NCT, bool FROMG = false>
 static int launch_draw_rng(corahip_ctx *ctx, const double *T, size_t t_ldl, int t_row0, const int32_t *info,
-                           uint64_t seed, int lmax, int F, int nu0, int nnu, int Gout, double *alm) {
+                           uint64_t seed, const double *gsrc, int lmax, int F, int nu0, int nnu, int Gout, double *alm) {
     constexpr int NC = 16 * NCT;
     const size_t shm = sizeof(double) * DRAW_NBUF * NC * DRAW_KC;
-    HIP_TRY(hipFuncSetAttribute((const void *)draw_rng_kernel<NCT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    HIP_TRY(hipFuncSetAttribute((const void *)draw_rng_kernel<NCT, FROMG>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)shm));
     // scratch slot 3: 4096 bytes of zeros (DMA source of padded rows) + the work queue counter behind them
     char *zq = nullptr;
@@ -464,9 +532,9 @@ static int launch_draw_rng(corahip_ctx *ctx, const double *T, size_t t_ldl, int 
     // persistent: one workgroup per CU for the 128-channel shape (106 KB of LDS), two for the narrower ones
     const int per_cu = (shm + 8300 > 80 * 1024) ? 1 : 2;
     dim3 grid((unsigned)std::min<long>(nitems, (long)ctx->num_cu * per_cu));
-    draw_rng_kernel<NCT><<<grid, 64 * DRAW_WAVES, shm, ctx->stream>>>(T, t_ldl, t_row0, info, (const double *)zq, seed, lmax,
-                                                                      F, nu0, nnu, Gout, (int)nslots, ncg, alm,
-                                                                      (unsigned *)(zq + 4096));
+    draw_rng_kernel<NCT, FROMG><<<grid, 64 * DRAW_WAVES, shm, ctx->stream>>>(T, t_ldl, t_row0, info, (const double *)zq, seed,
+                                                                             gsrc, lmax, F, nu0, nnu, Gout, (int)nslots, ncg,
+                                                                             alm, (unsigned *)(zq + 4096));
     LAUNCH_CHECK();
 #if DRAW_STAMPS
     {
@@ -549,6 +617,13 @@ static int draw_host_stream(corahip_ctx *ctx, const double *T, size_t t_ldl, int
     StageTimer t(ctx, "draw");
     const int Gout = (nnu + 3) / 4;
     const int ncol = 4 * Gout;
+    if (!(F & 1) && !getenv("CORAHIP_DRAW_GENERIC")) {
+        // the persistent MFMA kernel of the device-RNG mode with its A operands read from the stream buffer
+        if (ncol <= 16) return launch_draw_rng<1, true>(ctx, T, t_ldl, t_row0, info, 0, g, lmax, F, nu0, nnu, Gout, alm_dev);
+        if (ncol <= 32) return launch_draw_rng<2, true>(ctx, T, t_ldl, t_row0, info, 0, g, lmax, F, nu0, nnu, Gout, alm_dev);
+        if (ncol <= 64) return launch_draw_rng<4, true>(ctx, T, t_ldl, t_row0, info, 0, g, lmax, F, nu0, nnu, Gout, alm_dev);
+        return launch_draw_rng<8, true>(ctx, T, t_ldl, t_row0, info, 0, g, lmax, F, nu0, nnu, Gout, alm_dev);
+    }
     if (ncol <= 16) return launch_draw<1>(ctx, T, t_ldl, t_row0, info, g, lmax, F, nu0, nnu, Gout, alm_dev);
     if (ncol <= 32) return launch_draw<2>(ctx, T, t_ldl, t_row0, info, g, lmax, F, nu0, nnu, Gout, alm_dev);
     if (ncol <= 64) return launch_draw<4>(ctx, T, t_ldl, t_row0, info, g, lmax, F, nu0, nnu, Gout, alm_dev);
@@ -570,10 +645,10 @@ static int draw_philox(corahip_ctx *ctx, const double *T, size_t t_ldl, int t_ro
     StageTimer t(ctx, "draw");
     const int Gout = (nnu + 3) / 4;
     const int ncol = 4 * Gout;
-    if (ncol <= 16) return launch_draw_rng<1>(ctx, T, t_ldl, t_row0, info, seed, lmax, F, nu0, nnu, Gout, alm_dev);
-    if (ncol <= 32) return launch_draw_rng<2>(ctx, T, t_ldl, t_row0, info, seed, lmax, F, nu0, nnu, Gout, alm_dev);
-    if (ncol <= 64) return launch_draw_rng<4>(ctx, T, t_ldl, t_row0, info, seed, lmax, F, nu0, nnu, Gout, alm_dev);
-    return launch_draw_rng<8>(ctx, T, t_ldl, t_row0, info, seed, lmax, F, nu0, nnu, Gout, alm_dev);
+    if (ncol <= 16) return launch_draw_rng<1>(ctx, T, t_ldl, t_row0, info, seed, nullptr, lmax, F, nu0, nnu, Gout, alm_dev);
+    if (ncol <= 32) return launch_draw_rng<2>(ctx, T, t_ldl, t_row0, info, seed, nullptr, lmax, F, nu0, nnu, Gout, alm_dev);
+    if (ncol <= 64) return launch_draw_rng<4>(ctx, T, t_ldl, t_row0, info, seed, nullptr, lmax, F, nu0, nnu, Gout, alm_dev);
+    return launch_draw_rng<8>(ctx, T, t_ldl, t_row0, info, seed, nullptr, lmax, F, nu0, nnu, Gout, alm_dev);
 }
 
 int corahip_draw_alm_philox(corahip_ctx *ctx, const double *T, const int32_t *info, uint64_t seed, int lmax, int F,
@@ -595,6 +670,13 @@ int corahip_draw_alm(corahip_ctx *ctx, const double *T, const int32_t *info, con
     ARG_CHECK(ctx != nullptr && T != nullptr && g != nullptr && alm_dev != nullptr);
     ARG_CHECK(lmax >= 0 && F >= 1 && nu0 >= 0 && nnu >= 1 && nu0 + nnu <= F);
     return draw_host_stream(ctx, T, (size_t)F * F, 0, info, g, lmax, F, nu0, nnu, alm_dev);
+}
+
+int corahip_draw_alm_rows(corahip_ctx *ctx, const double *T_rows, const int32_t *info, const double *g, int lmax, int F,
+                          int nu0, int nnu, double *alm_dev) {
+    ARG_CHECK(ctx != nullptr && T_rows != nullptr && g != nullptr && alm_dev != nullptr);
+    ARG_CHECK(lmax >= 0 && F >= 1 && nu0 >= 0 && nnu >= 1 && nu0 + nnu <= F);
+    return draw_host_stream(ctx, T_rows, (size_t)nnu * F, nu0, info, g, lmax, F, nu0, nnu, alm_dev);
 }
 
 int corahip_alm_dev_to_square(corahip_ctx *ctx, const double *alm_dev, int lmax, int nnu, double *square) {

@@ -360,6 +360,26 @@ class SkyShard:
         self.draw(seed, factors)
         return self.ctx.alm2map(self.alm_buf, self.nside, self.lmax, self.nnu, out=self.maps_buf)
 
+    def realise_numpy(self, rng, factors=None):
+        """As :meth:`realise` with the REFERENCE's normal stream: ``rng`` is what cora's callers pass to
+        ``mkfullsky`` - a ``numpy.random.Generator`` (on PCG64 it is continued on the device, bit for bit, and left where
+        cora would leave it) or ``None`` (numpy's legacy global state, consumed on the host) - see
+        ``skysim.stream_normals``.  Every rank consumes the whole stream (identically seeded generators)."""
+        import torch
+
+        from .core import skysim
+
+        ctx = self.ctx
+        T, info, rows = factors if factors is not None else self.factors()
+        g = skysim.stream_normals(ctx, self.F, self.lmax, rng)
+        if rows:   # the stream-order kernel takes full factors: embed the row block
+            Tf = torch.zeros((self.lmax + 1, self.F, self.F), dtype=torch.float64, device=ctx.device)
+            Tf[:, self.nu0:self.nu0 + self.nnu, :] = T
+            T = Tf
+        ctx.draw_alm(T, info, g, self.lmax, self.F, nu0=self.nu0, nnu=self.nnu, out=self.alm_buf)
+        del g
+        return ctx.alm2map(self.alm_buf, self.nside, self.lmax, self.nnu, out=self.maps_buf)
+
 
 class SkySum:
     """Sum of independent Gaussian components on one channel grid - BASELINE configs[3]: 21cm (``Corr21cm``) +

@@ -32,7 +32,7 @@ extern "C" {
 #endif
 
 #define CORAHIP_ABI_VERSION 1
-#define CORAHIP_ABI_MINOR 1      /* additions since version 1: 1 = normals_pcg64, pcg64_advance */
+#define CORAHIP_ABI_MINOR 1      /* additions since version 1: 1 = normals_pcg64, pcg64_advance, draw_alm_rows */
 
 #define CORAHIP_EINVAL (-1)   /* bad argument / shape */
 #define CORAHIP_ENOMEM (-2)   /* workspace too small / allocation refused */
@@ -172,6 +172,11 @@ int corahip_pcg64_advance(const uint64_t host_state[2], const uint64_t host_inc[
  *   nnu_pad = nnu rounded up to a multiple of 4, padding channels are written as 0).  */
 int corahip_draw_alm(corahip_ctx *ctx, const double *T, const int32_t *info, const double *g, int lmax,
                      int F, int nu0, int nnu, double *alm_dev);
+
+/* draw_alm with only the rank's rows of the factors resident: T_rows [lmax+1, nnu, F] = rows nu0 .. nu0+nnu-1 of every T_l
+ * (see draw_alm_philox_rows) */
+int corahip_draw_alm_rows(corahip_ctx *ctx, const double *T_rows, const int32_t *info, const double *g, int lmax,
+                          int F, int nu0, int nnu, double *alm_dev);
 
 /* draw_alm with the device stream generated in registers (same values as normals_philox(seed) followed by
  * draw_alm, without the 16*F*nalm-byte normal buffer) */

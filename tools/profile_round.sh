@@ -8,9 +8,9 @@ TAG=${1:-r03}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd $GRAFT_REPO_ROOT
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o stats -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-host-delivered > $OUT/bench_under_rocprof.json 2> $OUT/stats.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o stats -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-host-delivered --no-seeded-modes > $OUT/bench_under_rocprof.json 2> $OUT/stats.err
 run() { n=$1; shift
-  rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT -o $n -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-host-delivered > /dev/null 2> $OUT/$n.err
+  rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT -o $n -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-host-delivered --no-seeded-modes > /dev/null 2> $OUT/$n.err
 }
 run sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_F64 SQ_WAVES
 run tcc2 FETCH_SIZE GRBM_GUI_ACTIVE
