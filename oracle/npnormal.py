@@ -37,6 +37,74 @@ ZIG_R = 3.6541528853610087963519472518
 ZIG_INV_R = 0.27366123732975827203338247596
 
 
+def glibc_log1p(x):
+    """glibc's ``log1p`` (sysdeps/ieee754/dbl-64/s_log1p.c: fdlibm's algorithm with glibc's split evaluation of the
+    polynomial) for -1 < x < 0.41, operation by operation in IEEE double - python floats do not contract.  This is
+    the restatement cora_amd/csrc/npnormal.hip runs for the tail samples (``glibc_log1p_neg``); tests/test_oracle.py
+    compares it with ``math.log1p`` (libm) bit for bit."""
+    import struct
+
+    def hi(v):
+        h = struct.unpack("<q", struct.pack("<d", v))[0] >> 32
+        return h
+
+    def sethi(v, h):
+        lo = struct.unpack("<Q", struct.pack("<d", v))[0] & 0xFFFFFFFF
+        return struct.unpack("<d", struct.pack("<Q", ((h & 0xFFFFFFFF) << 32) | lo))[0]
+
+    ln2_hi, ln2_lo = 6.93147180369123816490e-01, 1.90821492927058770002e-10
+    Lp = [0.0, 6.666666666666735130e-01, 3.999999999940941908e-01, 2.857142874366239149e-01, 2.222219843214978396e-01,
+          1.818357216161805012e-01, 1.531383769920937332e-01, 1.479819860511658591e-01]
+    hx = hi(x)
+    ax = hx & 0x7FFFFFFF
+    k, c, f, hu = 1, 0.0, 0.0, 0
+    if hx < 0x3FDA827A:
+        if ax < 0x3E200000:
+            if ax < 0x3C900000:
+                return x
+            return x - x * x * 0.5
+        if hx > 0 or hx <= (0xBFD2BEC3 - 2**32):
+            k, f, hu = 0, x, 1
+    if k != 0:
+        u = 1.0 + x
+        hu = hi(u)
+        k = (hu >> 20) - 1023
+        c = (1.0 - (u - x)) if k > 0 else (x - (u - 1.0))
+        c /= u
+        hu &= 0x000FFFFF
+        if hu < 0x6A09E:
+            u = sethi(u, hu | 0x3FF00000)
+        else:
+            k += 1
+            u = sethi(u, hu | 0x3FE00000)
+            hu = (0x00100000 - hu) >> 2
+        f = u - 1.0
+    hfsq = 0.5 * f * f
+    if hu == 0:
+        if f == 0.0:
+            if k == 0:
+                return 0.0
+            c += k * ln2_lo
+            return k * ln2_hi + c
+        R = hfsq * (1.0 - 0.66666666666666666 * f)
+        if k == 0:
+            return f - R
+        return k * ln2_hi - ((R - (k * ln2_lo + c)) - f)
+    s = f / (2.0 + f)
+    z = s * s
+    R1 = z * Lp[1]
+    z2 = z * z
+    R2 = Lp[2] + z * Lp[3]
+    z4 = z2 * z2
+    R3 = Lp[4] + z * Lp[5]
+    z6 = z4 * z2
+    R4 = Lp[6] + z * Lp[7]
+    R = R1 + z2 * R2 + z4 * R3 + z6 * R4
+    if k == 0:
+        return f - (hfsq - s * (hfsq + R))
+    return k * ln2_hi - ((hfsq - (s * (hfsq + R) + (k * ln2_lo + c))) - f)
+
+
 def tables():
     """(ki, wi, fi) parsed from the generated include file the kernels are compiled with."""
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "cora_amd", "csrc", "zig_tab.inc")

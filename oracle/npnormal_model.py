@@ -4,7 +4,10 @@ against the sequential restatement (oracle/npnormal.py) and against numpy itself
 
 The sequential sampler consumes a data-dependent number of raw 64-bit draws per normal (1 on the fast path, 2 for a
 wedge sample - accepted or not -, 1 + 2 i for a tail sample), so "which raw position starts a sample" is a prefix
-problem.  Decomposition (R positions per thread, T threads per block):
+problem.  The device uses R = 64 (one position per lane, the class masks are the compare results of a wave), T = 16 rows per
+block = one wave, the rows of a block evaluated together in lanes 0..15 for both carries in and the carries resolved
+with one add; this model keeps R and T free and resolves a block by fixed-point iteration - the same function.
+Decomposition (R positions per chunk, T chunks per block):
 
   chunk    classification of every position AS IF it started a sample: nf (not fast), z (tail class: nf and
            idx == 0), wacc (wedge test of (p, p + 1) passes).  Position p of a chunk entered with `k` positions

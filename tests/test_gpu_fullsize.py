@@ -419,3 +419,46 @@ def ctypes_int():
     import ctypes
 
     return ctypes.c_int()
+
+
+# ------------------------------------------------------------------ a7 + a9: the reference's seeded call at cfg-3 size
+def test_cfg3_seeded_mkfullsky_channels_vs_oracle(ctx):
+    """``mkfullsky(C[2049, 256, 256], 1024, rng=default_rng(s))`` - the reference's own call (cora/core/skysim.py:72-136)
+    at the headline configuration, with numpy's stream continued on the DEVICE - against the oracle chain for the same
+    seed on channels 0 and 255: numpy's normals (host), scipy Cholesky of the jittered blocks, T_l g_l, the C/OpenMP
+    synthesis.  Tolerance: 1e-10 x rms (21cm blocks are well conditioned)."""
+    import scipy.linalg as la
+    import torch
+    from cora_amd.core import skysim
+    from cora_amd.signal import corr21cm
+    from oracle import sht as osht
+
+    F, lmax, nside, seed = 256, 2048, 1024, 31
+    L = lmax + 1
+    Cd = skysim.clarray_device(corr21cm.Corr21cm().angular_powerspectrum, lmax, _freqs(F), zromb=3)
+    rng = np.random.default_rng(seed)
+    maps = skysim.mkfullsky_device(Cd, nside, rng=rng)
+    got = {f: maps[f].cpu().numpy() for f in (0, F - 1)}
+    del maps
+    C = Cd.cpu().numpy()
+    del Cd
+    torch.cuda.empty_cache()
+    twin = np.random.default_rng(seed)
+    nalm = L * (L + 1) // 2
+    packed = {0: np.zeros(nalm, dtype=np.complex128), F - 1: np.zeros(nalm, dtype=np.complex128)}
+    m_all = np.arange(L)
+    for l in range(L):
+        cm = C[l] + np.identity(F) * C[l].diagonal().max() * 1e-14
+        T = la.cholesky(cm, lower=True)
+        re = twin.standard_normal((F, l + 1))
+        im = twin.standard_normal((F, l + 1))
+        idx = m_all[:l + 1] * (2 * lmax + 1 - m_all[:l + 1]) // 2 + l
+        for f in packed:
+            packed[f][idx] = (T[f] @ re + 1j * (T[f] @ im)) / np.sqrt(2.0)
+    # the caller's generator is where numpy leaves it after the same draws
+    assert rng.bit_generator.state == twin.bit_generator.state
+    for f in packed:
+        ref = osht.alm2map(packed[f], nside, lmax, rings_c=True)
+        err = np.abs(got[f] - ref).max() / ref.std()
+        print("cfg3 seeded mkfullsky channel", f, "max|err|/rms =", err)
+        assert err <= 1e-10, (f, err)

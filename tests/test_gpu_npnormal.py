@@ -1,0 +1,154 @@
+"""The reference's own seeded normal stream on the device (corahip_normals_pcg64) - run with -m gpu.
+
+cora draws every normal of mkfullsky from the caller's numpy Generator (cora/util/nputil.py:121-125 called from
+cora/core/skysim.py:120; ``default_rng(seed)`` in cora/signal/lss.py:449-450).  numpy is on the GPU box, so the device
+stream is compared with numpy ITSELF, bit for bit: fast-path, wedge and tail samples, the raw draws consumed (= the
+state the generator is left in), block / tile boundaries of the kernels' decomposition, and the layouts and callers on
+top (stream order of complex_std_normal, the reference's golden a_lm, K3 reading the stream buffer).
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ZIG_R = 3.6541528853610088
+
+
+def _device_stream(ctx, rng, n):
+    from cora_amd import _lib
+
+    st = rng.bit_generator.state["state"]
+    g, nraw = ctx.normals_pcg64(st["state"], st["inc"], n)
+    return g.cpu().numpy(), _lib.pcg64_advance(st["state"], st["inc"], nraw)
+
+
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 1000, 1023, 1024, 1025, 4096, 100003, 524288 * 2 + 77])
+def test_device_stream_is_numpys_small_and_boundary_sizes(ctx, n):
+    """Sizes around the kernels' row (64), block (1024) and tile (512 blocks) boundaries, from a generator that has
+    already been used (a state that is not a seed state)."""
+    for seed in (0, 1, 2):
+        rng = np.random.default_rng(1000 * n + seed)
+        rng.standard_normal(seed * 37)
+        dev, state_after = _device_stream(ctx, rng, n)
+        ref = rng.standard_normal(n)
+        assert np.array_equal(dev.view(np.uint64), ref.view(np.uint64)), (n, seed)
+        assert state_after == int(rng.bit_generator.state["state"]["state"]), (n, seed)
+
+
+def test_device_stream_is_numpys_over_1e8_samples(ctx):
+    """1.2e8 normals: every value equal to numpy's bit for bit - 3e4 tail samples (glibc's log1p restated on the device)
+    and 9e5 accepted wedge samples among them - and the same number of raw draws consumed."""
+    n = 120_000_000
+    rng = np.random.default_rng(20240)
+    dev, state_after = _device_stream(ctx, rng, n)
+    ref = rng.standard_normal(n)
+    same = dev.view(np.uint64) == ref.view(np.uint64)
+    ntail = int((np.abs(ref) > ZIG_R).sum())
+    assert ntail > 25_000
+    if not same.all():
+        bad = np.flatnonzero(~same)
+        ulp = np.abs(dev.view(np.int64)[bad] - ref.view(np.int64)[bad])
+        # (a libm other than glibc may round its log1p differently: tail samples only, one ulp at most)
+        assert np.all(np.abs(ref[bad]) > ZIG_R) and ulp.max() <= 1, (bad[:5], ulp.max())
+    assert state_after == int(rng.bit_generator.state["state"]["state"])
+    assert abs(dev.mean()) < 5e-4 and abs(dev.std() - 1.0) < 5e-4
+
+
+@pytest.mark.parametrize("F,lmax", [(5, 33), (8, 64), (40, 200)])
+def test_stream_normals_order_and_generator_state(ctx, F, lmax):
+    """skysim.stream_normals = the reference's draw order (per l: F (l + 1) reals, then the imaginaries; nputil.py:121-125)
+    and leaves the caller's Generator exactly where numpy would: the next draws agree, a buffered 32-bit half included."""
+    from cora_amd.core import skysim
+
+    a, b = np.random.default_rng(77), np.random.default_rng(77)
+    for r in (a, b):
+        r.integers(0, 2**32, dtype=np.uint32)              # leaves has_uint32 = 1 in the bit generator's state
+    g_dev = skysim.stream_normals(ctx, F, lmax, a).cpu().numpy()
+    g_ref = skysim._host_normals(F, lmax, b)
+    assert np.array_equal(g_dev.view(np.uint64), g_ref.view(np.uint64))
+    assert a.bit_generator.state == b.bit_generator.state
+    assert np.array_equal(a.standard_normal(100), b.standard_normal(100))
+    assert a.integers(0, 2**32, dtype=np.uint32) == b.integers(0, 2**32, dtype=np.uint32)
+
+
+def test_other_generators_are_consumed_on_the_host(ctx, monkeypatch):
+    """Only Generator(PCG64) is continued on the device; the legacy global state (rng=None), other bit generators and
+    RandomState objects keep the host path (same values as the reference draws)."""
+    from cora_amd.core import skysim
+
+    def boom(*a, **k):
+        raise AssertionError("device PCG64 stream used for a generator that is not PCG64")
+
+    monkeypatch.setattr(type(ctx), "normals_pcg64", boom)
+    F, lmax = 6, 20
+    for make in (lambda: np.random.Generator(np.random.MT19937(5)), lambda: np.random.Generator(np.random.PCG64DXSM(5)),
+                 lambda: np.random.Generator(np.random.Philox(5))):
+        assert np.array_equal(skysim.stream_normals(ctx, F, lmax, make()).cpu().numpy(), skysim._host_normals(F, lmax, make()))
+    np.random.seed(99)
+    g = skysim.stream_normals(ctx, F, lmax, None).cpu().numpy()
+    np.random.seed(99)
+    assert np.array_equal(g, skysim._host_normals(F, lmax, None))
+
+
+@pytest.mark.parametrize("key,cl,seed,nside", [("alm_21cm_F4_l16_seed3", "cla_21cm_F4_l16_zromb1", 3, 8),
+                                               ("alm_21cm_F8_l64_seed4", "cla_21cm_F8_l64_zromb3", 4, 32)])
+def test_reference_golden_alm_with_the_device_stream(ctx, golden, monkeypatch, key, cl, seed, nside):
+    """The reference's own mkfullsky(alms=True, rng=default_rng(seed)) output reproduced with NO normal generated on the
+    host, and the generator left where the reference leaves it."""
+    from cora_amd.core import skysim
+
+    def boom(*a, **k):
+        raise AssertionError("host normal stream used for a PCG64 Generator")
+
+    monkeypatch.setattr(skysim, "_upload_host_normals", boom)
+    monkeypatch.setattr(skysim, "_host_normals", boom)
+    rng = np.random.default_rng(seed)
+    a = skysim.mkfullsky(golden[cl], nside, alms=True, rng=rng)
+    ref = golden[key]
+    assert a.shape == ref.shape and np.abs(a - ref).max() <= 1e-12 * np.abs(ref).max()
+    twin = np.random.default_rng(seed)
+    F, L = golden[cl].shape[1], golden[cl].shape[0]
+    for l in range(L):
+        twin.standard_normal((F, l + 1))
+        twin.standard_normal((F, l + 1))
+    assert rng.bit_generator.state == twin.bit_generator.state
+
+
+@pytest.mark.parametrize("F,lmax,nu0,nnu", [(8, 40, 0, 8), (24, 70, 0, 24), (72, 150, 0, 72), (136, 260, 0, 136),
+                                            (256, 300, 64, 64), (256, 300, 192, 64), (40, 90, 8, 16), (264, 140, 0, 264)])
+def test_draw_from_stream_buffer_matches_numpy(ctx, F, lmax, nu0, nnu, monkeypatch):
+    """K3 with its normals read from a stream-order buffer (the persistent MFMA kernel's FROMG mode; every tile width, a
+    frequency shard, lower-triangular and dense factors, row-block factors) against numpy's T_l g_l, and against the
+    generic kernel of round 1."""
+    import torch
+
+    rs = np.random.default_rng(F * 1000 + lmax)
+    L = lmax + 1
+    T = np.tril(rs.standard_normal((L, F, F))) + 3.0 * np.eye(F)
+    T[3] = rs.standard_normal((F, F))                          # a dense root (eigen branch)
+    info = np.zeros(L, dtype=np.int32)
+    info[3] = 1
+    g = skysim_host_normals(F, lmax, rs)
+    Td, infod, gd = ctx.to_device(T), torch.from_numpy(info).to(ctx.device), ctx.to_device(g)
+    alm = ctx.draw_alm(Td, infod, gd, lmax, F, nu0=nu0, nnu=nnu)
+    sq = ctx.alm_dev_to_square(alm, lmax, nnu).cpu().numpy()[:, 0]          # [nnu, l, m]
+    off = 0
+    worst = 0.0
+    for l in range(L):
+        n = F * (l + 1)
+        gl = (g[off:off + n].reshape(F, l + 1) + 1j * g[off + n:off + 2 * n].reshape(F, l + 1)) / np.sqrt(2.0)
+        ref = T[l, nu0:nu0 + nnu] @ gl
+        worst = max(worst, np.abs(sq[:, l, :l + 1] - ref).max() / np.abs(ref).max())
+        off += 2 * n
+    assert worst < 1e-13, worst
+    rows = ctx.draw_alm_rows(Td[:, nu0:nu0 + nnu, :].contiguous(), infod, gd, lmax, F, nu0, nnu)
+    assert torch.equal(rows, alm)
+    monkeypatch.setenv("CORAHIP_DRAW_GENERIC", "1")
+    old = ctx.draw_alm(Td, infod, gd, lmax, F, nu0=nu0, nnu=nnu)
+    assert (old - alm).abs().max().item() <= 1e-12 * alm.abs().max().item()
+
+
+def skysim_host_normals(F, lmax, rng):
+    from cora_amd.core import skysim
+
+    return skysim._host_normals(F, lmax, rng)

@@ -514,3 +514,97 @@ def test_c_ring_stage_equals_the_numpy_definition(nside, lmax):
     ref = sht.alm2map(a, nside, lmax)
     got = sht.alm2map(a, nside, lmax, rings_c=True)
     assert np.abs(got - ref).max() <= 1e-13 * ref.std()
+
+
+# ------------------------------------------------------------------ numpy's seeded normal stream (oracle/npnormal.py)
+def test_zig_tables_are_numpys_own():
+    """cora_amd/csrc/zig_tab.inc (what the kernels and the oracle use) equals the tables inside numpy's shipped library."""
+    import os
+    import sys
+
+    from oracle import npnormal
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import gen_zig_tabs
+
+    try:
+        ki, wi, fi = gen_zig_tabs.tables()
+    except (OSError, KeyError) as e:
+        pytest.skip("numpy's libnpyrandom.a not readable here: %s" % e)
+    gen_zig_tabs.check_construction(ki, wi, fi)
+    oki, owi, ofi = npnormal.tables()
+    assert [int(v) for v in ki] == oki
+    assert np.array_equal(np.array(owi), wi) and np.array_equal(np.array(ofi), fi)
+
+
+@pytest.mark.parametrize("seed", [0, 3, 12345])
+def test_npnormal_oracle_is_numpys_stream(seed):
+    """The restatement of PCG64 + ziggurat equals numpy's Generator value by value - fast path, wedge and tail samples -
+    and consumes the same number of raw draws (the generator's own state afterwards); advance = bit_generator.advance."""
+    from oracle import npnormal as o
+
+    rng = np.random.default_rng(seed)
+    s, inc = o.state_of(rng)
+    n = 150_000
+    stats = {}
+    v, nraw = o.standard_normal(s, inc, n, stats)
+    ref = rng.standard_normal(n)
+    assert np.array_equal(v.view(np.uint64), ref.view(np.uint64))
+    assert stats["wedge_accept"] > 500 and stats["wedge_reject"] > 500 and stats["tail"] > 10
+    assert o.advance(s, inc, nraw) == o.state_of(rng)[0]
+    raw, s5 = o.raw_stream(s, inc, 5)
+    assert np.array_equal(raw, np.random.PCG64(seed).random_raw(5))
+    for d in (0, 1, 4097, 10**12 + 7, 2**64 - 3):
+        bg = np.random.PCG64(seed)
+        bg.advance(d)
+        assert o.advance(s, inc, d) == o.state_of(bg)[0]
+
+
+def test_glibc_log1p_restatement_matches_libm():
+    """The operation-by-operation log1p the kernels run for tail samples is libm's: every range of the argument."""
+    import math
+    import random
+
+    from oracle import npnormal as o
+
+    random.seed(1)
+    for i in range(60_000):
+        k = random.getrandbits(53)
+        if i % 3 == 0:
+            k >>= random.randrange(0, 50)
+        if i % 7 == 0:
+            k = (1 << 53) - 1 - (k >> random.randrange(0, 50))
+        u = k * (1.0 / 9007199254740992.0)
+        assert o.glibc_log1p(-u) == math.log1p(-u), (k, u)
+
+
+@pytest.mark.parametrize("seed,n,R,T,margin", [(0, 30000, 16, 8, 1.0225), (5, 30000, 7, 3, 1.0225), (2, 20000, 30, 2, 1.0225),
+                                               (9, 20000, 16, 4, 1.0), (4, 40000, 64, 16, 1.0225)])
+def test_npnormal_parallel_model_is_numpys_stream(seed, n, R, T, margin):
+    """The block / scan / emit decomposition of the device (run scan by integer add, boundary state = positions consumed,
+    repair of blocks entered with k >= 2, several rounds when the raw range was short) gives numpy's values and count."""
+    from oracle import npnormal as o
+    from oracle import npnormal_model as m
+
+    rng = np.random.default_rng(seed)
+    s, inc = o.state_of(rng)
+    stats = {}
+    v, nraw = m.parallel_normals(s, inc, n, R=R, T=T, margin=margin, stats=stats)
+    ref = rng.standard_normal(n)
+    assert np.array_equal(v.view(np.uint64), ref.view(np.uint64))
+    assert o.advance(s, inc, nraw) == o.state_of(rng)[0]
+    if margin < 1.01:
+        assert stats["rounds"] >= 2
+
+
+def test_pcg64_advance_abi_is_numpys_advance():
+    """corahip_pcg64_advance (host arithmetic of the library, no GPU) against numpy's bit_generator.advance."""
+    from cora_amd import _lib
+    from oracle import npnormal as o
+
+    for seed in (0, 7):
+        s, inc = o.state_of(np.random.PCG64(seed))
+        for d in (0, 1, 5, 4096, 10**9 + 7, 2**63 + 12345):
+            bg = np.random.PCG64(seed)
+            bg.advance(d)
+            assert _lib.pcg64_advance(s, inc, d) == o.state_of(bg)[0] == o.advance(s, inc, d)
