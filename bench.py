@@ -230,7 +230,7 @@ def main():
     # where numpy would leave it) instead of the library's Philox stream; and the legacy mode (rng=None: numpy's global
     # MT19937 + polar method), whose normals are host-generated - measured on a bounded sample and extrapolated
     seeded_numpy = legacy_rng = None
-    if rank == 0 and world == 1 and args.emulate_shard <= 1 and len(comps) == 1 and not args.no_seeded_modes:
+    if rank == 0 and world == 1 and args.emulate_shard <= 1 and len(comps) == 1 and not (args.no_seeded_modes or args.checksum):
         seeded_numpy, legacy_rng = seeded_modes(ctx, shard, cold_factors, F, lmax, barrier, args.steps)
 
     # host-delivered rate: the reference's own signature returns numpy arrays (cora/core/skysim.py:130-136), i.e. every
