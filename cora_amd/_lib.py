@@ -20,6 +20,7 @@ PTR = c_void_p
 # name -> (restype, argtypes): every symbol include/corahip.h declares
 SIGNATURES = {
     "corahip_abi_version": (c_int, []),
+    "corahip_abi_minor": (c_int, []),
     "corahip_last_error": (c_char_p, []),
     "corahip_device_count": (c_int, [ctypes.POINTER(c_int)]),
     "corahip_ctx_create": (c_int, [c_int, ctypes.POINTER(c_void_p)]),
@@ -261,6 +262,12 @@ class Context:
         """The 21cm tables (dd, dv, vv) stay as they are under this generation number: K1 keeps its transposed copy
         of them between calls (corahip_clarray_tables_pin).  The model that owns the tables calls this."""
         _check(self.lib.corahip_clarray_tables_pin(self.h, self._f64(dd), self._f64(dv), self._f64(vv), c_u64(int(generation))))
+
+    def unpin_tables(self, generation=0):
+        """Withdraws the pin of ``generation`` (0: whatever is pinned): the owner calls this before its tables are
+        freed or replaced - a recycled device address must never be taken for the pinned tables."""
+        if self.h:
+            _check(self.lib.corahip_clarray_tables_pin(self.h, None, None, None, c_u64(int(generation))))
 
     def clarray_table21cm(self, dd, dv, vv, kperpmin, kperpmax, kparmax, chi, pfd, f, b, F, zint, w, log10l):
         nl = log10l.numel()

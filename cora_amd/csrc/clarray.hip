@@ -79,7 +79,8 @@ clarray21_kernel(const double *__restrict__ tt, int nkperp, int nkpar, double kp
 #pragma unroll
     for (int k = 0; k < CL_LPT; k++) {
         const int li = l_base + tid + 256 * k;
-        lxs[k] = (li < nl_total ? log10l[li] : 0.0) * xscale;
+        // (entries past the range repeat its last multipole: every lane of the clamp-free path stays inside the profile)
+        lxs[k] = log10l[min(li, nl_total - 1)] * xscale;
         acc[k] = 0.0;
     }
     // rows the l range can touch: x(l_first) <= x <= x(l_last) + 1 (x is monotone in l; log10l ascending)
@@ -406,11 +407,14 @@ static int clarray21_pairs(corahip_ctx *ctx, const double *dd, const double *dv,
     // the x-contiguous copy of the tables: made on every call unless the caller has pinned exactly these tables
     // (corahip_clarray_tables_pin) and the copy of that generation is still the one in the scratch slot
     const bool pinned = ctx->tt_pinned && ctx->tt_pin[0] == dd && ctx->tt_pin[1] == dv && ctx->tt_pin[2] == vv;
-    if (!(pinned && ctx->tt_valid && ctx->scratch_bytes[0] == tt_bytes)) {
+    // (the kept copy was written by work queued on tt_stream: a call on another stream has no ordering with it and
+    //  makes its own)
+    if (!(pinned && ctx->tt_valid && ctx->tt_stream == ctx->stream && ctx->scratch_bytes[0] == tt_bytes)) {
         dim3 grid((nkpar + 31) / 32, CL_XS / 32, 3);
         cl_transpose_kernel<<<grid, 256, 0, ctx->stream>>>(dd, dv, vv, nkperp, nkpar, tt);
         LAUNCH_CHECK();
         ctx->tt_valid = pinned;
+        ctx->tt_stream = ctx->stream;
     }
     const double xscale = (double)(nkperp - 1) / log10(kperpmax / kperpmin);
     const double yscale = kparmax / M_PI;
@@ -427,6 +431,8 @@ static int clarray21_pairs(corahip_ctx *ctx, const double *dd, const double *dv,
 
 int corahip_clarray_tables_pin(corahip_ctx *ctx, const double *dd, const double *dv, const double *vv, uint64_t generation) {
     ARG_CHECK(ctx != nullptr);
+    if (dd == nullptr && generation != 0 && !(ctx->tt_pinned && ctx->tt_pin_gen == generation))
+        return 0;                  // an owner withdrawing a pin that another generation has replaced: nothing of its own left
     const bool same = ctx->tt_pinned && dd && ctx->tt_pin[0] == dd && ctx->tt_pin[1] == dv && ctx->tt_pin[2] == vv &&
                       ctx->tt_pin_gen == generation;
     if (same) return 0;

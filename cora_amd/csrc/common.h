@@ -53,6 +53,7 @@ struct corahip_ctx {
     const void *tt_pin[3] = {nullptr, nullptr, nullptr};
     uint64_t tt_pin_gen = 0;
     bool tt_pinned = false, tt_valid = false;
+    hipStream_t tt_stream = nullptr;               // stream the kept copy was made on
     // K1 pair list resident in scratch slot 2: (F, first, step, slots, device pointer it was written to)
     long pairs_key[4] = {-1, -1, -1, -1};
     void *pairs_ptr = nullptr;

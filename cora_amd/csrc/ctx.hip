@@ -29,6 +29,8 @@ extern "C" {
 
 int corahip_abi_version(void) { return CORAHIP_ABI_VERSION; }
 
+int corahip_abi_minor(void) { return CORAHIP_ABI_MINOR; }
+
 const char *corahip_last_error(void) { return g_err; }
 
 int corahip_device_count(int *count) {

@@ -354,7 +354,8 @@ draw_rng_kernel(const double *__restrict__ T, size_t t_ldl, int t_row0, const in
         auto half_steps = [&](auto tmin_c, const double *sb, int k0, auto half_c) {
             constexpr int TMIN = decltype(tmin_c)::value;
             constexpr int half = decltype(half_c)::value;
-#pragma unroll(FROMG ? 4 : DRAW_KK_UNROLL)
+            constexpr int UNR = FROMG ? 4 : DRAW_KK_UNROLL;     // (FROMG indexes its operand registers by kk)
+#pragma unroll UNR
             for (int kk = 4 * half; kk < 4 * half + 4; kk++) {
                 const int kp = k0 + 4 * kk + kq;
                 const int kl = 4 * kk + kq;          // k within the chunk

@@ -132,7 +132,9 @@ legendre_kernel(int lmax, int npair, int nring, int ncols, const double *__restr
             asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
                          :
                          : "v"(vo), "s"(rsrc), "s"(rdst), "n"(IMM)
-                         : "memory", "scc");     // (s_add_u32 writes SCC: undeclared, it ate the stage loop's compare)
+                         : "memory", "scc");     // (s_add_u32 writes SCC: undeclared, it ate the stage loop's compare; M0 cannot be
+                                                 //  declared: hipcc treats it as reserved - "may not be preserved" - so the
+                                                 //  contract stays the comment above, checked in the ISA by tools/asm_of.sh)
     };
     auto issue_coef = [&](const item_t &w, int st) {
         const int l = w.l_begin + st * LEG_KT + lane;

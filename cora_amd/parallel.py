@@ -130,7 +130,7 @@ def _rows_unpack(recv, counts):
     """[world, l_stride, nnu, F] + per-rank l counts -> [sum counts, nnu, F] (corahip_factor_rows_unpack on the device)."""
     import torch
 
-    if recv.is_cuda:
+    if recv.is_cuda and recv.shape[0] <= 64:      # (the kernel takes the l-block table as an argument: <= 64 ranks)
         from . import _lib
 
         return _lib.get_context(recv.device.index).factor_rows_unpack(recv, counts)
@@ -532,9 +532,7 @@ def mkfullsky_sharded(corr_local, global_shape, nside, rng=None, alms=False, ctx
     nu0, nnu = sp.nu0, sp.nnu
     T_loc, i_loc = skysim.factor_device(corr_local) if n_local else (ctx.empty((0, F, F)), torch.empty(
         (0,), dtype=torch.int32, device=ctx.device))
-    pad_T = torch.zeros((lc, F, F), dtype=torch.float64, device=ctx.device)
     pad_i = torch.zeros((lc,), dtype=torch.int32, device=ctx.device)
-    pad_T[:n_local].copy_(T_loc)
     pad_i[:n_local].copy_(i_loc)
     i_all = torch.empty((world * lc,), dtype=torch.int32, device=ctx.device)
     dist.all_gather_into_tensor(i_all, pad_i)
@@ -543,6 +541,8 @@ def mkfullsky_sharded(corr_local, global_shape, nside, rng=None, alms=False, ctx
         recv = _all_to_all(_rows_pack(T_loc, lc, world), world)           # [src, lc, nnu, F]
         T = _rows_unpack(recv, counts)
     else:
+        pad_T = torch.zeros((lc, F, F), dtype=torch.float64, device=ctx.device)
+        pad_T[:n_local].copy_(T_loc)
         recv = torch.empty((world * lc, F, F), dtype=torch.float64, device=ctx.device)
         dist.all_gather_into_tensor(recv, pad_T)
         recv = recv.view(world, lc, F, F)

@@ -224,6 +224,9 @@ class RedshiftCorrelation(object):
         # (the other devices' copies stay: a second context must not evict the first one's tables)
         if getattr(self, "_dev_tables", None) is None:
             self._dev_tables = {}
+        pins = self.__dict__.get("_pins")
+        if pins and ctx.device.index in pins:              # the set being replaced is pinned: not any more
+            self._unpin({ctx.device.index: pins.pop(ctx.device.index)})
         self._dev_tables[ctx.device.index] = (dd, dv, vv)
         self._host_tables = None
         self._aps_cache = True
@@ -243,7 +246,7 @@ class RedshiftCorrelation(object):
             [self._host_copy(k) if k != i else None for k in range(3)] if self._aps_cache else [None, None, None])
         cur[i] = np.ascontiguousarray(value, dtype=np.float64)
         self._host_tables = tuple(cur)
-        self._dev_tables = {}
+        self._drop_dev_tables()
         if all(t is not None for t in cur):
             self.nkperp, self.nkpar = cur[0].shape
             self._aps_cache = True
@@ -262,9 +265,28 @@ class RedshiftCorrelation(object):
         self._host_tables = (a["dd"], a["dv"], a["vv"])
         self.nkperp, self.nkpar = self._host_tables[0].shape
         self._aps_cache = True
-        self._dev_tables = {}
+        self._drop_dev_tables()
 
     _table_generation = [0]      # process-wide counter: every (re)built / uploaded table set gets its own number
+
+    @staticmethod
+    def _unpin(pins):
+        """Withdraws the K1 pins listed in ``pins`` ({device index: (ctx, generation)}): called when the device tables they
+        vouch for are dropped - by the setters, ``load_fft_cache``, a rebuild - and by the finaliser of the model (the
+        caching allocator hands a freed block to the next same-size request: a stale pin would vouch for foreign data)."""
+        for ctx, gen in list(pins.values()):
+            try:
+                ctx.unpin_tables(gen)
+            except Exception:       # (interpreter shutdown: the context may be gone already)
+                pass
+        pins.clear()
+
+    def _drop_dev_tables(self):
+        pins = self.__dict__.get("_pins")
+        if pins:
+            self._unpin(pins)
+        self.__dict__.pop("_dev_table_gen", None)
+        self._dev_tables = {}
 
     def _tables_on(self, ctx):
         dd_dv_vv = self._tables_on_unpinned(ctx)
@@ -276,6 +298,13 @@ class RedshiftCorrelation(object):
             RedshiftCorrelation._table_generation[0] += 1
             gens[key] = (dd_dv_vv, RedshiftCorrelation._table_generation[0])
         ctx.pin_tables(*dd_dv_vv, gens[key][1])
+        pins = self.__dict__.get("_pins")
+        if pins is None:
+            import weakref
+
+            pins = self._pins = {}
+            weakref.finalize(self, RedshiftCorrelation._unpin, pins)     # (holds the dict, not the model)
+        pins[key] = (ctx, gens[key][1])
         return dd_dv_vv
 
     def _tables_on_unpinned(self, ctx):

@@ -43,6 +43,7 @@ typedef struct corahip_sht_plan corahip_sht_plan;
 
 /* ---- library / context ------------------------------------------------------------ */
 int corahip_abi_version(void);
+int corahip_abi_minor(void);      /* entry points added since the version was cut, see CORAHIP_ABI_MINOR */
 const char *corahip_last_error(void);
 int corahip_device_count(int *count);
 int corahip_ctx_create(int device_id, corahip_ctx **ctx);
@@ -106,7 +107,10 @@ int corahip_clarray_pairs_finish(corahip_ctx *ctx, const double *pairs_in, int F
  * 500 x 32768).  A caller that keeps the tables unchanged between calls - they are the per-model cache of the reference,
  * cora/signal/corr.py:909-942 - pins them: the copy made by the next call is then reused as long as the SAME pointers
  * are passed and no other pin is made.  `generation` distinguishes table sets that happen to reuse device addresses
- * (increment it whenever the tables are rebuilt or rewritten); dd = NULL removes the pin. */
+ * (increment it whenever the tables are rebuilt or rewritten).  The pin must not outlive the tables: dd = NULL removes it -
+ * with generation != 0 only if that generation is still the one pinned (an owner releasing its own pin when its tables
+ * are freed or replaced; it cannot remove a later owner's), with generation = 0 unconditionally.  The kept copy is tied
+ * to the stream it was made on; a call on another stream makes its own. */
 int corahip_clarray_tables_pin(corahip_ctx *ctx, const double *dd, const double *dv, const double *vv,
                                uint64_t generation);
 

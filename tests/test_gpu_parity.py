@@ -1205,6 +1205,39 @@ def test_pinned_tables_follow_table_changes(ctx):
     assert np.array_equal(skysim.clarray(m.angular_powerspectrum, 40, freq, zromb=1), C2)
 
 
+def test_table_pin_does_not_outlive_the_model(ctx):
+    """A model's pin of its tables (K1 keeps a transposed copy of pinned tables) is withdrawn when the model is
+    collected or its device tables are dropped: afterwards the SAME device blocks carrying other numbers - what the
+    caching allocator hands to the next caller - are read afresh, not taken for the pinned tables."""
+    import gc
+
+    import torch
+    from cora_amd.core import skysim
+    from cora_amd.signal import corr21cm
+
+    freq = 600.0 + 2.0 * np.arange(6)
+    for how in ("collected", "tables dropped"):
+        m = corr21cm.Corr21cm()
+        C1 = skysim.clarray_device(m.angular_powerspectrum, 40, freq, zromb=1)
+        p = m._table_plan(lambda za: 1420.40575177 / za - 1.0)["prepare"](ctx, freq)   # the raw arguments K1 was called with
+        dd, dv, vv = p["dd"], p["dv"], p["vv"]                                    # (our references keep the blocks alive)
+        args = (p["kperpmin"], p["kperpmax"], p["kparmax"], ctx.to_device(p["chi"]), ctx.to_device(p["pfd"]),
+                ctx.to_device(p["f"]), ctx.to_device(p["b"]), len(freq), 1, ctx.to_device(np.ones(1)),
+                ctx.to_device(np.log10(np.arange(1.0, 6.0))))
+        base = ctx.clarray_table21cm(dd, dv, vv, *args)                          # (pinned copy in use)
+        if how == "collected":
+            del m, p
+            gc.collect()
+        else:
+            m._aps_dd = m._aps_dd * 1.0                                          # a setter: device tables dropped, pin withdrawn
+        for t in (dd, dv, vv):
+            t.mul_(3.0)                                                          # same addresses, other numbers
+        torch.cuda.synchronize()
+        got = ctx.clarray_table21cm(dd, dv, vv, *args)
+        assert torch.equal(got, 3.0 * base), how
+        del C1
+
+
 def test_factor_rows_pack_unpack_kernels(ctx):
     """corahip_factor_rows_pack / _unpack (csrc/shard.hip) against the permutation they implement, including an
     empty l block (a rank with no multipoles), uneven blocks and an odd row length."""
