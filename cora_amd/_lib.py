@@ -56,6 +56,8 @@ SIGNATURES = {
     "corahip_draw_alm_philox_rows": (c_int, [c_void_p, PTR, PTR, c_u64, c_int, c_int, c_int, c_int, PTR]),
     "corahip_draw_alm": (c_int, [c_void_p, PTR, PTR, PTR, c_int, c_int, c_int, c_int, PTR]),
     "corahip_draw_alm_rows": (c_int, [c_void_p, PTR, PTR, PTR, c_int, c_int, c_int, c_int, PTR]),
+    "corahip_mkfullsky_workspace_bytes": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, ctypes.POINTER(c_size_t)]),
+    "corahip_mkfullsky": (c_int, [c_void_p, c_void_p, PTR, c_int, c_void_p, c_int, c_int, c_int, PTR, c_void_p, c_size_t]),
     "corahip_shard_plan": (c_int, [c_int, c_int, c_int, c_int, PTR]),
     "corahip_factor_rows_pack": (c_int, [c_void_p, PTR, c_int, c_int, c_int, c_int, PTR]),
     "corahip_factor_rows_unpack": (c_int, [c_void_p, PTR, PTR, c_int, c_int, c_int, c_int, PTR]),
@@ -506,6 +508,41 @@ class Context:
         ws = self.workspace(need)
         _check(self.lib.corahip_alm2map(self.h, plan, self._f64(alm), nnu, self._f64(maps), self._p(ws), need))
         return maps
+
+    def mkfullsky_fused(self, C, nside, rng, nu0=0, nnu=None, alms=False, workspace_bytes=None):
+        """``corahip_mkfullsky``: C [L, F, F] (device) -> maps [nnu, npix] or, with ``alms``, a_lm [nnu, 1, L, L] complex,
+        in one library call.  ``rng``: ("pcg64", state, inc) python ints of a numpy bit generator - returns the state
+        after the draws -, ("stream", g) device normals in stream order, or ("philox", seed).  Returns (out, state)."""
+        torch = _torch()
+        L, F = int(C.shape[0]), int(C.shape[1])
+        lmax = L - 1
+        nnu = F if nnu is None else nnu
+        plan = self.sht_plan(nside, lmax)
+
+        class Rng(ctypes.Structure):
+            _fields_ = [("kind", ctypes.c_int32), ("reserved", ctypes.c_int32), ("stream", c_void_p), ("seed", c_u64),
+                        ("state", c_u64 * 2), ("inc", c_u64 * 2)]
+
+        r = Rng()
+        M = 2**64 - 1
+        kind = {"stream": 0, "philox": 1, "pcg64": 2}[rng[0]]
+        r.kind = kind
+        if kind == 0:
+            r.stream = self._f64(rng[1])
+        elif kind == 1:
+            r.seed = int(rng[1]) & M
+        else:
+            r.state[0], r.state[1] = (int(rng[1]) >> 64) & M, int(rng[1]) & M
+            r.inc[0], r.inc[1] = (int(rng[2]) >> 64) & M, int(rng[2]) & M
+        b = c_size_t()
+        _check(self.lib.corahip_mkfullsky_workspace_bytes(plan, F, nu0, nnu, kind, 1 if alms else 0, ctypes.byref(b)))
+        need = int(b.value) if workspace_bytes is None else int(workspace_bytes)
+        ws = torch.empty((max(need, 1),), dtype=torch.uint8, device=self.device)
+        out = (torch.empty((nnu, 1, L, L), dtype=torch.complex128, device=self.device) if alms
+               else self.empty((nnu, 12 * nside * nside)))
+        _check(self.lib.corahip_mkfullsky(self.h, plan, self._f64(C), F, ctypes.byref(r), nu0, nnu, 1 if alms else 0,
+                                          c_void_p(out.data_ptr()), self._p(ws), need))
+        return out, ((int(r.state[0]) << 64) | int(r.state[1])) if kind == 2 else None
 
     def map2alm_workspace_bytes(self, plan, nnu):
         b = c_size_t()

@@ -1,0 +1,94 @@
+// mkfullsky.hip - the fused convenience entry point of the drop-in boundary: C_l(nu,nu') -> sky maps in ONE call.
+//
+// Replaces the body of skysim.mkfullsky (cora/core/skysim.py:72-136) for a single process: per-l jitter + root
+// (:115-119), the complex normals of nputil.complex_std_normal (:120; cora/util/nputil.py:104-125), a_lm = T_l g_l
+// (:121) and hputil.sphtrans_inv_sky (:130; cora/util/hputil.py:500-531) - by chaining the library's own entry points
+// (corahip_factor_batched, corahip_normals_pcg64 / corahip_draw_alm*, corahip_alm2map / corahip_alm_dev_to_square) on
+// buffers cut from one caller-owned workspace.  Nothing here that a caller could not do with those five calls.
+#include "sht_internal.h"
+
+#include <algorithm>
+
+namespace {
+struct mk_layout {
+    size_t off_T, off_info, off_alm, off_g, off_sht, total_min, total_full;
+};
+inline size_t up256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+int layout_of(const corahip_sht_plan *p, int F, int nnu, int rng_kind, int alms, mk_layout &lo) {
+    const size_t L = p->L, nalm = p->nalm;
+    const size_t G = ((size_t)nnu + 3) / 4;
+    lo.off_T = 0;
+    lo.off_info = up256(sizeof(double) * L * F * F);
+    lo.off_alm = lo.off_info + up256(sizeof(int32_t) * L);
+    lo.off_g = lo.off_alm + up256(sizeof(double) * nalm * G * 8);
+    lo.off_sht = lo.off_g + (rng_kind == CORAHIP_RNG_PCG64 ? up256(sizeof(double) * 2 * (size_t)F * nalm) : 0);
+    size_t full = 0;
+    if (!alms) {
+        int rc = corahip_alm2map_workspace_bytes(p, nnu, &full);
+        if (rc) return rc;
+    }
+    lo.total_full = lo.off_sht + full;
+    // smallest synthesis workspace corahip_alm2map accepts (it then works through the channels in chunks of 8)
+    const size_t chunk8 = alms ? 0 : (size_t)p->nring * 2 * p->L * 8 * sizeof(double) + (size_t)p->nalm * 16 * sizeof(double) + K5_TAIL_PAD;
+    lo.total_min = std::min(lo.total_full, lo.off_sht + chunk8);
+    return 0;
+}
+}  // namespace
+
+extern "C" {
+
+int corahip_mkfullsky_workspace_bytes(const corahip_sht_plan *plan, int F, int nu0, int nnu, int rng_kind, int alms,
+                                      size_t *bytes) {
+    ARG_CHECK(plan != nullptr && bytes != nullptr && F >= 1 && nu0 >= 0 && nnu >= 1 && nu0 + nnu <= F);
+    ARG_CHECK(rng_kind == CORAHIP_RNG_STREAM || rng_kind == CORAHIP_RNG_PHILOX || rng_kind == CORAHIP_RNG_PCG64);
+    mk_layout lo;
+    int rc = layout_of(plan, F, nnu, rng_kind, alms, lo);
+    if (rc) return rc;
+    *bytes = lo.total_full;
+    return 0;
+}
+
+int corahip_mkfullsky(corahip_ctx *ctx, const corahip_sht_plan *plan, const double *C, int F, corahip_rng *rng, int nu0,
+                      int nnu, int alms, double *out, void *workspace, size_t workspace_bytes) {
+    ARG_CHECK(ctx != nullptr && plan != nullptr && C != nullptr && rng != nullptr && out != nullptr && workspace != nullptr);
+    ARG_CHECK(F >= 1 && nu0 >= 0 && nnu >= 1 && nu0 + nnu <= F);
+    ARG_CHECK(rng->kind == CORAHIP_RNG_STREAM || rng->kind == CORAHIP_RNG_PHILOX || rng->kind == CORAHIP_RNG_PCG64);
+    ARG_CHECK(rng->kind != CORAHIP_RNG_STREAM || rng->stream != nullptr);
+    mk_layout lo;
+    int rc = layout_of(plan, F, nnu, rng->kind, alms, lo);
+    if (rc) return rc;
+    if (workspace_bytes < lo.total_min) {
+        corahip_set_error("mkfullsky workspace too small: %zu bytes, need at least %zu (%zu for one synthesis pass)", workspace_bytes,
+                          lo.total_min, lo.total_full);
+        return CORAHIP_ENOMEM;
+    }
+    char *ws = (char *)workspace;
+    double *T = (double *)(ws + lo.off_T);
+    int32_t *info = (int32_t *)(ws + lo.off_info);
+    double *alm = (double *)(ws + lo.off_alm);
+    const int lmax = plan->lmax, L = plan->L;
+    // skysim.py:115-119: C_l + I max(diag) 1e-14 -> Cholesky, eigen root where that fails (nputil.py:51-101, threshold 1e-16)
+    if ((rc = corahip_factor_batched(ctx, C, L, F, 1e-14, 1e-16, T, info))) return rc;
+    // skysim.py:120-121
+    if (rng->kind == CORAHIP_RNG_PHILOX) {
+        rc = corahip_draw_alm_philox(ctx, T, info, rng->seed, lmax, F, nu0, nnu, alm);
+    } else if (rng->kind == CORAHIP_RNG_STREAM) {
+        rc = corahip_draw_alm(ctx, T, info, rng->stream, lmax, F, nu0, nnu, alm);
+    } else {
+        double *g = (double *)(ws + lo.off_g);
+        uint64_t n_raw = 0;
+        if ((rc = corahip_normals_pcg64(ctx, rng->state, rng->inc, (int64_t)2 * F * plan->nalm, g, &n_raw))) return rc;
+        uint64_t after[2];
+        if ((rc = corahip_pcg64_advance(rng->state, rng->inc, n_raw, after))) return rc;
+        rng->state[0] = after[0];                  // the generator as numpy would leave it
+        rng->state[1] = after[1];
+        rc = corahip_draw_alm(ctx, T, info, g, lmax, F, nu0, nnu, alm);
+    }
+    if (rc) return rc;
+    // skysim.py:123-130
+    if (alms) return corahip_alm_dev_to_square(ctx, alm, lmax, nnu, out);
+    return corahip_alm2map(ctx, plan, alm, nnu, out, ws + lo.off_sht, workspace_bytes - lo.off_sht);
+}
+
+}  // extern "C"

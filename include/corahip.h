@@ -32,7 +32,7 @@ extern "C" {
 #endif
 
 #define CORAHIP_ABI_VERSION 1
-#define CORAHIP_ABI_MINOR 1      /* additions since version 1: 1 = normals_pcg64, pcg64_advance, draw_alm_rows */
+#define CORAHIP_ABI_MINOR 1      /* additions since version 1: 1 = normals_pcg64, pcg64_advance, draw_alm_rows, mkfullsky, mkfullsky_workspace_bytes, abi_minor */
 
 #define CORAHIP_EINVAL (-1)   /* bad argument / shape */
 #define CORAHIP_ENOMEM (-2)   /* workspace too small / allocation refused */
@@ -192,6 +192,36 @@ int corahip_draw_alm_philox(corahip_ctx *ctx, const double *T, const int32_t *in
  * l-sharded factor stack: 1/N of the all-gather traffic and memory).                                */
 int corahip_draw_alm_philox_rows(corahip_ctx *ctx, const double *T_rows, const int32_t *info, uint64_t seed,
                                  int lmax, int F, int nu0, int nnu, double *alm_dev);
+
+/* ---- the whole of skysim.mkfullsky in one call (cora/core/skysim.py:72-136, single process) --------------------
+ * C [L, F, F] (device; L = lmax + 1 of `plan`) -> maps of channels nu0 .. nu0+nnu-1: jitter + root per l (:115-119),
+ * complex normals (:120), a_lm = T_l g_l (:121), HEALPix synthesis (:130).  A chain of the entry points above
+ * (factor_batched, normals_pcg64 / draw_alm*, alm2map) on buffers cut from ONE caller-owned device workspace.
+ *   rng   which normals (host struct):
+ *           CORAHIP_RNG_PCG64   the reference's seeded call, rng = numpy.random.default_rng(seed): `state`, `inc` are
+ *                               bit_generator.state["state"]["state" | "inc"] as {high, low} 64-bit words; numpy's
+ *                               sequence is continued on the device and `state` is UPDATED to the state numpy would be
+ *                               left in (the call synchronises the stream for that);
+ *           CORAHIP_RNG_STREAM  `stream`: DEVICE pointer to 2 F nalm normals in stream order (any generator, drawn by
+ *                               the caller in the reference's order - e.g. rng=None, numpy's legacy global state);
+ *           CORAHIP_RNG_PHILOX  the library's counter-based stream under `seed` (not numpy's numbers).
+ *   alms  0: out = maps [nnu, npix] RING (skysim.py:130-136);  1: out = a_lm [nnu, 1, L, L] complex128, m > l zero (:123-125)
+ *   workspace  >= corahip_mkfullsky_workspace_bytes(...) for one synthesis pass; a smaller one (down to the factors,
+ *              the a_lm, the normals of the PCG64 kind and one 8-channel synthesis chunk) is worked through in chunks;
+ *              CORAHIP_ENOMEM with the sizes in corahip_last_error() below that.                                      */
+#define CORAHIP_RNG_STREAM 0
+#define CORAHIP_RNG_PHILOX 1
+#define CORAHIP_RNG_PCG64 2
+typedef struct corahip_rng {
+    int32_t kind, reserved;
+    const double *stream;
+    uint64_t seed;
+    uint64_t state[2], inc[2];
+} corahip_rng;
+int corahip_mkfullsky_workspace_bytes(const corahip_sht_plan *plan, int F, int nu0, int nnu, int rng_kind, int alms,
+                                      size_t *bytes);
+int corahip_mkfullsky(corahip_ctx *ctx, const corahip_sht_plan *plan, const double *C, int F, corahip_rng *host_rng,
+                      int nu0, int nnu, int alms, double *out, void *workspace, size_t workspace_bytes);
 
 /* ---- frequency sharding for callers that pass the messages themselves -----------------------------
  * The reference distributes this path with caput.mpiarray over MPI (cora/core/skysim.py:97-110: C_l and the a_lm

@@ -1183,6 +1183,41 @@ def test_c_abi_with_ctypes_only_no_torch(tmp_path, golden):
         assert np.abs(got - a1).max() <= 1e-12 * np.abs(a1).max()
 
 
+def test_fused_mkfullsky_entry_point(ctx, golden):
+    """corahip_mkfullsky (the fused convenience entry) against the five-call chain behind
+    skysim.mkfullsky_device, for its three kinds of normals; the PCG64 kind hands back the generator state numpy would
+    be left in; a workspace too small for one synthesis pass is worked through in chunks, one too small for anything
+    is refused with CORAHIP_ENOMEM."""
+    import torch
+    from cora_amd import _lib
+    from cora_amd.core import skysim
+    from cora_amd.util.nputil import DeviceRNG
+
+    C = golden["cla_21cm_F8_l64_zromb3"]
+    Cd = ctx.to_device(C)
+    F, nside = C.shape[1], 32
+    rng = np.random.default_rng(4)
+    st = rng.bit_generator.state["state"]
+    ref_maps = skysim.mkfullsky_device(C, nside, rng=np.random.default_rng(4))
+    maps, after = ctx.mkfullsky_fused(Cd, nside, ("pcg64", st["state"], st["inc"]))
+    assert torch.equal(maps, ref_maps)
+    g = skysim._host_normals(F, C.shape[0] - 1, rng)                   # advances `rng` as the reference's draws do
+    assert after == int(rng.bit_generator.state["state"]["state"])
+    alm, _ = ctx.mkfullsky_fused(Cd, nside, ("pcg64", st["state"], st["inc"]), alms=True)
+    ref_alm = golden["alm_21cm_F8_l64_seed4"]
+    assert np.abs(alm.cpu().numpy() - ref_alm).max() <= 1e-12 * np.abs(ref_alm).max()
+    maps_s, _ = ctx.mkfullsky_fused(Cd, nside, ("stream", ctx.to_device(g)))
+    assert torch.equal(maps_s, ref_maps)
+    maps_p, _ = ctx.mkfullsky_fused(Cd, nside, ("philox", 77), nu0=2, nnu=4)
+    assert torch.equal(maps_p, skysim.mkfullsky_device(C, nside, rng=DeviceRNG(77), nu_range=(2, 4)))
+    # chunked synthesis: the minimum the entry accepts is in the error text of a refused call
+    with pytest.raises(RuntimeError) as ei:
+        ctx.mkfullsky_fused(Cd, nside, ("stream", ctx.to_device(g)), workspace_bytes=1024)
+    need_min = int(str(ei.value).split("need at least ")[1].split()[0])
+    maps_c, _ = ctx.mkfullsky_fused(Cd, nside, ("stream", ctx.to_device(g)), workspace_bytes=need_min)
+    assert torch.equal(maps_c, ref_maps)
+
+
 def test_pinned_tables_follow_table_changes(ctx):
     """K1 keeps its transposed copy of the 21cm tables between calls while the model has them pinned
     (corahip_clarray_tables_pin); assigning new tables (the setters the reference's load_fft_cache uses,
@@ -1231,10 +1266,10 @@ def test_table_pin_does_not_outlive_the_model(ctx):
         else:
             m._aps_dd = m._aps_dd * 1.0                                          # a setter: device tables dropped, pin withdrawn
         for t in (dd, dv, vv):
-            t.mul_(3.0)                                                          # same addresses, other numbers
+            t.mul_(2.0)                                                          # same addresses, other numbers (x 2: exact)
         torch.cuda.synchronize()
         got = ctx.clarray_table21cm(dd, dv, vv, *args)
-        assert torch.equal(got, 3.0 * base), how
+        assert torch.equal(got, 2.0 * base), how
         del C1
 
 

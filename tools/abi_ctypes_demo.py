@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """The C ABI driven with ctypes + numpy only - no torch in the process - exactly as INTEGRATION.md shows a
-cora maintainer would bind it: C_l -> factors -> seeded draw -> HEALPix maps, and maps -> a_lm back.
+cora maintainer would bind it: ONE call, corahip_mkfullsky, takes C_l and the state of the caller's numpy Generator to the
+HEALPix maps (numpy's normal stream is continued on the device and the generator state comes back advanced); then maps
+-> a_lm back through the analysis entry point.
 Prints one line `ABI_DEMO max_map_err <e1> max_alm_err <e2>`; run by tests/test_gpu_parity.py against the oracle.
 
     python tools/abi_ctypes_demo.py <golden.npz key> <nside> <seed> <out.npz>
@@ -49,27 +51,46 @@ def main():
     nalm = L * (L + 1) // 2
     npix = 12 * nside * nside
     G = (F + 3) // 4
-    # the stream cora draws (skysim.py:120 via nputil.py:125): per l, F(l+1) reals then F(l+1) imags
+    # the generator cora's caller passes (cora/signal/lss.py:449-450): its PCG64 state goes to the library as it is
     rng = np.random.default_rng(seed)
-    g = np.concatenate([x.ravel() for l in range(L) for x in (rng.standard_normal((F, l + 1)), rng.standard_normal((F, l + 1)))])
+    st = rng.bit_generator.state["state"]
+    M64 = 2**64 - 1
+
+    class Rng(ctypes.Structure):
+        _fields_ = [("kind", ctypes.c_int32), ("reserved", ctypes.c_int32), ("stream", P), ("seed", ctypes.c_uint64),
+                    ("state", ctypes.c_uint64 * 2), ("inc", ctypes.c_uint64 * 2)]
+
+    def pcg64():
+        r = Rng()
+        r.kind = 2                                                  # CORAHIP_RNG_PCG64
+        r.state[0], r.state[1] = st["state"] >> 64, st["state"] & M64
+        r.inc[0], r.inc[1] = st["inc"] >> 64, st["inc"] & M64
+        return r
+
     ctx = Ctx()
-    dC, dg = ctx.dev(corr), ctx.dev(g)
-    dT, dinfo = ctx.dev(np.empty(L * F * F)), ctx.dev(np.empty(L, np.int32))
-    dalm, dmaps = ctx.dev(np.empty(nalm * G * 8)), ctx.dev(np.empty(F * npix))
-    _chk(_lib.corahip_factor_batched(ctx.h, dC, I(L), I(F), D(1e-14), D(1e-16), dT, dinfo))
-    _chk(_lib.corahip_draw_alm(ctx.h, dT, dinfo, dg, I(lmax), I(F), I(0), I(F), dalm))
+    dC = ctx.dev(corr)
     plan = P()
     _chk(_lib.corahip_sht_plan_create(ctx.h, I(nside), I(lmax), ctypes.byref(plan)))
     nb = SZ()
-    _chk(_lib.corahip_alm2map_workspace_bytes(plan, I(F), ctypes.byref(nb)))
+    _chk(_lib.corahip_mkfullsky_workspace_bytes(plan, I(F), I(0), I(F), I(2), I(0), ctypes.byref(nb)))
     ws = P()
     _chk(_lib.corahip_malloc(ctx.h, nb, ctypes.byref(ws)))
-    _chk(_lib.corahip_alm2map(ctx.h, plan, dalm, I(F), dmaps, ws, nb))
+    dmaps = ctx.dev(np.empty(F * npix))
+    r1 = pcg64()
+    _chk(_lib.corahip_mkfullsky(ctx.h, plan, dC, I(F), ctypes.byref(r1), I(0), I(F), I(0), dmaps, ws, nb))   # skysim.py:72-136
     _chk(_lib.corahip_ctx_sync(ctx.h))
     maps = ctx.host(dmaps, (F, npix))
+    # the same call with alms = 1 (skysim.py:123-125), from the same generator state
     dsq = ctx.dev(np.empty((F, 1, L, L), np.complex128))
-    _chk(_lib.corahip_alm_dev_to_square(ctx.h, dalm, I(lmax), I(F), dsq))
+    r2 = pcg64()
+    _chk(_lib.corahip_mkfullsky(ctx.h, plan, dC, I(F), ctypes.byref(r2), I(0), I(F), I(1), dsq, ws, nb))
     alm = ctx.host(dsq, (F, 1, L, L), np.complex128)
+    # the state that came back is where numpy leaves the generator after the reference's draws
+    for l in range(L):
+        rng.standard_normal((F, l + 1))
+        rng.standard_normal((F, l + 1))
+    after = int(rng.bit_generator.state["state"]["state"])
+    assert (int(r1.state[0]) << 64 | int(r1.state[1])) == after == (int(r2.state[0]) << 64 | int(r2.state[1]))
     # analysis direction: one unweighted quadrature pass of the maps
     nb2 = SZ()
     _chk(_lib.corahip_map2alm_workspace_bytes(plan, I(F), ctypes.byref(nb2)))
@@ -84,7 +105,7 @@ def main():
     rec = ctx.host(dsq2, (F, 1, L, L), np.complex128)
     _chk(_lib.corahip_ctx_sync(ctx.h))
     np.savez(out, maps=maps, alm=alm, rec=rec)
-    for p in (dC, dg, dT, dinfo, dalm, dmaps, ws, dsq, ws2, drec, dsq2):
+    for p in (dC, dmaps, ws, dsq, ws2, drec, dsq2):
         _chk(_lib.corahip_free(ctx.h, p))
     _chk(_lib.corahip_sht_plan_destroy(ctx.h, plan))
     _chk(_lib.corahip_ctx_destroy(ctx.h))
