@@ -314,6 +314,10 @@ def main():
                                                            if args.sum_mode == "joint" else ", one draw per component, a_lm added"),
                                (" - ONE GPU doing the share of the most loaded of %d ranks (%d channels, no exchanges): "
                                 "value counts those maps only" % (emu, nnu)) if emu else ""),
+                "sum_mode": (args.sum_mode + (": ONE draw of the summed covariance - same distribution as, not the same numbers per seed as, "
+                                              "the reference's one getsky() per component" if args.sum_mode == "joint"
+                                              else ": one factorisation + draw per component, as the reference's per-component getsky() calls"))
+                            if len(comps) > 1 else None,
                 "parallelism": "freq-shard x%d (pair-sharded C_l -> all-to-all -> l-sharded factor -> all-to-all of factor row blocks)" % world if world > 1 else "single GPU",
                 "realisations_per_s": args.steps / dt,
                 "warm_path": None if warm_ms is None else {"ms_per_step": warm_ms, "maps_per_s": F / (warm_ms * 1e-3)},
@@ -351,7 +355,8 @@ def main():
                 "frac": (16.0 * (4 * nside - 1) * L * nnu + 8.0 * npix * nnu) / (stages.get("ringfft", {"ms_per_launch": float("nan")})["ms_per_launch"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
             },
             # every stage against the roof that bounds it (algorithmic work of SURVEY 8(d) / DESIGN section 3 per launch)
-            "stage_rooflines": stage_rooflines(stages, nside, lmax, F, nnu, zromb, flops_exec, nu0),
+            "stage_rooflines": stage_rooflines(stages, comps, F, nside, lmax, nnu, nu0, max(world, emu, 1), args.sum_mode,
+                                               flops_exec),
             "hbm_roofline_whole_step": {
                 "algorithmic_GB": alg_bytes / 1e9,
                 "achieved_GBs": alg_bytes / 1e9 / (ms_step * 1e-3),
@@ -369,29 +374,61 @@ def main():
     return result
 
 
-def stage_rooflines(stages, nside, lmax, F, nnu, zromb, legendre_executed_flops, nu0=0):
+def stage_work(comps, F, nside, lmax, nnu, nu0, nranks, sum_mode, legendre_executed_flops):
+    """Algorithmic work of ONE RANK per step, per stage: {stage: (bound, flops, bytes, note)} (DESIGN
+    section 3).  `comps` = [(model name, zromb)], `nranks` = ranks the work is cut over (the world size, or the N of
+    --emulate-shard N), channels [nu0, nu0 + nnu) are this rank's.
+      clarray   pair-sharded: F (F + 1) / 2 / nranks channel pairs x zint^2 sub-sample pairs x L multipoles x a NOMINAL 60
+                flop per evaluation of the table model (interpolations + prefactors; not an executed-instruction count);
+                separable components cost an outer product (no flops counted), bytes = the C_l rows written
+      factor    l-sharded: L / nranks blocks of F^3 / 3 for every component that is factored per l (the table model; the
+                summed covariance in joint mode); a separable component is ONE F^3 / 3 (its root serves every l)
+      draw      triangular factors: channel nu takes nu + 1 columns, re and im: 4 nalm sum_{nu in the shard} (nu + 1) flop
+                per draw (joint mode: one draw; separate: one per component)
+      legendre  the MFMAs the kernel executes (the plan's count); ringfft: the cells read + the pixels written"""
     L = lmax + 1
     nalm = L * (L + 1) // 2
     npix = 12 * nside * nside
-    zint = 2**zromb + 1 if zromb else 1
-    work = {
-        # name: (bound, algorithmic flops, algorithmic bytes)
-        "clarray": ("valu", 60.0 * L * (F * zint) ** 2 / 2, 8.0 * L * F * F),
-        "factor": ("valu", L * F**3 / 3.0, 16.0 * L * F * F),
-        # triangular factors: channel nu takes nu + 1 columns, re and im: 4 nalm sum_{nu in the shard} (nu + 1) flop
-        # (2 F^2 nalm for all channels; the LAST rank of a frequency shard has nearly full rows - twice the average)
-        "draw": ("mfma", 4.0 * nalm * nnu * (nu0 + 0.5 * (nnu + 1)), 8.0 * L * F * nnu + 16.0 * nalm * nnu),
-        # (executed flops: the plan's MFMA count, see `roofline`)
-        "legendre": ("mfma", legendre_executed_flops, 16.0 * nalm * nnu + 16.0 * (4 * nside - 1) * L * nnu),
-        "ringfft": ("hbm", 2.5 * npix * np.log2(4 * nside) * nnu, 16.0 * (4 * nside - 1) * L * nnu + 8.0 * npix * nnu),
+    kinds = ["table" if m == "21cm" else "separable" for m, _ in comps]
+    k1_flops = k1_bytes = 0.0
+    for (m, z), kind in zip(comps, kinds):
+        zint = 2**z + 1 if z else 1
+        if kind == "table":
+            k1_flops += 60.0 * L * (F * (F + 1) / 2.0 / nranks) * zint * zint
+        k1_bytes += 8.0 * L * F * F / nranks
+    joint = len(comps) > 1 and sum_mode == "joint"
+    per_l = 1 if joint else sum(1 for k in kinds if k == "table")
+    once = 0 if joint else sum(1 for k in kinds if k == "separable")
+    k2_flops = per_l * (L / nranks) * F**3 / 3.0 + once * F**3 / 3.0
+    k2_bytes = 16.0 * (per_l * (L / nranks) + once) * F * F
+    ndraw = 1 if joint else len(comps)
+    k3_flops = ndraw * 4.0 * nalm * nnu * (nu0 + 0.5 * (nnu + 1))
+    k3_bytes = ndraw * (8.0 * L * F * nnu + 16.0 * nalm * nnu)
+    return {
+        "clarray": ("valu", k1_flops, k1_bytes, "nominal 60 flop per table evaluation; pairs of this rank only"),
+        "factor": ("valu", k2_flops, k2_bytes, "multipoles of this rank only"),
+        "draw": ("mfma", k3_flops, k3_bytes, "rows of this rank's channels; %d draw(s) per step" % ndraw),
+        "legendre": ("mfma", legendre_executed_flops, 16.0 * nalm * nnu + 16.0 * (4 * nside - 1) * L * nnu, "executed MFMAs"),
+        "ringfft": ("hbm", 2.5 * npix * np.log2(4 * nside) * nnu, 16.0 * (4 * nside - 1) * L * nnu + 8.0 * npix * nnu, ""),
     }
+
+
+def stage_rooflines(stages, comps, F, nside, lmax, nnu, nu0, nranks, sum_mode, legendre_executed_flops):
+    """Every stage of the step against the roof that bounds it: the rank's algorithmic work per STEP (stage_work) over the
+    stage's measured time per step.  All fractions are <= 1 by construction of the work model for any rank count,
+    --emulate-shard and multi-component workloads (tests/test_host.py checks the committed lines)."""
     out = {}
-    for k, (bound, flops, nbytes) in work.items():
+    for k, (bound, flops, nbytes, note) in stage_work(comps, F, nside, lmax, nnu, nu0, nranks, sum_mode,
+                                                      legendre_executed_flops).items():
         if k not in stages:
             continue
-        sec = stages[k]["ms_per_launch"] * 1e-3
-        e = {"ms": stages[k]["ms_per_launch"], "bound": bound, "TFLOPs": flops / sec / 1e12, "GBs": nbytes / sec / 1e9}
+        sec = stages[k]["ms_per_step"] * 1e-3
+        e = {"ms": stages[k]["ms_per_step"], "bound": bound, "TFLOPs": flops / sec / 1e12, "GBs": nbytes / sec / 1e9}
         e["frac"] = e["GBs"] / HBM_PEAK_GBS if bound == "hbm" else e["TFLOPs"] / FP64_MFMA_PEAK_TFLOPS
+        if note:
+            e["work"] = note
+        if k == "clarray":
+            e["frac_is_nominal"] = True       # a nominal flop count over the FP64 peak, not a measured VALU utilisation
         out[k] = e
     return out
 

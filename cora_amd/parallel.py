@@ -159,6 +159,49 @@ def exchange_factor_rows(T_local, info_local, plan):
     return _rows_unpack(recv, counts), i_all[: plan.L]
 
 
+def rank_memory_bytes(kinds, F, nside, lmax, world, sum_mode="joint", rng="philox"):
+    """Device bytes ONE rank of a ``world``-rank job holds at the peak of a cold step: the buffers of
+    :class:`SkyShard` / :class:`SkySum` counted from their shapes (no GPU needed; ``tests/test_host.py`` sums them for
+    BASELINE configs[3] and [4] at 8 ranks against the 288 GB of an MI355X, ``tests/test_gpu_parity.py`` compares the
+    single-rank figure with what torch actually allocates).
+
+    kinds : per component "table21cm" | "separable";  rng : "philox" (no normal buffer) | "numpy" (the whole stream of
+    a realisation in HBM, 16 F nalm bytes on EVERY rank, plus the generator's block tables)."""
+    L = lmax + 1
+    nalm = L * (L + 1) // 2
+    npix = 12 * nside * nside
+    npair, nring = 2 * nside, 4 * nside - 1
+    nnu = -(-F // world)
+    lsh = -(-L // world)
+    ntab = sum(1 for k in kinds if k == "table21cm")
+    joint = len(kinds) > 1 and sum_mode == "joint"
+    out = {}
+    out["maps"] = 8 * npix * nnu
+    out["a_lm"] = 16 * nalm * (-(-nnu // 4) * 4) * (1 if (joint or len(kinds) == 1) else 2)      # separate: + the component being added
+    out["synthesis workspace (F_m cells)"] = nring * (-(-nnu // 8) * 2) * L * 64
+    out["plan (recurrence coefficients, polar seeds, first-l tables, ring FFT tables)"] = (
+        2 * 16 * nalm + 2 * 16 * L * npair + 4 * L * npair + int(1.0e8 * (nside / 1024.0) ** 2))
+    if ntab:
+        out["21cm tables + their transposed copy"] = 2 * 3 * 500 * 32768 * 8
+        pairs = F * (F + 1) // 2
+        # pair shard of K1 [pairs / world, L padded], the same after all-to-all #1, the C_l block and its factor
+        out["C_l: pair slabs (sent + received), block of this rank's multipoles, its factors"] = (
+            (2 * 8 * (-(-pairs // world)) * (lsh * world) if world > 1 else 8 * pairs * L) + 2 * 8 * lsh * F * F)
+    if joint:
+        out["summed covariance block"] = 8 * lsh * F * F
+    ndraw = 1 if joint else len(kinds)
+    if world > 1:
+        # factor row blocks of this rank's channels + the slabs of all-to-all #2 while it runs
+        out["factor rows [L, nnu, F] (+ exchange slabs)"] = ndraw * 8 * L * nnu * F + 2 * 8 * world * lsh * nnu * F
+    elif not ntab:
+        out["factor rows [L, nnu, F] (+ exchange slabs)"] = ndraw * 8 * L * nnu * F
+    if rng == "numpy":
+        nn = 2 * F * nalm
+        out["numpy normal stream + generator block tables"] = 8 * nn + int(0.33 * nn * 1.03)
+    out["total"] = sum(out.values())
+    return out
+
+
 class SkyShard:
     """One rank's share of a Gaussian sky realisation (what ``Sky3d.getsky()`` does on one GPU, cora/core/maps.py:227-237,
     cut over ``world`` GPUs as described at the top of this module).  Everything the realisation reads is put in HBM

@@ -462,3 +462,26 @@ def test_cfg3_seeded_mkfullsky_channels_vs_oracle(ctx):
         err = np.abs(got[f] - ref).max() / ref.std()
         print("cfg3 seeded mkfullsky channel", f, "max|err|/rms =", err)
         assert err <= 1e-10, (f, err)
+
+
+def test_rank_memory_model_against_torch_at_cfg3(ctx):
+    """parallel.rank_memory_bytes (the figure tests/test_host.py holds against 288 GB for the 8-GPU configurations) is
+    what a rank really allocates: one cold cfg-3 step on one GPU, torch's peak allocation within 25 % of the model."""
+    import torch
+    from cora_amd.parallel import SkyShard, rank_memory_bytes
+    from cora_amd.signal import corr21cm
+
+    F, nside, lmax = 256, 1024, 2048
+    torch.cuda.synchronize()
+    ctx._workspace = None
+    torch.cuda.empty_cache()
+    base = torch.cuda.memory_allocated()
+    torch.cuda.reset_peak_memory_stats()
+    shard = SkyShard(corr21cm.Corr21cm(), _freqs(F), nside, lmax, zromb=3, ctx=ctx)
+    shard.realise(5)
+    torch.cuda.synchronize()
+    peak = torch.cuda.max_memory_allocated() - base
+    model = rank_memory_bytes(["table21cm"], F, nside, lmax, 1)["total"]
+    print("cfg3 peak allocation %.1f GB, model %.1f GB" % (peak / 1e9, model / 1e9))
+    assert 0.75 * model <= peak <= 1.25 * model, (peak, model)
+    del shard

@@ -391,3 +391,49 @@ def test_bench_self_launch_command(monkeypatch):
     assert seen["kw"]["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
     for name in ("cfg3", "cfg4", "cfg5"):
         assert name in bench.WORKLOADS
+
+
+# ------------------------------------------------------------------ bench line bookkeeping (no GPU)
+@pytest.mark.parametrize("line,workload,nranks,nu0,nnu,mode", [
+    ("bench_cfg3_r03_final.json", "cfg3", 1, 0, 256, "joint"),
+    ("bench_cfg3_emulated_shard8_r03.json", "cfg3", 8, 224, 32, "joint"),
+    ("bench_cfg3_emulated_shard2_r03.json", "cfg3", 2, 128, 128, "joint"),
+    ("bench_cfg4_r03_joint.json", "cfg4", 1, 0, 512, "joint"),
+    ("bench_cfg4_r03_separate.json", "cfg4", 1, 0, 512, "separate"),
+    ("bench_cfg5_emulated_shard_r03.json", "cfg5", 8, 896, 128, "joint")])
+def test_stage_rooflines_are_fractions_for_sharded_and_multicomponent_lines(line, workload, nranks, nu0, nnu, mode):
+    """bench.stage_rooflines prices every stage with the work of THE RANK that ran it: recorded stage times of the
+    sharded / emulated / multi-component lines give fractions in (0, 1] (round 3 printed 13.9 for K1 of the cfg-5 share:
+    the full F^2 over one eighth of the time)."""
+    import json
+
+    import bench
+
+    d = json.load(open(os.path.join(ROOT, "profiles", line)))
+    comps, F, _, _, nside, lmax = bench.WORKLOADS[workload]
+    stages = {k: {"ms_per_step": v} for k, v in d["stages_ms"].items()}
+    r = bench.stage_rooflines(stages, comps, F, nside, lmax, nnu, nu0, nranks, mode,
+                              d["roofline"]["executed_flops_per_launch"])
+    assert set(r) == set(stages)
+    for k, e in r.items():
+        assert 0.0 < e["frac"] <= 1.0, (line, k, e)
+
+
+def test_rank_memory_of_the_8_gpu_configs_fits_an_mi355x():
+    """BASELINE configs[3] (three components, 512 channels) and configs[4] (1024 channels, nside 2048, lmax 4096) at 8
+    ranks: maps, a_lm, F_m workspace, factor rows, C_l shard and plan of ONE rank stay under 0.9 x 288 GB; cfg 5 on
+    one GPU does not (that is why the bench emulates one rank of it)."""
+    from cora_amd.parallel import rank_memory_bytes
+
+    hbm = 288e9
+    c4 = rank_memory_bytes(["table21cm", "separable", "separable"], 512, 1024, 2048, 8)
+    c4s = rank_memory_bytes(["table21cm", "separable", "separable"], 512, 1024, 2048, 8, sum_mode="separate")
+    c5 = rank_memory_bytes(["table21cm"], 1024, 2048, 4096, 8)
+    for m in (c4, c4s, c5):
+        assert m["total"] == sum(v for k, v in m.items() if k != "total")
+        assert m["total"] < 0.9 * hbm, m
+    assert 120e9 < c5["total"] < 200e9
+    assert rank_memory_bytes(["table21cm"], 1024, 2048, 4096, 1)["total"] > hbm
+    # the numpy-seeded mode keeps the whole normal stream of a realisation on every rank: fine at cfg 3 / 4, not at cfg 5
+    assert rank_memory_bytes(["table21cm"], 256, 1024, 2048, 1, rng="numpy")["total"] < 0.9 * hbm
+    assert rank_memory_bytes(["table21cm"], 1024, 2048, 4096, 8, rng="numpy")["total"] > 0.9 * hbm
