@@ -75,7 +75,8 @@ struct corahip_sht_plan {
     struct ring_class {
         int P = 0;        // Bluestein length, 0 = direct power-of-two transform
         int N = 0;        // direct classes: the half length h of the rings (all equal), 0 = mixed (run-time length)
-        int P3 = 0;       // 3 * 2^k Bluestein length all rings of the class also admit (0 = none): see d_bfilt3
+        int P3 = 0;       // Bluestein length the compile-time kernels take for the class, filters in d_bfilt3 (0 = none):
+                          // 3 * 2^k (1536, 3072, 6144) where it holds 2 h - 1, or P = 8192 in the compile-time pass order
         int nch = 4;      // channels transformed together per workgroup
         int threads = 0;  // workgroup size (0: K5_THREADS)
         int bstride = 0;  // complex elements per channel buffer in LDS

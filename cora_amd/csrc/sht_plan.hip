@@ -550,11 +550,16 @@ int corahip_sht_plan_create_ex(corahip_ctx *ctx, int nside, int lmax, int cut_ex
             if (is_pow2(h)) continue;
             int P = 1;
             while (P < 2 * h - 1) P <<= 1;
+            // the length the compile-time kernels take for this ring, with a filter in THEIR storage order: 3 P / 4 where
+            // it still holds 2 h - 1, and P = 8192 itself (their 16 x 16 x 32 schedule differs from the generic passes)
             const int P3 = 3 * (P / 4);
-            if ((P3 == 1536 || P3 == 3072) && P3 >= 2 * h - 1) {
-                p->h_blu3_P[i - 1] = P3;
+            int alt = 0;
+            if ((P3 == 1536 || P3 == 3072 || P3 == 6144) && P3 >= 2 * h - 1) alt = P3;
+            else if (P == 8192) alt = P;
+            if (alt) {
+                p->h_blu3_P[i - 1] = alt;
                 fo3[i - 1] = nf3;
-                nf3 += P3;
+                nf3 += alt;
             }
         }
         if ((rc = dev_upload(&p->d_blu3_foff, fo3, s))) return rc;
@@ -577,7 +582,9 @@ int corahip_sht_plan_create_ex(corahip_ctx *ctx, int nside, int lmax, int cut_ex
                 if (!is_pow2(h)) {
                     P = 1;
                     while (P < 2 * h - 1) P <<= 1;
-                    P = 4 * P + (p->h_blu3_P[icap - 1] ? 1 : 0);   // rings that also admit 3 P / 4: a class of their own
+                    // rings with a compile-time length of their own (3 P / 4: code 1; P in the compile-time order: 2)
+                    const int alt = p->h_blu3_P[icap - 1];
+                    P = 4 * P + (alt == 0 ? 0 : (alt == P ? 2 : 1));
                 }
             }
             by_len[P].push_back(r);
@@ -587,7 +594,7 @@ int corahip_sht_plan_create_ex(corahip_ctx *ctx, int nside, int lmax, int cut_ex
         for (auto &kv : by_len) {
             corahip_sht_plan::ring_class c;
             c.P = kv.first > 0 ? kv.first / 4 : 0;
-            c.P3 = (kv.first > 0 && (kv.first & 1)) ? 3 * (c.P / 4) : 0;
+            c.P3 = kv.first > 0 ? ((kv.first & 3) == 1 ? 3 * (c.P / 4) : ((kv.first & 3) == 2 ? c.P : 0)) : 0;
             c.N = kv.first < 0 ? -kv.first : 0;
             c.bstride = fpad_len(c.P ? c.P : 2 * nside + 1) + K5_CH_SKEW;
             c.nch = 4;

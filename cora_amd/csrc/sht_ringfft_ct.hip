@@ -63,6 +63,19 @@ struct Sch<1536> {
     static constexpr int R0 = 12, R1 = 16, R2 = 8;
 };
 
+// cfg-5 geometry (nside 2048): the cap rings 1025 .. 2047 need Bluestein lengths above 4096, one channel per workgroup
+// (152 KB).  Three passes with the large radix (32, 24 = 3 * 8) in the FIRST, strided pass - half of whose inputs are
+// the zero padding, as half of the last inverse pass's outputs do not exist - and the register-fused middle stage at
+// radix 16 like the shorter lengths (a radix-32 middle stage holds 32 filter values on top of its 32 points: spills)
+template <>
+struct Sch<8192> {
+    static constexpr int R0 = 32, R1 = 16, R2 = 16;
+};
+template <>
+struct Sch<6144> {
+    static constexpr int R0 = 24, R1 = 16, R2 = 16;
+};
+
 // 12-point DFT, natural order in and out: n = 3 a + c, k = k1 + 4 k2: DFT4 over a, twiddle w12^{c k1}, DFT3 over c
 template <int SIGN>
 struct DftR<12, SIGN> {
@@ -103,6 +116,62 @@ __device__ constexpr double kSin16[16] = {0.0, 0.19509032201612826785, 0.3826834
                                           0.70710678118654752440, 0.83146961230254523708, 0.92387953251128675613, 0.98078528040323044913,
                                           1.0, 0.98078528040323044913, 0.92387953251128675613, 0.83146961230254523708,
                                           0.70710678118654752440, 0.55557023301960222474, 0.38268343236508977173, 0.19509032201612826785};
+
+// 32-point DFT, natural order in and out: DFT16 of the even and of the odd inputs, combined with w32^k = e^{SIGN i pi k / 16}
+template <int SIGN>
+struct DftR<32, SIGN> {
+    __device__ __forceinline__ static void run(double2 (&x)[32]) {
+        double2 e[16], o[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            e[k] = x[2 * k];
+            o[k] = x[2 * k + 1];
+        }
+        DftR<16, SIGN>::run(e);
+        DftR<16, SIGN>::run(o);
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const double2 t = k == 0 ? o[0] : cmul(o[k], make_double2(kCos16[k], SIGN * kSin16[k]));
+            x[k] = cadd(e[k], t);
+            x[k + 16] = csub(e[k], t);
+        }
+    }
+};
+
+// 24-point DFT, natural order in and out: n = 3 a + c, k = k1 + 8 k2: DFT8 over a, twiddle w24^{c k1}, DFT3 over c
+template <int SIGN>
+struct DftR<24, SIGN> {
+    __device__ __forceinline__ static void run(double2 (&x)[24]) {
+        const double h3 = 0.86602540378443864676;   // sqrt(3) / 2
+        // cos, sin of pi k / 12, k = 0 .. 14 (w24^j = e^{SIGN i pi j / 12}; c k1 <= 14)
+        constexpr double c12[15] = {1.0, 0.96592582628906828675, 0.86602540378443864676, 0.70710678118654752440, 0.5,
+                                    0.25881904510252076235, 0.0, -0.25881904510252076235, -0.5, -0.70710678118654752440,
+                                    -0.86602540378443864676, -0.96592582628906828675, -1.0, -0.96592582628906828675,
+                                    -0.86602540378443864676};
+        constexpr double s12[15] = {0.0, 0.25881904510252076235, 0.5, 0.70710678118654752440, 0.86602540378443864676,
+                                    0.96592582628906828675, 1.0, 0.96592582628906828675, 0.86602540378443864676,
+                                    0.70710678118654752440, 0.5, 0.25881904510252076235, 0.0, -0.25881904510252076235, -0.5};
+        double2 t[3][8];
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+#pragma unroll
+            for (int a = 0; a < 8; a++) t[c][a] = x[3 * a + c];
+            DftR<8, SIGN>::run(t[c]);                  // t[c][k1]
+        }
+#pragma unroll
+        for (int k1 = 0; k1 < 8; k1++) {
+            const double2 a = t[0][k1];
+            const double2 b = k1 == 0 ? t[1][0] : cmul(t[1][k1], make_double2(c12[k1], SIGN * s12[k1]));
+            const double2 c = k1 == 0 ? t[2][0] : cmul(t[2][k1], make_double2(c12[2 * k1], SIGN * s12[2 * k1]));
+            const double2 sm = cadd(b, c), d = csub(b, c);
+            const double2 m = make_double2(a.x - 0.5 * sm.x, a.y - 0.5 * sm.y);
+            const double2 n = cmuli<SIGN>(make_double2(h3 * d.x, h3 * d.y));
+            x[k1] = cadd(a, sm);
+            x[k1 + 8] = cadd(m, n);
+            x[k1 + 16] = csub(m, n);
+        }
+    }
+};
 
 __device__ __forceinline__ static double2 csqr(double2 a) {
     return make_double2(fma(a.x, a.x, -(a.y * a.y)), 2.0 * a.x * a.y);
@@ -216,7 +285,7 @@ __device__ __forceinline__ static void fold_cell(double2 *sm, int m, int n, int 
 // Ends with a barrier.  X_k, k = 0..h, is then at sm[c BS + fpad(k)].
 // TAIL: one more register slot for the cell m = tid + MC CT_T, index clamped to the last cell of the row (the belt
 // has lmax + 1 = MC CT_T + 1 cells: read in place, that one cell exposed a whole memory latency per item).
-template <int NCH, int BS, int MC, bool TAIL, int T>
+template <int NCH, int BS, int MC, bool TAIL, int T, int KPN = 4>
 struct FrontEnd {
     cell_ct<NCH> pf[MC + (TAIL ? 1 : 0)];
     // PART 0 / 1: first / second half of the cells (the requests of one item are spread over two phases: a burst of all
@@ -237,7 +306,7 @@ struct FrontEnd {
 #pragma unroll
             for (int c = 0; c < NCH; c++) asm volatile("" ::"v"(pf[k].re[c]), "v"(pf[k].im[c]));
     }
-    static constexpr int KP = 4;
+    static constexpr int KP = KPN;
     double2 phk[KP];    // e^{i m phi0} at m = tid + k T, k < KP (the Bluestein pre-pass derives e^{i pi k / h} from them)
     // fold with the phase computed here (two sincospi per thread and item: ~150 DP instructions)
     __device__ __forceinline__ void fold(double2 *sm, const double *__restrict__ cell, int Lr, int n, double phi0_over_pi, const int tid) {
@@ -485,7 +554,7 @@ ringfft_blu_ct(const int32_t *__restrict__ ring_list, int nlist, int nside, int 
         const int ch0 = (item % ngrp) * NCH;
         return inter + ((size_t)ring * G + (ch0 >> 2)) * L * 8 + (ch0 & 3);
     };
-    FrontEnd<NCH, BS, MC, false, T> fe;
+    FrontEnd<NCH, BS, MC, false, T, (U > 4 ? U : 4)> fe;
     double2 cbn[U];    // chirp b_k, k = tid + u T, of the NEXT item (index clamped: unused lanes load a valid slot)
     auto load_cbn = [&](int item, int t) {
         const int ring = ring_list[item / ngrp];
@@ -522,10 +591,19 @@ ringfft_blu_ct(const int32_t *__restrict__ ring_list, int nlist, int nside, int 
         // filter values of the register-fused middle (storage positions t R2 + r; the same for every channel), requested
         // first thing: vmcnt completes in order and the pixel stores of the previous item are ahead of these loads;
         // by the middle pass they have long been acknowledged
+        // (BPT > 1: one channel per workgroup and fewer threads than middle-stage butterflies - the 256-thread kernels of
+        //  P = 8192 / 6144: thread t takes the butterflies t, t + T, ... and holds the filter values of each)
+        constexpr int BPT = (P / R2 + T - 1) / T;
         const double2 *f = filt + foff[icap - 1] + (size_t)(tid % (P / R2)) * R2;
-        double2 fl[R2];
+        // (the radix-32 / 24 kernels at 512 threads have no registers to hold the filter values across the strided passes:
+        //  they request them behind forward pass 1 - the filter of a ring serves all its channel items: L2)
+        constexpr bool FL_EARLY = !(R0 > 16 && T == 512);
+        double2 fl[BPT][R2];
+        if constexpr (FL_EARLY)
 #pragma unroll
-        for (int r = 0; r < (R2 + 1) / 2; r++) fl[r] = f[r];     // (second half behind the fold: spread requests)
+        for (int q = 0; q < BPT; q++)
+#pragma unroll
+            for (int r = 0; r < (R2 + 1) / 2; r++) fl[q][r] = f[(size_t)min(q * T, P / R2 - 1 - (int)(tid % (P / R2))) * R2 + r];   // (second half behind the fold: spread requests; clamped: 6144 / 16 = 384 butterflies on 256 threads)
         // fold phases e^{i tid phi0}, e^{i T phi0} of this cap ring from the plan's table (the two sincospi they replace
         // were ~150 DP instructions per thread and item); requested here, consumed behind the barrier
         const double2 fph0 = foldph[(size_t)(icap - 1) * 512 + tid];
@@ -538,8 +616,11 @@ ringfft_blu_ct(const int32_t *__restrict__ ring_list, int nlist, int nside, int 
         CTSTAMP(0);
         fe.fold(sm, cell_ptr(item), Lr, n, fph0, fphs, tid);
         CTSTAMP(1);
+        if constexpr (FL_EARLY)
 #pragma unroll
-        for (int r = (R2 + 1) / 2; r < R2; r++) fl[r] = f[r];
+        for (int q = 0; q < BPT; q++)
+#pragma unroll
+            for (int r = (R2 + 1) / 2; r < R2; r++) fl[q][r] = f[(size_t)min(q * T, P / R2 - 1 - (int)(tid % (P / R2))) * R2 + r];
         __syncthreads();
         CTSTAMP(2);
         // ---- pre-pass for the pairs (k, h - k), with w = e^{2 pi i / n} and b_{h-k} = b_k, w^{h-k} = -conj(w^k) (h even):
@@ -547,7 +628,7 @@ ringfft_blu_ct(const int32_t *__restrict__ ring_list, int nlist, int nside, int 
         //        y_{h-k} = b_k [(X_{h-k} + conj X_k) - i conj(w^k) (X_{h-k} - conj X_k)]
         //      w^k = e^{i pi k / h} is the square of the fold phase e^{i k phi0} (phi0 = pi / 2h on a cap ring);
         //      zeros on [h, HALF)
-        static_assert(U <= 4, "four fold phases are kept");
+        static_assert(U <= decltype(fe)::KP, "the pre-pass takes w^k from the fold phases that are kept");
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const int k = tid + u * T;
@@ -609,6 +690,10 @@ ringfft_blu_ct(const int32_t *__restrict__ ring_list, int nlist, int nside, int 
         }
         fe.template prefetch<1>(cell_ptr(nitem), L, tid);
         load_cbn(nitem, tid);
+        if constexpr (!FL_EARLY) {
+#pragma unroll
+            for (int r = 0; r < R2; r++) fl[0][r] = f[r];
+        }
         __syncthreads();
         CTSTAMP(4);
         ct_pass<P, NCH, BS, Q0, R1, -1, false, T>(sm, wB, tid);
@@ -618,28 +703,49 @@ ringfft_blu_ct(const int32_t *__restrict__ ring_list, int nlist, int nside, int 
         {
             // thread -> (channel, butterfly t) with t = tid mod NB in EVERY iteration (the filter registers fl[] belong to
             // that t): CPI whole channels per iteration, threads beyond CPI NB idle (NB = 192 for the 3 * 2^k lengths)
-            constexpr int NB = P / R2, CPI = T / NB, IT = (NCH + CPI - 1) / CPI;
-            static_assert(CPI >= 1, "a channel's butterflies must fit one iteration");
+            constexpr int NB = P / R2;
+            if constexpr (BPT == 1) {
+                constexpr int CPI = T / NB, IT = (NCH + CPI - 1) / CPI;
 #pragma unroll
-            for (int it = 0; it < IT; it++) {
-                const int chl = tid / NB, t = tid - chl * NB;
-                const int ch = it * CPI + chl;
-                if (chl >= CPI || ch >= NCH) break;
-                double2 *p = sm + ch * BS + fpad(t * R2);
-                double2 x[R2];
+                for (int it = 0; it < IT; it++) {
+                    const int chl = tid / NB, t = tid - chl * NB;
+                    const int ch = it * CPI + chl;
+                    if (chl >= CPI || ch >= NCH) break;
+                    double2 *p = sm + ch * BS + fpad(t * R2);
+                    double2 x[R2];
 #pragma unroll
-                for (int r = 0; r < R2; r++) x[r] = p[fpc(r)];
-                DftR<R2, -1>::run(x);
+                    for (int r = 0; r < R2; r++) x[r] = p[fpc(r)];
+                    DftR<R2, -1>::run(x);
 #pragma unroll
-                for (int r = 0; r < R2; r++) x[r] = cmul(x[r], fl[r]);
-                DftR<R2, 1>::run(x);
+                    for (int r = 0; r < R2; r++) x[r] = cmul(x[r], fl[0][r]);
+                    DftR<R2, 1>::run(x);
 #pragma unroll
-                for (int r = 0; r < R2; r++) p[fpc(r)] = x[r];
+                    for (int r = 0; r < R2; r++) p[fpc(r)] = x[r];
+                }
+            } else {
+#pragma unroll
+                for (int ch = 0; ch < NCH; ch++)
+#pragma unroll
+                    for (int q = 0; q < BPT; q++) {
+                        if ((NB % T) != 0 && tid + q * T >= NB) break;
+                        double2 *p = sm + ch * BS + fpad((tid + q * T) * R2);
+                        double2 x[R2];
+#pragma unroll
+                        for (int r = 0; r < R2; r++) x[r] = p[fpc(r)];
+                        DftR<R2, -1>::run(x);
+#pragma unroll
+                        for (int r = 0; r < R2; r++) x[r] = cmul(x[r], fl[q][r]);
+                        DftR<R2, 1>::run(x);
+#pragma unroll
+                        for (int r = 0; r < R2; r++) p[fpc(r)] = x[r];
+                    }
             }
         }
-        // chirp of the outputs this thread forms in the last pass: j0 + r Q0 < h, r < R0 / 2
-        double2 ob[R0 / 2];
-        {
+        // chirp of the outputs this thread forms in the last pass: j0 + r Q0 < h, r < R0 / 2 (requested two passes ahead;
+        // the radix-32 / 24 kernels have no registers to hold 16 of them across the passes and read them at the store)
+        constexpr bool OB_EARLY = R0 <= 16;
+        double2 ob[OB_EARLY ? R0 / 2 : 1];
+        if constexpr (OB_EARLY) {
             const int j0 = tid & (Q0 - 1);
 #pragma unroll
             for (int r = 0; r < R0 / 2; r++) ob[r] = bch[min(j0 + r * Q0, h - 1)];
@@ -670,7 +776,7 @@ ringfft_blu_ct(const int32_t *__restrict__ ring_list, int nlist, int nside, int 
                     for (int r = 0; r < R0 / 2; r++) {
                         const int jj = j0 + r * Q0;
                         if (jj < h) {
-                            double2 zv = cmul(x[r], ob[r]);
+                            double2 zv = cmul(x[r], OB_EARLY ? ob[OB_EARLY ? r : 0] : bch[jj]);
                             zv.x *= invP;
                             zv.y *= invP;
                             *reinterpret_cast<double2 *>(out + 2 * jj) = zv;
@@ -763,7 +869,18 @@ int sht_ringfft_ct(corahip_ctx *ctx, const corahip_sht_plan *p, const corahip_sh
     } else {
         static const bool no3 = getenv("CORAHIP_K5_NO3") != nullptr;   // diagnostics: power-of-two lengths only
         static const bool half = getenv("CORAHIP_K5_HALF") != nullptr;   // A/B: 256-thread workgroups of one channel, two per CU
-        if (half && c.P3 == 3072 && !no3) rc = launch_blu<3072, 1, 8, 256>(ctx, st, 0, p, c, inter, G, nnu, maps, p->d_blu3_foff, p->d_bfilt3);
+        // (one channel fills the LDS)
+        // Measured at the cfg-5 rank share (128 channels; the generic kernel took 30.6 ms for the two classes): 512 threads
+        // (two waves per SIMD, but the radix-32 / 24 butterflies then spill: 268 / 72 bytes) 16.5 / 10.1 ms, 256 threads
+        // (one wave per SIMD, no spill) 13.8 / 10.8 ms for P = 8192 / 6144: each takes the faster form.
+        // CORAHIP_K5_BIG=256|512 forces one form for both (A/B).
+        static const char *bigenv = getenv("CORAHIP_K5_BIG");
+        const int big = bigenv ? atoi(bigenv) : 0;
+        if (c.P3 == 8192 && big != 512) rc = launch_blu<8192, 1, 16, 256>(ctx, st, 0, p, c, inter, G, nnu, maps, p->d_blu3_foff, p->d_bfilt3);
+        else if (c.P3 == 8192) rc = launch_blu<8192, 1, 8, 512>(ctx, st, 0, p, c, inter, G, nnu, maps, p->d_blu3_foff, p->d_bfilt3);
+        else if (c.P3 == 6144 && big != 256) rc = launch_blu<6144, 1, 8, 512>(ctx, st, 0, p, c, inter, G, nnu, maps, p->d_blu3_foff, p->d_bfilt3);
+        else if (c.P3 == 6144) rc = launch_blu<6144, 1, 16, 256>(ctx, st, 0, p, c, inter, G, nnu, maps, p->d_blu3_foff, p->d_bfilt3);
+        else if (half && c.P3 == 3072 && !no3) rc = launch_blu<3072, 1, 8, 256>(ctx, st, 0, p, c, inter, G, nnu, maps, p->d_blu3_foff, p->d_bfilt3);
         else if (half && c.P3 != 1536 && c.P == 4096) rc = launch_blu<4096, 1, 8, 256>(ctx, st, 0, p, c, inter, G, nnu, maps);
         else if (c.P3 == 3072 && !no3) rc = launch_blu<3072, 2, 4, 512>(ctx, st, 0, p, c, inter, G, nnu, maps, p->d_blu3_foff, p->d_bfilt3);
         else if (c.P3 == 1536 && !no3) rc = launch_blu<1536, 4, 2, 512>(ctx, st, 0, p, c, inter, G, nnu, maps, p->d_blu3_foff, p->d_bfilt3);
@@ -869,6 +986,10 @@ int sht_blu3_tables(corahip_ctx *ctx, corahip_sht_plan *p, int64_t total) {
     }
     BLU3_LAUNCH(1536)
     BLU3_LAUNCH(3072)
+    if (p->nside > 1024) {
+        BLU3_LAUNCH(6144)
+        BLU3_LAUNCH(8192)
+    }
 #undef BLU3_LAUNCH
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     (void)hipFree(d_p3);

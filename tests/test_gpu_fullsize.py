@@ -104,7 +104,9 @@ def test_cfg3_alm2map_pixel_parity_256_channel_launch(ctx):
 
 def test_cfg5_alm2map_pixel_parity(ctx):
     """configs[4] geometry (nside 2048, lmax 4096): an 8-channel launch, channels 0 and 5 against the oracle pixel
-    by pixel; classes here: belt h = 4096 (two channels per workgroup), Bluestein P = 8192 (one channel)."""
+    by pixel; classes here: belt h = 4096 (two channels per workgroup), Bluestein P = 4096 / 3072 (two) and the
+    one-channel compile-time kernels of P = 6144 (24 x 16 x 16) and 8192 (32 x 16 x 16) for the rings 1025 .. 2047; the
+    same launch through the generic run-time kernels must agree."""
     import torch
     from oracle import sht
 
@@ -120,7 +122,7 @@ def test_cfg5_alm2map_pixel_parity(ctx):
     del maps, alm
     torch.cuda.empty_cache()
     print("cfg5 alm2map max|err|/rms per class:", worst)
-    assert set(worst) >= {0, 4096, 8192}, worst
+    assert set(worst) >= {0, 3072, 4096, 6144, 8192}, worst
     # l^2 eps growth of the fp64 three-term recurrence: 4x the cfg-3 bound at lmax = 4096
     assert max(worst.values()) <= 4e-11, worst
 
