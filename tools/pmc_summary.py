@@ -49,7 +49,7 @@ summary = {"tag": tag, "source": "rocprofv3 --pmc passes of `bench.py --steps 1 
            "fetch_correction": "FETCH_SIZE x 2 (gfx950: wide streaming reads are reported at half their bytes, MI355X_MICROARCH.md)",
            "kernels": {}}
 for k in sorted(set(fetch) | set(write)):
-    if not any(s in k for s in ("legendre", "ringfft", "draw", "clarray", "cl_", "chol", "factor", "jacobi")):
+    if not any(s in k for s in ("legendre", "ringfft", "draw", "clarray", "cl_", "chol", "factor", "jacobi", "zig_")):
         continue
     nf = max(1, len(fetch.get(k, {})))
     nw = max(1, len(write.get(k, {})))
@@ -65,4 +65,18 @@ for k in sorted(set(fetch) | set(write)):
         for c in ("SQ_INSTS_VALU_MFMA_F64", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES"):
             e[c + "_per_launch"] = sum(d.get(c, 0.0) for d in sq[k].values()) / n
     summary["kernels"][k] = e
+# cfg-5 rank share: K4 from the SQ pass + the kernel trace of the cfg-5 runs
+sq5, dur5 = counters("cfg5sq1"), durations("cfg5stats")
+for k in sorted(sq5):
+    if "legendre" not in k:
+        continue
+    n = len(sq5[k])
+    ms = sum(dur5.get(k, [0.0])) / max(1, len(dur5.get(k, [])))
+    e = {"avg_ms": ms, "launches_in_pmc_pass": n}
+    for c in ("SQ_INSTS_VALU_MFMA_F64", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES"):
+        e[c + "_per_launch"] = sum(d.get(c, 0.0) for d in sq5[k].values()) / n
+    if ms > 0:
+        e["executed_TFLOPs"] = 2048.0 * e["SQ_INSTS_VALU_MFMA_F64_per_launch"] / (ms * 1e-3) / 1e12
+        e["frac_of_78.6_TF"] = e["executed_TFLOPs"] / 78.6
+    summary.setdefault("cfg5_rank_share", {})[k] = e
 print(json.dumps(summary, indent=1))
