@@ -19,6 +19,7 @@ out_dir, tag = sys.argv[1], sys.argv[2]
 
 
 def short(name):
+    name = name.replace("(anonymous namespace)::", "")
     name = re.sub(r"\(.*$", "", name)
     name = re.sub(r"^void\s+", "", name)
     return name.strip()
