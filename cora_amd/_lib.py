@@ -51,6 +51,7 @@ SIGNATURES = {
     "corahip_normals_philox": (c_int, [c_void_p, c_u64, c_int, c_int, PTR]),
     "corahip_normals_pcg64": (c_int, [c_void_p, ctypes.POINTER(c_u64), ctypes.POINTER(c_u64), ctypes.c_int64, PTR,
                                       ctypes.POINTER(c_u64)]),
+    "corahip_normals_mt19937_legacy": (c_int, [c_void_p, c_void_p, ctypes.c_int64, PTR]),
     "corahip_pcg64_advance": (c_int, [ctypes.POINTER(c_u64), ctypes.POINTER(c_u64), c_u64, ctypes.POINTER(c_u64)]),
     "corahip_draw_alm_philox": (c_int, [c_void_p, PTR, PTR, c_u64, c_int, c_int, c_int, c_int, PTR]),
     "corahip_draw_alm_philox_rows": (c_int, [c_void_p, PTR, PTR, c_u64, c_int, c_int, c_int, c_int, PTR]),
@@ -389,6 +390,29 @@ class Context:
         nraw = c_u64(0)
         _check(self.lib.corahip_normals_pcg64(self.h, st, ic, int(n), self._f64(g), ctypes.byref(nraw)))
         return g, int(nraw.value)
+
+    def normals_legacy(self, state, n, out=None):
+        """The next ``n`` values of numpy's LEGACY stream (``np.random.standard_normal`` / ``RandomState``: MT19937 + polar
+        method) from ``state`` = ``get_state(legacy=False)``, generated on the device; returns (g, state after) with the
+        state as a dict ``set_state`` takes."""
+        import numpy as np
+
+        class MtState(ctypes.Structure):
+            _fields_ = [("key", ctypes.c_uint32 * 624), ("pos", ctypes.c_int32), ("has_gauss", ctypes.c_int32),
+                        ("gauss", c_double)]
+
+        if state["bit_generator"] != "MT19937":
+            raise ValueError("legacy stream on the device: MT19937 only")
+        ms = MtState()
+        key = np.ascontiguousarray(state["state"]["key"], dtype=np.uint32)
+        ctypes.memmove(ms.key, key.ctypes.data, 624 * 4)
+        ms.pos, ms.has_gauss, ms.gauss = int(state["state"]["pos"]), int(state["has_gauss"]), float(state["gauss"])
+        g = out if out is not None else self.empty((n,))
+        assert g.numel() >= n
+        _check(self.lib.corahip_normals_mt19937_legacy(self.h, ctypes.byref(ms), int(n), self._f64(g)))
+        new = {"bit_generator": "MT19937", "state": {"key": np.frombuffer(ms.key, dtype=np.uint32).copy(), "pos": int(ms.pos)},
+               "has_gauss": int(ms.has_gauss), "gauss": float(ms.gauss)}
+        return g, new
 
     def draw_alm(self, T, info, g, lmax, F, nu0=0, nnu=None, out=None):
         nnu = F if nnu is None else nnu

@@ -184,16 +184,43 @@ def _is_pcg64_generator(rng):
     return isinstance(rng, np.random.Generator) and type(rng.bit_generator) is np.random.PCG64
 
 
+def _legacy_state_of(rng):
+    """(get_state, set_state, lock) of a numpy LEGACY generator on MT19937 - ``None`` = the global state behind
+    ``np.random.standard_normal`` (cora/util/nputil.py:121-123), or a ``RandomState`` instance - else None."""
+    import threading
+
+    if rng is None:
+        rs = getattr(np.random.mtrand, "_rand", None)
+        if rs is None or np.random.get_state(legacy=False)["bit_generator"] != "MT19937":
+            return None
+        return np.random.get_state, np.random.set_state, getattr(rs, "_bit_generator", rs).lock if hasattr(
+            getattr(rs, "_bit_generator", rs), "lock") else threading.Lock()
+    if isinstance(rng, np.random.RandomState) and rng.get_state(legacy=False)["bit_generator"] == "MT19937":
+        bg = getattr(rng, "_bit_generator", None)
+        return rng.get_state, rng.set_state, bg.lock if bg is not None and hasattr(bg, "lock") else threading.Lock()
+    return None
+
+
 def stream_normals(ctx, numz, maxl, rng):
     """The normal stream of one realisation in the reference's draw order (:func:`_host_normals`) as a device array.
 
     A ``Generator`` on PCG64 is continued ON THE DEVICE (``corahip_normals_pcg64``: the same PCG64 + ziggurat
     sequence, bit for bit) and left exactly where ``rng.standard_normal`` would have left it: its state is advanced by
-    the number of raw draws the normals consumed.  Any other generator (``rng=None`` = numpy's legacy global MT19937 +
-    polar method, other bit generators) is consumed on the host and uploaded (:func:`_upload_host_normals`)."""
+    the number of raw draws the normals consumed.  ``rng=None`` - numpy's legacy global MT19937 + polar method, what the
+    reference draws from when no generator is passed - and ``RandomState`` instances are continued on the device too
+    (``corahip_normals_mt19937_legacy``: the same accepted attempts and generator state, values within a few ulp).  Any
+    other generator is consumed on the host and uploaded (:func:`_upload_host_normals`)."""
+    n = 2 * numz * ((maxl + 1) * (maxl + 2) // 2)
+    legacy = _legacy_state_of(rng)
+    if legacy is not None:
+        # numpy's legacy stream (MT19937 + polar method): rng=None = the global state, what Sky3d.getsky() draws from
+        get_state, set_state, lock = legacy
+        with lock:
+            g, new = ctx.normals_legacy(get_state(legacy=False), n)
+            set_state(new)
+        return g
     if not _is_pcg64_generator(rng):
         return _upload_host_normals(ctx, numz, maxl, rng)
-    n = 2 * numz * ((maxl + 1) * (maxl + 2) // 2)
     bg = rng.bit_generator
     with bg.lock:                                          # the lock numpy's own draws hold
         st = bg.state

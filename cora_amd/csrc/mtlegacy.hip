@@ -1,0 +1,367 @@
+// mtlegacy.hip - numpy's LEGACY normal stream (np.random.standard_normal, the global MT19937 RandomState) on the device.
+//
+// The reference called without a generator - `Sky3d.getsky()` -> `skysim.mkfullsky(cla, nside)`, cora/core/maps.py:235-237;
+// `rng=None` in cora/util/nputil.py:121-123 - draws its 2 F nalm normals from numpy's global legacy state: MT19937 +
+// Marsaglia's polar method with its one cached value (numpy/random/src/legacy/legacy-distributions.c `legacy_gauss`,
+// numpy/random/src/mt19937/mt19937.c).  ~10 s per cfg-3 realisation on the host.  The same stream here:
+//
+//   uniform   a = next32 >> 5, b = next32 >> 6, (a 2^26 + b) / 2^53                               (exact in fp64)
+//   attempt   x1 = 2 u1 - 1, x2 = 2 u2 - 1, r2 = x1^2 + x2^2; accepted iff 0 < r2 < 1 (pi / 4 of them);
+//             f = sqrt(-2 log(r2) / r2); the normals f x2, then f x1
+// An attempt ALWAYS consumes four 32-bit words: attempt a of a stream sits at words 4 a .. 4 a + 3, whatever happened
+// before - the accept decisions and every x are exact arithmetic on those words, so which attempts are accepted, and
+// with it the generator state afterwards, is numpy's bit for bit; the values go through log / sqrt / two divisions
+// (sqrt and division are correctly rounded here as in libm; log is the device library's, <= 1 ulp: a value may differ
+// from numpy's in its last bits - tests/test_gpu_npnormal.py bounds it at 4 ulp).
+//
+// MT19937 itself is the sequential part: x[k + 624] = x[k + 397] ^ twist(x[k], x[k + 1]).  It is linear over GF(2), so
+// the window J words on is g(T) applied to the window, g = x^J mod phi (phi the minimal polynomial, degree 19937):
+// mt_jump.inc (tools/gen_mt_jump.py: Berlekamp-Massey on numpy's own output, square-and-multiply mod phi, checked
+// against plain stepping; restated in oracle/mtlegacy.py) holds x^(S 2^k - 1) for the segment length S = 2^18 words.
+// The stream is cut into segments of S words = 65536 attempts; the segment start windows come from a doubling tree
+// (level k: segments 2^k .. 2^(k+1) - 1 from segments 0 .. 2^k - 1 with polynomial k: 14 launches at cfg 3), each
+// application = extend the source window by 19938 words in LDS and XOR the windows at the polynomial's set bits.
+// Then one wave per segment: pass 1 counts the accepted attempts, a one-workgroup scan gives every segment its first
+// output position, pass 2 regenerates and writes the normals (an accepted lane writes its pair: consecutive lanes,
+// consecutive addresses).  The wave that meets the last needed attempt writes out the state numpy would be left in:
+// the 624-word block it is in, the position inside it, and the cached second value when an odd count was asked for.
+#include "common.h"
+
+#include <algorithm>
+#include <cmath>
+#include <vector>
+
+#include "mt_jump.inc"
+
+namespace {
+
+constexpr int MTN = 624, MTM = 397;
+constexpr int MT_DEG = 19937;
+constexpr int MT_ATT_BLOCK = MTN / 4;                       // attempts per 624-word block
+constexpr long MT_SEG_WORDS = 1L << MT_SEG_LOG2;
+constexpr long MT_SEG_ATT = MT_SEG_WORDS / 4;               // attempts per segment
+
+__host__ __device__ inline unsigned mt_next(unsigned u, unsigned v, unsigned w) {
+    const unsigned y = (u & 0x80000000u) | (v & 0x7fffffffu);
+    return w ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+}
+__device__ inline unsigned mt_temper(unsigned y) {
+    y ^= y >> 11;
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= y >> 18;
+    return y;
+}
+
+// the next 624 words in place (mt19937_gen), by ONE wave: chunk c = words 64 c .. 64 c + 63.  Word k + 1 is old when
+// it is read (the lanes of a chunk read before they write; the next chunk is untouched), word k + 397 is old for
+// k < 227 and the new word k - 227 of an EARLIER chunk after that: LDS serves a wave's instructions in order.
+__device__ inline void mt_block_next(unsigned *mt, int lane) {
+#pragma unroll
+    for (int c = 0; c < (MTN + 63) / 64; c++) {
+        const int k = 64 * c + lane;
+        if (k < MTN) {
+            const unsigned u = mt[k], v = mt[k + 1 < MTN ? k + 1 : 0], w = mt[k + MTM < MTN ? k + MTM : k + MTM - MTN];
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            mt[k] = mt_next(u, v, w);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+struct mt_status {
+    unsigned key[MTN];          // the block the generator is left in
+    int pos, has_gauss;
+    double gauss;
+    unsigned long long total_accepted;
+    int done, pad;
+};
+
+// ---- jump: dst windows from src windows, one workgroup per application ---------------------------------------------
+// xs = the source window and the 19938 words that follow it (wave 0 steps the recurrence, 64 words at a time: word
+// 624 + k needs words k, k + 1 and k + 397, the last one at least 227 words back); meanwhile the other waves expand the
+// polynomial's bit mask into the list of its set positions (LDS).  Then out[w] = xor over the list of xs[i + 1 + w]:
+// 16 list entries per round, all their reads in flight together (one LDS round trip per BIT was 64 ms at cfg 3).
+#define MT_JUMP_T 256
+#define MT_JUMP_XS (MTN + MT_DEG + 1 + 64 + MTM + 8)
+__global__ void __launch_bounds__(MT_JUMP_T)
+mt_jump_kernel(unsigned *__restrict__ seg_state, long src0, long dst0, long count, int k) {
+    extern __shared__ unsigned xs[];                          // [MT_JUMP_XS] words, then the position list (u16)
+    __shared__ unsigned short wcnt[MTN + 1];
+    __shared__ unsigned npos_s;
+    unsigned short *plist = reinterpret_cast<unsigned short *>(xs + MT_JUMP_XS);
+    const long a = blockIdx.x;
+    if (a >= count) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const unsigned *src = seg_state + (src0 + a) * MTN;
+    const unsigned *g = MT_JUMP[k];
+    for (int i = tid; i < MTN; i += MT_JUMP_T) {
+        xs[i] = src[i];
+        wcnt[i] = (unsigned short)__builtin_popcount(g[i]);
+    }
+    __syncthreads();
+    if (tid < 64) {
+        for (int k0 = 0; k0 < MT_DEG + 1; k0 += 64) {
+            const int kk = k0 + lane;
+            const unsigned nw = mt_next(xs[kk], xs[kk + 1], xs[kk + MTM]);
+            if (kk < MT_DEG + 1) xs[MTN + kk] = nw;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+        }
+    } else if (tid == 64) {
+        unsigned run = 0;                                     // exclusive prefix of the per-word bit counts
+        for (int i = 0; i < MTN; i++) {
+            const unsigned c = wcnt[i];
+            wcnt[i] = (unsigned short)run;
+            run += c;
+        }
+        npos_s = run;
+    }
+    __syncthreads();
+    for (int i = tid; i < MTN; i += MT_JUMP_T) {
+        unsigned m = g[i];
+        unsigned o = wcnt[i];
+        while (m) {
+            plist[o++] = (unsigned short)(32 * i + __builtin_ctz(m) + 1);
+            m &= m - 1;
+        }
+    }
+    __syncthreads();
+    const int npos = (int)npos_s;
+    constexpr int NQ = (MTN + MT_JUMP_T - 1) / MT_JUMP_T;
+    unsigned acc[NQ] = {};
+    const bool last_ok = tid + (NQ - 1) * MT_JUMP_T < MTN;
+    int p = 0;
+    for (; p + 16 <= npos; p += 16) {
+        unsigned v[16][NQ];
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+            const int i = plist[p + e];
+#pragma unroll
+            for (int q = 0; q < NQ; q++) v[e][q] = xs[i + tid + q * MT_JUMP_T];     // (q = NQ - 1 may read past word 623 of the window: inside xs, discarded)
+        }
+#pragma unroll
+        for (int e = 0; e < 16; e++)
+#pragma unroll
+            for (int q = 0; q < NQ; q++) acc[q] ^= v[e][q];
+    }
+    for (; p < npos; p++) {
+        const int i = plist[p];
+#pragma unroll
+        for (int q = 0; q < NQ; q++) acc[q] ^= xs[i + tid + q * MT_JUMP_T];
+    }
+    unsigned *dst = seg_state + (dst0 + a) * MTN;
+#pragma unroll
+    for (int q = 0; q < NQ; q++) {
+        const int w = tid + q * MT_JUMP_T;
+        if (w < MTN && (q < NQ - 1 || last_ok)) dst[w] = acc[q];
+    }
+}
+
+// ---- one attempt of the polar method from four words of the block --------------------------------------------------
+struct mt_attempt {
+    double x1, x2, r2;
+    bool ok;
+};
+__device__ inline mt_attempt mt_try(const unsigned *mt, int a) {
+#pragma clang fp contract(off)
+    const uint4 w = *reinterpret_cast<const uint4 *>(mt + 4 * a);
+    const double u1 = ((double)(mt_temper(w.x) >> 5) * 67108864.0 + (double)(mt_temper(w.y) >> 6)) / 9007199254740992.0;
+    const double u2 = ((double)(mt_temper(w.z) >> 5) * 67108864.0 + (double)(mt_temper(w.w) >> 6)) / 9007199254740992.0;
+    mt_attempt t;
+    t.x1 = 2.0 * u1 - 1.0;
+    t.x2 = 2.0 * u2 - 1.0;
+    t.r2 = t.x1 * t.x1 + t.x2 * t.x2;
+    t.ok = !(t.r2 >= 1.0 || t.r2 == 0.0);
+    return t;
+}
+
+#define MT_WG 256
+// pass 1 / pass 2 over the segments, one wave each.  EMIT = false: seg_cnt[j] = accepted attempts of segment j.
+// EMIT = true: the normals of the accepted attempts at g[2 (base + rank)], g[.. + 1] while below `need`, and the state
+// after the attempt that yields normal number `need`.
+template <bool EMIT>
+__global__ void __launch_bounds__(MT_WG)
+mt_segment_kernel(const unsigned *__restrict__ seg_state, long nseg, unsigned *__restrict__ seg_cnt,
+                  const unsigned long long *__restrict__ seg_base, unsigned long long need, double *__restrict__ g,
+                  mt_status *st) {
+#pragma clang fp contract(off)
+    __shared__ __attribute__((aligned(16))) unsigned blk[MT_WG / 64][MTN + 8];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const long j = (long)blockIdx.x * (MT_WG / 64) + wv;
+    if (j >= nseg) return;
+    unsigned *mt = blk[wv];
+    const bool al16 = (reinterpret_cast<size_t>(g) & 15) == 0;
+    const unsigned long long pairs = (need + 1) / 2;          // accepted attempts that are needed
+    unsigned long long ord = EMIT ? seg_base[j] : 0ull;       // accepted attempts before the next one
+    if (EMIT && ord >= pairs) return;
+    for (int i = lane; i < MTN; i += 64) mt[i] = seg_state[j * MTN + i];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    unsigned cnt = 0;
+    for (long a0 = 0; a0 < MT_SEG_ATT; a0 += MT_ATT_BLOCK) {
+        const int nb = (int)std::min<long>(MT_ATT_BLOCK, MT_SEG_ATT - a0);      // attempts of this block that belong to the segment
+#pragma unroll
+        for (int r = 0; r < (MT_ATT_BLOCK + 63) / 64; r++) {
+            const int a = 64 * r + lane;
+            const bool in = a < nb;
+            mt_attempt t;
+            t.ok = false;
+            if (in) t = mt_try(mt, a);
+            const unsigned long long acc = __ballot(in && t.ok);
+            if constexpr (EMIT) {
+                if (in && t.ok) {
+                    const unsigned long long o = ord + __builtin_amdgcn_mbcnt_hi((unsigned)(acc >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)acc, 0u));
+                    if (o < pairs) {
+                        const double f = sqrt(-2.0 * log(t.r2) / t.r2);
+                        const double first = f * t.x2, second = f * t.x1;
+                        if (2 * o + 1 < need) {
+                            if (al16) *reinterpret_cast<double2 *>(g + 2 * o) = make_double2(first, second);
+                            else {                 // (a pair behind an odd offset - the cached value came first - is not 16-byte aligned)
+                                g[2 * o] = first;
+                                g[2 * o + 1] = second;
+                            }
+                        } else g[2 * o] = first;
+                        if (o + 1 == pairs) {
+                            // the generator after this attempt: inside this block, behind the attempt's four words; the
+                            // second value stays cached when an odd number of normals was asked for
+                            st->pos = 4 * (a + 1);
+                            st->has_gauss = (need & 1ull) ? 1 : 0;
+                            st->gauss = (need & 1ull) ? second : 0.0;
+                            st->done = 1;
+                        }
+                    }
+                }
+                const unsigned long long nacc = __builtin_popcountll(acc);
+                if (ord < pairs && ord + nacc >= pairs) {
+                    // (wave-uniform) this block holds the last needed attempt: it is the key numpy is left with
+                    for (int i = lane; i < MTN; i += 64) st->key[i] = mt[i];
+                }
+                ord += nacc;
+            } else {
+                cnt += (unsigned)__builtin_popcountll(acc);
+            }
+        }
+        if (EMIT && ord >= pairs) return;
+        mt_block_next(mt, lane);
+    }
+    if (!EMIT && lane == 0) seg_cnt[j] = cnt;
+}
+
+// one workgroup: first accepted-attempt ordinal of every segment
+__global__ void __launch_bounds__(1024)
+mt_scan_kernel(long nseg, const unsigned *__restrict__ seg_cnt, unsigned long long *__restrict__ seg_base, mt_status *st) {
+    __shared__ unsigned long long part[1024];
+    const int t = threadIdx.x;
+    const long per = (nseg + 1023) / 1024;
+    const long a = std::min<long>(nseg, t * per), b = std::min<long>(nseg, a + per);
+    unsigned long long s = 0;
+    for (long i = a; i < b; i++) s += seg_cnt[i];
+    part[t] = s;
+    __syncthreads();
+    if (t == 0) {
+        unsigned long long run = 0;
+        for (int i = 0; i < 1024; i++) {
+            const unsigned long long v = part[i];
+            part[i] = run;
+            run += v;
+        }
+        st->total_accepted = run;
+    }
+    __syncthreads();
+    s = part[t];
+    for (long i = a; i < b; i++) {
+        seg_base[i] = s;
+        s += seg_cnt[i];
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int corahip_normals_mt19937_legacy(corahip_ctx *ctx, corahip_mt_state *state, int64_t n, double *g) {
+    ARG_CHECK(ctx != nullptr && state != nullptr && n >= 0 && (n == 0 || g != nullptr));
+    ARG_CHECK(state->pos >= 0 && state->pos <= MTN);
+    if (n == 0) return 0;
+    StageTimer timer(ctx, "normals_legacy");
+    int64_t off0 = 0;
+    if (state->has_gauss) {                    // the value legacy_gauss kept from its last pair comes first
+        HIP_TRY(hipMemcpyAsync(g, &state->gauss, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        state->has_gauss = 0;
+        state->gauss = 0.0;
+        off0 = 1;
+        if (n == 1) return 0;
+    }
+    const unsigned long long need = (unsigned long long)(n - off0);
+    // attempts to look at: need / 2 accepted ones at an acceptance of pi / 4, + 2 % and a floor (the count of accepted
+    // attempts among N has a relative sigma of 0.5 / sqrt(N))
+    const unsigned long long pairs = (need + 1) / 2;
+    const long double want = (long double)pairs / 0.78539816339744830962L;
+    const long natt = (long)(want * 1.02L) + 8192;
+    const long nseg = (natt + MT_SEG_ATT - 1) / MT_SEG_ATT;
+    int levels = 0;
+    while ((1L << levels) < nseg) levels++;
+    if (levels > MT_NPOLY) {
+        corahip_set_error("normals_mt19937_legacy: %lld normals need %ld segments, the jump table holds %d levels", (long long)n, nseg,
+                          MT_NPOLY);
+        return CORAHIP_EINVAL;
+    }
+    // the window at the generator's position: x[pos .. pos + 623] (host: at most 624 steps)
+    std::vector<unsigned> x(state->key, state->key + MTN);
+    x.resize(MTN + state->pos);
+    for (int k = 0; k < state->pos; k++) x[MTN + k] = mt_next(x[k], x[k + 1], x[k + MTM]);
+    const size_t off_cnt = sizeof(unsigned) * MTN * (size_t)nseg;
+    const size_t off_base = (off_cnt + sizeof(unsigned) * (size_t)nseg + 15) & ~(size_t)15;
+    const size_t off_st = off_base + sizeof(unsigned long long) * (size_t)nseg;
+    char *ws = nullptr;
+    int rc = corahip_ctx_scratch(ctx, 6, off_st + sizeof(mt_status), (void **)&ws);
+    if (rc) return rc;
+    unsigned *seg_state = (unsigned *)ws;
+    unsigned *seg_cnt = (unsigned *)(ws + off_cnt);
+    unsigned long long *seg_base = (unsigned long long *)(ws + off_base);
+    mt_status *st = (mt_status *)(ws + off_st);
+    HIP_TRY(hipMemsetAsync(st, 0, sizeof(mt_status), ctx->stream));
+    HIP_TRY(hipMemcpyAsync(seg_state, x.data() + state->pos, sizeof(unsigned) * MTN, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));           // (x is a local)
+    {
+        StageTimer t0(ctx, "mt_jump");
+        const size_t shm = sizeof(unsigned) * MT_JUMP_XS + sizeof(unsigned short) * (MT_DEG + 8);
+        HIP_TRY(hipFuncSetAttribute((const void *)mt_jump_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+        for (int k = 0; (1L << k) < nseg; k++) {
+            const long have = 1L << k, count = std::min<long>(have, nseg - have);
+            mt_jump_kernel<<<(unsigned)count, MT_JUMP_T, shm, ctx->stream>>>(seg_state, 0, have, count, k);
+            LAUNCH_CHECK();
+        }
+    }
+    const unsigned grid = (unsigned)((nseg + MT_WG / 64 - 1) / (MT_WG / 64));
+    {
+        StageTimer t1(ctx, "mt_count");
+        mt_segment_kernel<false><<<grid, MT_WG, 0, ctx->stream>>>(seg_state, nseg, seg_cnt, seg_base, need, g + off0, st);
+        LAUNCH_CHECK();
+        mt_scan_kernel<<<1, 1024, 0, ctx->stream>>>(nseg, seg_cnt, seg_base, st);
+        LAUNCH_CHECK();
+    }
+    {
+        StageTimer t2(ctx, "mt_emit");
+        mt_segment_kernel<true><<<grid, MT_WG, 0, ctx->stream>>>(seg_state, nseg, seg_cnt, seg_base, need, g + off0, st);
+        LAUNCH_CHECK();
+    }
+    mt_status hs;
+    HIP_TRY(hipMemcpyAsync(&hs, st, sizeof(hs), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (!hs.done || hs.total_accepted < pairs) {
+        corahip_set_error("normals_mt19937_legacy: %llu accepted attempts in %ld segments, %llu needed", hs.total_accepted, nseg, pairs);
+        return CORAHIP_ESTATE;
+    }
+    std::copy(hs.key, hs.key + MTN, state->key);
+    state->pos = hs.pos;
+    state->has_gauss = hs.has_gauss;
+    state->gauss = hs.gauss;
+    return 0;
+}
+
+}  // extern "C"

@@ -32,7 +32,7 @@ extern "C" {
 #endif
 
 #define CORAHIP_ABI_VERSION 1
-#define CORAHIP_ABI_MINOR 1      /* additions since version 1: 1 = normals_pcg64, pcg64_advance, draw_alm_rows, mkfullsky, mkfullsky_workspace_bytes, abi_minor */
+#define CORAHIP_ABI_MINOR 1      /* additions since version 1: 1 = normals_pcg64, pcg64_advance, draw_alm_rows, mkfullsky, mkfullsky_workspace_bytes, abi_minor, normals_mt19937_legacy */
 
 #define CORAHIP_EINVAL (-1)   /* bad argument / shape */
 #define CORAHIP_ENOMEM (-2)   /* workspace too small / allocation refused */
@@ -168,6 +168,22 @@ int corahip_normals_pcg64(corahip_ctx *ctx, const uint64_t host_state[2], const 
 /* host arithmetic: the PCG64 state after `delta` steps (numpy's bit_generator.advance) */
 int corahip_pcg64_advance(const uint64_t host_state[2], const uint64_t host_inc[2], uint64_t delta,
                           uint64_t host_out_state[2]);
+
+/* numpy's LEGACY normal stream on the device: the next n values of np.random.standard_normal - what the reference
+ * draws when it is called WITHOUT a generator (rng=None in cora/util/nputil.py:121-123; Sky3d.getsky(),
+ * cora/core/maps.py:235-237): the global MT19937 state + the polar method of numpy's legacy_gauss with its one cached
+ * value.  host_state: np.random.get_state(legacy=False) as a struct - key (624 words), pos, has_gauss, gauss - in; the
+ * state numpy would be left in out (an equivalent (key, pos) pair: the 624-word block the generator is in and the
+ * position inside it).  Which attempts of the polar method are accepted - and with it the state - is numpy's exactly;
+ * the values pass through log / sqrt / two divisions and may differ from numpy's in the last bits (<= 4 ulp).
+ * Synchronises the context's stream.  Algorithm: csrc/mtlegacy.hip (MT19937 cut into segments by jump-ahead polynomials
+ * over GF(2), csrc/mt_jump.inc); restated in oracle/mtlegacy.py. */
+typedef struct corahip_mt_state {
+    uint32_t key[624];
+    int32_t pos, has_gauss;
+    double gauss;
+} corahip_mt_state;
+int corahip_normals_mt19937_legacy(corahip_ctx *ctx, corahip_mt_state *host_state, int64_t n, double *g);
 
 /* a_lm(nu) = sum_nu' T_l[nu,nu'] g_lm(nu')  (skysim.py:121) for channels nu0 <= nu < nu0+nnu.
  *   T [lmax+1, F, F], info [lmax+1] (from factor_batched; NULL = treat all as dense),
