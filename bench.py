@@ -228,7 +228,7 @@ def main():
     # the REFERENCE's seeded call (rng = numpy Generator, cora/core/skysim.py:72,120; cora/signal/lss.py:449-450): the same
     # cold step with numpy's PCG64 + ziggurat stream generated on the device (bit-identical to numpy, the generator left
     # where numpy would leave it) instead of the library's Philox stream; and the legacy mode (rng=None: numpy's global
-    # MT19937 + polar method), whose normals are host-generated - measured on a bounded sample and extrapolated
+    # MT19937 + polar method, what Sky3d.getsky() draws from), generated on the device as well
     seeded_numpy = legacy_rng = None
     if rank == 0 and world == 1 and args.emulate_shard <= 1 and len(comps) == 1 and not (args.no_seeded_modes or args.checksum):
         seeded_numpy, legacy_rng = seeded_modes(ctx, shard, cold_factors, F, lmax, barrier, args.steps)
@@ -438,10 +438,9 @@ def seeded_modes(ctx, shard, cold_factors, F, lmax, barrier, steps):
 
     seeded_numpy_mode: HBM-resident ms per COLD step when the caller passes ``rng = numpy.random.default_rng(seed)`` as
     cora's callers do - the normals are numpy's own PCG64 + ziggurat sequence, generated on the device.
-    legacy_rng_mode: ``rng=None`` (numpy's global MT19937 + polar method, cora/util/nputil.py:121-123) - that stream is
-    generated by numpy on the host; its rate is measured on a bounded sample (3e7 normals) and the step time is that
-    extrapolated to the 2 F nalm normals of a realisation (the upload overlaps the generation; the device part of the
-    step is the measured seeded step without its generator)."""
+    legacy_rng_mode: the same with ``rng=None`` (numpy's global MT19937 + polar method, cora/util/nputil.py:121-123;
+    ``Sky3d.getsky()``'s default) - since round 4 also continued on the device; numpy's own rate on the host (1e7
+    normals timed) is reported beside it."""
     import torch
 
     nrep = max(1, min(3, steps))
@@ -465,17 +464,32 @@ def seeded_modes(ctx, shard, cold_factors, F, lmax, barrier, steps):
     seeded = {"ms_per_step": ms, "maps_per_s": F / (ms * 1e-3), "stages_ms": st, "normals_per_step": nnorm,
               "rng": "numpy.random.default_rng(seed): PCG64 + ziggurat standard_normal continued on the device "
                      "(corahip_normals_pcg64), bit-identical to numpy; the Generator's state is advanced as numpy would"}
-    nsample = 30_000_000
+    # rng=None: numpy's legacy global state, continued on the device (corahip_normals_mt19937_legacy)
     np.random.seed(12345)
+    shard.realise_numpy(None, cold_factors())
+    barrier()
+    ctx.profile_reset()
+    ctx.profile_enable(True)
+    t0 = time.time()
+    for _ in range(nrep):
+        shard.realise_numpy(None, cold_factors())
+    barrier()
+    lms = (time.time() - t0) / nrep * 1e3
+    ctx.profile_enable(False)
+    lst = {}
+    for name in ("normals_legacy", "mt_jump", "mt_count", "mt_emit", "draw"):
+        t, n = ctx.profile_get(name)
+        if n:
+            lst[name] = round(t / nrep, 3)
+    nsample = 10_000_000
     t0 = time.time()
     np.random.standard_normal(nsample)
     rate = nsample / (time.time() - t0)
-    host_s = nnorm / rate
-    dev_ms = ms - st.get("normals_pcg64", 0.0)
-    legacy = {"ms_per_step_estimated": max(host_s * 1e3, dev_ms) + 0.0, "maps_per_s_estimated": F / max(host_s, dev_ms * 1e-3),
-              "host_normals_per_s": rate, "host_generation_s_per_step": host_s, "sample": "%d legacy normals timed, scaled to %d" % (nsample, nnorm),
-              "rng": "rng=None: numpy's legacy global MT19937 + polar method, generated on the host in the reference's order "
-                     "and uploaded through pinned staging (skysim._upload_host_normals); single thread, as numpy"}
+    legacy = {"ms_per_step": lms, "maps_per_s": F / (lms * 1e-3), "stages_ms": lst,
+              "rng": "rng=None: numpy's legacy global MT19937 + polar method (what Sky3d.getsky() draws from), continued on the "
+                     "device: MT19937 cut into segments by GF(2) jump-ahead polynomials; same accepted attempts and generator "
+                     "state as numpy, values within 4 ulp",
+              "host_numpy_would_take_s": nnorm / rate, "host_normals_per_s": rate}
     torch.cuda.synchronize()
     return seeded, legacy
 

@@ -17,10 +17,12 @@
 // MT19937 itself is the sequential part: x[k + 624] = x[k + 397] ^ twist(x[k], x[k + 1]).  It is linear over GF(2), so
 // the window J words on is g(T) applied to the window, g = x^J mod phi (phi the minimal polynomial, degree 19937):
 // mt_jump.inc (tools/gen_mt_jump.py: Berlekamp-Massey on numpy's own output, square-and-multiply mod phi, checked
-// against plain stepping; restated in oracle/mtlegacy.py) holds x^(S 2^k - 1) for the segment length S = 2^18 words.
-// The stream is cut into segments of S words = 65536 attempts; the segment start windows come from a doubling tree
-// (level k: segments 2^k .. 2^(k+1) - 1 from segments 0 .. 2^k - 1 with polynomial k: 14 launches at cfg 3), each
-// application = extend the source window by 19938 words in LDS and XOR the windows at the polynomial's set bits.
+// against plain stepping; restated in oracle/mtlegacy.py) holds x^(S 2^k - 1) for the segment length S = 2^20 words.
+// The stream is cut into segments of S words = 262144 attempts; the segment start windows come from a doubling tree
+// (level k: segments 2^k .. 2^(k+1) - 1 from segments 0 .. 2^k - 1 with polynomial k: 12 launches at cfg 3), each
+// application = extend the source window by 19938 words in LDS and XOR the windows at the polynomial's ~10^4 set bits
+// (6e6 word operations: with S = 2^18 the tree was 10.9 of 19.6 ms, with 2^20 it is 4.0 of 15.3 - fewer, longer
+// segments cost the two passes 2.6 ms of occupancy).
 // Then one wave per segment: pass 1 counts the accepted attempts, a one-workgroup scan gives every segment its first
 // output position, pass 2 regenerates and writes the normals (an accepted lane writes its pair: consecutive lanes,
 // consecutive addresses).  The wave that meets the last needed attempt writes out the state numpy would be left in:
@@ -53,18 +55,29 @@ __device__ inline unsigned mt_temper(unsigned y) {
     return y;
 }
 
-// the next 624 words in place (mt19937_gen), by ONE wave: chunk c = words 64 c .. 64 c + 63.  Word k + 1 is old when
-// it is read (the lanes of a chunk read before they write; the next chunk is untouched), word k + 397 is old for
-// k < 227 and the new word k - 227 of an EARLIER chunk after that: LDS serves a wave's instructions in order.
+// the next 624 words in place (mt19937_gen), by ONE wave, in three phases of <= 227 words: within a phase every word
+// needs only OLD words (k, k + 1, and k + 397 for k < 227) or words of an EARLIER phase (k - 227), so all reads of a
+// phase go out together, then all its writes - three LDS round trips per block (64 words at a time took ten).  Word 623
+// takes the NEW word 0 as its k + 1.
 __device__ inline void mt_block_next(unsigned *mt, int lane) {
 #pragma unroll
-    for (int c = 0; c < (MTN + 63) / 64; c++) {
-        const int k = 64 * c + lane;
-        if (k < MTN) {
-            const unsigned u = mt[k], v = mt[k + 1 < MTN ? k + 1 : 0], w = mt[k + MTM < MTN ? k + MTM : k + MTM - MTN];
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-            __builtin_amdgcn_wave_barrier();
-            mt[k] = mt_next(u, v, w);
+    for (int ph = 0; ph < 3; ph++) {
+        const int k0 = 227 * ph, k1 = ph == 2 ? MTN : 227 * (ph + 1);
+        unsigned nw[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const int k = k0 + 64 * c + lane;
+            if (k < k1) {
+                const unsigned u = mt[k], v = mt[k + 1 < MTN ? k + 1 : 0], w = mt[k + MTM < MTN ? k + MTM : k + MTM - MTN];
+                nw[c] = mt_next(u, v, w);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const int k = k0 + 64 * c + lane;
+            if (k < k1) mt[k] = nw[c];
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         __builtin_amdgcn_wave_barrier();
@@ -85,7 +98,7 @@ struct mt_status {
 // polynomial's bit mask into the list of its set positions (LDS).  Then out[w] = xor over the list of xs[i + 1 + w]:
 // 16 list entries per round, all their reads in flight together (one LDS round trip per BIT was 64 ms at cfg 3).
 #define MT_JUMP_T 256
-#define MT_JUMP_XS (MTN + MT_DEG + 1 + 64 + MTM + 8)
+#define MT_JUMP_XS (MTN + MT_DEG + 1 + 256 + MTM + 8)
 __global__ void __launch_bounds__(MT_JUMP_T)
 mt_jump_kernel(unsigned *__restrict__ seg_state, long src0, long dst0, long count, int k) {
     extern __shared__ unsigned xs[];                          // [MT_JUMP_XS] words, then the position list (u16)
@@ -103,10 +116,22 @@ mt_jump_kernel(unsigned *__restrict__ seg_state, long src0, long dst0, long coun
     }
     __syncthreads();
     if (tid < 64) {
-        for (int k0 = 0; k0 < MT_DEG + 1; k0 += 64) {
-            const int kk = k0 + lane;
-            const unsigned nw = mt_next(xs[kk], xs[kk + 1], xs[kk + MTM]);
-            if (kk < MT_DEG + 1) xs[MTN + kk] = nw;
+        // 227 words per step (four reads-then-writes of 64): word 624 + k needs words k, k + 1 and k + 397, the last at
+        // least 227 words back, i.e. of an earlier step
+        for (int k0 = 0; k0 < MT_DEG + 1; k0 += 227) {
+            unsigned nw[4];
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const int kk = k0 + 64 * c + lane;
+                nw[c] = mt_next(xs[kk], xs[kk + 1], xs[kk + MTM]);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const int kk = k0 + 64 * c + lane;
+                if (64 * c + lane < 227 && kk < MT_DEG + 1) xs[MTN + kk] = nw[c];
+            }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
             __builtin_amdgcn_wave_barrier();
         }

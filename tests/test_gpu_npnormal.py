@@ -72,8 +72,8 @@ def test_stream_normals_order_and_generator_state(ctx, F, lmax):
 
 
 def test_other_generators_are_consumed_on_the_host(ctx, monkeypatch):
-    """Only Generator(PCG64) is continued on the device; the legacy global state (rng=None), other bit generators and
-    RandomState objects keep the host path (same values as the reference draws)."""
+    """Generator(PCG64) and the legacy MT19937 state (rng=None, RandomState) are continued on the device; a Generator on
+    any other bit generator keeps the host path (same values as the reference draws)."""
     from cora_amd.core import skysim
 
     def boom(*a, **k):
@@ -84,10 +84,6 @@ def test_other_generators_are_consumed_on_the_host(ctx, monkeypatch):
     for make in (lambda: np.random.Generator(np.random.MT19937(5)), lambda: np.random.Generator(np.random.PCG64DXSM(5)),
                  lambda: np.random.Generator(np.random.Philox(5))):
         assert np.array_equal(skysim.stream_normals(ctx, F, lmax, make()).cpu().numpy(), skysim._host_normals(F, lmax, make()))
-    np.random.seed(99)
-    g = skysim.stream_normals(ctx, F, lmax, None).cpu().numpy()
-    np.random.seed(99)
-    assert np.array_equal(g, skysim._host_normals(F, lmax, None))
 
 
 @pytest.mark.parametrize("key,cl,seed,nside", [("alm_21cm_F4_l16_seed3", "cla_21cm_F4_l16_zromb1", 3, 8),
@@ -152,3 +148,76 @@ def skysim_host_normals(F, lmax, rng):
     from cora_amd.core import skysim
 
     return skysim._host_normals(F, lmax, rng)
+
+
+# ------------------------------------------------------------------ numpy's LEGACY stream (rng=None) on the device
+def _ulps(a, b):
+    return np.abs(a.view(np.int64) - b.view(np.int64))
+
+
+@pytest.mark.parametrize("n,skip", [(1, 0), (2, 3), (3, 1001), (311, 1), (312, 2), (313, 77), (262143, 0), (524289, 5),
+                                    (2_100_000, 11)])
+def test_legacy_device_stream_is_numpys(ctx, n, skip):
+    """corahip_normals_mt19937_legacy against numpy's RandomState from a state with an arbitrary position and a cached
+    value: every value within 4 ulp (log is the device library's; the rest is exact or correctly rounded), most of them
+    bit-identical, and the generator state afterwards equivalent to numpy's - the next uniforms AND normals agree.
+    Sizes around the 156-attempt block and the 262144-attempt segment (jump-ahead polynomial) boundaries."""
+    rs = np.random.RandomState(9000 + n % 1000)
+    rs.standard_normal(skip)
+    st = rs.get_state(legacy=False)
+    g, new = ctx.normals_legacy(st, n)
+    dev = g.cpu().numpy()
+    ref = rs.standard_normal(n)
+    d = _ulps(dev, ref)
+    assert d.max() <= 4, (n, skip, int(d.max()))
+    assert (d == 0).mean() > 0.95 or n < 50
+    twin = np.random.RandomState(0)
+    twin.set_state(new)
+    assert np.array_equal(twin.random_sample(1500), rs.random_sample(1500))
+    assert _ulps(twin.standard_normal(7), rs.standard_normal(7)).max() == 0
+
+
+def test_legacy_device_stream_3e7(ctx):
+    """3e7 normals = 73 segments (the doubling tree of jump polynomials, seven levels): values within 4 ulp of numpy,
+    the same accepted attempts (an ordinal shift would show as O(1) errors), the state equivalent afterwards."""
+    rs = np.random.RandomState(31)
+    rs.standard_normal(1)                                  # leaves a cached value
+    st = rs.get_state(legacy=False)
+    n = 30_000_001
+    g, new = ctx.normals_legacy(st, n)
+    ref = rs.standard_normal(n)
+    d = _ulps(g.cpu().numpy(), ref)
+    assert d.max() <= 4 and (d == 0).mean() > 0.98
+    twin = np.random.RandomState(0)
+    twin.set_state(new)
+    assert twin.get_state(legacy=False)["has_gauss"] == rs.get_state(legacy=False)["has_gauss"]
+    assert np.array_equal(twin.random_sample(3000), rs.random_sample(3000))
+
+
+def test_mkfullsky_without_a_generator_draws_on_the_device(ctx, golden, monkeypatch):
+    """rng=None - what Sky3d.getsky() does (cora/core/maps.py:235-237) - reproduces the reference's own legacy-seeded
+    a_lm golden with NO normal generated on the host, and np.random is left where the reference leaves it."""
+    from cora_amd.core import skysim
+
+    def boom(*a, **k):
+        raise AssertionError("host normal stream used for the legacy global state")
+
+    monkeypatch.setattr(skysim, "_upload_host_normals", boom)
+    monkeypatch.setattr(skysim, "_host_normals", boom)
+    C = golden["cla_21cm_F4_l16_zromb1"]
+    np.random.seed(1234)
+    a = skysim.mkfullsky(C, 8, alms=True)
+    ref = golden["alm_21cm_F4_l16_legacy1234"]
+    assert np.abs(a - ref).max() <= 1e-12 * np.abs(ref).max()
+    after = np.random.random_sample(100)
+    np.random.seed(1234)
+    for l in range(C.shape[0]):
+        np.random.standard_normal((C.shape[1], l + 1))
+        np.random.standard_normal((C.shape[1], l + 1))
+    assert np.array_equal(after, np.random.random_sample(100))
+    # a RandomState instance is the same legacy generator
+    rs, twin = np.random.RandomState(5), np.random.RandomState(5)
+    g = skysim.stream_normals(ctx, 6, 20, rs).cpu().numpy()
+    monkeypatch.undo()
+    assert _ulps(g, skysim._host_normals(6, 20, twin)).max() <= 4
+    assert np.array_equal(rs.random_sample(50), twin.random_sample(50))

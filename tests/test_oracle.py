@@ -608,3 +608,64 @@ def test_pcg64_advance_abi_is_numpys_advance():
             bg = np.random.PCG64(seed)
             bg.advance(d)
             assert _lib.pcg64_advance(s, inc, d) == o.state_of(bg)[0] == o.advance(s, inc, d)
+
+
+# ------------------------------------------------------------------ numpy's LEGACY normal stream (oracle/mtlegacy.py)
+@pytest.mark.parametrize("seed", [1234, 7])
+def test_legacy_oracle_is_numpys_stream(seed):
+    """MT19937 + tempering + the polar method with its cached value, restated, equals np.random.standard_normal bit
+    for bit and leaves the same global state (key, pos, has_gauss, gauss)."""
+    from oracle import mtlegacy as m
+
+    np.random.seed(seed)
+    ls = m.LegacyStream()
+    ref = np.random.standard_normal(3001)
+    got = ls.standard_normal(3001)
+    assert np.array_equal(got.view(np.uint64), ref.view(np.uint64))
+    st = np.random.get_state(legacy=False)
+    assert list(st["state"]["key"]) == ls.key and st["state"]["pos"] == ls.pos
+    assert st["has_gauss"] == ls.has_gauss == 1 and st["gauss"] == ls.gauss
+
+
+def test_mt19937_jump_polynomials():
+    """The minimal polynomial of MT19937 (Berlekamp-Massey on numpy's output: degree 19937, 135 terms) annihilates the
+    output bits of another seed, x^J mod phi applied to a window equals plain stepping, and the first entries of the
+    generated table the kernels use (cora_amd/csrc/mt_jump.inc) are x^(S 2^k - 1) mod phi."""
+    import os
+    import re
+
+    from oracle import mtlegacy as m
+
+    phi = m.minimal_polynomial()
+    assert phi.bit_length() - 1 == m.DEG and bin(phi).count("1") == 135
+    w = np.random.RandomState(99).randint(0, 2**32, size=2 * m.DEG + 300, dtype=np.uint64)
+    bits = 0
+    for i, v in enumerate(w):
+        bits |= ((int(v) >> 7) & 1) << i
+    for t0 in (0, 17, m.DEG + 100):
+        assert bin((bits >> t0) & phi).count("1") % 2 == 0
+    np.random.seed(1234)
+    key = [int(v) for v in np.random.get_state(legacy=False)["state"]["key"]]
+    J = 70000
+    g1 = m.x_pow_mod(J - 1, phi)
+    x = m.extend(key, m.DEG + 1)
+    out = [0] * m.N
+    i = 0
+    while g1:
+        if g1 & 1:
+            for k in range(m.N):
+                out[k] ^= x[i + 1 + k]
+        g1 >>= 1
+        i += 1
+    assert out == m.step_window(key, J)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    txt = open(os.path.join(root, "cora_amd", "csrc", "mt_jump.inc")).read()
+    seg = int(re.search(r"#define MT_SEG_LOG2 (\d+)", txt).group(1))
+    words = [int(t, 16) for t in re.findall(r"0x([0-9a-f]{8})u,", txt)]
+    npoly = int(re.search(r"#define MT_NPOLY (\d+)", txt).group(1))
+    assert len(words) == npoly * 624
+    g = m.x_pow_mod((1 << seg) - 1, phi)
+    for k in range(3):
+        got = sum(v << (32 * j) for j, v in enumerate(words[624 * k:624 * (k + 1)]))
+        assert got == g, k
+        g = m.polymod(m.polysqr_mod(g, phi) << 1, phi)
