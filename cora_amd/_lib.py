@@ -543,13 +543,26 @@ class Context:
         nnu = F if nnu is None else nnu
         plan = self.sht_plan(nside, lmax)
 
+        class MtState(ctypes.Structure):
+            _fields_ = [("key", ctypes.c_uint32 * 624), ("pos", ctypes.c_int32), ("has_gauss", ctypes.c_int32),
+                        ("gauss", c_double)]
+
         class Rng(ctypes.Structure):
             _fields_ = [("kind", ctypes.c_int32), ("reserved", ctypes.c_int32), ("stream", c_void_p), ("seed", c_u64),
-                        ("state", c_u64 * 2), ("inc", c_u64 * 2)]
+                        ("state", c_u64 * 2), ("inc", c_u64 * 2), ("legacy", ctypes.POINTER(MtState))]
 
         r = Rng()
         M = 2**64 - 1
-        kind = {"stream": 0, "philox": 1, "pcg64": 2}[rng[0]]
+        kind = {"stream": 0, "philox": 1, "pcg64": 2, "legacy": 3}[rng[0]]
+        ms = None
+        if kind == 3:        # ("legacy", np.random.get_state(legacy=False)): returns the state dict after the draws
+            import numpy as np
+
+            ms = MtState()
+            key = np.ascontiguousarray(rng[1]["state"]["key"], dtype=np.uint32)
+            ctypes.memmove(ms.key, key.ctypes.data, 624 * 4)
+            ms.pos, ms.has_gauss, ms.gauss = int(rng[1]["state"]["pos"]), int(rng[1]["has_gauss"]), float(rng[1]["gauss"])
+            r.legacy = ctypes.pointer(ms)
         r.kind = kind
         if kind == 0:
             r.stream = self._f64(rng[1])
@@ -566,6 +579,11 @@ class Context:
                else self.empty((nnu, 12 * nside * nside)))
         _check(self.lib.corahip_mkfullsky(self.h, plan, self._f64(C), F, ctypes.byref(r), nu0, nnu, 1 if alms else 0,
                                           c_void_p(out.data_ptr()), self._p(ws), need))
+        if kind == 3:
+            import numpy as np
+
+            return out, {"bit_generator": "MT19937", "state": {"key": np.frombuffer(ms.key, dtype=np.uint32).copy(), "pos": int(ms.pos)},
+                         "has_gauss": int(ms.has_gauss), "gauss": float(ms.gauss)}
         return out, ((int(r.state[0]) << 64) | int(r.state[1])) if kind == 2 else None
 
     def map2alm_workspace_bytes(self, plan, nnu):

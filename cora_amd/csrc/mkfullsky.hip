@@ -22,7 +22,7 @@ int layout_of(const corahip_sht_plan *p, int F, int nnu, int rng_kind, int alms,
     lo.off_info = up256(sizeof(double) * L * F * F);
     lo.off_alm = lo.off_info + up256(sizeof(int32_t) * L);
     lo.off_g = lo.off_alm + up256(sizeof(double) * nalm * G * 8);
-    lo.off_sht = lo.off_g + (rng_kind == CORAHIP_RNG_PCG64 ? up256(sizeof(double) * 2 * (size_t)F * nalm) : 0);
+    lo.off_sht = lo.off_g + ((rng_kind == CORAHIP_RNG_PCG64 || rng_kind == CORAHIP_RNG_MT19937) ? up256(sizeof(double) * 2 * (size_t)F * nalm) : 0);
     size_t full = 0;
     if (!alms) {
         int rc = corahip_alm2map_workspace_bytes(p, nnu, &full);
@@ -41,7 +41,8 @@ extern "C" {
 int corahip_mkfullsky_workspace_bytes(const corahip_sht_plan *plan, int F, int nu0, int nnu, int rng_kind, int alms,
                                       size_t *bytes) {
     ARG_CHECK(plan != nullptr && bytes != nullptr && F >= 1 && nu0 >= 0 && nnu >= 1 && nu0 + nnu <= F);
-    ARG_CHECK(rng_kind == CORAHIP_RNG_STREAM || rng_kind == CORAHIP_RNG_PHILOX || rng_kind == CORAHIP_RNG_PCG64);
+    ARG_CHECK(rng_kind == CORAHIP_RNG_STREAM || rng_kind == CORAHIP_RNG_PHILOX || rng_kind == CORAHIP_RNG_PCG64 ||
+              rng_kind == CORAHIP_RNG_MT19937);
     mk_layout lo;
     int rc = layout_of(plan, F, nnu, rng_kind, alms, lo);
     if (rc) return rc;
@@ -53,8 +54,10 @@ int corahip_mkfullsky(corahip_ctx *ctx, const corahip_sht_plan *plan, const doub
                       int nnu, int alms, double *out, void *workspace, size_t workspace_bytes) {
     ARG_CHECK(ctx != nullptr && plan != nullptr && C != nullptr && rng != nullptr && out != nullptr && workspace != nullptr);
     ARG_CHECK(F >= 1 && nu0 >= 0 && nnu >= 1 && nu0 + nnu <= F);
-    ARG_CHECK(rng->kind == CORAHIP_RNG_STREAM || rng->kind == CORAHIP_RNG_PHILOX || rng->kind == CORAHIP_RNG_PCG64);
+    ARG_CHECK(rng->kind == CORAHIP_RNG_STREAM || rng->kind == CORAHIP_RNG_PHILOX || rng->kind == CORAHIP_RNG_PCG64 ||
+              rng->kind == CORAHIP_RNG_MT19937);
     ARG_CHECK(rng->kind != CORAHIP_RNG_STREAM || rng->stream != nullptr);
+    ARG_CHECK(rng->kind != CORAHIP_RNG_MT19937 || rng->legacy != nullptr);
     mk_layout lo;
     int rc = layout_of(plan, F, nnu, rng->kind, alms, lo);
     if (rc) return rc;
@@ -75,6 +78,10 @@ int corahip_mkfullsky(corahip_ctx *ctx, const corahip_sht_plan *plan, const doub
         rc = corahip_draw_alm_philox(ctx, T, info, rng->seed, lmax, F, nu0, nnu, alm);
     } else if (rng->kind == CORAHIP_RNG_STREAM) {
         rc = corahip_draw_alm(ctx, T, info, rng->stream, lmax, F, nu0, nnu, alm);
+    } else if (rng->kind == CORAHIP_RNG_MT19937) {
+        double *g = (double *)(ws + lo.off_g);
+        if ((rc = corahip_normals_mt19937_legacy(ctx, rng->legacy, (int64_t)2 * F * plan->nalm, g))) return rc;
+        rc = corahip_draw_alm(ctx, T, info, g, lmax, F, nu0, nnu, alm);
     } else {
         double *g = (double *)(ws + lo.off_g);
         uint64_t n_raw = 0;

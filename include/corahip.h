@@ -220,6 +220,9 @@ int corahip_draw_alm_philox_rows(corahip_ctx *ctx, const double *T_rows, const i
  *                               left in (the call synchronises the stream for that);
  *           CORAHIP_RNG_STREAM  `stream`: DEVICE pointer to 2 F nalm normals in stream order (any generator, drawn by
  *                               the caller in the reference's order - e.g. rng=None, numpy's legacy global state);
+ *           CORAHIP_RNG_MT19937 the reference called WITHOUT a generator (rng=None: numpy's legacy global state, what
+ *                               Sky3d.getsky() draws from): `legacy` points to np.random.get_state(legacy=False) as a
+ *                               corahip_mt_state; continued on the device (corahip_normals_mt19937_legacy) and UPDATED;
  *           CORAHIP_RNG_PHILOX  the library's counter-based stream under `seed` (not numpy's numbers).
  *   alms  0: out = maps [nnu, npix] RING (skysim.py:130-136);  1: out = a_lm [nnu, 1, L, L] complex128, m > l zero (:123-125)
  *   workspace  >= corahip_mkfullsky_workspace_bytes(...) for one synthesis pass; a smaller one (down to the factors,
@@ -228,11 +231,13 @@ int corahip_draw_alm_philox_rows(corahip_ctx *ctx, const double *T_rows, const i
 #define CORAHIP_RNG_STREAM 0
 #define CORAHIP_RNG_PHILOX 1
 #define CORAHIP_RNG_PCG64 2
+#define CORAHIP_RNG_MT19937 3
 typedef struct corahip_rng {
     int32_t kind, reserved;
     const double *stream;
     uint64_t seed;
     uint64_t state[2], inc[2];
+    corahip_mt_state *legacy;
 } corahip_rng;
 int corahip_mkfullsky_workspace_bytes(const corahip_sht_plan *plan, int F, int nu0, int nnu, int rng_kind, int alms,
                                       size_t *bytes);

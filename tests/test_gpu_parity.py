@@ -1210,6 +1210,16 @@ def test_fused_mkfullsky_entry_point(ctx, golden):
     assert torch.equal(maps_s, ref_maps)
     maps_p, _ = ctx.mkfullsky_fused(Cd, nside, ("philox", 77), nu0=2, nnu=4)
     assert torch.equal(maps_p, skysim.mkfullsky_device(C, nside, rng=DeviceRNG(77), nu_range=(2, 4)))
+    # rng=None of the reference: numpy's legacy global state through the same entry
+    np.random.seed(1234)
+    alm_l, st_l = ctx.mkfullsky_fused(ctx.to_device(golden["cla_21cm_F4_l16_zromb1"]), 8, ("legacy", np.random.get_state(legacy=False)),
+                                      alms=True)
+    ref_l = golden["alm_21cm_F4_l16_legacy1234"]
+    assert np.abs(alm_l.cpu().numpy() - ref_l).max() <= 1e-12 * np.abs(ref_l).max()
+    twin = np.random.RandomState(0)
+    twin.set_state(st_l)
+    skysim._host_normals(4, 16, None)                                  # (np.random was seeded 1234: the reference's draws)
+    assert np.array_equal(twin.random_sample(64), np.random.random_sample(64))
     # chunked synthesis: the minimum the entry accepts is in the error text of a refused call
     with pytest.raises(RuntimeError) as ei:
         ctx.mkfullsky_fused(Cd, nside, ("stream", ctx.to_device(g)), workspace_bytes=1024)

@@ -58,7 +58,7 @@ def main():
 
     class Rng(ctypes.Structure):
         _fields_ = [("kind", ctypes.c_int32), ("reserved", ctypes.c_int32), ("stream", P), ("seed", ctypes.c_uint64),
-                    ("state", ctypes.c_uint64 * 2), ("inc", ctypes.c_uint64 * 2)]
+                    ("state", ctypes.c_uint64 * 2), ("inc", ctypes.c_uint64 * 2), ("legacy", P)]
 
     def pcg64():
         r = Rng()
