@@ -568,7 +568,7 @@ class Context:
             r.stream = self._f64(rng[1])
         elif kind == 1:
             r.seed = int(rng[1]) & M
-        else:
+        elif kind == 2:
             r.state[0], r.state[1] = (int(rng[1]) >> 64) & M, int(rng[1]) & M
             r.inc[0], r.inc[1] = (int(rng[2]) >> 64) & M, int(rng[2]) & M
         b = c_size_t()

@@ -204,8 +204,9 @@ static inline long draw_slots(int lmax) {
 // FROMG: the normals come from a stream-order buffer `gsrc` (the caller's numpy stream: uploaded, or generated on the
 // device by corahip_normals_pcg64) instead of the Philox chain.  The A operands of a chunk (8 k-steps x (re, im) = 16
 // doubles per lane) are requested one chunk ahead by asm loads that take their place in the counted vmcnt scheme of the
-// staging: after the barrier of chunk c a wave issues the loads of chunk c + 1, THEN the DMA pieces of stage c + 2, so
-// the wait that leaves those QPW pieces in flight covers the loads as well.
+// staging by HALF chunks: behind the barrier of chunk c a wave requests the second half of chunk c, THEN the DMA pieces
+// of stage c + 2 - the wait in front of the second half leaves those QPW pieces in flight and covers the loads; the
+// first half of chunk c + 1 is requested at that point and waited for, with everything else, at the next chunk begin.
 template <int NCT, bool FROMG = false>
 __global__ void __launch_bounds__(64 * DRAW_WAVES, 2)
 draw_rng_kernel(const double *__restrict__ T, size_t t_ldl, int t_row0, const int32_t *__restrict__ info,
@@ -400,7 +401,10 @@ draw_rng_kernel(const double *__restrict__ T, size_t t_ldl, int t_row0, const in
             }
         };
         auto chunk_begin = [&](int c) {
-            if (c == 0 || c + 1 >= nchunk) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // FROMG: the first-half operands of this chunk were requested at the middle of the previous one, BEHIND the
+            // DMA pieces of stage c + 1 - they are the youngest requests in flight, so everything is waited for (stage
+            // c + 1 has then had one chunk, not two, to land; the counted wait is the one in front of the second half)
+            if (FROMG || c == 0 || c + 1 >= nchunk) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(QPW) : "memory");
             if constexpr (FROMG) {
                 if (wave_has_rows) pin_a(a_x);
