@@ -139,6 +139,8 @@ def test_draw_from_stream_buffer_matches_numpy(ctx, F, lmax, nu0, nnu, monkeypat
     assert worst < 1e-13, worst
     rows = ctx.draw_alm_rows(Td[:, nu0:nu0 + nnu, :].contiguous(), infod, gd, lmax, F, nu0, nnu)
     assert torch.equal(rows, alm)
+    for _ in range(3):         # (run to run: an operand prefetch that is not covered by its wait shows as a bit difference)
+        assert torch.equal(ctx.draw_alm(Td, infod, gd, lmax, F, nu0=nu0, nnu=nnu), alm)
     monkeypatch.setenv("CORAHIP_DRAW_GENERIC", "1")
     old = ctx.draw_alm(Td, infod, gd, lmax, F, nu0=nu0, nnu=nnu)
     assert (old - alm).abs().max().item() <= 1e-12 * alm.abs().max().item()
