@@ -51,6 +51,7 @@ struct corahip_sht_plan {
     // seed tables (the spin-2 and the analysis kernels keep the (A, B) form)
     double2 *d_coefmu = nullptr;                          // [nalm]: (alpha_l, s_l) at alm_idx(l,m)
     double2 *d_seedmu = nullptr;                          // [L][npair]: (mu_{lstart-1}, mu_{lstart})
+    double2 *d_seed4 = nullptr;                           // [L][npair][4]: (mu_{R-2}, mu_{R-1}) in front of lane group kq's entry row R (seed_kernel)
     int32_t *d_lmin = nullptr;                            // [L][ntile] first l per (m, ring tile)
     unsigned *d_queue = nullptr;                          // K4 work-queue head
     int32_t *d_mcut = nullptr;                            // [nring] number of m with any non-negligible lambda_lm

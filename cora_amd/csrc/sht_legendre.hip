@@ -15,6 +15,22 @@
 #define LEG_MS_UNROLL 7   // (= LEG_KT / 8 at the shipped stage length; only the rolled head / tail stages use it) macro-step loop of a stage fully unrolled (loop counters and pointer increments become immediates): 71.0 -> 69.5 ms; factors 2 and 3: no change
 #endif
 
+#ifndef LEG_STAMPS
+#define LEG_STAMPS 0      // diagnostic build (make k4stamps): s_memtime per phase of the item loop, summed over the workgroups' first waves
+#endif
+#if LEG_STAMPS
+__device__ unsigned long long g_leg_stamps[16];
+#define LEG_STAMP(acc)                                                                       \
+    {                                                                                        \
+        unsigned long long _t;                                                               \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)::"memory");           \
+        acc += _t - leg_last;                                                                \
+        leg_last = _t;                                                                       \
+    }
+#else
+#define LEG_STAMP(acc)
+#endif
+
 // Lane roles (wave = 16 rings x 4 k-slots, the A operand of v_mfma_f64_16x16x4_f64):
 // lane (ri = lane&15, kq = lane>>4) runs the recurrence of ring ri STAGGERED by 2 kq steps, so that
 // at every macro-step (8 consecutive l, base l0) the first two values it produces are exactly the
@@ -27,6 +43,11 @@
 // fma per step instead of two multiplies and an fma - and only the two values a lane feeds to the MFMAs are scaled back
 // (lambda = s mu): 18 instead of 24 DP instructions per macro-step.  `coef` holds (alpha_l, s_l), `seed` the mu pair at
 // the first contributing l (sht_plan.hip: d_coefmu, d_seedmu); rows past lmax are zeros: s = 0 makes their A operand 0.
+// Round 4: a lane ENTERS AT A WINDOW START.  `seed` is the plan's d_seed4: per (m, ring) four states (mu_{R-2},
+// mu_{R-1}), one per lane group kq, in front of the first row R = m + 2 kq + 8 k >= lstart - 1 (seed_kernel).  The
+// head stages' macro-steps then carry one compare + two selects per ring (is this window the entry?) instead of a
+// compare + three selects per ROW (19.2k against 16.4k cycles per stage, 13 % of the kernel's time was in head
+// stages), and the item prologue no longer walks lanes forward from the first contributing row with dependent loads.
 // NT = 16-column tiles per wave, RT = 16-ring row tiles per wave (RT x NT x 2 parities = 16 accumulator
 // tiles = 128 VGPRs in both shipped shapes: <8,1> for >= 128 columns, <4,2> for 64-column shards, where a
 // second, independent recurrence per lane keeps the recurrence : MFMA ratio of the wide shape).
@@ -182,6 +203,11 @@ legendre_kernel(int lmax, int npair, int nring, int ncols, const double *__restr
     for (int st = 0; st < LEG_NBUF - 1; st++)
         if (st < w.nstage) issue_stage(w, st);
 
+#if LEG_STAMPS
+    unsigned long long leg_last, t_pro = 0, t_head = 0, t_clean = 0, t_tail = 0, t_bnd = 0, t_epi = 0, t_bar2 = 0;
+    unsigned long long n_head = 0, n_clean = 0, n_tail = 0, n_items = 0;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(leg_last)::"memory");
+#endif
     for (;;) {
         const int m = w.m;
         if (tid == 0) s_next = map_item((int)(nwg_q + atomicAdd(my_queue, 1u)));  // latency hidden behind this item
@@ -199,7 +225,6 @@ legendre_kernel(int lmax, int npair, int nring, int ncols, const double *__restr
             double x[RT], p0[RT], p1[RT];
             double2 sd[RT];
             int my_ls[RT], inj_l[RT];
-            const double2 *cf = coef + w.base_m;
             int ls_min = lmax + 1;
 #pragma unroll
             for (int q = 0; q < RT; q++) {
@@ -211,26 +236,14 @@ legendre_kernel(int lmax, int npair, int nring, int ncols, const double *__restr
                     x[q] = z[ring];
                     const long o = (long)m * npair + ring;
                     my_ls[q] = lstart[o];
-                    sd[q] = seed[o];
+                    sd[q] = seed[4 * o + kq];
                 }
                 ls_min = min(ls_min, my_ls[q]);
-                // per-lane start state: (lambda_{lf-2}, lambda_{lf-1}) with lf = l_begin + d the first l of this
-                // lane.  If the ring's first contributing l lies before lf, advance from the seeds.
+                // the lane's state is zero until its entry row (a window start of this lane group: >= l_begin + d)
                 p0[q] = 0.0;
                 p1[q] = 0.0;
-                inj_l[q] = my_ls[q];  // l at which the seeds are injected
-                const int lf = w.l_begin + d;
-                if (my_ls[q] < lf) {
-                    p0[q] = sd[q].x;
-                    p1[q] = sd[q].y;
-                    for (int l = my_ls[q] + 1; l < lf; l++) {
-                        const double2 c = (l <= lmax) ? cf[l] : make_double2(0.0, 0.0);
-                        const double vv = fma(c.x * x[q], p1[q], -p0[q]);        // scaled form: see the lane-role note
-                        p0[q] = p1[q];
-                        p1[q] = vv;
-                    }
-                    inj_l[q] = 0x7fffffff;
-                }
+                const int t = my_ls[q] - 1 - m - d;
+                inj_l[q] = my_ls[q] <= lmax ? m + d + (t > 0 ? ((t + 7) >> 3) << 3 : 0) : 0x7fffffff;
             }
             // wave-uniform bounds of the start rows: the skip tests of the macro-step loop become scalar compares
             // (every vector instruction there costs issue time next to the MFMAs)
@@ -267,13 +280,21 @@ legendre_kernel(int lmax, int npair, int nring, int ncols, const double *__restr
                             w.nstage - LEG_NBUF + 1);
             st_hi = __builtin_amdgcn_readfirstlane(st_hi);
             int st = 0;
-#define LEG_CLEAN 0
-#define LEG_MS_PRAGMA _Pragma("unroll 1")
-            for (; st < w.nstage && !(stage_lo(st) && st < st_hi); st++) {
+            LEG_STAMP(t_pro);
+#if LEG_STAMPS
+            int st_mark = 0;
+#endif
+#define LEG_CLEAN 2
+#define LEG_MS_PRAGMA _Pragma("unroll")
+            for (; st < st_hi && !stage_lo(st); st++) {
 #include "leg_stage_body.inc"
             }
 #undef LEG_CLEAN
 #undef LEG_MS_PRAGMA
+            LEG_STAMP(t_head);
+#if LEG_STAMPS
+            n_head += st - st_mark, st_mark = st;
+#endif
 #define LEG_CLEAN 1
 #define LEG_MS_PRAGMA _Pragma("unroll")
             for (; st < st_hi; st++) {
@@ -281,6 +302,10 @@ legendre_kernel(int lmax, int npair, int nring, int ncols, const double *__restr
             }
 #undef LEG_CLEAN
 #undef LEG_MS_PRAGMA
+            LEG_STAMP(t_clean);
+#if LEG_STAMPS
+            n_clean += st - st_mark, st_mark = st;
+#endif
 #define LEG_CLEAN 0
 #define LEG_MS_PRAGMA _Pragma("unroll 1")
             for (; st < w.nstage; st++) {
@@ -288,6 +313,10 @@ legendre_kernel(int lmax, int npair, int nring, int ncols, const double *__restr
             }
 #undef LEG_CLEAN
 #undef LEG_MS_PRAGMA
+            LEG_STAMP(t_tail);
+#if LEG_STAMPS
+            n_tail += st - st_mark, n_items++;
+#endif
         }
 
         // ---- next item: start its first stages now, so they land behind this item's epilogue stores
@@ -301,6 +330,7 @@ legendre_kernel(int lmax, int npair, int nring, int ncols, const double *__restr
             for (int st = 0; st < LEG_NBUF - 1; st++)
                 if (st < w.nstage) issue_stage(w, st);
         }
+        LEG_STAMP(t_bnd);
 
         // ---- epilogue: north = even + odd, south mirror = even - odd.  Adjacent lanes (columns n, n+1 of the
         //      same rows) swap one value each so that every lane stores 16 bytes: half the store instructions.
@@ -338,9 +368,19 @@ legendre_kernel(int lmax, int npair, int nring, int ncols, const double *__restr
                     }
                 }
         }
+        LEG_STAMP(t_epi);
         if (!have_next) break;
         __syncthreads();  // everyone has read s_next before thread 0 overwrites it
+        LEG_STAMP(t_bar2);
     }
+#if LEG_STAMPS
+    if (tid == 0) {
+        atomicAdd(&g_leg_stamps[0], t_pro), atomicAdd(&g_leg_stamps[1], t_head), atomicAdd(&g_leg_stamps[2], t_clean);
+        atomicAdd(&g_leg_stamps[3], t_tail), atomicAdd(&g_leg_stamps[4], t_bnd), atomicAdd(&g_leg_stamps[5], t_epi);
+        atomicAdd(&g_leg_stamps[6], t_bar2), atomicAdd(&g_leg_stamps[7], n_head), atomicAdd(&g_leg_stamps[8], n_clean);
+        atomicAdd(&g_leg_stamps[9], n_tail), atomicAdd(&g_leg_stamps[10], n_items);
+    }
+#endif
 }
 
 // K4 for polarisation (spin 2): (E, B) -> (Q, U), what healpy.alm2map([T, E, B]) does for Q and U behind
@@ -574,9 +614,23 @@ static int launch_legendre(corahip_ctx *ctx, const corahip_sht_plan *p, int ncol
     dim3 grid((unsigned)std::min<long>(nitems, (long)ctx->num_cu * per_cu));
     HIP_TRY(hipMemsetAsync(p->d_queue, 0, 1024, ctx->stream));
     legendre_kernel<NT, RT><<<grid, 64 * LEG_WAVES, shm, ctx->stream>>>(p->lmax, p->npair, p->nring, ncols, p->d_z,
-                                                                       p->d_coefmu, p->d_lstart, p->d_seedmu, p->d_lmin,
+                                                                       p->d_coefmu, p->d_lstart, p->d_seed4, p->d_lmin,
                                                                        alm, p->d_zeros, inter, p->d_queue);
     LAUNCH_CHECK();
+#if LEG_STAMPS
+    {
+        unsigned long long hs[16], zero[16] = {0};
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        HIP_TRY(hipMemcpyFromSymbol(hs, HIP_SYMBOL(g_leg_stamps), sizeof(hs)));
+        HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_leg_stamps), zero, sizeof(zero)));
+        const double tot = (double)(hs[0] + hs[1] + hs[2] + hs[3] + hs[4] + hs[5] + hs[6]);
+        fprintf(stderr, "K4 stamps <%d,%d> wg=%u items=%llu: prologue %.3f head %.3f (%llu st) clean %.3f (%llu st) tail %.3f (%llu st) "
+                "boundary %.3f epilogue %.3f barrier2 %.3f | ticks/item %.0f ticks/clean-stage %.0f ticks/head-stage %.0f ticks/tail-stage %.0f\n",
+                NT, RT, grid.x, hs[10], hs[0] / tot, hs[1] / tot, hs[7], hs[2] / tot, hs[8], hs[3] / tot, hs[9], hs[4] / tot, hs[5] / tot,
+                hs[6] / tot, tot / std::max<double>(1.0, (double)hs[10]), hs[2] / std::max<double>(1.0, (double)hs[8]),
+                hs[1] / std::max<double>(1.0, (double)hs[7]), hs[3] / std::max<double>(1.0, (double)hs[9]));
+    }
+#endif
     return 0;
 }
 int sht_legendre(corahip_ctx *ctx, const corahip_sht_plan *p, int ncols, const double *alm, double *inter) {

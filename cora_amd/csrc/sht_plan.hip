@@ -52,10 +52,32 @@ __device__ static inline void scaled_pow(double s, int n, double &mant, int &ex)
 __global__ void seed_kernel(int lmax, int npair, int min_exp, const double *__restrict__ z, const double *__restrict__ sth,
                             const double *__restrict__ pref, const double2 *__restrict__ coef,
                             const double2 *__restrict__ coefmu, int32_t *__restrict__ lstart, double2 *__restrict__ seed,
-                            double2 *__restrict__ seedmu) {
+                            double2 *__restrict__ seedmu, double2 *__restrict__ seed4) {
     int r = blockIdx.x * blockDim.x + threadIdx.x;
     int m = blockIdx.y;
     if (r >= npair) return;
+    // seed4[o][kq]: the state (mu_{R-2}, mu_{R-1}) of the scaled recurrence in front of row R = R_kq, the first row of the
+    // form m + 2 kq + 8 k (k >= 0) that is >= lstart - 1 - the start of the first 8-row window of legendre_kernel's lane
+    // group kq in which the ring contributes (its lanes feed rows R, R + 1 of every window).  Every lane then enters at
+    // a window start: no per-step injection tests in the kernel.  Rows lstart - 3 .. lstart - 1 appear with their true
+    // values (below the cut, i.e. < 2^min_exp: harmless); in front of row m the state is (-mu_m, 0), which makes
+    // mu_m = alpha_m x 0 + mu_m and mu_{m+1} = alpha_{m+1} x mu_m come out of the recurrence itself.
+    auto emit4 = [&](long o, int ls, const double *lam /* rows ls-3 .. ls+5 */) {
+        const double2 *cm = coefmu + alm_idx(0, m, lmax);
+        double mu[9];
+        for (int i = 0; i < 9; i++) {
+            const int row = ls - 3 + i;
+            mu[i] = (row >= m && row <= lmax) ? lam[i] / cm[row].y : 0.0;
+        }
+        for (int i = 0; i < 9; i++)
+            if (ls - 3 + i == m - 2) mu[i] = -(lam[m - (ls - 3)] / cm[m].y);   // (s_m = 1)
+        for (int kq = 0; kq < 4; kq++) {
+            const int t = ls - 1 - m - 2 * kq;
+            const int R = m + 2 * kq + (t > 0 ? ((t + 7) >> 3) << 3 : 0);
+            const int i0 = R - 2 - (ls - 3);
+            seed4[4 * o + kq] = make_double2(mu[i0], mu[i0 + 1]);
+        }
+    };
     double x = z[r];
     double pm;
     int pe;
@@ -65,22 +87,44 @@ __global__ void seed_kernel(int lmax, int npair, int min_exp, const double *__re
     int sc = pe + t;
     if (m & 1) mant = -mant;
     long o = (long)m * npair + r;
+    const double2 *cf = coef + alm_idx(0, m, lmax);
+    double lam[9] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};       // lambda at rows lstart - 3 .. lstart + 5
+    auto forward5 = [&](int ls, double q0, double q1, int e) {           // rows ls + 1 .. ls + 5 behind (q0, q1) 2^e
+        for (int l = ls + 1; l <= ls + 5; l++) {
+            double v = 0.0;
+            if (l <= lmax) {
+                const double2 c = cf[l];
+                v = fma(c.x * x, q1, -(c.y * q0));
+            }
+            q0 = q1;
+            q1 = v;
+            lam[3 + l - ls] = ldexp(v, e);
+        }
+    };
     if (sc >= min_exp) {
         lstart[o] = m;
         seed[o] = make_double2(0.0, ldexp(mant, sc));
         seedmu[o] = make_double2(0.0, ldexp(mant, sc));     // s_m = 1
+        lam[3] = ldexp(mant, sc);
+        forward5(m, 0.0, mant, sc);
+        emit4(o, m, lam);
         return;
     }
-    const double2 *cf = coef + alm_idx(0, m, lmax);
     double p0 = 0.0, p1 = mant;  // scaled by 2^sc
+    double pm1 = 0.0, pm2 = 0.0; // the two rows in front of p0
     int found = lmax + 1;
     double s0 = 0.0, s1 = 0.0;
+    const double lam_m = ldexp(mant, sc);   // (may underflow to 0: row m - 2 is only asked for when lstart <= m + 1)
     for (int l = m + 1; l <= lmax; l++) {
         double2 c = cf[l];
         double v = fma(c.x * x, p1, -(c.y * p0));
+        pm2 = pm1;
+        pm1 = p0;
         p0 = p1;
         p1 = v;
         if (fabs(p1) > 0x1p100) {
+            pm2 *= 0x1p-100;
+            pm1 *= 0x1p-100;
             p0 *= 0x1p-100;
             p1 *= 0x1p-100;
             sc += 100;
@@ -94,6 +138,14 @@ __global__ void seed_kernel(int lmax, int npair, int min_exp, const double *__re
     }
     lstart[o] = found;
     seed[o] = make_double2(s0, s1);
+    if (found <= lmax) {
+        lam[0] = ldexp(pm2, sc), lam[1] = ldexp(pm1, sc), lam[2] = s0, lam[3] = s1;
+        if (m >= found - 3) lam[m - (found - 3)] = lam_m;   // (row m itself, wherever it sits in the window)
+        forward5(found, p0, p1, sc);
+        emit4(o, found, lam);
+    } else {
+        for (int kq = 0; kq < 4; kq++) seed4[4 * o + kq] = make_double2(0.0, 0.0);
+    }
     // the same pair in the scaled form of the synthesis kernel: mu_l = lambda_l / s_l
     const double2 *cm = coefmu + alm_idx(0, m, lmax);
     seedmu[o] = found <= lmax ? make_double2(s0 / cm[found - 1].y, s1 / cm[found].y) : make_double2(0.0, 0.0);
@@ -280,6 +332,7 @@ int corahip_sht_plan_destroy(corahip_ctx *ctx, corahip_sht_plan *p) {
     (void)hipFree(p->d_seed);
     (void)hipFree(p->d_coefmu);
     (void)hipFree(p->d_seedmu);
+    (void)hipFree(p->d_seed4);
     (void)hipFree(p->d_tw);
     (void)hipFree(p->d_zeros);
     (void)hipFree(p->d_lmin);
@@ -469,10 +522,11 @@ int corahip_sht_plan_create_ex(corahip_ctx *ctx, int nside, int lmax, int cut_ex
     HIP_TRY(hipMalloc((void **)&p->d_lstart, sizeof(int32_t) * (size_t)p->L * p->npair));
     HIP_TRY(hipMalloc((void **)&p->d_seed, sizeof(double2) * (size_t)p->L * p->npair));
     HIP_TRY(hipMalloc((void **)&p->d_seedmu, sizeof(double2) * (size_t)p->L * p->npair));
+    HIP_TRY(hipMalloc((void **)&p->d_seed4, sizeof(double2) * 4 * (size_t)p->L * p->npair));
     {
         dim3 grid((p->npair + 63) / 64, p->L);
         seed_kernel<<<grid, 64, 0, s>>>(lmax, p->npair, cut_exp, p->d_z, p->d_sth, d_pref, p->d_coef, p->d_coefmu, p->d_lstart,
-                                        p->d_seed, p->d_seedmu);
+                                        p->d_seed, p->d_seedmu, p->d_seed4);
         LAUNCH_CHECK();
     }
     {

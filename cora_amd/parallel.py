@@ -180,7 +180,7 @@ def rank_memory_bytes(kinds, F, nside, lmax, world, sum_mode="joint", rng="philo
     out["a_lm"] = 16 * nalm * (-(-nnu // 4) * 4) * (1 if (joint or len(kinds) == 1) else 2)      # separate: + the component being added
     out["synthesis workspace (F_m cells)"] = nring * (-(-nnu // 8) * 2) * L * 64
     out["plan (recurrence coefficients, polar seeds, first-l tables, ring FFT tables)"] = (
-        2 * 16 * nalm + 2 * 16 * L * npair + 4 * L * npair + int(1.0e8 * (nside / 1024.0) ** 2))
+        2 * 16 * nalm + (2 * 16 + 64) * L * npair + 4 * L * npair + int(1.0e8 * (nside / 1024.0) ** 2))   # (64: the four entry states per (m, ring) of K4's lane groups)
     if ntab:
         out["21cm tables + their transposed copy"] = 2 * 3 * 500 * 32768 * 8
         pairs = F * (F + 1) // 2
