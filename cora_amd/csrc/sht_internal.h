@@ -34,6 +34,8 @@ struct corahip_sht_plan {
     int nside = 0, lmax = 0, L = 0, npair = 0, nring = 0;
     int cut_exp = 0;                                      // terms of the Legendre sums with |lambda_lm| < 2^cut_exp are dropped
     std::map<int, uint64_t> k4_macro_steps;               // by RT: macro-steps legendre_kernel executes per column group (lazy)
+    std::map<std::pair<int, int>, std::pair<int2 *, int>> k4_items;   // by (RT, column groups): legendre_kernel's list of non-empty items (lazy, sht_k4_items)
+    std::vector<int32_t> h_lmin;                          // host copy of d_lmin (lazy)
     long npix = 0, nalm = 0;
     std::vector<int64_t> h_start;
     std::vector<int32_t> h_nphi;
@@ -544,6 +546,9 @@ static inline int nnu_pad_of(int nnu) { return (nnu + 7) & ~7; }
 // ---- cross-translation-unit host functions -------------------------------------------------
 // K4: alm [nalm][ncols] -> F_m cells; the launch shape is chosen from the number of 16-column tiles
 int sht_legendre(corahip_ctx *ctx, const corahip_sht_plan *p, int ncols, const double *alm, double *inter);
+// legendre_kernel's work list for (RT ring row tiles per wave, ncg column groups): the (m, column group, ring tile) items with at
+// least one contributing l, m-major, as (m | rtile << 15 | cg << 23, first contributing l); cached in the plan
+int sht_k4_items(corahip_ctx *ctx, const corahip_sht_plan *p, int rt, int ncg, const int2 **items, int *nitems);
 // K4 spin-2: interleaved (E, B) channels -> (Q, U) cells (builds the plan's g table on first use)
 int sht_legendre_pol(corahip_ctx *ctx, corahip_sht_plan *p, int ncols, const double *alm, double *inter);
 // K5: F_m cells -> maps for nnu_valid channels (nnu_chunk_pad = channels in the cell layout)

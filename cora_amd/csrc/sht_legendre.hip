@@ -5,9 +5,6 @@
 #ifndef LEG_ST_UNROLL
 #define LEG_ST_UNROLL 1   // unroll factor of the stage loop (3 would make the LDS ring offsets immediates)
 #endif
-#ifndef LEG_XCD_PAIR
-#define LEG_XCD_PAIR 0    // 1: the two ring tiles (2k, 2k+1) of an a_lm slice are taken by workgroups of ONE XCD (see map_item); measured neutral in time, +12 % FETCH_SIZE: off
-#endif
 #ifndef LEG_RING_BLOCKS
 #define LEG_RING_BLOCKS 0   // (measured neutral: 56.6 vs 56.5 ms, off) 1: a wave takes CONSECUTIVE rings of the tile (its own first contributing l), the two waves of a SIMD complementary blocks; 0: rings interleaved over the waves
 #endif
@@ -55,7 +52,7 @@ template <int NT, int RT>
 __global__ void __launch_bounds__(64 * LEG_WAVES, LEG_WAVES <= 4 ? 2 : 1)
 legendre_kernel(int lmax, int npair, int nring, int ncols, const double *__restrict__ z,
                 const double2 *__restrict__ coef, const int32_t *__restrict__ lstart,
-                const double2 *__restrict__ seed, const int32_t *__restrict__ lmin_tab,
+                const double2 *__restrict__ seed, const int2 *__restrict__ items, int nitems,
                 const double *__restrict__ alm, const double *__restrict__ zeros, double *__restrict__ inter,
                 unsigned *__restrict__ queue) {
     constexpr int TCOLS = 16 * NT;          // columns of this block
@@ -68,7 +65,7 @@ legendre_kernel(int lmax, int npair, int nring, int ncols, const double *__restr
     constexpr int RPM = RPW / (LEG_KT / 8);             // a_lm pieces each wave issues per macro-step
     static_assert(RPM * (LEG_KT / 8) == RPW && RPM >= 1 && RPM == LEG_RPM, "whole a_lm pieces per macro-step");
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    int &s_next = *reinterpret_cast<int *>(lds + LEG_NBUF * STAGE);  // next work item (carved after the ring)
+    int *const s_next = reinterpret_cast<int *>(lds + LEG_NBUF * STAGE);  // next work item, two slots used in turn (carved after the ring)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -77,10 +74,6 @@ legendre_kernel(int lmax, int npair, int nring, int ncols, const double *__restr
     const int d = 2 * kq;
     const int L = lmax + 1;
     const int G = ncols >> 3;
-    const int ntile128 = (npair + LMIN_RINGS - 1) / LMIN_RINGS;   // granularity of lmin_tab
-    const int ntile = (npair + TRINGS - 1) / TRINGS;
-    const int ncg = ncols / TCOLS;
-    const int nitems = L * ncg * ntile;
     const long last_row = nalm_of(lmax) - 1;
     const unsigned lds_base_bytes = (unsigned)(size_t)(__attribute__((address_space(3))) double *)lds;
     const bool odd_lane = lane & 1;
@@ -97,7 +90,11 @@ legendre_kernel(int lmax, int npair, int nring, int ncols, const double *__restr
     // Persistent workgroups.  Work item = (m, column group, ring tile); consecutive items are the ring
     // tiles of one a_lm slice, so the workgroups running at the same time share slices in L2 (they are
     // dealt over all 8 XCDs; packing a slice group onto ONE XCD was measured 24 % slower: every resident
-    // workgroup of the XCD then hits the same 1-2 L2 channels in lock step).  Small m (long K) first.
+    // workgroup of the XCD then hits the same 1-2 L2 channels in lock step; pairing the two ring tiles of a slice on
+    // one XCD - LEG_XCD_PAIR of rounds 2-3 - was neutral and is gone).  Small m (long K) first.
+    // `items` is the plan's list of the NON-EMPTY items in that order (sht_plan.hip: sht_k4_items; 27 % of the
+    // (m, ring tile) pairs of cfg 3 have no contributing l at all), each with its first contributing l: decoding an
+    // item is one 8-byte scalar load (rounds 1-3: two integer divisions and dependent loads from the first-l table).
     struct item_t {
         int m, cg, rtile, l_begin, nstage;
         long base_m;
@@ -106,16 +103,13 @@ legendre_kernel(int lmax, int npair, int nring, int ncols, const double *__restr
     };
     auto decode = [&](int it) {
         item_t w;
-        const int gidx = it / ntile;
-        w.rtile = it - gidx * ntile;
-        w.m = gidx / ncg;
-        w.cg = gidx - w.m * ncg;
-        int lmin = lmax + 1;
-        const int t_first = (w.rtile * TRINGS) / LMIN_RINGS;
-        const int t_last = min((w.rtile * TRINGS + TRINGS - 1) / LMIN_RINGS, ntile128 - 1);
-        for (int t128 = t_first; t128 <= t_last; t128++) lmin = min(lmin, lmin_tab[w.m * ntile128 + t128]);
+        const int2 e = items[it];                 // (m | rtile << 15 | cg << 23, first contributing l): wave-uniform
+        w.m = e.x & 0x7fff;
+        w.rtile = (e.x >> 15) & 0xff;
+        w.cg = (e.x >> 23) & 0xff;
+        const int lmin = e.y;
         w.l_begin = w.m + ((lmin - w.m) & ~7);
-        w.nstage = lmin <= lmax ? (lmax - w.l_begin) / LEG_KT + 1 : 0;
+        w.nstage = (lmax - w.l_begin) / LEG_KT + 1;
         w.base_m = alm_idx(0, w.m, lmax);
         w.src0 = alm + (size_t)w.cg * TCOLS + (size_t)(w.base_m + w.l_begin) * ncols;
         w.row_limit = (int)(last_row - (w.base_m + w.l_begin));
@@ -176,32 +170,43 @@ legendre_kernel(int lmax, int npair, int nring, int ncols, const double *__restr
 
     // dynamic work queue (one atomic per item, fetched one item ahead): items differ a lot in length
     // (polar ring tiles start late, large m is short), a static assignment left ~10 % on the table.
-    // LEG_XCD_PAIR: one queue per XCD (workgroups with equal blockIdx % 8 share an XCD under round-robin placement - a
-    // matter of speed only).  The pairs of ring tiles (2k, 2k+1) of all slices are dealt over the eight queues -
-    // pair q to queue (q + q / 8) % 8: the eight pairs of a block go to eight different XCDs and the rotation lets every
-    // XCD see polar and equatorial tiles alike - and the two tiles of a pair are consecutive entries of their queue:
-    // two workgroups of the XCD stream the same a_lm rows at the same time, so that L2 fetches the slice once
-    // for both.  Measured (round 2, cfg 3): 56.8 ms either way and FETCH_SIZE 85 GB against 76 GB with the global queue -
-    // the partner's rows have left the 4 MB L2 (32 workgroups x two 57 KB stages + the F_m stores) before it asks for
-    // them; the re-reads of a slice are absorbed by the 256 MB Infinity Cache, which FETCH_SIZE counts as fetches
-    // (MI355X_MICROARCH.md).  All eight tiles of a slice on one XCD had been 24 % slower (L2-channel hot-spotting).
-    const bool xcd_pair = LEG_XCD_PAIR && (ntile % 2 == 0) && (gridDim.x % 8 == 0);
-    const int xcd = blockIdx.x & 7;
-    const int nwg_q = xcd_pair ? (int)(gridDim.x >> 3) : (int)gridDim.x;      // workgroups feeding from this queue
-    unsigned *const my_queue = queue + (xcd_pair ? 32 * xcd : 0);
-    auto map_item = [&](int t) {       // t-th entry of this workgroup's queue -> item index (nitems: the queue is exhausted)
-        if (!xcd_pair) return t;
-        const int s = t >> 1;
-        const long q = 8L * s + ((xcd - s) & 7);                             // pair index: (slice group, tile pair)
-        const long it = q * 2 + (t & 1);                                     // = gidx * ntile + 2 kp + half  (ntile even)
-        return it < nitems ? (int)it : nitems;
+    // The first gridDim.x entries are pre-assigned; the queue starts behind them.
+    const int nwg = (int)gridDim.x;
+    auto clamp_item = [&](unsigned t) { return t < (unsigned)nitems ? (int)t : nitems; };
+    // ring state of an item: cos(theta), first contributing l and the lane group's entry state (plan: d_seed4)
+    auto load_rings = [&](const item_t &w, double (&x)[RT], int (&my_ls)[RT], double2 (&sd)[RT]) {
+#pragma unroll
+        for (int q = 0; q < RT; q++) {
+            const int ring = w.rtile * TRINGS + ring_in_tile(ri + 16 * q);
+            x[q] = 0.0;
+            my_ls[q] = lmax + 1;
+            sd[q] = make_double2(0.0, 0.0);
+            if (ring < npair) {
+                x[q] = z[ring];
+                const long o = (long)w.m * npair + ring;
+                my_ls[q] = lstart[o];
+                sd[q] = seed[4 * o + kq];
+            }
+        }
     };
-    int item = map_item(xcd_pair ? (int)(blockIdx.x >> 3) : (int)blockIdx.x);  // the first entries are pre-assigned; the queue starts behind them
+    int item = (int)blockIdx.x;
     if (item >= nitems) return;
     item_t w = decode(item);
+    double x[RT];
+    int my_ls[RT];
+    double2 sd[RT];
+    // order of the vector-memory operations at an item boundary (vmcnt retires in order): queue atomic, ring state,
+    // first stage(s) of the next item, THEN the epilogue stores of the current one; the next item's prologue then has
+    // nothing to load.  (Measured and dropped, round 4: a first-stage wait of vmcnt(<stores of a full tile>) that lets
+    // the stores drain behind the next item's first macro-steps: +0.45 ms - the refill pieces of that stage queue behind
+    // the stores; and an epilogue with a DPP exchange and scalar-base addressing, half the VALU instructions and no
+    // LDS permutes: no change - the epilogue runs at the CU's store path, 32 B/clk for these 64-byte segments.)
+    if (tid == 0) s_next[0] = clamp_item(nwg + atomicAdd(queue, 1u));
+    load_rings(w, x, my_ls, sd);
 #pragma unroll
     for (int st = 0; st < LEG_NBUF - 1; st++)
         if (st < w.nstage) issue_stage(w, st);
+    int slot = 0;
 
 #if LEG_STAMPS
     unsigned long long leg_last, t_pro = 0, t_head = 0, t_clean = 0, t_tail = 0, t_bnd = 0, t_epi = 0, t_bar2 = 0;
@@ -210,7 +215,6 @@ legendre_kernel(int lmax, int npair, int nring, int ncols, const double *__restr
 #endif
     for (;;) {
         const int m = w.m;
-        if (tid == 0) s_next = map_item((int)(nwg_q + atomicAdd(my_queue, 1u)));  // latency hidden behind this item
         d4_t acce[RT][NT], acco[RT][NT];
 #pragma unroll
         for (int q = 0; q < RT; q++)
@@ -219,25 +223,14 @@ legendre_kernel(int lmax, int npair, int nring, int ncols, const double *__restr
                 acce[q][t] = (d4_t){0.0, 0.0, 0.0, 0.0};
                 acco[q][t] = (d4_t){0.0, 0.0, 0.0, 0.0};
             }
-        if (w.nstage > 0) {
+        {
             // rings are dealt to the waves interleaved (ring = tile base + 8 (ri + 16 q) + wave) so that every
             // wave of the workgroup has the same mix of first-contributing l and reaches the barriers together
-            double x[RT], p0[RT], p1[RT];
-            double2 sd[RT];
-            int my_ls[RT], inj_l[RT];
+            double p0[RT], p1[RT];
+            int inj_l[RT];
             int ls_min = lmax + 1;
 #pragma unroll
             for (int q = 0; q < RT; q++) {
-                const int ring = w.rtile * TRINGS + ring_in_tile(ri + 16 * q);
-                x[q] = 0.0;
-                my_ls[q] = lmax + 1;
-                sd[q] = make_double2(0.0, 0.0);
-                if (ring < npair) {
-                    x[q] = z[ring];
-                    const long o = (long)m * npair + ring;
-                    my_ls[q] = lstart[o];
-                    sd[q] = seed[4 * o + kq];
-                }
                 ls_min = min(ls_min, my_ls[q]);
                 // the lane's state is zero until its entry row (a window start of this lane group: >= l_begin + d)
                 p0[q] = 0.0;
@@ -319,13 +312,20 @@ legendre_kernel(int lmax, int npair, int nring, int ncols, const double *__restr
 #endif
         }
 
-        // ---- next item: start its first stages now, so they land behind this item's epilogue stores
-        const int cur_rtile = w.rtile, cur_cg = w.cg, cur_m = w.m, cur_nstage = w.nstage;
-        __syncthreads();  // all waves are done reading the stage ring; s_next is visible
-        item = __builtin_amdgcn_readfirstlane(s_next);
+        // ---- next item: queue fetch for the one after it, its ring state and its first stages now, in front of this
+        //      item's epilogue stores (see the note on the order above)
+        const int cur_rtile = w.rtile, cur_cg = w.cg, cur_m = w.m;
+        __syncthreads();  // all waves are done reading the stage ring; s_next[slot] (written during the previous boundary) is visible
+        item = __builtin_amdgcn_readfirstlane(s_next[slot]);
         const bool have_next = item < nitems;
+        unsigned fetched = 0;
+        double xn[RT];
+        int lsn[RT];
+        double2 sdn[RT];
         if (have_next) {
+            if (tid == 0) fetched = atomicAdd(queue, 1u);     // (its value is only needed behind the epilogue)
             w = decode(item);
+            load_rings(w, xn, lsn, sdn);
 #pragma unroll
             for (int st = 0; st < LEG_NBUF - 1; st++)
                 if (st < w.nstage) issue_stage(w, st);
@@ -334,8 +334,8 @@ legendre_kernel(int lmax, int npair, int nring, int ncols, const double *__restr
 
         // ---- epilogue: north = even + odd, south mirror = even - odd.  Adjacent lanes (columns n, n+1 of the
         //      same rows) swap one value each so that every lane stores 16 bytes: half the store instructions.
-        //      A tile with no contributing l at all is not written: K5 never reads cells with m >= mcut(ring).
-        if (cur_nstage > 0) {
+        //      (Tiles with no contributing l at all are not in the item list: K5 never reads cells with m >= mcut(ring).)
+        {
 #pragma unroll
             for (int q = 0; q < RT; q++)
 #pragma unroll
@@ -370,7 +370,11 @@ legendre_kernel(int lmax, int npair, int nring, int ncols, const double *__restr
         }
         LEG_STAMP(t_epi);
         if (!have_next) break;
-        __syncthreads();  // everyone has read s_next before thread 0 overwrites it
+        // the other slot: its last readers passed the barrier above
+        if (tid == 0) s_next[slot ^ 1] = clamp_item(nwg + fetched);
+        slot ^= 1;
+#pragma unroll
+        for (int q = 0; q < RT; q++) x[q] = xn[q], my_ls[q] = lsn[q], sd[q] = sdn[q];
         LEG_STAMP(t_bar2);
     }
 #if LEG_STAMPS
@@ -607,14 +611,17 @@ static int launch_legendre(corahip_ctx *ctx, const corahip_sht_plan *p, int ncol
     const size_t shm = sizeof(double) * LEG_NBUF * (LEG_KT * STRIDE + 2 * (LEG_KT + 8)) + 16;
     HIP_TRY(hipFuncSetAttribute((const void *)legendre_kernel<NT, RT>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)shm));
-    const int ntile = (p->npair + LEG_RINGS * RT - 1) / (LEG_RINGS * RT);
-    const long nitems = (long)p->L * (ncols / (16 * NT)) * ntile;
+    const int2 *d_items = nullptr;
+    int nitems = 0;
+    int rc = sht_k4_items(ctx, p, RT, ncols / (16 * NT), &d_items, &nitems);
+    if (rc) return rc;
+    if (nitems == 0) return 0;
     // persistent: as many workgroups as fit (LDS-limited: one per CU for NT = 8)
     const int per_cu = std::max<int>(1, std::min<int>(2, (int)((160 * 1024) / shm)));
     dim3 grid((unsigned)std::min<long>(nitems, (long)ctx->num_cu * per_cu));
     HIP_TRY(hipMemsetAsync(p->d_queue, 0, 1024, ctx->stream));
     legendre_kernel<NT, RT><<<grid, 64 * LEG_WAVES, shm, ctx->stream>>>(p->lmax, p->npair, p->nring, ncols, p->d_z,
-                                                                       p->d_coefmu, p->d_lstart, p->d_seed4, p->d_lmin,
+                                                                       p->d_coefmu, p->d_lstart, p->d_seed4, d_items, nitems,
                                                                        alm, p->d_zeros, inter, p->d_queue);
     LAUNCH_CHECK();
 #if LEG_STAMPS

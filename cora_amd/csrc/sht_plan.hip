@@ -318,6 +318,42 @@ static int dev_upload(T **dptr, const std::vector<T> &h, hipStream_t s) {
     return 0;
 }
 
+int sht_k4_items(corahip_ctx *ctx, const corahip_sht_plan *cp, int rt, int ncg, const int2 **items, int *nitems) {
+    corahip_sht_plan *p = const_cast<corahip_sht_plan *>(cp);      // (lazy caches of the plan)
+    const auto key = std::make_pair(rt, ncg);
+    auto it = p->k4_items.find(key);
+    if (it == p->k4_items.end()) {
+        const int ntile128 = (p->npair + LMIN_RINGS - 1) / LMIN_RINGS;
+        if (p->h_lmin.empty()) {
+            p->h_lmin.resize((size_t)p->L * ntile128);
+            HIP_TRY(hipMemcpyAsync(p->h_lmin.data(), p->d_lmin, sizeof(int32_t) * p->h_lmin.size(), hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
+        }
+        const int trings = LEG_RINGS * rt;
+        const int ntile = (p->npair + trings - 1) / trings;
+        ARG_CHECK(p->lmax < (1 << 15) && ntile <= 256 && ncg <= 256);
+        std::vector<int2> list;
+        list.reserve((size_t)p->L * ncg * ntile);
+        for (int m = 0; m <= p->lmax; m++)
+            for (int cg = 0; cg < ncg; cg++)
+                for (int t = 0; t < ntile; t++) {
+                    int lmin = p->lmax + 1;
+                    const int t_first = (t * trings) / LMIN_RINGS;
+                    const int t_last = std::min((t * trings + trings - 1) / LMIN_RINGS, ntile128 - 1);
+                    for (int t128 = t_first; t128 <= t_last; t128++) lmin = std::min(lmin, p->h_lmin[(size_t)m * ntile128 + t128]);
+                    if (lmin <= p->lmax) list.push_back(make_int2(m | (t << 15) | (cg << 23), lmin));
+                }
+        int2 *d = nullptr;
+        HIP_TRY(hipMalloc((void **)&d, sizeof(int2) * std::max<size_t>(1, list.size())));
+        HIP_TRY(hipMemcpyAsync(d, list.data(), sizeof(int2) * list.size(), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        it = p->k4_items.emplace(key, std::make_pair(d, (int)list.size())).first;
+    }
+    *items = it->second.first;
+    *nitems = it->second.second;
+    return 0;
+}
+
 extern "C" {
 
 int corahip_sht_plan_destroy(corahip_ctx *ctx, corahip_sht_plan *p) {
@@ -333,6 +369,7 @@ int corahip_sht_plan_destroy(corahip_ctx *ctx, corahip_sht_plan *p) {
     (void)hipFree(p->d_coefmu);
     (void)hipFree(p->d_seedmu);
     (void)hipFree(p->d_seed4);
+    for (auto &kv : p->k4_items) (void)hipFree(kv.second.first);
     (void)hipFree(p->d_tw);
     (void)hipFree(p->d_zeros);
     (void)hipFree(p->d_lmin);
