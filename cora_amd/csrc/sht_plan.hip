@@ -645,7 +645,9 @@ int corahip_sht_plan_create_ex(corahip_ctx *ctx, int nside, int lmax, int cut_ex
             // it still holds 2 h - 1, and P = 8192 itself (their 16 x 16 x 32 schedule differs from the generic passes)
             const int P3 = 3 * (P / 4);
             int alt = 0;
-            if ((P3 == 1536 || P3 == 3072 || P3 == 6144) && P3 >= 2 * h - 1) alt = P3;
+            if (P == 4096 && 2560 >= 2 * h - 1 && !getenv("CORAHIP_K5_NO57")) alt = 2560;          // 5 * 2^9
+            else if ((P3 == 1536 || P3 == 3072 || P3 == 6144) && P3 >= 2 * h - 1) alt = P3;
+            else if (P == 4096 && 3584 >= 2 * h - 1 && !getenv("CORAHIP_K5_NO57")) alt = 3584;     // 7 * 2^9
             else if (P == 8192) alt = P;
             if (alt) {
                 p->h_blu3_P[i - 1] = alt;
@@ -673,9 +675,10 @@ int corahip_sht_plan_create_ex(corahip_ctx *ctx, int nside, int lmax, int cut_ex
                 if (!is_pow2(h)) {
                     P = 1;
                     while (P < 2 * h - 1) P <<= 1;
-                    // rings with a compile-time length of their own (3 P / 4: code 1; P in the compile-time order: 2)
+                    // rings with a compile-time length of their own (3 P / 4: code 1; P in the compile-time order: 2;
+                    // 5 P / 8: 3; 7 P / 8: 4)
                     const int alt = p->h_blu3_P[icap - 1];
-                    P = 4 * P + (alt == 0 ? 0 : (alt == P ? 2 : 1));
+                    P = 8 * P + (alt == 0 ? 0 : (alt == P ? 2 : (alt == 3 * (P / 4) ? 1 : (alt == 5 * (P / 8) ? 3 : 4))));
                 }
             }
             by_len[P].push_back(r);
@@ -684,8 +687,11 @@ int corahip_sht_plan_create_ex(corahip_ctx *ctx, int nside, int lmax, int cut_ex
         if (getenv("CORAHIP_K5_LDS_KB")) lds_budget = (size_t)atoi(getenv("CORAHIP_K5_LDS_KB")) * 1024;
         for (auto &kv : by_len) {
             corahip_sht_plan::ring_class c;
-            c.P = kv.first > 0 ? kv.first / 4 : 0;
-            c.P3 = kv.first > 0 ? ((kv.first & 3) == 1 ? 3 * (c.P / 4) : ((kv.first & 3) == 2 ? c.P : 0)) : 0;
+            c.P = kv.first > 0 ? kv.first / 8 : 0;
+            {
+                const int code = kv.first > 0 ? (kv.first & 7) : 0;
+                c.P3 = code == 1 ? 3 * (c.P / 4) : (code == 2 ? c.P : (code == 3 ? 5 * (c.P / 8) : (code == 4 ? 7 * (c.P / 8) : 0)));
+            }
             c.N = kv.first < 0 ? -kv.first : 0;
             c.bstride = fpad_len(c.P ? c.P : 2 * nside + 1) + K5_CH_SKEW;
             c.nch = 4;

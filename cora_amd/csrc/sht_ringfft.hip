@@ -496,7 +496,7 @@ int sht_ringfft(corahip_ctx *ctx, const corahip_sht_plan *p, const double *inter
         const corahip_sht_plan::ring_class *pb = nullptr, *pc = nullptr;
         for (const auto &c : p->classes) {
             if (c.P == 0 && c.N > 0) pb = &c;
-            if (c.P == 4096) pc = &c;
+            if (c.P == 4096 && c.P3 == 0) pc = &c;
         }
         bool paired = false;
         if (pb && pc && !class_times) {

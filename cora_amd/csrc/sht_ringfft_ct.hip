@@ -63,6 +63,17 @@ struct Sch<1536> {
     static constexpr int R0 = 12, R1 = 16, R2 = 8;
 };
 
+// 5 * 2^9 and 7 * 2^9 (round 4): of the rings whose 2 h - 1 needs more than 2048, those up to 2560 / between 3072 and
+// 3584 get a length 17 % / 12.5 % shorter than 3072 / 4096.  Radix 10 / 14 in the first, strided pass (stride 256)
+template <>
+struct Sch<2560> {
+    static constexpr int R0 = 10, R1 = 16, R2 = 16;
+};
+template <>
+struct Sch<3584> {
+    static constexpr int R0 = 14, R1 = 16, R2 = 16;
+};
+
 // cfg-5 geometry (nside 2048): the cap rings 1025 .. 2047 need Bluestein lengths above 4096, one channel per workgroup
 // (152 KB).  Three passes with the large radix (32, 24 = 3 * 8) in the FIRST, strided pass - half of whose inputs are
 // the zero padding, as half of the last inverse pass's outputs do not exist - and the register-fused middle stage at
@@ -104,6 +115,90 @@ struct DftR<12, SIGN> {
         }
 #pragma unroll
         for (int k = 0; k < 12; k++) x[k] = y[k];
+    }
+};
+
+// 5- and 7-point DFTs (w = e^{SIGN 2 pi i / R}) through the sums / differences of the pairs (j, R - j): X_k = a_k + SIGN i b_k,
+// X_{R-k} = a_k - SIGN i b_k with a_k = x_0 + sum_j cos(2 pi j k / R) (x_j + x_{R-j}), b_k = sum_j sin(2 pi j k / R) (x_j - x_{R-j})
+template <int SIGN>
+__device__ __forceinline__ static void dft5(double2 (&x)[5]) {
+    constexpr double c1 = 0.30901699437494742410, c2 = -0.80901699437494742410;   // cos(2 pi / 5), cos(4 pi / 5)
+    constexpr double s1 = 0.95105651629515357212, s2 = 0.58778525229247312917;    // sin(2 pi / 5), sin(4 pi / 5)
+    const double2 t1 = cadd(x[1], x[4]), t2 = cadd(x[2], x[3]), t3 = csub(x[1], x[4]), t4 = csub(x[2], x[3]);
+    const double2 a1 = make_double2(fma(c2, t2.x, fma(c1, t1.x, x[0].x)), fma(c2, t2.y, fma(c1, t1.y, x[0].y)));
+    const double2 a2 = make_double2(fma(c1, t2.x, fma(c2, t1.x, x[0].x)), fma(c1, t2.y, fma(c2, t1.y, x[0].y)));
+    const double2 b1 = make_double2(fma(s2, t4.x, s1 * t3.x), fma(s2, t4.y, s1 * t3.y));
+    const double2 b2 = make_double2(fma(-s1, t4.x, s2 * t3.x), fma(-s1, t4.y, s2 * t3.y));
+    const double2 ib1 = cmuli<SIGN>(b1), ib2 = cmuli<SIGN>(b2);
+    x[0] = cadd(x[0], cadd(t1, t2));
+    x[1] = cadd(a1, ib1);
+    x[4] = csub(a1, ib1);
+    x[2] = cadd(a2, ib2);
+    x[3] = csub(a2, ib2);
+}
+template <int SIGN>
+__device__ __forceinline__ static void dft7(double2 (&x)[7]) {
+    constexpr double c[4] = {1.0, 0.62348980185873353053, -0.22252093395631440429, -0.90096886790241912624};   // cos(2 pi k / 7)
+    constexpr double sn[4] = {0.0, 0.78183148246802980871, 0.97492791218182360702, 0.43388373911755812048};  // sin(2 pi k / 7)
+    const double2 t[4] = {x[0], cadd(x[1], x[6]), cadd(x[2], x[5]), cadd(x[3], x[4])};
+    const double2 d[4] = {x[0], csub(x[1], x[6]), csub(x[2], x[5]), csub(x[3], x[4])};
+    double2 y[7];
+    y[0] = cadd(cadd(x[0], t[1]), cadd(t[2], t[3]));
+#pragma unroll
+    for (int k = 1; k <= 3; k++) {
+        double2 a = x[0], b = make_double2(0.0, 0.0);
+#pragma unroll
+        for (int j = 1; j <= 3; j++) {
+            const int q = (j * k) % 7;                       // cos(2 pi q / 7) = c[min(q, 7 - q)], sin = +- sn[min(q, 7 - q)]
+            const double cc = c[q <= 3 ? q : 7 - q], ss = q <= 3 ? sn[q] : -sn[7 - q];
+            a = make_double2(fma(cc, t[j].x, a.x), fma(cc, t[j].y, a.y));
+            b = make_double2(fma(ss, d[j].x, b.x), fma(ss, d[j].y, b.y));
+        }
+        const double2 ib = cmuli<SIGN>(b);
+        y[k] = cadd(a, ib);
+        y[7 - k] = csub(a, ib);
+    }
+#pragma unroll
+    for (int k = 0; k < 7; k++) x[k] = y[k];
+}
+// 10- and 14-point DFTs, natural order in and out, by the prime-factor map (no twiddles between the two stages):
+// n = (R n1 + 2 n2) mod 2R, k = (R k1 + 2 (2^{-1} mod R) k2) mod 2R with R = 5 / 7 - DFT2 over n1, DFT_R over n2
+template <int SIGN>
+struct DftR<10, SIGN> {
+    __device__ __forceinline__ static void run(double2 (&x)[10]) {
+        double2 u0[5], u1[5];
+#pragma unroll
+        for (int n2 = 0; n2 < 5; n2++) {
+            const double2 a = x[(2 * n2) % 10], b = x[(5 + 2 * n2) % 10];
+            u0[n2] = cadd(a, b);
+            u1[n2] = csub(a, b);
+        }
+        dft5<SIGN>(u0);
+        dft5<SIGN>(u1);
+#pragma unroll
+        for (int k2 = 0; k2 < 5; k2++) {
+            x[(6 * k2) % 10] = u0[k2];
+            x[(5 + 6 * k2) % 10] = u1[k2];
+        }
+    }
+};
+template <int SIGN>
+struct DftR<14, SIGN> {
+    __device__ __forceinline__ static void run(double2 (&x)[14]) {
+        double2 u0[7], u1[7];
+#pragma unroll
+        for (int n2 = 0; n2 < 7; n2++) {
+            const double2 a = x[(2 * n2) % 14], b = x[(7 + 2 * n2) % 14];
+            u0[n2] = cadd(a, b);
+            u1[n2] = csub(a, b);
+        }
+        dft7<SIGN>(u0);
+        dft7<SIGN>(u1);
+#pragma unroll
+        for (int k2 = 0; k2 < 7; k2++) {
+            x[(8 * k2) % 14] = u0[k2];
+            x[(7 + 8 * k2) % 14] = u1[k2];
+        }
     }
 };
 
@@ -882,6 +977,8 @@ int sht_ringfft_ct(corahip_ctx *ctx, const corahip_sht_plan *p, const corahip_sh
         else if (c.P3 == 6144) rc = launch_blu<6144, 1, 16, 256>(ctx, st, 0, p, c, inter, G, nnu, maps, p->d_blu3_foff, p->d_bfilt3);
         else if (half && c.P3 == 3072 && !no3) rc = launch_blu<3072, 1, 8, 256>(ctx, st, 0, p, c, inter, G, nnu, maps, p->d_blu3_foff, p->d_bfilt3);
         else if (half && c.P3 != 1536 && c.P == 4096) rc = launch_blu<4096, 1, 8, 256>(ctx, st, 0, p, c, inter, G, nnu, maps);
+        else if (c.P3 == 2560 && !no3) rc = launch_blu<2560, 2, 4, 512>(ctx, st, 0, p, c, inter, G, nnu, maps, p->d_blu3_foff, p->d_bfilt3);
+        else if (c.P3 == 3584 && !no3) rc = launch_blu<3584, 2, 4, 512>(ctx, st, 0, p, c, inter, G, nnu, maps, p->d_blu3_foff, p->d_bfilt3);
         else if (c.P3 == 3072 && !no3) rc = launch_blu<3072, 2, 4, 512>(ctx, st, 0, p, c, inter, G, nnu, maps, p->d_blu3_foff, p->d_bfilt3);
         else if (c.P3 == 1536 && !no3) rc = launch_blu<1536, 4, 2, 512>(ctx, st, 0, p, c, inter, G, nnu, maps, p->d_blu3_foff, p->d_bfilt3);
         else if (c.P == 4096) rc = launch_blu<4096, 2, 4, 512>(ctx, st, 0, p, c, inter, G, nnu, maps);
@@ -916,7 +1013,7 @@ int sht_ringfft_ct_pair(corahip_ctx *ctx, const corahip_sht_plan *p, const corah
     // full width - the half-width kernels lose more per item than the overlap returns - so the pairing is OFF unless
     // CORAHIP_K5_PAIR is set; kept for the record and for other shapes.
     static const bool on = getenv("CORAHIP_K5_PAIR") != nullptr && getenv("CORAHIP_K5_GENERIC") == nullptr;
-    if (!on || !(belt.P == 0 && belt.N == 2048 && cap.P == 4096)) return 0;
+    if (!on || !(belt.P == 0 && belt.N == 2048 && cap.P == 4096 && cap.P3 == 0)) return 0;
     int rcs = sht_second_stream(ctx);
     if (rcs) return rcs;
     HIP_TRY(hipEventRecord(ctx->ev_fork, ctx->stream));
@@ -985,7 +1082,9 @@ int sht_blu3_tables(corahip_ctx *ctx, corahip_sht_plan *p, int64_t total) {
         LAUNCH_CHECK();                                                                                                   \
     }
     BLU3_LAUNCH(1536)
+    BLU3_LAUNCH(2560)
     BLU3_LAUNCH(3072)
+    BLU3_LAUNCH(3584)
     if (p->nside > 1024) {
         BLU3_LAUNCH(6144)
         BLU3_LAUNCH(8192)
