@@ -32,7 +32,7 @@ struct corahip_linefft_plan {
     double2 *rtw = nullptr;    // [n/2 + 1]  e^{+2 pi i k / 2n}: (un)packing of a real transform of length 2n
 };
 
-#define CORAHIP_NSCRATCH 7
+#define CORAHIP_NSCRATCH 8
 struct corahip_ctx {
     int device = 0;
     hipStream_t stream = nullptr;

@@ -550,6 +550,245 @@ chol_ll_kernel(const double *__restrict__ C, int F, double jitter_rel, double *_
 }
 
 // ------------------------------------------------------------------------------------
+// COOPERATIVE form of the left-looking factorisation for the last few matrices of a batch (round 4).  chol_ll_kernel
+// gives a matrix one workgroup, two of them share a CU: 513 matrices of F = 1024 (a cfg-5 rank: L = 8 x 512 + 1) are two
+// rounds of 512 and a third in which ONE workgroup works for 4.4 ms while 255 CUs idle.  Here G workgroups (4 G waves)
+// share a matrix: the 32 x 32 tiles of a block column are dealt over all their waves (one tile each: 4 G >= F / 32),
+// the diagonal tile is factored by the first wave and published through the output matrix, the rows of the panel
+// solve are dealt over all threads; two device-scope barriers per block column (arrival counter in global memory, one
+// spinning thread per workgroup - the grid is at most one workgroup per CU and is launched behind the batch kernel on
+// the same stream, so its workgroups are co-resident).  Same arithmetic per tile as the 32 x 32 form of chol_ll_kernel.
+// ------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+chol_coop_kernel(const double *__restrict__ C, int F, double jitter_rel, double *T, int32_t *__restrict__ info, int mat0, int nrem,
+                 int G, unsigned *bar, int *gflag, double *rd, int *xcc_min, int *xcc_max) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    double *D = lds;                                   // [32][33] diagonal block
+    double *red = lds + CH_NB * (CH_NB + 1);           // [256] reduction scratch
+    double *rdiag = red + 256 + 2;                     // [32] 1 / L_jj of the diagonal block
+    double *stage = rdiag + CH_NB;                     // per wave: A block [32][CHM_S], B block [32][CHM_S]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ri = lane & 15, kq = lane >> 4;
+    // The G workgroups of a matrix are blocks with equal blockIdx % 8: under the round-robin dispatch of workgroups over
+    // the eight XCDs they share ONE L2, and a barrier between them needs no L2 write-back / invalidate (an agent-scope
+    // fence does both on gfx942 / gfx950 - the L2s of different XCDs are not coherent for ordinary device memory).
+    // That placement is a property of the dispatcher, not a guarantee: every workgroup publishes its XCC_ID and the
+    // group takes the cheap barrier only if all of them agree (otherwise agent-scope fences: slower, still correct).
+    const int xslot = blockIdx.x >> 3;
+    const int mi = (xslot / G) * 8 + (blockIdx.x & 7), wgl = xslot % G;   // matrix of the remainder, workgroup within its group
+    if (mi >= nrem) return;
+    const int gw = 4 * wgl + wave, NW = 4 * G;                  // this wave among the waves of the matrix
+    const size_t off = (size_t)(mat0 + mi) * F * F;
+    const double *A = C + off;
+    double *Tl = T + off;
+    double *PA = stage + (size_t)wave * 2 * 32 * CHM_S, *PB = PA + 32 * CHM_S;
+
+    double dmax = -INFINITY;
+    for (int i = tid; i < F; i += 256) dmax = fmax(dmax, A[(size_t)i * F + i]);
+    red[tid] = dmax;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) red[tid] = fmax(red[tid], red[tid + s]);
+        __syncthreads();
+    }
+    const double jit = red[0] * jitter_rel;
+    __syncthreads();
+
+    unsigned nsync = 0;
+    bool same_xcc = false;
+    // barrier over the G workgroups of this matrix; writes before it are visible behind it.
+    // same_xcc: the stores are in the shared L2 once they are acknowledged (write-through L1), and no CU holds a stale
+    // L1 line of anything read behind the barrier: a tile's lines are read by another CU only after they are final
+    // (the panel solve reads and rewrites a row in ONE thread), and the words that ARE rewritten (1 / diag, the failure
+    // flag, the counter) are read with device-scope atomic loads.
+    auto group_sync = [&]() {
+        if (same_xcc) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        else __threadfence();
+        __syncthreads();
+        nsync++;
+        if (tid == 0) {
+            __hip_atomic_fetch_add(&bar[mi], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            while (__hip_atomic_load(&bar[mi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nsync * (unsigned)G)
+                __builtin_amdgcn_s_sleep(2);
+        }
+        __syncthreads();
+        if (!same_xcc) __threadfence();
+    };
+    {
+        const int xcc = (int)__builtin_amdgcn_s_getreg((3 << 11) | 20) & 15;     // HW_REG_XCC_ID, bits 3:0
+        if (tid == 0) {
+            __hip_atomic_fetch_min(&xcc_min[mi], xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_max(&xcc_max[mi], xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        group_sync();
+        same_xcc = __hip_atomic_load(&xcc_min[mi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ==
+                   __hip_atomic_load(&xcc_max[mi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+
+    const int nblk = (F + 31) / 32;
+    const int srow = lane >> 1, scol = 16 * (lane & 1);
+    auto load_block = [&](int row0, int col0, double2 (&v)[8]) {
+        const double *src = Tl + (size_t)(row0 + srow < F ? row0 + srow : 0) * F + col0 + scol;
+#pragma unroll
+        for (int q = 0; q < 8; q++) v[q] = *reinterpret_cast<const double2 *>(src + 2 * q);
+    };
+    auto store_block = [&](double *P, const double2 (&v)[8], double sign, int row0) {
+        const double sg = row0 + srow < F ? sign : 0.0;
+#pragma unroll
+        for (int q = 0; q < 8; q++)
+            *reinterpret_cast<double2 *>(P + srow * CHM_S + scol + 2 * q) = make_double2(sg * v[q].x, sg * v[q].y);
+    };
+    int failed = 0;
+    for (int j = 0; j < nblk; j++) {
+        const int kb = 32 * j;
+        const int nb = min(CH_NB, F - kb);
+        // ---- A. tiles (i >= j, j): input block minus the products of the factor blocks to the left (one tile per wave)
+        for (int i = j + gw; i < nblk; i += NW) {
+            const int i0 = 32 * i;
+            d4_t acc[2][2];
+#pragma unroll
+            for (int a = 0; a < 2; a++)
+#pragma unroll
+                for (int b = 0; b < 2; b++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const int row = i0 + 16 * a + kq + 4 * r, col = kb + 16 * b + ri;
+                        double v = 0.0;
+                        if (row < F && col <= row) v = A[(size_t)row * F + col] + (row == col ? jit : 0.0);
+                        acc[a][b][r] = v;
+                    }
+            if (j > 0) {
+                double2 va[8], vb[8];
+                load_block(i0, 0, va);
+                load_block(kb, 0, vb);
+                for (int k = 0; k < j; k++) {
+                    store_block(PA, va, -1.0, i0);
+                    store_block(PB, vb, 1.0, kb);
+                    if (k + 1 < j) {
+                        load_block(i0, 32 * (k + 1), va);
+                        load_block(kb, 32 * (k + 1), vb);
+                    }
+#pragma unroll
+                    for (int s = 0; s < 8; s++) {
+                        double af[2], bf[2];
+#pragma unroll
+                        for (int a = 0; a < 2; a++) {
+                            af[a] = PA[(16 * a + ri) * CHM_S + 4 * s + kq];
+                            bf[a] = PB[(16 * a + ri) * CHM_S + 4 * s + kq];
+                        }
+#pragma unroll
+                        for (int a = 0; a < 2; a++)
+#pragma unroll
+                            for (int b = 0; b < 2; b++)
+                                acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[a], bf[b], acc[a][b], 0, 0, 0);
+                    }
+                }
+            }
+            if (i == j) {      // (first wave of the group) the diagonal tile goes to LDS
+#pragma unroll
+                for (int a = 0; a < 2; a++)
+#pragma unroll
+                    for (int b = 0; b < 2; b++)
+#pragma unroll
+                        for (int r = 0; r < 4; r++) D[(16 * a + kq + 4 * r) * (CH_NB + 1) + 16 * b + ri] = acc[a][b][r];
+            } else {           // stored for the solve; its mirror tile of the upper triangle is zeroed
+#pragma unroll
+                for (int a = 0; a < 2; a++)
+#pragma unroll
+                    for (int b = 0; b < 2; b++)
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            const int row = i0 + 16 * a + kq + 4 * r, col = kb + 16 * b + ri;
+                            if (row < F && col < F) Tl[(size_t)row * F + col] = acc[a][b][r];
+                        }
+                if (kb + srow < F) {
+                    double *z = Tl + (size_t)(kb + srow) * F + i0 + scol;
+#pragma unroll
+                    for (int q = 0; q < 8; q++)
+                        if (i0 + scol + 2 * q < F) *reinterpret_cast<double2 *>(z + 2 * q) = make_double2(0.0, 0.0);
+                }
+            }
+        }
+        // ---- B. the first wave factors the diagonal block (row i in the registers of lane i) and publishes it
+        if (gw == 0) {
+            auto bcast = [](double v, int src) {
+                const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+                const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+                return __hiloint2double(hi, lo);
+            };
+            double row[CH_NB];
+#pragma unroll
+            for (int k = 0; k < CH_NB; k++) row[k] = (lane < nb && k <= lane) ? D[lane * (CH_NB + 1) + k] : 0.0;
+            bool bad = false;
+#pragma unroll
+            for (int jj = 0; jj < CH_NB; jj++) {
+                if (jj < nb && !bad) {
+                    const double d = bcast(row[jj], jj);
+                    if (!(d > 0.0)) {
+                        bad = true;
+                    } else {
+                        double y = __builtin_amdgcn_rsq(d);
+                        const double hd = 0.5 * d;
+                        y = fma(y, fma(-hd * y, y, 0.5), y);
+                        y = fma(y, fma(-hd * y, y, 0.5), y);
+                        const double lij = row[jj] * y;
+                        row[jj] = lij;
+                        if (lane == jj) __hip_atomic_store(&rd[mi * CH_NB + jj], y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                        for (int k = jj + 1; k < CH_NB; k++) row[k] = fma(-lij, bcast(lij, k), row[k]);
+                    }
+                }
+            }
+            if (lane < nb) {
+                double *o = Tl + (size_t)(kb + lane) * F + kb;
+#pragma unroll
+                for (int k = 0; k < CH_NB; k++)
+                    if (k < nb) o[k] = k <= lane ? row[k] : 0.0;
+            }
+            if (bad && lane == 0) __hip_atomic_store(&gflag[mi], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        group_sync();
+        failed = __hip_atomic_load(&gflag[mi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (failed) break;
+        // ---- C. every workgroup takes L_jj and 1 / diag into its LDS and solves its share of the rows below, in place
+        for (int q = tid; q < CH_NB * CH_NB; q += 256) {
+            const int i = q >> 5, jj = q & 31;
+            D[i * (CH_NB + 1) + jj] = (i < nb && jj <= i) ? Tl[(size_t)(kb + i) * F + kb + jj] : 0.0;
+        }
+        if (tid < CH_NB) rdiag[tid] = tid < nb ? __hip_atomic_load(&rd[mi * CH_NB + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+        __syncthreads();
+        for (int r = kb + nb + wgl * 256 + tid; r < F; r += 256 * G) {
+            double x[CH_NB];
+            double *row = Tl + (size_t)r * F + kb;
+#pragma unroll
+            for (int jj = 0; jj < CH_NB; jj += 2) {
+                const double2 v = *reinterpret_cast<const double2 *>(row + jj);
+                x[jj] = v.x;
+                x[jj + 1] = v.y;
+            }
+#pragma unroll
+            for (int jj = 0; jj < CH_NB; jj++) {
+                if (jj < nb) {
+                    double s[4] = {x[jj], 0.0, 0.0, 0.0};
+#pragma unroll
+                    for (int p = 0; p < CH_NB; p++)
+                        if (p < jj) s[p & 3] = fma(-x[p], D[jj * (CH_NB + 1) + p], s[p & 3]);
+                    x[jj] = ((s[0] + s[1]) + (s[2] + s[3])) * rdiag[jj];
+                }
+            }
+#pragma unroll
+            for (int jj = 0; jj < CH_NB; jj += 2) *reinterpret_cast<double2 *>(row + jj) = make_double2(x[jj], x[jj + 1]);
+        }
+        group_sync();       // the block column is final for every workgroup of the group
+    }
+    if (wgl == 0 && tid == 0) {
+        info[mat0 + mi] = failed;
+        xcc_max[mi] = same_xcc ? 0x100 : 0x200;       // (diagnostics: which barrier the group took - CORAHIP_K2_COOP_DEBUG)
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // eigen branch: parallel cyclic Jacobi on Cm = C + jitter (symmetric), one workgroup per
 // listed matrix.  W = working copy of Cm [F][F], V = eigenvectors [F][F] (global scratch).
 // root = V * sqrt(max(lambda,0) thresholded), columns ordered by ascending eigenvalue
@@ -720,9 +959,47 @@ extern "C" int corahip_factor_batched(corahip_ctx *ctx, const double *C, int nl,
         static const char *tall_env = getenv("CORAHIP_K2_TALL");
         const bool tall = tall_env ? atoi(tall_env) != 0 : F >= 384;
         const size_t shm = sizeof(double) * (CH_NB * (CH_NB + 1) + 256 + 2 + CH_NB + (tall ? 6 : 8) * 32 * CHM_S) + 16;
+        // The last nl mod (2 x CUs) matrices of a tall batch, if they are few, go to the cooperative kernel behind the batch:
+        // a straggler round of the one-workgroup form costs a whole single-matrix latency (4.4 ms at F = 1024) for them.
+        // CORAHIP_K2_COOP=0 switches it off (A/B).
+        const char *coop_env = getenv("CORAHIP_K2_COOP");   // (read per call: the tests switch it)
+        const int nblk = (F + 31) / 32;
+        const int G = (nblk + 3) / 4;                      // one tile per wave in every block column
+        int nrem = 0;
+        if (tall && (F % 32) == 0 && !(coop_env && atoi(coop_env) == 0) && !CHM_STAMPS) {
+            const int slots = 2 * ctx->num_cu;
+            const int r = nl % slots;
+            if (nl > slots && r > 0 && ((r + 7) / 8) * 8 * G <= ctx->num_cu && r <= 16) nrem = r;
+            if (coop_env && atoi(coop_env) == 2 && ((nl + 7) / 8) * 8 * G <= ctx->num_cu) nrem = nl;     // (tests: every matrix through the cooperative kernel)
+        }
+        const int nmain = nl - nrem;
         if (tall) {
             HIP_TRY(hipFuncSetAttribute((const void *)chol_ll_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-            chol_ll_kernel<true><<<nl, 256, shm, ctx->stream>>>(C, F, jitter_rel, T, info);
+            if (nmain > 0) chol_ll_kernel<true><<<nmain, 256, shm, ctx->stream>>>(C, F, jitter_rel, T, info);
+            if (nrem > 0) {
+                void *ws = nullptr;
+                const size_t wsb = (size_t)nrem * (sizeof(unsigned) + 3 * sizeof(int) + CH_NB * sizeof(double)) + 64;
+                int rcs = corahip_ctx_scratch(ctx, 7, wsb, &ws);
+                if (rcs) return rcs;
+                HIP_TRY(hipMemsetAsync(ws, 0, wsb, ctx->stream));
+                double *rd = reinterpret_cast<double *>(ws);
+                unsigned *bar = reinterpret_cast<unsigned *>(rd + (size_t)nrem * CH_NB);
+                int *gflag = reinterpret_cast<int *>(bar + nrem);
+                int *xmin = gflag + nrem, *xmax = xmin + nrem;
+                HIP_TRY(hipMemsetAsync(xmin, 0x7f, sizeof(int) * nrem, ctx->stream));   // (min starts high; max at 0)
+                const size_t shm2 = sizeof(double) * (CH_NB * (CH_NB + 1) + 256 + 2 + CH_NB + 8 * 32 * CHM_S) + 16;
+                HIP_TRY(hipFuncSetAttribute((const void *)chol_coop_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm2));
+                chol_coop_kernel<<<((nrem + 7) / 8) * 8 * G, 256, shm2, ctx->stream>>>(C, F, jitter_rel, T, info, nmain, nrem, G, bar, gflag, rd,
+                                                                                     xmin, xmax);
+                if (getenv("CORAHIP_K2_COOP_DEBUG")) {
+                    std::vector<int> hx(nrem);
+                    HIP_TRY(hipMemcpyAsync(hx.data(), xmax, sizeof(int) * nrem, hipMemcpyDeviceToHost, ctx->stream));
+                    HIP_TRY(hipStreamSynchronize(ctx->stream));
+                    int same = 0;
+                    for (int v : hx) same += v == 0x100;
+                    fprintf(stderr, "K2 cooperative kernel: %d matrices, %d workgroups each, %d groups on one XCC\n", nrem, G, same);
+                }
+            }
         } else {
             HIP_TRY(hipFuncSetAttribute((const void *)chol_ll_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
             chol_ll_kernel<false><<<nl, 256, shm, ctx->stream>>>(C, F, jitter_rel, T, info);

@@ -210,7 +210,7 @@ legendre_kernel(int lmax, int npair, int nring, int ncols, const double *__restr
 
 #if LEG_STAMPS
     unsigned long long leg_last, t_pro = 0, t_head = 0, t_clean = 0, t_tail = 0, t_bnd = 0, t_epi = 0, t_bar2 = 0;
-    unsigned long long n_head = 0, n_clean = 0, n_tail = 0, n_items = 0;
+    unsigned long long n_head = 0, n_clean = 0, n_tail = 0, n_items = 0, t_tbar = 0, n_tail_ms = 0;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(leg_last)::"memory");
 #endif
     for (;;) {
@@ -383,6 +383,7 @@ legendre_kernel(int lmax, int npair, int nring, int ncols, const double *__restr
         atomicAdd(&g_leg_stamps[3], t_tail), atomicAdd(&g_leg_stamps[4], t_bnd), atomicAdd(&g_leg_stamps[5], t_epi);
         atomicAdd(&g_leg_stamps[6], t_bar2), atomicAdd(&g_leg_stamps[7], n_head), atomicAdd(&g_leg_stamps[8], n_clean);
         atomicAdd(&g_leg_stamps[9], n_tail), atomicAdd(&g_leg_stamps[10], n_items);
+        atomicAdd(&g_leg_stamps[11], t_tbar), atomicAdd(&g_leg_stamps[12], n_tail_ms);
     }
 #endif
 }
@@ -630,7 +631,9 @@ static int launch_legendre(corahip_ctx *ctx, const corahip_sht_plan *p, int ncol
         HIP_TRY(hipStreamSynchronize(ctx->stream));
         HIP_TRY(hipMemcpyFromSymbol(hs, HIP_SYMBOL(g_leg_stamps), sizeof(hs)));
         HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_leg_stamps), zero, sizeof(zero)));
-        const double tot = (double)(hs[0] + hs[1] + hs[2] + hs[3] + hs[4] + hs[5] + hs[6]);
+        const double tot = (double)(hs[0] + hs[1] + hs[2] + hs[3] + hs[4] + hs[5] + hs[6] + hs[11]);
+        fprintf(stderr, "K4 stamps: tail stages: wait + barrier %.0f ticks per stage, %.2f macro-steps with MFMAs per stage\n",
+                hs[11] / std::max<double>(1.0, (double)hs[9]), hs[12] / std::max<double>(1.0, (double)hs[9]));
         fprintf(stderr, "K4 stamps <%d,%d> wg=%u items=%llu: prologue %.3f head %.3f (%llu st) clean %.3f (%llu st) tail %.3f (%llu st) "
                 "boundary %.3f epilogue %.3f barrier2 %.3f | ticks/item %.0f ticks/clean-stage %.0f ticks/head-stage %.0f ticks/tail-stage %.0f\n",
                 NT, RT, grid.x, hs[10], hs[0] / tot, hs[1] / tot, hs[7], hs[2] / tot, hs[8], hs[3] / tot, hs[9], hs[4] / tot, hs[5] / tot,

@@ -491,3 +491,35 @@ def test_rank_memory_model_against_torch_at_cfg3(ctx):
     print("cfg3 peak allocation %.1f GB, model %.1f GB" % (peak / 1e9, model / 1e9))
     assert 0.75 * model <= peak <= 1.25 * model, (peak, model)
     del shard
+
+
+def test_k2_cooperative_kernel_matches_one_workgroup_form(ctx, monkeypatch):
+    """The cooperative Cholesky (G workgroups per matrix: the straggler matrices of a tall batch, csrc/factor.hip
+    chol_coop_kernel) against the one-workgroup form on the same matrices, F = 1024 and 512: equal to rounding (same
+    tile arithmetic; the panel solve and the tile sums run in the same order), info flags equal - including a matrix
+    that is not positive definite, whose eigen-route root must come out the same - and T T^T = C."""
+    import torch
+
+    for F, nl, bad in ((1024, 3, False), (512, 5, False), (384, 4, True)):
+        A = ctx.empty((nl, F, F + 8)).normal_()
+        C = A @ A.transpose(1, 2) + 0.1 * torch.eye(F, device=ctx.device, dtype=torch.float64)
+        del A
+        if bad:
+            C[1, 300, 300] = -1.0                          # block 1: Cholesky fails in block column 300 / 32 (eigen route)
+        monkeypatch.setenv("CORAHIP_K2_COOP", "0")
+        T0, i0 = ctx.factor_batched(C)
+        T0, i0 = T0.clone(), i0.clone()
+        monkeypatch.setenv("CORAHIP_K2_COOP", "2")         # every matrix through the cooperative kernel
+        T1, i1 = ctx.factor_batched(C)
+        monkeypatch.delenv("CORAHIP_K2_COOP")
+        assert torch.equal(i0, i1), (i0, i1)
+        assert (int(i0[1].item()) != 0) == bad and int(i0[0].item()) == 0
+        scale = T0.abs().amax().item()
+        err = (T0 - T1).abs().amax().item() / scale
+        print("F=%d: cooperative vs one-workgroup Cholesky, max |dT| / max |T| = %.2e" % (F, err))
+        assert err <= 1e-13, (F, err)
+        for k in (0, nl - 1):
+            jit = C[k].diagonal().max() * 1e-14
+            res = (T1[k] @ T1[k].T - C[k] - jit * torch.eye(F, device=ctx.device, dtype=torch.float64)).abs().amax().item()
+            assert res <= 1e-12 * C[k].abs().amax().item(), (F, k, res)
+            assert torch.all(torch.triu(T1[k], 1) == 0)
