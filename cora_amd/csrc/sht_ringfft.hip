@@ -564,7 +564,7 @@ int sht_ringfft(corahip_ctx *ctx, const corahip_sht_plan *p, const double *inter
                 (void)hipEventRecord(ce1, ctx->stream);
                 (void)hipEventSynchronize(ce1);
                 (void)hipEventElapsedTime(&ms, ce0, ce1);
-                fprintf(stderr, "K5 class P=%d nch=%d rings=%d: %.3f ms\n", c.P, c.nch, c.count, ms);
+                fprintf(stderr, "K5 class P=%d (length %d) rings=%d: %.3f ms\n", c.P, c.P3 ? c.P3 : (c.P ? c.P : c.N), c.count, ms);
                 (void)hipEventDestroy(ce0);
                 (void)hipEventDestroy(ce1);
             }
