@@ -488,7 +488,7 @@ def seeded_modes(ctx, shard, cold_factors, F, lmax, barrier, steps):
     legacy = {"ms_per_step": lms, "maps_per_s": F / (lms * 1e-3), "stages_ms": lst,
               "rng": "rng=None: numpy's legacy global MT19937 + polar method (what Sky3d.getsky() draws from), continued on the "
                      "device: MT19937 cut into segments by GF(2) jump-ahead polynomials; same accepted attempts and generator "
-                     "state as numpy, values within 4 ulp",
+                     "state as numpy and - glibc's log restated operation by operation - the same values bit for bit",
               "host_numpy_would_take_s": nnorm / rate, "host_normals_per_s": rate}
     torch.cuda.synchronize()
     return seeded, legacy

@@ -208,7 +208,7 @@ def stream_normals(ctx, numz, maxl, rng):
     sequence, bit for bit) and left exactly where ``rng.standard_normal`` would have left it: its state is advanced by
     the number of raw draws the normals consumed.  ``rng=None`` - numpy's legacy global MT19937 + polar method, what the
     reference draws from when no generator is passed - and ``RandomState`` instances are continued on the device too
-    (``corahip_normals_mt19937_legacy``: the same accepted attempts and generator state, values within a few ulp).  Any
+    (``corahip_normals_mt19937_legacy``: the same accepted attempts, generator state and values - glibc's log is restated on the device).  Any
     other generator is consumed on the host and uploaded (:func:`_upload_host_normals`)."""
     n = 2 * numz * ((maxl + 1) * (maxl + 2) // 2)
     legacy = _legacy_state_of(rng)

@@ -11,8 +11,9 @@
 // An attempt ALWAYS consumes four 32-bit words: attempt a of a stream sits at words 4 a .. 4 a + 3, whatever happened
 // before - the accept decisions and every x are exact arithmetic on those words, so which attempts are accepted, and
 // with it the generator state afterwards, is numpy's bit for bit; the values go through log / sqrt / two divisions
-// (sqrt and division are correctly rounded here as in libm; log is the device library's, <= 1 ulp: a value may differ
-// from numpy's in its last bits - tests/test_gpu_npnormal.py bounds it at 4 ulp).
+// (sqrt and division are correctly rounded here as in libm; log is glibc's routine restated operation by operation -
+// glibc_log_fma below -: the values are numpy's bit for bit on a host whose libm is glibc's FMA build, within 4 ulp on any
+// other; tests/test_gpu_npnormal.py asserts whichever applies).
 //
 // MT19937 itself is the sequential part: x[k + 624] = x[k + 397] ^ twist(x[k], x[k + 1]).  It is linear over GF(2), so
 // the window J words on is g(T) applied to the window, g = x^J mod phi (phi the minimal polynomial, degree 19937):
@@ -185,6 +186,63 @@ mt_jump_kernel(unsigned *__restrict__ seg_state, long src0, long dst0, long coun
     }
 }
 
+// ---- glibc's log as numpy calls it -------------------------------------------------------------------------------------
+// legacy_gauss takes log(r2) from libm.  glibc's routine (sysdeps/ieee754/dbl-64/e_log.c: 128-entry table of (1 / c,
+// log c), degree-5 polynomial in r = z / c - 1; a degree-11 polynomial for 1 - 2^-4 <= x < 1 + 0x1.09p-4) in the
+// evaluation order of its FMA build - the one the loader selects on every CPU with FMA + AVX2 - operation by operation:
+// what is fused there is an fma here, what is separate stays separate (contraction off).  Constants: glibc_log_tab.inc
+// (tools/gen_glibc_log_tab.py reads them out of the installed libm).  For positive normal x (r2 >= 2^-104 here);
+// oracle/mtlegacy.py restates the same sequence and tests/test_oracle.py pins it to the host's log bit for bit.
+#include "glibc_log_tab.inc"
+__device__ const double2 g_glog_T[128] = GLIBC_LOG_T;
+__device__ inline double glibc_log_fma(double x) {
+#pragma clang fp contract(off)
+    constexpr double A[5] = GLIBC_LOG_A;
+    constexpr double B[11] = GLIBC_LOG_B;
+    const unsigned long long ix = (unsigned long long)__double_as_longlong(x);
+    if (ix - 0x3FEE000000000000ull <= 0x308FFFFFFFFFFull) {
+        if (x == 1.0) return 0.0;
+        const double r = x - 1.0;
+        double p2 = fma(r, B[2], B[1]);
+        double p3 = fma(r, B[5], B[4]);
+        const double r2 = r * r;
+        const double p5 = fma(r, B[8], B[7]);
+        p2 = fma(r2, B[3], p2);
+        p3 = fma(r2, B[6], p3);
+        const double r3 = r * r2;
+        double p1 = fma(r2, B[9], p5);
+        p1 = fma(r3, B[10], p1);
+        p1 = fma(p1, r3, p3);
+        p1 = fma(p1, r3, p2);
+        const double t = fma(r, 134217728.0, r);
+        const double rhi = fma(-134217728.0, r, t);
+        const double rhi2 = rhi * rhi;
+        const double rlo = r - rhi;
+        const double hi = fma(rhi2, B[0], r);
+        double lo = fma(rhi2, B[0], r - hi);
+        lo = fma(B[0] * rlo, r + rhi, lo);
+        return fma(p1, r3, lo) + hi;
+    }
+    const unsigned long long tmp = ix - 0x3FE6000000000000ull;
+    const int i = (int)(tmp >> 45) & 127;
+    const int k = (int)((long long)tmp >> 52);
+    const double z = __longlong_as_double((long long)(ix - (tmp & 0xFFF0000000000000ull)));
+    const double2 tc = g_glog_T[i];
+    const double kd = (double)k;
+    const double r = fma(z, tc.x, -1.0);
+    const double w = fma(kd, GLIBC_LOG_LN2HI, tc.y);
+    const double q = fma(r, A[2], A[1]);
+    const double hi = r + w;
+    const double r2 = r * r;
+    double lo = (w - hi) + r;
+    lo = fma(kd, GLIBC_LOG_LN2LO, lo);
+    const double r3 = r * r2;
+    double p = fma(r, A[4], A[3]);
+    lo = fma(r2, A[0], lo);
+    p = fma(p, r2, q);
+    return fma(r3, p, lo) + hi;
+}
+
 // ---- one attempt of the polar method from four words of the block --------------------------------------------------
 struct mt_attempt {
     double x1, x2, r2;
@@ -240,7 +298,7 @@ mt_segment_kernel(const unsigned *__restrict__ seg_state, long nseg, unsigned *_
                 if (in && t.ok) {
                     const unsigned long long o = ord + __builtin_amdgcn_mbcnt_hi((unsigned)(acc >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)acc, 0u));
                     if (o < pairs) {
-                        const double f = sqrt(-2.0 * log(t.r2) / t.r2);
+                        const double f = sqrt(-2.0 * glibc_log_fma(t.r2) / t.r2);     // (sqrt and the division are correctly rounded on both sides)
                         const double first = f * t.x2, second = f * t.x1;
                         if (2 * o + 1 < need) {
                             if (al16) *reinterpret_cast<double2 *>(g + 2 * o) = make_double2(first, second);

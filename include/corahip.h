@@ -175,7 +175,8 @@ int corahip_pcg64_advance(const uint64_t host_state[2], const uint64_t host_inc[
  * value.  host_state: np.random.get_state(legacy=False) as a struct - key (624 words), pos, has_gauss, gauss - in; the
  * state numpy would be left in out (an equivalent (key, pos) pair: the 624-word block the generator is in and the
  * position inside it).  Which attempts of the polar method are accepted - and with it the state - is numpy's exactly;
- * the values pass through log / sqrt / two divisions and may differ from numpy's in the last bits (<= 4 ulp).
+ * the values take glibc's log restated operation by operation (its FMA build, csrc/mtlegacy.hip glibc_log_fma) and
+ * correctly rounded sqrt / divisions: numpy's bit for bit where numpy's libm is that routine, within 4 ulp elsewhere.
  * Synchronises the context's stream.  Algorithm: csrc/mtlegacy.hip (MT19937 cut into segments by jump-ahead polynomials
  * over GF(2), csrc/mt_jump.inc); restated in oracle/mtlegacy.py. */
 typedef struct corahip_mt_state {

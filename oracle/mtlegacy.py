@@ -206,3 +206,91 @@ def step_window(window, j):
     """The window j words on by plain stepping."""
     x = extend(window, j)
     return x[j:j + N]
+
+
+# ---- glibc's log, FMA build -------------------------------------------------------------------------------------------
+def _fma(a, b, c):
+    """fma(a, b, c) exactly rounded (python 3.10 has no math.fma): rational arithmetic, one rounding."""
+    from fractions import Fraction
+    return float(Fraction(a) * Fraction(b) + Fraction(c))
+
+
+def glibc_log_tables():
+    """(ln2hi, ln2lo, A, B, T) parsed from the generated include file the kernels are compiled with
+    (cora_amd/csrc/glibc_log_tab.inc, written by tools/gen_glibc_log_tab.py from the installed libm)."""
+    import os
+    import re
+
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "cora_amd", "csrc", "glibc_log_tab.inc")
+    txt = open(path).read()
+    hx = r"-?0x[01]\.[0-9a-f]+p[+-]?\d+"
+    ln2hi = float.fromhex(re.search(r"LN2HI (%s)" % hx, txt).group(1))
+    ln2lo = float.fromhex(re.search(r"LN2LO (%s)" % hx, txt).group(1))
+    A = [float.fromhex(t) for t in re.findall(hx, re.search(r"GLIBC_LOG_A \{(.*)\}", txt).group(1))]
+    B = [float.fromhex(t) for t in re.findall(hx, re.search(r"GLIBC_LOG_B \{(.*)\}", txt).group(1))]
+    T = [float.fromhex(t) for t in re.findall(hx, txt[txt.index("GLIBC_LOG_T"):])]
+    assert len(A) == 5 and len(B) == 11 and len(T) == 256
+    return ln2hi, ln2lo, A, B, T
+
+
+_LOGTAB = None
+
+
+def glibc_log_fma(x):
+    """glibc's ``log`` (sysdeps/ieee754/dbl-64/e_log.c) for a positive normal double, in the evaluation order of its
+    FMA build (``__log_fma``, what the loader selects on CPUs with FMA + AVX2 - read off the installed libm's code):
+    every fused operation below is fused there, every separate one separate.  cora_amd/csrc/mtlegacy.hip runs the same
+    sequence (``glibc_log_fma``); tests/test_oracle.py compares this with ``math.log`` on the host."""
+    import struct
+
+    global _LOGTAB
+    if _LOGTAB is None:
+        _LOGTAB = glibc_log_tables()
+    ln2hi, ln2lo, A, B, T = _LOGTAB
+    ix = struct.unpack("<Q", struct.pack("<d", x))[0]
+    if (ix - 0x3FEE000000000000) & 0xFFFFFFFFFFFFFFFF <= 0x308FFFFFFFFFF:       # 1 - 2^-4 <= x < 1 + 0x1.09p-4
+        if x == 1.0:
+            return 0.0
+        r = x - 1.0
+        p2 = _fma(r, B[2], B[1])
+        p3 = _fma(r, B[5], B[4])
+        r2 = r * r
+        p5 = _fma(r, B[8], B[7])
+        p2 = _fma(r2, B[3], p2)
+        p3 = _fma(r2, B[6], p3)
+        r3 = r * r2
+        p1 = _fma(r2, B[9], p5)
+        p1 = _fma(r3, B[10], p1)
+        p1 = _fma(p1, r3, p3)
+        p1 = _fma(p1, r3, p2)
+        t = _fma(r, 134217728.0, r)
+        rhi = _fma(-134217728.0, r, t)
+        rhi2 = rhi * rhi
+        rlo = r - rhi
+        hi = _fma(rhi2, B[0], r)
+        lo = _fma(rhi2, B[0], r - hi)
+        lo = _fma(B[0] * rlo, r + rhi, lo)
+        y = _fma(p1, r3, lo)
+        return y + hi
+    tmp = (ix - 0x3FE6000000000000) & 0xFFFFFFFFFFFFFFFF
+    i = (tmp >> 45) & 127
+    k = tmp >> 52
+    if k >= 2048:
+        k -= 4096
+    iz = (ix - (tmp & 0xFFF0000000000000)) & 0xFFFFFFFFFFFFFFFF
+    z = struct.unpack("<d", struct.pack("<Q", iz))[0]
+    invc, logc = T[2 * i], T[2 * i + 1]
+    kd = float(k)
+    r = _fma(z, invc, -1.0)
+    w = _fma(kd, ln2hi, logc)
+    q = _fma(r, A[2], A[1])
+    hi = r + w
+    r2 = r * r
+    lo = (w - hi) + r
+    lo = _fma(kd, ln2lo, lo)
+    r3 = r * r2
+    p = _fma(r, A[4], A[3])
+    lo = _fma(r2, A[0], lo)
+    p = _fma(p, r2, q)
+    y = _fma(r3, p, lo)
+    return y + hi

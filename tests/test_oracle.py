@@ -669,3 +669,28 @@ def test_mt19937_jump_polynomials():
         got = sum(v << (32 * j) for j, v in enumerate(words[624 * k:624 * (k + 1)]))
         assert got == g, k
         g = m.polymod(m.polysqr_mod(g, phi) << 1, phi)
+
+
+def test_glibc_log_restatement_is_the_hosts_log():
+    """oracle.mtlegacy.glibc_log_fma - glibc's table-driven log in the evaluation order of its FMA build, the sequence
+    cora_amd/csrc/mtlegacy.hip runs for the legacy normals - against math.log (the libm numpy calls) on this host:
+    both branches (table + degree-5 polynomial; degree-11 polynomial around 1), r2-like arguments down to 2^-104.
+    Skipped where the host's libm is another routine (no FMA, another libc): the device values are then only within
+    4 ulp of numpy's (tests/test_gpu_npnormal.py takes the same switch)."""
+    import math
+    import random
+
+    from oracle import mtlegacy
+
+    probe = [0.9375, 0.99999, 0.5, 0.1234567, 3e-7, 2.0**-104, 0.7071, 0.96, 0.30103]
+    if not all(mtlegacy.glibc_log_fma(x) == math.log(x) for x in probe):
+        pytest.skip("this host's log is not glibc's FMA build")
+    random.seed(11)
+    xs = [random.random() for _ in range(6000)] + [1.0 - random.random() * 2.0**-4 for _ in range(2000)]
+    xs += [random.random() * 10.0 ** (-random.randint(1, 30)) for _ in range(1000)] + [1.0 - 2.0**-53, 0.9375, 2.0**-104]
+    bad = [x for x in xs if x > 0.0 and mtlegacy.glibc_log_fma(x) != math.log(x)]
+    assert not bad, bad[:5]
+    ln2hi, ln2lo, A, B, T = mtlegacy.glibc_log_tables()
+    assert ln2hi + ln2lo == math.log(2.0) and abs(A[0] + 0.5) < 1e-15 and B[0] == -0.5
+    for i in range(128):
+        assert abs(math.log(1.0 / T[2 * i]) - T[2 * i + 1]) < 1e-9
