@@ -28,6 +28,9 @@ static_assert(K5_SWZ == 0, "the compile-time kernels assume the padded LDS layou
 #ifndef CT_STAMPS
 #define CT_STAMPS 0   // diagnostic build (make k5ctstamps): s_memtime per phase of the Bluestein kernel, summed over waves
 #endif
+#ifndef CT_ABLATE_TW
+#define CT_ABLATE_TW 0
+#endif
 #if CT_STAMPS
 __device__ unsigned long long g_ct_stamps[12];
 #define CTSTAMP(k) { unsigned long long _t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)::"memory"); ct_acc[k] += _t - ct_last; ct_last = _t; }
@@ -288,7 +291,11 @@ __device__ __forceinline__ static void tw_apply(double2 (&x)[R], double2 w1) {
 #pragma unroll
     for (int r = 2; r < R; r++) {
         const int lb = r & (-r);
+#if CT_ABLATE_TW     // diagnostic (wrong results): no twiddle powers - what would a table of them be worth?
+        w[r] = make_double2(w1.x + (double)r, w1.y);
+#else
         w[r] = (lb == r) ? csqr(w[r >> 1]) : cmul(w[r - lb], w[lb]);
+#endif
         x[r] = cmul(x[r], w[r]);
     }
 }
