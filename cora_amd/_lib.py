@@ -95,6 +95,7 @@ SIGNATURES = {
     "corahip_sht_plan_rings": (c_int, [c_void_p, PTR, PTR, PTR, PTR]),
     "corahip_sht_plan_ring_classes": (c_int, [c_void_p, PTR]),
     "corahip_sht_lambda": (c_int, [c_void_p, c_void_p, c_int, c_int, PTR]),
+    "corahip_sht_lambda_entry": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, PTR]),
 }
 
 
@@ -769,6 +770,14 @@ class Context:
         plan = self.sht_plan(nside, lmax)
         out = self.empty((lmax - m + 1,))
         _check(self.lib.corahip_sht_lambda(self.h, plan, m, ring_pair, self._f64(out)))
+        return out
+
+    def sht_lambda_entry(self, nside, lmax, m, ring_pair, kq):
+        """lambda_lm as lane group ``kq`` of the synthesis kernel forms them (entry at a window start from the plan's
+        four entry states per (m, ring))."""
+        plan = self.sht_plan(nside, lmax)
+        out = self.empty((lmax - m + 1,))
+        _check(self.lib.corahip_sht_lambda_entry(self.h, plan, m, ring_pair, kq, self._f64(out)))
         return out
 
 

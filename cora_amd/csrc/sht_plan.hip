@@ -173,6 +173,33 @@ __global__ void lambda_kernel(int lmax, int npair, int m, int r, const double *_
         out[l - m] = l >= ls ? v * c.y : 0.0;
     }
 }
+
+// test hook: the same values as legendre_kernel's lane group kq forms them - zero in front of its entry row
+// R = m + 2 kq + 8 k >= lstart - 1, the plan's entry state (seed4) there, the scaled recurrence behind it
+__global__ void lambda_entry_kernel(int lmax, int npair, int m, int r, int kq, const double *__restrict__ z,
+                                    const double2 *__restrict__ coefmu, const int32_t *__restrict__ lstart,
+                                    const double2 *__restrict__ seed4, double *__restrict__ out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const double x = z[r];
+    const long o = (long)m * npair + r;
+    const int ls = lstart[o];
+    const double2 sd = seed4[4 * o + kq];
+    const double2 *cf = coefmu + alm_idx(0, m, lmax);
+    const int t = ls - 1 - m - 2 * kq;
+    const int R = ls <= lmax ? m + 2 * kq + (t > 0 ? ((t + 7) >> 3) << 3 : 0) : 0x7fffffff;
+    double p0 = 0.0, p1 = 0.0;
+    for (int l = m; l <= lmax; l++) {
+        if (l == R) {
+            p0 = sd.x;
+            p1 = sd.y;
+        }
+        const double2 c = cf[l];
+        const double v = fma(c.x * x, p1, -p0);
+        p0 = p1;
+        p1 = v;
+        out[l - m] = v * c.y;
+    }
+}
 // per ring: mcut = number of m (from 0) whose lambda_lm reach the plan's cut for some l <= lmax; F_m of the ring
 // is exactly zero beyond (lstart is monotone in m), so K4 need not write and K5 need not read those cells
 __global__ void mcut_kernel(int lmax, int npair, int nring, const int32_t *__restrict__ lstart,
@@ -744,6 +771,15 @@ int corahip_sht_lambda(corahip_ctx *ctx, const corahip_sht_plan *p, int m, int r
     ARG_CHECK(m >= 0 && m <= p->lmax && ring_pair >= 0 && ring_pair < p->npair);
     lambda_kernel<<<1, 64, 0, ctx->stream>>>(p->lmax, p->npair, m, ring_pair, p->d_z, p->d_coefmu, p->d_lstart,
                                              p->d_seedmu, out);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int corahip_sht_lambda_entry(corahip_ctx *ctx, const corahip_sht_plan *p, int m, int ring_pair, int kq, double *out) {
+    ARG_CHECK(ctx != nullptr && p != nullptr && out != nullptr);
+    ARG_CHECK(m >= 0 && m <= p->lmax && ring_pair >= 0 && ring_pair < p->npair && kq >= 0 && kq < 4);
+    lambda_entry_kernel<<<1, 64, 0, ctx->stream>>>(p->lmax, p->npair, m, ring_pair, kq, p->d_z, p->d_coefmu, p->d_lstart,
+                                                   p->d_seed4, out);
     LAUNCH_CHECK();
     return 0;
 }

@@ -425,6 +425,10 @@ int corahip_sht_plan_ring_classes(const corahip_sht_plan *plan, int32_t *host_le
 /* normalised associated Legendre values lambda_lm(cos theta_ring) the synthesis uses
  * (device recurrence incl. the polar seed table), l = m..lmax -> out [lmax-m+1] (device) */
 int corahip_sht_lambda(corahip_ctx *ctx, const corahip_sht_plan *plan, int m, int ring_pair, double *out);
+/* the same values as lane group kq (0..3) of the synthesis kernel forms them: zero in front of the group's entry row
+ * R = m + 2 kq + 8 k >= lstart - 1, the plan's entry state there (four per (m, ring)), the recurrence behind it; equal
+ * to corahip_sht_lambda from row max(R, lstart) on, and below the plan's cut before it.  For tests. */
+int corahip_sht_lambda_entry(corahip_ctx *ctx, const corahip_sht_plan *plan, int m, int ring_pair, int kq, double *out);
 
 #ifdef __cplusplus
 }

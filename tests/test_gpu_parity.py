@@ -47,6 +47,41 @@ def test_lambda_recurrence(ctx, nside, lmax, m, pair):
     assert np.abs(dev - ref).max() <= 1e-11 * scale + 2.0**-79
 
 
+@pytest.mark.parametrize("nside,lmax,m,pair", [(8, 16, 0, 3), (8, 16, 5, 0), (8, 16, 16, 1), (64, 128, 100, 2),
+                                              (64, 128, 127, 3), (256, 512, 500, 0), (256, 512, 400, 30),
+                                              (1024, 2048, 2000, 5), (1024, 2048, 1000, 400), (1024, 2048, 1, 0),
+                                              (1024, 2048, 2047, 900), (1024, 2048, 2048, 2047)])
+def test_lambda_from_the_lane_group_entry_states(ctx, nside, lmax, m, pair):
+    """Round 4: legendre_kernel's lanes enter at a window start from the plan's FOUR entry states per (m, ring)
+    (sht_plan.hip seed_kernel, d_seed4: one per lane group kq, in front of row R = m + 2 kq + 8 k >= lstart - 1).  The
+    recurrence started from each of them (corahip_sht_lambda_entry) must reproduce the oracle's lambda_lm from its entry
+    row on - including the rows lstart - 1 .. lstart - 3 it may carry below the cut, the start at l = m through the
+    state (-mu_m, 0), and the last m - and be zero in front of it."""
+    from oracle import healpix, sht
+
+    ri = healpix.ring_info(nside)
+    ref = sht.lambda_lm(lmax, m, ri["z"][pair])
+    one = ctx.sht_lambda(nside, lmax, m, pair).cpu().numpy()
+    scale = max(np.abs(ref).max(), 1e-300)
+    nz = np.nonzero(one)[0]
+    ls = m + (int(nz[0]) if len(nz) else lmax + 1 - m)             # the plan's first contributing row
+    for kq in range(4):
+        dev = ctx.sht_lambda_entry(nside, lmax, m, pair, kq).cpu().numpy()
+        t = ls - 1 - m - 2 * kq
+        R = m + 2 * kq + (((t + 7) >> 3) << 3 if t > 0 else 0)
+        if ls > lmax or R > lmax:           # the ring (or this lane group) never enters
+            assert not dev.any()
+            continue
+        assert not dev[: max(0, R - m)].any(), (kq, R)
+        # as close to the oracle as the single-start form is (the ring next to the pole at m = 1 is ill-conditioned for
+        # ANY double recurrence: 5e-11 of the scale there, 1e-13 elsewhere)
+        base = np.abs(one[max(ls, R) - m:] - ref[max(ls, R) - m:]).max()
+        assert np.abs(dev[R - m:] - ref[R - m:]).max() <= max(1e-11 * scale, 3.0 * base) + 2.0**-79, (kq, R, ls)
+        # from the later of the two starts on, the two device forms agree to rounding (times that conditioning)
+        k0 = max(R, ls) - m
+        assert np.abs(dev[k0:] - one[k0:]).max() <= max(1e-13 * scale, 0.1 * base) + 2.0**-100, (kq, R, ls)
+
+
 # ------------------------------------------------------------------ K4 + K5
 @pytest.mark.parametrize("nside,lmax,nnu", [(1, 2, 1), (2, 5, 3), (4, 11, 8), (8, 16, 4), (8, 23, 9), (16, 32, 16),
                                             (32, 95, 5), (64, 128, 24)])
