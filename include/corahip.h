@@ -32,7 +32,7 @@ extern "C" {
 #endif
 
 #define CORAHIP_ABI_VERSION 1
-#define CORAHIP_ABI_MINOR 1      /* additions since version 1: 1 = normals_pcg64, pcg64_advance, draw_alm_rows, mkfullsky, mkfullsky_workspace_bytes, abi_minor, normals_mt19937_legacy */
+#define CORAHIP_ABI_MINOR 2      /* additions since version 1: 1 = normals_pcg64, pcg64_advance, draw_alm_rows, mkfullsky, mkfullsky_workspace_bytes, abi_minor, normals_mt19937_legacy; 2 = sht_lambda_entry (test hook) */
 
 #define CORAHIP_EINVAL (-1)   /* bad argument / shape */
 #define CORAHIP_ENOMEM (-2)   /* workspace too small / allocation refused */
