@@ -609,8 +609,20 @@ chol_coop_kernel(const double *__restrict__ C, int F, double jitter_rel, double 
         nsync++;
         if (tid == 0) {
             __hip_atomic_fetch_add(&bar[mi], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            while (__hip_atomic_load(&bar[mi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nsync * (unsigned)G)
+            // (bounded: if a workgroup of the group never arrives - the grid was not co-resident after all - the group
+            //  gives up after ~2^25 polls, a few seconds, and reports the matrix as failed: it then takes the eigen route
+            //  like any block the Cholesky rejects, instead of hanging the device)
+            unsigned polls = 0;
+            while (__hip_atomic_load(&bar[mi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nsync * (unsigned)G) {
                 __builtin_amdgcn_s_sleep(2);
+                if ((++polls & 1023u) == 0) {
+                    if (__hip_atomic_load(&gflag[mi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 3) break;
+                    if (polls >= (1u << 25)) {
+                        __hip_atomic_store(&gflag[mi], 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        break;
+                    }
+                }
+            }
         }
         __syncthreads();
         if (!same_xcc) __threadfence();
@@ -624,6 +636,10 @@ chol_coop_kernel(const double *__restrict__ C, int F, double jitter_rel, double 
         group_sync();
         same_xcc = __hip_atomic_load(&xcc_min[mi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ==
                    __hip_atomic_load(&xcc_max[mi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__hip_atomic_load(&gflag[mi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {     // (the barrier gave up)
+            if (wgl == 0 && tid == 0) info[mat0 + mi] = 3;
+            return;
+        }
     }
 
     const int nblk = (F + 31) / 32;
