@@ -490,12 +490,12 @@ class Context:
 
     # -- K4/K5 ------------------------------------------------------------------------
     # truncation exponent of the Legendre sums used by plans made without an explicit one (0 = the library's
-    # default, 2^-80); `Context.sht_cut_exp = -900` before the first transform keeps every representable term
+    # default, 2^-70); `Context.sht_cut_exp = -900` before the first transform keeps every representable term
     sht_cut_exp = 0
 
     def sht_plan(self, nside, lmax, cut_exp=None):
         """The (nside, lmax) transform plan; terms of the Legendre sums below 2^cut_exp are dropped (pixel error
-        <= 2 sum |a_lm| 2^cut_exp; default -80, see corahip_sht_plan_create_ex)."""
+        <= 2 sum |a_lm| 2^cut_exp; default -70, see corahip_sht_plan_create_ex)."""
         cut = int(self.sht_cut_exp if cut_exp is None else cut_exp)
         key = (int(nside), int(lmax)) if cut == 0 else (int(nside), int(lmax), cut)
         if key not in self._plans:

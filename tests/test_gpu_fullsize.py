@@ -382,7 +382,7 @@ def test_k4_mfma_count_matches_pmc_profile(ctx):
 
 def test_legendre_cut_is_a_plan_parameter(ctx):
     """corahip_sht_plan_create_ex: the truncation exponent of the Legendre sums is chosen per plan.  With the cut
-    the oracle uses (2^-900) the device maps equal the oracle's to the digits the default plan (2^-80) gives - the
+    the oracle uses (2^-900) the device maps equal the oracle's to the digits the default plan (2^-70) gives - the
     default drops nothing that matters for O(1) coefficients - and coefficients of extreme dynamic range, where
     the documented bound sum |a_lm| 2^cut says the default is NOT enough, are reproduced only by the lower cut."""
     from oracle import sht
@@ -393,10 +393,10 @@ def test_legendre_cut_is_a_plan_parameter(ctx):
     ref = sht.alm2map(_packed_of(alm, 3), nside, lmax)
     e80 = np.abs(ctx.alm2map(alm, nside, lmax, nnu)[3].cpu().numpy() - ref).max() / ref.std()
     e900 = np.abs(ctx.alm2map(alm, nside, lmax, nnu, cut_exp=-900)[3].cpu().numpy() - ref).max() / ref.std()
-    print("nside 256 / lmax 512: max|err|/rms with cut 2^-80: %.2e, with 2^-900: %.2e" % (e80, e900))
+    print("nside 256 / lmax 512: max|err|/rms with the default cut: %.2e, with 2^-900: %.2e" % (e80, e900))
     assert e80 <= 1e-11 and e900 <= 1e-11
-    # one huge coefficient at high m next to an O(1) sky: on the polar rings lambda_lm of that mode is below 2^-80
-    # but 1e40 x it is not negligible - the bound sum |a_lm| 2^cut = 1e40 x 8e-25 tells the caller so
+    # one huge coefficient at high m next to an O(1) sky: on the polar rings lambda_lm of that mode is below the cut
+    # but 1e40 x it is not negligible - the bound sum |a_lm| 2^cut tells the caller so
     m0 = 500
     idx = m0 * (2 * lmax + 1 - m0) // 2 + lmax
     alm2 = alm.clone()
@@ -410,15 +410,15 @@ def test_legendre_cut_is_a_plan_parameter(ctx):
     d80 = np.abs(ctx.alm2map(alm2, nside, lmax, nnu)[3].cpu().numpy() - ref2)
     d900 = np.abs(ctx.alm2map(alm2, nside, lmax, nnu, cut_exp=-900)[3].cpu().numpy() - ref2)
     rel80, rel900 = (ring_of(d80) / rmax).max(), (ring_of(d900) / rmax).max()
-    bound = 2.0 * 1e40 * 2.0**-80                                # 2 sum |a_lm| 2^cut (c_m = 2 for m > 0)
-    print("1e40 coefficient: worst ring error / ring max with cut 2^-80: %.2e, with 2^-900: %.2e; max abs error of the "
+    cut = ctypes_int()
+    assert ctx.lib.corahip_sht_plan_cut_exp(ctx.sht_plan(nside, lmax), cut) == 0 and cut.value == -70      # the default
+    bound = 2.0 * 1e40 * 2.0**cut.value                          # 2 sum |a_lm| 2^cut (c_m = 2 for m > 0)
+    print("1e40 coefficient: worst ring error / ring max with the default cut: %.2e, with 2^-900: %.2e; max abs error of the "
           "default plan on the rings it truncates %.3e <= bound %.3e" % (rel80, rel900, ring_of(d80)[ring_of(d80) > 1e-6 * rmax].max(), bound))
     assert rel900 <= 1e-7, rel900                    # (l^2 eps of the recurrence relative to the ring's own scale)
-    assert rel80 >= 1e-3, rel80                      # the default cut visibly drops the mode where it is < 2^-80 ...
+    assert rel80 >= 1e-3, rel80                      # the default cut visibly drops the mode where it is below it ...
     assert np.all(ring_of(d80) <= bound * 1.01 + 1e-7 * rmax)     # ... and never more than the documented bound
-    cut = ctypes_int()
     assert ctx.lib.corahip_sht_plan_cut_exp(ctx.sht_plan(nside, lmax, -900), cut) == 0 and cut.value == -900
-    assert ctx.lib.corahip_sht_plan_cut_exp(ctx.sht_plan(nside, lmax), cut) == 0 and cut.value == -80
 
 
 def ctypes_int():

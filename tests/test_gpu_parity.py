@@ -43,8 +43,8 @@ def test_lambda_recurrence(ctx, nside, lmax, m, pair):
     ref = sht.lambda_lm(lmax, m, ri["z"][pair])
     dev = ctx.sht_lambda(nside, lmax, m, pair).cpu().numpy()
     scale = max(np.abs(ref).max(), 1e-300)
-    # terms below 2^-80 (8.3e-25) are dropped on the device by design (SEED_MIN_EXP, csrc/sht_plan.hip)
-    assert np.abs(dev - ref).max() <= 1e-11 * scale + 2.0**-79
+    # terms below 2^-70 (8.5e-22) are dropped on the device by design (SEED_MIN_EXP, csrc/sht_plan.hip)
+    assert np.abs(dev - ref).max() <= 1e-11 * scale + 2.0**-69
 
 
 @pytest.mark.parametrize("nside,lmax,m,pair", [(8, 16, 0, 3), (8, 16, 5, 0), (8, 16, 16, 1), (64, 128, 100, 2),
@@ -76,7 +76,7 @@ def test_lambda_from_the_lane_group_entry_states(ctx, nside, lmax, m, pair):
         # as close to the oracle as the single-start form is (the ring next to the pole at m = 1 is ill-conditioned for
         # ANY double recurrence: 5e-11 of the scale there, 1e-13 elsewhere)
         base = np.abs(one[max(ls, R) - m:] - ref[max(ls, R) - m:]).max()
-        assert np.abs(dev[R - m:] - ref[R - m:]).max() <= max(1e-11 * scale, 3.0 * base) + 2.0**-79, (kq, R, ls)
+        assert np.abs(dev[R - m:] - ref[R - m:]).max() <= max(1e-11 * scale, 3.0 * base) + 2.0**-69, (kq, R, ls)
         # from the later of the two starts on, the two device forms agree to rounding (times that conditioning)
         k0 = max(R, ls) - m
         assert np.abs(dev[k0:] - one[k0:]).max() <= max(1e-13 * scale, 0.1 * base) + 2.0**-100, (kq, R, ls)
