@@ -38,7 +38,25 @@ __device__ unsigned long long g_ct_stamps[12];
 #define CTSTAMP(k)
 #endif
 
-__host__ __device__ constexpr int fpc(int i) { return i + (i >> 3) + ((i >> 7) << 3); }
+// LDS padding of a channel buffer, per kernel family (PK, a template parameter of everything below that touches a
+// buffer): 0 = one spare 16-byte slot per 8 elements plus 8 per 128 (rounds 1-3), 1 = one spare slot per 16 elements.
+// In the lane-group simulation of ds_read_b128 / ds_write_b128 (tools/lds_bank_sim.py) padding 0 makes every read of
+// a pass 2-way conflicted (a padded unit-stride run is no longer aligned to the bank rows the read groups assume);
+// padding 1 leaves only the strided first / last passes so.  Measured: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE of the
+// Bluestein classes 0.32 -> 0.12 (tools/pmc_lds.sh), their time -1 .. -5 %; the belt (direct class: radix-8 last pass fused
+// with the pixel store) reads 0.18 -> 0.27 and +3 % with it and keeps padding 0.
+template <int PK>
+__host__ __device__ constexpr int fpk(int i) {
+    return PK ? i + (i >> 4) : i + (i >> 3) + ((i >> 7) << 3);
+}
+#define fpad(i) fpk<PK>(i)
+#define fpc(i) fpk<PK>(i)
+#ifndef K5_PK_BLU
+#define K5_PK_BLU 1
+#endif
+#ifndef K5_PK_DIRECT
+#define K5_PK_DIRECT 0
+#endif
 
 template <int N>
 struct Sch;   // DIF radices of a three-pass transform, largest stride first
@@ -303,7 +321,7 @@ __device__ __forceinline__ static void tw_apply(double2 (&x)[R], double2 w1) {
 // one in-LDS pass of a length-N transform on NCH channel buffers (channel c at sm + c BS), sub-length Ls, radix R.
 // DIT = false: DFT then twiddle (decimation in frequency); true: twiddle then DFT.  w1 = e^{+2 pi i j / Ls} of this
 // thread's j = tid mod (Ls / R) (the same for every butterfly the thread ever gets in this pass).
-template <int N, int NCH, int BS, int Ls, int R, int SIGN, bool DIT, int T>
+template <int PK, int N, int NCH, int BS, int Ls, int R, int SIGN, bool DIT, int T>
 __device__ __forceinline__ static void ct_pass(double2 *sm, const double2 w1, const int tid) {
     constexpr int NB = N / R, Q = Ls / R, TOT = NCH * NB;
     constexpr int IT = (TOT + T - 1) / T;
@@ -352,7 +370,7 @@ __device__ __forceinline__ static cell_ct<NCH> load_cell_ct(const double *cell, 
 }
 
 // phase e^{i m phi0} and fold of one cell onto the bins 0..h of the Hermitian spectrum (see ringfft_kernel)
-template <int NCH, int BS>
+template <int PK, int NCH, int BS>
 __device__ __forceinline__ static void fold_cell(double2 *sm, int m, int n, int h, bool noalias, const double2 ph,
                                                  const cell_ct<NCH> &cv) {
     double *smd = reinterpret_cast<double *>(sm);
@@ -387,7 +405,7 @@ __device__ __forceinline__ static void fold_cell(double2 *sm, int m, int n, int 
 // Ends with a barrier.  X_k, k = 0..h, is then at sm[c BS + fpad(k)].
 // TAIL: one more register slot for the cell m = tid + MC CT_T, index clamped to the last cell of the row (the belt
 // has lmax + 1 = MC CT_T + 1 cells: read in place, that one cell exposed a whole memory latency per item).
-template <int NCH, int BS, int MC, bool TAIL, int T, int KPN = 4>
+template <int PK, int NCH, int BS, int MC, bool TAIL, int T, int KPN = 4>
 struct FrontEnd {
     cell_ct<NCH> pf[MC + (TAIL ? 1 : 0)];
     // PART 0 / 1: first / second half of the cells (the requests of one item are spread over two phases: a burst of all
@@ -441,15 +459,15 @@ struct FrontEnd {
         for (int k = 1; k < KP; k++) phk[k] = cmul(phk[k - 1], phstep);
 #pragma unroll
         for (int k = 0; k < MC; k++) {
-            if (tid + k * T < Lr) fold_cell<NCH, BS>(sm, tid + k * T, n, h, noalias, ph, pf[k]);
+            if (tid + k * T < Lr) fold_cell<PK, NCH, BS>(sm, tid + k * T, n, h, noalias, ph, pf[k]);
             ph = cmul(ph, phstep);
         }
         if (TAIL) {
-            if (tid + MC * T < Lr) fold_cell<NCH, BS>(sm, tid + MC * T, n, h, noalias, ph, pf[MC]);
+            if (tid + MC * T < Lr) fold_cell<PK, NCH, BS>(sm, tid + MC * T, n, h, noalias, ph, pf[MC]);
             ph = cmul(ph, phstep);
         }
         for (int m = tid + (MC + (TAIL ? 1 : 0)) * T; m < Lr; m += T) {   // cells beyond the prefetch window, read in place
-            fold_cell<NCH, BS>(sm, m, n, h, noalias, ph, load_cell_ct<NCH>(cell, m));
+            fold_cell<PK, NCH, BS>(sm, m, n, h, noalias, ph, load_cell_ct<NCH>(cell, m));
             ph = cmul(ph, phstep);
         }
     }
@@ -474,6 +492,7 @@ __global__ void __launch_bounds__(T)
 ringfft_direct_ct(const int32_t *__restrict__ ring_list, int nlist, int lmax, int G, int nnu, long npix,
                   const int64_t *__restrict__ start_a, const double *__restrict__ phi0_a,
                   const double *inter, double *maps, const int32_t *__restrict__ mcut) {   // (not __restrict__: see ringfft_blu_ct)
+    constexpr int PK = K5_PK_DIRECT;
     constexpr int R0 = Sch<N>::R0, R1 = Sch<N>::R1, R2 = Sch<N>::R2;
     static_assert(R0 == 16 && R1 == 16, "digit map of the fused store assumes 16 x 16 x R2");
     constexpr int Q0 = N / R0;              // stride of the first pass
@@ -503,7 +522,7 @@ ringfft_direct_ct(const int32_t *__restrict__ ring_list, int nlist, int lmax, in
         const int ch0 = (item % ngrp) * NCH;
         return inter + ((size_t)ring * G + (ch0 >> 2)) * L * 8 + (ch0 & 3);
     };
-    FrontEnd<NCH, BS, MC, true, T> fe;
+    FrontEnd<PK, NCH, BS, MC, true, T> fe;
     // fold phases e^{i m phi0}: phi0 of a belt ring is 0 or pi / (4 nside) = pi / (2 N) (sht_plan.hip), so e^{i tid phi0}
     // and the step e^{i T phi0} are per-thread constants of the kernel (the same expressions FrontEnd::fold evaluates
     // per item - two sincospi, ~150 DP instructions per thread and item, 7 % of the belt's cycles)
@@ -583,7 +602,7 @@ ringfft_direct_ct(const int32_t *__restrict__ ring_list, int nlist, int lmax, in
             }
         }
         __syncthreads();
-        ct_pass<N, NCH, BS, Q0, R1, 1, false, T>(sm, wB, tid);
+        ct_pass<PK, N, NCH, BS, Q0, R1, 1, false, T>(sm, wB, tid);
         __syncthreads();
         // ---- last pass (radix R2 on contiguous elements, no twiddles) with the pixel store: butterfly t = 16 k0 + k1
         //      holds the natural indices k0 + 16 k1 + 256 r.  Lane bits: 0-2 = k0 low, 3-5 = k1 low, 6 = k0 high,
@@ -628,6 +647,7 @@ ringfft_blu_ct(const int32_t *__restrict__ ring_list, int nlist, int nside, int 
     //  barriers / pixel stores, and the places where this kernel requests them - one phase ahead of their use, and all
     //  of them completed before the first store - are the places where they are issued; with __restrict__ the chirp
     //  loads of the last pass were sunk to their use and waited out in full)
+    constexpr int PK = K5_PK_BLU;
     constexpr int R0 = Sch<P>::R0, R1 = Sch<P>::R1, R2 = Sch<P>::R2;
     constexpr int Q0 = P / R0;
     constexpr int BS = fpc(P) + K5_CH_SKEW;
@@ -656,7 +676,7 @@ ringfft_blu_ct(const int32_t *__restrict__ ring_list, int nlist, int nside, int 
         const int ch0 = (item % ngrp) * NCH;
         return inter + ((size_t)ring * G + (ch0 >> 2)) * L * 8 + (ch0 & 3);
     };
-    FrontEnd<NCH, BS, MC, false, T, (U > 4 ? U : 4)> fe;
+    FrontEnd<PK, NCH, BS, MC, false, T, (U > 4 ? U : 4)> fe;
     double2 cbn[U];    // chirp b_k, k = tid + u T, of the NEXT item (index clamped: unused lanes load a valid slot)
     auto load_cbn = [&](int item, int t) {
         const int ring = ring_list[item / ngrp];
@@ -798,7 +818,7 @@ ringfft_blu_ct(const int32_t *__restrict__ ring_list, int nlist, int nside, int 
         }
         __syncthreads();
         CTSTAMP(4);
-        ct_pass<P, NCH, BS, Q0, R1, -1, false, T>(sm, wB, tid);
+        ct_pass<PK, P, NCH, BS, Q0, R1, -1, false, T>(sm, wB, tid);
         __syncthreads();
         CTSTAMP(5);
         // ---- last forward pass, filter, first inverse pass: R2 contiguous elements, no twiddles, in registers
@@ -854,7 +874,7 @@ ringfft_blu_ct(const int32_t *__restrict__ ring_list, int nlist, int nside, int 
         }
         __syncthreads();
         CTSTAMP(6);
-        ct_pass<P, NCH, BS, Q0, R1, 1, true, T>(sm, wB, tid);
+        ct_pass<PK, P, NCH, BS, Q0, R1, 1, true, T>(sm, wB, tid);
         __syncthreads();
         CTSTAMP(7);
         // ---- last inverse pass (sign +): only the outputs j0 + r Q0 < h exist; times b_j / P, pixel pairs to HBM
@@ -901,6 +921,7 @@ ringfft_blu_ct(const int32_t *__restrict__ ring_list, int nlist, int nside, int 
 template <int N, int NCH, int MC, int T>
 static int launch_direct(corahip_ctx *ctx, hipStream_t stream, int wg_per_cu, const corahip_sht_plan *p,
                          const corahip_sht_plan::ring_class &c, const double *inter, int G, int nnu, double *maps) {
+    constexpr int PK = K5_PK_DIRECT;
     constexpr int BS = fpc(N) + 1 + K5_CH_SKEW;
     const size_t shm = sizeof(double2) * (size_t)NCH * BS;
     const long nitems = (long)c.count * ((nnu + NCH - 1) / NCH);
@@ -925,6 +946,7 @@ static int launch_blu(corahip_ctx *ctx, hipStream_t stream, int wg_per_cu, const
         d_foff = p->d_blu_foff;
         d_filt = p->d_bfilt;
     }
+    constexpr int PK = K5_PK_BLU;
     constexpr int BS = fpc(P) + K5_CH_SKEW;
     const size_t shm = sizeof(double2) * (size_t)NCH * BS;
     const long nitems = (long)c.count * ((nnu + NCH - 1) / NCH);
@@ -1042,6 +1064,7 @@ template <int P>
 __global__ void __launch_bounds__(CT_T)
 blu3_filter_kernel(int nside, const int32_t *__restrict__ p3_of, const int64_t *__restrict__ boff, const int64_t *__restrict__ foff3,
                    const double2 *__restrict__ chirp, double2 *__restrict__ filt3) {
+    constexpr int PK = K5_PK_BLU;
     constexpr int R0 = Sch<P>::R0, R1 = Sch<P>::R1, R2 = Sch<P>::R2;
     constexpr int Q0 = P / R0, BS = fpc(P) + K5_CH_SKEW;
     extern __shared__ __attribute__((aligned(16))) double2 sm[];
@@ -1065,11 +1088,11 @@ blu3_filter_kernel(int nside, const int32_t *__restrict__ p3_of, const int64_t *
         sincospi(2.0 * (double)(tid & (Q0 / R1 - 1)) / (double)Q0, &sv, &cv);
         wB = make_double2(cv, sv);
     }
-    ct_pass<P, 1, BS, P, R0, -1, false, CT_T>(sm, wA, tid);
+    ct_pass<PK, P, 1, BS, P, R0, -1, false, CT_T>(sm, wA, tid);
     __syncthreads();
-    ct_pass<P, 1, BS, Q0, R1, -1, false, CT_T>(sm, wB, tid);
+    ct_pass<PK, P, 1, BS, Q0, R1, -1, false, CT_T>(sm, wB, tid);
     __syncthreads();
-    ct_pass<P, 1, BS, Q0 / R1, R2, -1, false, CT_T>(sm, wB, tid);   // (stride 1: no twiddles)
+    ct_pass<PK, P, 1, BS, Q0 / R1, R2, -1, false, CT_T>(sm, wB, tid);   // (stride 1: no twiddles)
     __syncthreads();
     double2 *f = filt3 + foff3[i - 1];
     for (int j = tid; j < P; j += CT_T) f[j] = sm[fpad(j)];
@@ -1083,7 +1106,7 @@ int sht_blu3_tables(corahip_ctx *ctx, corahip_sht_plan *p, int64_t total) {
     const int nb = p->nside - 1;
 #define BLU3_LAUNCH(PP)                                                                                                   \
     {                                                                                                                     \
-        const size_t shm = sizeof(double2) * (size_t)(fpc(PP) + K5_CH_SKEW);                                              \
+        const size_t shm = sizeof(double2) * (size_t)(fpk<K5_PK_BLU>(PP) + K5_CH_SKEW);                                              \
         HIP_TRY(hipFuncSetAttribute((const void *)blu3_filter_kernel<PP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
         blu3_filter_kernel<PP><<<nb, CT_T, shm, ctx->stream>>>(p->nside, d_p3, p->d_blu_boff, p->d_blu3_foff, p->d_bchirp, p->d_bfilt3); \
         LAUNCH_CHECK();                                                                                                   \
