@@ -229,9 +229,13 @@ def main():
     # cold step with numpy's PCG64 + ziggurat stream generated on the device (bit-identical to numpy, the generator left
     # where numpy would leave it) instead of the library's Philox stream; and the legacy mode (rng=None: numpy's global
     # MT19937 + polar method, what Sky3d.getsky() draws from), generated on the device as well
+    # Since round 5 the stream is generated range of multipoles by range (no 16 F nalm byte buffer), so the legs run on
+    # every line: multi-component workloads (separate: the components draw one after the other from the one generator),
+    # emulated shards and real ranks (every rank consumes the whole stream for its own rows of the factors).
     seeded_numpy = legacy_rng = None
-    if rank == 0 and world == 1 and args.emulate_shard <= 1 and len(comps) == 1 and not (args.no_seeded_modes or args.checksum):
-        seeded_numpy, legacy_rng = seeded_modes(ctx, shard, cold_factors, F, lmax, barrier, args.steps)
+    if not (args.no_seeded_modes or args.checksum or args.warm):
+        seeded_numpy, legacy_rng = seeded_modes(ctx, shard, cold_factors, F, lmax, barrier, args.steps, len(comps)
+                                                if args.sum_mode == "separate" else 1, nnu)
 
     # host-delivered rate: the reference's own signature returns numpy arrays (cora/core/skysim.py:130-136), i.e. every
     # realisation crosses PCIe.  skysim.mkfullsky_stream double-buffers that copy (pinned memory, copy stream) behind the
@@ -259,6 +263,19 @@ def main():
             import hashlib
 
             print("CHECKSUM", hashlib.sha1(st.numpy().round(decimals=14).tobytes()).hexdigest(), float(st[:, 1].sum()), file=sys.stderr)
+        # the reference's seeded call and its rng=None call: EVERY PIXEL of every channel hashed (sha1 of the raw
+        # bytes per channel, gathered in channel order) - a sharded run must reproduce the single-rank maps bit for bit
+        import hashlib
+
+        for tag, mk in (("CHECKSUM_SEEDED", lambda: np.random.default_rng(77)), ("CHECKSUM_LEGACY", lambda: np.random.seed(78))):
+            m = shard.realise_numpy(mk(), cold_factors()).cpu().numpy()
+            hs = [hashlib.sha1(m[i].tobytes()).hexdigest() for i in range(m.shape[0])]
+            if dist is not None:
+                parts = [None] * world
+                dist.all_gather_object(parts, (nu0, hs))
+                hs = [h for p in sorted(parts, key=lambda x: x[0]) for h in p[1]]
+            if rank == 0:
+                print(tag, hashlib.sha1("".join(hs).encode()).hexdigest(), file=sys.stderr)
 
     result = None
     if rank == 0:
@@ -433,7 +450,7 @@ def stage_rooflines(stages, comps, F, nside, lmax, nnu, nu0, nranks, sum_mode, l
     return out
 
 
-def seeded_modes(ctx, shard, cold_factors, F, lmax, barrier, steps):
+def seeded_modes(ctx, shard, cold_factors, F, lmax, barrier, steps, ndraw=1, nmaps=None):
     """(seeded_numpy_mode, legacy_rng_mode) of the bench line.
 
     seeded_numpy_mode: HBM-resident ms per COLD step when the caller passes ``rng = numpy.random.default_rng(seed)`` as
@@ -456,14 +473,17 @@ def seeded_modes(ctx, shard, cold_factors, F, lmax, barrier, steps):
     ms = (time.time() - t0) / nrep * 1e3
     ctx.profile_enable(False)
     st = {}
-    for name in ("normals_pcg64", "zig_count", "zig_scan", "zig_emit", "draw"):
+    for name in ("zig_seek", "zig_count", "zig_scan", "zig_emit", "draw"):
         t, n = ctx.profile_get(name)
         if n:
             st[name] = round(t / nrep, 3)
-    nnorm = 2 * F * ((lmax + 1) * (lmax + 2) // 2)
-    seeded = {"ms_per_step": ms, "maps_per_s": F / (ms * 1e-3), "stages_ms": st, "normals_per_step": nnorm,
-              "rng": "numpy.random.default_rng(seed): PCG64 + ziggurat standard_normal continued on the device "
-                     "(corahip_normals_pcg64), bit-identical to numpy; the Generator's state is advanced as numpy would"}
+    nnorm = ndraw * 2 * F * ((lmax + 1) * (lmax + 2) // 2)
+    nmaps = F if nmaps is None else nmaps
+    seeded = {"ms_per_step": ms, "maps_per_s": nmaps / (ms * 1e-3), "stages_ms": st, "normals_per_step": nnorm,
+              "rng": "numpy.random.default_rng(seed): PCG64 + ziggurat standard_normal continued on the device, bit-identical to "
+                     "numpy, emitted one range of multipoles at a time into a two-slot ring that K3 consumes "
+                     "(corahip_draw_alm_numpy: no 16 F nalm byte stream buffer; 'draw' spans the emit + K3 pipeline); the "
+                     "Generator's state is advanced as numpy would"}
     # rng=None: numpy's legacy global state, continued on the device (corahip_normals_mt19937_legacy)
     np.random.seed(12345)
     shard.realise_numpy(None, cold_factors())
@@ -477,7 +497,7 @@ def seeded_modes(ctx, shard, cold_factors, F, lmax, barrier, steps):
     lms = (time.time() - t0) / nrep * 1e3
     ctx.profile_enable(False)
     lst = {}
-    for name in ("normals_legacy", "mt_jump", "mt_count", "mt_emit", "draw"):
+    for name in ("mt_jump", "mt_count", "mt_emit", "draw"):
         t, n = ctx.profile_get(name)
         if n:
             lst[name] = round(t / nrep, 3)
@@ -485,10 +505,11 @@ def seeded_modes(ctx, shard, cold_factors, F, lmax, barrier, steps):
     t0 = time.time()
     np.random.standard_normal(nsample)
     rate = nsample / (time.time() - t0)
-    legacy = {"ms_per_step": lms, "maps_per_s": F / (lms * 1e-3), "stages_ms": lst,
+    legacy = {"ms_per_step": lms, "maps_per_s": nmaps / (lms * 1e-3), "stages_ms": lst,
               "rng": "rng=None: numpy's legacy global MT19937 + polar method (what Sky3d.getsky() draws from), continued on the "
                      "device: MT19937 cut into segments by GF(2) jump-ahead polynomials; same accepted attempts and generator "
-                     "state as numpy and - glibc's log restated operation by operation - the same values bit for bit",
+                     "state as numpy and - glibc's log restated operation by operation - the same values bit for bit; emitted "
+                     "one range of multipoles at a time into the ring K3 consumes (corahip_draw_alm_numpy)",
               "host_numpy_would_take_s": nnorm / rate, "host_normals_per_s": rate}
     torch.cuda.synchronize()
     return seeded, legacy

@@ -57,6 +57,10 @@ SIGNATURES = {
     "corahip_draw_alm_philox_rows": (c_int, [c_void_p, PTR, PTR, c_u64, c_int, c_int, c_int, c_int, PTR]),
     "corahip_draw_alm": (c_int, [c_void_p, PTR, PTR, PTR, c_int, c_int, c_int, c_int, PTR]),
     "corahip_draw_alm_rows": (c_int, [c_void_p, PTR, PTR, PTR, c_int, c_int, c_int, c_int, PTR]),
+    "corahip_draw_alm_numpy": (c_int, [c_void_p, PTR, c_int, PTR, c_void_p, c_int, c_int, c_int, c_int, PTR, c_size_t]),
+    "corahip_draw_alm_numpy_begin": (c_int, [c_void_p, PTR, c_int, PTR, c_void_p, c_int, c_int, c_int, c_int, PTR, c_size_t,
+                                             ctypes.POINTER(c_void_p)]),
+    "corahip_draw_alm_numpy_end": (c_int, [c_void_p, c_void_p, c_void_p]),
     "corahip_mkfullsky_workspace_bytes": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, ctypes.POINTER(c_size_t)]),
     "corahip_mkfullsky": (c_int, [c_void_p, c_void_p, PTR, c_int, c_void_p, c_int, c_int, c_int, PTR, c_void_p, c_size_t]),
     "corahip_shard_plan": (c_int, [c_int, c_int, c_int, c_int, PTR]),
@@ -154,6 +158,35 @@ def _torch():
     import torch
 
     return torch
+
+
+class _MtState(ctypes.Structure):          # corahip_mt_state
+    _fields_ = [("key", ctypes.c_uint32 * 624), ("pos", ctypes.c_int32), ("has_gauss", ctypes.c_int32), ("gauss", c_double)]
+
+
+class _Rng(ctypes.Structure):              # corahip_rng
+    _fields_ = [("kind", ctypes.c_int32), ("reserved", ctypes.c_int32), ("stream", c_void_p), ("seed", c_u64),
+                ("state", c_u64 * 2), ("inc", c_u64 * 2), ("legacy", ctypes.POINTER(_MtState))]
+
+
+def _rng_struct(rng):
+    """("pcg64", state, inc) | ("legacy", state dict) -> (corahip_rng, corahip_mt_state or None)."""
+    r = _Rng()
+    M = 2**64 - 1
+    if rng[0] == "pcg64":
+        r.kind = 2
+        r.state[0], r.state[1] = (int(rng[1]) >> 64) & M, int(rng[1]) & M
+        r.inc[0], r.inc[1] = (int(rng[2]) >> 64) & M, int(rng[2]) & M
+        return r, None
+    if rng[0] != "legacy" or rng[1]["bit_generator"] != "MT19937":
+        raise ValueError("numpy stream on the device: ('pcg64', state, inc) or ('legacy', MT19937 state dict)")
+    ms = _MtState()
+    key = np.ascontiguousarray(rng[1]["state"]["key"], dtype=np.uint32)
+    ctypes.memmove(ms.key, key.ctypes.data, 624 * 4)
+    ms.pos, ms.has_gauss, ms.gauss = int(rng[1]["state"]["pos"]), int(rng[1]["has_gauss"]), float(rng[1]["gauss"])
+    r.kind = 3
+    r.legacy = ctypes.pointer(ms)
+    return r, ms
 
 
 class Context:
@@ -433,6 +466,38 @@ class Context:
         _check(self.lib.corahip_draw_alm_rows(self.h, self._f64(T_rows), self._p(info) if info is not None else None,
                                               self._f64(g), lmax, F, nu0, nnu, self._f64(alm)))
         return alm
+
+    def draw_alm_numpy(self, T, info, rng, lmax, F, nu0=0, nnu=None, out=None, rows=False, ring_bytes=0, defer=False):
+        """``corahip_draw_alm_numpy``: K3 with numpy's own stream generated on the device range by range (no 16 F nalm
+        byte buffer).  ``rng``: ("pcg64", state, inc) python ints of a PCG64 bit generator, or ("legacy",
+        get_state(legacy=False) dict).  ``rows``: T is the row block [L, nnu, F].  Returns (alm, state after): the PCG64
+        state as a python int, or the legacy state dict ``set_state`` takes.  ``defer``: returns (alm, finish) instead -
+        everything is enqueued, nothing waited for; ``finish()`` (``corahip_draw_alm_numpy_end``: the one read-back)
+        returns the state after and is called once the caller has enqueued what follows (the synthesis)."""
+        import numpy as np
+
+        nnu = F if nnu is None else nnu
+        assert tuple(T.shape) == ((lmax + 1, nnu, F) if rows else (lmax + 1, F, F)), T.shape
+        nalm = (lmax + 1) * (lmax + 2) // 2
+        alm = out if out is not None else self.empty((nalm, (nnu + 3) // 4, 2, 4))
+        r, ms = _rng_struct(rng)
+        pend = c_void_p()
+        _check(self.lib.corahip_draw_alm_numpy_begin(self.h, self._f64(T), 1 if rows else 0,
+                                                     self._p(info) if info is not None else None, ctypes.byref(r), lmax, F,
+                                                     nu0, nnu, self._f64(alm), int(ring_bytes), ctypes.byref(pend)))
+        keep = [T, info, alm]           # (alive until the queue has been waited for)
+
+        def finish():
+            _check(self.lib.corahip_draw_alm_numpy_end(self.h, pend, ctypes.byref(r)))
+            keep.clear()
+            if ms is not None:
+                return {"bit_generator": "MT19937", "state": {"key": np.frombuffer(ms.key, dtype=np.uint32).copy(), "pos": int(ms.pos)},
+                        "has_gauss": int(ms.has_gauss), "gauss": float(ms.gauss)}
+            return (int(r.state[0]) << 64) | int(r.state[1])
+
+        if defer:
+            return alm, finish
+        return alm, finish()
 
     def draw_alm_philox(self, T, info, seed, lmax, F, nu0=0, nnu=None, out=None):
         nnu = F if nnu is None else nnu

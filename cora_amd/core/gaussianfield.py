@@ -5,10 +5,12 @@ and attributes, with ``getfield`` = (normals * kweight) -> ``irfftn`` running in
 The k-space weights come from the user's ``powerspectrum`` callable (host, once) and then stay
 resident on the device.
 """
+import math
+
 import numpy as np
 
 from .. import _lib
-from ..util import fftutil
+from ..util import constants, fftutil
 from . import maps
 
 
@@ -102,3 +104,38 @@ class RandomFieldA2F(_MapGeometryField, maps.Map3d):
 
 class RandomFieldA2(_MapGeometryField, maps.Map2d):
     """Two angles; geometry from the ``Map2d`` attributes (gaussianfield.py:141-156)."""
+
+
+class Cmb(RandomFieldA2):
+    r"""A patch of the CMB (gaussianfield.py:159-182): ``psfile`` holds (l, l(l+1)C_l/2pi) rows as CAMB writes them
+    (``cambnorm``) or (l, C_l) rows; the spectrum is a log-log spline in \|k\|.  (The reference's default file,
+    ``cora/core/ps_cmb2.dat``, is not part of its tree: a ``psfile`` must be given.)"""
+
+    def __init__(self, psfile=None, cambnorm=True):
+        from ..util.cubicspline import LogInterpolater
+
+        if psfile is None:
+            from os.path import dirname, join
+
+            psfile = join(dirname(__file__), "ps_cmb2.dat")
+        if cambnorm:
+            a = np.loadtxt(psfile)
+            l = a[:, 0]
+            tt = (2 * math.pi) * a[:, 1] / (l * (l + 1.0))
+            self._powerspectrum_int = LogInterpolater(np.vstack((l, tt)).T)
+        else:
+            self._powerspectrum_int = LogInterpolater.fromfile(psfile)
+
+    def powerspectrum(self, karray):
+        return self._powerspectrum_int((karray**2).sum(axis=2) ** 0.5)
+
+
+class TestF(RandomFieldA2F):
+    """Test spectrum: a Gaussian of 250 MHz^-1 along frequency times a 1-degree Gaussian on the sky
+    (gaussianfield.py:185-191)."""
+
+    __test__ = False      # (not a pytest class)
+
+    def powerspectrum(self, karray):
+        return (np.exp(-0.5 * (karray[..., 0] / (2 * math.pi / 250.0)) ** 2)
+                * np.exp(-0.5 * (karray[..., 1:3] ** 2).sum(axis=3) / (2 * math.pi / (1.0 * constants.degree)) ** 2))

@@ -102,6 +102,29 @@ class Map3d(Map2d):
     # older spelling still used by callers of the reference
     nu_pixels = frequencies
 
+    @classmethod
+    def like_kiyo_map(cls, mapobj, *args, **kwargs):
+        r"""A Map3d (or subclass) with the geometry of one of Kiyo's map objects (maps.py:175-201): ``mapobj`` offers
+        ``get_axis("freq" | "ra" | "dec")`` (frequencies in Hz, angles in degrees) and ``info["dec_centre"]``."""
+        c = cls(*args, **kwargs)
+
+        freq_axis = mapobj.get_axis("freq")
+        ra_axis = mapobj.get_axis("ra")
+        dec_axis = mapobj.get_axis("dec")
+
+        ra_fact = np.cos(np.pi * mapobj.info["dec_centre"] / 180.0)
+        c.x_width = (max(ra_axis) - min(ra_axis)) * ra_fact
+        c.y_width = max(dec_axis) - min(dec_axis)
+        c.x_num, c.y_num = (len(ra_axis), len(dec_axis))
+
+        c.nu_lower = min(freq_axis) / 1.0e6
+        c.nu_upper = max(freq_axis) / 1.0e6
+        c.nu_num = len(freq_axis)
+
+        print("Map3D: %dx%d field (%fx%f deg) from nu=%f to nu=%f (%d bins)"
+              % (c.x_num, c.y_num, c.x_width, c.y_width, c.nu_lower, c.nu_upper, c.nu_num))
+        return c
+
     def _set_nu_num(self, num):
         self._nu_num = num
 

@@ -202,7 +202,9 @@ def _legacy_state_of(rng):
 
 
 def stream_normals(ctx, numz, maxl, rng):
-    """The normal stream of one realisation in the reference's draw order (:func:`_host_normals`) as a device array.
+    """The WHOLE normal stream of one realisation in the reference's draw order (:func:`_host_normals`) as a device
+    array of 2 F nalm doubles - for callers that want the numbers themselves (tests, `corahip_draw_alm`); the product
+    path does not materialise it any more (:func:`draw_numpy_stream`).
 
     A ``Generator`` on PCG64 is continued ON THE DEVICE (``corahip_normals_pcg64``: the same PCG64 + ziggurat
     sequence, bit for bit) and left exactly where ``rng.standard_normal`` would have left it: its state is advanced by
@@ -229,6 +231,75 @@ def stream_normals(ctx, numz, maxl, rng):
         st["state"]["state"] = _lib.pcg64_advance(s, inc, nraw)
         bg.state = st                                      # (has_uint32 / uinteger untouched, as standard_normal leaves them)
     return g
+
+
+def draw_numpy_stream(ctx, T, info, rng, maxl, numz, nu0=0, nnu=None, out=None, rows=False, defer=False):
+    """K3 with the REFERENCE's normals: ``a_lm = T_l g_l`` for channels ``[nu0, nu0 + nnu)`` where ``g`` is what
+    ``complex_std_normal((numz, l + 1), rng)`` returns inside the reference's l loop (cora/core/skysim.py:114-121,
+    cora/util/nputil.py:104-125) - drawn the way the reference draws them: range of multipoles by range, never the
+    16 F nalm bytes of a whole realisation at once (``corahip_draw_alm_numpy``).
+
+    rng : ``numpy.random.Generator`` on PCG64 (``default_rng(seed)``, cora/signal/lss.py:449-450), ``None`` (numpy's
+        legacy global state, what ``Sky3d.getsky()`` draws from, cora/core/maps.py:235-237) or a ``RandomState``:
+        continued on the device bit for bit and left where numpy would leave it (for the legacy generators as an
+        equivalent (key, pos) pair: the NEXT draws are numpy's, ``get_state()`` itself may differ in representation).
+        Any other generator is consumed on the host, l by l, and uploaded.
+    T : full factors ``[L, F, F]`` or, with ``rows``, the row block ``[L, nnu, F]`` of a frequency shard.
+    defer : return ``(alm, finish)``: the draw is only ENQUEUED; ``finish()`` - to be called after the caller has
+        enqueued what follows, e.g. the synthesis - waits for the queue and writes the generator's state back (the
+        generator's lock is held until then).  Default: ``alm``, generator already updated.
+    A device-side failure of the generator (its margins are > 100 sigma) falls back to the host stream with the
+    caller's generator untouched."""
+    nnu = numz if nnu is None else nnu
+
+    def host_path():
+        g = _upload_host_normals(ctx, numz, maxl, rng)
+        if rows:
+            return ctx.draw_alm_rows(T, info, g, maxl, numz, nu0, nnu, out=out)
+        return ctx.draw_alm(T, info, g, maxl, numz, nu0=nu0, nnu=nnu, out=out)
+
+    def done(alm, finish=lambda: None):
+        if defer:
+            return alm, finish
+        finish()
+        return alm
+
+    legacy = _legacy_state_of(rng)
+    pcg = legacy is None and _is_pcg64_generator(rng)
+    if legacy is None and not pcg:
+        return done(host_path())
+    if legacy is not None:
+        get_state, set_state, lock = legacy
+    else:
+        bg = rng.bit_generator
+        lock = bg.lock                                     # the lock numpy's own draws hold
+    lock.acquire()
+    try:
+        if legacy is not None:
+            spec = ("legacy", get_state(legacy=False))
+        else:
+            st = bg.state
+            spec = ("pcg64", int(st["state"]["state"]), int(st["state"]["inc"]))
+        alm, fin = ctx.draw_alm_numpy(T, info, spec, maxl, numz, nu0=nu0, nnu=nnu, out=out, rows=rows, defer=True)
+    except _lib.CoraHipError:
+        lock.release()
+        return done(host_path())
+    except BaseException:
+        lock.release()
+        raise
+
+    def finish():
+        try:
+            after = fin()
+            if legacy is not None:
+                set_state(after)
+            else:
+                st["state"]["state"] = after
+                bg.state = st                              # (has_uint32 / uinteger untouched, as standard_normal leaves them)
+        finally:
+            lock.release()
+
+    return done(alm, finish)
 
 
 def factor_device(corr):
@@ -266,9 +337,13 @@ def mkfullsky_device(corr, nside, alms=False, rng=None, factors=None, nu_range=N
     if isinstance(rng, DeviceRNG):
         alm = ctx.draw_alm_philox(T, info, rng.next_seed(), maxl, numz, nu0=nu0, nnu=nnu)
     else:
-        g = stream_normals(ctx, numz, maxl, rng)
-        alm = ctx.draw_alm(T, info, g, maxl, numz, nu0=nu0, nnu=nnu)
-        del g
+        # the draw is enqueued, the synthesis behind it; only then is the generator's state waited for
+        alm, finish = draw_numpy_stream(ctx, T, info, rng, maxl, numz, nu0=nu0, nnu=nnu, defer=True)
+        try:
+            out = ctx.alm_dev_to_square(alm, maxl, nnu) if alms else ctx.alm2map(alm, int(nside), maxl, nnu)
+        finally:
+            finish()
+        return out
     if alms:
         return ctx.alm_dev_to_square(alm, maxl, nnu)
     return ctx.alm2map(alm, int(nside), maxl, nnu)
@@ -288,9 +363,12 @@ def mkfullsky(corr, nside, alms=False, rng=None):
     rng : numpy Generator, :class:`cora_amd.DeviceRNG`, optional
         Seeded generator.  A numpy ``Generator`` on PCG64 (``default_rng(seed)``) is continued
         on the GPU - the same values cora draws, in the reference's order, and the generator
-        is left in the state cora would leave it in; ``None`` (numpy's legacy global state)
-        and other bit generators are consumed on the host in that order; a ``DeviceRNG``
-        is the library's own counter-based stream (not numpy's numbers).
+        is left in the state cora would leave it in; ``None`` (numpy's legacy global MT19937
+        state, what the reference draws from here) and ``RandomState`` instances are continued
+        on the GPU as well (an equivalent (key, pos) state is written back: the next draws are
+        numpy's); other bit generators are consumed on the host in that order; a ``DeviceRNG``
+        is the library's own counter-based stream (not numpy's numbers).  The normals are
+        generated range of multipoles by range, as the reference's loop consumes them.
 
     Returns
     -------

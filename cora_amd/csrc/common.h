@@ -38,14 +38,19 @@ struct corahip_ctx {
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;                 // second stream for kernels that run beside those of `stream` (K5 pair)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // the l-range pipeline of the numpy-stream draw (drawstream.hip): its generator stream and the ring's events
+    hipStream_t gen_stream = nullptr;
+    hipEvent_t ev_ring[8] = {};
     hipEvent_t t0 = nullptr, t1 = nullptr;
     bool profile = false;
     std::map<std::string, corahip_prof_entry> prof;
     std::vector<corahip_pending_event> pending;
     int num_cu = 256;
+    size_t total_mem = 0;                          // device memory (bytes)
     // grow-only device scratch slots owned by the context (freed by ctx_destroy)
     // slots: 0 K1 transposed tables, 1 K1 pair results / odd-F normal stream, 2 K1 pair list, 3 zeros,
-    //        4 Legendre matrix of legendre_project, 5 its zero-padded operand, 6 block tables of normals_pcg64
+    //        4 Legendre matrix of legendre_project, 5 its zero-padded operand, 6 block tables of normals_pcg64 /
+    //        segment tables of normals_mt19937_legacy, 7 the two-slot ring of the l-range pipeline (drawstream.hip)
     void *scratch[CORAHIP_NSCRATCH] = {};
     size_t scratch_bytes[CORAHIP_NSCRATCH] = {};
     // K1 transposed tables resident in scratch slot 0: valid for the pinned (dd, dv, vv, generation) only
@@ -69,16 +74,19 @@ struct StageTimer {
     corahip_ctx *ctx;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     const char *name;
-    StageTimer(corahip_ctx *c, const char *n) : ctx(c), name(n) {
+    hipStream_t stream;
+    // `on`: the stream the timed launches go to (default: the context's; the events of another stream must have completed
+    // by the time the context's stream is drained - true for the side streams of the library, which it always joins)
+    StageTimer(corahip_ctx *c, const char *n, hipStream_t on = nullptr, bool other = false) : ctx(c), name(n), stream(other ? on : c->stream) {
         if (ctx->profile) {
             (void)hipEventCreate(&e0);
             (void)hipEventCreate(&e1);
-            (void)hipEventRecord(e0, ctx->stream);
+            (void)hipEventRecord(e0, stream);
         }
     }
     ~StageTimer() {
         if (ctx->profile) {
-            (void)hipEventRecord(e1, ctx->stream);
+            (void)hipEventRecord(e1, stream);
             ctx->pending.push_back({name, e0, e1});
         }
     }

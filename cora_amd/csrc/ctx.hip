@@ -55,6 +55,7 @@ int corahip_ctx_create(int device_id, corahip_ctx **out) {
     corahip_ctx *c = new corahip_ctx();
     c->device = device_id;
     c->num_cu = prop.multiProcessorCount;
+    c->total_mem = prop.totalGlobalMem;
     HIP_TRY(hipEventCreate(&c->t0));
     HIP_TRY(hipEventCreate(&c->t1));
     *out = c;
@@ -75,6 +76,12 @@ int corahip_ctx_destroy(corahip_ctx *ctx) {
         (void)hipStreamDestroy(ctx->stream2);
         (void)hipEventDestroy(ctx->ev_fork);
         (void)hipEventDestroy(ctx->ev_join);
+    }
+    if (ctx->gen_stream) {
+        (void)hipStreamSynchronize(ctx->gen_stream);
+        (void)hipStreamDestroy(ctx->gen_stream);
+        for (auto &e : ctx->ev_ring)
+            if (e) (void)hipEventDestroy(e);
     }
     for (int i = 0; i < CORAHIP_NSCRATCH; i++)
         if (ctx->scratch[i]) (void)hipFree(ctx->scratch[i]);

@@ -14,6 +14,7 @@
 #include <type_traits>
 
 #include "rng_dev.h"
+#include "stream_internal.h"
 
 // The device stream: the real and the imaginary normal of (l, nu', m) are the two Box-Muller outputs of Philox
 // counter {lo = m, hi = l F + nu'} under key = seed, built from the four output words as rng_dev.h describes
@@ -61,12 +62,13 @@ __global__ void normals_kernel(uint64_t seed, int lmax, int F, double *__restric
 template <int NCT>
 __global__ void __launch_bounds__(256)
 draw_kernel(const double *__restrict__ T, size_t t_ldl, int t_row0, const int32_t *__restrict__ info,
-            const double *__restrict__ g, int lmax, int F, int nu0, int nnu, int Gout, double *__restrict__ alm) {
+            const double *__restrict__ g, size_t g_off, int l_lo, int lmax, int F, int nu0, int nnu, int Gout,
+            double *__restrict__ alm) {
     constexpr int NC = 16 * NCT;
     constexpr int STRIDE = DRAW_KC + 2;  // doubles per channel row: 272 B, so 16 consecutive rows hit 16 distinct 16-B slots
     extern __shared__ __attribute__((aligned(16))) double lds[];  // Bs[n][k] = T_l[nu0+col0+n][k0+k], [NC][STRIDE]
 
-    const int l = blockIdx.x;
+    const int l = l_lo + blockIdx.x;
     const int nrow = 2 * (l + 1);
     const int row0 = blockIdx.y * DRAW_ROWS;
     if (row0 >= nrow) return;
@@ -75,8 +77,8 @@ draw_kernel(const double *__restrict__ T, size_t t_ldl, int t_row0, const int32_
     const int ri = lane & 15, kq = lane >> 4;
     const int lp1 = l + 1;
 
-    // stream offset of this l: sum_{l'<l} 2 F (l'+1) = F l (l+1)
-    const double *gl = g + (size_t)F * l * (l + 1);
+    // stream offset of this l: sum_{l'<l} 2 F (l'+1) = F l (l+1); g[0] is element g_off of the stream
+    const double *gl = g + ((size_t)F * l * (l + 1) - g_off);
     const double *Tl = T + (size_t)l * t_ldl - (size_t)t_row0 * F;  // row nu of T_l at Tl + nu F (rows < t_row0 never read)
     const bool dense = (info == nullptr) || (info[l] != 0);
 
@@ -194,10 +196,10 @@ __device__ static inline void draw_static_for(Fn &&f) {
 #define DRAW_MB (16 * DRAW_WAVES)    // m per work item
 #define DRAW_NBUF 3                  // stages in the LDS ring
 
-// number of (l, m-block) slots: l in band j = l >> 7 has j + 1 blocks of 128 m
-static inline long draw_slots(int lmax) {
+// number of (l, m-block) slots of the multipoles l_lo .. l_hi: l in band j = l >> 7 has j + 1 blocks of 128 m
+static inline long draw_slots(int l_lo, int l_hi) {
     long n = 0;
-    for (int l = 0; l <= lmax; l++) n += (l / DRAW_MB) + 1;
+    for (int l = l_lo; l <= l_hi; l++) n += (l / DRAW_MB) + 1;
     return n;
 }
 
@@ -210,8 +212,9 @@ static inline long draw_slots(int lmax) {
 template <int NCT, bool FROMG = false>
 __global__ void __launch_bounds__(64 * DRAW_WAVES, 2)
 draw_rng_kernel(const double *__restrict__ T, size_t t_ldl, int t_row0, const int32_t *__restrict__ info,
-                const double *__restrict__ zeros, uint64_t seed, const double *__restrict__ gsrc, int lmax, int F, int nu0,
-                int nnu, int Gout, int nslots, int ncg, double *__restrict__ alm, unsigned *__restrict__ queue) {
+                const double *__restrict__ zeros, uint64_t seed, const double *__restrict__ gsrc, size_t g_off, int l_lo,
+                int l_hi, int lmax, int F, int nu0, int nnu, int Gout, int nslots, int ncg, double *__restrict__ alm,
+                unsigned *__restrict__ queue) {
     constexpr int NC = 16 * NCT;
     constexpr int ROWD = DRAW_KC;            // doubles per channel row in LDS: 256 B, unpadded (DMA is lane-linear)
     constexpr int BUF = NC * ROWD;           // doubles per stage
@@ -243,9 +246,9 @@ draw_rng_kernel(const double *__restrict__ T, size_t t_ldl, int t_row0, const in
         const int cg = ncg - 1 - it / nslots;          // the column groups with the longest nu' range first
         int s = it - (it / nslots) * nslots;
         int l = 0, mb = 0;
-        for (int j = lmax / DRAW_MB; j >= 0; j--) {    // bands of l from the top: j + 1 blocks of m per l
-            const int lhi = min(lmax, DRAW_MB * j + DRAW_MB - 1);
-            const int cnt = (lhi - DRAW_MB * j + 1) * (j + 1);
+        for (int j = l_hi / DRAW_MB; j >= l_lo / DRAW_MB; j--) {    // bands of l from the top of the launch's range [l_lo, l_hi]: j + 1 blocks of m per l
+            const int lhi = min(l_hi, DRAW_MB * j + DRAW_MB - 1), llo = max(l_lo, DRAW_MB * j);
+            const int cnt = (lhi - llo + 1) * (j + 1);
             if (s < cnt) {
                 l = lhi - s / (j + 1);
                 mb = s - (s / (j + 1)) * (j + 1);
@@ -305,12 +308,13 @@ draw_rng_kernel(const double *__restrict__ T, size_t t_ldl, int t_row0, const in
     // a_y the second; each is requested half a chunk before its use
     double a_x[8], a_y[8];
     // requests half `half` of chunk c of item `w` for this wave's rows: element (l, c, nu', m) of the stream-order buffer
-    // sits at F l (l + 1) + c F (l + 1) + nu' (l + 1) + m; rows past l and nu' past F - 1 are read from the clamped
+    // sits at F l (l + 1) + c F (l + 1) + nu' (l + 1) + m - g_off (g_off = F l_lo (l_lo + 1) when gsrc holds the stream
+    // from multipole l_lo on: one slot of the l-range ring); rows past l and nu' past F - 1 are read from the clamped
     // address (finite values: their products meet staged zeros or are never stored)
     auto issue_a = [&](const item_t &w, int c, int half, double (&dst)[8]) {
         const int lp1 = w.l + 1;
         const int m = min(w.mb * DRAW_MB + 16 * wave + ri, w.l);
-        const double *gre = gsrc + (size_t)F * w.l * lp1 + m;
+        const double *gre = gsrc + ((size_t)F * w.l * lp1 - g_off) + m;
         const size_t im_off = (size_t)F * lp1;
 #pragma unroll
         for (int kk = 0; kk < 4; kk++) {
@@ -518,9 +522,12 @@ draw_rng_kernel(const double *__restrict__ T, size_t t_ldl, int t_row0, const in
 #endif
 }
 
+// l_lo .. l_hi: the multipoles of this launch (0 .. lmax: all); FROMG: gsrc[0] is element g_off of the stream-order
+// buffer; `stream`: where the launch goes (the context's stream, or the draw stream of the l-range pipeline)
 template <int NCT, bool FROMG = false>
-static int launch_draw_rng(corahip_ctx *ctx, const double *T, size_t t_ldl, int t_row0, const int32_t *info,
-                           uint64_t seed, const double *gsrc, int lmax, int F, int nu0, int nnu, int Gout, double *alm) {
+static int launch_draw_rng(corahip_ctx *ctx, hipStream_t stream, const double *T, size_t t_ldl, int t_row0, const int32_t *info,
+                           uint64_t seed, const double *gsrc, size_t g_off, int l_lo, int l_hi, int lmax, int F, int nu0,
+                           int nnu, int Gout, double *alm) {
     constexpr int NC = 16 * NCT;
     const size_t shm = sizeof(double) * DRAW_NBUF * NC * DRAW_KC;
     HIP_TRY(hipFuncSetAttribute((const void *)draw_rng_kernel<NCT, FROMG>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -529,22 +536,22 @@ static int launch_draw_rng(corahip_ctx *ctx, const double *T, size_t t_ldl, int 
     char *zq = nullptr;
     int rc = corahip_ctx_scratch(ctx, 3, 8192, (void **)&zq);
     if (rc) return rc;
-    HIP_TRY(hipMemsetAsync(zq, 0, 8192, ctx->stream));
+    HIP_TRY(hipMemsetAsync(zq, 0, 8192, stream));
     const int ncg = (4 * Gout + NC - 1) / NC;
-    const long nslots = draw_slots(lmax);
+    const long nslots = draw_slots(l_lo, l_hi);
     const long nitems = nslots * ncg;
     ARG_CHECK(nitems < (1L << 30));
     // persistent: one workgroup per CU for the 128-channel shape (106 KB of LDS), two for the narrower ones
     const int per_cu = (shm + 8300 > 80 * 1024) ? 1 : 2;
     dim3 grid((unsigned)std::min<long>(nitems, (long)ctx->num_cu * per_cu));
-    draw_rng_kernel<NCT, FROMG><<<grid, 64 * DRAW_WAVES, shm, ctx->stream>>>(T, t_ldl, t_row0, info, (const double *)zq, seed,
-                                                                             gsrc, lmax, F, nu0, nnu, Gout, (int)nslots, ncg,
-                                                                             alm, (unsigned *)(zq + 4096));
+    draw_rng_kernel<NCT, FROMG><<<grid, 64 * DRAW_WAVES, shm, stream>>>(T, t_ldl, t_row0, info, (const double *)zq, seed, gsrc,
+                                                                        g_off, l_lo, l_hi, lmax, F, nu0, nnu, Gout,
+                                                                        (int)nslots, ncg, alm, (unsigned *)(zq + 4096));
     LAUNCH_CHECK();
 #if DRAW_STAMPS
     {
         unsigned long long hs[8], z[8] = {0};
-        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        HIP_TRY(hipStreamSynchronize(stream));
         HIP_TRY(hipMemcpyFromSymbol(hs, HIP_SYMBOL(g_draw_stamps), sizeof(hs)));
         const double per = 1.0 / (double)std::max<unsigned long long>(hs[7], 1);
         fprintf(stderr, "K3 NCT=%d waves=%llu: cycles/wave  prologue %.0f wait+barrier %.0f (first chunk of an item %.0f) stage-issue %.0f rng+mfma %.0f next-item %.0f epilogue %.0f\n",
@@ -595,13 +602,14 @@ __global__ void packed_to_dev_kernel(const double *__restrict__ packed, long nal
 }
 
 template <int NCT>
-static int launch_draw(corahip_ctx *ctx, const double *T, size_t t_ldl, int t_row0, const int32_t *info,
-                       const double *g, int lmax, int F, int nu0, int nnu, int Gout, double *alm) {
+static int launch_draw(corahip_ctx *ctx, hipStream_t stream, const double *T, size_t t_ldl, int t_row0, const int32_t *info,
+                       const double *g, size_t g_off, int l_lo, int l_hi, int lmax, int F, int nu0, int nnu, int Gout,
+                       double *alm) {
     constexpr int NC = 16 * NCT;
     const size_t shm = sizeof(double) * NC * (DRAW_KC + 2);
     HIP_TRY(hipFuncSetAttribute((const void *)draw_kernel<NCT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-    dim3 grid(lmax + 1, (2 * (lmax + 1) + DRAW_ROWS - 1) / DRAW_ROWS, (4 * Gout + NC - 1) / NC);
-    draw_kernel<NCT><<<grid, 256, shm, ctx->stream>>>(T, t_ldl, t_row0, info, g, lmax, F, nu0, nnu, Gout, alm);
+    dim3 grid(l_hi - l_lo + 1, (2 * (l_hi + 1) + DRAW_ROWS - 1) / DRAW_ROWS, (4 * Gout + NC - 1) / NC);
+    draw_kernel<NCT><<<grid, 256, shm, stream>>>(T, t_ldl, t_row0, info, g, g_off, l_lo, lmax, F, nu0, nnu, Gout, alm);
     LAUNCH_CHECK();
     return 0;
 }
@@ -617,23 +625,30 @@ int corahip_normals_philox(corahip_ctx *ctx, uint64_t seed, int lmax, int F, dou
     return 0;
 }
 
-static int draw_host_stream(corahip_ctx *ctx, const double *T, size_t t_ldl, int t_row0, const int32_t *info,
-                            const double *g, int lmax, int F, int nu0, int nnu, double *alm_dev) {
-    StageTimer t(ctx, "draw");
+// K3 of the multipoles l_lo .. l_hi from a stream-order buffer whose first element is element g_off of the stream
+static int draw_stream_range(corahip_ctx *ctx, hipStream_t stream, const double *T, size_t t_ldl, int t_row0, const int32_t *info,
+                             const double *g, size_t g_off, int l_lo, int l_hi, int lmax, int F, int nu0, int nnu,
+                             double *alm_dev) {
     const int Gout = (nnu + 3) / 4;
     const int ncol = 4 * Gout;
     if (!(F & 1) && !getenv("CORAHIP_DRAW_GENERIC")) {
         // the persistent MFMA kernel of the device-RNG mode with its A operands read from the stream buffer
-        if (ncol <= 16) return launch_draw_rng<1, true>(ctx, T, t_ldl, t_row0, info, 0, g, lmax, F, nu0, nnu, Gout, alm_dev);
-        if (ncol <= 32) return launch_draw_rng<2, true>(ctx, T, t_ldl, t_row0, info, 0, g, lmax, F, nu0, nnu, Gout, alm_dev);
-        if (ncol <= 64) return launch_draw_rng<4, true>(ctx, T, t_ldl, t_row0, info, 0, g, lmax, F, nu0, nnu, Gout, alm_dev);
-        return launch_draw_rng<8, true>(ctx, T, t_ldl, t_row0, info, 0, g, lmax, F, nu0, nnu, Gout, alm_dev);
+        if (ncol <= 16) return launch_draw_rng<1, true>(ctx, stream, T, t_ldl, t_row0, info, 0, g, g_off, l_lo, l_hi, lmax, F, nu0, nnu, Gout, alm_dev);
+        if (ncol <= 32) return launch_draw_rng<2, true>(ctx, stream, T, t_ldl, t_row0, info, 0, g, g_off, l_lo, l_hi, lmax, F, nu0, nnu, Gout, alm_dev);
+        if (ncol <= 64) return launch_draw_rng<4, true>(ctx, stream, T, t_ldl, t_row0, info, 0, g, g_off, l_lo, l_hi, lmax, F, nu0, nnu, Gout, alm_dev);
+        return launch_draw_rng<8, true>(ctx, stream, T, t_ldl, t_row0, info, 0, g, g_off, l_lo, l_hi, lmax, F, nu0, nnu, Gout, alm_dev);
     }
-    if (ncol <= 16) return launch_draw<1>(ctx, T, t_ldl, t_row0, info, g, lmax, F, nu0, nnu, Gout, alm_dev);
-    if (ncol <= 32) return launch_draw<2>(ctx, T, t_ldl, t_row0, info, g, lmax, F, nu0, nnu, Gout, alm_dev);
-    if (ncol <= 64) return launch_draw<4>(ctx, T, t_ldl, t_row0, info, g, lmax, F, nu0, nnu, Gout, alm_dev);
-    if (ncol <= 128) return launch_draw<8>(ctx, T, t_ldl, t_row0, info, g, lmax, F, nu0, nnu, Gout, alm_dev);
-    return launch_draw<16>(ctx, T, t_ldl, t_row0, info, g, lmax, F, nu0, nnu, Gout, alm_dev);
+    if (ncol <= 16) return launch_draw<1>(ctx, stream, T, t_ldl, t_row0, info, g, g_off, l_lo, l_hi, lmax, F, nu0, nnu, Gout, alm_dev);
+    if (ncol <= 32) return launch_draw<2>(ctx, stream, T, t_ldl, t_row0, info, g, g_off, l_lo, l_hi, lmax, F, nu0, nnu, Gout, alm_dev);
+    if (ncol <= 64) return launch_draw<4>(ctx, stream, T, t_ldl, t_row0, info, g, g_off, l_lo, l_hi, lmax, F, nu0, nnu, Gout, alm_dev);
+    if (ncol <= 128) return launch_draw<8>(ctx, stream, T, t_ldl, t_row0, info, g, g_off, l_lo, l_hi, lmax, F, nu0, nnu, Gout, alm_dev);
+    return launch_draw<16>(ctx, stream, T, t_ldl, t_row0, info, g, g_off, l_lo, l_hi, lmax, F, nu0, nnu, Gout, alm_dev);
+}
+
+static int draw_host_stream(corahip_ctx *ctx, const double *T, size_t t_ldl, int t_row0, const int32_t *info,
+                            const double *g, int lmax, int F, int nu0, int nnu, double *alm_dev) {
+    StageTimer t(ctx, "draw");
+    return draw_stream_range(ctx, ctx->stream, T, t_ldl, t_row0, info, g, 0, 0, lmax, lmax, F, nu0, nnu, alm_dev);
 }
 
 static int draw_philox(corahip_ctx *ctx, const double *T, size_t t_ldl, int t_row0, const int32_t *info,
@@ -650,10 +665,10 @@ static int draw_philox(corahip_ctx *ctx, const double *T, size_t t_ldl, int t_ro
     StageTimer t(ctx, "draw");
     const int Gout = (nnu + 3) / 4;
     const int ncol = 4 * Gout;
-    if (ncol <= 16) return launch_draw_rng<1>(ctx, T, t_ldl, t_row0, info, seed, nullptr, lmax, F, nu0, nnu, Gout, alm_dev);
-    if (ncol <= 32) return launch_draw_rng<2>(ctx, T, t_ldl, t_row0, info, seed, nullptr, lmax, F, nu0, nnu, Gout, alm_dev);
-    if (ncol <= 64) return launch_draw_rng<4>(ctx, T, t_ldl, t_row0, info, seed, nullptr, lmax, F, nu0, nnu, Gout, alm_dev);
-    return launch_draw_rng<8>(ctx, T, t_ldl, t_row0, info, seed, nullptr, lmax, F, nu0, nnu, Gout, alm_dev);
+    if (ncol <= 16) return launch_draw_rng<1>(ctx, ctx->stream, T, t_ldl, t_row0, info, seed, nullptr, 0, 0, lmax, lmax, F, nu0, nnu, Gout, alm_dev);
+    if (ncol <= 32) return launch_draw_rng<2>(ctx, ctx->stream, T, t_ldl, t_row0, info, seed, nullptr, 0, 0, lmax, lmax, F, nu0, nnu, Gout, alm_dev);
+    if (ncol <= 64) return launch_draw_rng<4>(ctx, ctx->stream, T, t_ldl, t_row0, info, seed, nullptr, 0, 0, lmax, lmax, F, nu0, nnu, Gout, alm_dev);
+    return launch_draw_rng<8>(ctx, ctx->stream, T, t_ldl, t_row0, info, seed, nullptr, 0, 0, lmax, lmax, F, nu0, nnu, Gout, alm_dev);
 }
 
 int corahip_draw_alm_philox(corahip_ctx *ctx, const double *T, const int32_t *info, uint64_t seed, int lmax, int F,
@@ -705,3 +720,10 @@ int corahip_alm_packed_to_dev(corahip_ctx *ctx, const double *packed, int lmax, 
 }
 
 }  // extern "C"
+
+// (stream_internal.h) K3 of one l range of the numpy-stream pipeline (drawstream.hip)
+int corahip_draw_range(corahip_ctx *ctx, hipStream_t stream, const double *T, int rows, const int32_t *info, const double *gslot,
+                       size_t g_off, int l_lo, int l_hi, int lmax, int F, int nu0, int nnu, double *alm_dev) {
+    return draw_stream_range(ctx, stream, T, rows ? (size_t)nnu * F : (size_t)F * F, rows ? nu0 : 0, info, gslot, g_off, l_lo, l_hi,
+                             lmax, F, nu0, nnu, alm_dev);
+}

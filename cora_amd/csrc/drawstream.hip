@@ -1,0 +1,179 @@
+// drawstream.hip - K3 fed with numpy's OWN normal stream, generated on the device one range of multipoles at a time.
+//
+// The reference draws inside its l loop (cora/core/skysim.py:114-121: for every l `complex_std_normal((numz, l + 1), rng)`,
+// cora/util/nputil.py:121-125, then `np.dot(trans, gaussvars)`): at no time do more than 2 F (l + 1) normals exist.
+// Rounds 1-4 of this library materialised the whole stream of a realisation first (16 F nalm bytes: 8.6 GB at cfg 3,
+// 137 GB at cfg 5 - more than the rest of a rank's working set).  Here the stream is produced the way it is consumed:
+//
+//   prepare   the generator's count + scan passes over the WHOLE stream (they are what solves the prefix problem of the
+//             ziggurat / the compaction of the polar method, npnormal.hip / mtlegacy.hip) - tables of ~0.3 bytes per normal
+//   ranges    the multipoles are cut into ranges of <= slot bytes of normals (whole l, at least one); the emit pass of
+//             range r writes slot r % 2 of a two-slot ring on the generator stream while K3 (draw.hip, the persistent
+//             MFMA kernel reading its A operands from the slot) consumes range r - 1 on the context's stream; two events
+//             per slot order "emitted -> drawn -> refilled"
+//   finish    the generator state numpy would be left in: ONE read-back, which the caller places where it likes
+//             (corahip_draw_alm_numpy_end) - behind the launches of the synthesis, so that the host never waits with an
+//             empty queue in the middle of a step
+//
+// Every rank of a frequency-sharded job runs this for its own rows of the factors (rows = 1: T is the row block
+// [L, nnu, F] the all-to-all delivered, no zero-padded [L, F, F] stack).
+#include "stream_internal.h"
+
+#include <algorithm>
+#include <cstdlib>
+
+namespace {
+
+int ring_setup(corahip_ctx *ctx) {
+    if (!ctx->gen_stream) {
+        HIP_TRY(hipStreamCreateWithFlags(&ctx->gen_stream, hipStreamNonBlocking));
+        for (auto &e : ctx->ev_ring) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    return 0;
+}
+
+}  // namespace
+
+struct corahip_draw_pending {
+    zig_session *zs = nullptr;
+    mt_session *ms = nullptr;
+};
+
+static void pending_free(corahip_draw_pending *p) {
+    if (!p) return;
+    if (p->zs) zig_stream_free(p->zs);
+    if (p->ms) mt_stream_free(p->ms);
+    delete p;
+}
+
+extern "C" {
+
+int corahip_draw_alm_numpy_begin(corahip_ctx *ctx, const double *T, int rows, const int32_t *info, const corahip_rng *rng,
+                                 int lmax, int F, int nu0, int nnu, double *alm_dev, size_t ring_bytes,
+                                 corahip_draw_pending **pending) {
+    ARG_CHECK(ctx != nullptr && T != nullptr && rng != nullptr && alm_dev != nullptr && pending != nullptr);
+    ARG_CHECK(lmax >= 0 && F >= 1 && nu0 >= 0 && nnu >= 1 && nu0 + nnu <= F);
+    ARG_CHECK(rng->kind == CORAHIP_RNG_PCG64 || rng->kind == CORAHIP_RNG_MT19937);
+    ARG_CHECK(rng->kind != CORAHIP_RNG_MT19937 || rng->legacy != nullptr);
+    *pending = nullptr;
+    int rc = ring_setup(ctx);
+    if (rc) return rc;
+    const unsigned long long total = (unsigned long long)F * (lmax + 1) * (lmax + 2);
+    if (ring_bytes == 0) {
+        // Default: ranges cost time, not save it (measured, cfg 3: one range 12.97 ms, 5 ranges 13.6, 35 ranges 14.4, 135
+        // ranges 18.6 - every range is an emit launch, an event hop and a K3 launch with its own ramp and tail, and the
+        // emit pass cannot run BESIDE K3: 223 VGPRs x 2 waves per SIMD leave no room for its 107), so a stream that is a
+        // small part of the device's memory (<= 1/8: cfg 3 8.6 GB, cfg 4 17.2 GB of 288 GB) stays one range; a larger one
+        // (cfg 5: 137 GB) goes through a ring of 1/16 of the memory (~15 ranges there).  CORAHIP_RING_MB overrides.
+        const char *e = getenv("CORAHIP_RING_MB");
+        if (e) ring_bytes = (size_t)std::max(1L, atol(e)) << 20;
+        else if (8 * total <= ctx->total_mem / 8) ring_bytes = (size_t)16 * total;       // one slot = the whole stream
+        else ring_bytes = std::max<size_t>(ctx->total_mem / 16, (size_t)1 << 30);
+    }
+    // ranges of whole multipoles: l contributes 2 F (l + 1) normals; a slot holds at least the largest l
+    const unsigned long long per_lmax = 2ull * F * (lmax + 1);
+    const unsigned long long slot_elems = std::min(total, std::max<unsigned long long>(ring_bytes / 16, per_lmax));
+    std::vector<int> l_first;
+    std::vector<unsigned long long> bounds;
+    {
+        unsigned long long fill = 0;
+        for (int l = 0; l <= lmax; l++) {
+            const unsigned long long nl = 2ull * F * (l + 1);
+            if (l == 0 || fill + nl > slot_elems) {
+                l_first.push_back(l);
+                bounds.push_back((unsigned long long)F * l * (l + 1));
+                fill = 0;
+            }
+            fill += nl;
+        }
+        bounds.push_back(total);
+        l_first.push_back(lmax + 1);
+    }
+    const int nr = (int)bounds.size() - 1;
+    const int64_t n = (int64_t)total;
+    double *ring = nullptr;
+    if ((rc = corahip_ctx_scratch(ctx, 7, sizeof(double) * (nr > 1 ? 2 : 1) * (size_t)slot_elems, (void **)&ring))) return rc;
+
+    hipStream_t A = ctx->stream, B = ctx->gen_stream;
+    hipEvent_t ev_prep = ctx->ev_ring[0], ev_emit[2] = {ctx->ev_ring[1], ctx->ev_ring[2]}, ev_drawn[2] = {ctx->ev_ring[3], ctx->ev_ring[4]};
+    // The generator stream never starts before the context's stream has reached this call (the ring and the generator
+    // tables may still be read by a draw queued there: a caller that pipelines realisations without synchronising)
+    HIP_TRY(hipEventRecord(ev_prep, A));
+    HIP_TRY(hipStreamWaitEvent(B, ev_prep, 0));
+    corahip_draw_pending *pd = new corahip_draw_pending();
+    if (rng->kind == CORAHIP_RNG_PCG64) rc = zig_stream_prepare(ctx, B, rng->state, rng->inc, n, bounds, &pd->zs);
+    else {
+        corahip_mt_state st0 = *rng->legacy;       // (prepare reads it; the caller's copy is rewritten by _end only)
+        rc = mt_stream_prepare(ctx, B, &st0, n, bounds, &pd->ms);
+    }
+    if (rc) {
+        pending_free(pd);
+        return rc;
+    }
+#define DS_TRY(expr)                                                                                         \
+    do {                                                                                                     \
+        hipError_t _e = (expr);                                                                              \
+        if (_e != hipSuccess) {                                                                              \
+            corahip_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__);   \
+            (void)hipStreamSynchronize(B);                                                                   \
+            (void)hipStreamSynchronize(A);                                                                   \
+            pending_free(pd);                                                                                \
+            return (int)_e;                                                                                  \
+        }                                                                                                    \
+    } while (0)
+    {
+        StageTimer t(ctx, "draw");
+        for (int r = 0; r < nr && !rc; r++) {
+            const int sl = r & 1;
+            double *slot = ring + (size_t)sl * slot_elems;
+            if (r >= 2) DS_TRY(hipStreamWaitEvent(B, ev_drawn[sl], 0));       // the slot's previous range has been drawn
+            rc = pd->zs ? zig_stream_emit_range(ctx, B, pd->zs, r, slot) : mt_stream_emit_range(ctx, B, pd->ms, r, slot);
+            if (rc) break;
+            DS_TRY(hipEventRecord(ev_emit[sl], B));
+            DS_TRY(hipStreamWaitEvent(A, ev_emit[sl], 0));
+            rc = corahip_draw_range(ctx, A, T, rows, info, slot, (size_t)bounds[r], l_first[r], l_first[r + 1] - 1, lmax, F, nu0, nnu,
+                                    alm_dev);
+            if (rc) break;
+            DS_TRY(hipEventRecord(ev_drawn[sl], A));
+        }
+    }
+#undef DS_TRY
+    if (rc) {
+        (void)hipStreamSynchronize(B);
+        (void)hipStreamSynchronize(A);
+        pending_free(pd);
+        return rc;
+    }
+    // (the last draw waited for the last emit: everything of the generator stream is behind the context stream's tail)
+    *pending = pd;
+    return 0;
+}
+
+int corahip_draw_alm_numpy_end(corahip_ctx *ctx, corahip_draw_pending *pd, corahip_rng *rng) {
+    ARG_CHECK(ctx != nullptr && pd != nullptr && rng != nullptr);
+    int rc;
+    if (pd->zs) {
+        uint64_t n_raw = 0, after[2];
+        rc = zig_stream_finish(ctx, ctx->stream, pd->zs, &n_raw);
+        if (!rc) rc = corahip_pcg64_advance(rng->state, rng->inc, n_raw, after);
+        if (!rc) {
+            rng->state[0] = after[0];              // the generator as numpy would leave it
+            rng->state[1] = after[1];
+        }
+    } else {
+        rc = rng->legacy ? mt_stream_finish(ctx, ctx->stream, pd->ms, rng->legacy) : CORAHIP_EINVAL;
+    }
+    if (rc) (void)hipStreamSynchronize(ctx->gen_stream);
+    pending_free(pd);
+    return rc;
+}
+
+int corahip_draw_alm_numpy(corahip_ctx *ctx, const double *T, int rows, const int32_t *info, corahip_rng *rng, int lmax, int F,
+                           int nu0, int nnu, double *alm_dev, size_t ring_bytes) {
+    corahip_draw_pending *pd = nullptr;
+    int rc = corahip_draw_alm_numpy_begin(ctx, T, rows, info, rng, lmax, F, nu0, nnu, alm_dev, ring_bytes, &pd);
+    if (rc) return rc;
+    return corahip_draw_alm_numpy_end(ctx, pd, rng);
+}
+
+}  // extern "C"

@@ -3,15 +3,15 @@
 // Replaces the body of skysim.mkfullsky (cora/core/skysim.py:72-136) for a single process: per-l jitter + root
 // (:115-119), the complex normals of nputil.complex_std_normal (:120; cora/util/nputil.py:104-125), a_lm = T_l g_l
 // (:121) and hputil.sphtrans_inv_sky (:130; cora/util/hputil.py:500-531) - by chaining the library's own entry points
-// (corahip_factor_batched, corahip_normals_pcg64 / corahip_draw_alm*, corahip_alm2map / corahip_alm_dev_to_square) on
-// buffers cut from one caller-owned workspace.  Nothing here that a caller could not do with those five calls.
+// (corahip_factor_batched, corahip_draw_alm* / corahip_draw_alm_numpy, corahip_alm2map / corahip_alm_dev_to_square) on
+// buffers cut from one caller-owned workspace.  Nothing here that a caller could not do with those calls.
 #include "sht_internal.h"
 
 #include <algorithm>
 
 namespace {
 struct mk_layout {
-    size_t off_T, off_info, off_alm, off_g, off_sht, total_min, total_full;
+    size_t off_T, off_info, off_alm, off_sht, total_min, total_full;
 };
 inline size_t up256(size_t v) { return (v + 255) & ~(size_t)255; }
 
@@ -21,8 +21,10 @@ int layout_of(const corahip_sht_plan *p, int F, int nnu, int rng_kind, int alms,
     lo.off_T = 0;
     lo.off_info = up256(sizeof(double) * L * F * F);
     lo.off_alm = lo.off_info + up256(sizeof(int32_t) * L);
-    lo.off_g = lo.off_alm + up256(sizeof(double) * nalm * G * 8);
-    lo.off_sht = lo.off_g + ((rng_kind == CORAHIP_RNG_PCG64 || rng_kind == CORAHIP_RNG_MT19937) ? up256(sizeof(double) * 2 * (size_t)F * nalm) : 0);
+    // (the PCG64 / MT19937 kinds keep no normal buffer here: corahip_draw_alm_numpy generates the stream range by range
+    //  into the library's own ring)
+    (void)rng_kind;
+    lo.off_sht = lo.off_alm + up256(sizeof(double) * nalm * G * 8);
     size_t full = 0;
     if (!alms) {
         int rc = corahip_alm2map_workspace_bytes(p, nnu, &full);
@@ -74,28 +76,26 @@ int corahip_mkfullsky(corahip_ctx *ctx, const corahip_sht_plan *plan, const doub
     // skysim.py:115-119: C_l + I max(diag) 1e-14 -> Cholesky, eigen root where that fails (nputil.py:51-101, threshold 1e-16)
     if ((rc = corahip_factor_batched(ctx, C, L, F, 1e-14, 1e-16, T, info))) return rc;
     // skysim.py:120-121
+    corahip_draw_pending *pending = nullptr;
     if (rng->kind == CORAHIP_RNG_PHILOX) {
         rc = corahip_draw_alm_philox(ctx, T, info, rng->seed, lmax, F, nu0, nnu, alm);
     } else if (rng->kind == CORAHIP_RNG_STREAM) {
         rc = corahip_draw_alm(ctx, T, info, rng->stream, lmax, F, nu0, nnu, alm);
-    } else if (rng->kind == CORAHIP_RNG_MT19937) {
-        double *g = (double *)(ws + lo.off_g);
-        if ((rc = corahip_normals_mt19937_legacy(ctx, rng->legacy, (int64_t)2 * F * plan->nalm, g))) return rc;
-        rc = corahip_draw_alm(ctx, T, info, g, lmax, F, nu0, nnu, alm);
     } else {
-        double *g = (double *)(ws + lo.off_g);
-        uint64_t n_raw = 0;
-        if ((rc = corahip_normals_pcg64(ctx, rng->state, rng->inc, (int64_t)2 * F * plan->nalm, g, &n_raw))) return rc;
-        uint64_t after[2];
-        if ((rc = corahip_pcg64_advance(rng->state, rng->inc, n_raw, after))) return rc;
-        rng->state[0] = after[0];                  // the generator as numpy would leave it
-        rng->state[1] = after[1];
-        rc = corahip_draw_alm(ctx, T, info, g, lmax, F, nu0, nnu, alm);
+        // numpy's own stream (PCG64 + ziggurat, or the legacy MT19937 + polar method), continued on the device range by
+        // range: enqueued here, the generator state read back (rng->state / rng->legacy left where numpy would leave
+        // them) once the synthesis has been enqueued behind it
+        rc = corahip_draw_alm_numpy_begin(ctx, T, 0, info, rng, lmax, F, nu0, nnu, alm, 0, &pending);
     }
     if (rc) return rc;
     // skysim.py:123-130
-    if (alms) return corahip_alm_dev_to_square(ctx, alm, lmax, nnu, out);
-    return corahip_alm2map(ctx, plan, alm, nnu, out, ws + lo.off_sht, workspace_bytes - lo.off_sht);
+    if (alms) rc = corahip_alm_dev_to_square(ctx, alm, lmax, nnu, out);
+    else rc = corahip_alm2map(ctx, plan, alm, nnu, out, ws + lo.off_sht, workspace_bytes - lo.off_sht);
+    if (pending) {
+        const int rc2 = corahip_draw_alm_numpy_end(ctx, pending, rng);
+        if (!rc) rc = rc2;
+    }
+    return rc;
 }
 
 }  // extern "C"

@@ -35,6 +35,7 @@
 #include <vector>
 
 #include "mt_jump.inc"
+#include "stream_internal.h"
 
 namespace {
 
@@ -262,30 +263,38 @@ __device__ inline mt_attempt mt_try(const unsigned *mt, int a) {
 }
 
 #define MT_WG 256
-// pass 1 / pass 2 over the segments, one wave each.  EMIT = false: seg_cnt[j] = accepted attempts of segment j.
-// EMIT = true: the normals of the accepted attempts at g[2 (base + rank)], g[.. + 1] while below `need`, and the state
-// after the attempt that yields normal number `need`.
-template <bool EMIT>
+// The count pass runs one wave per SEGMENT (a segment start costs a jump application), the emit pass one wave per
+// SUB-SEGMENT of MT_SUB_BLOCKS blocks: the count pass leaves a snapshot of the generator (624 words) and the number of
+// accepted attempts for every sub-segment, so the emit pass can start anywhere with ~3400 accepted attempts of
+// granularity - which is what lets it run on a RANGE of the stream (one slot of the l-range ring, drawstream.hip) with
+// a thousand waves in flight instead of the forty segments a range spans - and runs at full occupancy on the whole
+// stream as well.
+constexpr int MT_SUB_BLOCKS = 28;
+constexpr int MT_SEG_BLOCKS = (int)((MT_SEG_ATT + MT_ATT_BLOCK - 1) / MT_ATT_BLOCK);   // 1681, the last one partial (64 attempts)
+constexpr int MT_NSUB = MT_SEG_BLOCKS / MT_SUB_BLOCKS;                                 // 60; the last sub-segment takes the remainder
+
+// pass 1, one wave per segment: sub_state[(j NSUB + k)] = the block the generator is in at block k SUB_BLOCKS of segment
+// j, sub_cnt[..] = accepted attempts of that sub-segment
 __global__ void __launch_bounds__(MT_WG)
-mt_segment_kernel(const unsigned *__restrict__ seg_state, long nseg, unsigned *__restrict__ seg_cnt,
-                  const unsigned long long *__restrict__ seg_base, unsigned long long need, double *__restrict__ g,
-                  mt_status *st) {
+mt_count_kernel(const unsigned *__restrict__ seg_state, long nseg, unsigned *__restrict__ sub_state, unsigned *__restrict__ sub_cnt) {
 #pragma clang fp contract(off)
     __shared__ __attribute__((aligned(16))) unsigned blk[MT_WG / 64][MTN + 8];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const long j = (long)blockIdx.x * (MT_WG / 64) + wv;
     if (j >= nseg) return;
     unsigned *mt = blk[wv];
-    const bool al16 = (reinterpret_cast<size_t>(g) & 15) == 0;
-    const unsigned long long pairs = (need + 1) / 2;          // accepted attempts that are needed
-    unsigned long long ord = EMIT ? seg_base[j] : 0ull;       // accepted attempts before the next one
-    if (EMIT && ord >= pairs) return;
     for (int i = lane; i < MTN; i += 64) mt[i] = seg_state[j * MTN + i];
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     __builtin_amdgcn_wave_barrier();
-    unsigned cnt = 0;
-    for (long a0 = 0; a0 < MT_SEG_ATT; a0 += MT_ATT_BLOCK) {
-        const int nb = (int)std::min<long>(MT_ATT_BLOCK, MT_SEG_ATT - a0);      // attempts of this block that belong to the segment
+    unsigned cnt = 0, cnt0 = 0;
+    for (int bi = 0; bi < MT_SEG_BLOCKS; bi++) {
+        if (bi % MT_SUB_BLOCKS == 0 && bi / MT_SUB_BLOCKS < MT_NSUB) {
+            const long sidx = j * MT_NSUB + bi / MT_SUB_BLOCKS;
+            for (int i = lane; i < MTN; i += 64) sub_state[sidx * MTN + i] = mt[i];
+            if (bi > 0 && lane == 0) sub_cnt[sidx - 1] = cnt - cnt0;
+            cnt0 = cnt;
+        }
+        const int nb = (int)std::min<long>(MT_ATT_BLOCK, MT_SEG_ATT - (long)bi * MT_ATT_BLOCK);   // attempts of this block that belong to the segment
 #pragma unroll
         for (int r = 0; r < (MT_ATT_BLOCK + 63) / 64; r++) {
             const int a = 64 * r + lane;
@@ -293,27 +302,71 @@ mt_segment_kernel(const unsigned *__restrict__ seg_state, long nseg, unsigned *_
             mt_attempt t;
             t.ok = false;
             if (in) t = mt_try(mt, a);
-            const unsigned long long acc = __ballot(in && t.ok);
-            if constexpr (EMIT) {
+            cnt += (unsigned)__builtin_popcountll(__ballot(in && t.ok));
+        }
+        mt_block_next(mt, lane);
+    }
+    if (lane == 0) sub_cnt[j * MT_NSUB + MT_NSUB - 1] = cnt - cnt0;
+}
+
+// pass 2, one wave per sub-segment (grid-stride from *sub_first, NULL = 0): the normals of accepted attempt o are
+// elements e = off0 + 2 o and e + 1 of the stream (off0 = 1 when numpy's cached second value came first); an element is
+// written to g[e - w_lo] iff w_lo <= e < w_hi and e < n.  The wave that meets the last needed attempt (number
+// `pairs`) leaves the state numpy would be left in.
+__global__ void __launch_bounds__(MT_WG)
+mt_emit_kernel(const unsigned *__restrict__ sub_state, long nsub, const unsigned long long *__restrict__ sub_base,
+               const long *__restrict__ sub_first, unsigned long long w_lo, unsigned long long w_hi, unsigned off0,
+               unsigned long long n, double *__restrict__ g, mt_status *st) {
+#pragma clang fp contract(off)
+    __shared__ __attribute__((aligned(16))) unsigned blk[MT_WG / 64][MTN + 8];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    unsigned *mt = blk[wv];
+    const unsigned long long need = n - off0;
+    const unsigned long long pairs = (need + 1) / 2;          // accepted attempts that are needed
+    // accepted attempts o with an element below w_hi: off0 + 2 o < w_hi
+    const unsigned long long p_end = std::min<unsigned long long>(pairs, w_hi > off0 ? (w_hi - off0 + 1) / 2 : 0ull);
+    const unsigned long long w_n = w_hi - w_lo;
+    const bool al16 = ((reinterpret_cast<size_t>(g) >> 3) + (size_t)off0 - (size_t)(w_lo & 1ull)) % 2 == 0;   // element off0 + 2 o at a 16-byte boundary
+    const long s0 = sub_first ? *sub_first : 0L;
+    for (long s = s0 + (long)blockIdx.x * (MT_WG / 64) + wv; s < nsub; s += (long)gridDim.x * (MT_WG / 64)) {
+        unsigned long long ord = sub_base[s];                  // accepted attempts before the next one
+        if (ord >= p_end) break;
+        for (int i = lane; i < MTN; i += 64) mt[i] = sub_state[s * MTN + i];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        const int k = (int)(s % MT_NSUB);
+        const int b0 = k * MT_SUB_BLOCKS, b1 = k == MT_NSUB - 1 ? MT_SEG_BLOCKS : b0 + MT_SUB_BLOCKS;
+        for (int bi = b0; bi < b1; bi++) {
+            const int nb = (int)std::min<long>(MT_ATT_BLOCK, MT_SEG_ATT - (long)bi * MT_ATT_BLOCK);
+#pragma unroll
+            for (int r = 0; r < (MT_ATT_BLOCK + 63) / 64; r++) {
+                const int a = 64 * r + lane;
+                const bool in = a < nb;
+                mt_attempt t;
+                t.ok = false;
+                if (in) t = mt_try(mt, a);
+                const unsigned long long acc = __ballot(in && t.ok);
                 if (in && t.ok) {
                     const unsigned long long o = ord + __builtin_amdgcn_mbcnt_hi((unsigned)(acc >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)acc, 0u));
                     if (o < pairs) {
-                        const double f = sqrt(-2.0 * glibc_log_fma(t.r2) / t.r2);     // (sqrt and the division are correctly rounded on both sides)
-                        const double first = f * t.x2, second = f * t.x1;
-                        if (2 * o + 1 < need) {
-                            if (al16) *reinterpret_cast<double2 *>(g + 2 * o) = make_double2(first, second);
-                            else {                 // (a pair behind an odd offset - the cached value came first - is not 16-byte aligned)
-                                g[2 * o] = first;
-                                g[2 * o + 1] = second;
+                        const unsigned long long e = (unsigned long long)off0 + 2 * o;
+                        const bool in0 = e - w_lo < w_n, in1 = e + 1 - w_lo < w_n && 2 * o + 1 < need;
+                        if (in0 || in1 || o + 1 == pairs) {
+                            const double f = sqrt(-2.0 * glibc_log_fma(t.r2) / t.r2);     // (sqrt and the division are correctly rounded on both sides)
+                            const double first = f * t.x2, second = f * t.x1;
+                            if (in0 && in1 && al16) *reinterpret_cast<double2 *>(g + (e - w_lo)) = make_double2(first, second);
+                            else {             // (a pair behind an odd offset, or one cut by the window's edge)
+                                if (in0) g[e - w_lo] = first;
+                                if (in1) g[e + 1 - w_lo] = second;
                             }
-                        } else g[2 * o] = first;
-                        if (o + 1 == pairs) {
-                            // the generator after this attempt: inside this block, behind the attempt's four words; the
-                            // second value stays cached when an odd number of normals was asked for
-                            st->pos = 4 * (a + 1);
-                            st->has_gauss = (need & 1ull) ? 1 : 0;
-                            st->gauss = (need & 1ull) ? second : 0.0;
-                            st->done = 1;
+                            if (o + 1 == pairs) {
+                                // the generator after this attempt: inside this block, behind the attempt's four words; the
+                                // second value stays cached when an odd number of normals was asked for
+                                st->pos = 4 * (a + 1);
+                                st->has_gauss = (need & 1ull) ? 1 : 0;
+                                st->gauss = (need & 1ull) ? second : 0.0;
+                                st->done = 1;
+                            }
                         }
                     }
                 }
@@ -323,17 +376,33 @@ mt_segment_kernel(const unsigned *__restrict__ seg_state, long nseg, unsigned *_
                     for (int i = lane; i < MTN; i += 64) st->key[i] = mt[i];
                 }
                 ord += nacc;
-            } else {
-                cnt += (unsigned)__builtin_popcountll(acc);
             }
+            if (ord >= p_end) break;
+            mt_block_next(mt, lane);
         }
-        if (EMIT && ord >= pairs) return;
-        mt_block_next(mt, lane);
     }
-    if (!EMIT && lane == 0) seg_cnt[j] = cnt;
 }
 
-// one workgroup: first accepted-attempt ordinal of every segment
+// the cached second value of numpy's last pair is the first element of the stream
+__global__ void mt_put_kernel(double *g, double v) { g[0] = v; }
+
+// first sub-segment of every range [bounds[r], bounds[r + 1]) of stream elements: the one that holds accepted attempt
+// (bounds[r] - off0) / 2 (the largest s with sub_base[s] <= that)
+__global__ void mt_range_kernel(const unsigned long long *__restrict__ sub_base, long nsub, const unsigned long long *__restrict__ bounds,
+                                int nr, unsigned off0, long *__restrict__ sub_first) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nr) return;
+    const unsigned long long o = bounds[r] > off0 ? (bounds[r] - off0) / 2 : 0ull;
+    long lo = 0, hi = nsub - 1;
+    while (lo < hi) {
+        const long mid = (lo + hi + 1) >> 1;
+        if (sub_base[mid] <= o) lo = mid;
+        else hi = mid - 1;
+    }
+    sub_first[r] = lo;
+}
+
+// one workgroup: first accepted-attempt ordinal of every sub-segment
 __global__ void __launch_bounds__(1024)
 mt_scan_kernel(long nseg, const unsigned *__restrict__ seg_cnt, unsigned long long *__restrict__ seg_base, mt_status *st) {
     __shared__ unsigned long long part[1024];
@@ -363,81 +432,134 @@ mt_scan_kernel(long nseg, const unsigned *__restrict__ seg_cnt, unsigned long lo
 
 }  // namespace
 
-extern "C" {
+// ---- host side (stream_internal.h): prepare = jump tree + count + scan; emit = one window of the stream -------------------
+struct mt_session {
+    std::vector<unsigned> x;                     // the window at the generator's position (kept until finish: asynchronous upload)
+    std::vector<unsigned long long> bounds;      // [nr + 1] stream elements
+    long nseg = 0, nsub = 0;
+    unsigned off0 = 0;
+    double gauss0 = 0.0;
+    unsigned long long n = 0, pairs = 0;
+    unsigned *seg_state = nullptr, *sub_state = nullptr, *sub_cnt = nullptr;
+    unsigned long long *sub_base = nullptr, *d_bounds = nullptr;
+    long *d_first = nullptr;
+    mt_status *st = nullptr;
+    int nr = 0;
+};
 
-int corahip_normals_mt19937_legacy(corahip_ctx *ctx, corahip_mt_state *state, int64_t n, double *g) {
-    ARG_CHECK(ctx != nullptr && state != nullptr && n >= 0 && (n == 0 || g != nullptr));
-    ARG_CHECK(state->pos >= 0 && state->pos <= MTN);
-    if (n == 0) return 0;
-    StageTimer timer(ctx, "normals_legacy");
-    int64_t off0 = 0;
-    if (state->has_gauss) {                    // the value legacy_gauss kept from its last pair comes first
-        HIP_TRY(hipMemcpyAsync(g, &state->gauss, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-        HIP_TRY(hipStreamSynchronize(ctx->stream));
-        state->has_gauss = 0;
-        state->gauss = 0.0;
-        off0 = 1;
-        if (n == 1) return 0;
-    }
-    const unsigned long long need = (unsigned long long)(n - off0);
+int mt_stream_prepare(corahip_ctx *ctx, hipStream_t stream, corahip_mt_state *state, int64_t n,
+                      const std::vector<unsigned long long> &bounds, mt_session **out) {
+    ARG_CHECK(state != nullptr && n > 0 && state->pos >= 0 && state->pos <= MTN);
+    ARG_CHECK(bounds.size() >= 2 && bounds.front() == 0 && bounds.back() == (unsigned long long)n);
+    const bool other = stream != ctx->stream;
+    mt_session *s = new mt_session();
+    s->n = (unsigned long long)n;
+    s->bounds = bounds;
+    s->nr = (int)bounds.size() - 1;
+    s->off0 = state->has_gauss ? 1u : 0u;          // the value legacy_gauss kept from its last pair comes first
+    s->gauss0 = state->gauss;
+    const unsigned long long need = s->n - s->off0;
     // attempts to look at: need / 2 accepted ones at an acceptance of pi / 4, + 2 % and a floor (the count of accepted
     // attempts among N has a relative sigma of 0.5 / sqrt(N))
-    const unsigned long long pairs = (need + 1) / 2;
-    const long double want = (long double)pairs / 0.78539816339744830962L;
+    s->pairs = (need + 1) / 2;
+    const long double want = (long double)s->pairs / 0.78539816339744830962L;
     const long natt = (long)(want * 1.02L) + 8192;
-    const long nseg = (natt + MT_SEG_ATT - 1) / MT_SEG_ATT;
+    s->nseg = std::max<long>(1, (natt + MT_SEG_ATT - 1) / MT_SEG_ATT);
+    s->nsub = s->nseg * MT_NSUB;
     int levels = 0;
-    while ((1L << levels) < nseg) levels++;
+    while ((1L << levels) < s->nseg) levels++;
     if (levels > MT_NPOLY) {
-        corahip_set_error("normals_mt19937_legacy: %lld normals need %ld segments, the jump table holds %d levels", (long long)n, nseg,
+        corahip_set_error("normals_mt19937_legacy: %lld normals need %ld segments, the jump table holds %d levels", (long long)n, s->nseg,
                           MT_NPOLY);
+        delete s;
         return CORAHIP_EINVAL;
     }
     // the window at the generator's position: x[pos .. pos + 623] (host: at most 624 steps)
-    std::vector<unsigned> x(state->key, state->key + MTN);
-    x.resize(MTN + state->pos);
-    for (int k = 0; k < state->pos; k++) x[MTN + k] = mt_next(x[k], x[k + 1], x[k + MTM]);
-    const size_t off_cnt = sizeof(unsigned) * MTN * (size_t)nseg;
-    const size_t off_base = (off_cnt + sizeof(unsigned) * (size_t)nseg + 15) & ~(size_t)15;
-    const size_t off_st = off_base + sizeof(unsigned long long) * (size_t)nseg;
+    s->x.assign(state->key, state->key + MTN);
+    s->x.resize(MTN + state->pos);
+    for (int k = 0; k < state->pos; k++) s->x[MTN + k] = mt_next(s->x[k], s->x[k + 1], s->x[k + MTM]);
+    const size_t nb = bounds.size();
+    const size_t off_sub = sizeof(unsigned) * MTN * (size_t)s->nseg;
+    const size_t off_cnt = off_sub + sizeof(unsigned) * MTN * (size_t)s->nsub;
+    const size_t off_base = (off_cnt + sizeof(unsigned) * (size_t)s->nsub + 15) & ~(size_t)15;
+    const size_t off_bnd = off_base + sizeof(unsigned long long) * (size_t)s->nsub;
+    const size_t off_first = off_bnd + sizeof(unsigned long long) * nb;
+    const size_t off_st = (off_first + sizeof(long) * nb + 15) & ~(size_t)15;
     char *ws = nullptr;
     int rc = corahip_ctx_scratch(ctx, 6, off_st + sizeof(mt_status), (void **)&ws);
-    if (rc) return rc;
-    unsigned *seg_state = (unsigned *)ws;
-    unsigned *seg_cnt = (unsigned *)(ws + off_cnt);
-    unsigned long long *seg_base = (unsigned long long *)(ws + off_base);
-    mt_status *st = (mt_status *)(ws + off_st);
-    HIP_TRY(hipMemsetAsync(st, 0, sizeof(mt_status), ctx->stream));
-    HIP_TRY(hipMemcpyAsync(seg_state, x.data() + state->pos, sizeof(unsigned) * MTN, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));           // (x is a local)
+    if (rc) {
+        delete s;
+        return rc;
+    }
+    s->seg_state = (unsigned *)ws;
+    s->sub_state = (unsigned *)(ws + off_sub);
+    s->sub_cnt = (unsigned *)(ws + off_cnt);
+    s->sub_base = (unsigned long long *)(ws + off_base);
+    s->d_bounds = (unsigned long long *)(ws + off_bnd);
+    s->d_first = (long *)(ws + off_first);
+    s->st = (mt_status *)(ws + off_st);
+    auto fail = [&](hipError_t e, const char *what) {
+        corahip_set_error("normals_mt19937_legacy: %s failed: %s", what, hipGetErrorString(e));
+        delete s;
+        return (int)e;
+    };
+    hipError_t e;
+    if ((e = hipMemsetAsync(s->st, 0, sizeof(mt_status), stream)) != hipSuccess) return fail(e, "memset");
+    if ((e = hipMemcpyAsync(s->seg_state, s->x.data() + state->pos, sizeof(unsigned) * MTN, hipMemcpyHostToDevice, stream)) != hipSuccess)
+        return fail(e, "upload of the generator window");
+    if ((e = hipMemcpyAsync(s->d_bounds, s->bounds.data(), sizeof(unsigned long long) * nb, hipMemcpyHostToDevice, stream)) != hipSuccess)
+        return fail(e, "upload of the range bounds");
     {
-        StageTimer t0(ctx, "mt_jump");
+        StageTimer t0(ctx, "mt_jump", stream, other);
         const size_t shm = sizeof(unsigned) * MT_JUMP_XS + sizeof(unsigned short) * (MT_DEG + 8);
-        HIP_TRY(hipFuncSetAttribute((const void *)mt_jump_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-        for (int k = 0; (1L << k) < nseg; k++) {
-            const long have = 1L << k, count = std::min<long>(have, nseg - have);
-            mt_jump_kernel<<<(unsigned)count, MT_JUMP_T, shm, ctx->stream>>>(seg_state, 0, have, count, k);
-            LAUNCH_CHECK();
+        if ((e = hipFuncSetAttribute((const void *)mt_jump_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm)) != hipSuccess)
+            return fail(e, "hipFuncSetAttribute");
+        for (int k = 0; (1L << k) < s->nseg; k++) {
+            const long have = 1L << k, count = std::min<long>(have, s->nseg - have);
+            mt_jump_kernel<<<(unsigned)count, MT_JUMP_T, shm, stream>>>(s->seg_state, 0, have, count, k);
         }
     }
-    const unsigned grid = (unsigned)((nseg + MT_WG / 64 - 1) / (MT_WG / 64));
     {
-        StageTimer t1(ctx, "mt_count");
-        mt_segment_kernel<false><<<grid, MT_WG, 0, ctx->stream>>>(seg_state, nseg, seg_cnt, seg_base, need, g + off0, st);
-        LAUNCH_CHECK();
-        mt_scan_kernel<<<1, 1024, 0, ctx->stream>>>(nseg, seg_cnt, seg_base, st);
+        StageTimer t1(ctx, "mt_count", stream, other);
+        const unsigned grid = (unsigned)((s->nseg + MT_WG / 64 - 1) / (MT_WG / 64));
+        mt_count_kernel<<<grid, MT_WG, 0, stream>>>(s->seg_state, s->nseg, s->sub_state, s->sub_cnt);
+        mt_scan_kernel<<<1, 1024, 0, stream>>>(s->nsub, s->sub_cnt, s->sub_base, s->st);
+        mt_range_kernel<<<(s->nr + 63) / 64, 64, 0, stream>>>(s->sub_base, s->nsub, s->d_bounds, s->nr, s->off0, s->d_first);
+    }
+    if ((e = hipGetLastError()) != hipSuccess) return fail(e, "a launch of the count pass");
+    // numpy hands the cached value back and clears it; the state is rewritten by finish
+    *out = s;
+    return 0;
+}
+
+int mt_stream_emit_range(corahip_ctx *ctx, hipStream_t stream, mt_session *s, int r, double *slot) {
+    ARG_CHECK(s != nullptr && r >= 0 && r < s->nr && slot != nullptr);
+    const unsigned long long w_lo = s->bounds[r], w_hi = s->bounds[r + 1];
+    StageTimer t2(ctx, "mt_emit", stream, stream != ctx->stream);
+    if (w_lo == 0 && s->off0) {
+        mt_put_kernel<<<1, 1, 0, stream>>>(slot, s->gauss0);
         LAUNCH_CHECK();
     }
-    {
-        StageTimer t2(ctx, "mt_emit");
-        mt_segment_kernel<true><<<grid, MT_WG, 0, ctx->stream>>>(seg_state, nseg, seg_cnt, seg_base, need, g + off0, st);
-        LAUNCH_CHECK();
-    }
+    // one wave per sub-segment of ~3400 accepted attempts (MT_SUB_BLOCKS x 156 attempts x pi / 4); the loop strides
+    const long est = (long)((w_hi - w_lo) / 2 / 3300) + 8;
+    const unsigned grid = (unsigned)std::max<long>(1, std::min<long>((est + MT_WG / 64 - 1) / (MT_WG / 64), (long)ctx->num_cu * 64));
+    mt_emit_kernel<<<grid, MT_WG, 0, stream>>>(s->sub_state, s->nsub, s->sub_base, s->d_first + r, w_lo, w_hi, s->off0, s->n, slot, s->st);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int mt_stream_finish(corahip_ctx *ctx, hipStream_t stream, mt_session *s, corahip_mt_state *state) {
+    ARG_CHECK(s != nullptr && state != nullptr);
     mt_status hs;
-    HIP_TRY(hipMemcpyAsync(&hs, st, sizeof(hs), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
-    if (!hs.done || hs.total_accepted < pairs) {
-        corahip_set_error("normals_mt19937_legacy: %llu accepted attempts in %ld segments, %llu needed", hs.total_accepted, nseg, pairs);
+    HIP_TRY(hipMemcpyAsync(&hs, s->st, sizeof(hs), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    if (s->pairs == 0) {                           // n = 1 with a cached value: no attempt was needed, the key stays
+        state->has_gauss = 0;
+        state->gauss = 0.0;
+        return 0;
+    }
+    if (!hs.done || hs.total_accepted < s->pairs) {
+        corahip_set_error("normals_mt19937_legacy: %llu accepted attempts in %ld segments, %llu needed", hs.total_accepted, s->nseg, s->pairs);
         return CORAHIP_ESTATE;
     }
     std::copy(hs.key, hs.key + MTN, state->key);
@@ -445,6 +567,24 @@ int corahip_normals_mt19937_legacy(corahip_ctx *ctx, corahip_mt_state *state, in
     state->has_gauss = hs.has_gauss;
     state->gauss = hs.gauss;
     return 0;
+}
+
+void mt_stream_free(mt_session *s) { delete s; }
+
+extern "C" {
+
+int corahip_normals_mt19937_legacy(corahip_ctx *ctx, corahip_mt_state *state, int64_t n, double *g) {
+    ARG_CHECK(ctx != nullptr && state != nullptr && n >= 0 && (n == 0 || g != nullptr));
+    ARG_CHECK(state->pos >= 0 && state->pos <= MTN);
+    if (n == 0) return 0;
+    StageTimer timer(ctx, "normals_legacy");
+    mt_session *s = nullptr;
+    int rc = mt_stream_prepare(ctx, ctx->stream, state, n, std::vector<unsigned long long>{0ull, (unsigned long long)n}, &s);
+    if (rc) return rc;
+    rc = mt_stream_emit_range(ctx, ctx->stream, s, 0, g);
+    if (!rc) rc = mt_stream_finish(ctx, ctx->stream, s, state);
+    mt_stream_free(s);
+    return rc;
 }
 
 }  // extern "C"

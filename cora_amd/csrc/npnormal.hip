@@ -38,6 +38,8 @@
 #include <algorithm>
 #include <cstdlib>
 
+#include "stream_internal.h"
+
 #define ZIG_TAB_Q __device__ static const
 #include "zig_tab.inc"
 
@@ -791,12 +793,15 @@ zig_entry_kernel(long nblk, long ntile, const unsigned *__restrict__ fun, const 
     }
 }
 
-// pass 2: every block with its true entry; the normals go to g[ordinal] for ordinal < n.  Lane p of row j holds position
-// 64 j + p: the samples of a row leave as one store instruction to consecutive addresses.
+// pass 2: every block with its true entry; the normals with ordinals in [o_lo, o_hi) go to g[ordinal - o_lo] (the whole
+// stream: o_lo = 0, o_hi = n; one range of the l-range pipeline: its ordinals, g = the ring slot).  blk_first: device
+// word holding the first block to look at - the one that contains ordinal o_lo (zig_range_kernel) -, NULL = block 0.
+// Lane p of row j holds position 64 j + p: the samples of a row leave as one store instruction to consecutive addresses.
 __global__ void __launch_bounds__(ZIG_WG)
 zig_emit_kernel(const ulonglong2 *__restrict__ blk_state, uint64_t i_hi, uint64_t i_lo, long nblk,
                 const ulonglong2 *__restrict__ entry, const ulonglong2 *__restrict__ classes,
                 const unsigned long long *__restrict__ tails, unsigned long long pos0, unsigned long long n,
+                unsigned long long o_lo, unsigned long long o_hi, const long *__restrict__ blk_first,
                 double *__restrict__ g, zig_status *st) {
     __shared__ zig_lds L;
     zig_lds_fill(L);
@@ -807,10 +812,12 @@ zig_emit_kernel(const ulonglong2 *__restrict__ blk_state, uint64_t i_hi, uint64_
     const jump_t lj = ZIG_LANE.v[lane];
     const u128 lane_m = mk128(lj.mhi, lj.mlo), lane_c = inc * mk128(lj.ghi, lj.glo);
     const long wave0 = (long)blockIdx.x * (ZIG_WG / 64) + (threadIdx.x >> 6), nwave = (long)gridDim.x * (ZIG_WG / 64);
-    for (long b = wave0; b < nblk; b += nwave) {
+    const long b_first = blk_first ? *blk_first : 0L;
+    const unsigned long long o_n = o_hi - o_lo;            // ordinal o is written iff o - o_lo < o_n (unsigned: o < o_lo wraps)
+    for (long b = b_first + wave0; b < nblk; b += nwave) {
         const ulonglong2 en = entry[b];
         const unsigned long long ord_blk = uni64(en.y);
-        if (ord_blk >= n) break;                            // (blocks are in ordinal order: nothing left to write)
+        if (ord_blk >= o_hi) break;                         // (blocks are in ordinal order: nothing left to write)
         const ulonglong2 bs = blk_state[b];
         const u128 s_blk = mk128(uni64(bs.x), uni64(bs.y));
         // classes of the 16 rows, row j in lane j
@@ -849,26 +856,26 @@ zig_emit_kernel(const ulonglong2 *__restrict__ blk_state, uint64_t i_hi, uint64_
                             zig_tail_from(bcast128(s, pz), inc, v, consumed, &st->error);
                             const unsigned long long o = ord_blk + readlane32(base_col, j) +
                                                          __builtin_popcountll(all & ((1ull << pz) - 1ull));
-                            if (lane == 0 && o < n) {
-                                g[o] = v;
+                            if (lane == 0 && o - o_lo < o_n) {
+                                g[o - o_lo] = v;
                                 if (o + 1 == n) st->n_raw = blk_pos + 64u * j + pz + 1 + consumed;
                             }
                         }
                         if ((e >> lane) & 1) {
                             const unsigned long long o = ord_blk + readlane32(base_col, j) + mbcnt64(all);
-                            if (o < n) {
-                                g[o] = zig_value(raw, L.wi);
+                            if (o - o_lo < o_n) {
+                                g[o - o_lo] = zig_value(raw, L.wi);
                                 if (o + 1 == n) st->n_raw = blk_pos + 64u * j + lane + 1 + ((readlane64(ew_col, j) >> lane) & 1);
                             }
                         }
                     } else if ((e >> lane) & 1) {
                         const unsigned long long o = ord_blk + readlane32(base_col, j) + mbcnt64(e);
 #if ZIG_ABLATE == 4
-                        if (o < n && raw == 12345) {
+                        if (o - o_lo < o_n && raw == 12345) {
 #else
-                        if (o < n) {
+                        if (o - o_lo < o_n) {
 #endif
-                            g[o] = zig_value(raw, L.wi);
+                            g[o - o_lo] = zig_value(raw, L.wi);
                             if (o + 1 == n) st->n_raw = blk_pos + 64u * j + lane + 1 + ((readlane64(ew_col, j) >> lane) & 1);
                         }
                     }
@@ -889,8 +896,8 @@ zig_emit_kernel(const ulonglong2 *__restrict__ blk_state, uint64_t i_hi, uint64_
                 const uint64_t e = r.e_fast | r.e_wedge;
                 if ((e >> lane) & 1) {
                     const unsigned long long o = ord + mbcnt64(e);
-                    if (o < n) {
-                        g[o] = zig_value(raw, L.wi);
+                    if (o - o_lo < o_n) {
+                        g[o - o_lo] = zig_value(raw, L.wi);
                         if (o + 1 == n) st->n_raw = blk_pos + 64u * j + lane + 1 + ((r.e_wedge >> lane) & 1);
                     }
                 }
@@ -899,8 +906,8 @@ zig_emit_kernel(const ulonglong2 *__restrict__ blk_state, uint64_t i_hi, uint64_
                 double v;
                 unsigned consumed;
                 zig_tail_walk(s_blk, inc, 64u * j + r.tl_bit, v, consumed, &st->error);
-                if (lane == 0 && ord < n) {
-                    g[ord] = v;
+                if (lane == 0 && ord - o_lo < o_n) {
+                    g[ord - o_lo] = v;
                     if (ord + 1 == n) st->n_raw = blk_pos + 64u * j + r.tl_bit + 1 + consumed;
                 }
                 ord += 1;
@@ -908,6 +915,22 @@ zig_emit_kernel(const ulonglong2 *__restrict__ blk_state, uint64_t i_hi, uint64_
             }
         }
     }
+}
+
+// first block of every range of the l-range pipeline: blk_first[r] = the block that contains ordinal bounds[r] (the
+// largest b with entry[b].ordinal <= bounds[r]; entry ordinals increase with b)
+__global__ void zig_range_kernel(const ulonglong2 *__restrict__ entry, long nblk, const unsigned long long *__restrict__ bounds,
+                                 int nr, long *__restrict__ blk_first) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nr) return;
+    const unsigned long long o = bounds[r];
+    long lo = 0, hi = nblk - 1;                              // invariant: entry[lo].y <= o (or lo = 0), answer in [lo, hi]
+    while (lo < hi) {
+        const long mid = (lo + hi + 1) >> 1;
+        if (entry[mid].y <= o) lo = mid;
+        else hi = mid - 1;
+    }
+    blk_first[r] = lo;
 }
 
 __global__ void zig_debug_kernel(const ulonglong2 *blk_state, uint64_t i_hi, uint64_t i_lo, long b, uint64_t *out) {
@@ -928,6 +951,187 @@ __global__ void zig_debug_kernel(const ulonglong2 *blk_state, uint64_t i_hi, uin
 
 }  // namespace
 
+// ---- host side: one round = the tables of nblk blocks from raw position pos0 on ------------------------------------------
+struct zig_round {
+    long nblk = 0, ntile = 0;
+    unsigned patch_cap = 0, grid = 0;
+    ulonglong2 *blk_state = nullptr, *entry = nullptr, *patch = nullptr, *classes = nullptr, *tile_entry = nullptr;
+    unsigned *fun = nullptr;
+    unsigned long long *tails = nullptr;
+    uint4 *tile_fun = nullptr;
+    zig_status *st = nullptr;
+    char *extra = nullptr;          // `extra_bytes` more, 16-byte aligned, behind the status word (range tables of the l-range pipeline)
+};
+// the block tables of a round that has to yield `want` normals, cut from scratch slot 6
+static int zig_round_tables(corahip_ctx *ctx, unsigned long long want, size_t extra_bytes, zig_round &rd) {
+    // 1.02145 raw draws per normal on average; the margin covers 200 sigma, and a short round is followed by another
+    rd.nblk = (long)((want + want / 44 + 2 * ZIG_BLK) / ZIG_BLK) + 1;
+    rd.patch_cap = (unsigned)(rd.nblk / 64 + 1024);
+    rd.ntile = (rd.nblk + ZIG_TILE - 1) / ZIG_TILE;
+    const size_t nblk = (size_t)rd.nblk, ntile = (size_t)rd.ntile;
+    const size_t off_fun = sizeof(ulonglong2) * nblk;
+    const size_t off_entry = off_fun + sizeof(unsigned) * 2 * nblk;
+    const size_t off_patch = off_entry + sizeof(ulonglong2) * nblk;
+    const size_t off_cls = off_patch + sizeof(ulonglong2) * rd.patch_cap;
+    const size_t off_tt = off_cls + sizeof(ulonglong2) * ZIG_ROWS * nblk;
+    const size_t off_tf = off_tt + sizeof(unsigned long long) * nblk;
+    const size_t off_te = off_tf + sizeof(uint4) * ntile;
+    const size_t off_st = off_te + sizeof(ulonglong2) * ntile;
+    const size_t off_ex = (off_st + sizeof(zig_status) + 15) & ~(size_t)15;
+    char *ws = nullptr;
+    int rc = corahip_ctx_scratch(ctx, 6, off_ex + extra_bytes, (void **)&ws);
+    if (rc) return rc;
+    rd.blk_state = (ulonglong2 *)ws;
+    rd.fun = (unsigned *)(ws + off_fun);
+    rd.entry = (ulonglong2 *)(ws + off_entry);
+    rd.patch = (ulonglong2 *)(ws + off_patch);
+    rd.classes = (ulonglong2 *)(ws + off_cls);
+    rd.tails = (unsigned long long *)(ws + off_tt);
+    rd.tile_fun = (uint4 *)(ws + off_tf);
+    rd.tile_entry = (ulonglong2 *)(ws + off_te);
+    rd.st = (zig_status *)(ws + off_st);
+    rd.extra = ws + off_ex;
+    rd.grid = (unsigned)std::min<long>((rd.nblk + ZIG_WG / 64 - 1) / (ZIG_WG / 64), (long)ctx->num_cu * 32);
+    return 0;
+}
+// seek + pass 1 + the scan over the block functions, on `stream`: afterwards every block has its (k, first ordinal)
+static int zig_round_count_scan(corahip_ctx *ctx, hipStream_t stream, const uint64_t state[2], const uint64_t inc[2],
+                                unsigned long long pos0, unsigned long long ord0, const zig_round &rd) {
+    const bool other = stream != ctx->stream;
+    HIP_TRY(hipMemsetAsync(rd.st, 0, sizeof(zig_status), stream));
+    {
+        StageTimer t0(ctx, "zig_seek", stream, other);
+        zig_seek_kernel<<<(unsigned)((rd.nblk + 255) / 256), 256, 0, stream>>>(state[0], state[1], inc[0], inc[1], pos0, rd.nblk,
+                                                                              rd.blk_state);
+        LAUNCH_CHECK();
+    }
+    {
+        StageTimer t1(ctx, "zig_count", stream, other);
+        zig_count_kernel<<<rd.grid, ZIG_WG, 0, stream>>>(rd.blk_state, inc[0], inc[1], rd.nblk, rd.fun, rd.classes, rd.tails, rd.patch,
+                                                        rd.patch_cap, rd.st);
+        LAUNCH_CHECK();
+    }
+    {
+        StageTimer t2(ctx, "zig_scan", stream, other);
+        const unsigned tgrid = (unsigned)((rd.ntile + 3) / 4);
+        zig_tile_kernel<<<tgrid, 256, 0, stream>>>(rd.nblk, rd.ntile, rd.fun, rd.patch, rd.patch_cap, rd.tile_fun, rd.st);
+        LAUNCH_CHECK();
+        zig_top_kernel<<<1, ZIG_TOP_T, 0, stream>>>(rd.nblk, rd.ntile, rd.fun, rd.patch, rd.patch_cap, rd.tile_fun, ord0, rd.tile_entry,
+                                                   rd.st);
+        LAUNCH_CHECK();
+        zig_entry_kernel<<<tgrid, 256, 0, stream>>>(rd.nblk, rd.ntile, rd.fun, rd.patch, rd.patch_cap, rd.tile_entry, rd.entry, rd.st);
+        LAUNCH_CHECK();
+    }
+    return 0;
+}
+static void zig_debug_dump(corahip_ctx *ctx, const zig_round &rd, const uint64_t inc[2], const zig_status &hs) {
+    const long nb = std::min<long>(rd.nblk, 8);
+    std::vector<unsigned> hf(2 * nb);
+    std::vector<ulonglong2> he(nb), hb(nb);
+    uint4 tf;
+    ulonglong2 te;
+    (void)hipMemcpy(hf.data(), rd.fun, sizeof(unsigned) * 2 * nb, hipMemcpyDeviceToHost);
+    (void)hipMemcpy(he.data(), rd.entry, sizeof(ulonglong2) * nb, hipMemcpyDeviceToHost);
+    (void)hipMemcpy(hb.data(), rd.blk_state, sizeof(ulonglong2) * nb, hipMemcpyDeviceToHost);
+    (void)hipMemcpy(&tf, rd.tile_fun, sizeof(tf), hipMemcpyDeviceToHost);
+    (void)hipMemcpy(&te, rd.tile_entry, sizeof(te), hipMemcpyDeviceToHost);
+    fprintf(stderr, "zig debug: nblk %ld ntile %ld total %llu k_last %u npatch %u err %u n_raw %llu | tile0 fun (%u %u %u %u) entry (%llu %llu)\n",
+            rd.nblk, rd.ntile, hs.total, hs.k_last, hs.npatch, hs.error, hs.n_raw, tf.x, tf.y, tf.z, tf.w, te.x, te.y);
+    {
+        uint64_t *dbg = nullptr, h[192];
+        (void)hipMalloc(&dbg, sizeof(h));
+        zig_debug_kernel<<<1, 64, 0, ctx->stream>>>(rd.blk_state, inc[0], inc[1], 1, dbg);
+        (void)hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost);
+        (void)hipFree(dbg);
+        fprintf(stderr, "  blk 1 raws: hoisted %016llx %016llx %016llx | table %016llx %016llx %016llx | row 1 %016llx %016llx\n",
+                (unsigned long long)h[0], (unsigned long long)h[1], (unsigned long long)h[63], (unsigned long long)h[64],
+                (unsigned long long)h[65], (unsigned long long)h[127], (unsigned long long)h[128], (unsigned long long)h[129]);
+    }
+    for (long i = 0; i < nb; i++)
+        fprintf(stderr, "  blk %ld: state %016llx%016llx fun0 (k %u cnt %u) fun1 (k %u cnt %u) entry (k %llu ord %llu)\n", i,
+                hb[i].x, hb[i].y, hf[2 * i] >> 16, hf[2 * i] & 0xffff, hf[2 * i + 1] >> 16, hf[2 * i + 1] & 0xffff,
+                he[i].x, he[i].y);
+}
+
+// ---- the stream in ranges (stream_internal.h): one round, its tables kept for the emit launches of the ranges -----------
+struct zig_session {
+    zig_round rd;
+    uint64_t state[2], inc[2];
+    unsigned long long n = 0;
+    std::vector<unsigned long long> bounds;      // [nr + 1] ordinals; kept until finish (the upload is asynchronous)
+    unsigned long long *d_bounds = nullptr;
+    long *d_first = nullptr;
+    int nr = 0;
+};
+
+int zig_stream_prepare(corahip_ctx *ctx, hipStream_t stream, const uint64_t state[2], const uint64_t inc[2], int64_t n,
+                       const std::vector<unsigned long long> &bounds, zig_session **out) {
+    ARG_CHECK(n > 0 && bounds.size() >= 2 && bounds.front() == 0 && bounds.back() == (unsigned long long)n);
+    zig_session *s = new zig_session();
+    s->n = (unsigned long long)n;
+    s->bounds = bounds;
+    s->nr = (int)bounds.size() - 1;
+    for (int i = 0; i < 2; i++) {
+        s->state[i] = state[i];
+        s->inc[i] = inc[i];
+    }
+    const size_t nb = bounds.size();
+    int rc = zig_round_tables(ctx, s->n, (sizeof(unsigned long long) + sizeof(long)) * nb, s->rd);
+    if (!rc) {
+        s->d_bounds = (unsigned long long *)s->rd.extra;
+        s->d_first = (long *)(s->rd.extra + sizeof(unsigned long long) * nb);
+        rc = zig_round_count_scan(ctx, stream, state, inc, 0ull, 0ull, s->rd);
+    }
+    if (!rc) {
+        hipError_t e = hipMemcpyAsync(s->d_bounds, s->bounds.data(), sizeof(unsigned long long) * nb, hipMemcpyHostToDevice, stream);
+        if (e != hipSuccess) rc = (int)e;
+    }
+    if (rc) {
+        delete s;
+        return rc;
+    }
+    zig_range_kernel<<<(s->nr + 63) / 64, 64, 0, stream>>>(s->rd.entry, s->rd.nblk, s->d_bounds, s->nr, s->d_first);
+    if (hipGetLastError() != hipSuccess) {
+        delete s;
+        corahip_set_error("zig_range_kernel launch failed");
+        return CORAHIP_ESTATE;
+    }
+    *out = s;
+    return 0;
+}
+
+int zig_stream_emit_range(corahip_ctx *ctx, hipStream_t stream, zig_session *s, int r, double *slot) {
+    ARG_CHECK(s != nullptr && r >= 0 && r < s->nr && slot != nullptr);
+    const unsigned long long o_lo = s->bounds[r], o_hi = s->bounds[r + 1];
+    // one wave per block of ~1000 normals; the grid covers the range's blocks (+ slack: the loop strides, nothing is missed)
+    const long est = (long)((o_hi - o_lo) / 960) + 8;
+    const unsigned grid = (unsigned)std::max<long>(1, std::min<long>((est + ZIG_WG / 64 - 1) / (ZIG_WG / 64), (long)ctx->num_cu * 32));
+    StageTimer t3(ctx, "zig_emit", stream, stream != ctx->stream);
+    zig_emit_kernel<<<grid, ZIG_WG, 0, stream>>>(s->rd.blk_state, s->inc[0], s->inc[1], s->rd.nblk, s->rd.entry, s->rd.classes,
+                                                s->rd.tails, 0ull, s->n, o_lo, o_hi, s->d_first + r, slot, s->rd.st);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int zig_stream_finish(corahip_ctx *ctx, hipStream_t stream, zig_session *s, uint64_t *n_raw) {
+    ARG_CHECK(s != nullptr && n_raw != nullptr);
+    zig_status hs;
+    HIP_TRY(hipMemcpyAsync(&hs, s->rd.st, sizeof(hs), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    if (hs.error) {
+        corahip_set_error("normals_pcg64 (ranges): device status %u (1 tail loop cap, 2 patch list full, 4 patch missing)", hs.error);
+        return CORAHIP_ESTATE;
+    }
+    if (hs.total < s->n) {      // (the margin of the block count is 200 sigma: never met)
+        corahip_set_error("normals_pcg64 (ranges): the raw range held %llu normals, %llu needed", hs.total, s->n);
+        return CORAHIP_ESTATE;
+    }
+    *n_raw = hs.n_raw;
+    return 0;
+}
+
+void zig_stream_free(zig_session *s) { delete s; }
+
 extern "C" {
 
 int corahip_pcg64_advance(const uint64_t state[2], const uint64_t inc[2], uint64_t delta, uint64_t out_state[2]) {
@@ -947,92 +1151,21 @@ int corahip_normals_pcg64(corahip_ctx *ctx, const uint64_t state[2], const uint6
     StageTimer timer(ctx, "normals_pcg64");
     unsigned long long pos0 = 0, ord0 = 0;
     for (int round = 0; round < 64; round++) {
-        const unsigned long long want = (unsigned long long)n - ord0;
-        // 1.02145 raw draws per normal on average; the margin covers 200 sigma, and a short round is followed by another
-        const long nblk = (long)((want + want / 44 + 2 * ZIG_BLK) / ZIG_BLK) + 1;
-        const unsigned patch_cap = (unsigned)(nblk / 64 + 1024);
-        const long ntile = (nblk + ZIG_TILE - 1) / ZIG_TILE;
-        const size_t off_fun = sizeof(ulonglong2) * (size_t)nblk;
-        const size_t off_entry = off_fun + sizeof(unsigned) * 2 * (size_t)nblk;
-        const size_t off_patch = off_entry + sizeof(ulonglong2) * (size_t)nblk;
-        const size_t off_cls = off_patch + sizeof(ulonglong2) * patch_cap;
-        const size_t off_tt = off_cls + sizeof(ulonglong2) * ZIG_ROWS * (size_t)nblk;
-        const size_t off_tf = off_tt + sizeof(unsigned long long) * (size_t)nblk;
-        const size_t off_te = off_tf + sizeof(uint4) * (size_t)ntile;
-        const size_t off_st = off_te + sizeof(ulonglong2) * (size_t)ntile;
-        char *ws = nullptr;
-        int rc = corahip_ctx_scratch(ctx, 6, off_st + sizeof(zig_status), (void **)&ws);
+        zig_round rd;
+        int rc = zig_round_tables(ctx, (unsigned long long)n - ord0, 0, rd);
         if (rc) return rc;
-        ulonglong2 *blk_state = (ulonglong2 *)ws;
-        unsigned *fun = (unsigned *)(ws + off_fun);
-        ulonglong2 *entry = (ulonglong2 *)(ws + off_entry);
-        ulonglong2 *patch = (ulonglong2 *)(ws + off_patch);
-        ulonglong2 *classes = (ulonglong2 *)(ws + off_cls);
-        unsigned long long *tails = (unsigned long long *)(ws + off_tt);
-        uint4 *tile_fun = (uint4 *)(ws + off_tf);
-        ulonglong2 *tile_entry = (ulonglong2 *)(ws + off_te);
-        zig_status *st = (zig_status *)(ws + off_st);
-        HIP_TRY(hipMemsetAsync(st, 0, sizeof(zig_status), ctx->stream));
-        {
-            StageTimer t0(ctx, "zig_seek");
-            zig_seek_kernel<<<(unsigned)((nblk + 255) / 256), 256, 0, ctx->stream>>>(state[0], state[1], inc[0], inc[1], pos0,
-                                                                                    nblk, blk_state);
-            LAUNCH_CHECK();
-        }
-        const unsigned grid = (unsigned)std::min<long>((nblk + ZIG_WG / 64 - 1) / (ZIG_WG / 64), (long)ctx->num_cu * 32);
-        {
-            StageTimer t1(ctx, "zig_count");
-            zig_count_kernel<<<grid, ZIG_WG, 0, ctx->stream>>>(blk_state, inc[0], inc[1], nblk, fun, classes, tails, patch,
-                                                              patch_cap, st);
-            LAUNCH_CHECK();
-        }
-        {
-            StageTimer t2(ctx, "zig_scan");
-            const unsigned tgrid = (unsigned)((ntile + 3) / 4);
-            zig_tile_kernel<<<tgrid, 256, 0, ctx->stream>>>(nblk, ntile, fun, patch, patch_cap, tile_fun, st);
-            LAUNCH_CHECK();
-            zig_top_kernel<<<1, ZIG_TOP_T, 0, ctx->stream>>>(nblk, ntile, fun, patch, patch_cap, tile_fun, ord0, tile_entry, st);
-            LAUNCH_CHECK();
-            zig_entry_kernel<<<tgrid, 256, 0, ctx->stream>>>(nblk, ntile, fun, patch, patch_cap, tile_entry, entry, st);
-            LAUNCH_CHECK();
-        }
+        if ((rc = zig_round_count_scan(ctx, ctx->stream, state, inc, pos0, ord0, rd))) return rc;
         {
             StageTimer t3(ctx, "zig_emit");
-            zig_emit_kernel<<<grid, ZIG_WG, 0, ctx->stream>>>(blk_state, inc[0], inc[1], nblk, entry, classes, tails, pos0,
-                                                             (unsigned long long)n, g, st);
+            zig_emit_kernel<<<rd.grid, ZIG_WG, 0, ctx->stream>>>(rd.blk_state, inc[0], inc[1], rd.nblk, rd.entry, rd.classes, rd.tails,
+                                                                pos0, (unsigned long long)n, 0ull, (unsigned long long)n, nullptr,
+                                                                g, rd.st);
             LAUNCH_CHECK();
         }
         zig_status hs;
-        HIP_TRY(hipMemcpyAsync(&hs, st, sizeof(hs), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(&hs, rd.st, sizeof(hs), hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(hipStreamSynchronize(ctx->stream));
-        if (getenv("CORAHIP_ZIG_DEBUG")) {
-            const long nb = std::min<long>(nblk, 8);
-            std::vector<unsigned> hf(2 * nb);
-            std::vector<ulonglong2> he(nb), hb(nb);
-            uint4 tf;
-            ulonglong2 te;
-            (void)hipMemcpy(hf.data(), fun, sizeof(unsigned) * 2 * nb, hipMemcpyDeviceToHost);
-            (void)hipMemcpy(he.data(), entry, sizeof(ulonglong2) * nb, hipMemcpyDeviceToHost);
-            (void)hipMemcpy(hb.data(), blk_state, sizeof(ulonglong2) * nb, hipMemcpyDeviceToHost);
-            (void)hipMemcpy(&tf, tile_fun, sizeof(tf), hipMemcpyDeviceToHost);
-            (void)hipMemcpy(&te, tile_entry, sizeof(te), hipMemcpyDeviceToHost);
-            fprintf(stderr, "zig debug: nblk %ld ntile %ld total %llu k_last %u npatch %u err %u n_raw %llu | tile0 fun (%u %u %u %u) entry (%llu %llu)\n",
-                    nblk, ntile, hs.total, hs.k_last, hs.npatch, hs.error, hs.n_raw, tf.x, tf.y, tf.z, tf.w, te.x, te.y);
-            {
-                uint64_t *dbg = nullptr, h[192];
-                (void)hipMalloc(&dbg, sizeof(h));
-                zig_debug_kernel<<<1, 64, 0, ctx->stream>>>(blk_state, inc[0], inc[1], 1, dbg);
-                (void)hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost);
-                (void)hipFree(dbg);
-                fprintf(stderr, "  blk 1 raws: hoisted %016llx %016llx %016llx | table %016llx %016llx %016llx | row 1 %016llx %016llx\n",
-                        (unsigned long long)h[0], (unsigned long long)h[1], (unsigned long long)h[63], (unsigned long long)h[64],
-                        (unsigned long long)h[65], (unsigned long long)h[127], (unsigned long long)h[128], (unsigned long long)h[129]);
-            }
-            for (long i = 0; i < nb; i++)
-                fprintf(stderr, "  blk %ld: state %016llx%016llx fun0 (k %u cnt %u) fun1 (k %u cnt %u) entry (k %llu ord %llu)\n", i,
-                        hb[i].x, hb[i].y, hf[2 * i] >> 16, hf[2 * i] & 0xffff, hf[2 * i + 1] >> 16, hf[2 * i + 1] & 0xffff,
-                        he[i].x, he[i].y);
-        }
+        if (getenv("CORAHIP_ZIG_DEBUG")) zig_debug_dump(ctx, rd, inc, hs);
         if (hs.error) {
             corahip_set_error("normals_pcg64: device status %u (1 tail loop cap, 2 patch list full, 4 patch missing)", hs.error);
             return CORAHIP_ESTATE;
@@ -1041,7 +1174,7 @@ int corahip_normals_pcg64(corahip_ctx *ctx, const uint64_t state[2], const uint6
             *n_raw = hs.n_raw;
             return 0;
         }
-        pos0 += (unsigned long long)nblk * ZIG_BLK + hs.k_last;
+        pos0 += (unsigned long long)rd.nblk * ZIG_BLK + hs.k_last;
         ord0 = hs.total;
     }
     corahip_set_error("normals_pcg64: no convergence");

@@ -159,14 +159,29 @@ def exchange_factor_rows(T_local, info_local, plan):
     return _rows_unpack(recv, counts), i_all[: plan.L]
 
 
+def numpy_ring_bytes(F, lmax, device_bytes=288e9):
+    """Bytes of the normal-stream ring ``corahip_draw_alm_numpy`` allocates by default (csrc/drawstream.hip): the whole
+    stream of a realisation (16 F nalm bytes) as ONE range while that is at most 1/8 of the device memory (ranges cost
+    time: every range is an emit launch, an event hop and a K3 launch), else two slots in 1/16 of it - a slot never
+    smaller than the normals of l = lmax."""
+    L = lmax + 1
+    stream = 8 * F * L * (L + 1)
+    if stream <= device_bytes / 8:
+        return int(stream)
+    ring = max(device_bytes / 16, 2.0**30)
+    slot = max(ring / 2, 16.0 * F * L)
+    return int(min(stream, 2 * slot))
+
+
 def rank_memory_bytes(kinds, F, nside, lmax, world, sum_mode="joint", rng="philox"):
     """Device bytes ONE rank of a ``world``-rank job holds at the peak of a cold step: the buffers of
     :class:`SkyShard` / :class:`SkySum` counted from their shapes (no GPU needed; ``tests/test_host.py`` sums them for
     BASELINE configs[3] and [4] at 8 ranks against the 288 GB of an MI355X, ``tests/test_gpu_parity.py`` compares the
     single-rank figure with what torch actually allocates).
 
-    kinds : per component "table21cm" | "separable";  rng : "philox" (no normal buffer) | "numpy" (the whole stream of
-    a realisation in HBM, 16 F nalm bytes on EVERY rank, plus the generator's block tables)."""
+    kinds : per component "table21cm" | "separable";  rng : "philox" (no normal buffer) | "numpy" (numpy's own stream,
+    PCG64 + ziggurat or the legacy MT19937 + polar method, generated range of multipoles by range on EVERY rank: the
+    ring of :func:`numpy_ring_bytes` plus the generator's count / scan tables, ~0.38 bytes per normal)."""
     L = lmax + 1
     nalm = L * (L + 1) // 2
     npix = 12 * nside * nside
@@ -197,7 +212,7 @@ def rank_memory_bytes(kinds, F, nside, lmax, world, sum_mode="joint", rng="philo
         out["factor rows [L, nnu, F] (+ exchange slabs)"] = ndraw * 8 * L * nnu * F
     if rng == "numpy":
         nn = 2 * F * nalm
-        out["numpy normal stream + generator block tables"] = 8 * nn + int(0.33 * nn * 1.03)
+        out["numpy normal stream: ring of l ranges + generator tables"] = numpy_ring_bytes(F, lmax) + int(0.38 * nn)
     out["total"] = sum(out.values())
     return out
 
@@ -406,22 +421,23 @@ class SkyShard:
     def realise_numpy(self, rng, factors=None):
         """As :meth:`realise` with the REFERENCE's normal stream: ``rng`` is what cora's callers pass to
         ``mkfullsky`` - a ``numpy.random.Generator`` (on PCG64 it is continued on the device, bit for bit, and left where
-        cora would leave it) or ``None`` (numpy's legacy global state, consumed on the host) - see
-        ``skysim.stream_normals``.  Every rank consumes the whole stream (identically seeded generators)."""
-        import torch
+        cora would leave it) or ``None`` (numpy's legacy global MT19937 state, continued on the device as well) - see
+        ``skysim.draw_numpy_stream``.  Every rank consumes the whole stream (identically seeded generators) range of
+        multipoles by range - no 16 F nalm byte buffer - against its own rows of the factors."""
+        _, finish = self.draw_numpy(rng, factors, defer=True)
+        try:     # (the synthesis is enqueued behind the draw before the generator's state is waited for)
+            return self.ctx.alm2map(self.alm_buf, self.nside, self.lmax, self.nnu, out=self.maps_buf)
+        finally:
+            finish()
 
+    def draw_numpy(self, rng, factors=None, out=None, defer=False):
+        """a_lm of this rank's channels from the reference's normal stream (see :meth:`realise_numpy`); ``defer``:
+        ``(alm, finish)`` as ``skysim.draw_numpy_stream``."""
         from .core import skysim
 
-        ctx = self.ctx
         T, info, rows = factors if factors is not None else self.factors()
-        g = skysim.stream_normals(ctx, self.F, self.lmax, rng)
-        if rows:   # the stream-order kernel takes full factors: embed the row block
-            Tf = torch.zeros((self.lmax + 1, self.F, self.F), dtype=torch.float64, device=ctx.device)
-            Tf[:, self.nu0:self.nu0 + self.nnu, :] = T
-            T = Tf
-        ctx.draw_alm(T, info, g, self.lmax, self.F, nu0=self.nu0, nnu=self.nnu, out=self.alm_buf)
-        del g
-        return ctx.alm2map(self.alm_buf, self.nside, self.lmax, self.nnu, out=self.maps_buf)
+        return skysim.draw_numpy_stream(self.ctx, T, info, rng, self.lmax, self.F, nu0=self.nu0, nnu=self.nnu,
+                                        out=self.alm_buf if out is None else out, rows=rows, defer=defer)
 
 
 class SkySum:
@@ -516,6 +532,31 @@ class SkySum:
         self.draw(seed, factors)
         return self.ctx.alm2map(self.alm_buf, self.nside, self.lmax, self.nnu, out=self.maps_buf)
 
+    def realise_numpy(self, rng, factors=None):
+        """As :meth:`realise` with the REFERENCE's normal stream (:meth:`SkyShard.realise_numpy`).  ``separate``: the
+        components draw one after the other from the SAME generator, in component order - the numbers of the
+        reference's one ``getsky()`` per component called in that order with that generator (or, ``rng=None``, with
+        numpy's global state) - and the a_lm are added before the one synthesis.  ``joint``: one draw of the summed
+        covariance from the generator (the same distribution, not those numbers)."""
+        factors = factors if factors is not None else self.factors()
+        finish = lambda: None   # noqa: E731
+        if self.mode == "joint":
+            _, finish = self.shards[0].draw_numpy(rng, factors[0], out=self.alm_buf, defer=True)
+        else:
+            for k, (sh, fac) in enumerate(zip(self.shards, factors)):
+                last = k == len(self.shards) - 1       # (a component's generator state feeds the next one's draw: only the last waits late)
+                if k == 0:
+                    r = sh.draw_numpy(rng, fac, out=self.alm_buf, defer=last)
+                else:
+                    r = sh.draw_numpy(rng, fac, out=self._tmp, defer=last)
+                    self.alm_buf.add_(self._tmp)
+                if last:
+                    finish = r[1]
+        try:
+            return self.ctx.alm2map(self.alm_buf, self.nside, self.lmax, self.nnu, out=self.maps_buf)
+        finally:
+            finish()
+
 
 def getsky_shard(sky, seed, rank=0, world=1, lmax=None):
     """``Sky3d.getsky()`` for one rank of ``world`` GPUs: (maps [nnu, npix] device tensor, nu0) for a cora_amd
@@ -601,12 +642,7 @@ def mkfullsky_sharded(corr_local, global_shape, nside, rng=None, alms=False, ctx
         alm = (ctx.draw_alm_philox_rows(T, info, seed, lmax, F, nu0, nnu) if rows
                else ctx.draw_alm_philox(T, info, seed, lmax, F, nu0=nu0, nnu=nnu))
     else:
-        g = skysim.stream_normals(ctx, F, lmax, rng)
-        if rows:   # the host-stream kernel takes full factors: embed the row block
-            Tf = torch.zeros((L, F, F), dtype=torch.float64, device=ctx.device)
-            Tf[:, nu0:nu0 + nnu, :] = T
-            T = Tf
-        alm = ctx.draw_alm(T, info, g, lmax, F, nu0=nu0, nnu=nnu)
+        alm = skysim.draw_numpy_stream(ctx, T, info, rng, lmax, F, nu0=nu0, nnu=nnu, rows=rows)
     if alms:
         return ctx.alm_dev_to_square(alm, lmax, nnu), nu0
     return ctx.alm2map(alm, int(nside), lmax, nnu), nu0

@@ -162,9 +162,7 @@ def _21cm(fstate, nside, pol, filename, eor, oversample, seed):
     """Generate a Gaussian simulation of the unresolved 21cm background."""
     from ..signal import corr21cm
 
-    if eor:
-        raise click.ClickException("EoR21cm is not part of cora_amd")
-    cr = corr21cm.Corr21cm()
+    cr = corr21cm.EoR21cm() if eor else corr21cm.Corr21cm()
     cr.nside = nside
     cr.frequencies = fstate.frequencies
     cr.oversample = oversample if oversample is not None else 3

@@ -105,3 +105,27 @@ class Corr21cm(corr.RedshiftCorrelation, maps.Sky3d):
         z1, z2 = self._band_redshifts()
         return self.realisation(z1, z2, self.x_width, self.y_width, self.nu_num, self.x_num, self.y_num,
                                 refinement=refinement, zspace=False, seed=seed)
+
+
+class EoR21cm(Corr21cm):
+    """The 21cm model with parameters for the epoch of reionisation (corr21cm.py:333-385) - what ``cora-makesky 21cm
+    --eor`` instantiates (cora/scripts/makesky.py:316-334).  Only the per-redshift quantities change (T_b, Omega_HI,
+    x_h, bias 3), so the table model, the device tables and K1 are those of :class:`Corr21cm`."""
+
+    def T_b(self, z):
+        r"""Mean 21cm brightness temperature in K, Eq. (4) of Santos, Ferramacho & Silva 2009 (corr21cm.py:334-360)."""
+        c = self.cosmology
+        h = c.H0 / 100.0
+        return (23e-3 * (c.omega_b * h**2 / 0.02) * (0.15 / (c.omega_m * h**2) * ((1.0 + z) / 10)) ** 0.5
+                * (h / 0.7) ** -1)
+
+    def omega_HI(self, z):
+        return 5e-3
+
+    def x_h(self, z):
+        """Neutral hydrogen fraction: a constant (corr21cm.py:365-380)."""
+        return 0.25
+
+    def bias_z(self, z):
+        """Bias 3, after the EoR estimates of Santos 2004 (corr21cm.py:382-385)."""
+        return np.ones_like(z) * 3.0

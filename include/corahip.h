@@ -32,7 +32,7 @@ extern "C" {
 #endif
 
 #define CORAHIP_ABI_VERSION 1
-#define CORAHIP_ABI_MINOR 2      /* additions since version 1: 1 = normals_pcg64, pcg64_advance, draw_alm_rows, mkfullsky, mkfullsky_workspace_bytes, abi_minor, normals_mt19937_legacy; 2 = sht_lambda_entry (test hook) */
+#define CORAHIP_ABI_MINOR 3      /* additions since version 1: 1 = normals_pcg64, pcg64_advance, draw_alm_rows, mkfullsky, mkfullsky_workspace_bytes, abi_minor, normals_mt19937_legacy; 2 = sht_lambda_entry (test hook); 3 = draw_alm_numpy, draw_alm_numpy_begin / _end */
 
 #define CORAHIP_EINVAL (-1)   /* bad argument / shape */
 #define CORAHIP_ENOMEM (-2)   /* workspace too small / allocation refused */
@@ -227,7 +227,8 @@ int corahip_draw_alm_philox_rows(corahip_ctx *ctx, const double *T_rows, const i
  *           CORAHIP_RNG_PHILOX  the library's counter-based stream under `seed` (not numpy's numbers).
  *   alms  0: out = maps [nnu, npix] RING (skysim.py:130-136);  1: out = a_lm [nnu, 1, L, L] complex128, m > l zero (:123-125)
  *   workspace  >= corahip_mkfullsky_workspace_bytes(...) for one synthesis pass; a smaller one (down to the factors,
- *              the a_lm, the normals of the PCG64 kind and one 8-channel synthesis chunk) is worked through in chunks;
+ *              the a_lm and one 8-channel synthesis chunk) is worked through in chunks; the PCG64 / MT19937 kinds draw
+ *              through corahip_draw_alm_numpy (below): their normals live in the library's own ring, range by range;
  *              CORAHIP_ENOMEM with the sizes in corahip_last_error() below that.                                      */
 #define CORAHIP_RNG_STREAM 0
 #define CORAHIP_RNG_PHILOX 1
@@ -244,6 +245,28 @@ int corahip_mkfullsky_workspace_bytes(const corahip_sht_plan *plan, int F, int n
                                       size_t *bytes);
 int corahip_mkfullsky(corahip_ctx *ctx, const corahip_sht_plan *plan, const double *C, int F, corahip_rng *host_rng,
                       int nu0, int nnu, int alms, double *out, void *workspace, size_t workspace_bytes);
+
+/* draw_alm with numpy's OWN normal stream generated on the device RANGE BY RANGE, as the reference consumes it inside its
+ * l loop (cora/core/skysim.py:114-121, cora/util/nputil.py:121-125): normals_pcg64 / normals_mt19937_legacy followed by
+ * draw_alm (rows = 0: T [lmax+1, F, F]) or draw_alm_rows (rows = 1: T_rows [lmax+1, nnu, F]), bit for bit, WITHOUT the
+ * 16 F nalm-byte stream buffer (8.6 GB at F = 256, lmax = 2048; 137 GB at F = 1024, lmax = 4096): the generator's
+ * count + scan passes cover the whole stream, its emit pass fills one slot of a two-slot ring (library-owned, ring_bytes
+ * in total, 0 = the default: the whole stream as one range while it is <= 1/8 of the device memory,
+ * else a ring of 1/16 of it, or CORAHIP_RING_MB; a slot is never smaller than the normals of l = lmax) per range
+ * of multipoles on a second stream while K3 consumes the other slot.
+ *   host_rng  (the struct of corahip_mkfullsky above) kind CORAHIP_RNG_PCG64 (state, inc as in corahip_normals_pcg64) or CORAHIP_RNG_MT19937 (legacy state);
+ *             UPDATED to the state numpy would be left in.  Synchronises the context's stream (that read-back).
+ * _begin / _end: the same in two halves.  _begin enqueues everything and returns without waiting; the caller goes on
+ * enqueueing (the synthesis of the a_lm) and calls _end when it wants the generator state: _end waits for the context's
+ * stream, updates host_rng and frees `pending`.  Between the two, no other numpy-stream draw may be started on the
+ * context and host_rng->legacy (MT19937 kind) must stay valid. */
+typedef struct corahip_draw_pending corahip_draw_pending;
+int corahip_draw_alm_numpy(corahip_ctx *ctx, const double *T, int rows, const int32_t *info, corahip_rng *host_rng,
+                           int lmax, int F, int nu0, int nnu, double *alm_dev, size_t ring_bytes);
+int corahip_draw_alm_numpy_begin(corahip_ctx *ctx, const double *T, int rows, const int32_t *info, const corahip_rng *host_rng,
+                                 int lmax, int F, int nu0, int nnu, double *alm_dev, size_t ring_bytes,
+                                 corahip_draw_pending **pending);
+int corahip_draw_alm_numpy_end(corahip_ctx *ctx, corahip_draw_pending *pending, corahip_rng *host_rng);
 
 /* ---- frequency sharding for callers that pass the messages themselves -----------------------------
  * The reference distributes this path with caput.mpiarray over MPI (cora/core/skysim.py:97-110: C_l and the a_lm

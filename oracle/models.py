@@ -267,6 +267,25 @@ class Corr21cm:
         return self.aps_z(l, NU21 / nu1 - 1.0, NU21 / nu2 - 1.0)
 
 
+class EoR21cm(Corr21cm):
+    """corr21cm.py:333-385: the 21cm model with reionisation-epoch parameters (T_b of Santos et al. 2009, bias 3).
+    ``share`` = a Corr21cm whose lookup tables are reused (they depend on P(k) only)."""
+
+    bias = 3.0
+
+    def __init__(self, cosmology=None, share=None, **kw):
+        Corr21cm.__init__(self, cosmology=cosmology, **kw)
+        if share is not None:
+            self._tables = share.tables()
+
+    def T_b(self, z):
+        """corr21cm.py:334-360."""
+        c = self.cosmology
+        return (23e-3 * (c.omega_b * (c.H0 / 100.0) ** 2 / 0.02)
+                * (0.15 / (c.omega_m * (c.H0 / 100.0) ** 2) * ((1.0 + z) / 10)) ** 0.5
+                * ((c.H0 / 100.0) / 0.7) ** -1)
+
+
 # ---------------------------------------------------------------- foregrounds
 class ForegroundSCK:
     """gaussianfg.py:87-130.  C_l = A (l/l0)^-beta (nu1 nu2/nu0^2)^-alpha exp(-(ln(nu1/nu2)/zeta)^2/2), C_0=0."""

@@ -26,6 +26,7 @@ def _bench(args):
     lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, p.stdout          # stdout carries exactly one line: the JSON
     m = re.search(r"CHECKSUM (\w+)", p.stderr)
+    _bench.seeded = tuple(re.findall(r"CHECKSUM_(?:SEEDED|LEGACY) (\w+)", p.stderr))
     return json.loads(lines[0]), (m.group(1) if m else None)
 
 
@@ -36,11 +37,16 @@ def test_bench_launches_its_own_ranks(workload):
     2-rank realisation equal the single-rank ones (tiny3: three summed components, parallel.SkySum)."""
     common = ["--workload", workload, "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--checksum"]
     one, c1 = _bench(common)
+    s1 = _bench.seeded
     two, c2 = _bench(["--gpus", "2", "--dist-backend", "gloo", "--same-device"] + common)
+    s2 = _bench.seeded
     assert one["n_gpus"] == 1 and one["ranks_seen"] == 1
     assert two["n_gpus"] == 2 and two["ranks_seen"] == 2
     assert c1 is not None and c1 == c2, (c1, c2)
     assert two["value"] > 0 and two["metric"] == one["metric"]
+    # the reference's seeded call (rng = default_rng(seed)) and its rng=None call through the sharded path - every rank
+    # generates numpy's stream range by range for its own factor rows: every pixel of every channel bit for bit
+    assert len(s1) == 2 and s1 == s2, (s1, s2)
 
 
 def test_mkfullsky_l_distributed_mpiarray():

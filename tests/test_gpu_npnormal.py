@@ -241,3 +241,96 @@ def test_mkfullsky_without_a_generator_draws_on_the_device(ctx, golden, monkeypa
     monkeypatch.undo()
     assert _ulps(g, skysim._host_normals(6, 20, twin)).max() <= _LEGACY_ULP
     assert np.array_equal(rs.random_sample(50), twin.random_sample(50))
+
+
+# ------------------------------------------------------------------ the stream in l ranges (corahip_draw_alm_numpy)
+def _factors(ctx, F, lmax, seed):
+    import torch
+
+    rs = np.random.default_rng(seed)
+    L = lmax + 1
+    T = np.tril(rs.standard_normal((L, F, F))) + 3.0 * np.eye(F)
+    T[min(3, lmax)] = rs.standard_normal((F, F))              # a dense root (eigen branch)
+    info = np.zeros(L, dtype=np.int32)
+    info[min(3, lmax)] = 1
+    return ctx.to_device(T), torch.from_numpy(info).to(ctx.device)
+
+
+@pytest.mark.parametrize("F,lmax,nu0,nnu,ring_kb", [(8, 40, 0, 8, 1), (24, 70, 0, 24, 64), (72, 150, 0, 72, 700),
+                                                    (136, 260, 0, 136, 3000), (256, 300, 64, 64, 5000),
+                                                    (256, 300, 192, 64, 1 << 20), (40, 90, 8, 16, 100), (7, 33, 2, 5, 10)])
+def test_pcg64_stream_in_l_ranges_equals_the_full_buffer(ctx, F, lmax, nu0, nnu, ring_kb):
+    """corahip_draw_alm_numpy (numpy's PCG64 stream emitted one range of multipoles at a time into a two-slot ring, K3
+    consuming range by range) against normals_pcg64 + draw_alm on the whole stream: the a_lm bit for bit, the generator
+    state after, for ring sizes that put the range edges anywhere inside the generator's 1024-position blocks (1 KB:
+    one l per range; 1 GB: one range), full and row-block factors, odd F (generic kernel)."""
+    import torch
+
+    from cora_amd import _lib
+
+    Td, infod = _factors(ctx, F, lmax, F * 1000 + lmax)
+    rng = np.random.default_rng(4242 + F)
+    rng.standard_normal(13)
+    st = rng.bit_generator.state["state"]
+    n = 2 * F * ((lmax + 1) * (lmax + 2) // 2)
+    g, nraw = ctx.normals_pcg64(st["state"], st["inc"], n)
+    ref = ctx.draw_alm(Td, infod, g, lmax, F, nu0=nu0, nnu=nnu)
+    after_ref = _lib.pcg64_advance(st["state"], st["inc"], nraw)
+    for rows in (False, True):
+        Tin = Td[:, nu0:nu0 + nnu, :].contiguous() if rows else Td
+        alm, after = ctx.draw_alm_numpy(Tin, infod, ("pcg64", st["state"], st["inc"]), lmax, F, nu0=nu0, nnu=nnu, rows=rows,
+                                        ring_bytes=ring_kb * 1024)
+        assert torch.equal(alm, ref), (rows, (alm - ref).abs().max().item())
+        assert after == after_ref
+    ref_np = rng.standard_normal(n)                            # (and numpy itself, once)
+    assert np.array_equal(g.cpu().numpy().view(np.uint64), ref_np.view(np.uint64))
+    assert after_ref == int(rng.bit_generator.state["state"]["state"])
+
+
+@pytest.mark.parametrize("F,lmax,nu0,nnu,ring_kb,skip", [(8, 40, 0, 8, 1, 0), (24, 70, 0, 24, 64, 1), (72, 150, 0, 72, 700, 3),
+                                                         (136, 260, 8, 64, 3000, 1), (256, 300, 192, 64, 1 << 20, 5),
+                                                         (7, 33, 2, 5, 10, 1)])
+def test_legacy_stream_in_l_ranges_equals_the_full_buffer(ctx, F, lmax, nu0, nnu, ring_kb, skip):
+    """The same for numpy's legacy MT19937 + polar-method stream (rng=None): ranges cut anywhere inside the sub-segments
+    of the emit pass, with and without a cached value in front (an odd `skip` leaves one: every pair then straddles an
+    even element index), the state numpy is left in."""
+    import torch
+
+    Td, infod = _factors(ctx, F, lmax, F * 1000 + lmax + 1)
+    rs = np.random.RandomState(777 + F)
+    rs.standard_normal(skip)
+    st = rs.get_state(legacy=False)
+    n = 2 * F * ((lmax + 1) * (lmax + 2) // 2)
+    g, new_ref = ctx.normals_legacy(st, n)
+    ref = ctx.draw_alm(Td, infod, g, lmax, F, nu0=nu0, nnu=nnu)
+    d = _ulps(g.cpu().numpy(), rs.standard_normal(n))
+    assert d.max() <= _LEGACY_ULP, int(d.max())
+    for rows in (False, True):
+        Tin = Td[:, nu0:nu0 + nnu, :].contiguous() if rows else Td
+        alm, new = ctx.draw_alm_numpy(Tin, infod, ("legacy", st), lmax, F, nu0=nu0, nnu=nnu, rows=rows, ring_bytes=ring_kb * 1024)
+        assert torch.equal(alm, ref), (rows, (alm - ref).abs().max().item())
+        twin = np.random.RandomState(0)
+        twin.set_state(new)
+        assert twin.get_state(legacy=False)["has_gauss"] == rs.get_state(legacy=False)["has_gauss"]
+        probe = np.random.RandomState(0)
+        probe.set_state(rs.get_state(legacy=False))
+        assert np.array_equal(twin.random_sample(700), probe.random_sample(700))
+
+
+def test_ranged_stream_leaves_generators_where_numpy_does(ctx):
+    """skysim.draw_numpy_stream: the caller's Generator / numpy's global state after a ranged draw = after the reference's
+    loop of complex_std_normal calls."""
+    from cora_amd.core import skysim
+
+    F, lmax = 12, 50
+    Td, infod = _factors(ctx, F, lmax, 5)
+    a, b = np.random.default_rng(99), np.random.default_rng(99)
+    skysim.draw_numpy_stream(ctx, Td, infod, a, lmax, F)
+    skysim._host_normals(F, lmax, b)
+    assert a.bit_generator.state == b.bit_generator.state
+    np.random.seed(4321)
+    skysim.draw_numpy_stream(ctx, Td, infod, None, lmax, F)
+    after = np.random.random_sample(50)
+    np.random.seed(4321)
+    skysim._host_normals(F, lmax, None)
+    assert np.array_equal(after, np.random.random_sample(50))

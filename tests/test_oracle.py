@@ -9,6 +9,8 @@ import pytest
 from oracle import healpix, models, sht
 from oracle import skysim as osk
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
 
 def _rel(a, b):
     return np.abs(np.asarray(a) - np.asarray(b)).max() / np.abs(b).max()
@@ -694,3 +696,28 @@ def test_glibc_log_restatement_is_the_hosts_log():
     assert ln2hi + ln2lo == math.log(2.0) and abs(A[0] + 0.5) < 1e-15 and B[0] == -0.5
     for i in range(128):
         assert abs(math.log(1.0 / T[2 * i]) - T[2 * i + 1]) < 1e-9
+
+
+# ------------------------------------------------------------------ EoR21cm (cora/signal/corr21cm.py:333-385)
+@pytest.fixture(scope="module")
+def eor_golden():
+    """Outputs of the reference's own EoR21cm / Cmb / TestF (tests/golden/make_golden_eor.py)."""
+    return np.load(os.path.join(ROOT, "tests", "golden", "eor_vectors.npz"))
+
+
+def test_eor21cm_oracle_vs_reference_outputs(model21, eor_golden):
+    """The oracle's EoR21cm (T_b of Santos et al. 2009, bias 3) against the reference's own class: T_b, the aps on the
+    150-200 MHz band, and clarray as Sky3d.getsky() drives it (zromb 0 / 1 / 3, and a 100-200 MHz band with zwidth)."""
+    g = eor_golden
+    eor = models.EoR21cm(share=model21)
+    assert _rel(eor.T_b(g["z"]), g["T_b"]) < 1e-15
+    fa = g["fa"]
+    aps1 = eor.angular_powerspectrum(np.arange(1000.0), 180.0, 180.0)
+    assert _rel(aps1, g["aps_180_180"]) < 1e-13
+    row = eor.angular_powerspectrum(np.full((1, 1), 200.0), fa[:, None], fa[None, :])
+    assert _rel(row, g["aps2_l200"]) < 1e-13
+    for zr in (0, 1, 3):
+        cla = osk.clarray(eor.angular_powerspectrum, 64, g["f8"], zromb=zr)
+        assert _rel(cla, g["cla_eor_F8_l64_zromb%d" % zr]) < 1e-13, zr
+    cla = osk.clarray(eor.angular_powerspectrum, 40, g["f6"], zromb=2, zwidth=1.0)
+    assert _rel(cla, g["cla_eor_F6_l40_zromb2_zw1"]) < 1e-13
