@@ -215,6 +215,32 @@ def test_cfg3_clarray_rows_vs_oracle(model21):
     assert sym == 0.0
 
 
+def test_eor_band_clarray_rows_vs_oracle(model21):
+    """K1 at configs[2] size on the EoR band (EoR21cm, F = 256 channels 100-200 MHz, zromb 3, lmax 2048): table rows
+    x ~ 300-345 at l = 2048 and y up to ~19000 columns - twice the |chi - chi'| of the 400-800 MHz band -, multipoles
+    0, 1, 2, 700, 2048 of the full launch against the oracle's EoR21cm, element by element."""
+    import torch
+    from cora_amd.core import skysim
+    from cora_amd.signal import corr21cm
+    from oracle import models
+    from oracle import skysim as osk
+
+    F, lmax = 256, 2048
+    rows = [0, 1, 2, 700, 2048]
+    freq = 100.0 + (np.arange(F) + 0.5) * (100.0 / F)
+    C = skysim.clarray_device(corr21cm.EoR21cm().angular_powerspectrum, lmax, freq, zromb=3)
+    got = C[rows].cpu().numpy()
+    sym = (C - C.transpose(1, 2)).abs().max().item()
+    del C
+    torch.cuda.empty_cache()
+    ref = osk.clarray(models.EoR21cm(share=model21).angular_powerspectrum, lmax, freq, zromb=3, rows=rows)
+    for k, l in enumerate(rows):
+        err = np.abs(got[k] - ref[k]).max() / np.abs(ref[k]).max()
+        print("EoR band C_l row", l, "max|err|/max =", err)
+        assert err <= 1e-11, (l, err)
+    assert sym == 0.0
+
+
 @pytest.fixture(scope="module")
 def cfg5_cl(ctx):
     """C_l of configs[4] (F = 1024, lmax 4096, zromb 3; 34.4 GB) integrated once on the device."""

@@ -1,4 +1,6 @@
 """Parity of the HIP path (through the C ABI) against the CPU oracle.  Run with -m gpu."""
+import os
+
 import numpy as np
 import pytest
 
@@ -970,6 +972,67 @@ def test_makesky_cli_21cm_and_gaussianfg(tmp_path):
     assert np.all(st[:, 1] > 0) and np.all(st[:, 2] > 0) and np.all(st[:, 1:3] < st[:, :1])      # Q, U present, fainter than T
     assert np.all(st[:, 3] < 1e-5 * st[:, 0])                    # V: only the 1e-14 diagonal jitter of mkfullsky
     del galaxy
+
+
+# ------------------------------------------------------------------ EoR21cm (cora/signal/corr21cm.py:333-385)
+@pytest.fixture(scope="module")
+def eor_golden():
+    """Outputs of the reference's own EoR21cm (tests/golden/make_golden_eor.py)."""
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "eor_vectors.npz"))
+
+
+def test_eor21cm_reference_vectors_through_k1(eor_golden):
+    """EoR21cm through the device path: the aps on the 150-200 MHz band (other table rows and y columns than any
+    400-800 MHz test reaches: chi ~ 6000-6800 Mpc/h) and clarray (K1) at zromb 0 / 1 / 3 and with an explicit
+    zwidth on 100-200 MHz against outputs of the reference's own class, <= 1e-12 of the maximum."""
+    from cora_amd.core import skysim
+    from cora_amd.signal import corr21cm
+
+    g = eor_golden
+    eor = corr21cm.EoR21cm()
+    aps1 = eor.angular_powerspectrum(np.arange(1000), 180.0, 180.0)
+    assert np.abs(aps1 - g["aps_180_180"]).max() <= 1e-12 * np.abs(g["aps_180_180"]).max()
+    fa = g["fa"]
+    aps2 = eor.angular_powerspectrum(np.arange(1000)[:, None, None], fa[None, :, None], fa[None, None, :])
+    got = np.array([aps1.sum(), aps2[400, 10, 10], aps2[200, 3, 10], aps2[0, 5, 6], aps2[999, 15, 0]])
+    assert np.abs(got / g["aps2_samples"] - 1.0).max() < 1e-9, got            # (the far off-diagonal samples are 1e-7 of the diagonal)
+    assert np.abs(aps2[200] - g["aps2_l200"]).max() <= 1e-12 * np.abs(g["aps2_l200"]).max()
+    for zr in (0, 1, 3):
+        ref = g["cla_eor_F8_l64_zromb%d" % zr]
+        cla = skysim.clarray(eor.angular_powerspectrum, 64, g["f8"].copy(), zromb=zr)
+        assert cla.shape == ref.shape and np.abs(cla - ref).max() <= 1e-12 * np.abs(ref).max(), zr
+    ref = g["cla_eor_F6_l40_zromb2_zw1"]
+    cla = skysim.clarray(eor.angular_powerspectrum, 40, g["f6"].copy(), zromb=2, zwidth=1.0)
+    assert np.abs(cla - ref).max() <= 1e-12 * np.abs(ref).max()
+    # bias 3 and the Santos et al. T_b are what separates it from Corr21cm on the same band
+    c21 = skysim.clarray(_shared_corr21cm().angular_powerspectrum, 64, g["f8"].copy(), zromb=0)
+    assert np.abs(c21 - g["cla_eor_F8_l64_zromb0"]).max() > 0.5 * np.abs(c21).max()
+
+
+def test_makesky_cli_21cm_eor(tmp_path):
+    """`cora-makesky 21cm --eor` (cora/scripts/makesky.py:316-334) = EoR21cm through getsky: same-seed maps equal the
+    module API, and differ from the intensity-mapping model's."""
+    from click.testing import CliRunner
+
+    from cora_amd.scripts import makesky
+    from cora_amd.signal import corr21cm
+
+    out = str(tmp_path / "eor.h5")
+    args = ["21cm", "--nside", "16", "--freq", "150", "190", "4", "--freq-mode", "edge", "--pol", "none", "--oversample", "1",
+            "--seed", "9", "--filename"]
+    r = CliRunner().invoke(makesky.cli, args[:1] + ["--eor"] + args[1:] + [out])
+    assert r.exit_code == 0, r.output
+    f = np.load(out + ".npz")
+    assert f["map"].shape == (4, 1, 12 * 16 * 16)
+    cr = corr21cm.EoR21cm()
+    cr.nside = 16
+    cr.frequencies = np.array([155.0, 165.0, 175.0, 185.0])
+    cr.oversample = 1
+    assert np.array_equal(f["map"][:, 0], cr.getsky(rng=np.random.default_rng(9)))
+    out2 = str(tmp_path / "im.h5")
+    r = CliRunner().invoke(makesky.cli, args + [out2])
+    assert r.exit_code == 0, r.output
+    assert f["map"].std() > 3.0 * np.load(out2 + ".npz")["map"].std()
 
 
 # ------------------------------------------------------------------ full-size pipeline / remaining BASELINE configs
