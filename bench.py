@@ -42,6 +42,8 @@ WORKLOADS = {
     "cfg5": ([("21cm", 3)], 1024, 400.0, 800.0, 2048, 4096),
     "tiny": ([("21cm", 1)], 16, 600.0, 625.0, 64, 128),
     "tiny3": ([("21cm", 1), ("synchrotron", 0), ("pointsource", 0)], 16, 600.0, 625.0, 64, 128),
+    "tiny32": ([("21cm", 1)], 32, 600.0, 650.0, 64, 128),          # (32 channels: the folded assignment at 2 and 4 ranks)
+    "tiny32s": ([("21cm", 1), ("synchrotron", 0), ("pointsource", 0)], 32, 600.0, 650.0, 64, 128),
 }
 MIN_RANKS = {"cfg5": 8}        # workloads that do not fit fewer GPUs: emulate one rank's share instead
 
@@ -99,7 +101,11 @@ def main():
     ap.add_argument("--same-device", action="store_true")
     ap.add_argument("--checksum", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="take the multi-rank code path (process group, exchanges) even with 1 rank")
-    ap.add_argument("--emulate-shard", type=int, default=0, help="time the work of the LAST rank of an N-rank job, no comm")
+    ap.add_argument("--emulate-shard", type=int, default=0,
+                    help="time the share of EVERY rank of an N-rank job in turn on this GPU (no comm); the line is the critical rank's")
+    ap.add_argument("--emulate-rank", type=int, default=None, help="with --emulate-shard: time this rank's share only")
+    ap.add_argument("--fold", action="store_true",
+                    help="folded channel assignment: rank r owns chunks r and 2N-1-r of 2N (balances the triangular draw)")
     ap.add_argument("--sum-mode", default="joint", choices=["joint", "separate"],
                     help="multi-component workloads (cfg4): one factorisation + draw of the summed covariance, or one per component")
     args = ap.parse_args()
@@ -155,60 +161,92 @@ def main():
     ctx = _lib.get_context(local_rank)
     freq = nu_lo + (np.arange(F) + 0.5) * ((nu_hi - nu_lo) / F)
 
-    # ---- untimed setup: everything the timed region reads is put in HBM (tables, plan, buffers) ----------
-    t_setup = time.time()
-    if len(comps) == 1:
-        shard = SkyShard(build_model(comps[0][0]), freq, nside, lmax, zromb=zromb, rank=rank, world=world, ctx=ctx,
-                         distributed=multi, emulate_world=args.emulate_shard)
-    else:
-        shard = SkySum([(build_model(m), z) for m, z in comps], freq, nside, lmax, rank=rank, world=world, ctx=ctx,
-                       distributed=multi, emulate_world=args.emulate_shard, mode=args.sum_mode)
-    nnu, nu0 = shard.nnu, shard.nu0
-    maps_buf = shard.maps_buf
-    torch.cuda.synchronize()
-    t_setup = time.time() - t_setup
-
     seed_box = [1000]
-    cold_factors = shard.factors
-    cached = {}
-
-    def step():
-        if args.warm:
-            if "f" not in cached:
-                cached["f"] = cold_factors()
-            fac = cached["f"]
-        else:
-            fac = cold_factors()     # K1 (+ all-to-all) -> K2 (+ all-to-all)
-        seed_box[0] += 1
-        # K3 (device Philox normals generated inside the draw kernel: no 8.6 GB normal buffer) -> K4 -> K5
-        shard.realise(seed_box[0], fac)
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    ctx.profile_reset()
-    ctx.profile_enable(True)
-    t0 = time.time()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    dt = time.time() - t0
-    ctx.profile_enable(False)
-    if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device=ctx.device)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    def measure(emulate_rank):
+        """Build the rank's pipeline object (untimed: everything the timed region reads is put in HBM - tables, plan,
+        buffers) and time `steps` steps after `warmup`; returns the shard, its step function, wall time, stage times."""
+        t_setup = time.time()
+        kw = dict(rank=rank, world=world, ctx=ctx, distributed=multi, emulate_world=args.emulate_shard, fold=args.fold,
+                  emulate_rank=emulate_rank)
+        if len(comps) == 1:
+            shard = SkyShard(build_model(comps[0][0]), freq, nside, lmax, zromb=zromb, **kw)
+        else:
+            shard = SkySum([(build_model(m), z) for m, z in comps], freq, nside, lmax, mode=args.sum_mode, **kw)
+        torch.cuda.synchronize()
+        t_setup = time.time() - t_setup
+        cold_factors = shard.factors
+        cached = {}
 
-    stages = {}
-    for name in ("clarray", "factor", "normals", "draw", "legendre", "ringfft"):
-        ms, n = ctx.profile_get(name)
-        if n:
-            stages[name] = {"ms_per_launch": ms / n, "launches": n, "ms_per_step": ms / args.steps}
+        def step():
+            if args.warm:
+                if "f" not in cached:
+                    cached["f"] = cold_factors()
+                fac = cached["f"]
+            else:
+                fac = cold_factors()     # K1 (+ all-to-all) -> K2 (+ all-to-all)
+            seed_box[0] += 1
+            # K3 (device Philox normals generated inside the draw kernel: no 8.6 GB normal buffer) -> K4 -> K5
+            shard.realise(seed_box[0], fac)
+
+        for _ in range(args.warmup):
+            step()
+        barrier()
+        ctx.profile_reset()
+        ctx.profile_enable(True)
+        t0 = time.time()
+        for _ in range(args.steps):
+            step()
+        barrier()
+        dt = time.time() - t0
+        ctx.profile_enable(False)
+        if dist is not None:
+            tt = torch.tensor([dt], dtype=torch.float64, device=ctx.device)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        stages = {}
+        for name in ("clarray", "factor", "normals", "draw", "legendre", "ringfft"):
+            ms, n = ctx.profile_get(name)
+            if n:
+                stages[name] = {"ms_per_launch": ms / n, "launches": n, "ms_per_step": ms / args.steps}
+        return dict(shard=shard, dt=dt, stages=stages, t_setup=t_setup, rank=emulate_rank)
+
+    # --emulate-shard N: the share of every rank of an N-rank job, one after the other on this GPU (no exchanges); the
+    # line below is the CRITICAL rank's (the slowest), `emulated_ranks` lists them all
+    emulated_ranks = None
+    if args.emulate_shard > 1 and args.emulate_rank is None:
+        runs = []
+        for r in range(args.emulate_shard):
+            m = measure(r)
+            runs.append({"rank": r, "ms_per_step": m["dt"] / args.steps * 1e3, "channels": [list(c) for c in m["shard"].chunks],
+                         "stages_ms": {k: round(v["ms_per_step"], 3) for k, v in m["stages"].items()}})
+            keep = m
+            if r + 1 < args.emulate_shard:
+                del m, keep
+                torch.cuda.empty_cache()
+        crit = max(runs, key=lambda x: x["ms_per_step"])
+        emulated_ranks = {"per_rank": runs, "per_rank_ms": [round(x["ms_per_step"], 3) for x in runs],
+                          "critical_rank": crit["rank"], "critical_path_ms": crit["ms_per_step"],
+                          "job_maps_per_s_no_exchange": F / (crit["ms_per_step"] * 1e-3),
+                          "fold": bool(args.fold),
+                          "note": "one GPU doing the share of each of %d ranks in turn, exchanges excluded: unmeasured on "
+                                  "multi-GPU hardware" % args.emulate_shard}
+        if crit["rank"] != args.emulate_shard - 1:
+            del keep
+            torch.cuda.empty_cache()
+            keep = measure(crit["rank"])
+        m = keep
+    else:
+        m = measure(args.emulate_rank)
+    shard, dt, stages, t_setup = m["shard"], m["dt"], m["stages"], m["t_setup"]
+    nnu, nu0 = shard.nnu, shard.nu0
+    maps_buf = shard.maps_buf
+    cold_factors = shard.factors
 
     # warm path (factors cached: draw + synthesis only - what repeated seeds amortise, cora/signal/lss.py:424-478),
     # measured after the timed region and reported next to the headline (cold) number
@@ -257,8 +295,11 @@ def main():
         st = torch.stack([maps_buf.mean(dim=1), (maps_buf**2).mean(dim=1).sqrt()], dim=1).cpu()
         if dist is not None:
             parts = [None] * world
-            dist.all_gather_object(parts, (nu0, st))
-            st = torch.cat([p[1] for p in sorted(parts, key=lambda x: x[0])])
+            dist.all_gather_object(parts, (shard.channels, st))
+            full = torch.empty((F, 2), dtype=st.dtype)
+            for chn, pst in parts:          # (a folded shard holds two chunks: every row goes to its channel)
+                full[torch.as_tensor(chn)] = pst
+            st = full
         if rank == 0:
             import hashlib
 
@@ -272,8 +313,9 @@ def main():
             hs = [hashlib.sha1(m[i].tobytes()).hexdigest() for i in range(m.shape[0])]
             if dist is not None:
                 parts = [None] * world
-                dist.all_gather_object(parts, (nu0, hs))
-                hs = [h for p in sorted(parts, key=lambda x: x[0]) for h in p[1]]
+                dist.all_gather_object(parts, (shard.channels, hs))
+                byc = {int(c): h for chn, ph in parts for c, h in zip(chn, ph)}
+                hs = [byc[c] for c in range(F)]
             if rank == 0:
                 print(tag, hashlib.sha1("".join(hs).encode()).hexdigest(), file=sys.stderr)
 
@@ -329,13 +371,17 @@ def main():
                                "warm (cached factors)" if args.warm else "cold (C_l integration + factor + draw + synthesis)",
                                "" if len(comps) == 1 else (", components summed as ONE Gaussian field (covariances added, one factorisation + one draw)"
                                                            if args.sum_mode == "joint" else ", one draw per component, a_lm added"),
-                               (" - ONE GPU doing the share of the most loaded of %d ranks (%d channels, no exchanges): "
-                                "value counts those maps only" % (emu, nnu)) if emu else ""),
+                               (" - ONE GPU doing the share of rank %s of %d ranks (%d channels%s, no exchanges), the slowest of "
+                                "the %d shares timed in turn: value counts those maps only"
+                                % (m["rank"] if m["rank"] is not None else emu - 1, emu, nnu, ", folded" if args.fold else "", emu))
+                               if emu else ""),
                 "sum_mode": (args.sum_mode + (": ONE draw of the summed covariance - same distribution as, not the same numbers per seed as, "
                                               "the reference's one getsky() per component" if args.sum_mode == "joint"
                                               else ": one factorisation + draw per component, as the reference's per-component getsky() calls"))
                             if len(comps) > 1 else None,
                 "parallelism": "freq-shard x%d (pair-sharded C_l -> all-to-all -> l-sharded factor -> all-to-all of factor row blocks)" % world if world > 1 else "single GPU",
+                "channel_assignment": ("folded: rank r owns chunks r and 2N-1-r of 2N" if args.fold else "contiguous blocks (the reference's split)"),
+                "emulated_ranks": emulated_ranks,
                 "realisations_per_s": args.steps / dt,
                 "warm_path": None if warm_ms is None else {"ms_per_step": warm_ms, "maps_per_s": F / (warm_ms * 1e-3)},
                 "setup_s": t_setup,
@@ -373,7 +419,7 @@ def main():
             },
             # every stage against the roof that bounds it (algorithmic work of SURVEY 8(d) / DESIGN section 3 per launch)
             "stage_rooflines": stage_rooflines(stages, comps, F, nside, lmax, nnu, nu0, max(world, emu, 1), args.sum_mode,
-                                               flops_exec),
+                                               flops_exec, shard.channels if shard.folded else None),
             "hbm_roofline_whole_step": {
                 "algorithmic_GB": alg_bytes / 1e9,
                 "achieved_GBs": alg_bytes / 1e9 / (ms_step * 1e-3),
@@ -391,7 +437,7 @@ def main():
     return result
 
 
-def stage_work(comps, F, nside, lmax, nnu, nu0, nranks, sum_mode, legendre_executed_flops):
+def stage_work(comps, F, nside, lmax, nnu, nu0, nranks, sum_mode, legendre_executed_flops, channels=None):
     """Algorithmic work of ONE RANK per step, per stage: {stage: (bound, flops, bytes, note)} (DESIGN
     section 3).  `comps` = [(model name, zromb)], `nranks` = ranks the work is cut over (the world size, or the N of
     --emulate-shard N), channels [nu0, nu0 + nnu) are this rank's.
@@ -419,7 +465,8 @@ def stage_work(comps, F, nside, lmax, nnu, nu0, nranks, sum_mode, legendre_execu
     k2_flops = per_l * (L / nranks) * F**3 / 3.0 + once * F**3 / 3.0
     k2_bytes = 16.0 * (per_l * (L / nranks) + once) * F * F
     ndraw = 1 if joint else len(comps)
-    k3_flops = ndraw * 4.0 * nalm * nnu * (nu0 + 0.5 * (nnu + 1))
+    # (channels: the global indices of the rank's channels when they are not the block [nu0, nu0 + nnu) - a folded shard)
+    k3_flops = ndraw * 4.0 * nalm * (nnu * (nu0 + 0.5 * (nnu + 1)) if channels is None else float(sum(int(c) + 1 for c in channels)))
     k3_bytes = ndraw * (8.0 * L * F * nnu + 16.0 * nalm * nnu)
     return {
         "clarray": ("valu", k1_flops, k1_bytes, "nominal 60 flop per table evaluation; pairs of this rank only"),
@@ -430,13 +477,13 @@ def stage_work(comps, F, nside, lmax, nnu, nu0, nranks, sum_mode, legendre_execu
     }
 
 
-def stage_rooflines(stages, comps, F, nside, lmax, nnu, nu0, nranks, sum_mode, legendre_executed_flops):
+def stage_rooflines(stages, comps, F, nside, lmax, nnu, nu0, nranks, sum_mode, legendre_executed_flops, channels=None):
     """Every stage of the step against the roof that bounds it: the rank's algorithmic work per STEP (stage_work) over the
     stage's measured time per step.  All fractions are <= 1 by construction of the work model for any rank count,
     --emulate-shard and multi-component workloads (tests/test_host.py checks the committed lines)."""
     out = {}
     for k, (bound, flops, nbytes, note) in stage_work(comps, F, nside, lmax, nnu, nu0, nranks, sum_mode,
-                                                      legendre_executed_flops).items():
+                                                      legendre_executed_flops, channels).items():
         if k not in stages:
             continue
         sec = stages[k]["ms_per_step"] * 1e-3

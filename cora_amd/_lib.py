@@ -61,6 +61,9 @@ SIGNATURES = {
     "corahip_draw_alm_numpy_begin": (c_int, [c_void_p, PTR, c_int, PTR, c_void_p, c_int, c_int, c_int, c_int, PTR, c_size_t,
                                              ctypes.POINTER(c_void_p)]),
     "corahip_draw_alm_numpy_end": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "corahip_draw_alm_numpy_begin_set": (c_int, [c_void_p, PTR, PTR, c_void_p, c_int, c_int, c_void_p, PTR, c_size_t,
+                                                 ctypes.POINTER(c_void_p)]),
+    "corahip_draw_alm_philox_rows_set": (c_int, [c_void_p, PTR, PTR, c_u64, c_int, c_int, c_void_p, PTR]),
     "corahip_mkfullsky_workspace_bytes": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, ctypes.POINTER(c_size_t)]),
     "corahip_mkfullsky": (c_int, [c_void_p, c_void_p, PTR, c_int, c_void_p, c_int, c_int, c_int, PTR, c_void_p, c_size_t]),
     "corahip_shard_plan": (c_int, [c_int, c_int, c_int, c_int, PTR]),
@@ -167,6 +170,22 @@ class _MtState(ctypes.Structure):          # corahip_mt_state
 class _Rng(ctypes.Structure):              # corahip_rng
     _fields_ = [("kind", ctypes.c_int32), ("reserved", ctypes.c_int32), ("stream", c_void_p), ("seed", c_u64),
                 ("state", c_u64 * 2), ("inc", c_u64 * 2), ("legacy", ctypes.POINTER(_MtState))]
+
+
+class _ChanSet(ctypes.Structure):          # corahip_chanset
+    _fields_ = [("nchunks", ctypes.c_int32), ("chunk_nnu", ctypes.c_int32), ("nu0", ctypes.c_int32 * 2)]
+
+
+def _chanset(chunks):
+    """[(first channel, count)] (one block, or the two equal chunks of a folded shard) -> corahip_chanset."""
+    cs = _ChanSet()
+    chunks = [(int(a), int(n)) for a, n in chunks]
+    if len(chunks) not in (1, 2) or (len(chunks) == 2 and chunks[0][1] != chunks[1][1]):
+        raise ValueError("a channel set is one block or two equal chunks")
+    cs.nchunks, cs.chunk_nnu = len(chunks), chunks[0][1]
+    cs.nu0[0] = chunks[0][0]
+    cs.nu0[1] = chunks[1][0] if len(chunks) == 2 else 0
+    return cs
 
 
 def _rng_struct(rng):
@@ -467,24 +486,35 @@ class Context:
                                               self._f64(g), lmax, F, nu0, nnu, self._f64(alm)))
         return alm
 
-    def draw_alm_numpy(self, T, info, rng, lmax, F, nu0=0, nnu=None, out=None, rows=False, ring_bytes=0, defer=False):
+    def draw_alm_numpy(self, T, info, rng, lmax, F, nu0=0, nnu=None, out=None, rows=False, ring_bytes=0, defer=False,
+                       chunks=None):
         """``corahip_draw_alm_numpy``: K3 with numpy's own stream generated on the device range by range (no 16 F nalm
         byte buffer).  ``rng``: ("pcg64", state, inc) python ints of a PCG64 bit generator, or ("legacy",
         get_state(legacy=False) dict).  ``rows``: T is the row block [L, nnu, F].  Returns (alm, state after): the PCG64
         state as a python int, or the legacy state dict ``set_state`` takes.  ``defer``: returns (alm, finish) instead -
         everything is enqueued, nothing waited for; ``finish()`` (``corahip_draw_alm_numpy_end``: the one read-back)
-        returns the state after and is called once the caller has enqueued what follows (the synthesis)."""
+        returns the state after and is called once the caller has enqueued what follows (the synthesis).
+        ``chunks``: [(first, count), (first, count)] - the two chunks of a folded frequency shard (row-block T in local
+        channel order) instead of ``nu0`` / ``nnu``."""
         import numpy as np
 
+        if chunks is not None:
+            rows, nu0, nnu = True, chunks[0][0], sum(c[1] for c in chunks)
         nnu = F if nnu is None else nnu
         assert tuple(T.shape) == ((lmax + 1, nnu, F) if rows else (lmax + 1, F, F)), T.shape
         nalm = (lmax + 1) * (lmax + 2) // 2
         alm = out if out is not None else self.empty((nalm, (nnu + 3) // 4, 2, 4))
         r, ms = _rng_struct(rng)
         pend = c_void_p()
-        _check(self.lib.corahip_draw_alm_numpy_begin(self.h, self._f64(T), 1 if rows else 0,
-                                                     self._p(info) if info is not None else None, ctypes.byref(r), lmax, F,
-                                                     nu0, nnu, self._f64(alm), int(ring_bytes), ctypes.byref(pend)))
+        if chunks is not None and len(chunks) > 1:
+            cs = _chanset(chunks)
+            _check(self.lib.corahip_draw_alm_numpy_begin_set(self.h, self._f64(T), self._p(info) if info is not None else None,
+                                                             ctypes.byref(r), lmax, F, ctypes.byref(cs), self._f64(alm),
+                                                             int(ring_bytes), ctypes.byref(pend)))
+        else:
+            _check(self.lib.corahip_draw_alm_numpy_begin(self.h, self._f64(T), 1 if rows else 0,
+                                                         self._p(info) if info is not None else None, ctypes.byref(r), lmax,
+                                                         F, nu0, nnu, self._f64(alm), int(ring_bytes), ctypes.byref(pend)))
         keep = [T, info, alm]           # (alive until the queue has been waited for)
 
         def finish():
@@ -516,6 +546,19 @@ class Context:
         alm = out if out is not None else self.empty((nalm, G, 2, 4))
         _check(self.lib.corahip_draw_alm_philox_rows(self.h, self._f64(T_rows), self._p(info) if info is not None else None,
                                                      c_u64(int(seed) & (2**64 - 1)), lmax, F, nu0, nnu, self._f64(alm)))
+        return alm
+
+    def draw_alm_philox_chunks(self, T_rows, info, seed, lmax, F, chunks, out=None):
+        """draw_alm_philox_rows for the channels of ``chunks`` = [(first, count), ...]: one block, or the two equal
+        chunks of a folded frequency shard; T_rows [lmax+1, sum(count), F] in local channel order."""
+        nnu = sum(int(c[1]) for c in chunks)
+        assert tuple(T_rows.shape) == (lmax + 1, nnu, F), T_rows.shape
+        nalm = (lmax + 1) * (lmax + 2) // 2
+        alm = out if out is not None else self.empty((nalm, (nnu + 3) // 4, 2, 4))
+        cs = _chanset(chunks)
+        _check(self.lib.corahip_draw_alm_philox_rows_set(self.h, self._f64(T_rows), self._p(info) if info is not None else None,
+                                                         c_u64(int(seed) & (2**64 - 1)), lmax, F, ctypes.byref(cs),
+                                                         self._f64(alm)))
         return alm
 
     # -- frequency sharding: the data movements around the factor row-block all-to-all ---------

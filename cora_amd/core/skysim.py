@@ -233,7 +233,7 @@ def stream_normals(ctx, numz, maxl, rng):
     return g
 
 
-def draw_numpy_stream(ctx, T, info, rng, maxl, numz, nu0=0, nnu=None, out=None, rows=False, defer=False):
+def draw_numpy_stream(ctx, T, info, rng, maxl, numz, nu0=0, nnu=None, out=None, rows=False, defer=False, chunks=None):
     """K3 with the REFERENCE's normals: ``a_lm = T_l g_l`` for channels ``[nu0, nu0 + nnu)`` where ``g`` is what
     ``complex_std_normal((numz, l + 1), rng)`` returns inside the reference's l loop (cora/core/skysim.py:114-121,
     cora/util/nputil.py:104-125) - drawn the way the reference draws them: range of multipoles by range, never the
@@ -244,16 +244,31 @@ def draw_numpy_stream(ctx, T, info, rng, maxl, numz, nu0=0, nnu=None, out=None, 
         continued on the device bit for bit and left where numpy would leave it (for the legacy generators as an
         equivalent (key, pos) pair: the NEXT draws are numpy's, ``get_state()`` itself may differ in representation).
         Any other generator is consumed on the host, l by l, and uploaded.
-    T : full factors ``[L, F, F]`` or, with ``rows``, the row block ``[L, nnu, F]`` of a frequency shard.
+    T : full factors ``[L, F, F]`` or, with ``rows``, the row block ``[L, nnu, F]`` of a frequency shard
+        (``chunks`` = [(first, count), (first, count)]: the two chunks of a FOLDED shard, rows in local order).
     defer : return ``(alm, finish)``: the draw is only ENQUEUED; ``finish()`` - to be called after the caller has
         enqueued what follows, e.g. the synthesis - waits for the queue and writes the generator's state back (the
         generator's lock is held until then).  Default: ``alm``, generator already updated.
     A device-side failure of the generator (its margins are > 100 sigma) falls back to the host stream with the
     caller's generator untouched."""
+    if chunks is not None:
+        rows, nu0, nnu = True, chunks[0][0], sum(c[1] for c in chunks)
     nnu = numz if nnu is None else nnu
 
     def host_path():
         g = _upload_host_normals(ctx, numz, maxl, rng)
+        if chunks is not None and len(chunks) > 1:       # (the whole-buffer kernel takes one block: chunk by chunk)
+            import torch
+
+            parts, o = [], 0
+            for c0, cn in chunks:
+                parts.append(ctx.draw_alm_rows(T[:, o:o + cn, :].contiguous(), info, g, maxl, numz, c0, cn))
+                o += cn
+            alm = torch.cat(parts, dim=1)
+            if out is not None:
+                out.copy_(alm)
+                return out
+            return alm
         if rows:
             return ctx.draw_alm_rows(T, info, g, maxl, numz, nu0, nnu, out=out)
         return ctx.draw_alm(T, info, g, maxl, numz, nu0=nu0, nnu=nnu, out=out)
@@ -280,7 +295,7 @@ def draw_numpy_stream(ctx, T, info, rng, maxl, numz, nu0=0, nnu=None, out=None, 
         else:
             st = bg.state
             spec = ("pcg64", int(st["state"]["state"]), int(st["state"]["inc"]))
-        alm, fin = ctx.draw_alm_numpy(T, info, spec, maxl, numz, nu0=nu0, nnu=nnu, out=out, rows=rows, defer=True)
+        alm, fin = ctx.draw_alm_numpy(T, info, spec, maxl, numz, nu0=nu0, nnu=nnu, out=out, rows=rows, defer=True, chunks=chunks)
     except _lib.CoraHipError:
         lock.release()
         return done(host_path())

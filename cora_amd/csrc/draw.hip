@@ -211,10 +211,10 @@ static inline long draw_slots(int l_lo, int l_hi) {
 // first half of chunk c + 1 is requested at that point and waited for, with everything else, at the next chunk begin.
 template <int NCT, bool FROMG = false>
 __global__ void __launch_bounds__(64 * DRAW_WAVES, 2)
-draw_rng_kernel(const double *__restrict__ T, size_t t_ldl, int t_row0, const int32_t *__restrict__ info,
+draw_rng_kernel(const double *__restrict__ T, size_t t_ldl, int rows, const int32_t *__restrict__ info,
                 const double *__restrict__ zeros, uint64_t seed, const double *__restrict__ gsrc, size_t g_off, int l_lo,
-                int l_hi, int lmax, int F, int nu0, int nnu, int Gout, int nslots, int ncg, double *__restrict__ alm,
-                unsigned *__restrict__ queue) {
+                int l_hi, int lmax, int F, int nu0, int nu1, int cw, int nnu, int Gout, int nslots, int ncg0, int ncg,
+                double *__restrict__ alm, unsigned *__restrict__ queue) {
     constexpr int NC = 16 * NCT;
     constexpr int ROWD = DRAW_KC;            // doubles per channel row in LDS: 256 B, unpadded (DMA is lane-linear)
     constexpr int BUF = NC * ROWD;           // doubles per stage
@@ -236,10 +236,13 @@ draw_rng_kernel(const double *__restrict__ T, size_t t_ldl, int t_row0, const in
     { unsigned long long _t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)::"memory"); d_last = _t; }
 #endif
 
+    // The launch's channels: local channel c < cw is global channel nu0 + c, local channel c >= cw is nu1 + (c - cw) (the
+    // second chunk of a FOLDED frequency shard, parallel.py; cw >= nnu: one contiguous block).  Column groups never
+    // straddle the two chunks: groups 0 .. ncg0 - 1 tile chunk 0, the others chunk 1.
     struct item_t {
-        int l, mb, base0, kmax, nchunk, c_full;
+        int l, mb, base0, lbase, lend, kmax, nchunk, c_full;
         bool tri_tail;
-        const double *Tl;        // row nu of T_l at Tl + nu F (rows < t_row0 never read)
+        const double *Tl;        // row of the item's column n (global channel base0 + n, local channel lbase + n) at Tl + n F
     };
     auto decode = [&](int it) {
         item_t w;
@@ -258,7 +261,10 @@ draw_rng_kernel(const double *__restrict__ T, size_t t_ldl, int t_row0, const in
         }
         w.l = l;
         w.mb = mb;
-        w.base0 = nu0 + cg * NC;                       // first channel of the item
+        const bool second = cg >= ncg0;
+        w.lbase = second ? cw + (cg - ncg0) * NC : cg * NC;        // first local channel of the item
+        w.lend = second ? nnu : min(cw, nnu);                      // end of its chunk (local)
+        w.base0 = second ? nu1 + (cg - ncg0) * NC : nu0 + cg * NC; // first (global) channel of the item
         const bool dense = (info == nullptr) || (info[l] != 0);
         // lower-triangular T: channel nu only needs nu' <= nu
         w.kmax = dense ? F : min(F, w.base0 + NC);
@@ -272,7 +278,7 @@ draw_rng_kernel(const double *__restrict__ T, size_t t_ldl, int t_row0, const in
         // shards) takes every tile up to kmax - correct for the same reason, just not minimal.
         w.tri_tail = !dense && (w.base0 % DRAW_KC) == 0;
         w.c_full = w.tri_tail ? min(w.nchunk, w.base0 / DRAW_KC) : w.nchunk;
-        w.Tl = T + (size_t)l * t_ldl - (size_t)t_row0 * F;
+        w.Tl = T + (size_t)l * t_ldl + (size_t)(rows ? w.lbase : w.base0) * F;    // (a row block holds the local channels in order)
         return w;
     };
     // stage chunk c of the item (rows base0 .. base0+NC-1 of T_l, nu' in [c KC, c KC + KC)) into ring slot `slot`:
@@ -290,7 +296,7 @@ draw_rng_kernel(const double *__restrict__ T, size_t t_ldl, int t_row0, const in
             const int nu = w.base0 + n;
             const int k = k0 + 2 * slot_src;
             const double *src = zeros;  // F is even on this path (host wrapper), so k + 1 < F whenever k < F
-            if (nu - nu0 < nnu && nu < F && k + 1 < F) src = w.Tl + (size_t)nu * F + k;
+            if (w.lbase + n < w.lend && nu < F && k + 1 < F) src = w.Tl + (size_t)n * F + k;
 #if DRAW_ABLATE != 4   // diagnostic 4: no staging of T
             draw_glds16(src, lds_base + (unsigned)((slot * BUF + 4 * rq * ROWD) * sizeof(double)));
 #else
@@ -398,7 +404,11 @@ draw_rng_kernel(const double *__restrict__ T, size_t t_ldl, int t_row0, const in
         // start; then the first half of the next chunk is requested (a_x is free: the first half is done)
         auto mid_chunk = [&](int c) {
             if constexpr (FROMG) {
-                if (c + 2 < nchunk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(QPW) : "memory");
+                // (a wave that stages nothing - the 16-column shape has four row quads for eight waves - has only its own
+                //  operand loads in flight: it waits for all of them; counting QPW pieces it never issued would let the
+                //  youngest operand load through unfinished)
+                constexpr bool ALL_STAGE = QPW * DRAW_WAVES == NC / 4;
+                if (c + 2 < nchunk && (ALL_STAGE || wave < NC / 4)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(QPW) : "memory");
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 pin_a(a_y);
                 if (c + 1 < nchunk) issue_a(w, c + 1, 0, a_x);
@@ -458,7 +468,7 @@ draw_rng_kernel(const double *__restrict__ T, size_t t_ldl, int t_row0, const in
         // ---- next item: its first two stages are requested now, ahead of this item's stores.  Only the slot of the
         //      last chunk can still be in use by a slower wave, and the ring moves on past it.
         ring = (ring + nchunk) % DRAW_NBUF;
-        const int cur_base0 = w.base0;
+        const int cur_lbase = w.lbase, cur_lend4 = (w.lend + 3) & ~3;
         item = __builtin_amdgcn_readfirstlane(s_next[par]);   // (written before this item's first barrier)
         par ^= 1;
         const bool have_next = item < nitems;
@@ -489,8 +499,8 @@ draw_rng_kernel(const double *__restrict__ T, size_t t_ldl, int t_row0, const in
             };
 #pragma unroll
             for (int t = 0; t < NCT; t++) {
-                const int col = cur_base0 - nu0 + 16 * t + (ri & ~3);    // first (local) channel of the quad's cell
-                const bool col_ok = col < 4 * Gout;                       // (4 Gout is a multiple of 4: the whole cell or none)
+                const int col = cur_lbase + 16 * t + (ri & ~3);          // first (local) channel of the quad's cell
+                const bool col_ok = col < cur_lend4;                      // (the chunk's end rounded up to a cell: the whole cell or none)
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
                     const double re = acc0[t][r] * sc, im = acc1[t][r] * sc;
@@ -524,10 +534,14 @@ draw_rng_kernel(const double *__restrict__ T, size_t t_ldl, int t_row0, const in
 
 // l_lo .. l_hi: the multipoles of this launch (0 .. lmax: all); FROMG: gsrc[0] is element g_off of the stream-order
 // buffer; `stream`: where the launch goes (the context's stream, or the draw stream of the l-range pipeline)
+// chan: the launch's channels {nu0, nu1, cw, nnu} (see the kernel); rows: T holds the row block of the local channels
+struct draw_chan {
+    int nu0, nu1, cw, nnu;
+};
 template <int NCT, bool FROMG = false>
-static int launch_draw_rng(corahip_ctx *ctx, hipStream_t stream, const double *T, size_t t_ldl, int t_row0, const int32_t *info,
-                           uint64_t seed, const double *gsrc, size_t g_off, int l_lo, int l_hi, int lmax, int F, int nu0,
-                           int nnu, int Gout, double *alm) {
+static int launch_draw_rng(corahip_ctx *ctx, hipStream_t stream, const double *T, size_t t_ldl, int rows, const int32_t *info,
+                           uint64_t seed, const double *gsrc, size_t g_off, int l_lo, int l_hi, int lmax, int F,
+                           draw_chan ch, int Gout, double *alm) {
     constexpr int NC = 16 * NCT;
     const size_t shm = sizeof(double) * DRAW_NBUF * NC * DRAW_KC;
     HIP_TRY(hipFuncSetAttribute((const void *)draw_rng_kernel<NCT, FROMG>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -537,16 +551,18 @@ static int launch_draw_rng(corahip_ctx *ctx, hipStream_t stream, const double *T
     int rc = corahip_ctx_scratch(ctx, 3, 8192, (void **)&zq);
     if (rc) return rc;
     HIP_TRY(hipMemsetAsync(zq, 0, 8192, stream));
-    const int ncg = (4 * Gout + NC - 1) / NC;
+    const int n0 = std::min(ch.cw, ch.nnu), n1 = ch.nnu - n0;
+    const int ncg0 = (((n0 + 3) & ~3) + NC - 1) / NC, ncg = ncg0 + (((n1 + 3) & ~3) + NC - 1) / NC;
     const long nslots = draw_slots(l_lo, l_hi);
     const long nitems = nslots * ncg;
     ARG_CHECK(nitems < (1L << 30));
     // persistent: one workgroup per CU for the 128-channel shape (106 KB of LDS), two for the narrower ones
     const int per_cu = (shm + 8300 > 80 * 1024) ? 1 : 2;
     dim3 grid((unsigned)std::min<long>(nitems, (long)ctx->num_cu * per_cu));
-    draw_rng_kernel<NCT, FROMG><<<grid, 64 * DRAW_WAVES, shm, stream>>>(T, t_ldl, t_row0, info, (const double *)zq, seed, gsrc,
-                                                                        g_off, l_lo, l_hi, lmax, F, nu0, nnu, Gout,
-                                                                        (int)nslots, ncg, alm, (unsigned *)(zq + 4096));
+    draw_rng_kernel<NCT, FROMG><<<grid, 64 * DRAW_WAVES, shm, stream>>>(T, t_ldl, rows, info, (const double *)zq, seed, gsrc,
+                                                                        g_off, l_lo, l_hi, lmax, F, ch.nu0, ch.nu1, ch.cw,
+                                                                        ch.nnu, Gout, (int)nslots, ncg0, ncg, alm,
+                                                                        (unsigned *)(zq + 4096));
     LAUNCH_CHECK();
 #if DRAW_STAMPS
     {
@@ -625,19 +641,29 @@ int corahip_normals_philox(corahip_ctx *ctx, uint64_t seed, int lmax, int F, dou
     return 0;
 }
 
+// widest chunk of the launch's channels, in columns of whole cells: decides the tile shape
+static inline int chan_ncol(const draw_chan &ch) {
+    const int n0 = std::min(ch.cw, ch.nnu), n1 = ch.nnu - n0;
+    return (std::max(n0, n1) + 3) & ~3;
+}
+static inline bool chan_folded(const draw_chan &ch) { return ch.nnu > ch.cw; }
+
 // K3 of the multipoles l_lo .. l_hi from a stream-order buffer whose first element is element g_off of the stream
-static int draw_stream_range(corahip_ctx *ctx, hipStream_t stream, const double *T, size_t t_ldl, int t_row0, const int32_t *info,
-                             const double *g, size_t g_off, int l_lo, int l_hi, int lmax, int F, int nu0, int nnu,
+static int draw_stream_range(corahip_ctx *ctx, hipStream_t stream, const double *T, int rows, const int32_t *info,
+                             const double *g, size_t g_off, int l_lo, int l_hi, int lmax, int F, draw_chan ch,
                              double *alm_dev) {
-    const int Gout = (nnu + 3) / 4;
-    const int ncol = 4 * Gout;
+    const int Gout = (ch.nnu + 3) / 4;
+    const size_t t_ldl = rows ? (size_t)ch.nnu * F : (size_t)F * F;
     if (!(F & 1) && !getenv("CORAHIP_DRAW_GENERIC")) {
         // the persistent MFMA kernel of the device-RNG mode with its A operands read from the stream buffer
-        if (ncol <= 16) return launch_draw_rng<1, true>(ctx, stream, T, t_ldl, t_row0, info, 0, g, g_off, l_lo, l_hi, lmax, F, nu0, nnu, Gout, alm_dev);
-        if (ncol <= 32) return launch_draw_rng<2, true>(ctx, stream, T, t_ldl, t_row0, info, 0, g, g_off, l_lo, l_hi, lmax, F, nu0, nnu, Gout, alm_dev);
-        if (ncol <= 64) return launch_draw_rng<4, true>(ctx, stream, T, t_ldl, t_row0, info, 0, g, g_off, l_lo, l_hi, lmax, F, nu0, nnu, Gout, alm_dev);
-        return launch_draw_rng<8, true>(ctx, stream, T, t_ldl, t_row0, info, 0, g, g_off, l_lo, l_hi, lmax, F, nu0, nnu, Gout, alm_dev);
+        const int ncol = chan_ncol(ch);
+        if (ncol <= 16) return launch_draw_rng<1, true>(ctx, stream, T, t_ldl, rows, info, 0, g, g_off, l_lo, l_hi, lmax, F, ch, Gout, alm_dev);
+        if (ncol <= 32) return launch_draw_rng<2, true>(ctx, stream, T, t_ldl, rows, info, 0, g, g_off, l_lo, l_hi, lmax, F, ch, Gout, alm_dev);
+        if (ncol <= 64) return launch_draw_rng<4, true>(ctx, stream, T, t_ldl, rows, info, 0, g, g_off, l_lo, l_hi, lmax, F, ch, Gout, alm_dev);
+        return launch_draw_rng<8, true>(ctx, stream, T, t_ldl, rows, info, 0, g, g_off, l_lo, l_hi, lmax, F, ch, Gout, alm_dev);
     }
+    ARG_CHECK(!chan_folded(ch));          // (the generic kernel - odd F - takes one contiguous block of channels)
+    const int ncol = 4 * Gout, nu0 = ch.nu0, nnu = ch.nnu, t_row0 = rows ? nu0 : 0;
     if (ncol <= 16) return launch_draw<1>(ctx, stream, T, t_ldl, t_row0, info, g, g_off, l_lo, l_hi, lmax, F, nu0, nnu, Gout, alm_dev);
     if (ncol <= 32) return launch_draw<2>(ctx, stream, T, t_ldl, t_row0, info, g, g_off, l_lo, l_hi, lmax, F, nu0, nnu, Gout, alm_dev);
     if (ncol <= 64) return launch_draw<4>(ctx, stream, T, t_ldl, t_row0, info, g, g_off, l_lo, l_hi, lmax, F, nu0, nnu, Gout, alm_dev);
@@ -645,14 +671,14 @@ static int draw_stream_range(corahip_ctx *ctx, hipStream_t stream, const double 
     return launch_draw<16>(ctx, stream, T, t_ldl, t_row0, info, g, g_off, l_lo, l_hi, lmax, F, nu0, nnu, Gout, alm_dev);
 }
 
-static int draw_host_stream(corahip_ctx *ctx, const double *T, size_t t_ldl, int t_row0, const int32_t *info,
-                            const double *g, int lmax, int F, int nu0, int nnu, double *alm_dev) {
+static int draw_host_stream(corahip_ctx *ctx, const double *T, int rows, const int32_t *info, const double *g, int lmax, int F,
+                            draw_chan ch, double *alm_dev) {
     StageTimer t(ctx, "draw");
-    return draw_stream_range(ctx, ctx->stream, T, t_ldl, t_row0, info, g, 0, 0, lmax, lmax, F, nu0, nnu, alm_dev);
+    return draw_stream_range(ctx, ctx->stream, T, rows, info, g, 0, 0, lmax, lmax, F, ch, alm_dev);
 }
 
-static int draw_philox(corahip_ctx *ctx, const double *T, size_t t_ldl, int t_row0, const int32_t *info,
-                       uint64_t seed, int lmax, int F, int nu0, int nnu, double *alm_dev) {
+static int draw_philox(corahip_ctx *ctx, const double *T, int rows, const int32_t *info, uint64_t seed, int lmax, int F,
+                       draw_chan ch, double *alm_dev) {
     if (F & 1) {
         // odd F: a 16-byte LDS-DMA piece would straddle the end of a T row; materialise the (identical)
         // device stream and use the generic kernel instead
@@ -660,43 +686,68 @@ static int draw_philox(corahip_ctx *ctx, const double *T, size_t t_ldl, int t_ro
         int rc = corahip_ctx_scratch(ctx, 1, sizeof(double) * 2 * (size_t)F * nalm_of(lmax), (void **)&g);
         if (rc) return rc;
         if ((rc = corahip_normals_philox(ctx, seed, lmax, F, g))) return rc;
-        return draw_host_stream(ctx, T, t_ldl, t_row0, info, g, lmax, F, nu0, nnu, alm_dev);
+        return draw_host_stream(ctx, T, rows, info, g, lmax, F, ch, alm_dev);
     }
     StageTimer t(ctx, "draw");
-    const int Gout = (nnu + 3) / 4;
-    const int ncol = 4 * Gout;
-    if (ncol <= 16) return launch_draw_rng<1>(ctx, ctx->stream, T, t_ldl, t_row0, info, seed, nullptr, 0, 0, lmax, lmax, F, nu0, nnu, Gout, alm_dev);
-    if (ncol <= 32) return launch_draw_rng<2>(ctx, ctx->stream, T, t_ldl, t_row0, info, seed, nullptr, 0, 0, lmax, lmax, F, nu0, nnu, Gout, alm_dev);
-    if (ncol <= 64) return launch_draw_rng<4>(ctx, ctx->stream, T, t_ldl, t_row0, info, seed, nullptr, 0, 0, lmax, lmax, F, nu0, nnu, Gout, alm_dev);
-    return launch_draw_rng<8>(ctx, ctx->stream, T, t_ldl, t_row0, info, seed, nullptr, 0, 0, lmax, lmax, F, nu0, nnu, Gout, alm_dev);
+    const int Gout = (ch.nnu + 3) / 4;
+    const size_t t_ldl = rows ? (size_t)ch.nnu * F : (size_t)F * F;
+    const int ncol = chan_ncol(ch);
+    if (ncol <= 16) return launch_draw_rng<1>(ctx, ctx->stream, T, t_ldl, rows, info, seed, nullptr, 0, 0, lmax, lmax, F, ch, Gout, alm_dev);
+    if (ncol <= 32) return launch_draw_rng<2>(ctx, ctx->stream, T, t_ldl, rows, info, seed, nullptr, 0, 0, lmax, lmax, F, ch, Gout, alm_dev);
+    if (ncol <= 64) return launch_draw_rng<4>(ctx, ctx->stream, T, t_ldl, rows, info, seed, nullptr, 0, 0, lmax, lmax, F, ch, Gout, alm_dev);
+    return launch_draw_rng<8>(ctx, ctx->stream, T, t_ldl, rows, info, seed, nullptr, 0, 0, lmax, lmax, F, ch, Gout, alm_dev);
+}
+
+// a rank's channels as the C ABI hands them over: nchunks x chunk_nnu channels from nu0[0] (and nu0[1])
+static int chan_of(const corahip_chanset *set, int F, draw_chan &ch) {
+    ARG_CHECK(set != nullptr && (set->nchunks == 1 || set->nchunks == 2) && set->chunk_nnu >= 1);
+    ARG_CHECK(set->nu0[0] >= 0 && set->nu0[0] + set->chunk_nnu <= F);
+    if (set->nchunks == 2) {
+        ARG_CHECK(set->chunk_nnu % 4 == 0);                                   // whole a_lm cells per chunk
+        ARG_CHECK(set->nu0[1] >= set->nu0[0] + set->chunk_nnu && set->nu0[1] + set->chunk_nnu <= F);
+        ch = draw_chan{set->nu0[0], set->nu0[1], set->chunk_nnu, 2 * set->chunk_nnu};
+    } else {
+        ch = draw_chan{set->nu0[0], 0, set->chunk_nnu, set->chunk_nnu};
+    }
+    return 0;
 }
 
 int corahip_draw_alm_philox(corahip_ctx *ctx, const double *T, const int32_t *info, uint64_t seed, int lmax, int F,
                             int nu0, int nnu, double *alm_dev) {
     ARG_CHECK(ctx != nullptr && T != nullptr && alm_dev != nullptr);
     ARG_CHECK(lmax >= 0 && F >= 1 && nu0 >= 0 && nnu >= 1 && nu0 + nnu <= F);
-    return draw_philox(ctx, T, (size_t)F * F, 0, info, seed, lmax, F, nu0, nnu, alm_dev);
+    return draw_philox(ctx, T, 0, info, seed, lmax, F, draw_chan{nu0, 0, nnu, nnu}, alm_dev);
 }
 
 int corahip_draw_alm_philox_rows(corahip_ctx *ctx, const double *T_rows, const int32_t *info, uint64_t seed, int lmax,
                                  int F, int nu0, int nnu, double *alm_dev) {
     ARG_CHECK(ctx != nullptr && T_rows != nullptr && alm_dev != nullptr);
     ARG_CHECK(lmax >= 0 && F >= 1 && nu0 >= 0 && nnu >= 1 && nu0 + nnu <= F);
-    return draw_philox(ctx, T_rows, (size_t)nnu * F, nu0, info, seed, lmax, F, nu0, nnu, alm_dev);
+    return draw_philox(ctx, T_rows, 1, info, seed, lmax, F, draw_chan{nu0, 0, nnu, nnu}, alm_dev);
+}
+
+int corahip_draw_alm_philox_rows_set(corahip_ctx *ctx, const double *T_rows, const int32_t *info, uint64_t seed, int lmax,
+                                     int F, const corahip_chanset *set, double *alm_dev) {
+    ARG_CHECK(ctx != nullptr && T_rows != nullptr && alm_dev != nullptr && lmax >= 0 && F >= 1);
+    draw_chan ch;
+    int rc = chan_of(set, F, ch);
+    if (rc) return rc;
+    ARG_CHECK(!(chan_folded(ch) && (F & 1)));
+    return draw_philox(ctx, T_rows, 1, info, seed, lmax, F, ch, alm_dev);
 }
 
 int corahip_draw_alm(corahip_ctx *ctx, const double *T, const int32_t *info, const double *g, int lmax, int F,
                      int nu0, int nnu, double *alm_dev) {
     ARG_CHECK(ctx != nullptr && T != nullptr && g != nullptr && alm_dev != nullptr);
     ARG_CHECK(lmax >= 0 && F >= 1 && nu0 >= 0 && nnu >= 1 && nu0 + nnu <= F);
-    return draw_host_stream(ctx, T, (size_t)F * F, 0, info, g, lmax, F, nu0, nnu, alm_dev);
+    return draw_host_stream(ctx, T, 0, info, g, lmax, F, draw_chan{nu0, 0, nnu, nnu}, alm_dev);
 }
 
 int corahip_draw_alm_rows(corahip_ctx *ctx, const double *T_rows, const int32_t *info, const double *g, int lmax, int F,
                           int nu0, int nnu, double *alm_dev) {
     ARG_CHECK(ctx != nullptr && T_rows != nullptr && g != nullptr && alm_dev != nullptr);
     ARG_CHECK(lmax >= 0 && F >= 1 && nu0 >= 0 && nnu >= 1 && nu0 + nnu <= F);
-    return draw_host_stream(ctx, T_rows, (size_t)nnu * F, nu0, info, g, lmax, F, nu0, nnu, alm_dev);
+    return draw_host_stream(ctx, T_rows, 1, info, g, lmax, F, draw_chan{nu0, 0, nnu, nnu}, alm_dev);
 }
 
 int corahip_alm_dev_to_square(corahip_ctx *ctx, const double *alm_dev, int lmax, int nnu, double *square) {
@@ -723,7 +774,9 @@ int corahip_alm_packed_to_dev(corahip_ctx *ctx, const double *packed, int lmax, 
 
 // (stream_internal.h) K3 of one l range of the numpy-stream pipeline (drawstream.hip)
 int corahip_draw_range(corahip_ctx *ctx, hipStream_t stream, const double *T, int rows, const int32_t *info, const double *gslot,
-                       size_t g_off, int l_lo, int l_hi, int lmax, int F, int nu0, int nnu, double *alm_dev) {
-    return draw_stream_range(ctx, stream, T, rows ? (size_t)nnu * F : (size_t)F * F, rows ? nu0 : 0, info, gslot, g_off, l_lo, l_hi,
-                             lmax, F, nu0, nnu, alm_dev);
+                       size_t g_off, int l_lo, int l_hi, int lmax, int F, const corahip_chanset *set, double *alm_dev) {
+    draw_chan ch;
+    int rc = chan_of(set, F, ch);
+    if (rc) return rc;
+    return draw_stream_range(ctx, stream, T, rows, info, gslot, g_off, l_lo, l_hi, lmax, F, ch, alm_dev);
 }

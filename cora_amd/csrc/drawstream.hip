@@ -46,13 +46,11 @@ static void pending_free(corahip_draw_pending *p) {
     delete p;
 }
 
-extern "C" {
-
-int corahip_draw_alm_numpy_begin(corahip_ctx *ctx, const double *T, int rows, const int32_t *info, const corahip_rng *rng,
-                                 int lmax, int F, int nu0, int nnu, double *alm_dev, size_t ring_bytes,
-                                 corahip_draw_pending **pending) {
-    ARG_CHECK(ctx != nullptr && T != nullptr && rng != nullptr && alm_dev != nullptr && pending != nullptr);
-    ARG_CHECK(lmax >= 0 && F >= 1 && nu0 >= 0 && nnu >= 1 && nu0 + nnu <= F);
+static int draw_numpy_begin(corahip_ctx *ctx, const double *T, int rows, const int32_t *info, const corahip_rng *rng, int lmax,
+                            int F, const corahip_chanset *set, double *alm_dev, size_t ring_bytes,
+                            corahip_draw_pending **pending) {
+    ARG_CHECK(ctx != nullptr && T != nullptr && rng != nullptr && alm_dev != nullptr && pending != nullptr && set != nullptr);
+    ARG_CHECK(lmax >= 0 && F >= 1);
     ARG_CHECK(rng->kind == CORAHIP_RNG_PCG64 || rng->kind == CORAHIP_RNG_MT19937);
     ARG_CHECK(rng->kind != CORAHIP_RNG_MT19937 || rng->legacy != nullptr);
     *pending = nullptr;
@@ -131,7 +129,7 @@ int corahip_draw_alm_numpy_begin(corahip_ctx *ctx, const double *T, int rows, co
             if (rc) break;
             DS_TRY(hipEventRecord(ev_emit[sl], B));
             DS_TRY(hipStreamWaitEvent(A, ev_emit[sl], 0));
-            rc = corahip_draw_range(ctx, A, T, rows, info, slot, (size_t)bounds[r], l_first[r], l_first[r + 1] - 1, lmax, F, nu0, nnu,
+            rc = corahip_draw_range(ctx, A, T, rows, info, slot, (size_t)bounds[r], l_first[r], l_first[r + 1] - 1, lmax, F, set,
                                     alm_dev);
             if (rc) break;
             DS_TRY(hipEventRecord(ev_drawn[sl], A));
@@ -147,6 +145,22 @@ int corahip_draw_alm_numpy_begin(corahip_ctx *ctx, const double *T, int rows, co
     // (the last draw waited for the last emit: everything of the generator stream is behind the context stream's tail)
     *pending = pd;
     return 0;
+}
+
+extern "C" {
+
+int corahip_draw_alm_numpy_begin(corahip_ctx *ctx, const double *T, int rows, const int32_t *info, const corahip_rng *rng,
+                                 int lmax, int F, int nu0, int nnu, double *alm_dev, size_t ring_bytes,
+                                 corahip_draw_pending **pending) {
+    ARG_CHECK(nu0 >= 0 && nnu >= 1 && nu0 + nnu <= F);
+    const corahip_chanset set = {1, nnu, {nu0, 0}};
+    return draw_numpy_begin(ctx, T, rows, info, rng, lmax, F, &set, alm_dev, ring_bytes, pending);
+}
+
+int corahip_draw_alm_numpy_begin_set(corahip_ctx *ctx, const double *T_rows, const int32_t *info, const corahip_rng *rng,
+                                     int lmax, int F, const corahip_chanset *set, double *alm_dev, size_t ring_bytes,
+                                     corahip_draw_pending **pending) {
+    return draw_numpy_begin(ctx, T_rows, 1, info, rng, lmax, F, set, alm_dev, ring_bytes, pending);
 }
 
 int corahip_draw_alm_numpy_end(corahip_ctx *ctx, corahip_draw_pending *pd, corahip_rng *rng) {

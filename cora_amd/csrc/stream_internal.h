@@ -9,9 +9,10 @@
 
 // ---- K3 of one range (draw.hip) -----------------------------------------------------------------------------------
 // a_lm of the multipoles l_lo .. l_hi from `gslot`, whose element 0 is element g_off = F l_lo (l_lo + 1) of the
-// stream-order buffer; T full [L, F, F] (rows = 0) or the rank's row block [L, nnu, F] (rows = 1); on `stream`.
+// stream-order buffer; T full [L, F, F] (rows = 0) or the rank's row block [L, nnu, F] (rows = 1) for the channels
+// of `set` (one block, or the two chunks of a folded shard); on `stream`.
 int corahip_draw_range(corahip_ctx *ctx, hipStream_t stream, const double *T, int rows, const int32_t *info, const double *gslot,
-                       size_t g_off, int l_lo, int l_hi, int lmax, int F, int nu0, int nnu, double *alm_dev);
+                       size_t g_off, int l_lo, int l_hi, int lmax, int F, const corahip_chanset *set, double *alm_dev);
 
 // ---- numpy's PCG64 + ziggurat stream in ranges (npnormal.hip) -------------------------------------------------------
 // prepare: seek + count + scan of the whole stream of n normals on `stream` (every block's entry state and first

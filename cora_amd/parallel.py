@@ -18,6 +18,13 @@ a node of MI355X GPUs:
                   ``MPIArray.wrap(sky, axis=0)``).
 
 No reduction exists on this path, so there is no all-reduce.
+
+Channel assignment.  Default: the reference's contiguous split (rank r owns channels [r F / N, (r + 1) F / N)).  The
+draw is the one stage whose cost depends on WHICH channels a rank owns (T_l is lower triangular: channel nu takes
+nu + 1 terms), so the last rank of a contiguous split does (2N - 1) times the MFMA work of the first.  ``fold=True``
+(opt-in: it gives up the contiguous frequency blocks ``MPIArray.wrap(sky, axis=0)`` promises) cuts the channels into
+2 N chunks and gives rank r chunks r and 2 N - 1 - r: every rank then does the same work; ``SkyShard.channels`` is the
+list of global channel indices of the rank's maps, in the order of its buffers.
 """
 from dataclasses import dataclass
 
@@ -30,20 +37,42 @@ class ShardPlan:
     l_hi: int
     l_shard: int   # padded shard length (equal on all ranks, all-gather friendly)
     l_pad: int     # l_shard * world >= L
-    nu0: int       # this rank synthesises channels [nu0, nu0 + nnu)
+    nu0: int       # this rank synthesises channels [nu0, nu0 + nnu) - folded: its first chunk starts at nu0, nnu in total
     nnu: int
     L: int = 0     # total number of multipoles (lmax + 1)
+    chunks: tuple = ()   # ((first channel, count), ...): one block, or the two chunks of a folded shard
 
 
-def shard_plan(L, F, rank, world):
-    """Contiguous, balanced l and channel ranges (cost per l and per channel is uniform)."""
+def fold_chunks(F, rank, world):
+    """The two chunks (first channel, count) of rank ``rank`` under the folded assignment: chunks r and 2 N - 1 - r of
+    2 N equal chunks.  Needs F divisible by 8 N (whole a_lm cells of four channels per chunk)."""
+    if F % (2 * world) or (F // (2 * world)) % 4:
+        raise ValueError("fold=True needs F divisible by 8 * world (F = %d, world = %d)" % (F, world))
+    c = F // (2 * world)
+    return ((rank * c, c), ((2 * world - 1 - rank) * c, c))
+
+
+def fold_permutation(F, world):
+    """Global channel index of every row of the rank-major, local-order arrangement of the folded split: rows
+    [q F / N, (q + 1) F / N) are rank q's channels (its low chunk, then its high chunk)."""
+    import numpy as np
+
+    return np.concatenate([np.arange(a, a + n) for q in range(world) for a, n in fold_chunks(F, q, world)])
+
+
+def shard_plan(L, F, rank, world, fold=False):
+    """Contiguous, balanced l ranges and the rank's channels: the reference's contiguous block (cost per l and per
+    channel is uniform except in the draw), or with ``fold`` the two chunks of :func:`fold_chunks`."""
     l_shard = (L + world - 1) // world
     l_lo = min(rank * l_shard, L)
     l_hi = min(l_lo + l_shard, L)
+    if fold and world > 1:
+        ch = fold_chunks(F, rank, world)
+        return ShardPlan(rank, world, l_lo, l_hi, l_shard, l_shard * world, ch[0][0], 2 * ch[0][1], L, ch)
     base, extra = divmod(F, world)
     nnu = base + (1 if rank < extra else 0)
     nu0 = rank * base + min(rank, extra)
-    return ShardPlan(rank, world, l_lo, l_hi, l_shard, l_shard * world, nu0, nnu, L)
+    return ShardPlan(rank, world, l_lo, l_hi, l_shard, l_shard * world, nu0, nnu, L, ((nu0, nnu),))
 
 
 def allgather_factors(T_local, info_local, plan):
@@ -141,13 +170,16 @@ def exchange_factor_rows(T_local, info_local, plan):
     """l-sharded factors [l_hi - l_lo, F, F] -> (T_rows [L, nnu, F], info [L]): every rank ends up with the
     rows of ALL T_l that its own channels need.  Requires F % world == 0 (equal row blocks).  The pack / unpack
     around the all-to-all are the C entry points a caput / mpi4py caller would use (include/corahip.h,
-    INTEGRATION.md section 3)."""
+    INTEGRATION.md section 3).  A folded plan (two chunks per rank) first brings the rows into rank-major order."""
     import torch
     import torch.distributed as dist
 
     F = T_local.shape[1]
     W = plan.world
     assert F % W == 0 and plan.nnu == F // W
+    if len(plan.chunks) > 1:
+        perm = torch.as_tensor(fold_permutation(F, W), device=T_local.device)
+        T_local = T_local.index_select(1, perm)
     n = plan.l_hi - plan.l_lo
     pad_i = torch.zeros((plan.l_shard,), dtype=info_local.dtype, device=info_local.device)
     pad_i[:n].copy_(info_local)
@@ -228,11 +260,14 @@ class SkyShard:
     freq  : all F channel centres (MHz);  zromb : Romberg order of the channel average (``oversample``)
     distributed : run the exchanges (default: world > 1);  emulate_world : measurement hook - do the work of the most
         loaded rank of an ``emulate_world``-rank job on this GPU without any communication (K1: last pair shard,
-        K2: rank 0's multipoles on random SPD blocks, K3-K5: the last channel shard, factors those of a random SPD stack).
+        K2: rank 0's multipoles on random SPD blocks, K3-K5: the last channel shard, factors those of a random SPD stack);
+        ``emulate_rank``: the channel shard of THAT rank instead of the last one (bench.py times every rank in turn).
+    fold : the folded channel assignment (module docstring): this rank owns chunks r and 2 N - 1 - r of 2 N; its maps
+        are the channels ``self.channels`` (global indices, buffer order).  Ignored for one rank.
     """
 
     def __init__(self, model, freq, nside, lmax, zromb=3, rank=0, world=1, ctx=None, distributed=None, emulate_world=0,
-                 alm_buf=None, maps_buf=None):
+                 alm_buf=None, maps_buf=None, fold=False, emulate_rank=None):
         import numpy as np
 
         from . import _lib
@@ -247,14 +282,19 @@ class SkyShard:
         self.distributed = (world > 1) if distributed is None else bool(distributed)
         self.emulate_world = int(emulate_world)
         L = self.L
-        self.plan = shard_plan(L, F, rank, world)
+        self.fold = bool(fold)
+        self.plan = shard_plan(L, F, rank, world, fold=self.fold)
         if self.emulate_world > 1:
             N = self.emulate_world
-            self.plan = shard_plan(L, F, N - 1, N)
+            er = N - 1 if emulate_rank is None else int(emulate_rank)
+            self.plan = shard_plan(L, F, er, N, fold=self.fold)
             p0 = shard_plan(L, F, 0, N)
             self.plan.l_lo, self.plan.l_hi = p0.l_lo, p0.l_hi
         sp = self.plan
         self.nu0, self.nnu = sp.nu0, sp.nnu
+        self.chunks = tuple(sp.chunks)
+        self.folded = len(self.chunks) > 1
+        self.channels = np.concatenate([np.arange(a, a + n) for a, n in self.chunks])   # global index of every map of this rank
         self.zint = zint = 2**zromb + 1 if zromb else 1
         # channel half-width exactly as skysim.clarray takes it: from the two smallest sorted frequencies (skysim.py:41-45)
         fsort = np.sort(self.freq)
@@ -270,6 +310,8 @@ class SkyShard:
         nshard = max(world, self.emulate_world, 1)
         self.pair_sharded = (cplan["kind"] == "table21cm" and (self.distributed or self.emulate_world > 1)
                              and F % nshard == 0)
+        if self.folded and not (self.pair_sharded or cplan["kind"] != "table21cm"):
+            raise ValueError("fold=True needs the row-block exchange (F divisible by the number of ranks)")
         larr = np.arange(L, dtype=np.float64)
         if cplan["kind"] == "table21cm":
             p = cplan["prepare"](ctx, za)
@@ -302,7 +344,7 @@ class SkyShard:
             for l0 in range(0, L, lc):
                 Cc = ctx.empty((min(lc, L - l0), F, F)).normal_()
                 Tc, ic = ctx.factor_batched(Cc @ Cc.transpose(1, 2) + eye)
-                Tf[l0:l0 + Tc.shape[0]].copy_(Tc[:, self.nu0:self.nu0 + self.nnu, :] if rows else Tc)
+                Tf[l0:l0 + Tc.shape[0]].copy_(Tc[:, self._chan_index(), :] if rows else Tc)
                 inf[l0:l0 + Tc.shape[0]].copy_(ic)
                 del Cc, Tc, ic
             self._emulated = (Tf, inf, rows)
@@ -314,6 +356,14 @@ class SkyShard:
                 Cc = ctx.empty((min(lc, nl0 - l0), F, F)).normal_()
                 self._emu_C[l0:l0 + Cc.shape[0]].copy_(Cc @ Cc.transpose(1, 2) + eye)
                 del Cc
+
+    def _chan_index(self):
+        """Device index tensor of this rank's channels (cached)."""
+        import torch
+
+        if getattr(self, "_chan_idx", None) is None:
+            self._chan_idx = torch.as_tensor(self.channels, device=self.ctx.device)
+        return self._chan_idx
 
     # -- K1 in its two shardings -----------------------------------------------------------
     def _clarray_local(self):
@@ -336,7 +386,7 @@ class SkyShard:
         one = torch.ones((1,), dtype=torch.float64, device=ctx.device)
         bbar = ctx.clarray_separable(one, self._sep[1], self.F, self.zint, self.w)          # channel-averaged B [1, F, F]
         tb, ib = ctx.factor_batched(bbar)
-        rows = tb[0, self.nu0:self.nu0 + self.nnu, :]
+        rows = tb[0].index_select(0, self._chan_index())
         T = torch.sqrt(self._sep[2])[:, None, None] * rows[None, :, :]                       # [L, nnu, F]
         info = ib.expand(self.L).contiguous()
         return T.contiguous(), info, True
@@ -373,7 +423,7 @@ class SkyShard:
             Tr, ia = exchange_factor_rows(T, info, sp)
             return Tr, ia, True
         Ta, ia = allgather_factors(T, info, sp)
-        return Ta, ia, False
+        return Ta, ia, False          # (never folded: fold_chunks needs F divisible by 8 N)
 
     def factors(self):
         """(T, info, rows): the factors this rank's draw needs; ``rows`` tells whether T holds only the rank's row
@@ -409,6 +459,8 @@ class SkyShard:
         ctx = self.ctx
         out = self.alm_buf if out is None else out
         T, info, rows = factors if factors is not None else self.factors()
+        if rows and self.folded:
+            return ctx.draw_alm_philox_chunks(T, info, seed, self.lmax, self.F, self.chunks, out=out)
         if rows:
             return ctx.draw_alm_philox_rows(T, info, seed, self.lmax, self.F, self.nu0, self.nnu, out=out)
         return ctx.draw_alm_philox(T, info, seed, self.lmax, self.F, nu0=self.nu0, nnu=self.nnu, out=out)
@@ -437,7 +489,8 @@ class SkyShard:
 
         T, info, rows = factors if factors is not None else self.factors()
         return skysim.draw_numpy_stream(self.ctx, T, info, rng, self.lmax, self.F, nu0=self.nu0, nnu=self.nnu,
-                                        out=self.alm_buf if out is None else out, rows=rows, defer=defer)
+                                        out=self.alm_buf if out is None else out, rows=rows, defer=defer,
+                                        chunks=self.chunks if (rows and self.folded) else None)
 
 
 class SkySum:
@@ -465,7 +518,7 @@ class SkySum:
     _SEED_STRIDE = 0x9E3779B97F4A7C15      # component k draws with seed + k * stride (mod 2^64): disjoint Philox keys
 
     def __init__(self, components, freq, nside, lmax, rank=0, world=1, ctx=None, distributed=None, emulate_world=0,
-                 mode="joint"):
+                 mode="joint", fold=False, emulate_rank=None):
         from . import _lib
 
         if mode not in ("joint", "separate"):
@@ -476,12 +529,14 @@ class SkySum:
         alm_buf = maps_buf = None
         for model, zromb in components:
             sh = SkyShard(model, freq, nside, lmax, zromb=zromb, rank=rank, world=world, ctx=self.ctx,
-                          distributed=distributed, emulate_world=emulate_world, alm_buf=alm_buf, maps_buf=maps_buf)
+                          distributed=distributed, emulate_world=emulate_world, alm_buf=alm_buf, maps_buf=maps_buf,
+                          fold=fold, emulate_rank=emulate_rank)
             alm_buf, maps_buf = sh.alm_buf, sh.maps_buf
             self.shards.append(sh)
         s0 = self.shards[0]
         self.alm_buf, self.maps_buf = alm_buf, maps_buf
         self.nu0, self.nnu, self.F, self.nside, self.lmax, self.npix = s0.nu0, s0.nnu, s0.F, s0.nside, s0.lmax, s0.npix
+        self.channels, self.chunks, self.folded = s0.channels, s0.chunks, s0.folded
         self._tmp = self.ctx.empty(tuple(alm_buf.shape)) if (len(self.shards) > 1 and mode == "separate") else None
 
     def covariance_shard(self):
@@ -558,19 +613,21 @@ class SkySum:
             finish()
 
 
-def getsky_shard(sky, seed, rank=0, world=1, lmax=None):
+def getsky_shard(sky, seed, rank=0, world=1, lmax=None, fold=False):
     """``Sky3d.getsky()`` for one rank of ``world`` GPUs: (maps [nnu, npix] device tensor, nu0) for a cora_amd
     Gaussian model instance ``sky`` (frequencies, nside, oversample taken from it; lmax default 3 nside - 1 as
-    maps.py:230).  The process group must be initialised when world > 1."""
+    maps.py:230).  The process group must be initialised when world > 1.  ``fold``: the folded channel assignment -
+    the second return value is then the array of global channel indices of the maps."""
     lmax = 3 * sky.nside - 1 if lmax is None else lmax
     zromb = getattr(sky, "oversample", 3)
     import numpy as np
 
-    shard = SkyShard(sky, sky.nu_pixels, sky.nside, lmax, zromb=zromb if zromb is not None else 3, rank=rank, world=world)
+    shard = SkyShard(sky, sky.nu_pixels, sky.nside, lmax, zromb=zromb if zromb is not None else 3, rank=rank, world=world,
+                     fold=fold)
     maps = shard.realise(int(seed))
-    freq = np.asarray(sky.nu_pixels, dtype=np.float64)[shard.nu0:shard.nu0 + shard.nnu]
+    freq = np.asarray(sky.nu_pixels, dtype=np.float64)[shard.channels]
     mean = shard.ctx.to_device(np.asarray(sky.mean_nu(freq), dtype=np.float64) * np.ones(shard.nnu))
-    return maps + mean[:, None], shard.nu0
+    return maps + mean[:, None], (shard.channels if shard.folded else shard.nu0)
 
 
 def mkfullsky_sharded(corr_local, global_shape, nside, rng=None, alms=False, ctx=None):

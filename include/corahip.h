@@ -32,7 +32,7 @@ extern "C" {
 #endif
 
 #define CORAHIP_ABI_VERSION 1
-#define CORAHIP_ABI_MINOR 3      /* additions since version 1: 1 = normals_pcg64, pcg64_advance, draw_alm_rows, mkfullsky, mkfullsky_workspace_bytes, abi_minor, normals_mt19937_legacy; 2 = sht_lambda_entry (test hook); 3 = draw_alm_numpy, draw_alm_numpy_begin / _end */
+#define CORAHIP_ABI_MINOR 3      /* additions since version 1: 1 = normals_pcg64, pcg64_advance, draw_alm_rows, mkfullsky, mkfullsky_workspace_bytes, abi_minor, normals_mt19937_legacy; 2 = sht_lambda_entry (test hook); 3 = draw_alm_numpy, draw_alm_numpy_begin / _end, corahip_chanset: draw_alm_philox_rows_set, draw_alm_numpy_begin_set */
 
 #define CORAHIP_EINVAL (-1)   /* bad argument / shape */
 #define CORAHIP_ENOMEM (-2)   /* workspace too small / allocation refused */
@@ -210,6 +210,20 @@ int corahip_draw_alm_philox(corahip_ctx *ctx, const double *T, const int32_t *in
 int corahip_draw_alm_philox_rows(corahip_ctx *ctx, const double *T_rows, const int32_t *info, uint64_t seed,
                                  int lmax, int F, int nu0, int nnu, double *alm_dev);
 
+/* A rank's channels as one block or as the two chunks of a FOLDED frequency shard: local channel c < chunk_nnu is global
+ * channel nu0[0] + c, local channel chunk_nnu + c is nu0[1] + c (nchunks = 2; nu0[1] >= nu0[0] + chunk_nnu; chunk_nnu a
+ * multiple of 4; F even).  The draw's cost grows with the channel index (T_l is lower triangular: channel nu takes nu + 1
+ * terms), so a frequency shard made of a low and a high chunk - rank r of N takes chunks r and 2 N - 1 - r of 2 N - costs
+ * every rank the same (cora_amd.parallel, `fold=True`; the reference's contiguous split, cora/core/skysim.py:132-134,
+ * stays the default).  T_rows [lmax+1, nchunks * chunk_nnu, F] holds the rows of the local channels in local order;
+ * alm_dev and the maps made from it are in local order too. */
+typedef struct corahip_chanset {
+    int32_t nchunks, chunk_nnu;
+    int32_t nu0[2];
+} corahip_chanset;
+int corahip_draw_alm_philox_rows_set(corahip_ctx *ctx, const double *T_rows, const int32_t *info, uint64_t seed,
+                                     int lmax, int F, const corahip_chanset *set, double *alm_dev);
+
 /* ---- the whole of skysim.mkfullsky in one call (cora/core/skysim.py:72-136, single process) --------------------
  * C [L, F, F] (device; L = lmax + 1 of `plan`) -> maps of channels nu0 .. nu0+nnu-1: jitter + root per l (:115-119),
  * complex normals (:120), a_lm = T_l g_l (:121), HEALPix synthesis (:130).  A chain of the entry points above
@@ -267,6 +281,10 @@ int corahip_draw_alm_numpy_begin(corahip_ctx *ctx, const double *T, int rows, co
                                  int lmax, int F, int nu0, int nnu, double *alm_dev, size_t ring_bytes,
                                  corahip_draw_pending **pending);
 int corahip_draw_alm_numpy_end(corahip_ctx *ctx, corahip_draw_pending *pending, corahip_rng *host_rng);
+/* _begin for a channel set (the struct above; T_rows = the row block of its channels) */
+int corahip_draw_alm_numpy_begin_set(corahip_ctx *ctx, const double *T_rows, const int32_t *info, const corahip_rng *host_rng,
+                                     int lmax, int F, const corahip_chanset *set, double *alm_dev, size_t ring_bytes,
+                                     corahip_draw_pending **pending);
 
 /* ---- frequency sharding for callers that pass the messages themselves -----------------------------
  * The reference distributes this path with caput.mpiarray over MPI (cora/core/skysim.py:97-110: C_l and the a_lm

@@ -49,6 +49,21 @@ def test_bench_launches_its_own_ranks(workload):
     assert len(s1) == 2 and s1 == s2, (s1, s2)
 
 
+@pytest.mark.parametrize("workload,world", [("tiny32", 2), ("tiny32", 4), ("tiny32s", 2)])
+def test_folded_channel_assignment_reproduces_the_single_rank_realisation(workload, world):
+    """bench.py --fold: rank r owns chunks r and 2N-1-r of 2N (the draw's triangular work balanced over the ranks).
+    The union of the folded shards - Philox stream, the reference's seeded stream and its rng=None stream - equals the
+    single-rank realisation: per-channel statistics and every pixel (sha1) of every channel."""
+    common = ["--workload", workload, "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--checksum"]
+    one, c1 = _bench(common)
+    s1 = _bench.seeded
+    two, c2 = _bench(["--gpus", str(world), "--dist-backend", "gloo", "--same-device", "--fold"] + common)
+    s2 = _bench.seeded
+    assert two["ranks_seen"] == world and "folded" in two["config"]["channel_assignment"]
+    assert c1 is not None and c1 == c2, (c1, c2)
+    assert len(s1) == 2 and s1 == s2, (s1, s2)
+
+
 def test_mkfullsky_l_distributed_mpiarray():
     """skysim.mkfullsky(MPIArray-like l-distributed corr): 2 and 3 ranks (uneven l blocks, F = 8 and 7) return the
     frequency shards of the single-process realisation (DeviceRNG and identically seeded numpy Generators)."""

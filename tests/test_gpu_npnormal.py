@@ -111,11 +111,13 @@ def test_reference_golden_alm_with_the_device_stream(ctx, golden, monkeypatch, k
 
 
 @pytest.mark.parametrize("F,lmax,nu0,nnu", [(8, 40, 0, 8), (24, 70, 0, 24), (72, 150, 0, 72), (136, 260, 0, 136),
-                                            (256, 300, 64, 64), (256, 300, 192, 64), (40, 90, 8, 16), (264, 140, 0, 264)])
+                                            (256, 300, 64, 64), (256, 300, 192, 64), (40, 90, 8, 16), (264, 140, 0, 264),
+                                            (256, 300, 112, 16), (256, 300, 240, 16)])
 def test_draw_from_stream_buffer_matches_numpy(ctx, F, lmax, nu0, nnu, monkeypatch):
     """K3 with its normals read from a stream-order buffer (the persistent MFMA kernel's FROMG mode; every tile width, a
     frequency shard, lower-triangular and dense factors, row-block factors) against numpy's T_l g_l, and against the
-    generic kernel of round 1."""
+    generic kernel of round 1.  (The 16-channel shards past channel 64: three or more chunks of nu' with the 16-column
+    shape, where half of the waves stage nothing - their counted wait let an operand load through until round 5.)"""
     import torch
 
     rs = np.random.default_rng(F * 1000 + lmax)
@@ -334,3 +336,25 @@ def test_ranged_stream_leaves_generators_where_numpy_does(ctx):
     np.random.seed(4321)
     skysim._host_normals(F, lmax, None)
     assert np.array_equal(after, np.random.random_sample(50))
+
+
+@pytest.mark.parametrize("F,lmax,chunk,r,N", [(64, 120, 8, 1, 4), (256, 200, 16, 0, 8), (256, 200, 16, 7, 8), (512, 90, 32, 3, 8),
+                                              (1024, 40, 64, 2, 8)])
+def test_folded_two_chunk_draw_equals_the_columns_of_the_full_draw(ctx, F, lmax, chunk, r, N):
+    """K3 on the two chunks of a folded frequency shard (corahip_chanset: chunks r and 2N-1-r, row-block factors in
+    local order) = the same channels of the full draw, bit for bit - Philox stream and numpy's stream in l ranges."""
+    import torch
+
+    Td, infod = _factors(ctx, F, lmax, 31 * F + lmax)
+    chunks = [(r * chunk, chunk), ((2 * N - 1 - r) * chunk, chunk)]
+    ch = torch.cat([torch.arange(a, a + n) for a, n in chunks]).to(ctx.device)
+    Trows = Td.index_select(1, ch).contiguous()
+    full = ctx.alm_dev_to_square(ctx.draw_alm_philox(Td, infod, 99, lmax, F), lmax, F)
+    got = ctx.alm_dev_to_square(ctx.draw_alm_philox_chunks(Trows, infod, 99, lmax, F, chunks), lmax, 2 * chunk)
+    assert torch.equal(got, full.index_select(0, ch))
+    rng = np.random.default_rng(F)
+    st = rng.bit_generator.state["state"]
+    fulln, after_full = ctx.draw_alm_numpy(Td, infod, ("pcg64", st["state"], st["inc"]), lmax, F)
+    gotn, after = ctx.draw_alm_numpy(Trows, infod, ("pcg64", st["state"], st["inc"]), lmax, F, chunks=chunks, ring_bytes=1 << 22)
+    assert after == after_full
+    assert torch.equal(ctx.alm_dev_to_square(gotn, lmax, 2 * chunk), ctx.alm_dev_to_square(fulln, lmax, F).index_select(0, ch))

@@ -144,3 +144,74 @@ def test_allgather_channels_gloo(world):
     for p in procs:
         p.join(timeout=60)
     assert sorted(res) == [(r, True) for r in range(world)]
+
+
+# ------------------------------------------------------------------ folded channel assignment (parallel.fold_chunks)
+def test_folded_plan_covers_every_channel_once_and_balances_the_draw():
+    """fold=True: rank r owns chunks r and 2N-1-r of 2N; every channel exactly once, every rank the same number of
+    triangular terms sum(nu + 1) - the draw's cost - where the contiguous split gives the last rank (2N-1) x the first."""
+    from cora_amd.parallel import fold_chunks, fold_permutation, shard_plan
+
+    for F, world in ((256, 8), (512, 8), (1024, 8), (32, 2), (64, 4)):
+        seen = np.zeros(F, int)
+        work = []
+        for r in range(world):
+            p = shard_plan(100, F, r, world, fold=True)
+            assert p.chunks == fold_chunks(F, r, world) and p.nnu == F // world and p.nu0 == p.chunks[0][0]
+            ch = np.concatenate([np.arange(a, a + n) for a, n in p.chunks])
+            seen[ch] += 1
+            work.append(int((ch + 1).sum()))
+        assert np.all(seen == 1) and len(set(work)) == 1, work
+        perm = fold_permutation(F, world)
+        assert sorted(perm) == list(range(F))
+        contiguous = [int((np.arange(r * F // world, (r + 1) * F // world) + 1).sum()) for r in range(world)]
+        assert max(contiguous) > work[0] > min(contiguous) and work[0] * world == sum(contiguous)    # (the mean)
+        if world == 8:
+            assert max(contiguous) > 1.8 * work[0]
+    with pytest.raises(ValueError):
+        fold_chunks(100, 0, 8)
+    # one rank: nothing to fold
+    assert shard_plan(10, 16, 0, 1, fold=True).chunks == ((0, 16),)
+
+
+def _worker_fold(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+
+    sys.path.insert(0, ROOT)
+    from cora_amd.parallel import exchange_factor_rows, shard_plan
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    L, F = 13, 8 * world
+    p = shard_plan(L, F, rank, world, fold=True)
+    full = torch.arange(L * F * F, dtype=torch.float64).reshape(L, F, F)
+    info_full = (torch.arange(L) % 2).to(torch.int32)
+    Tr, info = exchange_factor_rows(full[p.l_lo:p.l_hi].clone(), info_full[p.l_lo:p.l_hi].clone(), p)
+    ch = torch.cat([torch.arange(a, a + n) for a, n in p.chunks])
+    ok = bool(torch.equal(Tr, full[:, ch, :]) and torch.equal(info, info_full))
+    # the union of the ranks' row blocks is every row exactly once
+    got = [None] * world
+    dist.all_gather_object(got, ch.tolist())
+    ok = ok and sorted(c for g in got for c in g) == list(range(F))
+    q.put((rank, ok))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_folded_factor_row_exchange_gloo(world):
+    """The factor row-block all-to-all under the folded assignment: rank r ends up with T_l[its two chunks, :] for
+    every l, in the local order of its buffers; the union over the ranks is the whole stack."""
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 35500 + os.getpid() % 2000 + world
+    procs = [ctx.Process(target=_worker_fold, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(r, True) for r in range(world)]
