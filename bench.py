@@ -329,8 +329,8 @@ def main():
         # the plan counts, from its first-contributing-l tables, the v_mfma_f64_16x16x4_f64 instructions (2048 flop
         # each) this launch issues (corahip_sht_plan_k4_mfma_count - the number SQ_INSTS_VALU_MFMA_F64 reads, checked
         # against the committed PMC profile by tests/test_gpu_fullsize.py).  The algorithmic 8 nside nalm F of SURVEY
-        # 8(d) counts Legendre terms below the plan's 2^-80 cut that nobody has to compute (libsharp, the engine
-        # behind healpy.alm2map, drops them too): it is reported as `algorithmic_tflops`, never as a fraction of peak.
+        # 8(d) counts Legendre terms below the plan's 2^-70 cut that nobody has to compute (pixel error bound
+        # 2 sum |a_lm| 2^-70): it is reported as `algorithmic_tflops`, never as a fraction of peak.
         leg = stages.get("legendre", {"ms_per_launch": float("nan")})
         flops_alg = 8.0 * nside * nalm * nnu           # per launch, SURVEY 8(d) / DESIGN.md
         mfma_insts = ctx.k4_mfma_count(nside, lmax, nnu)
@@ -401,7 +401,7 @@ def main():
                 "traffic_source": traffic_source,
                 "note": "achieved = EXECUTED flops / measured time: 2048 x the FP64 MFMA instructions this launch issues, counted "
                         "in this run from the plan's first-contributing-l tables (= SQ_INSTS_VALU_MFMA_F64); Legendre terms "
-                        "below 2^-80 are skipped (as libsharp does), so the algorithmic count of SURVEY 8(d) is larger",
+                        "below 2^-70 are skipped (pixel error <= 2 sum |a_lm| 2^-70), so the algorithmic count of SURVEY 8(d) is larger",
                 "executed_mfma_instructions_per_launch": mfma_insts,
                 "executed_flops_per_launch": flops_exec,
                 "pmc_mfma_instructions_per_launch": pmc_mfma,

@@ -32,7 +32,7 @@ struct corahip_linefft_plan {
     double2 *rtw = nullptr;    // [n/2 + 1]  e^{+2 pi i k / 2n}: (un)packing of a real transform of length 2n
 };
 
-#define CORAHIP_NSCRATCH 8
+#define CORAHIP_NSCRATCH 10
 struct corahip_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -50,7 +50,8 @@ struct corahip_ctx {
     // grow-only device scratch slots owned by the context (freed by ctx_destroy)
     // slots: 0 K1 transposed tables, 1 K1 pair results / odd-F normal stream, 2 K1 pair list, 3 zeros,
     //        4 Legendre matrix of legendre_project, 5 its zero-padded operand, 6 block tables of normals_pcg64 /
-    //        segment tables of normals_mt19937_legacy, 7 the two-slot ring of the l-range pipeline (drawstream.hip)
+    //        segment tables of normals_mt19937_legacy, 7 the two-slot ring of the l-range pipeline (drawstream.hip),
+    //        8 barrier words of the cooperative Cholesky
     void *scratch[CORAHIP_NSCRATCH] = {};
     size_t scratch_bytes[CORAHIP_NSCRATCH] = {};
     // K1 transposed tables resident in scratch slot 0: valid for the pinned (dd, dv, vv, generation) only

@@ -598,10 +598,13 @@ chol_coop_kernel(const double *__restrict__ C, int F, double jitter_rel, double 
     unsigned nsync = 0;
     bool same_xcc = false;
     // barrier over the G workgroups of this matrix; writes before it are visible behind it.
-    // same_xcc: the stores are in the shared L2 once they are acknowledged (write-through L1), and no CU holds a stale
-    // L1 line of anything read behind the barrier: a tile's lines are read by another CU only after they are final
-    // (the panel solve reads and rewrites a row in ONE thread), and the words that ARE rewritten (1 / diag, the failure
-    // flag, the counter) are read with device-scope atomic loads.
+    // same_xcc: the stores are in the shared L2 once they are acknowledged (write-through L1): no L2 write-back is needed
+    // on the release side.  The acquire side invalidates the CU's vector L1 (buffer_inv sc1, a few cycles per block
+    // column): a CU that wrote a tile in step A reads it again in a later block column after ANOTHER CU rewrote it in
+    // place in step C - whether the L1 keeps lines it wrote through is not documented, and a stale hit would be a
+    // silently wrong factor (round-4 advice; the LLVM memory model asks for the invalidate on every cross-CU acquire).
+    // The words that are rewritten between barriers (1 / diag, the failure flag, the counter) are read with
+    // device-scope atomic loads.
     auto group_sync = [&]() {
         if (same_xcc) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         else __threadfence();
@@ -609,15 +612,15 @@ chol_coop_kernel(const double *__restrict__ C, int F, double jitter_rel, double 
         nsync++;
         if (tid == 0) {
             __hip_atomic_fetch_add(&bar[mi], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            // (bounded: if a workgroup of the group never arrives - the grid was not co-resident after all - the group
-            //  gives up after ~2^25 polls, a few seconds, and reports the matrix as failed: it then takes the eigen route
-            //  like any block the Cholesky rejects, instead of hanging the device)
+            // (bounded: if a workgroup of the group never arrives - the grid was not co-resident after all: another
+            //  stream or process held the CUs - the group gives up after 2^21 polls, a few seconds, and reports the
+            //  matrix with info = 3: the host then factors it with the one-workgroup kernel, instead of hanging the device)
             unsigned polls = 0;
             while (__hip_atomic_load(&bar[mi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nsync * (unsigned)G) {
                 __builtin_amdgcn_s_sleep(2);
                 if ((++polls & 1023u) == 0) {
                     if (__hip_atomic_load(&gflag[mi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 3) break;
-                    if (polls >= (1u << 25)) {
+                    if (polls >= (1u << 21)) {
                         __hip_atomic_store(&gflag[mi], 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         break;
                     }
@@ -625,7 +628,8 @@ chol_coop_kernel(const double *__restrict__ C, int F, double jitter_rel, double 
             }
         }
         __syncthreads();
-        if (!same_xcc) __threadfence();
+        if (same_xcc) asm volatile("buffer_inv sc1" ::: "memory");
+        else __threadfence();
     };
     {
         const int xcc = (int)__builtin_amdgcn_s_getreg((3 << 11) | 20) & 15;     // HW_REG_XCC_ID, bits 3:0
@@ -988,6 +992,16 @@ extern "C" int corahip_factor_batched(corahip_ctx *ctx, const double *C, int nl,
             if (nl > slots && r > 0 && ((r + 7) / 8) * 8 * G <= ctx->num_cu && r <= 16) nrem = r;
             if (coop_env && atoi(coop_env) == 2 && ((nl + 7) / 8) * 8 * G <= ctx->num_cu) nrem = nl;     // (tests: every matrix through the cooperative kernel)
         }
+        const size_t shm2 = sizeof(double) * (CH_NB * (CH_NB + 1) + 256 + 2 + CH_NB + 8 * 32 * CHM_S) + 16;
+        if (nrem > 0) {
+            // the cooperative grid spins on barriers between its workgroups: it must be co-resident.  The occupancy
+            // calculation covers this kernel's own resources (what else holds CUs at launch time it cannot know: the
+            // barrier is bounded for that case); a grid that does not fit goes through the batch kernel
+            HIP_TRY(hipFuncSetAttribute((const void *)chol_coop_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm2));
+            int per_cu = 0;
+            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)chol_coop_kernel, 256, shm2));
+            if ((long)per_cu * ctx->num_cu < (long)((nrem + 7) / 8) * 8 * G) nrem = 0;
+        }
         const int nmain = nl - nrem;
         if (tall) {
             HIP_TRY(hipFuncSetAttribute((const void *)chol_ll_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
@@ -995,7 +1009,7 @@ extern "C" int corahip_factor_batched(corahip_ctx *ctx, const double *C, int nl,
             if (nrem > 0) {
                 void *ws = nullptr;
                 const size_t wsb = (size_t)nrem * (sizeof(unsigned) + 3 * sizeof(int) + CH_NB * sizeof(double)) + 64;
-                int rcs = corahip_ctx_scratch(ctx, 7, wsb, &ws);
+                int rcs = corahip_ctx_scratch(ctx, 8, wsb, &ws);
                 if (rcs) return rcs;
                 HIP_TRY(hipMemsetAsync(ws, 0, wsb, ctx->stream));
                 double *rd = reinterpret_cast<double *>(ws);
@@ -1003,8 +1017,6 @@ extern "C" int corahip_factor_batched(corahip_ctx *ctx, const double *C, int nl,
                 int *gflag = reinterpret_cast<int *>(bar + nrem);
                 int *xmin = gflag + nrem, *xmax = xmin + nrem;
                 HIP_TRY(hipMemsetAsync(xmin, 0x7f, sizeof(int) * nrem, ctx->stream));   // (min starts high; max at 0)
-                const size_t shm2 = sizeof(double) * (CH_NB * (CH_NB + 1) + 256 + 2 + CH_NB + 8 * 32 * CHM_S) + 16;
-                HIP_TRY(hipFuncSetAttribute((const void *)chol_coop_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm2));
                 chol_coop_kernel<<<((nrem + 7) / 8) * 8 * G, 256, shm2, ctx->stream>>>(C, F, jitter_rel, T, info, nmain, nrem, G, bar, gflag, rd,
                                                                                      xmin, xmax);
                 if (getenv("CORAHIP_K2_COOP_DEBUG")) {
@@ -1041,6 +1053,22 @@ extern "C" int corahip_factor_batched(corahip_ctx *ctx, const double *C, int nl,
     std::vector<int32_t> hinfo(nl);
     HIP_TRY(hipMemcpyAsync(hinfo.data(), info, sizeof(int32_t) * nl, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    // info = 3: a group of the cooperative kernel could not assemble - the one-workgroup kernel factors that matrix (the
+    // same arithmetic: the reference's Cholesky route, not the eigen route)
+    {
+        bool redo = false;
+        for (int l = 0; l < nl; l++)
+            if (hinfo[l] == 3) {
+                const size_t shm = sizeof(double) * (CH_NB * (CH_NB + 1) + 256 + 2 + CH_NB + 6 * 32 * CHM_S) + 16;
+                chol_ll_kernel<true><<<1, 256, shm, ctx->stream>>>(C + (size_t)l * F * F, F, jitter_rel, T + (size_t)l * F * F, info + l);
+                LAUNCH_CHECK();
+                redo = true;
+            }
+        if (redo) {
+            HIP_TRY(hipMemcpyAsync(hinfo.data(), info, sizeof(int32_t) * nl, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
+        }
+    }
     std::vector<int32_t> list;
     for (int l = 0; l < nl; l++)
         if (hinfo[l] != 0) list.push_back(l);

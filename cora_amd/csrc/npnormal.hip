@@ -11,6 +11,10 @@
 //                  one raw draw on the fast path (98.5 % of the positions), two for a wedge sample (accepted or
 //                  not), 1 + 2 i for a tail sample.  Tail samples use glibc's log1p restated operation by operation
 //                  (fdlibm's algorithm in glibc's evaluation order, no contraction): bit-identical to numpy on glibc.
+//                  One caveat: the WEDGE test compares against exp(-x^2 / 2) of the device library (<= 1 ulp), not
+//                  glibc's exp; an argument within one ulp of the acceptance threshold could flip an accept and shift
+//                  every later sample (probability ~1e-9 per cfg-3 realisation; never met in 2.4e8 compared samples,
+//                  tests/test_gpu_npnormal.py) - "bit for bit" holds up to that event.
 //
 // "Which raw position starts a sample" is a prefix problem; oracle/npnormal_model.py states the decomposition in python
 // (checked against numpy on the CPU), this is the same thing on the device:

@@ -36,25 +36,25 @@ __device__ static inline void scaled_pow(double s, int n, double &mant, int &ex)
 // Terms of the Legendre sums with |lambda_lm| < 2^SEED_MIN_EXP are dropped (K4 starts its recurrence at the first l
 // that reaches it; K4 neither writes nor K5 reads the F_m cells beyond the per-ring cut-off it implies).  Rounds 2-3: 2^-80 =
 // 8.3e-25: the sum of all 2e6 dropped terms of a channel stays below 2e-18 of an O(1) coefficient, two decades
-// under fp64 rounding; libsharp (the engine behind healpy.alm2map) truncates at m > lmax sin(theta) + max(100, lmax / 100),
-// which corresponds to about 2^-70 at lmax = 2048, i.e. is LOOSER.  The exponent is a PLAN parameter
+// under fp64 rounding.  (SHT engines truncate in the same spirit - libsharp, as the builder recalls it, by an m limit per
+// ring; its source is not in this image and no figure for it is claimed here.)  The exponent is a PLAN parameter
 // (corahip_sht_plan_create_ex, default SEED_MIN_EXP): the error of a pixel is bounded by sum_lm |a_lm| 2^cut, so a
 // caller with a_lm of extreme dynamic range lowers it (-900 = the oracle's "exactly zero").  The first version used 2^-900:
 // with it the rings 513..1023 of nside 1024 kept lmax + 1 > h + 1 cells, so their ring FFT took the aliased
 // (LDS-atomic) fold and read 20-45 % more cells; 2^-120 followed (K4 66.2 -> 58.3 ms), 2^-80 took another 1.1 ms off
 // K4 (56.4 -> 55.3 ms at cfg 3) with no change in any printed digit of the full-size comparisons.  The oracle keeps 2^-900.
-// Round 4: 2^-70 = 8.5e-22, libsharp's own cut - no term the reference's engine keeps is dropped.  tools/cut_probe.py
+// Round 4: 2^-70 = 8.5e-22 - this library's own choice, justified by the bound below and by measurement.  tools/cut_probe.py
 // (cfg 3, unit-variance a_lm, maps against the 2^-900 plan): 2^-120 1.6e-13, 2^-80 3.4e-13, 2^-70 3.6e-13, 2^-60 4.6e-13,
 // 2^-40 4.7e-13 of the rms - all of it the rounding of recurrences started at different rows, none of it truncation (the
 // bound with every dropped term of a pixel adding coherently, sum_lm |a_lm| 2^cut ~ sqrt(nalm) rms 2^-70, is 1e-18 rms at
-// lmax = 2048); K4 52.4 ms at 2^-80, 52.1 at 2^-70, 51.6 at 2^-60, 50.9 at 2^-40: a looser cut than the reference's would
-// buy another 0.5-1.2 ms and is not taken.
+// lmax = 2048); K4 52.4 ms at 2^-80, 52.1 at 2^-70, 51.6 at 2^-60, 50.9 at 2^-40: a looser cut would buy another
+// 0.5-1.2 ms and is not taken.
 #ifndef SEED_MIN_EXP
 #define SEED_MIN_EXP (-70)
 #endif
 
 // lstart[m][r]: first l at which |lambda_lm(ring r)| >= 2^min_exp (the plan's cut, default SEED_MIN_EXP = -70), with
-// the two recurrence values there; terms below (< 8.3e-25 at the default) are dropped (libsharp does the same).
+// the two recurrence values there; terms below (< 8.5e-22 at the default) are dropped.
 __global__ void seed_kernel(int lmax, int npair, int min_exp, const double *__restrict__ z, const double *__restrict__ sth,
                             const double *__restrict__ pref, const double2 *__restrict__ coef,
                             const double2 *__restrict__ coefmu, int32_t *__restrict__ lstart, double2 *__restrict__ seed,

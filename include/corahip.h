@@ -329,8 +329,8 @@ int corahip_alm_packed_to_dev(corahip_ctx *ctx, const double *packed, int lmax, 
 int corahip_sht_plan_create(corahip_ctx *ctx, int nside, int lmax, corahip_sht_plan **plan);
 /* ... with the truncation of the Legendre sums as a parameter: terms with |lambda_lm(theta)| < 2^cut_exp are dropped
  * (-1000 <= cut_exp < 0; 0 = the default, -70).  The error this leaves in a pixel is bounded by
- * 2 sum_lm |a_lm| 2^cut_exp (1.7e-21 per unit coefficient at the default, which is the cut of libsharp, the engine behind
- * healpy.alm2map - cora/util/hputil.py:388-391 -, at lmax = 2048): lower it for a_lm whose
+ * 2 sum_lm |a_lm| 2^cut_exp (1.7e-21 per unit coefficient at the default - the library's own choice; what the engine
+ * behind healpy.alm2map, cora/util/hputil.py:388-391, truncates is not pinned, healpy is absent): lower it for a_lm whose
  * dynamic range exceeds ~1e10; -900 keeps every term fp64 can represent (what the oracle does). */
 int corahip_sht_plan_create_ex(corahip_ctx *ctx, int nside, int lmax, int cut_exp, corahip_sht_plan **plan);
 int corahip_sht_plan_cut_exp(const corahip_sht_plan *plan, int *cut_exp);

@@ -549,3 +549,31 @@ def test_k2_cooperative_kernel_matches_one_workgroup_form(ctx, monkeypatch):
             res = (T1[k] @ T1[k].T - C[k] - jit * torch.eye(F, device=ctx.device, dtype=torch.float64)).abs().amax().item()
             assert res <= 1e-12 * C[k].abs().amax().item(), (F, k, res)
             assert torch.all(torch.triu(T1[k], 1) == 0)
+
+
+@pytest.mark.parametrize("nrem", [1, 7, 16])
+def test_k2_cooperative_kernel_repeats_bit_identically(ctx, monkeypatch, nrem):
+    """Stress of the cooperative Cholesky's same-XCD barrier (round-4 advice: a CU re-reads tiles another CU rewrote in
+    place; since round 5 the acquire side invalidates the vector L1): F = 1024, the straggler counts 1 / 7 / 16 of a
+    cfg-5 rank (L mod 512), every matrix through the cooperative kernel, 25 repetitions - every repetition bit-identical
+    to the first and to the one-workgroup kernel's factor within rounding; a stale line would show as a changed factor."""
+    import torch
+
+    F = 1024
+    A = ctx.empty((nrem, F, F + 8)).normal_()
+    C = A @ A.transpose(1, 2) + 0.1 * torch.eye(F, device=ctx.device, dtype=torch.float64)
+    del A
+    monkeypatch.setenv("CORAHIP_K2_COOP", "0")
+    T0, i0 = ctx.factor_batched(C)
+    T0 = T0.clone()
+    monkeypatch.setenv("CORAHIP_K2_COOP", "2")
+    first = None
+    for rep in range(25):
+        T1, i1 = ctx.factor_batched(C)
+        assert int(i1.abs().max().item()) == 0
+        if first is None:
+            first = T1.clone()
+            assert (first - T0).abs().amax().item() <= 1e-13 * T0.abs().amax().item()
+        else:
+            assert torch.equal(T1, first), rep
+    monkeypatch.delenv("CORAHIP_K2_COOP")

@@ -974,6 +974,33 @@ def test_makesky_cli_21cm_and_gaussianfg(tmp_path):
     del galaxy
 
 
+# ------------------------------------------------------------------ the healpy boundary itself, where healpy exists
+def test_healpy_cross_check_when_available(ctx):
+    """healpy is absent from this image and from the GPU boxes of the pool (the one boundary no reference
+    output pins).  On a box that HAS it this test lights up: the synthesis against ``healpy.alm2map`` - what
+    hputil.sphtrans_inv_real calls (cora/util/hputil.py:388-391) - at nside 64 / lmax 128, and the analysis against
+    ``healpy.map2alm(use_weights=True, iter=2)`` (cora/util/hputil.py:228-230), whose ring weights come from healpy's
+    data files where this library restates them by their defining property."""
+    hp = pytest.importorskip("healpy")
+    from cora_amd.util import hputil
+
+    nside, lmax = 64, 128
+    L = lmax + 1
+    rng = np.random.default_rng(64128)
+    alm = np.zeros((L, L), dtype=np.complex128)
+    for l in range(L):
+        alm[l, : l + 1] = (rng.standard_normal(l + 1) + 1j * rng.standard_normal(l + 1)) / (1.0 + l)
+    alm[:, 0] = alm[:, 0].real
+    got = hputil.sphtrans_inv_real(alm, nside)
+    ref = hp.alm2map(hputil.pack_alm(alm), nside, lmax=lmax, pol=False)
+    assert np.abs(got - ref).max() <= 1e-11 * ref.std()
+    back = hputil.sphtrans_real(ref, lmax=lmax)
+    ref_alm = hp.map2alm(ref, lmax=lmax, use_weights=True, iter=2)
+    ref2d = hputil.unpack_alm(ref_alm, lmax)
+    # (the restated ring weights equal healpy's file weights only approximately: the documented unpinned piece)
+    assert np.abs(back - ref2d).max() <= 1e-6 * np.abs(ref2d).max()
+
+
 # ------------------------------------------------------------------ EoR21cm (cora/signal/corr21cm.py:333-385)
 @pytest.fixture(scope="module")
 def eor_golden():
