@@ -2,6 +2,9 @@
 // deterministic reduction over ring tiles.  See sht_internal.h.
 #include "sht_internal.h"
 
+#ifndef ADJ_MU
+#define ADJ_MU 1         // 1: scaled two-instruction recurrence (mu form), scale applied per output row; 0: (A, B) form (A/B builds)
+#endif
 #ifndef ADJ_CUNROLL
 #define ADJ_CUNROLL 8    // recurrence steps whose (scalar-loaded) coefficients are fetched together; measured 8 / 16 / 32: 25.1 / 26.9 / 25.5 ms
 #endif
@@ -15,6 +18,9 @@
 // different rings, so their [32 l x 16 NCT] partial sums are added through LDS once per l-block; the four
 // ring tiles of an (m, column group) go to separate partial buffers summed by alm_reduce_kernel
 // (deterministic - no atomics).
+// Round 5: the recurrence runs in the synthesis kernel's scaled two-instruction form mu_l = (alpha_l x) mu_{l-1} - mu_{l-2}
+// (plan tables coefmu / seedmu); lambda_l = s_l mu_l with s_l the same for every ring, so the MFMAs contract mu and the scale
+// is applied once per OUTPUT row where the eight waves' partial tiles are added: one DP multiply less per recurrence step.
 template <int NCT>
 __global__ void __launch_bounds__(512)
 legendre_adj_kernel(int lmax, int npair, int nring, int ncols, const double *__restrict__ z,
@@ -111,7 +117,11 @@ legendre_adj_kernel(int lmax, int npair, int nring, int ncols, const double *__r
                     for (int j = 0; j < LB; j++) {
                         const int l = lb + j;
                         const double2 c = cf[l];
+#if ADJ_MU
+                        double vv = fma(c.x * x, p1, -p0);
+#else
                         double vv = fma(c.x * x, p1, -(c.y * p0));
+#endif
                         const bool inj = (l == my_ls);
                         vv = inj ? sd.y : vv;
                         p0 = inj ? sd.x : p1;
@@ -122,7 +132,11 @@ legendre_adj_kernel(int lmax, int npair, int nring, int ncols, const double *__r
 #pragma unroll ADJ_CUNROLL
                     for (int j = 0; j < LB; j++) {
                         const double2 c = cf[lb + j];
+#if ADJ_MU
+                        const double vv = fma(c.x * x, p1, -p0);
+#else
                         const double vv = fma(c.x * x, p1, -(c.y * p0));
+#endif
                         p0 = p1;
                         p1 = vv;
                         lamw[lane * LSTR + (j & 1) * 16 + (j >> 1)] = vv;
@@ -170,6 +184,17 @@ legendre_adj_kernel(int lmax, int npair, int nring, int ncols, const double *__r
             // transpose buffer exactly)
             for (int lb = lb0; lb <= lmax; lb += 2 * LB) {
                 d4_t acc0[2][NCT], acc1[2][NCT];
+#if ADJ_MU
+                // the row scales s_l of this thread's outputs of the reduction below, requested now: behind the barrier
+                // their latency would be exposed to the whole workgroup
+                double srow[2 * NCT];
+#pragma unroll
+                for (int u = 0; u < 2 * NCT; u++) {
+                    const int e = tid + 512 * u;
+                    const int el = e & 63, r = (e >> 6) & 3, q = e >> 8, par = (q / NCT) & 1, blk = q / (2 * NCT);
+                    srow[u] = cf[lb + blk * LB + 2 * ((el >> 4) + 4 * r) + par].y;      // (the table is padded: rows past lmax read zeros)
+                }
+#endif
 #pragma unroll
                 for (int par = 0; par < 2; par++)
 #pragma unroll
@@ -198,7 +223,11 @@ legendre_adj_kernel(int lmax, int npair, int nring, int ncols, const double *__r
                     for (int w = 0; w < ADJ_WAVES; w++) sum += lds[w * WREG + e];
                     const int el = e & 63, r = (e >> 6) & 3, q = e >> 8, t = q % NCT, par = (q / NCT) & 1, blk = q / (2 * NCT);
                     const int l = lb + blk * LB + 2 * ((el >> 4) + 4 * r) + par;
+#if ADJ_MU
+                    if (l <= lmax) pout[(size_t)l * ncols + 16 * t + (el & 15)] = sum * srow[u];    // lambda_l = s_l mu_l: the scale is a property of the ROW
+#else
                     if (l <= lmax) pout[(size_t)l * ncols + 16 * t + (el & 15)] = sum;
+#endif
                 }
                 __syncthreads();
             }
@@ -227,8 +256,9 @@ static int launch_legendre_adj(corahip_ctx *ctx, const corahip_sht_plan *p, int 
     const long nitems = (long)p->L * (ncols / (16 * NCT)) * ntile;
     dim3 grid((unsigned)std::min<long>(nitems, (long)ctx->num_cu));
     HIP_TRY(hipMemsetAsync(p->d_queue, 0, 64, ctx->stream));
-    legendre_adj_kernel<NCT><<<grid, 512, shm, ctx->stream>>>(p->lmax, p->npair, p->nring, ncols, p->d_z, p->d_coef,
-                                                             p->d_lstart, p->d_seed, p->d_lmin, p->d_mcut, inter, part,
+    legendre_adj_kernel<NCT><<<grid, 512, shm, ctx->stream>>>(p->lmax, p->npair, p->nring, ncols, p->d_z,
+                                                             ADJ_MU ? p->d_coefmu : p->d_coef, p->d_lstart,
+                                                             ADJ_MU ? p->d_seedmu : p->d_seed, p->d_lmin, p->d_mcut, inter, part,
                                                              p->d_queue);
     LAUNCH_CHECK();
     return 0;
