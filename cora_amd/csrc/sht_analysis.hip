@@ -18,6 +18,10 @@
 // different rings, so their [32 l x 16 NCT] partial sums are added through LDS once per l-block; the four
 // ring tiles of an (m, column group) go to separate partial buffers summed by alm_reduce_kernel
 // (deterministic - no atomics).
+// Round 5, tried and withdrawn: ONE workgroup walking the four ring tiles of its (m, column group) and adding the later
+// tiles' sums onto its own earlier stores (no partial buffers, no alm_reduce_kernel: 1.9 of 21 ms).  Correct, but the
+// kernel sits at 256 VGPRs (128 of them the G tile) and the restructured loop made the allocator spill B operands into
+// the MFMA loop (scratch 28 -> 450-520 bytes): 20.96 ms against 21.05, a single l block per reduction 24.5 ms.
 // Round 5: the recurrence runs in the synthesis kernel's scaled two-instruction form mu_l = (alpha_l x) mu_{l-1} - mu_{l-2}
 // (plan tables coefmu / seedmu); lambda_l = s_l mu_l with s_l the same for every ring, so the MFMAs contract mu and the scale
 // is applied once per OUTPUT row where the eight waves' partial tiles are added: one DP multiply less per recurrence step.
@@ -192,7 +196,7 @@ legendre_adj_kernel(int lmax, int npair, int nring, int ncols, const double *__r
                 for (int u = 0; u < 2 * NCT; u++) {
                     const int e = tid + 512 * u;
                     const int el = e & 63, r = (e >> 6) & 3, q = e >> 8, par = (q / NCT) & 1, blk = q / (2 * NCT);
-                    srow[u] = cf[lb + blk * LB + 2 * ((el >> 4) + 4 * r) + par].y;      // (the table is padded: rows past lmax read zeros)
+                    srow[u] = cf[min(lb + blk * LB + 2 * ((el >> 4) + 4 * r) + par, lmax + 31)].y;   // (the table is padded by 32 entries; rows past lmax are discarded)
                 }
 #endif
 #pragma unroll

@@ -594,7 +594,26 @@ int sht_ringana(corahip_ctx *ctx, const corahip_sht_plan *p, const double *maps,
     StageTimer t(ctx, "ringana");
     const int G = nnu_pad8 / 4;
     const int k5_threads = K5_THREADS;
+    // The class launches alternate between two streams, as in sht_ringfft: every class is a persistent grid that fills
+    // the chip, so two kernels in flight run one after the other except for their tails - the workgroups of the next
+    // class start on the CUs the finishing one frees (CORAHIP_K5_ONE_STREAM=1: everything on the context's stream).
+    static const bool one_stream = getenv("CORAHIP_K5_ONE_STREAM") != nullptr;
+    const bool two = !one_stream && p->classes.size() > 1;
+    hipStream_t const main_stream = ctx->stream;
+    struct Restore {
+        corahip_ctx *c;
+        hipStream_t s;
+        ~Restore() { c->stream = s; }
+    } restore{ctx, main_stream};
+    if (two) {
+        int rc2 = sht_second_stream(ctx);
+        if (rc2) return rc2;
+        HIP_TRY(hipEventRecord(ctx->ev_fork, main_stream));
+        HIP_TRY(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
+    }
+    int launch_no = 0;
     for (const auto &c : p->classes) {
+        if (two) ctx->stream = (launch_no++ & 1) ? ctx->stream2 : main_stream;
         const size_t shm = sizeof(double2) * ((size_t)c.nch * c.bstride + TWL_ENTRIES(p->pmax));
         const long nitems = (long)c.count * ((nnu_pad8 + c.nch - 1) / c.nch);
         dim3 grid((unsigned)std::min<long>(nitems, (long)ctx->num_cu * 4));
@@ -610,6 +629,11 @@ int sht_ringana(corahip_ctx *ctx, const corahip_sht_plan *p, const double *maps,
         else { RINGANA_LAUNCH(1); }
 #undef RINGANA_LAUNCH
         LAUNCH_CHECK();
+    }
+    ctx->stream = main_stream;
+    if (two) {
+        HIP_TRY(hipEventRecord(ctx->ev_join, ctx->stream2));
+        HIP_TRY(hipStreamWaitEvent(main_stream, ctx->ev_join, 0));
     }
     return 0;
 }
