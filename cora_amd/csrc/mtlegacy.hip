@@ -286,27 +286,28 @@ mt_count_kernel(const unsigned *__restrict__ seg_state, long nseg, unsigned *__r
     for (int i = lane; i < MTN; i += 64) mt[i] = seg_state[j * MTN + i];
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     __builtin_amdgcn_wave_barrier();
-    unsigned cnt = 0, cnt0 = 0;
-    for (int bi = 0; bi < MT_SEG_BLOCKS; bi++) {
-        if (bi % MT_SUB_BLOCKS == 0 && bi / MT_SUB_BLOCKS < MT_NSUB) {
-            const long sidx = j * MT_NSUB + bi / MT_SUB_BLOCKS;
-            for (int i = lane; i < MTN; i += 64) sub_state[sidx * MTN + i] = mt[i];
-            if (bi > 0 && lane == 0) sub_cnt[sidx - 1] = cnt - cnt0;
-            cnt0 = cnt;
-        }
-        const int nb = (int)std::min<long>(MT_ATT_BLOCK, MT_SEG_ATT - (long)bi * MT_ATT_BLOCK);   // attempts of this block that belong to the segment
+    // (sub-segment by sub-segment: the snapshot and the count are written at the loop level they belong to, no test
+    //  per block)
+    for (int k = 0; k < MT_NSUB; k++) {
+        const long sidx = j * MT_NSUB + k;
+        for (int i = lane; i < MTN; i += 64) sub_state[sidx * MTN + i] = mt[i];
+        const int b0 = k * MT_SUB_BLOCKS, b1 = k == MT_NSUB - 1 ? MT_SEG_BLOCKS : b0 + MT_SUB_BLOCKS;
+        unsigned cnt = 0;
+        for (int bi = b0; bi < b1; bi++) {
+            const int nb = (int)std::min<long>(MT_ATT_BLOCK, MT_SEG_ATT - (long)bi * MT_ATT_BLOCK);   // attempts of this block that belong to the segment
 #pragma unroll
-        for (int r = 0; r < (MT_ATT_BLOCK + 63) / 64; r++) {
-            const int a = 64 * r + lane;
-            const bool in = a < nb;
-            mt_attempt t;
-            t.ok = false;
-            if (in) t = mt_try(mt, a);
-            cnt += (unsigned)__builtin_popcountll(__ballot(in && t.ok));
+            for (int r = 0; r < (MT_ATT_BLOCK + 63) / 64; r++) {
+                const int a = 64 * r + lane;
+                const bool in = a < nb;
+                mt_attempt t;
+                t.ok = false;
+                if (in) t = mt_try(mt, a);
+                cnt += (unsigned)__builtin_popcountll(__ballot(in && t.ok));
+            }
+            mt_block_next(mt, lane);
         }
-        mt_block_next(mt, lane);
+        if (lane == 0) sub_cnt[sidx] = cnt;
     }
-    if (lane == 0) sub_cnt[j * MT_NSUB + MT_NSUB - 1] = cnt - cnt0;
 }
 
 // pass 2, one wave per sub-segment (grid-stride from *sub_first, NULL = 0): the normals of accepted attempt o are

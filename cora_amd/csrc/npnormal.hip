@@ -657,12 +657,46 @@ __device__ inline void tile_load(tile_t &t, const unsigned *fun, long tile, long
 #pragma unroll
     for (int j = 0; j < ZIG_SEG; j++) t.w2[j] = j < t.nv ? f2[t.b0 + j] : make_uint2(0u, 0u);
 }
+// The function value of block b entered with k >= 2 (a tail sample reached across the boundary: 1.5e-4 of the blocks)
+// is in the patch list, which pass 1 appends to in no order.  A lane that walked the list by itself held its whole wave
+// for npatch dependent loads (~150 at cfg 3, ~2500 at cfg 5: the scan kernels took 0.2-0.26 ms each for trivial work);
+// here the WAVE searches for it: every lane looks at npatch / 64 entries.  `need` lanes get their value in `w`.
+__device__ inline void patch_lookup_wave(bool need, long b, unsigned k, unsigned &w, const ulonglong2 *patch, unsigned npatch,
+                                         unsigned *err) {
+    const int lane = threadIdx.x & 63;
+    unsigned long long nm = __ballot(need);
+    while (nm) {
+        const int src = __builtin_ctzll(nm);
+        const unsigned long long key = (readlane64((uint64_t)b, src) << 16) | readlane32(k, src);
+        unsigned found = 0;
+        bool hit = false;
+        for (unsigned i = lane; i < npatch; i += 64)
+            if (patch[i].x == key) {
+                found = (unsigned)patch[i].y;
+                hit = true;
+            }
+        const unsigned long long hm = __ballot(hit);
+        unsigned val = 0;
+        if (hm) val = readlane32(found, __builtin_ctzll(hm));
+        else if (lane == src) atomicOr(err, 4u);
+        if (lane == src) w = val;
+        nm &= nm - 1;
+    }
+}
+// one lane = ZIG_SEG consecutive blocks; all lanes of the wave call this together (uniform control flow)
 __device__ inline void seg_eval(const tile_t &t, unsigned k, unsigned &kout, unsigned &cnt, const ulonglong2 *patch,
                                 unsigned npatch, unsigned *err) {
     unsigned c = 0;
 #pragma unroll
-    for (int j = 0; j < ZIG_SEG; j++)
-        if (j < t.nv) fun_step(t.b0 + j, t.w2[j], k, c, patch, npatch, err);
+    for (int j = 0; j < ZIG_SEG; j++) {
+        const bool act = j < t.nv;
+        unsigned w = k ? t.w2[j].y : t.w2[j].x;
+        patch_lookup_wave(act && k >= 2, t.b0 + j, k, w, patch, npatch, err);
+        if (act) {
+            k = w >> 16;
+            c += w & 0xffffu;
+        }
+    }
     kout = k;
     cnt = c;
 }
@@ -788,11 +822,13 @@ zig_entry_kernel(long nblk, long ntile, const unsigned *__restrict__ fun, const 
     unsigned long long o = te.y + (incl - cnt);
 #pragma unroll
     for (int j = 0; j < ZIG_SEG; j++) {
-        if (j < t.nv) {
-            entry[t.b0 + j] = make_ulonglong2(k, o);
-            unsigned c = 0;
-            fun_step(t.b0 + j, t.w2[j], k, c, patch, npatch, &st->error);
-            o += c;
+        const bool act = j < t.nv;
+        if (act) entry[t.b0 + j] = make_ulonglong2(k, o);
+        unsigned w = k ? t.w2[j].y : t.w2[j].x;
+        patch_lookup_wave(act && k >= 2, t.b0 + j, k, w, patch, npatch, &st->error);
+        if (act) {
+            k = w >> 16;
+            o += w & 0xffffu;
         }
     }
 }

@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""Where the seeded step's time goes: wall time and every stage timer of cold cfg-3 steps with the Philox stream, numpy's
+PCG64 stream and numpy's legacy stream (tools/seeded_probe.py [nrep])."""
+import os, sys, time
+import numpy as np
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from cora_amd import _lib
+from cora_amd.parallel import SkyShard
+from cora_amd.signal import corr21cm
+ctx = _lib.get_context()
+F, nside, lmax = 256, 1024, 2048
+freq = 400.0 + (np.arange(F) + 0.5) * (400.0 / F)
+sh = SkyShard(corr21cm.Corr21cm(), freq, nside, lmax, zromb=3, ctx=ctx)
+nrep = int(sys.argv[1]) if len(sys.argv) > 1 else 5
+names = ("clarray", "factor", "zig_seek", "zig_count", "zig_scan", "zig_emit", "mt_jump", "mt_count", "mt_emit", "draw", "legendre", "ringfft")
+rng = np.random.default_rng(1)
+np.random.seed(2)
+modes = {"philox": lambda i: sh.realise(100 + i, sh.factors()), "pcg64": lambda i: sh.realise_numpy(rng, sh.factors()),
+         "legacy": lambda i: sh.realise_numpy(None, sh.factors())}
+for tag, fn in modes.items():
+    fn(0); fn(1)
+    torch.cuda.synchronize()
+    ctx.profile_reset(); ctx.profile_enable(True)
+    t0 = time.time()
+    for i in range(nrep):
+        fn(i)
+    torch.cuda.synchronize()
+    ms = (time.time() - t0) / nrep * 1e3
+    ctx.profile_enable(False)
+    st = {n: round(ctx.profile_get(n)[0] / nrep, 3) for n in names if ctx.profile_get(n)[1]}
+    serial = sum(v for k, v in st.items() if k in ("clarray", "factor", "draw", "legendre", "ringfft"))
+    print("%-7s %.2f ms per step; stages %s; clarray+factor+draw+legendre+ringfft = %.2f" % (tag, ms, st, serial))
