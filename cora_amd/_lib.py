@@ -95,6 +95,7 @@ SIGNATURES = {
     "corahip_rfftn": (c_int, [c_void_p, PTR, c_int, PTR, c_int, PTR]),
     "corahip_randomfield_draw": (c_int, [c_void_p, PTR, ctypes.c_int64, ctypes.c_uint64, PTR]),
     "corahip_fg_mix": (c_int, [c_void_p, PTR, PTR, PTR, c_int, c_int, ctypes.c_int64, PTR]),
+    "corahip_randomfield_irfftn": (c_int, [c_void_p, PTR, c_int, PTR, ctypes.c_uint64, PTR, PTR]),
     "corahip_spec_mul_real": (c_int, [c_void_p, PTR, PTR, ctypes.c_int64]),
     "corahip_cube_affine": (c_int, [c_void_p, PTR, PTR, PTR, PTR, PTR, c_int, ctypes.c_int64, PTR]),
     "corahip_raytrace_slices": (c_int, [c_void_p, PTR, c_int, c_int, c_int, PTR, PTR, PTR, PTR, c_double, c_double,
@@ -822,6 +823,22 @@ class Context:
         _check(self.lib.corahip_randomfield_draw(self.h, self._f64(kweight), kweight.numel(), int(seed),
                                                  self._c128(spec)))
         return spec
+
+    def randomfield_irfftn(self, kweight, seed, last=None, spec=None):
+        """``randomfield_draw`` + ``irfftn`` over all axes in one call: the spectrum is generated where the first pass
+        loads it (same values, no separate draw pass).  kweight real [..., n/2 + 1]; returns the real field."""
+        torch = _torch()
+        nd = kweight.dim()
+        rshape = list(kweight.shape)
+        rshape[-1] = 2 * (kweight.shape[-1] - 1) if last is None else int(last)
+        if rshape[-1] // 2 + 1 != kweight.shape[-1]:
+            raise CoraHipError("randomfield_irfftn: last axis %d does not match %d spectral bins" % (rshape[-1], kweight.shape[-1]))
+        if spec is None:
+            spec = torch.empty(tuple(kweight.shape), dtype=torch.complex128, device=self.device)
+        out = self.empty(tuple(rshape))
+        _check(self.lib.corahip_randomfield_irfftn(self.h, self._f64(kweight), nd, self._dims(rshape), int(seed) & (2**64 - 1),
+                                                   self._c128(spec), self._f64(out)))
+        return out
 
     def fg_mix(self, freq_weight, normals, aff):
         """out[f] = aff * sum_c freq_weight[f, c] normals[c]  (complex [F, *aff.shape])."""

@@ -82,7 +82,8 @@ class RandomField(object):
             f *= self._kweight
             spec = ctx.to_device(f, dtype=np.complex128)
         else:
-            spec = ctx.randomfield_draw(self._device_kweight(), seed)
+            # draw + irfftn in one call: the spectrum is generated where the first transform pass loads it
+            return ctx.randomfield_irfftn(self._device_kweight(), seed)
         return ctx.irfftn(spec)
 
     def getfield(self, seed=None):

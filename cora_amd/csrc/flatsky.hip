@@ -177,8 +177,15 @@ struct linefft_args {
     int h;               // modes 3/4: complex length n_real / 2 (= n), the real length is 2 h
     const double2 *tw, *chirp, *filt;
     const double2 *rtw;  // modes 3/4: e^{+2 pi i k / (2h)}, k = 0 .. h/2
+    uint64_t seed;       // mode 5: Philox key of the generated input
+    int gen_lds;         // mode 5: Box-Muller tables in LDS (when they fit beside a second workgroup's tile)
 };
 
+// MODE 5: MODE 0, inverse, whose INPUT is generated where it is committed to LDS: element e of the (never materialised)
+// spectrum is kweight[e] (N(0,1) + i N(0,1)), the pair being the Box-Muller outputs of Philox counter e - exactly
+// what randomfield_draw_kernel writes, so that RandomField.getfield(seed) = (normals x kweight) -> irfftn
+// (cora/core/gaussianfield.py:115-119) loses the 16 bytes written and 16 read per element of a separate draw pass:
+// A.in = kweight (real), A.out = the spectrum workspace the following passes work on.
 // MODE 0: complex -> complex (in place allowed), 1: half-complex -> real (inverse), 2: real -> half-complex
 // (1 and 2 transform a full-length complex line and serve odd lengths); 3 / 4: the same two for EVEN real lengths
 // 2h through ONE complex transform of length h (A.n = h): c2r packs Z_k = (X_k + conj X_{h-k}) + i W^k (X_k -
@@ -195,7 +202,7 @@ template <int MODE>
 __global__ void __launch_bounds__(FS_THREADS, FS_WG_PER_CU * FS_THREADS / 256) linefft_kernel(const linefft_args A) {
     extern __shared__ double2 fs_lds[];
     const int n = A.n, P = A.P, logP = A.logP, T = A.T;
-    const bool inv = MODE == 1 || (MODE == 0 && A.inverse);
+    const bool inv = MODE == 1 || MODE == 5 || (MODE == 0 && A.inverse);
     const int h = A.h, hp = (h >> 1) + 1;      // modes 3/4: pairs (k, h - k), k = 0 .. h/2
     const double2 *in2 = reinterpret_cast<const double2 *>(A.in);
     double2 *out2 = reinterpret_cast<double2 *>(A.out);
@@ -209,6 +216,10 @@ __global__ void __launch_bounds__(FS_THREADS, FS_WG_PER_CU * FS_THREADS / 256) l
     double2 *twl = fs_lds + T * P;
     double2 *rtwl = twl + (A.twl ? (P >> 2) : 0);
     double2 *xh = rtwl + hp;
+    // mode 5: the Box-Muller tables of the generator (rng_dev.h) behind the twiddles: a table fetched from global memory
+    // inside the chain waits out an L2 round trip per element (the lesson of K3, round 2)
+    double2 *lg_l = twl + (A.twl ? (P >> 2) : 0), *sc_l = lg_l + 257;
+    const double2 *lg_t = (MODE == 5 && A.gen_lds) ? lg_l : RNG_LOG_TAB, *sc_t = (MODE == 5 && A.gen_lds) ? sc_l : RNG_SC_TAB;
 
     struct tile_t {
         long outer, i0;
@@ -247,7 +258,7 @@ __global__ void __launch_bounds__(FS_THREADS, FS_WG_PER_CU * FS_THREADS / 256) l
             if (e < tl.teff * nin) {
                 int t, j;
                 const long addr = locate(tl, e, nin, rcp_nin, t, j);
-                R[u] = MODE == 2 ? make_double2(A.in[addr], 0.0) : in2[addr];
+                R[u] = (MODE == 2 || MODE == 5) ? make_double2(A.in[addr], 0.0) : in2[addr];
             }
         }
     };
@@ -265,8 +276,12 @@ __global__ void __launch_bounds__(FS_THREADS, FS_WG_PER_CU * FS_THREADS / 256) l
             const int e = threadIdx.x + u * FS_THREADS;
             if (e < tl.teff * nin) {
                 int t, j;
-                (void)locate(tl, e, nin, rcp_nin, t, j);
+                const long addr = locate(tl, e, nin, rcp_nin, t, j);
                 double2 v = R[u];
+                if (MODE == 5) {      // the k-weight arrived in R[u].x: the normals of this element are made here
+                    const double2 z = philox_boxmuller((uint64_t)addr, A.seed, lg_t, sc_t);
+                    v = make_double2(z.x * v.x, z.y * v.x);
+                }
                 if (MODE == 3) {
                     // raw spectrum at natural positions; the packing pass below works on pairs in place
                     if (j == h)
@@ -300,8 +315,13 @@ __global__ void __launch_bounds__(FS_THREADS, FS_WG_PER_CU * FS_THREADS / 256) l
     if (tile >= ntiles) return;
     if (A.twl)
         for (int k = threadIdx.x; k < (P >> 2); k += FS_THREADS) twl[k] = A.tw[k];
-    if (MODE >= 3)
+    if (MODE == 3 || MODE == 4)
         for (int k = threadIdx.x; k < hp; k += FS_THREADS) rtwl[k] = A.rtw[k];
+    if (MODE == 5 && A.gen_lds) {
+        for (int k = threadIdx.x; k < 257; k += FS_THREADS) lg_l[k] = RNG_LOG_TAB[k];
+        for (int k = threadIdx.x; k < 256; k += FS_THREADS) sc_l[k] = RNG_SC_TAB[k];
+        __syncthreads();
+    }
     // Strided axes read and write 16 T-byte segments: two tiles that are neighbours along the contiguous axis share
     // every 128-byte line.  Workgroups b and b + 8 run on the same XCD (round-robin dispatch) at the same time, so
     // they (and b + 16, ...) are given adjacent tiles and a line is fetched into that XCD's L2 once instead of into several L2s.
@@ -575,13 +595,13 @@ static int get_linefft_plan(corahip_ctx *ctx, int n, const corahip_linefft_plan 
 
 template <int MODE>
 static int launch_linefft(corahip_ctx *ctx, const double *in, double *out, long nouter, int n, long inner,
-                          int inverse, double scale) {
+                          int inverse, double scale, uint64_t seed = 0) {
     ARG_CHECK(n >= 1 && n <= FS_MAXN);
     if (nouter * inner == 0) return 0;
     const corahip_linefft_plan *pl;
     int rc = get_linefft_plan(ctx, n, &pl);
     if (rc) return rc;
-    StageTimer pass_timer(ctx, (MODE == 1 || MODE == 3) ? "fft_c2r" : ((MODE == 2 || MODE == 4) ? "fft_r2c" : (inner == 1 ? "fft_c2c_contig" : "fft_c2c_strided")));
+    StageTimer pass_timer(ctx, (MODE == 1 || MODE == 3) ? "fft_c2r" : ((MODE == 2 || MODE == 4) ? "fft_r2c" : (MODE == 5 ? "fft_c2c_draw" : (inner == 1 ? "fft_c2c_contig" : "fft_c2c_strided"))));
     linefft_args A;
     A.in = in;
     A.out = out;
@@ -599,14 +619,18 @@ static int launch_linefft(corahip_ctx *ctx, const double *in, double *out, long 
     A.filt = pl->filt;
     A.rtw = pl->rtw;
     A.h = n;
+    A.seed = seed;
     int T = FS_LDS_ELEMS / pl->P;
     T = T < 1 ? 1 : (T > 16 ? 16 : T);
     if (MODE == 3)   // n + 1 input elements per line must fit the register prefetch of a tile
         while (T > 1 && (long)T * (n + 1) > (long)FS_NLOAD * FS_THREADS) T--;
     A.T = T;
     A.twl = pl->P <= 4096;
-    const size_t shm = sizeof(double2) * ((size_t)T * pl->P + (A.twl ? pl->P / 4 : 0) +
-                                          (MODE >= 3 ? (size_t)(n / 2 + 1) + T : 0));
+    size_t shm = sizeof(double2) * ((size_t)T * pl->P + (A.twl ? pl->P / 4 : 0) +
+                                    ((MODE == 3 || MODE == 4) ? (size_t)(n / 2 + 1) + T : 0));
+    // mode 5: the generator's tables in LDS only where they do not cost the second workgroup of the CU its place
+    A.gen_lds = MODE == 5 && 2 * (shm + sizeof(double2) * 513) <= 160 * 1024;
+    if (A.gen_lds) shm += sizeof(double2) * 513;
     const long chunks = (inner + T - 1) / T;
     const long ntiles = inner == 1 ? (nouter + T - 1) / T : nouter * chunks;
     const long per_cu = (FS_WG_PER_CU == 2 && shm * 2 <= 160 * 1024) ? 2 : 1;   // launch bounds allow two 8-wave workgroups per CU
@@ -655,6 +679,32 @@ int corahip_irfftn(corahip_ctx *ctx, double *spec, int ndim, const int64_t *rdim
     const int n = (int)rdims[ndim - 1];
     if (n % 2 == 0)   // even length: one complex transform of half the length
         return launch_linefft<3>(ctx, spec, out, prod(rdims, 0, ndim - 1), n / 2, 1, 1, 1.0 / n);
+    return launch_linefft<1>(ctx, spec, out, prod(rdims, 0, ndim - 1), n, 1, 1, 1.0 / n);
+}
+
+int corahip_randomfield_irfftn(corahip_ctx *ctx, const double *kweight, int ndim, const int64_t *rdims, uint64_t seed,
+                               double *spec, double *out) {
+    ARG_CHECK(ctx && kweight && spec && out && rdims && ndim >= 1 && ndim <= 8);
+    int64_t cd[8];
+    for (int i = 0; i < ndim; i++) {
+        ARG_CHECK(rdims[i] >= 1 && rdims[i] <= FS_MAXN);
+        cd[i] = rdims[i];
+    }
+    cd[ndim - 1] = rdims[ndim - 1] / 2 + 1;
+    if (ndim == 1) {          // (no complex pass to generate in: the two-step form)
+        int rc = corahip_randomfield_draw(ctx, kweight, cd[0], seed, spec);
+        return rc ? rc : corahip_irfftn(ctx, spec, ndim, rdims, ndim, out);
+    }
+    StageTimer st(ctx, "flatfft");
+    // first pass (axis 0): the spectrum is generated where the pass loads it
+    int rc = launch_linefft<5>(ctx, kweight, spec, 1, (int)cd[0], prod(cd, 1, ndim), 1, 1.0 / cd[0], seed);
+    if (rc) return rc;
+    for (int ax = 1; ax < ndim - 1; ax++) {
+        const int n = (int)cd[ax];
+        if ((rc = launch_linefft<0>(ctx, spec, spec, prod(cd, 0, ax), n, prod(cd, ax + 1, ndim), 1, 1.0 / n))) return rc;
+    }
+    const int n = (int)rdims[ndim - 1];
+    if (n % 2 == 0) return launch_linefft<3>(ctx, spec, out, prod(rdims, 0, ndim - 1), n / 2, 1, 1, 1.0 / n);
     return launch_linefft<1>(ctx, spec, out, prod(rdims, 0, ndim - 1), n, 1, 1, 1.0 / n);
 }
 

@@ -32,7 +32,7 @@ extern "C" {
 #endif
 
 #define CORAHIP_ABI_VERSION 1
-#define CORAHIP_ABI_MINOR 3      /* additions since version 1: 1 = normals_pcg64, pcg64_advance, draw_alm_rows, mkfullsky, mkfullsky_workspace_bytes, abi_minor, normals_mt19937_legacy; 2 = sht_lambda_entry (test hook); 3 = draw_alm_numpy, draw_alm_numpy_begin / _end, corahip_chanset: draw_alm_philox_rows_set, draw_alm_numpy_begin_set */
+#define CORAHIP_ABI_MINOR 3      /* additions since version 1: 1 = normals_pcg64, pcg64_advance, draw_alm_rows, mkfullsky, mkfullsky_workspace_bytes, abi_minor, normals_mt19937_legacy; 2 = sht_lambda_entry (test hook); 3 = draw_alm_numpy, draw_alm_numpy_begin / _end, corahip_chanset: draw_alm_philox_rows_set, draw_alm_numpy_begin_set, randomfield_irfftn */
 
 #define CORAHIP_EINVAL (-1)   /* bad argument / shape */
 #define CORAHIP_ENOMEM (-2)   /* workspace too small / allocation refused */
@@ -441,6 +441,12 @@ int corahip_randomfield_draw(corahip_ctx *ctx, const double *kweight, int64_t co
                              double *spec);
 int corahip_fg_mix(corahip_ctx *ctx, const double *freq_weight, const double *normals, const double *aff,
                    int F, int ncorr, int64_t M, double *out);
+/* randomfield_draw + irfftn (all axes) in one call, the spectrum GENERATED where the first pass loads it - the same
+ * values, bit for bit, without writing and re-reading the 16 bytes per element of a separate draw pass: kweight real
+ * [rdims[0], ..., rdims[-1]/2 + 1], spec a workspace of that many complex elements, out real rdims.  The whole of
+ * RandomField.getfield with the device stream (cora/core/gaussianfield.py:102-120).                              */
+int corahip_randomfield_irfftn(corahip_ctx *ctx, const double *kweight, int ndim, const int64_t *rdims, uint64_t seed,
+                               double *spec, double *out);
 /* The redshift-space cube of RedshiftCorrelation.realisation / Corr21cm.getfield (cora/signal/corr.py:562-770,
  * cora/signal/corr21cm.py:241-257) on top of the transforms above:
  * spec_mul_real:   spec[e] *= weight[e] (complex x real; the mu^2 factor of corr.py:590-599), count elements.

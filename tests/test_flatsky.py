@@ -206,6 +206,16 @@ def test_device_seeded_field_vs_oracle_stream_and_spectrum(ctx):
     assert _rel(f, want) < 1e-13
     assert np.array_equal(f, rf.getfield(seed=77)) and not np.array_equal(f, rf.getfield(seed=78))
 
+    # getfield(seed) is ONE library call since round 5 (the spectrum generated inside the first transform pass): the same
+    # field, bit for bit, as the draw followed by irfftn - 3-d, 2-d, non-power-of-two and odd sizes, and 1-d (two-step inside)
+    import torch
+
+    for shape in ([12, 10, 14], [16, 64], [9, 20], [33, 7, 11], [40]):
+        kw = ctx.empty(tuple(shape[:-1]) + (shape[-1] // 2 + 1,)).uniform_()
+        two = ctx.irfftn(ctx.randomfield_draw(kw, 123), last=shape[-1])
+        one = ctx.randomfield_irfftn(kw, 123, last=shape[-1])
+        assert torch.equal(one, two), shape
+
     n, w = 256, 400.0
     big = gaussianfield.RandomField(npix=[n, n, n], wsize=[w, w, w])
     big.powerspectrum = ps_model
