@@ -58,15 +58,18 @@ static int draw_numpy_begin(corahip_ctx *ctx, const double *T, int rows, const i
     if (rc) return rc;
     const unsigned long long total = (unsigned long long)F * (lmax + 1) * (lmax + 2);
     if (ring_bytes == 0) {
-        // Default: ranges cost time, not save it (measured, cfg 3: one range 12.97 ms, 5 ranges 13.6, 35 ranges 14.4, 135
-        // ranges 18.6 - every range is an emit launch, an event hop and a K3 launch with its own ramp and tail, and the
-        // emit pass cannot run BESIDE K3: 223 VGPRs x 2 waves per SIMD leave no room for its 107), so a stream that is a
-        // small part of the device's memory (<= 1/8: cfg 3 8.6 GB, cfg 4 17.2 GB of 288 GB) stays one range; a larger one
-        // (cfg 5: 137 GB) goes through a ring of 1/16 of the memory (~15 ranges there).  CORAHIP_RING_MB overrides.
+        // Default (measured at cfg 3, tools/seeded_probe.py, whole step): every range is an emit launch, an event hop and a
+        // K3 launch with its own ramp and tail, and the emit pass cannot run BESIDE K3 (223 VGPRs x 2 waves per SIMD leave
+        // no room for its 107) - the draw pipeline alone takes 12.65 ms as one range, 12.97 / 13.31 / 14.42 ms with a ring
+        // of 2 GB / 1 GB / 512 MB.  But the kernel BEHIND the draw pays for the footprint of the normals: K4's first run
+        // after a draw that streamed through 8.6 GB takes 53.5 ms, after a 2 GB ring 52.4, after 512 MB 51.8 (its usual
+        // time).  The step is shortest with a ring of 2 GiB (88.3 ms; 89.1 as one range, 89.2 at 512 MB): that is the
+        // default while the stream is a small part of the device memory; a stream beyond 1/8 of it (cfg 5: 137 GB, where
+        // every range carries 4x the MFMA work per byte) goes through a ring of 1/16 of the memory.  CORAHIP_RING_MB overrides.
         const char *e = getenv("CORAHIP_RING_MB");
         if (e) ring_bytes = (size_t)std::max(1L, atol(e)) << 20;
-        else if (8 * total <= ctx->total_mem / 8) ring_bytes = (size_t)16 * total;       // one slot = the whole stream
-        else ring_bytes = std::max<size_t>(ctx->total_mem / 16, (size_t)1 << 30);
+        else if (8 * total <= ctx->total_mem / 8) ring_bytes = (size_t)2 << 30;
+        else ring_bytes = std::max<size_t>(ctx->total_mem / 16, (size_t)2 << 30);
     }
     // ranges of whole multipoles: l contributes 2 F (l + 1) normals; a slot holds at least the largest l
     const unsigned long long per_lmax = 2ull * F * (lmax + 1);

@@ -192,15 +192,13 @@ def exchange_factor_rows(T_local, info_local, plan):
 
 
 def numpy_ring_bytes(F, lmax, device_bytes=288e9):
-    """Bytes of the normal-stream ring ``corahip_draw_alm_numpy`` allocates by default (csrc/drawstream.hip): the whole
-    stream of a realisation (16 F nalm bytes) as ONE range while that is at most 1/8 of the device memory (ranges cost
-    time: every range is an emit launch, an event hop and a K3 launch), else two slots in 1/16 of it - a slot never
-    smaller than the normals of l = lmax."""
+    """Bytes of the normal-stream ring ``corahip_draw_alm_numpy`` allocates by default (csrc/drawstream.hip): two slots
+    in 2 GiB while the whole stream of a realisation (16 F nalm bytes) is at most 1/8 of the device memory (the measured
+    optimum of the cfg-3 step: more ranges cost launches, fewer cost the kernel behind the draw its cache / TLB state),
+    else in 1/16 of the memory - a slot never smaller than the normals of l = lmax, the ring never larger than the stream."""
     L = lmax + 1
     stream = 8 * F * L * (L + 1)
-    if stream <= device_bytes / 8:
-        return int(stream)
-    ring = max(device_bytes / 16, 2.0**30)
+    ring = 2.0**31 if stream <= device_bytes / 8 else max(device_bytes / 16, 2.0**31)
     slot = max(ring / 2, 16.0 * F * L)
     return int(min(stream, 2 * slot))
 

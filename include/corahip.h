@@ -265,8 +265,8 @@ int corahip_mkfullsky(corahip_ctx *ctx, const corahip_sht_plan *plan, const doub
  * draw_alm (rows = 0: T [lmax+1, F, F]) or draw_alm_rows (rows = 1: T_rows [lmax+1, nnu, F]), bit for bit, WITHOUT the
  * 16 F nalm-byte stream buffer (8.6 GB at F = 256, lmax = 2048; 137 GB at F = 1024, lmax = 4096): the generator's
  * count + scan passes cover the whole stream, its emit pass fills one slot of a two-slot ring (library-owned, ring_bytes
- * in total, 0 = the default: the whole stream as one range while it is <= 1/8 of the device memory,
- * else a ring of 1/16 of it, or CORAHIP_RING_MB; a slot is never smaller than the normals of l = lmax) per range
+ * in total, 0 = the default: 2 GiB - the measured optimum of the whole step at F = 256, lmax = 2048 - while the
+ * stream is <= 1/8 of the device memory, else 1/16 of the memory, or CORAHIP_RING_MB; a slot is never smaller than the normals of l = lmax) per range
  * of multipoles on a second stream while K3 consumes the other slot.
  *   host_rng  (the struct of corahip_mkfullsky above) kind CORAHIP_RNG_PCG64 (state, inc as in corahip_normals_pcg64) or CORAHIP_RNG_MT19937 (legacy state);
  *             UPDATED to the state numpy would be left in.  Synchronises the context's stream (that read-back).

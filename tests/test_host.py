@@ -435,10 +435,10 @@ def test_rank_memory_of_the_8_gpu_configs_fits_an_mi355x():
     assert 120e9 < c5["total"] < 200e9
     assert rank_memory_bytes(["table21cm"], 1024, 2048, 4096, 1)["total"] > hbm
     # the numpy-seeded mode (the reference's own call): since round 5 the stream is generated range of multipoles by
-    # range - one range (8.6 / 17.2 GB) at cfg 3 / 4, a ring of 18 GB instead of the 137 GB stream at cfg 5
+    # range - a ring of 2 GiB at cfg 3 / 4 (8.6 / 17.2 GB streams), of 18 GB instead of the 137 GB stream at cfg 5
     from cora_amd.parallel import numpy_ring_bytes
 
-    assert numpy_ring_bytes(256, 2048) == 16 * 256 * (2049 * 2050 // 2)
+    assert numpy_ring_bytes(256, 2048) == 2**31 and numpy_ring_bytes(8, 64) == 16 * 8 * (65 * 66 // 2)
     assert numpy_ring_bytes(1024, 4096) == int(288e9 / 16)
     assert rank_memory_bytes(["table21cm"], 256, 1024, 2048, 1, rng="numpy")["total"] < 0.9 * hbm
     c5n = rank_memory_bytes(["table21cm"], 1024, 2048, 4096, 8, rng="numpy")
