@@ -39,6 +39,7 @@ struct corahip_ctx {
     hipStream_t stream2 = nullptr;                 // second stream for kernels that run beside those of `stream` (K5 pair)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // the l-range pipeline of the numpy-stream draw (drawstream.hip): its generator stream and the ring's events
+    bool mt_plist_ready = false;                   // scratch slot 9 holds the position lists (mtlegacy.hip)
     hipStream_t gen_stream = nullptr;
     hipEvent_t ev_ring[8] = {};
     hipEvent_t t0 = nullptr, t1 = nullptr;
@@ -51,7 +52,7 @@ struct corahip_ctx {
     // slots: 0 K1 transposed tables, 1 K1 pair results / odd-F normal stream, 2 K1 pair list, 3 zeros,
     //        4 Legendre matrix of legendre_project, 5 its zero-padded operand, 6 block tables of normals_pcg64 /
     //        segment tables of normals_mt19937_legacy, 7 the two-slot ring of the l-range pipeline (drawstream.hip),
-    //        8 barrier words of the cooperative Cholesky
+    //        8 barrier words of the cooperative Cholesky, 9 position lists of the MT19937 jump polynomials
     void *scratch[CORAHIP_NSCRATCH] = {};
     size_t scratch_bytes[CORAHIP_NSCRATCH] = {};
     // K1 transposed tables resident in scratch slot 0: valid for the pinned (dd, dv, vv, generation) only

@@ -32,6 +32,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <type_traits>
 #include <vector>
 
 #include "mt_jump.inc"
@@ -101,21 +102,64 @@ struct mt_status {
 // 16 list entries per round, all their reads in flight together (one LDS round trip per BIT was 64 ms at cfg 3).
 #define MT_JUMP_T 256
 #define MT_JUMP_XS (MTN + MT_DEG + 1 + 256 + MTM + 8)
+#define MT_PLIST_STRIDE (MT_DEG + 32)      // positions per polynomial in the device-wide list (a polynomial has <= 19937 terms)
+// one-off per context: the set positions (+ 1) of every jump polynomial as a list, npos[k] entries at plist[k][...] -
+// the kernels below walk the list with wave-uniform (scalar) loads instead of rebuilding it in LDS per application
 __global__ void __launch_bounds__(MT_JUMP_T)
-mt_jump_kernel(unsigned *__restrict__ seg_state, long src0, long dst0, long count, int k) {
+mt_plist_kernel(unsigned *__restrict__ plist_all, unsigned *__restrict__ npos_all) {
+    __shared__ unsigned wcnt[MTN + 1];
+    const int k = blockIdx.x, tid = threadIdx.x;
+    const unsigned *g = MT_JUMP[k];
+    for (int i = tid; i < MTN; i += MT_JUMP_T) wcnt[i] = (unsigned)__builtin_popcount(g[i]);
+    __syncthreads();
+    if (tid == 0) {
+        unsigned run = 0;                                     // exclusive prefix of the per-word bit counts
+        for (int i = 0; i < MTN; i++) {
+            const unsigned c = wcnt[i];
+            wcnt[i] = run;
+            run += c;
+        }
+        npos_all[k] = run;
+    }
+    __syncthreads();
+    unsigned *pl = plist_all + (size_t)k * MT_PLIST_STRIDE;
+    for (int i = tid; i < MTN; i += MT_JUMP_T) {
+        unsigned m = g[i];
+        unsigned o = wcnt[i];
+        while (m) {
+            pl[o++] = (unsigned)(32 * i + __builtin_ctz(m) + 1);
+            m &= m - 1;
+        }
+    }
+}
+
+// `split` workgroups share one application: workgroup (a, part) makes the output words [part, part + 1) * 624 / split (split
+// divides 624).  An application is bound by the LDS of its CU (10^4 windows x 624 words of 4-byte reads) and the tree's
+// first levels have 1, 2, 4, ... applications: split over up to 24 CUs (each extends the window for itself: 20 us) they
+// take a fraction of one application's latency (tree 3.93 -> 3.54 ms at cfg 3).  Inside a workgroup the threads are
+// (g, wi): word wi of the slice, positions g, g + G, ... of the list (G = 256 / words per slice when the slice is
+// narrower than the workgroup); the G partial words are combined through LDS.  The positions are copied into LDS from
+// the device-wide list (walking the list in global memory by scalar loads instead was measured SLOWER, tree 3.5 -> 4.7
+// ms: a load's latency per 16 positions is not hidden at one wave per SIMD).
+#define MT_JUMP_WG 1024                     // threads of a jump workgroup: MT_JUMP_WG / 256 position groups on the full window
+__global__ void __launch_bounds__(MT_JUMP_WG)
+mt_jump_kernel(unsigned *__restrict__ seg_state, long src0, long dst0, long count, int k, int split,
+               const unsigned *__restrict__ plist_all, const unsigned *__restrict__ npos_all) {
     extern __shared__ unsigned xs[];                          // [MT_JUMP_XS] words, then the position list (u16)
-    __shared__ unsigned short wcnt[MTN + 1];
-    __shared__ unsigned npos_s;
-    unsigned short *plist = reinterpret_cast<unsigned short *>(xs + MT_JUMP_XS);
-    const long a = blockIdx.x;
+    constexpr int NQ = (MTN + MT_JUMP_T - 1) / MT_JUMP_T;     // words per thread on the full window: 3
+    __shared__ unsigned red[NQ][MT_JUMP_WG];
+    unsigned short *plist = (unsigned short *)(xs + MT_JUMP_XS);
+    const long a = blockIdx.x / split;
+    const int part = blockIdx.x - (int)a * split;
     if (a >= count) return;
     const int tid = threadIdx.x, lane = tid & 63;
     const unsigned *src = seg_state + (src0 + a) * MTN;
-    const unsigned *g = MT_JUMP[k];
-    for (int i = tid; i < MTN; i += MT_JUMP_T) {
-        xs[i] = src[i];
-        wcnt[i] = (unsigned short)__builtin_popcount(g[i]);
+    const int npos = (int)npos_all[k];
+    {
+        const unsigned *__restrict__ pl = plist_all + (size_t)k * MT_PLIST_STRIDE;
+        for (int i = tid; i < npos; i += MT_JUMP_WG) plist[i] = (unsigned short)pl[i];
     }
+    for (int i = tid; i < MTN; i += MT_JUMP_WG) xs[i] = src[i];
     __syncthreads();
     if (tid < 64) {
         // 227 words per step (four reads-then-writes of 64): word 624 + k needs words k, k + 1 and k + 397, the last at
@@ -137,53 +181,57 @@ mt_jump_kernel(unsigned *__restrict__ seg_state, long src0, long dst0, long coun
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
             __builtin_amdgcn_wave_barrier();
         }
-    } else if (tid == 64) {
-        unsigned run = 0;                                     // exclusive prefix of the per-word bit counts
-        for (int i = 0; i < MTN; i++) {
-            const unsigned c = wcnt[i];
-            wcnt[i] = (unsigned short)run;
-            run += c;
-        }
-        npos_s = run;
     }
     __syncthreads();
-    for (int i = tid; i < MTN; i += MT_JUMP_T) {
-        unsigned m = g[i];
-        unsigned o = wcnt[i];
-        while (m) {
-            plist[o++] = (unsigned short)(32 * i + __builtin_ctz(m) + 1);
-            m &= m - 1;
-        }
-    }
-    __syncthreads();
-    const int npos = (int)npos_s;
-    constexpr int NQ = (MTN + MT_JUMP_T - 1) / MT_JUMP_T;
+    // threads as (gi, wi): words wi, wi + 256, .. of the slice, positions gi, gi + G, .. of the list.  A wave per SIMD
+    // cannot hide the LDS latency (the counter of outstanding LDS reads has four bits): sixteen waves take the reads of
+    // four position groups at once (jump tree of cfg 3: 3.5 -> 2.3 ms)
+    const int nw = MTN / split, w0 = part * nw;               // this workgroup's slice of the output window
+    const int nwt = nw < MT_JUMP_T ? nw : MT_JUMP_T;          // threads along the words
+    const int G = MT_JUMP_WG / nwt;                           // position groups
+    const int wi = tid % nwt, gi = tid / nwt;
     unsigned acc[NQ] = {};
-    const bool last_ok = tid + (NQ - 1) * MT_JUMP_T < MTN;
-    int p = 0;
-    for (; p + 16 <= npos; p += 16) {
-        unsigned v[16][NQ];
+    auto xor_windows = [&](auto nqe_c) {
+        constexpr int NQE = decltype(nqe_c)::value;
+        int p = gi;
+        for (; p + 15 * G < npos; p += 16 * G) {
+            unsigned v[16][NQE];
 #pragma unroll
-        for (int e = 0; e < 16; e++) {
-            const int i = plist[p + e];
+            for (int e = 0; e < 16; e++) {
+                const int i = plist[p + e * G];
 #pragma unroll
-            for (int q = 0; q < NQ; q++) v[e][q] = xs[i + tid + q * MT_JUMP_T];     // (q = NQ - 1 may read past word 623 of the window: inside xs, discarded)
+                for (int q = 0; q < NQE; q++) v[e][q] = xs[i + w0 + wi + q * MT_JUMP_T];   // (past the slice: inside xs, discarded)
+            }
+#pragma unroll
+            for (int e = 0; e < 16; e++)
+#pragma unroll
+                for (int q = 0; q < NQE; q++) acc[q] ^= v[e][q];
         }
+        for (; p < npos; p += G) {
+            const int i = plist[p];
 #pragma unroll
-        for (int e = 0; e < 16; e++)
-#pragma unroll
-            for (int q = 0; q < NQ; q++) acc[q] ^= v[e][q];
+            for (int q = 0; q < NQE; q++) acc[q] ^= xs[i + w0 + wi + q * MT_JUMP_T];
+        }
+    };
+    if (gi < G) {
+        if (nw <= MT_JUMP_T) xor_windows(std::integral_constant<int, 1>{});
+        else if (nw <= 2 * MT_JUMP_T) xor_windows(std::integral_constant<int, 2>{});
+        else xor_windows(std::integral_constant<int, NQ>{});
     }
-    for (; p < npos; p++) {
-        const int i = plist[p];
 #pragma unroll
-        for (int q = 0; q < NQ; q++) acc[q] ^= xs[i + tid + q * MT_JUMP_T];
-    }
-    unsigned *dst = seg_state + (dst0 + a) * MTN;
+    for (int q = 0; q < NQ; q++) red[q][tid] = gi < G ? acc[q] : 0u;
+    __syncthreads();
+    unsigned *dst = seg_state + (dst0 + a) * MTN + w0;
+    if (gi == 0) {
 #pragma unroll
-    for (int q = 0; q < NQ; q++) {
-        const int w = tid + q * MT_JUMP_T;
-        if (w < MTN && (q < NQ - 1 || last_ok)) dst[w] = acc[q];
+        for (int q = 0; q < NQ; q++) {
+            const int w = wi + q * MT_JUMP_T;
+            if (w < nw) {
+                unsigned r = 0;
+                for (int g2 = 0; g2 < G; g2++) r ^= red[q][g2 * nwt + wi];
+                dst[w] = r;
+            }
+        }
     }
 }
 
@@ -510,6 +558,23 @@ int mt_stream_prepare(corahip_ctx *ctx, hipStream_t stream, corahip_mt_state *st
         return fail(e, "upload of the generator window");
     if ((e = hipMemcpyAsync(s->d_bounds, s->bounds.data(), sizeof(unsigned long long) * nb, hipMemcpyHostToDevice, stream)) != hipSuccess)
         return fail(e, "upload of the range bounds");
+    // the position lists of the jump polynomials: made once per context (scratch slot 9), on this stream
+    unsigned *plist_all = nullptr;
+    {
+        const size_t pb = sizeof(unsigned) * ((size_t)MT_NPOLY * MT_PLIST_STRIDE + MT_NPOLY);
+        const bool fresh = ctx->scratch_bytes[9] < pb;
+        if (corahip_ctx_scratch(ctx, 9, pb, (void **)&plist_all)) {
+            delete s;
+            return CORAHIP_ENOMEM;
+        }
+        if (fresh || !ctx->mt_plist_ready) {
+            mt_plist_kernel<<<MT_NPOLY, MT_JUMP_T, 0, stream>>>(plist_all, plist_all + (size_t)MT_NPOLY * MT_PLIST_STRIDE);
+            // (later calls may run on another stream: the list must be complete before any of them can start)
+            if ((e = hipStreamSynchronize(stream)) != hipSuccess) return fail(e, "position lists of the jump polynomials");
+            ctx->mt_plist_ready = true;
+        }
+    }
+    const unsigned *npos_all = plist_all + (size_t)MT_NPOLY * MT_PLIST_STRIDE;
     {
         StageTimer t0(ctx, "mt_jump", stream, other);
         const size_t shm = sizeof(unsigned) * MT_JUMP_XS + sizeof(unsigned short) * (MT_DEG + 8);
@@ -517,7 +582,16 @@ int mt_stream_prepare(corahip_ctx *ctx, hipStream_t stream, corahip_mt_state *st
             return fail(e, "hipFuncSetAttribute");
         for (int k = 0; (1L << k) < s->nseg; k++) {
             const long have = 1L << k, count = std::min<long>(have, s->nseg - have);
-            mt_jump_kernel<<<(unsigned)count, MT_JUMP_T, shm, stream>>>(s->seg_state, 0, have, count, k);
+            // levels with fewer applications than CUs: several workgroups per application (divisors of 624).  (Splitting
+            // the last partial round of the larger levels as well was measured: no gain, 2.32 vs 2.36 ms.)
+            int split = 1;
+            for (int cand : {24, 12, 8, 6, 4, 3, 2})
+                if (count * cand <= ctx->num_cu + ctx->num_cu / 2) {
+                    split = cand;
+                    break;
+                }
+            mt_jump_kernel<<<(unsigned)(count * split), MT_JUMP_WG, shm, stream>>>(s->seg_state, 0, have, count, k, split, plist_all,
+                                                                                  npos_all);
         }
     }
     {
