@@ -566,6 +566,8 @@ int sht_second_stream(corahip_ctx *ctx);
 int sht_ringfft_ct_pair(corahip_ctx *ctx, const corahip_sht_plan *p, const corahip_sht_plan::ring_class &belt,
                         const corahip_sht_plan::ring_class &cap, const double *inter, int G, int nnu, double *maps, bool *took);
 // K5^T: maps -> weighted G_m cells for nnu_pad8 channels (nnu present in `maps`)
+int sht_ringana_ct(corahip_ctx *ctx, const corahip_sht_plan *p, const corahip_sht_plan::ring_class &c, const double *maps, int nvalid,
+                   int nnu_pad, const double *ring_w, int G, double *inter, bool *took);
 int sht_ringana(corahip_ctx *ctx, const corahip_sht_plan *p, const double *maps, int nnu, int nnu_pad8,
                 const double *ring_w, double *inter);
 // K4^T + reduction over ring tiles: G_m cells -> alm_dev (part: per-ring-tile scratch)

@@ -598,7 +598,8 @@ int sht_ringana(corahip_ctx *ctx, const corahip_sht_plan *p, const double *maps,
     // the chip, so two kernels in flight run one after the other except for their tails - the workgroups of the next
     // class start on the CUs the finishing one frees (CORAHIP_K5_ONE_STREAM=1: everything on the context's stream).
     static const bool one_stream = getenv("CORAHIP_K5_ONE_STREAM") != nullptr;
-    const bool two = !one_stream && p->classes.size() > 1;
+    static const bool class_times = getenv("CORAHIP_K5_TIMES") != nullptr;   // diagnostics: per-class ms on stderr
+    const bool two = !one_stream && !class_times && p->classes.size() > 1;
     hipStream_t const main_stream = ctx->stream;
     struct Restore {
         corahip_ctx *c;
@@ -614,6 +615,15 @@ int sht_ringana(corahip_ctx *ctx, const corahip_sht_plan *p, const double *maps,
     int launch_no = 0;
     for (const auto &c : p->classes) {
         if (two) ctx->stream = (launch_no++ & 1) ? ctx->stream2 : main_stream;
+        hipEvent_t ce0 = nullptr, ce1 = nullptr;
+        if (class_times) {
+            (void)hipEventCreate(&ce0);
+            (void)hipEventCreate(&ce1);
+            (void)hipEventRecord(ce0, ctx->stream);
+        }
+        bool took = false;   // compile-time kernel for this class?
+        const int rct = sht_ringana_ct(ctx, p, c, maps, nnu, nnu_pad8, ring_w, G, inter, &took);
+        if (rct) return rct;
         const size_t shm = sizeof(double2) * ((size_t)c.nch * c.bstride + TWL_ENTRIES(p->pmax));
         const long nitems = (long)c.count * ((nnu_pad8 + c.nch - 1) / c.nch);
         dim3 grid((unsigned)std::min<long>(nitems, (long)ctx->num_cu * 4));
@@ -624,11 +634,21 @@ int sht_ringana(corahip_ctx *ctx, const corahip_sht_plan *p, const double *maps,
                                                          p->d_nphi, p->d_start, p->d_phi0, maps, inter, p->d_tw,    \
                                                          p->pmax, p->d_blu_P, p->d_blu_boff, p->d_blu_foff,         \
                                                          p->d_bchirp, p->d_bfilt, c.bstride, p->d_mcut, ring_w, nnu)
-        if (c.nch == 4) { RINGANA_LAUNCH(4); }
+        if (took) {
+        } else if (c.nch == 4) { RINGANA_LAUNCH(4); }
         else if (c.nch == 2) { RINGANA_LAUNCH(2); }
         else { RINGANA_LAUNCH(1); }
 #undef RINGANA_LAUNCH
         LAUNCH_CHECK();
+        if (class_times) {
+            float ms = 0.f;
+            (void)hipEventRecord(ce1, ctx->stream);
+            (void)hipEventSynchronize(ce1);
+            (void)hipEventElapsedTime(&ms, ce0, ce1);
+            fprintf(stderr, "K5^T class P=%d (length %d) nch=%d rings=%d: %.3f ms\n", c.P, c.P3 ? c.P3 : (c.P ? c.P : c.N), c.nch, c.count, ms);
+            (void)hipEventDestroy(ce0);
+            (void)hipEventDestroy(ce1);
+        }
     }
     ctx->stream = main_stream;
     if (two) {

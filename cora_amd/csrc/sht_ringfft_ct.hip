@@ -916,6 +916,152 @@ ringfft_blu_ct(const int32_t *__restrict__ ring_list, int nlist, int nside, int 
 }
 
 // ------------------------------------------------------------------------------------
+// K5^T, direct class (the belt rings of map2alm, cora/util/hputil.py:195-234 through healpy.map2alm): the adjoint of
+// ringfft_direct_ct pass by pass.  The n = 2 N pixels of a ring are N complex numbers z_j = x_2j + i x_2j+1;
+//   pass C^H  radix R2 on the pixels in the lane <-> digit map of the synthesis' fused store (eight lanes load 128
+//             contiguous bytes; the loads of the NEXT item are issued behind this pass and complete behind the others),
+//   pass B^H, A^H  radix 16 with the conjugate twiddles in front (decimation in time): Z_k in natural order,
+//   split     X_m = 1/2 [(Z_m + conj Z_{N-m}) - i e^{-i pi m / N} (Z_m - conj Z_{N-m})], G_m = w_ring (4 pi / npix)
+//             e^{-i m phi0} X_m for m < mcut(ring) <= N + 1 (no aliasing on a belt ring), stored as whole 64-byte cells.
+// Every twiddle and phase is a per-thread constant of the kernel (phi0 of a belt ring is 0 or pi / (2 N)).
+// ------------------------------------------------------------------------------------
+template <int N, int NCH, int T>
+__global__ void __launch_bounds__(T)
+ringana_direct_ct(const int32_t *__restrict__ ring_list, int nlist, int lmax, int G, int nnu, int nvalid, long npix,
+                  const int64_t *__restrict__ start_a, const double *__restrict__ phi0_a, const double *maps, double *inter,
+                  const int32_t *__restrict__ mcut, const double *__restrict__ ring_w, int nring) {
+    constexpr int PK = K5_PK_DIRECT;
+    constexpr int R0 = Sch<N>::R0, R1 = Sch<N>::R1, R2 = Sch<N>::R2;
+    static_assert(R0 == 16 && R1 == 16, "digit map of the fused load assumes 16 x 16 x R2");
+    constexpr int Q0 = N / R0;
+    static_assert(Q0 % 128 == 0, "first-pass stride must be a multiple of the padding period");
+    constexpr int BS = fpc(N) + 1 + K5_CH_SKEW;
+    constexpr int TOT0 = NCH * 256, IT0 = (TOT0 + T - 1) / T;
+    static_assert(TOT0 % T == 0, "every thread loads whole butterflies");
+    constexpr int MO = N / T;                // cells per thread (plus m = N on one thread)
+    extern __shared__ __attribute__((aligned(16))) double2 sm[];
+    const int tid0 = threadIdx.x;
+    const int L = lmax + 1;
+    const int ngrp = (nnu + NCH - 1) / NCH;
+    const int nitems = nlist * ngrp;
+
+    double2 wA, wB;         // e^{2 pi i j0 / N}, e^{2 pi i j1 / (N / R0)} (the passes conjugate them)
+    double2 wS, wSstep;     // e^{-i pi tid / N} and its step over T cells: the split twiddle
+    double2 phS, phSstep;   // e^{-i tid pi / (2 N)} and its step: the phase of the shifted rings
+    {
+        const int j0 = tid0 & (Q0 - 1), j1 = tid0 & (Q0 / R1 - 1);
+        double s, c;
+        sincospi(2.0 * (double)j0 / (double)N, &s, &c);
+        wA = make_double2(c, s);
+        sincospi(2.0 * (double)j1 / (double)Q0, &s, &c);
+        wB = make_double2(c, s);
+        sincospi((double)tid0 / (double)N, &s, &c);
+        wS = make_double2(c, -s);
+        sincospi((double)T / (double)N, &s, &c);
+        wSstep = make_double2(c, -s);
+        sincospi((double)tid0 / (2.0 * N), &s, &c);
+        phS = make_double2(c, -s);
+        sincospi((double)T / (2.0 * N), &s, &c);
+        phSstep = make_double2(c, -s);
+    }
+    // the pixels of one item: butterfly idx = tid + it T of pass C^H holds z_j, j = k0 + 16 k1 + 256 r
+    double2 pf[IT0][R2];
+    auto prefetch = [&](int item, int tid) {
+        const int ring = ring_list[item / ngrp];
+        const int ch0 = (item % ngrp) * NCH;
+        const long start = start_a[ring];
+#pragma unroll
+        for (int it = 0; it < IT0; it++) {
+            const int idx = tid + it * T;
+            const int ch = idx >> 8;
+            const int k0 = (idx & 7) | ((idx >> 3) & 8);
+            const int k1 = ((idx >> 3) & 7) | ((idx >> 4) & 8);
+            // (a padding channel reads the last valid one: the loads stay unconditional, its cells are zeroed at the store)
+            const int chv = min(ch0 + ch, nvalid - 1);
+            const double *src = maps + (size_t)chv * npix + start + 2 * (k0 + 16 * k1);
+#pragma unroll
+            for (int r = 0; r < R2; r++) pf[it][r] = *reinterpret_cast<const double2 *>(src + 512 * r);
+        }
+    };
+    int vitem = blockIdx.x;
+    if (vitem < nitems) prefetch(vitem, tid0);
+    for (; vitem < nitems; vitem += gridDim.x) {
+        int tid = tid0;
+        asm volatile("" : "+v"(tid));          // (addresses of the passes are not loop invariants: see ringfft_direct_ct)
+        const int item = vitem;
+        const int ring = ring_list[item / ngrp];
+        const int ch0 = (item % ngrp) * NCH;
+        const bool shifted = phi0_a[ring] != 0.0;
+        const int Lr = mcut[ring];
+        const double wr = (ring_w ? ring_w[min(ring, nring - 1 - ring)] : 1.0) * (4.0 * M_PI / (double)npix);
+        __syncthreads();                       // previous item's LDS reads are done
+        // ---- pass C^H from the prefetched registers
+#pragma unroll
+        for (int it = 0; it < IT0; it++) {
+            const int idx = tid + it * T;
+            const int ch = idx >> 8;
+            const int k0 = (idx & 7) | ((idx >> 3) & 8);
+            const int k1 = ((idx >> 3) & 7) | ((idx >> 4) & 8);
+            double2 *p = sm + ch * BS + fpad((k0 * 16 + k1) * R2);
+            DftR<R2, -1>::run(pf[it]);
+#pragma unroll
+            for (int r = 0; r < R2; r++) p[fpc(r)] = pf[it][r];
+        }
+        // the next item's pixels (unconditional: the last iteration re-reads an item, so that the loads can be counted)
+        prefetch(min(vitem + (int)gridDim.x, nitems - 1), tid);
+        __syncthreads();
+        ct_pass<PK, N, NCH, BS, Q0, R1, -1, true, T>(sm, wB, tid);
+        __syncthreads();
+        ct_pass<PK, N, NCH, BS, N, R0, -1, true, T>(sm, wA, tid);
+        __syncthreads();
+        // ---- split + phase + cell store
+        {
+            double *cell0 = inter + ((size_t)ring * G + (ch0 >> 2)) * L * 8 + (ch0 & 3);
+            double2 w = wS, ph = shifted ? phS : make_double2(1.0, 0.0);
+            const double2 phstep = shifted ? phSstep : make_double2(1.0, 0.0);
+            asm volatile("" : "+v"(w.x), "+v"(w.y), "+v"(ph.x), "+v"(ph.y));
+            auto emit = [&](int m, const double2 wm, const double2 phm) {
+                const int ka = m == N ? 0 : m;                 // Z_N := Z_0
+                const int kb = m == 0 ? 0 : N - m;
+                double re[NCH], im[NCH];
+#pragma unroll
+                for (int c = 0; c < NCH; c++) {
+                    const double2 za = sm[c * BS + fpad(ka)], zb = sm[c * BS + fpad(kb)];
+                    const double2 sum = make_double2(za.x + zb.x, za.y - zb.y);
+                    const double2 dif = make_double2(za.x - zb.x, za.y + zb.y);
+                    const double2 t = cmul(dif, wm);
+                    const double2 X = make_double2(0.5 * (sum.x + t.y), 0.5 * (sum.y - t.x));
+                    const double2 g = cmul(X, make_double2(phm.x * wr, phm.y * wr));
+                    const bool live = ch0 + c < nvalid;
+                    re[c] = live ? g.x : 0.0;
+                    im[c] = live ? g.y : 0.0;
+                }
+                double *cell = cell0 + (size_t)m * 8;
+                if (NCH == 4) {
+                    *reinterpret_cast<double4 *>(cell) = make_double4(re[0], re[1 % NCH], re[2 % NCH], re[3 % NCH]);
+                    *reinterpret_cast<double4 *>(cell + 4) = make_double4(im[0], im[1 % NCH], im[2 % NCH], im[3 % NCH]);
+                } else if (NCH == 2) {
+                    *reinterpret_cast<double2 *>(cell) = make_double2(re[0], re[1 % NCH]);
+                    *reinterpret_cast<double2 *>(cell + 4) = make_double2(im[0], im[1 % NCH]);
+                } else {
+                    cell[0] = re[0];
+                    cell[4] = im[0];
+                }
+            };
+#pragma unroll
+            for (int u = 0; u < MO; u++) {
+                const int m = tid + u * T;
+                if (m < Lr) emit(m, w, ph);
+                w = cmul(w, wSstep);
+                ph = cmul(ph, phstep);
+            }
+            // m = N: e^{-i pi} = -1 and e^{-i N phi0} = e^{-i pi / 2} = -i on a shifted ring
+            if (tid == 0 && N < Lr) emit(N, make_double2(-1.0, 0.0), shifted ? make_double2(0.0, -1.0) : make_double2(1.0, 0.0));
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // host side: launch one class with the compile-time kernel if there is one for it
 // ------------------------------------------------------------------------------------
 template <int N, int NCH, int MC, int T>
@@ -1016,6 +1162,35 @@ int sht_ringfft_ct(corahip_ctx *ctx, const corahip_sht_plan *p, const corahip_sh
         else if (c.P == 1024) rc = launch_blu<1024, 4, 2, 256>(ctx, st, 0, p, c, inter, G, nnu, maps);   // (256 threads, two workgroups per CU: 0.61 -> 0.54 ms)
         else return 0;
     }
+    if (rc) return rc;
+    *took = true;
+    return 0;
+}
+
+// K5^T with the compile-time kernel of the class, if there is one (the belt); *took as in sht_ringfft_ct
+template <int N, int NCH, int T>
+static int launch_ana_direct(corahip_ctx *ctx, hipStream_t stream, const corahip_sht_plan *p, const corahip_sht_plan::ring_class &c,
+                             const double *maps, int nvalid, int nnu_pad, const double *ring_w, int G, double *inter) {
+    constexpr int PK = K5_PK_DIRECT;
+    constexpr int BS = fpc(N) + 1 + K5_CH_SKEW;
+    const size_t shm = sizeof(double2) * (size_t)NCH * BS;
+    const long nitems = (long)c.count * ((nnu_pad + NCH - 1) / NCH);
+    dim3 grid((unsigned)std::min<long>(nitems, (long)ctx->num_cu * std::max<int>(1, (int)((160 * 1024) / shm))));
+    HIP_TRY(hipFuncSetAttribute((const void *)ringana_direct_ct<N, NCH, T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    ringana_direct_ct<N, NCH, T><<<grid, T, shm, stream>>>(c.d_list, c.count, p->lmax, G, nnu_pad, nvalid, p->npix, p->d_start, p->d_phi0,
+                                                           maps, inter, p->d_mcut, ring_w, 4 * p->nside - 1);
+    LAUNCH_CHECK();
+    return 0;
+}
+int sht_ringana_ct(corahip_ctx *ctx, const corahip_sht_plan *p, const corahip_sht_plan::ring_class &c, const double *maps, int nvalid,
+                   int nnu_pad, const double *ring_w, int G, double *inter, bool *took) {
+    static const bool off = getenv("CORAHIP_K5_GENERIC") != nullptr;
+    *took = false;
+    if (off || nvalid < 1) return 0;
+    int rc;
+    if (c.P == 0 && c.N == 2048) rc = launch_ana_direct<2048, 4, 512>(ctx, ctx->stream, p, c, maps, nvalid, nnu_pad, ring_w, G, inter);
+    else if (c.P == 0 && c.N == 4096) rc = launch_ana_direct<4096, 2, 512>(ctx, ctx->stream, p, c, maps, nvalid, nnu_pad, ring_w, G, inter);
+    else return 0;
     if (rc) return rc;
     *took = true;
     return 0;
