@@ -1167,6 +1167,225 @@ int sht_ringfft_ct(corahip_ctx *ctx, const corahip_sht_plan *p, const corahip_sh
     return 0;
 }
 
+// ------------------------------------------------------------------------------------
+// K5^T, Bluestein class (cap rings): Z_k = sum_j z_j e^{-2 pi i j k / h} as the convolution ringfft_blu_ct runs - the
+// same five passes on the same chirp / filter tables, applied to conj(z_j) b_j (ringana_kernel's formulation) - with the
+// pixels in front (natural order, prefetched one item ahead) and, behind the last inverse pass, Z_k = conj(W_k b_k) / P
+// back in LDS for the split X_m = 1/2 [(Z_m + conj Z_{h-m}) - i e^{-i pi m / h} (Z_m - conj Z_{h-m})] and the cell
+// store.  Phase e^{-i m phi0} and split twiddle (its square: phi0 = pi / 2h on a cap ring) from the plan's fold table.
+// ------------------------------------------------------------------------------------
+template <int P, int NCH, int T>
+__global__ void __launch_bounds__(T)
+ringana_blu_ct(const int32_t *__restrict__ ring_list, int nlist, int nside, int lmax, int G, int nnu, int nvalid, long npix,
+               const int32_t *__restrict__ nphi_a, const int64_t *__restrict__ start_a, const double *maps, double *inter,
+               const int64_t *__restrict__ boff, const int64_t *__restrict__ foff, const double2 *chirp, const double2 *filt,
+               const int32_t *__restrict__ mcut, const double2 *foldph, const double2 *foldstep, const double *__restrict__ ring_w) {
+    constexpr int PK = K5_PK_BLU;
+    constexpr int R0 = Sch<P>::R0, R1 = Sch<P>::R1, R2 = Sch<P>::R2;
+    static_assert(R0 <= 16, "the lengths above 4096 keep the generic kernel");
+    constexpr int Q0 = P / R0;
+    constexpr int BS = fpc(P) + K5_CH_SKEW;
+    constexpr int HALF = (R0 / 2) * Q0;          // h <= HALF: the non-zero half of the padded input
+    constexpr int U = (HALF + T - 1) / T;        // pixel pairs per thread and channel
+    constexpr int NB = P / R2;
+    static_assert(NB <= T, "one middle-stage butterfly per thread and channel group");
+    extern __shared__ __attribute__((aligned(16))) double2 sm[];
+    const int tid0 = threadIdx.x;
+    const int L = lmax + 1;
+    const int ngrp = (nnu + NCH - 1) / NCH;
+    const int nitems = nlist * ngrp;
+    const int nring = 4 * nside - 1;
+    const double invP = 1.0 / (double)P;
+
+    double2 wA, wB;     // e^{2 pi i j0 / P}, e^{2 pi i j1 / (P / R0)}
+    {
+        const int j0 = tid0 & (Q0 - 1), j1 = tid0 & (Q0 / R1 - 1);
+        double s, c;
+        sincospi(2.0 * (double)j0 / (double)P, &s, &c);
+        wA = make_double2(c, s);
+        sincospi(2.0 * (double)j1 / (double)Q0, &s, &c);
+        wB = make_double2(c, s);
+    }
+    double2 pf[NCH][U];   // z_j, j = tid + u T, of the next item (index clamped; zeroed where j >= h at the commit)
+    double2 cbn[U];       // chirp b_j of the same positions
+    auto prefetch = [&](int item, int t) {
+        const int ring = ring_list[item / ngrp];
+        const int ch0 = (item % ngrp) * NCH;
+        const int hh = nphi_a[ring] >> 1;
+        const long start = start_a[ring];
+        const int ic = ring + 1 < nside ? ring + 1 : 4 * nside - (ring + 1);
+        const double2 *b = chirp + boff[ic - 1];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int j = min(t + u * T, hh - 1);
+            cbn[u] = b[j];
+#pragma unroll
+            for (int c = 0; c < NCH; c++)
+                pf[c][u] = *reinterpret_cast<const double2 *>(maps + (size_t)min(ch0 + c, nvalid - 1) * npix + start + 2 * j);
+        }
+    };
+    int vitem = blockIdx.x;
+    if (vitem < nitems) prefetch(ct_remap<NCH>(vitem, nitems), tid0);
+    for (; vitem < nitems; vitem += gridDim.x) {
+        int tid = tid0;                                   // opaque per item: see ringfft_direct_ct
+        asm volatile("" : "+v"(tid));
+        const int item = ct_remap<NCH>(vitem, nitems);
+        const int ring = ring_list[item / ngrp];
+        const int ch0 = (item % ngrp) * NCH;
+        const int n = nphi_a[ring];
+        const int h = n >> 1;
+        const int icap = ring + 1 < nside ? ring + 1 : 4 * nside - (ring + 1);
+        const int Lr = mcut[ring];
+        const double wr = (ring_w ? ring_w[min(ring, nring - 1 - ring)] : 1.0) * (4.0 * M_PI / (double)npix);
+        const double2 *bch = chirp + boff[icap - 1];
+        const double2 *f = filt + foff[icap - 1] + (size_t)(tid % NB) * R2;
+        double2 fl[R2];
+#pragma unroll
+        for (int r = 0; r < R2; r++) fl[r] = f[r];
+        const double2 fph0 = foldph[(size_t)(icap - 1) * 512 + tid];
+        const double2 fphs = foldstep[(icap - 1) * 2 + (T == 512 ? 1 : 0)];
+        __syncthreads();                                  // previous item's LDS reads are done
+        // ---- conj(z_j) b_j at position j, zeros on [h, HALF)
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int j = tid + u * T;
+            if (j < HALF) {
+#pragma unroll
+                for (int c = 0; c < NCH; c++) {
+                    double2 zv = make_double2(0.0, 0.0);
+                    if (j < h) zv = cmul(make_double2(pf[c][u].x, -pf[c][u].y), cbn[u]);
+                    sm[c * BS + fpad(j)] = zv;
+                }
+            }
+        }
+        // the next item's pixels and chirps (unconditional: the last iteration re-reads an item)
+        prefetch(ct_remap<NCH>(min(vitem + (int)gridDim.x, nitems - 1), nitems), tid);
+        __syncthreads();
+        // ---- forward pass 1 (sign -), inputs r >= R0 / 2 are the zero padding and are not read
+        {
+            constexpr int TOT = NCH * Q0;
+            constexpr int IT = (TOT + T - 1) / T;
+            const double2 w = cconj(wA);
+#pragma unroll
+            for (int it = 0; it < IT; it++) {
+                const int idx = tid + it * T;
+                if ((TOT % T) != 0 && idx >= TOT) break;
+                const int ch = idx / Q0, j0 = idx & (Q0 - 1);
+                double2 *p = sm + ch * BS + fpad(j0);
+                double2 x[R0];
+#pragma unroll
+                for (int r = 0; r < R0 / 2; r++) x[r] = p[fpc(r * Q0)];
+#pragma unroll
+                for (int r = R0 / 2; r < R0; r++) x[r] = make_double2(0.0, 0.0);
+                DftR<R0, -1>::run(x);
+                tw_apply<R0>(x, w);
+#pragma unroll
+                for (int r = 0; r < R0; r++) p[fpc(r * Q0)] = x[r];
+            }
+        }
+        __syncthreads();
+        ct_pass<PK, P, NCH, BS, Q0, R1, -1, false, T>(sm, wB, tid);
+        __syncthreads();
+        // ---- last forward pass, filter, first inverse pass in registers
+        {
+            constexpr int CPI = T / NB, IT = (NCH + CPI - 1) / CPI;
+#pragma unroll
+            for (int it = 0; it < IT; it++) {
+                const int chl = tid / NB, t = tid - chl * NB;
+                const int ch = it * CPI + chl;
+                if (chl >= CPI || ch >= NCH) break;
+                double2 *p = sm + ch * BS + fpad(t * R2);
+                double2 x[R2];
+#pragma unroll
+                for (int r = 0; r < R2; r++) x[r] = p[fpc(r)];
+                DftR<R2, -1>::run(x);
+#pragma unroll
+                for (int r = 0; r < R2; r++) x[r] = cmul(x[r], fl[r]);
+                DftR<R2, 1>::run(x);
+#pragma unroll
+                for (int r = 0; r < R2; r++) p[fpc(r)] = x[r];
+            }
+        }
+        // chirp of the outputs this thread forms in the last pass: j0 + r Q0 < h, r < R0 / 2
+        double2 ob[R0 / 2];
+        {
+            const int j0 = tid & (Q0 - 1);
+#pragma unroll
+            for (int r = 0; r < R0 / 2; r++) ob[r] = bch[min(j0 + r * Q0, h - 1)];
+        }
+        __syncthreads();
+        ct_pass<PK, P, NCH, BS, Q0, R1, 1, true, T>(sm, wB, tid);
+        __syncthreads();
+        // ---- last inverse pass (sign +): Z_k = conj(W_k b_k) / P for the outputs k = j0 + r Q0 < h, back to position k
+        {
+            constexpr int TOT = NCH * Q0;
+            constexpr int IT = (TOT + T - 1) / T;
+#pragma unroll
+            for (int it = 0; it < IT; it++) {
+                const int idx = tid + it * T;
+                if ((TOT % T) != 0 && idx >= TOT) break;
+                const int ch = idx / Q0, j0 = idx & (Q0 - 1);
+                double2 *p = sm + ch * BS + fpad(j0);
+                double2 x[R0];
+#pragma unroll
+                for (int r = 0; r < R0; r++) x[r] = p[fpc(r * Q0)];
+                tw_apply<R0>(x, wA);
+                DftR<R0, 1>::run(x);
+#pragma unroll
+                for (int r = 0; r < R0 / 2; r++) {
+                    const double2 zv = cmul(x[r], ob[r]);
+                    p[fpc(r * Q0)] = make_double2(zv.x * invP, -zv.y * invP);
+                }
+            }
+        }
+        __syncthreads();
+        // ---- split + phase + cell store (m >= n aliases back; bins above h are the conjugates of n - k)
+        {
+            double *cell0 = inter + ((size_t)ring * G + (ch0 >> 2)) * L * 8 + (ch0 & 3);
+            double2 ph = cconj(fph0);
+            const double2 phstep = cconj(fphs);
+            double2 w = csqr(ph);
+            const double2 wstep = csqr(phstep);
+            for (int m = tid; m < Lr; m += T) {
+                const int k = m < n ? m : m % n;
+                const bool cj = k > h;
+                const int kk = cj ? n - k : k;
+                const int ka = kk == h ? 0 : kk;
+                const int kb = kk == 0 ? 0 : h - kk;
+                const double2 wm = make_double2(w.x, cj ? -w.y : w.y);
+                const double2 phm = make_double2(ph.x * wr, ph.y * wr);
+                ph = cmul(ph, phstep);
+                w = cmul(w, wstep);
+                double re[NCH], im[NCH];
+#pragma unroll
+                for (int c = 0; c < NCH; c++) {
+                    const double2 za = sm[c * BS + fpad(ka)], zb = sm[c * BS + fpad(kb)];
+                    const double2 sum = make_double2(za.x + zb.x, za.y - zb.y);
+                    const double2 dif = make_double2(za.x - zb.x, za.y + zb.y);
+                    const double2 t = cmul(dif, wm);
+                    double2 X = make_double2(0.5 * (sum.x + t.y), 0.5 * (sum.y - t.x));
+                    if (cj) X.y = -X.y;
+                    const double2 g = cmul(X, phm);
+                    const bool live = ch0 + c < nvalid;
+                    re[c] = live ? g.x : 0.0;
+                    im[c] = live ? g.y : 0.0;
+                }
+                double *cell = cell0 + (size_t)m * 8;
+                if (NCH == 4) {
+                    *reinterpret_cast<double4 *>(cell) = make_double4(re[0], re[1 % NCH], re[2 % NCH], re[3 % NCH]);
+                    *reinterpret_cast<double4 *>(cell + 4) = make_double4(im[0], im[1 % NCH], im[2 % NCH], im[3 % NCH]);
+                } else if (NCH == 2) {
+                    *reinterpret_cast<double2 *>(cell) = make_double2(re[0], re[1 % NCH]);
+                    *reinterpret_cast<double2 *>(cell + 4) = make_double2(im[0], im[1 % NCH]);
+                } else {
+                    cell[0] = re[0];
+                    cell[4] = im[0];
+                }
+            }
+        }
+    }
+}
+
 // K5^T with the compile-time kernel of the class, if there is one (the belt); *took as in sht_ringfft_ct
 template <int N, int NCH, int T>
 static int launch_ana_direct(corahip_ctx *ctx, hipStream_t stream, const corahip_sht_plan *p, const corahip_sht_plan::ring_class &c,
@@ -1182,15 +1401,42 @@ static int launch_ana_direct(corahip_ctx *ctx, hipStream_t stream, const corahip
     LAUNCH_CHECK();
     return 0;
 }
+template <int P, int NCH, int T>
+static int launch_ana_blu(corahip_ctx *ctx, hipStream_t stream, const corahip_sht_plan *p, const corahip_sht_plan::ring_class &c,
+                          const double *maps, int nvalid, int nnu_pad, const double *ring_w, int G, double *inter, bool blu3) {
+    constexpr int PK = K5_PK_BLU;
+    constexpr int BS = fpc(P) + K5_CH_SKEW;
+    const size_t shm = sizeof(double2) * (size_t)NCH * BS;
+    const long nitems = (long)c.count * ((nnu_pad + NCH - 1) / NCH);
+    dim3 grid((unsigned)std::min<long>(nitems, (long)ctx->num_cu * std::max<int>(1, (int)((160 * 1024) / shm))));
+    HIP_TRY(hipFuncSetAttribute((const void *)ringana_blu_ct<P, NCH, T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    ringana_blu_ct<P, NCH, T><<<grid, T, shm, stream>>>(c.d_list, c.count, p->nside, p->lmax, G, nnu_pad, nvalid, p->npix, p->d_nphi,
+                                                        p->d_start, maps, inter, p->d_blu_boff, blu3 ? p->d_blu3_foff : p->d_blu_foff,
+                                                        p->d_bchirp, blu3 ? p->d_bfilt3 : p->d_bfilt, p->d_mcut, p->d_foldph,
+                                                        p->d_foldstep, ring_w);
+    LAUNCH_CHECK();
+    return 0;
+}
 int sht_ringana_ct(corahip_ctx *ctx, const corahip_sht_plan *p, const corahip_sht_plan::ring_class &c, const double *maps, int nvalid,
                    int nnu_pad, const double *ring_w, int G, double *inter, bool *took) {
     static const bool off = getenv("CORAHIP_K5_GENERIC") != nullptr;
+    static const bool no3 = getenv("CORAHIP_K5_NO3") != nullptr;
     *took = false;
     if (off || nvalid < 1) return 0;
+    hipStream_t st = ctx->stream;
     int rc;
-    if (c.P == 0 && c.N == 2048) rc = launch_ana_direct<2048, 4, 512>(ctx, ctx->stream, p, c, maps, nvalid, nnu_pad, ring_w, G, inter);
-    else if (c.P == 0 && c.N == 4096) rc = launch_ana_direct<4096, 2, 512>(ctx, ctx->stream, p, c, maps, nvalid, nnu_pad, ring_w, G, inter);
+#define ANA_ARGS ctx, st, p, c, maps, nvalid, nnu_pad, ring_w, G, inter
+    if (c.P == 0 && c.N == 2048) rc = launch_ana_direct<2048, 4, 512>(ANA_ARGS);
+    else if (c.P == 0 && c.N == 4096) rc = launch_ana_direct<4096, 2, 512>(ANA_ARGS);
+    else if (c.P3 == 2560 && !no3) rc = launch_ana_blu<2560, 2, 512>(ANA_ARGS, true);
+    else if (c.P3 == 3584 && !no3) rc = launch_ana_blu<3584, 2, 512>(ANA_ARGS, true);
+    else if (c.P3 == 3072 && !no3) rc = launch_ana_blu<3072, 2, 512>(ANA_ARGS, true);
+    else if (c.P3 == 1536 && !no3) rc = launch_ana_blu<1536, 4, 512>(ANA_ARGS, true);
+    else if (c.P == 4096 && c.P3 <= 4096) rc = launch_ana_blu<4096, 2, 512>(ANA_ARGS, false);
+    else if (c.P == 2048) rc = launch_ana_blu<2048, 4, 512>(ANA_ARGS, false);
+    else if (c.P == 1024) rc = launch_ana_blu<1024, 4, 256>(ANA_ARGS, false);
     else return 0;
+#undef ANA_ARGS
     if (rc) return rc;
     *took = true;
     return 0;
