@@ -32,6 +32,10 @@ struct corahip_linefft_plan {
     double2 *rtw = nullptr;    // [n/2 + 1]  e^{+2 pi i k / 2n}: (un)packing of a real transform of length 2n
 };
 
+// contiguous c2r pass of the flat-sky transforms with the compile-time FFT passes of sht_ringfft_ct.hip
+struct corahip_ctx;
+int flat_c2r_ct(corahip_ctx *ctx, const double *spec, double *out, long nlines, int h, double scale, bool *took);
+
 #define CORAHIP_NSCRATCH 10
 struct corahip_ctx {
     int device = 0;

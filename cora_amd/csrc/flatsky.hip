@@ -649,6 +649,22 @@ static long prod(const int64_t *d, int a, int b) {
     return p;
 }
 
+// half-complex -> real along the contiguous axis (real length n): even lengths through ONE complex transform of half
+// the length - with the compile-time passes where n / 2 has a schedule -, odd lengths as a full-length Hermitian line
+static int last_axis_c2r(corahip_ctx *ctx, double *spec, double *out, long nlines, int n) {
+    if (n % 2 == 0) {
+        bool took = false;
+        {
+            StageTimer pass_timer(ctx, "fft_c2r");
+            int rc = flat_c2r_ct(ctx, spec, out, nlines, n / 2, 1.0 / n, &took);
+            if (rc) return rc;
+        }
+        if (took) return 0;
+        return launch_linefft<3>(ctx, spec, out, nlines, n / 2, 1, 1, 1.0 / n);
+    }
+    return launch_linefft<1>(ctx, spec, out, nlines, n, 1, 1, 1.0 / n);
+}
+
 extern "C" {
 
 int corahip_fft_c2c(corahip_ctx *ctx, double *data, int ndim, const int64_t *dims, int axis, int inverse) {
@@ -677,9 +693,7 @@ int corahip_irfftn(corahip_ctx *ctx, double *spec, int ndim, const int64_t *rdim
         if (rc) return rc;
     }
     const int n = (int)rdims[ndim - 1];
-    if (n % 2 == 0)   // even length: one complex transform of half the length
-        return launch_linefft<3>(ctx, spec, out, prod(rdims, 0, ndim - 1), n / 2, 1, 1, 1.0 / n);
-    return launch_linefft<1>(ctx, spec, out, prod(rdims, 0, ndim - 1), n, 1, 1, 1.0 / n);
+    return last_axis_c2r(ctx, spec, out, prod(rdims, 0, ndim - 1), n);
 }
 
 int corahip_randomfield_irfftn(corahip_ctx *ctx, const double *kweight, int ndim, const int64_t *rdims, uint64_t seed,
@@ -704,8 +718,7 @@ int corahip_randomfield_irfftn(corahip_ctx *ctx, const double *kweight, int ndim
         if ((rc = launch_linefft<0>(ctx, spec, spec, prod(cd, 0, ax), n, prod(cd, ax + 1, ndim), 1, 1.0 / n))) return rc;
     }
     const int n = (int)rdims[ndim - 1];
-    if (n % 2 == 0) return launch_linefft<3>(ctx, spec, out, prod(rdims, 0, ndim - 1), n / 2, 1, 1, 1.0 / n);
-    return launch_linefft<1>(ctx, spec, out, prod(rdims, 0, ndim - 1), n, 1, 1, 1.0 / n);
+    return last_axis_c2r(ctx, spec, out, prod(rdims, 0, ndim - 1), n);
 }
 
 int corahip_rfftn(corahip_ctx *ctx, const double *in, int ndim, const int64_t *rdims, int naxes, double *spec) {

@@ -72,6 +72,19 @@ template <>
 struct Sch<4096> {
     static constexpr int R0 = 16, R1 = 16, R2 = 16;
 };
+// 256 and 512 (flat-sky lines only: linec2r_ct below): 16 x 16 and 16 x 16 x 2
+template <>
+struct Sch<256> {
+    static constexpr int R0 = 16, R1 = 16, R2 = 1;
+};
+template <>
+struct Sch<512> {
+    static constexpr int R0 = 16, R1 = 16, R2 = 2;
+};
+template <int SIGN>
+struct DftR<1, SIGN> {
+    __device__ __forceinline__ static void run(double2 (&)[1]) {}
+};
 // 3 * 2^k: the factor 3 sits in the first pass (radix 12), whose stride P / 12 is a power of two, so every
 // butterfly address is still base + immediates; the Bluestein length of a ring is then at most 1.5 (not 2) times
 // 2 h - 1
@@ -1059,6 +1072,166 @@ ringana_direct_ct(const int32_t *__restrict__ ring_list, int nlist, int lmax, in
             if (tid == 0 && N < Lr) emit(N, make_double2(-1.0, 0.0), shifted ? make_double2(0.0, -1.0) : make_double2(1.0, 0.0));
         }
     }
+}
+
+// ------------------------------------------------------------------------------------
+// Flat-sky fields (cora/core/gaussianfield.py:102-120, numpy.fft.irfftn's last axis): the half-complex -> real transform
+// of EVEN length 2 N along the contiguous axis as ringfft_direct_ct's three passes - Hermitian step fused into the
+// first, pixel-order store fused into the last - on NCH adjacent lines per item.  in: lines of N + 1 complex bins, out:
+// lines of 2 N reals, out = scale * irfft (numpy semantics: the imaginary parts of the DC and Nyquist bins are ignored).
+// The generic line kernel (flatsky.hip: radix-4 LDS stages, a barrier each) ran this pass at 3.1 TB/s.
+// ------------------------------------------------------------------------------------
+template <int N, int NCH, int T>
+__global__ void __launch_bounds__(T)
+linec2r_ct(const double2 *in, double *out, long nlines, double scale) {
+    constexpr int PK = 1;                    // (strides down to 16 elements: the one-slot-per-16 padding is additive for them)
+    constexpr int R0 = Sch<N>::R0, R1 = Sch<N>::R1, R2 = Sch<N>::R2;
+    static_assert(R0 == 16 && R1 == 16 && N == 256 * R2, "digit map of the fused store assumes 16 x 16 x R2");
+    constexpr int Q0 = N / R0;
+    static_assert(Q0 % 16 == 0, "first-pass stride must be a multiple of the padding period");
+    constexpr int BS = fpc(N) + 1 + K5_CH_SKEW;
+    constexpr int U = NCH * N / T;           // bins 0 .. N-1 per thread (the Nyquist bins: one more load on NCH threads)
+    static_assert((NCH * N) % T == 0 && (N & (N - 1)) == 0, "whole loads per thread");
+    extern __shared__ __attribute__((aligned(16))) double2 sm[];
+    const int tid0 = threadIdx.x;
+    const long nitems = (nlines + NCH - 1) / NCH;
+
+    double2 wH, wA, wB;     // e^{i pi j0 / N}, e^{2 pi i j0 / N}, e^{2 pi i j1 / (N / R0)}
+    {
+        const int j0 = tid0 & (Q0 - 1), j1 = tid0 & (Q0 / R1 - 1);
+        double s, c;
+        sincospi((double)j0 / (double)N, &s, &c);
+        wH = make_double2(c, s);
+        sincospi(2.0 * (double)j0 / (double)N, &s, &c);
+        wA = make_double2(c, s);
+        sincospi(2.0 * (double)j1 / (double)Q0, &s, &c);
+        wB = make_double2(c, s);
+    }
+    double2 pf[U], pfn;
+    auto prefetch = [&](long item, int tid) {
+        const long line0 = item * NCH;
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int e = tid + u * T;
+            const long line = min(line0 + e / N, nlines - 1);
+            pf[u] = in[line * (N + 1) + (e & (N - 1))];
+        }
+        pfn = in[min(line0 + (tid & (NCH - 1)), nlines - 1) * (N + 1) + N];
+    };
+    long vitem = blockIdx.x;
+    if (vitem < nitems) prefetch(vitem, tid0);
+    for (; vitem < nitems; vitem += gridDim.x) {
+        int tid = tid0;                                   // opaque per item: see ringfft_direct_ct
+        asm volatile("" : "+v"(tid));
+        const long line0 = vitem * NCH;
+        __syncthreads();                                  // previous item's LDS reads are done
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int e = tid + u * T;
+            const int c = e / N, k = e & (N - 1);
+            double2 v = pf[u];
+            if (k == 0) v.y = 0.0;
+            sm[c * BS + fpad(k)] = v;
+        }
+        if (tid < NCH) sm[tid * BS + fpad(N)] = make_double2(pfn.x, 0.0);
+        prefetch(min(vitem + (long)gridDim.x, nitems - 1), tid);
+        __syncthreads();
+        // ---- pass 1 with the Hermitian step (ringfft_direct_ct): Z_k = (X_k + conj X_{N-k}) + i w^k (X_k - conj X_{N-k})
+        {
+            constexpr int TOT = NCH * Q0;
+            constexpr int IT = (TOT + T - 1) / T;
+            double2 x[IT][R0];
+            double2 wh = wH;
+            asm volatile("" : "+v"(wh.x), "+v"(wh.y));
+#pragma unroll
+            for (int it = 0; it < IT; it++) {
+                const int idx = tid + it * T;
+                if ((TOT % T) != 0 && idx >= TOT) break;
+                const int ch = idx / Q0, j0 = idx & (Q0 - 1);
+                const double2 *pa = sm + ch * BS + fpad(j0);
+                const double2 *pb = sm + ch * BS + fpad(Q0 - j0);
+#pragma unroll
+                for (int r = 0; r < R0; r++) {
+                    const double2 xa = pa[fpc(r * Q0)];
+                    const double2 xb = pb[fpc((R0 - 1 - r) * Q0)];
+                    const double2 w = cmul(wh, make_double2(kCos16[r], kSin16[r]));
+                    const double2 sum = make_double2(xa.x + xb.x, xa.y - xb.y);
+                    const double2 dif = make_double2(xa.x - xb.x, xa.y + xb.y);
+                    const double2 t = cmul(dif, w);
+                    x[it][r] = make_double2(sum.x - t.y, sum.y + t.x);
+                }
+            }
+            __syncthreads();                              // every raw X has been read
+#pragma unroll
+            for (int it = 0; it < IT; it++) {
+                const int idx = tid + it * T;
+                if ((TOT % T) != 0 && idx >= TOT) break;
+                const int ch = idx / Q0, j0 = idx & (Q0 - 1);
+                double2 *pa = sm + ch * BS + fpad(j0);
+                DftR<R0, 1>::run(x[it]);
+                tw_apply<R0>(x[it], wA);
+#pragma unroll
+                for (int r = 0; r < R0; r++) pa[fpc(r * Q0)] = x[it][r];
+            }
+        }
+        __syncthreads();
+        ct_pass<PK, N, NCH, BS, Q0, R1, 1, false, T>(sm, wB, tid);
+        __syncthreads();
+        // ---- last pass (radix R2 on contiguous elements) with the store: butterfly t = 16 k0 + k1 holds the natural
+        //      indices k0 + 16 k1 + 256 r; eight consecutive lanes store 128 contiguous bytes
+        {
+            constexpr int TOT = NCH * 256;
+            constexpr int IT = (TOT + T - 1) / T;
+#pragma unroll
+            for (int it = 0; it < IT; it++) {
+                const int idx = tid + it * T;
+                if ((TOT % T) != 0 && idx >= TOT) break;
+                const int ch = idx >> 8;
+                const int k0 = (idx & 7) | ((idx >> 3) & 8);
+                const int k1 = ((idx >> 3) & 7) | ((idx >> 4) & 8);
+                const double2 *p = sm + ch * BS + fpad((k0 * 16 + k1) * R2);
+                double2 x[R2];
+#pragma unroll
+                for (int r = 0; r < R2; r++) x[r] = p[fpc(r)];
+                DftR<R2, 1>::run(x);
+                if (line0 + ch < nlines) {
+                    double *o = out + (line0 + ch) * (2L * N) + 2 * (k0 + 16 * k1);
+#pragma unroll
+                    for (int r = 0; r < R2; r++) *reinterpret_cast<double2 *>(o + 512 * r) = make_double2(x[r].x * scale, x[r].y * scale);
+                }
+            }
+        }
+    }
+}
+
+template <int N, int NCH, int T>
+static int launch_linec2r(corahip_ctx *ctx, const double *spec, double *out, long nlines, double scale) {
+    constexpr int PK = 1;
+    constexpr int BS = fpc(N) + 1 + K5_CH_SKEW;
+    const size_t shm = sizeof(double2) * (size_t)NCH * BS;
+    const long nitems = (nlines + NCH - 1) / NCH;
+    const long per_cu = std::max<long>(1, std::min<long>((160 * 1024) / shm, 2048 / T));
+    dim3 grid((unsigned)std::min<long>(nitems, (long)ctx->num_cu * per_cu));
+    HIP_TRY(hipFuncSetAttribute((const void *)linec2r_ct<N, NCH, T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    linec2r_ct<N, NCH, T><<<grid, T, shm, ctx->stream>>>(reinterpret_cast<const double2 *>(spec), out, nlines, scale);
+    LAUNCH_CHECK();
+    return 0;
+}
+// the contiguous half-complex -> real pass of corahip_irfftn for the complex lengths that have a compile-time schedule;
+// *took = false: the generic line kernel takes it
+int flat_c2r_ct(corahip_ctx *ctx, const double *spec, double *out, long nlines, int h, double scale, bool *took) {
+    static const bool off = getenv("CORAHIP_FLAT_GENERIC") != nullptr;
+    *took = false;
+    if (off || nlines < 1) return 0;
+    int rc;
+    if (h == 256) rc = launch_linec2r<256, 16, 256>(ctx, spec, out, nlines, scale);
+    else if (h == 512) rc = launch_linec2r<512, 16, 512>(ctx, spec, out, nlines, scale);
+    else if (h == 1024) rc = launch_linec2r<1024, 8, 512>(ctx, spec, out, nlines, scale);
+    else if (h == 2048) rc = launch_linec2r<2048, 4, 512>(ctx, spec, out, nlines, scale);
+    else return 0;
+    if (rc) return rc;
+    *took = true;
+    return 0;
 }
 
 // ------------------------------------------------------------------------------------

@@ -104,7 +104,10 @@ def test_fft_c2c_every_axis_position_vs_numpy(ctx, n):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("shape", [(8, 6, 10), (16, 16, 16), (30, 20, 14), (5, 7, 9), (128, 128), (1, 4), (100,),
-                                   (4096,), (3, 250), (64, 64, 64), (17, 33, 50), (2, 3, 4, 6), (1, 1, 2)])
+                                   (4096,), (3, 250), (64, 64, 64), (17, 33, 50), (2, 3, 4, 6), (1, 1, 2),
+                                   # last axes 512 / 1024 / 2048 / 4096: the compile-time c2r pass (16 / 16 / 8 / 4 lines per
+                                   # item; line counts that are not multiples of it, and a single line)
+                                   (5, 7, 512), (3, 11, 1024), (21, 2048), (9, 4096), (1, 1024), (33, 512)])
 def test_rfftn_irfftn_vs_numpy(ctx, shape):
     import torch
 
