@@ -598,10 +598,15 @@ static int launch_linefft(corahip_ctx *ctx, const double *in, double *out, long 
                           int inverse, double scale, uint64_t seed = 0) {
     ARG_CHECK(n >= 1 && n <= FS_MAXN);
     if (nouter * inner == 0) return 0;
+    StageTimer pass_timer(ctx, (MODE == 1 || MODE == 3) ? "fft_c2r" : ((MODE == 2 || MODE == 4) ? "fft_r2c" : (MODE == 5 ? "fft_c2c_draw" : (inner == 1 ? "fft_c2c_contig" : "fft_c2c_strided"))));
+    if ((MODE == 0 || MODE == 5) && inner > 1) {     // strided complex pass: the compile-time passes where the length has them
+        bool took = false;
+        int rct = flat_c2c_ct(ctx, in, out, nouter, n, inner, inverse, scale, MODE == 5, seed, &took);
+        if (rct || took) return rct;
+    }
     const corahip_linefft_plan *pl;
     int rc = get_linefft_plan(ctx, n, &pl);
     if (rc) return rc;
-    StageTimer pass_timer(ctx, (MODE == 1 || MODE == 3) ? "fft_c2r" : ((MODE == 2 || MODE == 4) ? "fft_r2c" : (MODE == 5 ? "fft_c2c_draw" : (inner == 1 ? "fft_c2c_contig" : "fft_c2c_strided"))));
     linefft_args A;
     A.in = in;
     A.out = out;

@@ -22,6 +22,7 @@
 // LDS stores are the expensive operation of these kernels (ds_write_b128: 13 cycles per wave-instruction against
 // 4 for ds_read_b128, MI355X_MICROARCH.md section LDS), hence the count of write passes above.
 #include "sht_internal.h"
+#include "rng_dev.h"
 
 static_assert(K5_SWZ == 0, "the compile-time kernels assume the padded LDS layout");
 #define CT_T 512
@@ -1202,6 +1203,170 @@ linec2r_ct(const double2 *in, double *out, long nlines, double scale) {
             }
         }
     }
+}
+
+// ------------------------------------------------------------------------------------
+// Flat-sky fields: complex -> complex along a STRIDED axis (element j of line (o, i) at ((o N + j) inner + i)), NCH
+// lines that are neighbours along the contiguous axis per item: rows of 16 NCH contiguous bytes (the generic kernel's
+// 64 KB tiles hold four lines of 1024: 64-byte segments, 2.8 TB/s).  Natural order in, three DIF passes, the store
+// reads through the digit map.  GEN: the input is generated where it is committed - element e = kweight[e] (N(0,1) +
+// i N(0,1)), the Box-Muller pair of Philox counter e (randomfield_draw_kernel's values: RandomField.getfield,
+// cora/core/gaussianfield.py:115-119) - `in` is then the real k-weight array.  In place allowed.
+// ------------------------------------------------------------------------------------
+template <int N, int NCH, int T, int SIGN, bool GEN>
+__global__ void __launch_bounds__(T)
+linec2c_ct(const double *in, double2 *out, long nouter, long inner, double scale, uint64_t seed) {
+    constexpr int PK = 1;
+    constexpr int R0 = Sch<N>::R0, R1 = Sch<N>::R1, R2 = Sch<N>::R2;
+    static_assert(R0 == 16 && R1 == 16 && N == 256 * R2, "16 x 16 x R2");
+    constexpr int Q0 = N / R0;
+    static_assert(Q0 % 16 == 0 && T % Q0 == 0, "per-thread twiddles");
+    constexpr int BS = fpc(N) + K5_CH_SKEW;
+    constexpr int U = NCH * N / T;
+    static_assert((NCH * N) % T == 0 && (NCH & (NCH - 1)) == 0, "whole loads per thread");
+    extern __shared__ __attribute__((aligned(16))) double2 sm[];
+    double2 *lg_l = sm + NCH * BS, *sc_l = lg_l + 257;       // GEN: the generator's tables (rng_dev.h)
+    const int tid0 = threadIdx.x;
+    const double2 *in2 = reinterpret_cast<const double2 *>(in);
+    const long chunks = (inner + NCH - 1) / NCH;
+    const long ntiles = nouter * chunks;
+    if (GEN) {
+        for (int k = tid0; k < 257; k += T) lg_l[k] = RNG_LOG_TAB[k];
+        for (int k = tid0; k < 256; k += T) sc_l[k] = RNG_SC_TAB[k];
+    }
+    double2 wA, wB;     // e^{2 pi i j0 / N}, e^{2 pi i j1 / (N / R0)}
+    {
+        const int j0 = tid0 & (Q0 - 1), j1 = tid0 & (Q0 / R1 - 1);
+        double s, c;
+        sincospi(2.0 * (double)j0 / (double)N, &s, &c);
+        wA = make_double2(c, s);
+        sincospi(2.0 * (double)j1 / (double)Q0, &s, &c);
+        wB = make_double2(c, s);
+    }
+    // tiles that are neighbours along the contiguous axis share 128-byte lines (the row pitch is odd in 16-byte units):
+    // the workgroups of one XCD take eight adjacent tiles at a time (flatsky.hip, FS_PAIR_XCD)
+    constexpr int GL = 3;
+    const long gmask = (8L << GL) - 1;
+    const bool pair_xcd = (ntiles & gmask) == 0 && (gridDim.x & gmask) == 0;
+    auto remap = [&](long v) {
+        if (!pair_xcd) return v;
+        const long slot = v >> 3, xcd = v & 7;
+        return (((slot >> GL) * 8 + xcd) << GL) + (slot & ((1 << GL) - 1));
+    };
+    struct tile_t {
+        long base;
+        int teff;
+    };
+    auto tile_of = [&](long v) {
+        const long outer = v / chunks, i0 = (v - outer * chunks) * NCH;
+        tile_t t;
+        t.base = outer * N * inner + i0;
+        t.teff = (int)min((long)NCH, inner - i0);
+        return t;
+    };
+    double2 R[U];
+    auto prefetch = [&](const tile_t &tl, int tid) {
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int e = tid + u * T;
+            const int c = e & (NCH - 1), j = e / NCH;
+            const long addr = tl.base + (long)j * inner + min(c, tl.teff - 1);
+            R[u] = GEN ? make_double2(in[addr], 0.0) : in2[addr];
+        }
+    };
+    long vt = blockIdx.x;
+    if (vt >= ntiles) return;
+    tile_t cur = tile_of(remap(vt));
+    prefetch(cur, tid0);
+    while (true) {
+        int tid = tid0;                                   // opaque per item: see ringfft_direct_ct
+        asm volatile("" : "+v"(tid));
+        __syncthreads();                                  // previous item's LDS reads are done (and the tables are filled)
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int e = tid + u * T;
+            const int c = e & (NCH - 1), j = e / NCH;
+            double2 v = R[u];
+            if (GEN) {
+                const long addr = cur.base + (long)j * inner + min(c, cur.teff - 1);
+                const double2 z = philox_boxmuller((uint64_t)addr, seed, lg_l, sc_l);
+                v = make_double2(z.x * v.x, z.y * v.x);
+            }
+            sm[c * BS + fpad(j)] = v;
+        }
+        const long vnext = vt + gridDim.x;
+        const tile_t nxt = tile_of(remap(min(vnext, ntiles - 1)));
+        prefetch(nxt, tid);                               // (unconditional: the last iteration re-reads a tile)
+        __syncthreads();
+        ct_pass<PK, N, NCH, BS, N, R0, SIGN, false, T>(sm, wA, tid);
+        __syncthreads();
+        ct_pass<PK, N, NCH, BS, Q0, R1, SIGN, false, T>(sm, wB, tid);
+        __syncthreads();
+        // ---- last pass (radix R2 on contiguous elements) with the store: butterfly t = 16 k0 + k1 of line ch holds the
+        //      natural indices k0 + 16 k1 + 256 r; the lines of a row leave as 16 NCH contiguous bytes
+        {
+            constexpr int TOT = NCH * 256;
+            constexpr int IT = (TOT + T - 1) / T;
+#pragma unroll
+            for (int it = 0; it < IT; it++) {
+                const int idx = tid + it * T;
+                if ((TOT % T) != 0 && idx >= TOT) break;
+                const int ch = idx & (NCH - 1), t = idx / NCH;
+                const int k0 = t >> 4, k1 = t & 15;
+                const double2 *p = sm + ch * BS + fpad(t * R2);
+                double2 x[R2];
+#pragma unroll
+                for (int r = 0; r < R2; r++) x[r] = p[fpc(r)];
+                DftR<R2, SIGN>::run(x);
+                if (ch < cur.teff) {
+                    double2 *o = out + cur.base + (long)(k0 + 16 * k1) * inner + ch;
+#pragma unroll
+                    for (int r = 0; r < R2; r++) o[(long)(256 * r) * inner] = make_double2(x[r].x * scale, x[r].y * scale);
+                }
+            }
+        }
+        if (vnext >= ntiles) break;
+        vt = vnext;
+        cur = nxt;
+    }
+}
+
+template <int N, int NCH, int T>
+static int launch_linec2c(corahip_ctx *ctx, const double *in, double *out, long nouter, long inner, int inverse, double scale, bool gen,
+                          uint64_t seed) {
+    constexpr int PK = 1;
+    constexpr int BS = fpc(N) + K5_CH_SKEW;
+    const size_t shm = sizeof(double2) * ((size_t)NCH * BS + (gen ? 513 : 0));
+    const long ntiles = nouter * ((inner + NCH - 1) / NCH);
+    const long per_cu = std::max<long>(1, std::min<long>((160 * 1024) / shm, 2048 / T));
+    dim3 grid((unsigned)std::min<long>(ntiles, (long)ctx->num_cu * per_cu));
+    double2 *o2 = reinterpret_cast<double2 *>(out);
+#define C2C_LAUNCH(SG, GN)                                                                                                  \
+    HIP_TRY(hipFuncSetAttribute((const void *)linec2c_ct<N, NCH, T, SG, GN>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+    linec2c_ct<N, NCH, T, SG, GN><<<grid, T, shm, ctx->stream>>>(in, o2, nouter, inner, scale, seed)
+    if (gen) { C2C_LAUNCH(1, true); }
+    else if (inverse) { C2C_LAUNCH(1, false); }
+    else { C2C_LAUNCH(-1, false); }
+#undef C2C_LAUNCH
+    LAUNCH_CHECK();
+    return 0;
+}
+// a strided complex pass of the flat-sky transforms (inner > 1) for the lengths that have a compile-time schedule;
+// gen: inverse pass whose input is generated from the real k-weights `in` (corahip_randomfield_irfftn).  *took = false:
+// the generic line kernel takes it
+int flat_c2c_ct(corahip_ctx *ctx, const double *in, double *out, long nouter, int n, long inner, int inverse, double scale, bool gen,
+                uint64_t seed, bool *took) {
+    static const bool off = getenv("CORAHIP_FLAT_GENERIC") != nullptr;
+    *took = false;
+    if (off || nouter < 1 || inner < 2) return 0;
+    int rc;
+    if (n == 256 && inner >= 16) rc = launch_linec2c<256, 16, 256>(ctx, in, out, nouter, inner, inverse, scale, gen, seed);
+    else if (n == 512 && inner >= 16) rc = launch_linec2c<512, 16, 512>(ctx, in, out, nouter, inner, inverse, scale, gen, seed);
+    else if (n == 1024 && inner >= 8) rc = launch_linec2c<1024, 8, 512>(ctx, in, out, nouter, inner, inverse, scale, gen, seed);
+    else return 0;
+    if (rc) return rc;
+    *took = true;
+    return 0;
 }
 
 template <int N, int NCH, int T>

@@ -85,7 +85,7 @@ def test_host_kweight_and_geometry_match_reference(fsg):
 
 
 # ------------------------------------------------------------------ GPU: line-FFT engine
-LENGTHS = [1, 2, 3, 4, 5, 7, 8, 12, 16, 31, 32, 64, 100, 128, 257, 1000, 1024, 2048, 3000, 4095, 4096]
+LENGTHS = [1, 2, 3, 4, 5, 7, 8, 12, 16, 31, 32, 64, 100, 128, 256, 257, 512, 1000, 1024, 2048, 3000, 4095, 4096]
 
 
 @pytest.mark.gpu
@@ -213,7 +213,8 @@ def test_device_seeded_field_vs_oracle_stream_and_spectrum(ctx):
     # field, bit for bit, as the draw followed by irfftn - 3-d, 2-d, non-power-of-two and odd sizes, and 1-d (two-step inside)
     import torch
 
-    for shape in ([12, 10, 14], [16, 64], [9, 20], [33, 7, 11], [40]):
+    # (first axes 256 / 512 / 1024: the generating pass with the compile-time FFT passes, whole and partial tiles)
+    for shape in ([12, 10, 14], [16, 64], [9, 20], [33, 7, 11], [40], [256, 6, 12], [512, 64], [1024, 5, 8], [256, 256, 30]):
         kw = ctx.empty(tuple(shape[:-1]) + (shape[-1] // 2 + 1,)).uniform_()
         two = ctx.irfftn(ctx.randomfield_draw(kw, 123), last=shape[-1])
         one = ctx.randomfield_irfftn(kw, 123, last=shape[-1])
