@@ -82,6 +82,19 @@ template <>
 struct Sch<512> {
     static constexpr int R0 = 16, R1 = 16, R2 = 2;
 };
+// 3 * 2^k flat-sky lengths (384^3, 768^3 cubes): radix 12 in the first pass, as Sch<1536> / Sch<3072>
+template <>
+struct Sch<192> {
+    static constexpr int R0 = 12, R1 = 16, R2 = 1;
+};
+template <>
+struct Sch<384> {
+    static constexpr int R0 = 12, R1 = 16, R2 = 2;
+};
+template <>
+struct Sch<768> {
+    static constexpr int R0 = 12, R1 = 16, R2 = 4;
+};
 template <int SIGN>
 struct DftR<1, SIGN> {
     __device__ __forceinline__ static void run(double2 (&)[1]) {}
@@ -248,6 +261,12 @@ __device__ constexpr double kSin16[16] = {0.0, 0.19509032201612826785, 0.3826834
                                           0.70710678118654752440, 0.55557023301960222474, 0.38268343236508977173, 0.19509032201612826785};
 
 // 32-point DFT, natural order in and out: DFT16 of the even and of the odd inputs, combined with w32^k = e^{SIGN i pi k / 16}
+__device__ constexpr double kCos12[12] = {1.0, 0.96592582628906828675, 0.86602540378443864676, 0.70710678118654752440, 0.5,
+                                          0.25881904510252076235, 0.0, -0.25881904510252076235, -0.5, -0.70710678118654752440,
+                                          -0.86602540378443864676, -0.96592582628906828675};
+__device__ constexpr double kSin12[12] = {0.0, 0.25881904510252076235, 0.5, 0.70710678118654752440, 0.86602540378443864676,
+                                          0.96592582628906828675, 1.0, 0.96592582628906828675, 0.86602540378443864676,
+                                          0.70710678118654752440, 0.5, 0.25881904510252076235};
 template <int SIGN>
 struct DftR<32, SIGN> {
     __device__ __forceinline__ static void run(double2 (&x)[32]) {
@@ -1087,12 +1106,12 @@ __global__ void __launch_bounds__(T)
 linec2r_ct(const double2 *in, double *out, long nlines, double scale) {
     constexpr int PK = 1;                    // (strides down to 16 elements: the one-slot-per-16 padding is additive for them)
     constexpr int R0 = Sch<N>::R0, R1 = Sch<N>::R1, R2 = Sch<N>::R2;
-    static_assert(R0 == 16 && R1 == 16 && N == 256 * R2, "digit map of the fused store assumes 16 x 16 x R2");
+    static_assert((R0 == 16 || R0 == 12) && R1 == 16 && N == R0 * R1 * R2, "digit map of the fused store assumes R0 x 16 x R2");
     constexpr int Q0 = N / R0;
     static_assert(Q0 % 16 == 0, "first-pass stride must be a multiple of the padding period");
     constexpr int BS = fpc(N) + 1 + K5_CH_SKEW;
     constexpr int U = NCH * N / T;           // bins 0 .. N-1 per thread (the Nyquist bins: one more load on NCH threads)
-    static_assert((NCH * N) % T == 0 && (N & (N - 1)) == 0, "whole loads per thread");
+    static_assert((NCH * N) % T == 0, "whole loads per thread");
     extern __shared__ __attribute__((aligned(16))) double2 sm[];
     const int tid0 = threadIdx.x;
     const long nitems = (nlines + NCH - 1) / NCH;
@@ -1115,7 +1134,7 @@ linec2r_ct(const double2 *in, double *out, long nlines, double scale) {
         for (int u = 0; u < U; u++) {
             const int e = tid + u * T;
             const long line = min(line0 + e / N, nlines - 1);
-            pf[u] = in[line * (N + 1) + (e & (N - 1))];
+            pf[u] = in[line * (N + 1) + e % N];
         }
         pfn = in[min(line0 + (tid & (NCH - 1)), nlines - 1) * (N + 1) + N];
     };
@@ -1129,7 +1148,7 @@ linec2r_ct(const double2 *in, double *out, long nlines, double scale) {
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const int e = tid + u * T;
-            const int c = e / N, k = e & (N - 1);
+            const int c = e / N, k = e % N;
             double2 v = pf[u];
             if (k == 0) v.y = 0.0;
             sm[c * BS + fpad(k)] = v;
@@ -1155,7 +1174,7 @@ linec2r_ct(const double2 *in, double *out, long nlines, double scale) {
                 for (int r = 0; r < R0; r++) {
                     const double2 xa = pa[fpc(r * Q0)];
                     const double2 xb = pb[fpc((R0 - 1 - r) * Q0)];
-                    const double2 w = cmul(wh, make_double2(kCos16[r], kSin16[r]));
+                    const double2 w = cmul(wh, R0 == 16 ? make_double2(kCos16[r % 16], kSin16[r % 16]) : make_double2(kCos12[r % 12], kSin12[r % 12]));
                     const double2 sum = make_double2(xa.x + xb.x, xa.y - xb.y);
                     const double2 dif = make_double2(xa.x - xb.x, xa.y + xb.y);
                     const double2 t = cmul(dif, w);
@@ -1179,26 +1198,28 @@ linec2r_ct(const double2 *in, double *out, long nlines, double scale) {
         ct_pass<PK, N, NCH, BS, Q0, R1, 1, false, T>(sm, wB, tid);
         __syncthreads();
         // ---- last pass (radix R2 on contiguous elements) with the store: butterfly t = 16 k0 + k1 holds the natural
-        //      indices k0 + 16 k1 + 256 r; eight consecutive lanes store 128 contiguous bytes
+        //      indices k0 + R0 k1 + 16 R0 r; R0 = 16: eight consecutive lanes store 128 contiguous bytes (lane bits as in
+        //      ringfft_direct_ct), R0 = 12: lanes along k0
         {
-            constexpr int TOT = NCH * 256;
+            constexpr int NB2 = R0 * R1;                  // butterflies per line
+            constexpr int TOT = NCH * NB2;
             constexpr int IT = (TOT + T - 1) / T;
 #pragma unroll
             for (int it = 0; it < IT; it++) {
                 const int idx = tid + it * T;
                 if ((TOT % T) != 0 && idx >= TOT) break;
-                const int ch = idx >> 8;
-                const int k0 = (idx & 7) | ((idx >> 3) & 8);
-                const int k1 = ((idx >> 3) & 7) | ((idx >> 4) & 8);
+                const int ch = idx / NB2, q = idx - ch * NB2;
+                const int k0 = R0 == 16 ? ((q & 7) | ((q >> 3) & 8)) : q % R0;
+                const int k1 = R0 == 16 ? (((q >> 3) & 7) | ((q >> 4) & 8)) : q / R0;
                 const double2 *p = sm + ch * BS + fpad((k0 * 16 + k1) * R2);
                 double2 x[R2];
 #pragma unroll
                 for (int r = 0; r < R2; r++) x[r] = p[fpc(r)];
                 DftR<R2, 1>::run(x);
                 if (line0 + ch < nlines) {
-                    double *o = out + (line0 + ch) * (2L * N) + 2 * (k0 + 16 * k1);
+                    double *o = out + (line0 + ch) * (2L * N) + 2 * (k0 + R0 * k1);
 #pragma unroll
-                    for (int r = 0; r < R2; r++) *reinterpret_cast<double2 *>(o + 512 * r) = make_double2(x[r].x * scale, x[r].y * scale);
+                    for (int r = 0; r < R2; r++) *reinterpret_cast<double2 *>(o + 2 * NB2 * r) = make_double2(x[r].x * scale, x[r].y * scale);
                 }
             }
         }
@@ -1218,7 +1239,7 @@ __global__ void __launch_bounds__(T)
 linec2c_ct(const double *in, double2 *out, long nouter, long inner, double scale, uint64_t seed) {
     constexpr int PK = 1;
     constexpr int R0 = Sch<N>::R0, R1 = Sch<N>::R1, R2 = Sch<N>::R2;
-    static_assert(R0 == 16 && R1 == 16 && N == 256 * R2, "16 x 16 x R2");
+    static_assert((R0 == 16 || R0 == 12) && R1 == 16 && N == R0 * R1 * R2, "R0 x 16 x R2");
     constexpr int Q0 = N / R0;
     static_assert(Q0 % 16 == 0 && T % Q0 == 0, "per-thread twiddles");
     constexpr int BS = fpc(N) + K5_CH_SKEW;
@@ -1303,9 +1324,9 @@ linec2c_ct(const double *in, double2 *out, long nouter, long inner, double scale
         ct_pass<PK, N, NCH, BS, Q0, R1, SIGN, false, T>(sm, wB, tid);
         __syncthreads();
         // ---- last pass (radix R2 on contiguous elements) with the store: butterfly t = 16 k0 + k1 of line ch holds the
-        //      natural indices k0 + 16 k1 + 256 r; the lines of a row leave as 16 NCH contiguous bytes
+        //      natural indices k0 + R0 k1 + 16 R0 r; the lines of a row leave as 16 NCH contiguous bytes
         {
-            constexpr int TOT = NCH * 256;
+            constexpr int TOT = NCH * R0 * R1;
             constexpr int IT = (TOT + T - 1) / T;
 #pragma unroll
             for (int it = 0; it < IT; it++) {
@@ -1319,9 +1340,9 @@ linec2c_ct(const double *in, double2 *out, long nouter, long inner, double scale
                 for (int r = 0; r < R2; r++) x[r] = p[fpc(r)];
                 DftR<R2, SIGN>::run(x);
                 if (ch < cur.teff) {
-                    double2 *o = out + cur.base + (long)(k0 + 16 * k1) * inner + ch;
+                    double2 *o = out + cur.base + (long)(k0 + R0 * k1) * inner + ch;
 #pragma unroll
-                    for (int r = 0; r < R2; r++) o[(long)(256 * r) * inner] = make_double2(x[r].x * scale, x[r].y * scale);
+                    for (int r = 0; r < R2; r++) o[(long)(R0 * R1 * r) * inner] = make_double2(x[r].x * scale, x[r].y * scale);
                 }
             }
         }
@@ -1363,6 +1384,8 @@ int flat_c2c_ct(corahip_ctx *ctx, const double *in, double *out, long nouter, in
     if (n == 256 && inner >= 16) rc = launch_linec2c<256, 16, 256>(ctx, in, out, nouter, inner, inverse, scale, gen, seed);
     else if (n == 512 && inner >= 16) rc = launch_linec2c<512, 16, 512>(ctx, in, out, nouter, inner, inverse, scale, gen, seed);
     else if (n == 1024 && inner >= 8) rc = launch_linec2c<1024, 8, 512>(ctx, in, out, nouter, inner, inverse, scale, gen, seed);
+    else if (n == 384 && inner >= 16) rc = launch_linec2c<384, 16, 512>(ctx, in, out, nouter, inner, inverse, scale, gen, seed);
+    else if (n == 768 && inner >= 8) rc = launch_linec2c<768, 8, 512>(ctx, in, out, nouter, inner, inverse, scale, gen, seed);
     else return 0;
     if (rc) return rc;
     *took = true;
@@ -1393,6 +1416,10 @@ int flat_c2r_ct(corahip_ctx *ctx, const double *spec, double *out, long nlines, 
     else if (h == 512) rc = launch_linec2r<512, 16, 512>(ctx, spec, out, nlines, scale);
     else if (h == 1024) rc = launch_linec2r<1024, 8, 512>(ctx, spec, out, nlines, scale);
     else if (h == 2048) rc = launch_linec2r<2048, 4, 512>(ctx, spec, out, nlines, scale);
+    else if (h == 192) rc = launch_linec2r<192, 16, 256>(ctx, spec, out, nlines, scale);
+    else if (h == 384) rc = launch_linec2r<384, 16, 512>(ctx, spec, out, nlines, scale);
+    else if (h == 768) rc = launch_linec2r<768, 8, 512>(ctx, spec, out, nlines, scale);
+    else if (h == 1536) rc = launch_linec2r<1536, 4, 512>(ctx, spec, out, nlines, scale);
     else return 0;
     if (rc) return rc;
     *took = true;

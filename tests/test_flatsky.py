@@ -85,7 +85,7 @@ def test_host_kweight_and_geometry_match_reference(fsg):
 
 
 # ------------------------------------------------------------------ GPU: line-FFT engine
-LENGTHS = [1, 2, 3, 4, 5, 7, 8, 12, 16, 31, 32, 64, 100, 128, 256, 257, 512, 1000, 1024, 2048, 3000, 4095, 4096]
+LENGTHS = [1, 2, 3, 4, 5, 7, 8, 12, 16, 31, 32, 64, 100, 128, 256, 257, 384, 512, 768, 1000, 1024, 2048, 3000, 4095, 4096]
 
 
 @pytest.mark.gpu
@@ -107,7 +107,9 @@ def test_fft_c2c_every_axis_position_vs_numpy(ctx, n):
                                    (4096,), (3, 250), (64, 64, 64), (17, 33, 50), (2, 3, 4, 6), (1, 1, 2),
                                    # last axes 512 / 1024 / 2048 / 4096: the compile-time c2r pass (16 / 16 / 8 / 4 lines per
                                    # item; line counts that are not multiples of it, and a single line)
-                                   (5, 7, 512), (3, 11, 1024), (21, 2048), (9, 4096), (1, 1024), (33, 512)])
+                                   (5, 7, 512), (3, 11, 1024), (21, 2048), (9, 4096), (1, 1024), (33, 512),
+                                   # 3 * 2^k: radix 12 in the first pass
+                                   (5, 7, 384), (19, 768), (9, 1536), (5, 3072), (384, 40, 6)])
 def test_rfftn_irfftn_vs_numpy(ctx, shape):
     import torch
 
@@ -214,7 +216,8 @@ def test_device_seeded_field_vs_oracle_stream_and_spectrum(ctx):
     import torch
 
     # (first axes 256 / 512 / 1024: the generating pass with the compile-time FFT passes, whole and partial tiles)
-    for shape in ([12, 10, 14], [16, 64], [9, 20], [33, 7, 11], [40], [256, 6, 12], [512, 64], [1024, 5, 8], [256, 256, 30]):
+    for shape in ([12, 10, 14], [16, 64], [9, 20], [33, 7, 11], [40], [256, 6, 12], [512, 64], [1024, 5, 8], [256, 256, 30],
+                  [384, 20, 12], [768, 3, 30]):
         kw = ctx.empty(tuple(shape[:-1]) + (shape[-1] // 2 + 1,)).uniform_()
         two = ctx.irfftn(ctx.randomfield_draw(kw, 123), last=shape[-1])
         one = ctx.randomfield_irfftn(kw, 123, last=shape[-1])
