@@ -35,6 +35,7 @@ struct corahip_linefft_plan {
 // contiguous c2r pass of the flat-sky transforms with the compile-time FFT passes of sht_ringfft_ct.hip
 struct corahip_ctx;
 int flat_c2r_ct(corahip_ctx *ctx, const double *spec, double *out, long nlines, int h, double scale, bool *took);
+int flat_r2c_ct(corahip_ctx *ctx, const double *in, double *spec, long nlines, int h, bool *took);
 int flat_c2c_ct(corahip_ctx *ctx, const double *in, double *out, long nouter, int n, long inner, int inverse, double scale, bool gen,
                 uint64_t seed, bool *took);
 

@@ -737,7 +737,15 @@ int corahip_rfftn(corahip_ctx *ctx, const double *in, int ndim, const int64_t *r
     cd[ndim - 1] = rdims[ndim - 1] / 2 + 1;
     StageTimer st(ctx, "flatfft");
     const int nlast = (int)rdims[ndim - 1];
-    int rc = nlast % 2 == 0 ? launch_linefft<4>(ctx, in, spec, prod(rdims, 0, ndim - 1), nlast / 2, 1, 0, 1.0)
+    int rc = 0;
+    bool took = false;
+    if (nlast % 2 == 0) {      // the compile-time passes where nlast / 2 has a schedule
+        StageTimer pass_timer(ctx, "fft_r2c");
+        rc = flat_r2c_ct(ctx, in, spec, prod(rdims, 0, ndim - 1), nlast / 2, &took);
+        if (rc) return rc;
+    }
+    if (!took)
+        rc = nlast % 2 == 0 ? launch_linefft<4>(ctx, in, spec, prod(rdims, 0, ndim - 1), nlast / 2, 1, 0, 1.0)
                             : launch_linefft<2>(ctx, in, spec, prod(rdims, 0, ndim - 1), nlast, 1, 0, 1.0);
     if (rc) return rc;
     for (int ax = ndim - 2; ax >= ndim - naxes; ax--) {

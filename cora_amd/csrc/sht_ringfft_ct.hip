@@ -1392,6 +1392,145 @@ int flat_c2c_ct(corahip_ctx *ctx, const double *in, double *out, long nouter, in
     return 0;
 }
 
+// ------------------------------------------------------------------------------------
+// Flat-sky fields: real -> half-complex along the contiguous axis (numpy.fft.rfftn's first pass, cora/util/fftutil.py:64-75;
+// the velocity cube of RedshiftCorrelation.realisation, cora/signal/corr.py:590-599), EVEN length 2 N: ringana_direct_ct's
+// passes - z_j = x_2j + i x_2j+1 loaded in the digit order of the first (radix R2) pass, two radix-16 DIT passes, then
+// the split X_k = 1/2 [(Z_k + conj Z_{N-k}) - i e^{-i pi k / N} (Z_k - conj Z_{N-k})], k = 0 .. N - on NCH adjacent lines.
+// ------------------------------------------------------------------------------------
+template <int N, int NCH, int T>
+__global__ void __launch_bounds__(T)
+liner2c_ct(const double *in, double2 *out, long nlines) {
+    constexpr int PK = 1;
+    constexpr int R0 = Sch<N>::R0, R1 = Sch<N>::R1, R2 = Sch<N>::R2;
+    static_assert((R0 == 16 || R0 == 12) && R1 == 16 && N == R0 * R1 * R2, "R0 x 16 x R2");
+    constexpr int Q0 = N / R0;
+    static_assert(Q0 % 16 == 0 && T % Q0 == 0, "per-thread twiddles");
+    constexpr int BS = fpc(N) + 1 + K5_CH_SKEW;
+    constexpr int NB2 = R0 * R1;
+    constexpr int TOT0 = NCH * NB2, IT0 = (TOT0 + T - 1) / T;
+    constexpr int MO = (NCH * N + T - 1) / T;            // output bins 0 .. N-1 per thread (bin N: one more on NCH threads)
+    extern __shared__ __attribute__((aligned(16))) double2 sm[];
+    const int tid0 = threadIdx.x;
+    const long nitems = (nlines + NCH - 1) / NCH;
+    double2 wA, wB, wS, wSstep;     // (wS: e^{-i pi (tid mod N) / N}, its step over T bins)
+    {
+        const int j0 = tid0 & (Q0 - 1), j1 = tid0 & (Q0 / R1 - 1);
+        double s, c;
+        sincospi(2.0 * (double)j0 / (double)N, &s, &c);
+        wA = make_double2(c, s);
+        sincospi(2.0 * (double)j1 / (double)Q0, &s, &c);
+        wB = make_double2(c, s);
+        sincospi((double)(tid0 % N) / (double)N, &s, &c);
+        wS = make_double2(c, -s);
+        sincospi((double)T / (double)N, &s, &c);
+        wSstep = make_double2(c, -s);
+    }
+    double2 pf[IT0 * R2];     // (flat: as [IT0][1] the array stayed in scratch memory)
+    auto prefetch = [&](long item, int tid) {
+        const long line0 = item * NCH;
+#pragma unroll
+        for (int it = 0; it < IT0; it++) {
+            const int idx = min(tid + it * T, TOT0 - 1);
+            const int ch = idx / NB2, q = idx - ch * NB2;
+            const int k0 = R0 == 16 ? ((q & 7) | ((q >> 3) & 8)) : q % R0;
+            const int k1 = R0 == 16 ? (((q >> 3) & 7) | ((q >> 4) & 8)) : q / R0;
+            const double *src = in + min(line0 + ch, nlines - 1) * (2L * N) + 2 * (k0 + R0 * k1);
+#pragma unroll
+            for (int r = 0; r < R2; r++) pf[it * R2 + r] = *reinterpret_cast<const double2 *>(src + 2 * NB2 * r);
+        }
+    };
+    long vitem = blockIdx.x;
+    if (vitem < nitems) prefetch(vitem, tid0);
+    for (; vitem < nitems; vitem += gridDim.x) {
+        int tid = tid0;
+        asm volatile("" : "+v"(tid));
+        const long line0 = vitem * NCH;
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < IT0; it++) {
+            const int idx = tid + it * T;
+            if ((TOT0 % T) != 0 && idx >= TOT0) break;
+            const int ch = idx / NB2, q = idx - ch * NB2;
+            const int k0 = R0 == 16 ? ((q & 7) | ((q >> 3) & 8)) : q % R0;
+            const int k1 = R0 == 16 ? (((q >> 3) & 7) | ((q >> 4) & 8)) : q / R0;
+            double2 *p = sm + ch * BS + fpad((k0 * 16 + k1) * R2);
+            double2 x[R2];
+#pragma unroll
+            for (int r = 0; r < R2; r++) x[r] = pf[it * R2 + r];
+            DftR<R2, -1>::run(x);
+#pragma unroll
+            for (int r = 0; r < R2; r++) p[fpc(r)] = x[r];
+        }
+        prefetch(min(vitem + (long)gridDim.x, nitems - 1), tid);
+        __syncthreads();
+        ct_pass<PK, N, NCH, BS, Q0, R1, -1, true, T>(sm, wB, tid);
+        __syncthreads();
+        ct_pass<PK, N, NCH, BS, N, R0, -1, true, T>(sm, wA, tid);
+        __syncthreads();
+        auto emit = [&](int c, int k, const double2 w) {       // w = e^{-i pi k / N}
+            const int ka = k == N ? 0 : k;                     // Z_N := Z_0
+            const int kb = k == 0 ? 0 : N - k;
+            const double2 za = sm[c * BS + fpad(ka)], zb = sm[c * BS + fpad(kb)];
+            const double2 sum = make_double2(za.x + zb.x, za.y - zb.y);
+            const double2 dif = make_double2(za.x - zb.x, za.y + zb.y);
+            const double2 t = cmul(dif, w);
+            if (line0 + c < nlines) out[(line0 + c) * (N + 1L) + k] = make_double2(0.5 * (sum.x + t.y), 0.5 * (sum.y - t.x));
+        };
+        // element e = tid + u T is bin k = e mod N of line e / N: the twiddle follows by one rotation per step and a sign
+        // per wrap (e^{-i pi (k - N) / N} = -e^{-i pi k / N})
+        {
+            int c = tid / N, k = tid - c * N;
+            double2 w = wS;
+            asm volatile("" : "+v"(w.x), "+v"(w.y));
+#pragma unroll
+            for (int u = 0; u < MO; u++) {
+                if ((NCH * N) % T == 0 || c < NCH) emit(c, k, w);
+                w = cmul(w, wSstep);
+                k += T;
+                while (k >= N) {
+                    k -= N;
+                    c++;
+                    w = make_double2(-w.x, -w.y);
+                }
+            }
+        }
+        if (tid < NCH) emit(tid, N, make_double2(-1.0, 0.0));
+    }
+}
+template <int N, int NCH, int T>
+static int launch_liner2c(corahip_ctx *ctx, const double *in, double *spec, long nlines) {
+    constexpr int PK = 1;
+    constexpr int BS = fpc(N) + 1 + K5_CH_SKEW;
+    const size_t shm = sizeof(double2) * (size_t)NCH * BS;
+    const long nitems = (nlines + NCH - 1) / NCH;
+    const long per_cu = std::max<long>(1, std::min<long>((160 * 1024) / shm, 2048 / T));
+    dim3 grid((unsigned)std::min<long>(nitems, (long)ctx->num_cu * per_cu));
+    HIP_TRY(hipFuncSetAttribute((const void *)liner2c_ct<N, NCH, T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    liner2c_ct<N, NCH, T><<<grid, T, shm, ctx->stream>>>(in, reinterpret_cast<double2 *>(spec), nlines);
+    LAUNCH_CHECK();
+    return 0;
+}
+// the contiguous real -> half-complex pass of corahip_rfftn (real length 2 h); *took = false: the generic kernel takes it
+int flat_r2c_ct(corahip_ctx *ctx, const double *in, double *spec, long nlines, int h, bool *took) {
+    static const bool off = getenv("CORAHIP_FLAT_GENERIC") != nullptr;
+    *took = false;
+    if (off || nlines < 1) return 0;
+    int rc;
+    if (h == 256) rc = launch_liner2c<256, 16, 512>(ctx, in, spec, nlines);
+    else if (h == 512) rc = launch_liner2c<512, 16, 512>(ctx, in, spec, nlines);
+    else if (h == 1024) rc = launch_liner2c<1024, 8, 512>(ctx, in, spec, nlines);
+    else if (h == 2048) rc = launch_liner2c<2048, 4, 512>(ctx, in, spec, nlines);
+    else if (h == 192) rc = launch_liner2c<192, 16, 512>(ctx, in, spec, nlines);
+    else if (h == 384) rc = launch_liner2c<384, 16, 512>(ctx, in, spec, nlines);
+    else if (h == 768) rc = launch_liner2c<768, 8, 512>(ctx, in, spec, nlines);
+    else if (h == 1536) rc = launch_liner2c<1536, 4, 512>(ctx, in, spec, nlines);
+    else return 0;
+    if (rc) return rc;
+    *took = true;
+    return 0;
+}
+
 template <int N, int NCH, int T>
 static int launch_linec2r(corahip_ctx *ctx, const double *spec, double *out, long nlines, double scale) {
     constexpr int PK = 1;
