@@ -26,6 +26,8 @@ struct corahip_pending_event {
 // tables of one line-FFT length of the flat-sky engine (flatsky.hip); device pointers
 struct corahip_linefft_plan {
     int n = 0, P = 0, logP = 0, blu = 0;
+    int Pct = 0;               // Bluestein lengths: convolution length of the compile-time passes (flatsky_ct.hip), 0 = none
+    double2 *filt_ct = nullptr;   // [Pct] its filter, in the passes' storage order
     double2 *tw = nullptr;     // [P]  exp(-2 pi i k / P)
     double2 *chirp = nullptr;  // [n]  exp(-i pi k^2 / n)                       (Bluestein lengths only)
     double2 *filt = nullptr;   // [P]  FFT_P(wrapped conj chirp) / P, bit-reversed (Bluestein lengths only)
@@ -35,6 +37,9 @@ struct corahip_linefft_plan {
 // contiguous c2r pass of the flat-sky transforms with the compile-time FFT passes of sht_ringfft_ct.hip
 struct corahip_ctx;
 int flat_c2r_ct(corahip_ctx *ctx, const double *spec, double *out, long nlines, int h, double scale, bool *took);
+int flat_blu_plan(corahip_ctx *ctx, int n, const double2 *chirp, int *Pct, double2 **filt_ct);
+int flat_blu_c2c_ct(corahip_ctx *ctx, const double *in, double *out, long nouter, int n, long inner, int inverse, double scale, bool gen,
+                    uint64_t seed, int Pct, const double2 *chirp, const double2 *filt_ct, bool *took);
 int flat_r2c_ct(corahip_ctx *ctx, const double *in, double *spec, long nlines, int h, bool *took);
 int flat_c2c_ct(corahip_ctx *ctx, const double *in, double *out, long nouter, int n, long inner, int inverse, double scale, bool gen,
                 uint64_t seed, bool *took);

@@ -89,6 +89,7 @@ int corahip_ctx_destroy(corahip_ctx *ctx) {
         if (kv.second.tw) (void)hipFree(kv.second.tw);
         if (kv.second.chirp) (void)hipFree(kv.second.chirp);
         if (kv.second.filt) (void)hipFree(kv.second.filt);
+        if (kv.second.filt_ct) (void)hipFree(kv.second.filt_ct);
         if (kv.second.rtw) (void)hipFree(kv.second.rtw);
     }
     delete ctx;

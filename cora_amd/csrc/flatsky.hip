@@ -578,6 +578,8 @@ static int get_linefft_plan(corahip_ctx *ctx, int n, const corahip_linefft_plan 
         HIP_TRY(hipMemcpy(pl.chirp, chirp.data(), sizeof(double2) * n, hipMemcpyHostToDevice));
         HIP_TRY(hipMalloc((void **)&pl.filt, sizeof(double2) * P));
         HIP_TRY(hipMemcpy(pl.filt, filt.data(), sizeof(double2) * P, hipMemcpyHostToDevice));
+        int rcb = flat_blu_plan(ctx, n, pl.chirp, &pl.Pct, &pl.filt_ct);   // (the compile-time convolution, where a schedule holds 2 n - 1)
+        if (rcb) return rcb;
     }
     {   // unpacking twiddles of the real transform of length 2n through this complex plan: e^{+2 pi i k / 2n}, k <= n/2
         std::vector<double2> rtw(n / 2 + 1);
@@ -607,6 +609,11 @@ static int launch_linefft(corahip_ctx *ctx, const double *in, double *out, long 
     const corahip_linefft_plan *pl;
     int rc = get_linefft_plan(ctx, n, &pl);
     if (rc) return rc;
+    if ((MODE == 0 || MODE == 5) && inner > 1 && pl->blu && pl->Pct) {
+        bool took = false;
+        int rct = flat_blu_c2c_ct(ctx, in, out, nouter, n, inner, inverse, scale, MODE == 5, seed, pl->Pct, pl->chirp, pl->filt_ct, &took);
+        if (rct || took) return rct;
+    }
     linefft_args A;
     A.in = in;
     A.out = out;

@@ -22,15 +22,11 @@
 // LDS stores are the expensive operation of these kernels (ds_write_b128: 13 cycles per wave-instruction against
 // 4 for ds_read_b128, MI355X_MICROARCH.md section LDS), hence the count of write passes above.
 #include "sht_internal.h"
-#include "rng_dev.h"
 
 static_assert(K5_SWZ == 0, "the compile-time kernels assume the padded LDS layout");
 #define CT_T 512
 #ifndef CT_STAMPS
 #define CT_STAMPS 0   // diagnostic build (make k5ctstamps): s_memtime per phase of the Bluestein kernel, summed over waves
-#endif
-#ifndef CT_ABLATE_TW
-#define CT_ABLATE_TW 0
 #endif
 #if CT_STAMPS
 __device__ unsigned long long g_ct_stamps[12];
@@ -39,343 +35,7 @@ __device__ unsigned long long g_ct_stamps[12];
 #define CTSTAMP(k)
 #endif
 
-// LDS padding of a channel buffer, per kernel family (PK, a template parameter of everything below that touches a
-// buffer): 0 = one spare 16-byte slot per 8 elements plus 8 per 128 (rounds 1-3), 1 = one spare slot per 16 elements.
-// In the lane-group simulation of ds_read_b128 / ds_write_b128 (tools/lds_bank_sim.py) padding 0 makes every read of
-// a pass 2-way conflicted (a padded unit-stride run is no longer aligned to the bank rows the read groups assume);
-// padding 1 leaves only the strided first / last passes so.  Measured: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE of the
-// Bluestein classes 0.32 -> 0.12 (tools/pmc_lds.sh), their time -1 .. -5 %; the belt (direct class: radix-8 last pass fused
-// with the pixel store) reads 0.18 -> 0.27 and +3 % with it and keeps padding 0.
-template <int PK>
-__host__ __device__ constexpr int fpk(int i) {
-    return PK ? i + (i >> 4) : i + (i >> 3) + ((i >> 7) << 3);
-}
-#define fpad(i) fpk<PK>(i)
-#define fpc(i) fpk<PK>(i)
-#ifndef K5_PK_BLU
-#define K5_PK_BLU 1
-#endif
-#ifndef K5_PK_DIRECT
-#define K5_PK_DIRECT 0
-#endif
-
-template <int N>
-struct Sch;   // DIF radices of a three-pass transform, largest stride first
-template <>
-struct Sch<1024> {
-    static constexpr int R0 = 16, R1 = 16, R2 = 4;
-};
-template <>
-struct Sch<2048> {
-    static constexpr int R0 = 16, R1 = 16, R2 = 8;
-};
-template <>
-struct Sch<4096> {
-    static constexpr int R0 = 16, R1 = 16, R2 = 16;
-};
-// 256 and 512 (flat-sky lines only: linec2r_ct below): 16 x 16 and 16 x 16 x 2
-template <>
-struct Sch<256> {
-    static constexpr int R0 = 16, R1 = 16, R2 = 1;
-};
-template <>
-struct Sch<512> {
-    static constexpr int R0 = 16, R1 = 16, R2 = 2;
-};
-// 3 * 2^k flat-sky lengths (384^3, 768^3 cubes): radix 12 in the first pass, as Sch<1536> / Sch<3072>
-template <>
-struct Sch<192> {
-    static constexpr int R0 = 12, R1 = 16, R2 = 1;
-};
-template <>
-struct Sch<384> {
-    static constexpr int R0 = 12, R1 = 16, R2 = 2;
-};
-template <>
-struct Sch<768> {
-    static constexpr int R0 = 12, R1 = 16, R2 = 4;
-};
-template <int SIGN>
-struct DftR<1, SIGN> {
-    __device__ __forceinline__ static void run(double2 (&)[1]) {}
-};
-// 3 * 2^k: the factor 3 sits in the first pass (radix 12), whose stride P / 12 is a power of two, so every
-// butterfly address is still base + immediates; the Bluestein length of a ring is then at most 1.5 (not 2) times
-// 2 h - 1
-template <>
-struct Sch<3072> {
-    static constexpr int R0 = 12, R1 = 16, R2 = 16;
-};
-template <>
-struct Sch<1536> {
-    static constexpr int R0 = 12, R1 = 16, R2 = 8;
-};
-
-// 5 * 2^9 and 7 * 2^9 (round 4): of the rings whose 2 h - 1 needs more than 2048, those up to 2560 / between 3072 and
-// 3584 get a length 17 % / 12.5 % shorter than 3072 / 4096.  Radix 10 / 14 in the first, strided pass (stride 256)
-template <>
-struct Sch<2560> {
-    static constexpr int R0 = 10, R1 = 16, R2 = 16;
-};
-template <>
-struct Sch<3584> {
-    static constexpr int R0 = 14, R1 = 16, R2 = 16;
-};
-
-// cfg-5 geometry (nside 2048): the cap rings 1025 .. 2047 need Bluestein lengths above 4096, one channel per workgroup
-// (152 KB).  Three passes with the large radix (32, 24 = 3 * 8) in the FIRST, strided pass - half of whose inputs are
-// the zero padding, as half of the last inverse pass's outputs do not exist - and the register-fused middle stage at
-// radix 16 like the shorter lengths (a radix-32 middle stage holds 32 filter values on top of its 32 points: spills)
-template <>
-struct Sch<8192> {
-    static constexpr int R0 = 32, R1 = 16, R2 = 16;
-};
-template <>
-struct Sch<6144> {
-    static constexpr int R0 = 24, R1 = 16, R2 = 16;
-};
-
-// 12-point DFT, natural order in and out: n = 3 a + c, k = k1 + 4 k2: DFT4 over a, twiddle w12^{c k1}, DFT3 over c
-template <int SIGN>
-struct DftR<12, SIGN> {
-    __device__ __forceinline__ static void run(double2 (&x)[12]) {
-        const double h3 = 0.86602540378443864676;   // sqrt(3) / 2
-#pragma unroll
-        for (int c = 0; c < 3; c++) dft4<SIGN>(x[c], x[3 + c], x[6 + c], x[9 + c]);
-        // now x[3 k1 + c] = t_c[k1]; twiddles w12^{c k1}: c = 1: w1, w2, w3 = SIGN i;  c = 2: w2, w4, w6 = -1
-        const double2 w1 = make_double2(h3, SIGN * 0.5), w2 = make_double2(0.5, SIGN * h3), w4 = make_double2(-0.5, SIGN * h3);
-        x[3 + 1] = cmul(x[3 + 1], w1);
-        x[6 + 1] = cmul(x[6 + 1], w2);
-        x[9 + 1] = cmuli<SIGN>(x[9 + 1]);
-        x[3 + 2] = cmul(x[3 + 2], w2);
-        x[6 + 2] = cmul(x[6 + 2], w4);
-        x[9 + 2] = make_double2(-x[9 + 2].x, -x[9 + 2].y);
-        double2 y[12];
-#pragma unroll
-        for (int k1 = 0; k1 < 4; k1++) {
-            const double2 a = x[3 * k1], b = x[3 * k1 + 1], c = x[3 * k1 + 2];
-            const double2 sm = cadd(b, c), d = csub(b, c);
-            const double2 m = make_double2(a.x - 0.5 * sm.x, a.y - 0.5 * sm.y);
-            const double2 n = cmuli<SIGN>(make_double2(h3 * d.x, h3 * d.y));
-            y[k1] = cadd(a, sm);
-            y[k1 + 4] = cadd(m, n);
-            y[k1 + 8] = csub(m, n);
-        }
-#pragma unroll
-        for (int k = 0; k < 12; k++) x[k] = y[k];
-    }
-};
-
-// 5- and 7-point DFTs (w = e^{SIGN 2 pi i / R}) through the sums / differences of the pairs (j, R - j): X_k = a_k + SIGN i b_k,
-// X_{R-k} = a_k - SIGN i b_k with a_k = x_0 + sum_j cos(2 pi j k / R) (x_j + x_{R-j}), b_k = sum_j sin(2 pi j k / R) (x_j - x_{R-j})
-template <int SIGN>
-__device__ __forceinline__ static void dft5(double2 (&x)[5]) {
-    constexpr double c1 = 0.30901699437494742410, c2 = -0.80901699437494742410;   // cos(2 pi / 5), cos(4 pi / 5)
-    constexpr double s1 = 0.95105651629515357212, s2 = 0.58778525229247312917;    // sin(2 pi / 5), sin(4 pi / 5)
-    const double2 t1 = cadd(x[1], x[4]), t2 = cadd(x[2], x[3]), t3 = csub(x[1], x[4]), t4 = csub(x[2], x[3]);
-    const double2 a1 = make_double2(fma(c2, t2.x, fma(c1, t1.x, x[0].x)), fma(c2, t2.y, fma(c1, t1.y, x[0].y)));
-    const double2 a2 = make_double2(fma(c1, t2.x, fma(c2, t1.x, x[0].x)), fma(c1, t2.y, fma(c2, t1.y, x[0].y)));
-    const double2 b1 = make_double2(fma(s2, t4.x, s1 * t3.x), fma(s2, t4.y, s1 * t3.y));
-    const double2 b2 = make_double2(fma(-s1, t4.x, s2 * t3.x), fma(-s1, t4.y, s2 * t3.y));
-    const double2 ib1 = cmuli<SIGN>(b1), ib2 = cmuli<SIGN>(b2);
-    x[0] = cadd(x[0], cadd(t1, t2));
-    x[1] = cadd(a1, ib1);
-    x[4] = csub(a1, ib1);
-    x[2] = cadd(a2, ib2);
-    x[3] = csub(a2, ib2);
-}
-template <int SIGN>
-__device__ __forceinline__ static void dft7(double2 (&x)[7]) {
-    constexpr double c[4] = {1.0, 0.62348980185873353053, -0.22252093395631440429, -0.90096886790241912624};   // cos(2 pi k / 7)
-    constexpr double sn[4] = {0.0, 0.78183148246802980871, 0.97492791218182360702, 0.43388373911755812048};  // sin(2 pi k / 7)
-    const double2 t[4] = {x[0], cadd(x[1], x[6]), cadd(x[2], x[5]), cadd(x[3], x[4])};
-    const double2 d[4] = {x[0], csub(x[1], x[6]), csub(x[2], x[5]), csub(x[3], x[4])};
-    double2 y[7];
-    y[0] = cadd(cadd(x[0], t[1]), cadd(t[2], t[3]));
-#pragma unroll
-    for (int k = 1; k <= 3; k++) {
-        double2 a = x[0], b = make_double2(0.0, 0.0);
-#pragma unroll
-        for (int j = 1; j <= 3; j++) {
-            const int q = (j * k) % 7;                       // cos(2 pi q / 7) = c[min(q, 7 - q)], sin = +- sn[min(q, 7 - q)]
-            const double cc = c[q <= 3 ? q : 7 - q], ss = q <= 3 ? sn[q] : -sn[7 - q];
-            a = make_double2(fma(cc, t[j].x, a.x), fma(cc, t[j].y, a.y));
-            b = make_double2(fma(ss, d[j].x, b.x), fma(ss, d[j].y, b.y));
-        }
-        const double2 ib = cmuli<SIGN>(b);
-        y[k] = cadd(a, ib);
-        y[7 - k] = csub(a, ib);
-    }
-#pragma unroll
-    for (int k = 0; k < 7; k++) x[k] = y[k];
-}
-// 10- and 14-point DFTs, natural order in and out, by the prime-factor map (no twiddles between the two stages):
-// n = (R n1 + 2 n2) mod 2R, k = (R k1 + 2 (2^{-1} mod R) k2) mod 2R with R = 5 / 7 - DFT2 over n1, DFT_R over n2
-template <int SIGN>
-struct DftR<10, SIGN> {
-    __device__ __forceinline__ static void run(double2 (&x)[10]) {
-        double2 u0[5], u1[5];
-#pragma unroll
-        for (int n2 = 0; n2 < 5; n2++) {
-            const double2 a = x[(2 * n2) % 10], b = x[(5 + 2 * n2) % 10];
-            u0[n2] = cadd(a, b);
-            u1[n2] = csub(a, b);
-        }
-        dft5<SIGN>(u0);
-        dft5<SIGN>(u1);
-#pragma unroll
-        for (int k2 = 0; k2 < 5; k2++) {
-            x[(6 * k2) % 10] = u0[k2];
-            x[(5 + 6 * k2) % 10] = u1[k2];
-        }
-    }
-};
-template <int SIGN>
-struct DftR<14, SIGN> {
-    __device__ __forceinline__ static void run(double2 (&x)[14]) {
-        double2 u0[7], u1[7];
-#pragma unroll
-        for (int n2 = 0; n2 < 7; n2++) {
-            const double2 a = x[(2 * n2) % 14], b = x[(7 + 2 * n2) % 14];
-            u0[n2] = cadd(a, b);
-            u1[n2] = csub(a, b);
-        }
-        dft7<SIGN>(u0);
-        dft7<SIGN>(u1);
-#pragma unroll
-        for (int k2 = 0; k2 < 7; k2++) {
-            x[(8 * k2) % 14] = u0[k2];
-            x[(7 + 8 * k2) % 14] = u1[k2];
-        }
-    }
-};
-
-// e^{i pi r / 16}, r < 16 (indices are compile-time after unrolling: these fold into immediates)
-__device__ constexpr double kCos16[16] = {1.0, 0.98078528040323044913, 0.92387953251128675613, 0.83146961230254523708,
-                                          0.70710678118654752440, 0.55557023301960222474, 0.38268343236508977173, 0.19509032201612826785,
-                                          0.0, -0.19509032201612826785, -0.38268343236508977173, -0.55557023301960222474,
-                                          -0.70710678118654752440, -0.83146961230254523708, -0.92387953251128675613, -0.98078528040323044913};
-__device__ constexpr double kSin16[16] = {0.0, 0.19509032201612826785, 0.38268343236508977173, 0.55557023301960222474,
-                                          0.70710678118654752440, 0.83146961230254523708, 0.92387953251128675613, 0.98078528040323044913,
-                                          1.0, 0.98078528040323044913, 0.92387953251128675613, 0.83146961230254523708,
-                                          0.70710678118654752440, 0.55557023301960222474, 0.38268343236508977173, 0.19509032201612826785};
-
-// 32-point DFT, natural order in and out: DFT16 of the even and of the odd inputs, combined with w32^k = e^{SIGN i pi k / 16}
-__device__ constexpr double kCos12[12] = {1.0, 0.96592582628906828675, 0.86602540378443864676, 0.70710678118654752440, 0.5,
-                                          0.25881904510252076235, 0.0, -0.25881904510252076235, -0.5, -0.70710678118654752440,
-                                          -0.86602540378443864676, -0.96592582628906828675};
-__device__ constexpr double kSin12[12] = {0.0, 0.25881904510252076235, 0.5, 0.70710678118654752440, 0.86602540378443864676,
-                                          0.96592582628906828675, 1.0, 0.96592582628906828675, 0.86602540378443864676,
-                                          0.70710678118654752440, 0.5, 0.25881904510252076235};
-template <int SIGN>
-struct DftR<32, SIGN> {
-    __device__ __forceinline__ static void run(double2 (&x)[32]) {
-        double2 e[16], o[16];
-#pragma unroll
-        for (int k = 0; k < 16; k++) {
-            e[k] = x[2 * k];
-            o[k] = x[2 * k + 1];
-        }
-        DftR<16, SIGN>::run(e);
-        DftR<16, SIGN>::run(o);
-#pragma unroll
-        for (int k = 0; k < 16; k++) {
-            const double2 t = k == 0 ? o[0] : cmul(o[k], make_double2(kCos16[k], SIGN * kSin16[k]));
-            x[k] = cadd(e[k], t);
-            x[k + 16] = csub(e[k], t);
-        }
-    }
-};
-
-// 24-point DFT, natural order in and out: n = 3 a + c, k = k1 + 8 k2: DFT8 over a, twiddle w24^{c k1}, DFT3 over c
-template <int SIGN>
-struct DftR<24, SIGN> {
-    __device__ __forceinline__ static void run(double2 (&x)[24]) {
-        const double h3 = 0.86602540378443864676;   // sqrt(3) / 2
-        // cos, sin of pi k / 12, k = 0 .. 14 (w24^j = e^{SIGN i pi j / 12}; c k1 <= 14)
-        constexpr double c12[15] = {1.0, 0.96592582628906828675, 0.86602540378443864676, 0.70710678118654752440, 0.5,
-                                    0.25881904510252076235, 0.0, -0.25881904510252076235, -0.5, -0.70710678118654752440,
-                                    -0.86602540378443864676, -0.96592582628906828675, -1.0, -0.96592582628906828675,
-                                    -0.86602540378443864676};
-        constexpr double s12[15] = {0.0, 0.25881904510252076235, 0.5, 0.70710678118654752440, 0.86602540378443864676,
-                                    0.96592582628906828675, 1.0, 0.96592582628906828675, 0.86602540378443864676,
-                                    0.70710678118654752440, 0.5, 0.25881904510252076235, 0.0, -0.25881904510252076235, -0.5};
-        double2 t[3][8];
-#pragma unroll
-        for (int c = 0; c < 3; c++) {
-#pragma unroll
-            for (int a = 0; a < 8; a++) t[c][a] = x[3 * a + c];
-            DftR<8, SIGN>::run(t[c]);                  // t[c][k1]
-        }
-#pragma unroll
-        for (int k1 = 0; k1 < 8; k1++) {
-            const double2 a = t[0][k1];
-            const double2 b = k1 == 0 ? t[1][0] : cmul(t[1][k1], make_double2(c12[k1], SIGN * s12[k1]));
-            const double2 c = k1 == 0 ? t[2][0] : cmul(t[2][k1], make_double2(c12[2 * k1], SIGN * s12[2 * k1]));
-            const double2 sm = cadd(b, c), d = csub(b, c);
-            const double2 m = make_double2(a.x - 0.5 * sm.x, a.y - 0.5 * sm.y);
-            const double2 n = cmuli<SIGN>(make_double2(h3 * d.x, h3 * d.y));
-            x[k1] = cadd(a, sm);
-            x[k1 + 8] = cadd(m, n);
-            x[k1 + 16] = csub(m, n);
-        }
-    }
-};
-
-__device__ __forceinline__ static double2 csqr(double2 a) {
-    return make_double2(fma(a.x, a.x, -(a.y * a.y)), 2.0 * a.x * a.y);
-}
-__device__ __forceinline__ static double2 cconj(double2 a) { return make_double2(a.x, -a.y); }
-
-// x[r] *= w^r, r = 1 .. R-1.  Powers of two by squaring (kept), every other power as w^(r - lowbit) * w^lowbit and
-// applied at once, so that besides w, w^2, w^4, w^8 only one or two products are live at a time (a table of all
-// powers cost 60 VGPRs and made the kernels spill).
-// The base twiddle is loop-invariant in the persistent item loop; without the empty asm the compiler hoists all 15
-// powers of every pass out of that loop and, having no registers for ~200 values, keeps them in scratch memory
-// (reloaded with vmcnt-ordered loads behind the prefetch).  Recomputing them costs 11 complex multiplies per butterfly.
-template <int R>
-__device__ __forceinline__ static void tw_apply(double2 (&x)[R], double2 w1) {
-    asm volatile("" : "+v"(w1.x), "+v"(w1.y));
-    double2 w[R];
-    w[1] = w1;
-    x[1] = cmul(x[1], w1);
-#pragma unroll
-    for (int r = 2; r < R; r++) {
-        const int lb = r & (-r);
-#if CT_ABLATE_TW     // diagnostic (wrong results): no twiddle powers - what would a table of them be worth?
-        w[r] = make_double2(w1.x + (double)r, w1.y);
-#else
-        w[r] = (lb == r) ? csqr(w[r >> 1]) : cmul(w[r - lb], w[lb]);
-#endif
-        x[r] = cmul(x[r], w[r]);
-    }
-}
-
-// one in-LDS pass of a length-N transform on NCH channel buffers (channel c at sm + c BS), sub-length Ls, radix R.
-// DIT = false: DFT then twiddle (decimation in frequency); true: twiddle then DFT.  w1 = e^{+2 pi i j / Ls} of this
-// thread's j = tid mod (Ls / R) (the same for every butterfly the thread ever gets in this pass).
-template <int PK, int N, int NCH, int BS, int Ls, int R, int SIGN, bool DIT, int T>
-__device__ __forceinline__ static void ct_pass(double2 *sm, const double2 w1, const int tid) {
-    constexpr int NB = N / R, Q = Ls / R, TOT = NCH * NB;
-    constexpr int IT = (TOT + T - 1) / T;
-    const double2 w = make_double2(w1.x, SIGN > 0 ? w1.y : -w1.y);
-#pragma unroll
-    for (int it = 0; it < IT; it++) {
-        const int idx = tid + it * T;
-        if ((TOT % T) != 0 && idx >= TOT) break;
-        const int ch = idx / NB, t = idx - ch * NB;
-        const int b = t / Q, j = t - b * Q;
-        double2 *p = sm + ch * BS + fpad(b * Ls + j);
-        double2 x[R];
-#pragma unroll
-        for (int r = 0; r < R; r++) x[r] = p[fpc(r * Q)];
-        if (DIT && Q > 1) tw_apply<R>(x, w);
-        DftR<R, SIGN>::run(x);
-        if (!DIT && Q > 1) tw_apply<R>(x, w);
-#pragma unroll
-        for (int r = 0; r < R; r++) p[fpc(r * Q)] = x[r];
-    }
-}
+#include "fft_ct.h"
 
 // ---- register prefetch of the F_m cells of one (ring, NCH channels) item ---------------------------------------
 template <int NCH>
@@ -1092,477 +752,6 @@ ringana_direct_ct(const int32_t *__restrict__ ring_list, int nlist, int lmax, in
             if (tid == 0 && N < Lr) emit(N, make_double2(-1.0, 0.0), shifted ? make_double2(0.0, -1.0) : make_double2(1.0, 0.0));
         }
     }
-}
-
-// ------------------------------------------------------------------------------------
-// Flat-sky fields (cora/core/gaussianfield.py:102-120, numpy.fft.irfftn's last axis): the half-complex -> real transform
-// of EVEN length 2 N along the contiguous axis as ringfft_direct_ct's three passes - Hermitian step fused into the
-// first, pixel-order store fused into the last - on NCH adjacent lines per item.  in: lines of N + 1 complex bins, out:
-// lines of 2 N reals, out = scale * irfft (numpy semantics: the imaginary parts of the DC and Nyquist bins are ignored).
-// The generic line kernel (flatsky.hip: radix-4 LDS stages, a barrier each) ran this pass at 3.1 TB/s.
-// ------------------------------------------------------------------------------------
-template <int N, int NCH, int T>
-__global__ void __launch_bounds__(T)
-linec2r_ct(const double2 *in, double *out, long nlines, double scale) {
-    constexpr int PK = 1;                    // (strides down to 16 elements: the one-slot-per-16 padding is additive for them)
-    constexpr int R0 = Sch<N>::R0, R1 = Sch<N>::R1, R2 = Sch<N>::R2;
-    static_assert((R0 == 16 || R0 == 12) && R1 == 16 && N == R0 * R1 * R2, "digit map of the fused store assumes R0 x 16 x R2");
-    constexpr int Q0 = N / R0;
-    static_assert(Q0 % 16 == 0, "first-pass stride must be a multiple of the padding period");
-    constexpr int BS = fpc(N) + 1 + K5_CH_SKEW;
-    constexpr int U = NCH * N / T;           // bins 0 .. N-1 per thread (the Nyquist bins: one more load on NCH threads)
-    static_assert((NCH * N) % T == 0, "whole loads per thread");
-    extern __shared__ __attribute__((aligned(16))) double2 sm[];
-    const int tid0 = threadIdx.x;
-    const long nitems = (nlines + NCH - 1) / NCH;
-
-    double2 wH, wA, wB;     // e^{i pi j0 / N}, e^{2 pi i j0 / N}, e^{2 pi i j1 / (N / R0)}
-    {
-        const int j0 = tid0 & (Q0 - 1), j1 = tid0 & (Q0 / R1 - 1);
-        double s, c;
-        sincospi((double)j0 / (double)N, &s, &c);
-        wH = make_double2(c, s);
-        sincospi(2.0 * (double)j0 / (double)N, &s, &c);
-        wA = make_double2(c, s);
-        sincospi(2.0 * (double)j1 / (double)Q0, &s, &c);
-        wB = make_double2(c, s);
-    }
-    double2 pf[U], pfn;
-    auto prefetch = [&](long item, int tid) {
-        const long line0 = item * NCH;
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            const int e = tid + u * T;
-            const long line = min(line0 + e / N, nlines - 1);
-            pf[u] = in[line * (N + 1) + e % N];
-        }
-        pfn = in[min(line0 + (tid & (NCH - 1)), nlines - 1) * (N + 1) + N];
-    };
-    long vitem = blockIdx.x;
-    if (vitem < nitems) prefetch(vitem, tid0);
-    for (; vitem < nitems; vitem += gridDim.x) {
-        int tid = tid0;                                   // opaque per item: see ringfft_direct_ct
-        asm volatile("" : "+v"(tid));
-        const long line0 = vitem * NCH;
-        __syncthreads();                                  // previous item's LDS reads are done
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            const int e = tid + u * T;
-            const int c = e / N, k = e % N;
-            double2 v = pf[u];
-            if (k == 0) v.y = 0.0;
-            sm[c * BS + fpad(k)] = v;
-        }
-        if (tid < NCH) sm[tid * BS + fpad(N)] = make_double2(pfn.x, 0.0);
-        prefetch(min(vitem + (long)gridDim.x, nitems - 1), tid);
-        __syncthreads();
-        // ---- pass 1 with the Hermitian step (ringfft_direct_ct): Z_k = (X_k + conj X_{N-k}) + i w^k (X_k - conj X_{N-k})
-        {
-            constexpr int TOT = NCH * Q0;
-            constexpr int IT = (TOT + T - 1) / T;
-            double2 x[IT][R0];
-            double2 wh = wH;
-            asm volatile("" : "+v"(wh.x), "+v"(wh.y));
-#pragma unroll
-            for (int it = 0; it < IT; it++) {
-                const int idx = tid + it * T;
-                if ((TOT % T) != 0 && idx >= TOT) break;
-                const int ch = idx / Q0, j0 = idx & (Q0 - 1);
-                const double2 *pa = sm + ch * BS + fpad(j0);
-                const double2 *pb = sm + ch * BS + fpad(Q0 - j0);
-#pragma unroll
-                for (int r = 0; r < R0; r++) {
-                    const double2 xa = pa[fpc(r * Q0)];
-                    const double2 xb = pb[fpc((R0 - 1 - r) * Q0)];
-                    const double2 w = cmul(wh, R0 == 16 ? make_double2(kCos16[r % 16], kSin16[r % 16]) : make_double2(kCos12[r % 12], kSin12[r % 12]));
-                    const double2 sum = make_double2(xa.x + xb.x, xa.y - xb.y);
-                    const double2 dif = make_double2(xa.x - xb.x, xa.y + xb.y);
-                    const double2 t = cmul(dif, w);
-                    x[it][r] = make_double2(sum.x - t.y, sum.y + t.x);
-                }
-            }
-            __syncthreads();                              // every raw X has been read
-#pragma unroll
-            for (int it = 0; it < IT; it++) {
-                const int idx = tid + it * T;
-                if ((TOT % T) != 0 && idx >= TOT) break;
-                const int ch = idx / Q0, j0 = idx & (Q0 - 1);
-                double2 *pa = sm + ch * BS + fpad(j0);
-                DftR<R0, 1>::run(x[it]);
-                tw_apply<R0>(x[it], wA);
-#pragma unroll
-                for (int r = 0; r < R0; r++) pa[fpc(r * Q0)] = x[it][r];
-            }
-        }
-        __syncthreads();
-        ct_pass<PK, N, NCH, BS, Q0, R1, 1, false, T>(sm, wB, tid);
-        __syncthreads();
-        // ---- last pass (radix R2 on contiguous elements) with the store: butterfly t = 16 k0 + k1 holds the natural
-        //      indices k0 + R0 k1 + 16 R0 r; R0 = 16: eight consecutive lanes store 128 contiguous bytes (lane bits as in
-        //      ringfft_direct_ct), R0 = 12: lanes along k0
-        {
-            constexpr int NB2 = R0 * R1;                  // butterflies per line
-            constexpr int TOT = NCH * NB2;
-            constexpr int IT = (TOT + T - 1) / T;
-#pragma unroll
-            for (int it = 0; it < IT; it++) {
-                const int idx = tid + it * T;
-                if ((TOT % T) != 0 && idx >= TOT) break;
-                const int ch = idx / NB2, q = idx - ch * NB2;
-                const int k0 = R0 == 16 ? ((q & 7) | ((q >> 3) & 8)) : q % R0;
-                const int k1 = R0 == 16 ? (((q >> 3) & 7) | ((q >> 4) & 8)) : q / R0;
-                const double2 *p = sm + ch * BS + fpad((k0 * 16 + k1) * R2);
-                double2 x[R2];
-#pragma unroll
-                for (int r = 0; r < R2; r++) x[r] = p[fpc(r)];
-                DftR<R2, 1>::run(x);
-                if (line0 + ch < nlines) {
-                    double *o = out + (line0 + ch) * (2L * N) + 2 * (k0 + R0 * k1);
-#pragma unroll
-                    for (int r = 0; r < R2; r++) *reinterpret_cast<double2 *>(o + 2 * NB2 * r) = make_double2(x[r].x * scale, x[r].y * scale);
-                }
-            }
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------
-// Flat-sky fields: complex -> complex along a STRIDED axis (element j of line (o, i) at ((o N + j) inner + i)), NCH
-// lines that are neighbours along the contiguous axis per item: rows of 16 NCH contiguous bytes (the generic kernel's
-// 64 KB tiles hold four lines of 1024: 64-byte segments, 2.8 TB/s).  Natural order in, three DIF passes, the store
-// reads through the digit map.  GEN: the input is generated where it is committed - element e = kweight[e] (N(0,1) +
-// i N(0,1)), the Box-Muller pair of Philox counter e (randomfield_draw_kernel's values: RandomField.getfield,
-// cora/core/gaussianfield.py:115-119) - `in` is then the real k-weight array.  In place allowed.
-// ------------------------------------------------------------------------------------
-template <int N, int NCH, int T, int SIGN, bool GEN>
-__global__ void __launch_bounds__(T)
-linec2c_ct(const double *in, double2 *out, long nouter, long inner, double scale, uint64_t seed) {
-    constexpr int PK = 1;
-    constexpr int R0 = Sch<N>::R0, R1 = Sch<N>::R1, R2 = Sch<N>::R2;
-    static_assert((R0 == 16 || R0 == 12) && R1 == 16 && N == R0 * R1 * R2, "R0 x 16 x R2");
-    constexpr int Q0 = N / R0;
-    static_assert(Q0 % 16 == 0 && T % Q0 == 0, "per-thread twiddles");
-    constexpr int BS = fpc(N) + K5_CH_SKEW;
-    constexpr int U = NCH * N / T;
-    static_assert((NCH * N) % T == 0 && (NCH & (NCH - 1)) == 0, "whole loads per thread");
-    extern __shared__ __attribute__((aligned(16))) double2 sm[];
-    double2 *lg_l = sm + NCH * BS, *sc_l = lg_l + 257;       // GEN: the generator's tables (rng_dev.h)
-    const int tid0 = threadIdx.x;
-    const double2 *in2 = reinterpret_cast<const double2 *>(in);
-    const long chunks = (inner + NCH - 1) / NCH;
-    const long ntiles = nouter * chunks;
-    if (GEN) {
-        for (int k = tid0; k < 257; k += T) lg_l[k] = RNG_LOG_TAB[k];
-        for (int k = tid0; k < 256; k += T) sc_l[k] = RNG_SC_TAB[k];
-    }
-    double2 wA, wB;     // e^{2 pi i j0 / N}, e^{2 pi i j1 / (N / R0)}
-    {
-        const int j0 = tid0 & (Q0 - 1), j1 = tid0 & (Q0 / R1 - 1);
-        double s, c;
-        sincospi(2.0 * (double)j0 / (double)N, &s, &c);
-        wA = make_double2(c, s);
-        sincospi(2.0 * (double)j1 / (double)Q0, &s, &c);
-        wB = make_double2(c, s);
-    }
-    // tiles that are neighbours along the contiguous axis share 128-byte lines (the row pitch is odd in 16-byte units):
-    // the workgroups of one XCD take eight adjacent tiles at a time (flatsky.hip, FS_PAIR_XCD)
-    constexpr int GL = 3;
-    const long gmask = (8L << GL) - 1;
-    const bool pair_xcd = (ntiles & gmask) == 0 && (gridDim.x & gmask) == 0;
-    auto remap = [&](long v) {
-        if (!pair_xcd) return v;
-        const long slot = v >> 3, xcd = v & 7;
-        return (((slot >> GL) * 8 + xcd) << GL) + (slot & ((1 << GL) - 1));
-    };
-    struct tile_t {
-        long base;
-        int teff;
-    };
-    auto tile_of = [&](long v) {
-        const long outer = v / chunks, i0 = (v - outer * chunks) * NCH;
-        tile_t t;
-        t.base = outer * N * inner + i0;
-        t.teff = (int)min((long)NCH, inner - i0);
-        return t;
-    };
-    double2 R[U];
-    auto prefetch = [&](const tile_t &tl, int tid) {
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            const int e = tid + u * T;
-            const int c = e & (NCH - 1), j = e / NCH;
-            const long addr = tl.base + (long)j * inner + min(c, tl.teff - 1);
-            R[u] = GEN ? make_double2(in[addr], 0.0) : in2[addr];
-        }
-    };
-    long vt = blockIdx.x;
-    if (vt >= ntiles) return;
-    tile_t cur = tile_of(remap(vt));
-    prefetch(cur, tid0);
-    while (true) {
-        int tid = tid0;                                   // opaque per item: see ringfft_direct_ct
-        asm volatile("" : "+v"(tid));
-        __syncthreads();                                  // previous item's LDS reads are done (and the tables are filled)
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            const int e = tid + u * T;
-            const int c = e & (NCH - 1), j = e / NCH;
-            double2 v = R[u];
-            if (GEN) {
-                const long addr = cur.base + (long)j * inner + min(c, cur.teff - 1);
-                const double2 z = philox_boxmuller((uint64_t)addr, seed, lg_l, sc_l);
-                v = make_double2(z.x * v.x, z.y * v.x);
-            }
-            sm[c * BS + fpad(j)] = v;
-        }
-        const long vnext = vt + gridDim.x;
-        const tile_t nxt = tile_of(remap(min(vnext, ntiles - 1)));
-        prefetch(nxt, tid);                               // (unconditional: the last iteration re-reads a tile)
-        __syncthreads();
-        ct_pass<PK, N, NCH, BS, N, R0, SIGN, false, T>(sm, wA, tid);
-        __syncthreads();
-        ct_pass<PK, N, NCH, BS, Q0, R1, SIGN, false, T>(sm, wB, tid);
-        __syncthreads();
-        // ---- last pass (radix R2 on contiguous elements) with the store: butterfly t = 16 k0 + k1 of line ch holds the
-        //      natural indices k0 + R0 k1 + 16 R0 r; the lines of a row leave as 16 NCH contiguous bytes
-        {
-            constexpr int TOT = NCH * R0 * R1;
-            constexpr int IT = (TOT + T - 1) / T;
-#pragma unroll
-            for (int it = 0; it < IT; it++) {
-                const int idx = tid + it * T;
-                if ((TOT % T) != 0 && idx >= TOT) break;
-                const int ch = idx & (NCH - 1), t = idx / NCH;
-                const int k0 = t >> 4, k1 = t & 15;
-                const double2 *p = sm + ch * BS + fpad(t * R2);
-                double2 x[R2];
-#pragma unroll
-                for (int r = 0; r < R2; r++) x[r] = p[fpc(r)];
-                DftR<R2, SIGN>::run(x);
-                if (ch < cur.teff) {
-                    double2 *o = out + cur.base + (long)(k0 + R0 * k1) * inner + ch;
-#pragma unroll
-                    for (int r = 0; r < R2; r++) o[(long)(R0 * R1 * r) * inner] = make_double2(x[r].x * scale, x[r].y * scale);
-                }
-            }
-        }
-        if (vnext >= ntiles) break;
-        vt = vnext;
-        cur = nxt;
-    }
-}
-
-template <int N, int NCH, int T>
-static int launch_linec2c(corahip_ctx *ctx, const double *in, double *out, long nouter, long inner, int inverse, double scale, bool gen,
-                          uint64_t seed) {
-    constexpr int PK = 1;
-    constexpr int BS = fpc(N) + K5_CH_SKEW;
-    const size_t shm = sizeof(double2) * ((size_t)NCH * BS + (gen ? 513 : 0));
-    const long ntiles = nouter * ((inner + NCH - 1) / NCH);
-    const long per_cu = std::max<long>(1, std::min<long>((160 * 1024) / shm, 2048 / T));
-    dim3 grid((unsigned)std::min<long>(ntiles, (long)ctx->num_cu * per_cu));
-    double2 *o2 = reinterpret_cast<double2 *>(out);
-#define C2C_LAUNCH(SG, GN)                                                                                                  \
-    HIP_TRY(hipFuncSetAttribute((const void *)linec2c_ct<N, NCH, T, SG, GN>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
-    linec2c_ct<N, NCH, T, SG, GN><<<grid, T, shm, ctx->stream>>>(in, o2, nouter, inner, scale, seed)
-    if (gen) { C2C_LAUNCH(1, true); }
-    else if (inverse) { C2C_LAUNCH(1, false); }
-    else { C2C_LAUNCH(-1, false); }
-#undef C2C_LAUNCH
-    LAUNCH_CHECK();
-    return 0;
-}
-// a strided complex pass of the flat-sky transforms (inner > 1) for the lengths that have a compile-time schedule;
-// gen: inverse pass whose input is generated from the real k-weights `in` (corahip_randomfield_irfftn).  *took = false:
-// the generic line kernel takes it
-int flat_c2c_ct(corahip_ctx *ctx, const double *in, double *out, long nouter, int n, long inner, int inverse, double scale, bool gen,
-                uint64_t seed, bool *took) {
-    static const bool off = getenv("CORAHIP_FLAT_GENERIC") != nullptr;
-    *took = false;
-    if (off || nouter < 1 || inner < 2) return 0;
-    int rc;
-    if (n == 256 && inner >= 16) rc = launch_linec2c<256, 16, 256>(ctx, in, out, nouter, inner, inverse, scale, gen, seed);
-    else if (n == 512 && inner >= 16) rc = launch_linec2c<512, 16, 512>(ctx, in, out, nouter, inner, inverse, scale, gen, seed);
-    else if (n == 1024 && inner >= 8) rc = launch_linec2c<1024, 8, 512>(ctx, in, out, nouter, inner, inverse, scale, gen, seed);
-    else if (n == 384 && inner >= 16) rc = launch_linec2c<384, 16, 512>(ctx, in, out, nouter, inner, inverse, scale, gen, seed);
-    else if (n == 768 && inner >= 8) rc = launch_linec2c<768, 8, 512>(ctx, in, out, nouter, inner, inverse, scale, gen, seed);
-    else return 0;
-    if (rc) return rc;
-    *took = true;
-    return 0;
-}
-
-// ------------------------------------------------------------------------------------
-// Flat-sky fields: real -> half-complex along the contiguous axis (numpy.fft.rfftn's first pass, cora/util/fftutil.py:64-75;
-// the velocity cube of RedshiftCorrelation.realisation, cora/signal/corr.py:590-599), EVEN length 2 N: ringana_direct_ct's
-// passes - z_j = x_2j + i x_2j+1 loaded in the digit order of the first (radix R2) pass, two radix-16 DIT passes, then
-// the split X_k = 1/2 [(Z_k + conj Z_{N-k}) - i e^{-i pi k / N} (Z_k - conj Z_{N-k})], k = 0 .. N - on NCH adjacent lines.
-// ------------------------------------------------------------------------------------
-template <int N, int NCH, int T>
-__global__ void __launch_bounds__(T)
-liner2c_ct(const double *in, double2 *out, long nlines) {
-    constexpr int PK = 1;
-    constexpr int R0 = Sch<N>::R0, R1 = Sch<N>::R1, R2 = Sch<N>::R2;
-    static_assert((R0 == 16 || R0 == 12) && R1 == 16 && N == R0 * R1 * R2, "R0 x 16 x R2");
-    constexpr int Q0 = N / R0;
-    static_assert(Q0 % 16 == 0 && T % Q0 == 0, "per-thread twiddles");
-    constexpr int BS = fpc(N) + 1 + K5_CH_SKEW;
-    constexpr int NB2 = R0 * R1;
-    constexpr int TOT0 = NCH * NB2, IT0 = (TOT0 + T - 1) / T;
-    constexpr int MO = (NCH * N + T - 1) / T;            // output bins 0 .. N-1 per thread (bin N: one more on NCH threads)
-    extern __shared__ __attribute__((aligned(16))) double2 sm[];
-    const int tid0 = threadIdx.x;
-    const long nitems = (nlines + NCH - 1) / NCH;
-    double2 wA, wB, wS, wSstep;     // (wS: e^{-i pi (tid mod N) / N}, its step over T bins)
-    {
-        const int j0 = tid0 & (Q0 - 1), j1 = tid0 & (Q0 / R1 - 1);
-        double s, c;
-        sincospi(2.0 * (double)j0 / (double)N, &s, &c);
-        wA = make_double2(c, s);
-        sincospi(2.0 * (double)j1 / (double)Q0, &s, &c);
-        wB = make_double2(c, s);
-        sincospi((double)(tid0 % N) / (double)N, &s, &c);
-        wS = make_double2(c, -s);
-        sincospi((double)T / (double)N, &s, &c);
-        wSstep = make_double2(c, -s);
-    }
-    double2 pf[IT0 * R2];     // (flat: as [IT0][1] the array stayed in scratch memory)
-    auto prefetch = [&](long item, int tid) {
-        const long line0 = item * NCH;
-#pragma unroll
-        for (int it = 0; it < IT0; it++) {
-            const int idx = min(tid + it * T, TOT0 - 1);
-            const int ch = idx / NB2, q = idx - ch * NB2;
-            const int k0 = R0 == 16 ? ((q & 7) | ((q >> 3) & 8)) : q % R0;
-            const int k1 = R0 == 16 ? (((q >> 3) & 7) | ((q >> 4) & 8)) : q / R0;
-            const double *src = in + min(line0 + ch, nlines - 1) * (2L * N) + 2 * (k0 + R0 * k1);
-#pragma unroll
-            for (int r = 0; r < R2; r++) pf[it * R2 + r] = *reinterpret_cast<const double2 *>(src + 2 * NB2 * r);
-        }
-    };
-    long vitem = blockIdx.x;
-    if (vitem < nitems) prefetch(vitem, tid0);
-    for (; vitem < nitems; vitem += gridDim.x) {
-        int tid = tid0;
-        asm volatile("" : "+v"(tid));
-        const long line0 = vitem * NCH;
-        __syncthreads();
-#pragma unroll
-        for (int it = 0; it < IT0; it++) {
-            const int idx = tid + it * T;
-            if ((TOT0 % T) != 0 && idx >= TOT0) break;
-            const int ch = idx / NB2, q = idx - ch * NB2;
-            const int k0 = R0 == 16 ? ((q & 7) | ((q >> 3) & 8)) : q % R0;
-            const int k1 = R0 == 16 ? (((q >> 3) & 7) | ((q >> 4) & 8)) : q / R0;
-            double2 *p = sm + ch * BS + fpad((k0 * 16 + k1) * R2);
-            double2 x[R2];
-#pragma unroll
-            for (int r = 0; r < R2; r++) x[r] = pf[it * R2 + r];
-            DftR<R2, -1>::run(x);
-#pragma unroll
-            for (int r = 0; r < R2; r++) p[fpc(r)] = x[r];
-        }
-        prefetch(min(vitem + (long)gridDim.x, nitems - 1), tid);
-        __syncthreads();
-        ct_pass<PK, N, NCH, BS, Q0, R1, -1, true, T>(sm, wB, tid);
-        __syncthreads();
-        ct_pass<PK, N, NCH, BS, N, R0, -1, true, T>(sm, wA, tid);
-        __syncthreads();
-        auto emit = [&](int c, int k, const double2 w) {       // w = e^{-i pi k / N}
-            const int ka = k == N ? 0 : k;                     // Z_N := Z_0
-            const int kb = k == 0 ? 0 : N - k;
-            const double2 za = sm[c * BS + fpad(ka)], zb = sm[c * BS + fpad(kb)];
-            const double2 sum = make_double2(za.x + zb.x, za.y - zb.y);
-            const double2 dif = make_double2(za.x - zb.x, za.y + zb.y);
-            const double2 t = cmul(dif, w);
-            if (line0 + c < nlines) out[(line0 + c) * (N + 1L) + k] = make_double2(0.5 * (sum.x + t.y), 0.5 * (sum.y - t.x));
-        };
-        // element e = tid + u T is bin k = e mod N of line e / N: the twiddle follows by one rotation per step and a sign
-        // per wrap (e^{-i pi (k - N) / N} = -e^{-i pi k / N})
-        {
-            int c = tid / N, k = tid - c * N;
-            double2 w = wS;
-            asm volatile("" : "+v"(w.x), "+v"(w.y));
-#pragma unroll
-            for (int u = 0; u < MO; u++) {
-                if ((NCH * N) % T == 0 || c < NCH) emit(c, k, w);
-                w = cmul(w, wSstep);
-                k += T;
-                while (k >= N) {
-                    k -= N;
-                    c++;
-                    w = make_double2(-w.x, -w.y);
-                }
-            }
-        }
-        if (tid < NCH) emit(tid, N, make_double2(-1.0, 0.0));
-    }
-}
-template <int N, int NCH, int T>
-static int launch_liner2c(corahip_ctx *ctx, const double *in, double *spec, long nlines) {
-    constexpr int PK = 1;
-    constexpr int BS = fpc(N) + 1 + K5_CH_SKEW;
-    const size_t shm = sizeof(double2) * (size_t)NCH * BS;
-    const long nitems = (nlines + NCH - 1) / NCH;
-    const long per_cu = std::max<long>(1, std::min<long>((160 * 1024) / shm, 2048 / T));
-    dim3 grid((unsigned)std::min<long>(nitems, (long)ctx->num_cu * per_cu));
-    HIP_TRY(hipFuncSetAttribute((const void *)liner2c_ct<N, NCH, T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    liner2c_ct<N, NCH, T><<<grid, T, shm, ctx->stream>>>(in, reinterpret_cast<double2 *>(spec), nlines);
-    LAUNCH_CHECK();
-    return 0;
-}
-// the contiguous real -> half-complex pass of corahip_rfftn (real length 2 h); *took = false: the generic kernel takes it
-int flat_r2c_ct(corahip_ctx *ctx, const double *in, double *spec, long nlines, int h, bool *took) {
-    static const bool off = getenv("CORAHIP_FLAT_GENERIC") != nullptr;
-    *took = false;
-    if (off || nlines < 1) return 0;
-    int rc;
-    if (h == 256) rc = launch_liner2c<256, 16, 512>(ctx, in, spec, nlines);
-    else if (h == 512) rc = launch_liner2c<512, 16, 512>(ctx, in, spec, nlines);
-    else if (h == 1024) rc = launch_liner2c<1024, 8, 512>(ctx, in, spec, nlines);
-    else if (h == 2048) rc = launch_liner2c<2048, 4, 512>(ctx, in, spec, nlines);
-    else if (h == 192) rc = launch_liner2c<192, 16, 512>(ctx, in, spec, nlines);
-    else if (h == 384) rc = launch_liner2c<384, 16, 512>(ctx, in, spec, nlines);
-    else if (h == 768) rc = launch_liner2c<768, 8, 512>(ctx, in, spec, nlines);
-    else if (h == 1536) rc = launch_liner2c<1536, 4, 512>(ctx, in, spec, nlines);
-    else return 0;
-    if (rc) return rc;
-    *took = true;
-    return 0;
-}
-
-template <int N, int NCH, int T>
-static int launch_linec2r(corahip_ctx *ctx, const double *spec, double *out, long nlines, double scale) {
-    constexpr int PK = 1;
-    constexpr int BS = fpc(N) + 1 + K5_CH_SKEW;
-    const size_t shm = sizeof(double2) * (size_t)NCH * BS;
-    const long nitems = (nlines + NCH - 1) / NCH;
-    const long per_cu = std::max<long>(1, std::min<long>((160 * 1024) / shm, 2048 / T));
-    dim3 grid((unsigned)std::min<long>(nitems, (long)ctx->num_cu * per_cu));
-    HIP_TRY(hipFuncSetAttribute((const void *)linec2r_ct<N, NCH, T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    linec2r_ct<N, NCH, T><<<grid, T, shm, ctx->stream>>>(reinterpret_cast<const double2 *>(spec), out, nlines, scale);
-    LAUNCH_CHECK();
-    return 0;
-}
-// the contiguous half-complex -> real pass of corahip_irfftn for the complex lengths that have a compile-time schedule;
-// *took = false: the generic line kernel takes it
-int flat_c2r_ct(corahip_ctx *ctx, const double *spec, double *out, long nlines, int h, double scale, bool *took) {
-    static const bool off = getenv("CORAHIP_FLAT_GENERIC") != nullptr;
-    *took = false;
-    if (off || nlines < 1) return 0;
-    int rc;
-    if (h == 256) rc = launch_linec2r<256, 16, 256>(ctx, spec, out, nlines, scale);
-    else if (h == 512) rc = launch_linec2r<512, 16, 512>(ctx, spec, out, nlines, scale);
-    else if (h == 1024) rc = launch_linec2r<1024, 8, 512>(ctx, spec, out, nlines, scale);
-    else if (h == 2048) rc = launch_linec2r<2048, 4, 512>(ctx, spec, out, nlines, scale);
-    else if (h == 192) rc = launch_linec2r<192, 16, 256>(ctx, spec, out, nlines, scale);
-    else if (h == 384) rc = launch_linec2r<384, 16, 512>(ctx, spec, out, nlines, scale);
-    else if (h == 768) rc = launch_linec2r<768, 8, 512>(ctx, spec, out, nlines, scale);
-    else if (h == 1536) rc = launch_linec2r<1536, 4, 512>(ctx, spec, out, nlines, scale);
-    else return 0;
-    if (rc) return rc;
-    *took = true;
-    return 0;
 }
 
 // ------------------------------------------------------------------------------------

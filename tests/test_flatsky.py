@@ -109,7 +109,9 @@ def test_fft_c2c_every_axis_position_vs_numpy(ctx, n):
                                    # item; line counts that are not multiples of it, and a single line)
                                    (5, 7, 512), (3, 11, 1024), (21, 2048), (9, 4096), (1, 1024), (33, 512),
                                    # 3 * 2^k: radix 12 in the first pass
-                                   (5, 7, 384), (19, 768), (9, 1536), (5, 3072), (384, 40, 6)])
+                                   (5, 7, 384), (19, 768), (9, 1536), (5, 3072), (384, 40, 6),
+                                   # arbitrary lengths on strided axes: Bluestein on the compile-time passes (P = 640, 640, 2048, 320)
+                                   (261, 316, 24), (628, 9, 10), (130, 20)])
 def test_rfftn_irfftn_vs_numpy(ctx, shape):
     import torch
 
@@ -217,7 +219,7 @@ def test_device_seeded_field_vs_oracle_stream_and_spectrum(ctx):
 
     # (first axes 256 / 512 / 1024: the generating pass with the compile-time FFT passes, whole and partial tiles)
     for shape in ([12, 10, 14], [16, 64], [9, 20], [33, 7, 11], [40], [256, 6, 12], [512, 64], [1024, 5, 8], [256, 256, 30],
-                  [384, 20, 12], [768, 3, 30]):
+                  [384, 20, 12], [768, 3, 30], [261, 30, 18], [100, 17, 8]):
         kw = ctx.empty(tuple(shape[:-1]) + (shape[-1] // 2 + 1,)).uniform_()
         two = ctx.irfftn(ctx.randomfield_draw(kw, 123), last=shape[-1])
         one = ctx.randomfield_irfftn(kw, 123, last=shape[-1])
