@@ -40,6 +40,8 @@ int flat_c2r_ct(corahip_ctx *ctx, const double *spec, double *out, long nlines, 
 int flat_blu_plan(corahip_ctx *ctx, int n, const double2 *chirp, int *Pct, double2 **filt_ct);
 int flat_blu_c2c_ct(corahip_ctx *ctx, const double *in, double *out, long nouter, int n, long inner, int inverse, double scale, bool gen,
                     uint64_t seed, int Pct, const double2 *chirp, const double2 *filt_ct, bool *took);
+int flat_blu_real_ct(corahip_ctx *ctx, bool c2r, const double *in, double *out, long nlines, int h, double scale, int Pct,
+                     const double2 *chirp, const double2 *filt_ct, const double2 *rtw, bool *took);
 int flat_r2c_ct(corahip_ctx *ctx, const double *in, double *spec, long nlines, int h, bool *took);
 int flat_c2c_ct(corahip_ctx *ctx, const double *in, double *out, long nouter, int n, long inner, int inverse, double scale, bool gen,
                 uint64_t seed, bool *took);

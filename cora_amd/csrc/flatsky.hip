@@ -609,6 +609,11 @@ static int launch_linefft(corahip_ctx *ctx, const double *in, double *out, long 
     const corahip_linefft_plan *pl;
     int rc = get_linefft_plan(ctx, n, &pl);
     if (rc) return rc;
+    if ((MODE == 3 || MODE == 4) && inner == 1 && pl->blu && pl->Pct) {      // even real length 2 n, n arbitrary
+        bool took = false;
+        int rct = flat_blu_real_ct(ctx, MODE == 3, in, out, nouter, n, scale, pl->Pct, pl->chirp, pl->filt_ct, pl->rtw, &took);
+        if (rct || took) return rct;
+    }
     if ((MODE == 0 || MODE == 5) && inner > 1 && pl->blu && pl->Pct) {
         bool took = false;
         int rct = flat_blu_c2c_ct(ctx, in, out, nouter, n, inner, inverse, scale, MODE == 5, seed, pl->Pct, pl->chirp, pl->filt_ct, &took);

@@ -527,6 +527,67 @@ flat_blu_filter_kernel(int n, const double2 *__restrict__ chirp, double2 *__rest
     }
 }
 
+// the inner stages of the convolution on NCH lines of P points in LDS (line c at sm + c BS, BS = fpc(P) + 1): forward pass
+// 1 (sign -; the inputs r >= R0 / 2 are the zero padding and are not read), forward pass 2, last forward pass + filter +
+// first inverse pass in registers (fl: the filter values of this thread's butterfly t = tid mod (P / R2)), inverse pass
+// 2.  Starts behind the caller's barrier, ends with one; the caller runs the last inverse pass (radix R0, stride P / R0).
+// `hook` runs in front of inverse pass 2: loads that are needed behind the last pass and have no registers to live in
+// across all of the passes (the output chirps) are requested there.
+struct blu_no_hook {
+    __device__ __forceinline__ void operator()() const {}
+};
+template <int P, int NCH, int T, class Hook = blu_no_hook>
+__device__ __forceinline__ static void blu_core(double2 *sm, const int tid, const double2 wA, const double2 wB,
+                                                const double2 (&fl)[Sch<P>::R2], Hook &&hook = Hook()) {
+    constexpr int PK = 1;
+    constexpr int R0 = Sch<P>::R0, R1 = Sch<P>::R1, R2 = Sch<P>::R2;
+    constexpr int Q0 = P / R0, BS = fpc(P) + 1, NB = P / R2;
+    constexpr int TOTL = NCH * Q0;
+    {
+        const double2 w = cconj(wA);
+        const int idx = tid;
+        if (TOTL == T || idx < TOTL) {
+            const int ch = idx / Q0, j0 = idx & (Q0 - 1);
+            double2 *p = sm + ch * BS + fpad(j0);
+            double2 x[R0];
+#pragma unroll
+            for (int r = 0; r < R0 / 2; r++) x[r] = p[fpc(r * Q0)];
+#pragma unroll
+            for (int r = R0 / 2; r < R0; r++) x[r] = make_double2(0.0, 0.0);
+            DftR<R0, -1>::run(x);
+            tw_apply<R0>(x, w);
+#pragma unroll
+            for (int r = 0; r < R0; r++) p[fpc(r * Q0)] = x[r];
+        }
+    }
+    __syncthreads();
+    ct_pass<PK, P, NCH, BS, Q0, R1, -1, false, T>(sm, wB, tid);
+    __syncthreads();
+    {
+        constexpr int CPI = T / NB, IT = (NCH + CPI - 1) / CPI;
+#pragma unroll
+        for (int it = 0; it < IT; it++) {
+            const int chl = tid / NB, t = tid - chl * NB;
+            const int ch = it * CPI + chl;
+            if (chl >= CPI || ch >= NCH) break;
+            double2 *p = sm + ch * BS + fpad(t * R2);
+            double2 x[R2];
+#pragma unroll
+            for (int r = 0; r < R2; r++) x[r] = p[fpc(r)];
+            DftR<R2, -1>::run(x);
+#pragma unroll
+            for (int r = 0; r < R2; r++) x[r] = cmul(x[r], fl[r]);
+            DftR<R2, 1>::run(x);
+#pragma unroll
+            for (int r = 0; r < R2; r++) p[fpc(r)] = x[r];
+        }
+    }
+    hook();      // (loads the caller needs behind the last pass are requested here: one pass ahead)
+    __syncthreads();
+    ct_pass<PK, P, NCH, BS, Q0, R1, 1, true, T>(sm, wB, tid);
+    __syncthreads();
+}
+
 template <int P, int NCH, int T, bool GEN>
 __global__ void __launch_bounds__(T)
 lineblu_c2c_ct(const double *in, double2 *out, long nouter, long inner, int n, double scale, int inverse, const double2 *chirp,
@@ -638,52 +699,7 @@ lineblu_c2c_ct(const double *in, double2 *out, long nouter, long inner, int n, d
         const tile_t nxt = tile_of(remap(min(vnext, ntiles - 1)));
         prefetch(nxt, tid);
         __syncthreads();
-        // ---- forward pass 1 (sign -), inputs r >= R0 / 2 are the zero padding and are not read
-        {
-            const double2 w = cconj(wA);
-#pragma unroll
-            for (int it = 0; it < ITL; it++) {
-                const int idx = tid + it * T;
-                if ((TOTL % T) != 0 && idx >= TOTL) break;
-                const int ch = idx / Q0, j0 = idx & (Q0 - 1);
-                double2 *p = sm + ch * BS + fpad(j0);
-                double2 x[R0];
-#pragma unroll
-                for (int r = 0; r < R0 / 2; r++) x[r] = p[fpc(r * Q0)];
-#pragma unroll
-                for (int r = R0 / 2; r < R0; r++) x[r] = make_double2(0.0, 0.0);
-                DftR<R0, -1>::run(x);
-                tw_apply<R0>(x, w);
-#pragma unroll
-                for (int r = 0; r < R0; r++) p[fpc(r * Q0)] = x[r];
-            }
-        }
-        __syncthreads();
-        ct_pass<PK, P, NCH, BS, Q0, R1, -1, false, T>(sm, wB, tid);
-        __syncthreads();
-        // ---- last forward pass, filter, first inverse pass in registers
-        {
-            constexpr int CPI = T / NB, IT = (NCH + CPI - 1) / CPI;
-#pragma unroll
-            for (int it = 0; it < IT; it++) {
-                const int chl = tid / NB, t = tid - chl * NB;
-                const int ch = it * CPI + chl;
-                if (chl >= CPI || ch >= NCH) break;
-                double2 *p = sm + ch * BS + fpad(t * R2);
-                double2 x[R2];
-#pragma unroll
-                for (int r = 0; r < R2; r++) x[r] = p[fpc(r)];
-                DftR<R2, -1>::run(x);
-#pragma unroll
-                for (int r = 0; r < R2; r++) x[r] = cmul(x[r], fl[r]);
-                DftR<R2, 1>::run(x);
-#pragma unroll
-                for (int r = 0; r < R2; r++) p[fpc(r)] = x[r];
-            }
-        }
-        __syncthreads();
-        ct_pass<PK, P, NCH, BS, Q0, R1, 1, true, T>(sm, wB, tid);
-        __syncthreads();
+        blu_core<P, NCH, T>(sm, tid, wA, wB, fl);
         // ---- last inverse pass (sign +) with the store: the outputs k = j0 + r Q0 < n, times c_k; the lines of a row in
         //      consecutive lanes (16 NCH contiguous bytes)
         {
@@ -715,6 +731,255 @@ lineblu_c2c_ct(const double *in, double2 *out, long nouter, long inner, int n, d
         if (vnext >= ntiles) break;
         vt = vnext;
         cur = nxt;
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// The contiguous passes of EVEN real length 2 h, h arbitrary, through the same convolution (flatsky.hip's modes 3 / 4 on
+// the compile-time passes): c2r packs the pairs (k, h - k) of the half spectrum into conj(Z) c (one complex transform of
+// length h; the inverse runs as conj(FFT(conj .))) and stores conj(c_j conv_j) = x_2j + i x_2j+1; r2c transforms z_j =
+// x_2j + i x_2j+1 and unpacks X_k, X_{h-k} from Z_k, Z_{h-k}.  Everything that depends on (thread, h) only - LDS offsets
+// of the elements a thread commits, its pairs, their twiddles e^{i pi k / h} (the plan's rtw) and chirps - is set up once
+// per kernel: h is the same for every line.
+// ------------------------------------------------------------------------------------
+template <int P, int NCH, int T>
+__global__ void __launch_bounds__(T)
+lineblu_c2r_ct(const double2 *in, double2 *out, long nlines, int h, double scale, const double2 *chirp, const double2 *filt,
+               const double2 *rtw) {
+    constexpr int PK = 1;
+    constexpr int R0 = Sch<P>::R0, R2 = Sch<P>::R2;
+    constexpr int Q0 = P / R0, BS = fpc(P) + 1, HALF = P / 2, NB = P / R2, TOTL = NCH * Q0;
+    static_assert(TOTL <= T && T % Q0 == 0 && NB <= T, "one first / last pass butterfly per thread");
+    constexpr int UL = (NCH * (HALF + 1) + T - 1) / T;        // input bins per thread
+    constexpr int UP = (NCH * (HALF / 2 + 1) + T - 1) / T;    // pairs per thread
+    extern __shared__ __attribute__((aligned(16))) double2 sm[];
+    const int tid0 = threadIdx.x;
+    const int hp = (h >> 1) + 1;
+    const long nitems = (nlines + NCH - 1) / NCH;
+    double2 wA, wB;
+    {
+        const int j0 = tid0 & (Q0 - 1), j1 = tid0 & (Q0 / 16 - 1);
+        double s, c;
+        sincospi(2.0 * (double)j0 / (double)P, &s, &c);
+        wA = make_double2(c, s);
+        sincospi(2.0 * (double)j1 / (double)Q0, &s, &c);
+        wB = make_double2(c, s);
+    }
+    double2 fl[R2];
+#pragma unroll
+    for (int r = 0; r < R2; r++) fl[r] = filt[(size_t)(tid0 % NB) * R2 + r];
+    int lofs[UL];          // LDS slot of input element tid + u T of the item's chunk (-1: none; bit 30: DC / Nyquist bin)
+#pragma unroll
+    for (int u = 0; u < UL; u++) {
+        const int e = tid0 + u * T;
+        lofs[u] = -1;
+        if (e < NCH * (h + 1)) {
+            const int c = e / (h + 1), k = e - c * (h + 1);
+            lofs[u] = (c * BS + fpad(k)) | ((k == 0 || k == h) ? (1 << 30) : 0);
+        }
+    }
+    int pofs[UP], pk[UP];  // pairs: line offset (-1: none), k
+    double2 pw[UP];
+#pragma unroll
+    for (int u = 0; u < UP; u++) {
+        const int e = tid0 + u * T;
+        pofs[u] = -1;
+        pk[u] = 0;
+        pw[u] = make_double2(0.0, 0.0);
+        if (e < NCH * hp) {
+            const int c = e / hp, k = e - c * hp;
+            pofs[u] = c * BS;
+            pk[u] = k;
+            pw[u] = rtw[k];
+        }
+    }
+    double2 R[UL];
+    const long nel = nlines * (h + 1L);
+    auto prefetch = [&](long item, int tid) {
+        const long base = item * NCH * (h + 1L);
+#pragma unroll
+        for (int u = 0; u < UL; u++) R[u] = in[min(base + tid + u * T, nel - 1)];
+    };
+    long vitem = blockIdx.x;
+    if (vitem < nitems) prefetch(vitem, tid0);
+    for (; vitem < nitems; vitem += gridDim.x) {
+        int tid = tid0;
+        asm volatile("" : "+v"(tid));
+        const long line0 = vitem * NCH;
+        // chirps of this thread's pairs (the same for every item, but there are no registers to keep them across the passes)
+        double2 pck[UP], pck2[UP];
+#pragma unroll
+        for (int u = 0; u < UP; u++) {
+            pck[u] = chirp[min(pk[u], h - 1)];
+            pck2[u] = chirp[min(h - pk[u], h - 1)];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < UL; u++)
+            if (lofs[u] >= 0) {
+                double2 v = R[u];
+                if (lofs[u] & (1 << 30)) v.y = 0.0;           // Im of the DC / Nyquist bins is ignored
+                sm[lofs[u] & ~(1 << 30)] = v;
+            }
+        prefetch(min(vitem + (long)gridDim.x, nitems - 1), tid);
+        __syncthreads();
+        // ---- pairs (k, h - k) -> conj(Z) c in place (flatsky.hip, mode 3); position h (the Nyquist bin) back to zero
+#pragma unroll
+        for (int u = 0; u < UP; u++)
+            if (pofs[u] >= 0) {
+                double2 *ln = sm + pofs[u];
+                const int k = pk[u], k2 = h - k;
+                const double2 xk = ln[fpad(k)], xc = ln[fpad(k2)];
+                const double2 E = make_double2(xk.x + xc.x, xk.y - xc.y);
+                const double2 O = cmul(make_double2(xk.x - xc.x, xk.y + xc.y), pw[u]);
+                const double2 a = make_double2(E.x - O.y, -(E.y + O.x));      // conj(E + i O)
+                const double2 b = make_double2(E.x + O.y, -(O.x - E.y));      // conj(conj E + i conj O)
+                ln[fpad(k)] = cmul(a, pck[u]);
+                if (k == 0) ln[fpad(h)] = make_double2(0.0, 0.0);
+                else if (k2 != k) ln[fpad(k2)] = cmul(b, pck2[u]);
+            }
+        for (int j = h + 1 + tid; j < HALF; j += T)
+#pragma unroll
+            for (int c = 0; c < NCH; c++) sm[c * BS + fpad(j)] = make_double2(0.0, 0.0);
+        __syncthreads();
+        double2 ob[R0 / 2];     // chirps of the outputs this thread forms
+        blu_core<P, NCH, T>(sm, tid, wA, wB, fl, [&]() {
+#pragma unroll
+            for (int r = 0; r < R0 / 2; r++) ob[r] = chirp[min((tid & (Q0 - 1)) + r * Q0, h - 1)];
+        });
+        if (TOTL == T || tid < TOTL) {
+            const int ch = tid / Q0, j0 = tid & (Q0 - 1);
+            const double2 *p = sm + ch * BS + fpad(j0);
+            double2 x[R0];
+#pragma unroll
+            for (int r = 0; r < R0; r++) x[r] = p[fpc(r * Q0)];
+            tw_apply<R0>(x, wA);
+            DftR<R0, 1>::run(x);
+            if (line0 + ch < nlines) {
+                double2 *o = out + (line0 + ch) * (long)h;
+#pragma unroll
+                for (int r = 0; r < R0 / 2; r++) {
+                    const int j = j0 + r * Q0;
+                    if (j < h) {
+                        const double2 v = cmul(x[r], ob[r]);
+                        o[j] = make_double2(v.x * scale, -v.y * scale);    // conj: x_{2j} + i x_{2j+1}
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int P, int NCH, int T>
+__global__ void __launch_bounds__(T)
+lineblu_r2c_ct(const double2 *in, double2 *out, long nlines, int h, const double2 *chirp, const double2 *filt, const double2 *rtw) {
+    constexpr int PK = 1;
+    constexpr int R0 = Sch<P>::R0, R2 = Sch<P>::R2;
+    constexpr int Q0 = P / R0, BS = fpc(P) + 1, HALF = P / 2, NB = P / R2, TOTL = NCH * Q0;
+    static_assert(TOTL <= T && T % Q0 == 0 && NB <= T, "one first / last pass butterfly per thread");
+    constexpr int UL = (NCH * HALF + T - 1) / T;              // z_j per thread
+    constexpr int UP = (NCH * (HALF / 2 + 1) + T - 1) / T;    // pairs per thread
+    extern __shared__ __attribute__((aligned(16))) double2 sm[];
+    const int tid0 = threadIdx.x;
+    const int hp = (h >> 1) + 1;
+    const long nitems = (nlines + NCH - 1) / NCH;
+    double2 wA, wB;
+    {
+        const int j0 = tid0 & (Q0 - 1), j1 = tid0 & (Q0 / 16 - 1);
+        double s, c;
+        sincospi(2.0 * (double)j0 / (double)P, &s, &c);
+        wA = make_double2(c, s);
+        sincospi(2.0 * (double)j1 / (double)Q0, &s, &c);
+        wB = make_double2(c, s);
+    }
+    double2 fl[R2];
+#pragma unroll
+    for (int r = 0; r < R2; r++) fl[r] = filt[(size_t)(tid0 % NB) * R2 + r];
+    int lofs[UL], lj[UL];
+#pragma unroll
+    for (int u = 0; u < UL; u++) {
+        const int e = tid0 + u * T;
+        lofs[u] = -1;
+        lj[u] = 0;
+        if (e < NCH * h) {
+            const int c = e / h, j = e - c * h;
+            lofs[u] = c * BS + fpad(j);
+            lj[u] = j;
+        }
+    }
+    int pofs[UP], pk[UP], pline[UP];
+    double2 pw[UP];
+#pragma unroll
+    for (int u = 0; u < UP; u++) {
+        const int e = tid0 + u * T;
+        pofs[u] = -1;
+        pk[u] = pline[u] = 0;
+        pw[u] = make_double2(0.0, 0.0);
+        if (e < NCH * hp) {
+            const int c = e / hp, k = e - c * hp;
+            pofs[u] = c * BS;
+            pline[u] = c;
+            pk[u] = k;
+            pw[u] = rtw[k];
+        }
+    }
+    double2 R[UL], lcb[UL];     // z_j of the next item and (requested with them) their chirps
+    const long nel = nlines * (long)h;
+    auto prefetch = [&](long item, int tid) {
+        const long base = item * NCH * (long)h;
+#pragma unroll
+        for (int u = 0; u < UL; u++) {
+            R[u] = in[min(base + tid + u * T, nel - 1)];
+            lcb[u] = chirp[lj[u]];
+        }
+    };
+    long vitem = blockIdx.x;
+    if (vitem < nitems) prefetch(vitem, tid0);
+    for (; vitem < nitems; vitem += gridDim.x) {
+        int tid = tid0;
+        asm volatile("" : "+v"(tid));
+        const long line0 = vitem * NCH;
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < UL; u++)
+            if (lofs[u] >= 0) sm[lofs[u]] = cmul(R[u], lcb[u]);
+        for (int j = h + tid; j < HALF; j += T)
+#pragma unroll
+            for (int c = 0; c < NCH; c++) sm[c * BS + fpad(j)] = make_double2(0.0, 0.0);
+        prefetch(min(vitem + (long)gridDim.x, nitems - 1), tid);
+        __syncthreads();
+        double2 ob[R0 / 2];
+        blu_core<P, NCH, T>(sm, tid, wA, wB, fl, [&]() {
+#pragma unroll
+            for (int r = 0; r < R0 / 2; r++) ob[r] = chirp[min((tid & (Q0 - 1)) + r * Q0, h - 1)];
+        });
+        // ---- last inverse pass: Z_k = c_k conv_k, k < h, back to position k
+        if (TOTL == T || tid < TOTL) {
+            const int ch = tid / Q0, j0 = tid & (Q0 - 1);
+            double2 *p = sm + ch * BS + fpad(j0);
+            double2 x[R0];
+#pragma unroll
+            for (int r = 0; r < R0; r++) x[r] = p[fpc(r * Q0)];
+            tw_apply<R0>(x, wA);
+            DftR<R0, 1>::run(x);
+#pragma unroll
+            for (int r = 0; r < R0 / 2; r++) p[fpc(r * Q0)] = cmul(x[r], ob[r]);
+        }
+        __syncthreads();
+        // ---- unpack the pairs: X_k = E_k + W^{-k} O_k, X_{h-k} = conj(E_k - W^{-k} O_k) (flatsky.hip, mode 4)
+#pragma unroll
+        for (int u = 0; u < UP; u++)
+            if (pofs[u] >= 0 && line0 + pline[u] < nlines) {
+                const double2 *ln = sm + pofs[u];
+                const int k = pk[u], k2 = h - k;
+                const double2 zk = ln[fpad(k)], zc = ln[fpad(k2 == h ? 0 : k2)];
+                const double2 Ea = make_double2(0.5 * (zk.x + zc.x), 0.5 * (zk.y - zc.y));
+                const double2 Oa = make_double2(0.5 * (zk.y + zc.y), -0.5 * (zk.x - zc.x));   // (zk - conj zc) / 2i
+                const double2 B = cmul(make_double2(pw[u].x, -pw[u].y), Oa);
+                double2 *o = out + (line0 + pline[u]) * (long)(h + 1);
+                o[k] = make_double2(Ea.x + B.x, Ea.y + B.y);
+                if (k2 != k) o[k2] = make_double2(Ea.x - B.x, -(Ea.y - B.y));
+            }
     }
 }
 
@@ -797,6 +1062,55 @@ int flat_blu_c2c_ct(corahip_ctx *ctx, const double *in, double *out, long nouter
     case 1280: rc = launch_lineblu_c2c<1280, 4, 512>(BLU_ARGS); break;
     case 1536: rc = launch_lineblu_c2c<1536, 4, 512>(BLU_ARGS); break;
     case 2048: rc = launch_lineblu_c2c<2048, 4, 512>(BLU_ARGS); break;
+    default: return 0;
+    }
+#undef BLU_ARGS
+    if (rc) return rc;
+    *took = true;
+    return 0;
+}
+
+template <int P, int NCH, int T>
+static int launch_lineblu_real(corahip_ctx *ctx, bool c2r, const double *in, double *out, long nlines, int h, double scale,
+                               const double2 *chirp, const double2 *filt, const double2 *rtw) {
+    constexpr int PK = 1;
+    constexpr int BS = fpc(P) + 1;
+    const size_t shm = sizeof(double2) * (size_t)NCH * BS;
+    const long nitems = (nlines + NCH - 1) / NCH;
+    const long per_cu = std::max<long>(1, std::min<long>((160 * 1024) / shm, 2048 / T));
+    dim3 grid((unsigned)std::min<long>(nitems, (long)ctx->num_cu * per_cu));
+    const double2 *i2 = reinterpret_cast<const double2 *>(in);
+    double2 *o2 = reinterpret_cast<double2 *>(out);
+    if (c2r) {
+        HIP_TRY(hipFuncSetAttribute((const void *)lineblu_c2r_ct<P, NCH, T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        lineblu_c2r_ct<P, NCH, T><<<grid, T, shm, ctx->stream>>>(i2, o2, nlines, h, scale, chirp, filt, rtw);
+    } else {
+        HIP_TRY(hipFuncSetAttribute((const void *)lineblu_r2c_ct<P, NCH, T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        lineblu_r2c_ct<P, NCH, T><<<grid, T, shm, ctx->stream>>>(i2, o2, nlines, h, chirp, filt, rtw);
+    }
+    LAUNCH_CHECK();
+    return 0;
+}
+// the contiguous pass of an even real length 2 h whose h needs Bluestein (c2r: half-complex -> real times scale; r2c: real
+// -> half-complex); Pct / filt_ct / chirp / rtw of the plan of length h.  *took = false: the generic kernel takes it
+int flat_blu_real_ct(corahip_ctx *ctx, bool c2r, const double *in, double *out, long nlines, int h, double scale, int Pct,
+                     const double2 *chirp, const double2 *filt_ct, const double2 *rtw, bool *took) {
+    static const bool off = getenv("CORAHIP_FLAT_GENERIC") != nullptr;
+    *took = false;
+    if (off || !Pct || !filt_ct || nlines < 1) return 0;
+    int rc;
+#define BLU_ARGS ctx, c2r, in, out, nlines, h, scale, chirp, filt_ct, rtw
+    switch (Pct) {
+    case 256: rc = launch_lineblu_real<256, 16, 512>(BLU_ARGS); break;
+    case 320: rc = launch_lineblu_real<320, 16, 512>(BLU_ARGS); break;
+    case 384: rc = launch_lineblu_real<384, 16, 512>(BLU_ARGS); break;
+    case 512: rc = launch_lineblu_real<512, 16, 512>(BLU_ARGS); break;
+    case 640: rc = launch_lineblu_real<640, 8, 512>(BLU_ARGS); break;
+    case 768: rc = launch_lineblu_real<768, 8, 512>(BLU_ARGS); break;
+    case 1024: rc = launch_lineblu_real<1024, 8, 512>(BLU_ARGS); break;
+    case 1280: rc = launch_lineblu_real<1280, 4, 512>(BLU_ARGS); break;
+    case 1536: rc = launch_lineblu_real<1536, 4, 512>(BLU_ARGS); break;
+    case 2048: rc = launch_lineblu_real<2048, 4, 512>(BLU_ARGS); break;
     default: return 0;
     }
 #undef BLU_ARGS

@@ -111,7 +111,10 @@ def test_fft_c2c_every_axis_position_vs_numpy(ctx, n):
                                    # 3 * 2^k: radix 12 in the first pass
                                    (5, 7, 384), (19, 768), (9, 1536), (5, 3072), (384, 40, 6),
                                    # arbitrary lengths on strided axes: Bluestein on the compile-time passes (P = 640, 640, 2048, 320)
-                                   (261, 316, 24), (628, 9, 10), (130, 20)])
+                                   (261, 316, 24), (628, 9, 10), (130, 20),
+                                   # even last axes 2 h with arbitrary h: the contiguous passes through the same convolution
+                                   # (P = 320, 640, 1024, 2048, 768, 512), and one line more than the lines per item
+                                   (7, 316), (5, 9, 628), (4, 1000), (6, 1800), (5, 700), (17, 500), (2500,)])
 def test_rfftn_irfftn_vs_numpy(ctx, shape):
     import torch
 

@@ -100,6 +100,7 @@ if os.environ.get("CUBE", "1") == "1":
         torch.cuda.synchronize()
         wall = (time.perf_counter() - t0) / reps * 1e3
         st = {k: round(ctx.profile_get(k)[0] / reps, 3) for k in ("flatdraw", "flatfft", "spec_mul", "cube_affine", "raytrace")}
+        st["passes"] = {k: round(ctx.profile_get(k)[0] / reps, 3) for k in ("fft_c2c_draw", "fft_c2c_strided", "fft_c2r", "fft_r2c")}
         ctx.profile_enable(False)
         print(json.dumps({"corr21cm_getfield": [nu_num, npx, npx], "comoving_box": box, "first_call_s": first,
                           "wall_ms": wall, "device_ms": st, "cubes_per_s": 1e3 / wall}), flush=True)
