@@ -986,6 +986,9 @@ extern "C" int corahip_factor_batched(corahip_ctx *ctx, const double *C, int nl,
         const int nblk = (F + 31) / 32;
         const int G = (nblk + 3) / 4;                      // one tile per wave in every block column
         int nrem = 0;
+        // (behind the 32 x 32 form - cfg 3 is 2049 = 4 x 512 + 1 matrices of F = 256 - it was measured in round 5 and does not
+        //  pay: 2048 matrices 1.50 ms, 2049 1.71 ms, 2049 with the last one here 1.75 ms: launch, memsets and barriers of
+        //  the cooperative form cost what the fifth round of one workgroup costs at that size)
         if (tall && (F % 32) == 0 && !(coop_env && atoi(coop_env) == 0) && !CHM_STAMPS) {
             const int slots = 2 * ctx->num_cu;
             const int r = nl % slots;
