@@ -367,3 +367,42 @@ def test_corr21cm_getfield_device_seed_vs_oracle():
     want = ofs.realisation(models.Corr21cm(), z1, z2, 3.0, 2.5, 6, 12, 10, stream, zspace=False)[0][::-1]
     assert cube.shape == (6, 12, 10) and _rel(cube, want) < 1e-11
     assert np.array_equal(cube, cr.getfield(seed=9))
+
+
+_AB_SCRIPT = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, sys.argv[1])
+from cora_amd import _lib
+ctx = _lib.get_context()
+out = {}
+for shape in [(256, 96, 64), (64, 384, 100), (37, 261, 316), (20, 130, 628)]:
+    kw = ctx.empty(tuple(shape[:-1]) + (shape[-1] // 2 + 1,)).uniform_(generator=torch.Generator(device=ctx.device).manual_seed(5))
+    f = ctx.randomfield_irfftn(kw, 11, last=shape[-1])
+    out["f_%d_%d_%d" % shape] = f.cpu().numpy()
+    out["s_%d_%d_%d" % shape] = ctx.rfftn(f).cpu().numpy()
+np.savez(sys.argv[2], **out)
+"""
+
+
+@pytest.mark.gpu
+def test_compile_time_passes_agree_with_the_generic_line_kernel(ctx, tmp_path):
+    """The transforms of flatsky_ct.hip (scheduled lengths, Bluestein on the compile-time passes, generated first pass)
+    against the generic line kernel of flatsky.hip (CORAHIP_FLAT_GENERIC=1, read once per process: a child process) on
+    the same seeded fields: field and its rfftn to rounding."""
+    import subprocess
+    import sys
+
+    script = tmp_path / "ab.py"
+    script.write_text(_AB_SCRIPT)
+    res = {}
+    for tag, extra in (("ct", {}), ("generic", {"CORAHIP_FLAT_GENERIC": "1"})):
+        env = dict(os.environ)
+        env.pop("CORAHIP_FLAT_GENERIC", None)
+        env.update(extra)
+        out = tmp_path / (tag + ".npz")
+        p = subprocess.run([sys.executable, str(script), ROOT, str(out)], env=env, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        res[tag] = np.load(out)
+    for k in res["ct"].files:
+        a, b = res["ct"][k], res["generic"][k]
+        assert a.shape == b.shape and _rel(a, b) < 1e-13, (k, _rel(a, b))
