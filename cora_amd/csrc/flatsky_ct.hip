@@ -985,7 +985,7 @@ lineblu_r2c_ct(const double2 *in, double2 *out, long nlines, int h, const double
 
 // the smallest scheduled length that holds the convolution of an n-point line (0: none)
 static int flat_blu_length(int n) {
-    static const int lens[] = {256, 320, 384, 512, 640, 768, 1024, 1280, 1536, 2048};
+    static const int lens[] = {256, 320, 384, 512, 640, 768, 1024, 1280, 1536, 2048, 2560, 3072, 3584, 4096};
     for (int P : lens)
         if (P >= 2 * n - 1) return P;
     return 0;
@@ -1012,7 +1012,7 @@ int flat_blu_plan(corahip_ctx *ctx, int n, const double2 *chirp, int *Pct, doubl
     switch (P) {
 #define BLU_CASE(PP) case PP: rc = blu_filter_build<PP>(ctx, n, chirp, f); break;
         BLU_CASE(256) BLU_CASE(320) BLU_CASE(384) BLU_CASE(512) BLU_CASE(640) BLU_CASE(768) BLU_CASE(1024) BLU_CASE(1280)
-        BLU_CASE(1536) BLU_CASE(2048)
+        BLU_CASE(1536) BLU_CASE(2048) BLU_CASE(2560) BLU_CASE(3072) BLU_CASE(3584) BLU_CASE(4096)
 #undef BLU_CASE
     }
     if (rc) {
@@ -1048,7 +1048,7 @@ int flat_blu_c2c_ct(corahip_ctx *ctx, const double *in, double *out, long nouter
                     uint64_t seed, int Pct, const double2 *chirp, const double2 *filt_ct, bool *took) {
     static const bool off = getenv("CORAHIP_FLAT_GENERIC") != nullptr;
     *took = false;
-    if (off || !Pct || !filt_ct || nouter < 1 || inner < 8) return 0;
+    if (off || !Pct || !filt_ct || nouter < 1 || inner < 2) return 0;
     int rc;
 #define BLU_ARGS ctx, in, out, nouter, inner, n, inverse, scale, gen, seed, chirp, filt_ct
     switch (Pct) {
@@ -1062,6 +1062,10 @@ int flat_blu_c2c_ct(corahip_ctx *ctx, const double *in, double *out, long nouter
     case 1280: rc = launch_lineblu_c2c<1280, 4, 512>(BLU_ARGS); break;
     case 1536: rc = launch_lineblu_c2c<1536, 4, 512>(BLU_ARGS); break;
     case 2048: rc = launch_lineblu_c2c<2048, 4, 512>(BLU_ARGS); break;
+    case 2560: rc = launch_lineblu_c2c<2560, 2, 512>(BLU_ARGS); break;
+    case 3072: rc = launch_lineblu_c2c<3072, 2, 512>(BLU_ARGS); break;
+    case 3584: rc = launch_lineblu_c2c<3584, 2, 512>(BLU_ARGS); break;
+    case 4096: rc = launch_lineblu_c2c<4096, 2, 512>(BLU_ARGS); break;
     default: return 0;
     }
 #undef BLU_ARGS
@@ -1111,6 +1115,10 @@ int flat_blu_real_ct(corahip_ctx *ctx, bool c2r, const double *in, double *out, 
     case 1280: rc = launch_lineblu_real<1280, 4, 512>(BLU_ARGS); break;
     case 1536: rc = launch_lineblu_real<1536, 4, 512>(BLU_ARGS); break;
     case 2048: rc = launch_lineblu_real<2048, 4, 512>(BLU_ARGS); break;
+    case 2560: rc = launch_lineblu_real<2560, 2, 512>(BLU_ARGS); break;
+    case 3072: rc = launch_lineblu_real<3072, 2, 512>(BLU_ARGS); break;
+    case 3584: rc = launch_lineblu_real<3584, 2, 512>(BLU_ARGS); break;
+    case 4096: rc = launch_lineblu_real<4096, 2, 512>(BLU_ARGS); break;
     default: return 0;
     }
 #undef BLU_ARGS

@@ -85,7 +85,8 @@ def test_host_kweight_and_geometry_match_reference(fsg):
 
 
 # ------------------------------------------------------------------ GPU: line-FFT engine
-LENGTHS = [1, 2, 3, 4, 5, 7, 8, 12, 16, 31, 32, 64, 100, 128, 256, 257, 384, 512, 768, 1000, 1024, 2048, 3000, 4095, 4096]
+LENGTHS = [1, 2, 3, 4, 5, 7, 8, 12, 16, 31, 32, 64, 100, 128, 256, 257, 384, 512, 768, 1000, 1024, 1265, 1700, 2000, 2048, 3000, 4095,
+           4096]
 
 
 @pytest.mark.gpu
@@ -114,7 +115,9 @@ def test_fft_c2c_every_axis_position_vs_numpy(ctx, n):
                                    (261, 316, 24), (628, 9, 10), (130, 20),
                                    # even last axes 2 h with arbitrary h: the contiguous passes through the same convolution
                                    # (P = 320, 640, 1024, 2048, 768, 512), and one line more than the lines per item
-                                   (7, 316), (5, 9, 628), (4, 1000), (6, 1800), (5, 700), (17, 500), (2500,)])
+                                   (7, 316), (5, 9, 628), (4, 1000), (6, 1800), (5, 700), (17, 500), (2500,),
+                                   # convolution lengths 2560 .. 4096 (two lines per item)
+                                   (3, 2600), (5, 4000), (1265, 12), (1500, 3, 6), (3, 3300)])
 def test_rfftn_irfftn_vs_numpy(ctx, shape):
     import torch
 
