@@ -1,8 +1,14 @@
 // flatsky_ct.hip - the flat-sky line transforms (RandomField.getfield, fftutil.rfftn / irfftn: cora/core/gaussianfield.py:
-// 102-120, cora/util/fftutil.py:64-87) for the lengths that have a compile-time pass schedule, built from the passes of
-// the ring transforms (fft_ct.h; sht_ringfft_ct.hip explains what the fixed shapes buy).  flatsky.hip calls flat_c2r_ct /
-// flat_c2c_ct / flat_r2c_ct first and keeps its generic line kernel (radix-4 LDS stages, Bluestein for every other length)
-// for what they decline; CORAHIP_FLAT_GENERIC=1 forces the generic kernel (A/B).
+// 102-120, cora/util/fftutil.py:64-87; the cubes of RedshiftCorrelation.realisation, cora/signal/corr.py:562-770) on the
+// compile-time FFT passes of the ring transforms (fft_ct.h; sht_ringfft_ct.hip explains what the fixed shapes buy):
+//   linec2r_ct / liner2c_ct      contiguous axis, even real length 2 N with a scheduled N (2^k, 3 * 2^k)
+//   linec2c_ct                   strided axis of a scheduled length, 8 - 16 neighbouring lines per item; GEN: the input is
+//                                generated where it is committed (corahip_randomfield_irfftn)
+//   lineblu_c2c_ct / _c2r_ct / _r2c_ct   every other length n <= 2048: Bluestein at a length out of {2, 3, 5} x 2^k >= 2 n - 1,
+//                                filter made at plan time by flat_blu_filter_kernel (flat_blu_plan)
+// flatsky.hip calls flat_c2r_ct / flat_r2c_ct / flat_c2c_ct / flat_blu_c2c_ct / flat_blu_real_ct first and keeps its
+// generic line kernel (radix-4 LDS stages, power-of-two Bluestein) for what they decline: odd real lengths, lengths
+// below 17 or above 2048, contiguous complex transforms; CORAHIP_FLAT_GENERIC=1 forces it (A/B, tests/test_flatsky.py).
 #include "fft_ct.h"
 #include "rng_dev.h"
 
