@@ -2,6 +2,7 @@
 // transform fixed at compile time (length, pass radices, channels per workgroup):
 //   ringfft_direct_ct<N, NCH>  rings whose half length h = N is a power of two (the belt: N = 2 nside)
 //   ringfft_blu_ct<P, NCH>     cap rings through a Bluestein convolution of length P (power of two or 3 * 2^k)
+//   ringana_direct_ct / ringana_blu_ct   K5^T, the analysis direction (map2alm): the same passes run backwards (round 5)
 // The generic kernel of sht_ringfft.hip (run-time lengths) stays for every other class and is the reference
 // these are tested against (tests/test_gpu_fullsize.py compares both with the oracle pixel by pixel).
 //
