@@ -270,6 +270,159 @@ linec2c_ct(const double *in, double2 *out, long nouter, long inner, double scale
     }
 }
 
+// ------------------------------------------------------------------------------------
+// linec2c_ct for lengths whose lines do not fit LDS sixteen at a time (N = 1024: 16 x 1024 x 16 bytes): the top radix-2
+// stage is done between registers and LDS.  The even rows of a 16-line tile are transformed first (N / 2 points per
+// line: three passes) and their result E_k read into registers, then the odd rows (O_k), and X_k = E_k + w^k O_k,
+// X_{k + N/2} = E_k - w^k O_k leave as rows of 16 lines = 256 contiguous bytes (8 lines per item: 128-byte rows,
+// 3.7 TB/s at 1024^3; sixteen: the rate of the 512-point passes).  Same thread -> (line, bin) map in both halves.
+// ------------------------------------------------------------------------------------
+template <int N, int NCH, int T, int SIGN, bool GEN>
+__global__ void __launch_bounds__(T)
+linec2c_h2_ct(const double *in, double2 *out, long nouter, long inner, double scale, uint64_t seed) {
+    constexpr int PK = 1;
+    constexpr int NH = N / 2;
+    constexpr int R0 = Sch<NH>::R0, R1 = Sch<NH>::R1, R2 = Sch<NH>::R2;
+    static_assert(R0 == 16 && R1 == 16 && R2 == 2 && NH == 512, "16 x 16 x 2 half transforms");
+    constexpr int Q0 = NH / R0;
+    static_assert(T % Q0 == 0 && NCH == 16 && T == 512, "thread -> bin map below");
+    constexpr int BS = fpc(NH) + K5_CH_SKEW;
+    constexpr int U = NCH * NH / T;                          // elements of a half tile per thread
+    constexpr int IT = NCH * 256 / T;                        // last-pass butterflies per thread
+    extern __shared__ __attribute__((aligned(16))) double2 sm[];
+    double2 *lg_l = sm + NCH * BS, *sc_l = lg_l + 257;
+    const int tid0 = threadIdx.x;
+    const double2 *in2 = reinterpret_cast<const double2 *>(in);
+    const long chunks = (inner + NCH - 1) / NCH;
+    const long ntiles = nouter * chunks;
+    if (GEN) {
+        for (int k = tid0; k < 257; k += T) lg_l[k] = RNG_LOG_TAB[k];
+        for (int k = tid0; k < 256; k += T) sc_l[k] = RNG_SC_TAB[k];
+    }
+    double2 wA, wB, wK, wK2;   // pass twiddles; w^k of this thread's first butterfly and the step w^2 between its butterflies
+    {
+        const int j0 = tid0 & (Q0 - 1), j1 = tid0 & (Q0 / R1 - 1);
+        double s, c;
+        sincospi(2.0 * (double)j0 / (double)NH, &s, &c);
+        wA = make_double2(c, s);
+        sincospi(2.0 * (double)j1 / (double)Q0, &s, &c);
+        wB = make_double2(c, s);
+        // butterfly idx = tid + it T of line idx & 15: t = idx >> 4 = 16 k0 + k1, bin k = k0 + 16 k1 = (tid >> 8) + 2 it + 16 ((tid >> 4) & 15)
+        const int kb = (tid0 >> 8) + 16 * ((tid0 >> 4) & 15);
+        sincospi(2.0 * (double)kb / (double)N, &s, &c);
+        wK = make_double2(c, SIGN > 0 ? s : -s);
+        sincospi(4.0 / (double)N, &s, &c);
+        wK2 = make_double2(c, SIGN > 0 ? s : -s);
+    }
+    constexpr int GL = 3;
+    const long gmask = (8L << GL) - 1;
+    const bool pair_xcd = (ntiles & gmask) == 0 && (gridDim.x & gmask) == 0;
+    auto remap = [&](long v) {
+        if (!pair_xcd) return v;
+        const long slot = v >> 3, xcd = v & 7;
+        return (((slot >> GL) * 8 + xcd) << GL) + (slot & ((1 << GL) - 1));
+    };
+    struct tile_t {
+        long base;
+        int teff;
+    };
+    auto tile_of = [&](long v) {
+        const long outer = v / chunks, i0 = (v - outer * chunks) * NCH;
+        tile_t t;
+        t.base = outer * N * inner + i0;
+        t.teff = (int)min((long)NCH, inner - i0);
+        return t;
+    };
+    double2 R[U];
+    // rows 2 jj + par of the tile
+    auto prefetch = [&](const tile_t &tl, int par, int tid) {
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int e = tid + u * T;
+            const int c = e & (NCH - 1), jj = e / NCH;
+            const long addr = tl.base + (long)(2 * jj + par) * inner + min(c, tl.teff - 1);
+            R[u] = GEN ? make_double2(in[addr], 0.0) : in2[addr];
+        }
+    };
+    auto commit = [&](const tile_t &tl, int par, int tid) {
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int e = tid + u * T;
+            const int c = e & (NCH - 1), jj = e / NCH;
+            double2 v = R[u];
+            if (GEN) {
+                const long addr = tl.base + (long)(2 * jj + par) * inner + min(c, tl.teff - 1);
+                const double2 z = philox_boxmuller((uint64_t)addr, seed, lg_l, sc_l);
+                v = make_double2(z.x * v.x, z.y * v.x);
+            }
+            sm[c * BS + fpad(jj)] = v;
+        }
+    };
+    long vt = blockIdx.x;
+    if (vt >= ntiles) return;
+    tile_t cur = tile_of(remap(vt));
+    prefetch(cur, 0, tid0);
+    while (true) {
+        int tid = tid0;                                   // opaque per item: see ringfft_direct_ct
+        asm volatile("" : "+v"(tid));
+        __syncthreads();                                  // previous item's LDS reads are done (and the tables are filled)
+        commit(cur, 0, tid);
+        prefetch(cur, 1, tid);                            // the odd rows, behind the passes of the even ones
+        __syncthreads();
+        ct_pass<PK, NH, NCH, BS, NH, R0, SIGN, false, T>(sm, wA, tid);
+        __syncthreads();
+        ct_pass<PK, NH, NCH, BS, Q0, R1, SIGN, false, T>(sm, wB, tid);
+        __syncthreads();
+        double2 E[IT][2];
+#pragma unroll
+        for (int it = 0; it < IT; it++) {
+            const int idx = tid + it * T;
+            const int ch = idx & (NCH - 1), t = idx / NCH;
+            const double2 *p = sm + ch * BS + fpad(t * R2);
+            const double2 x0 = p[0], x1 = p[fpc(1)];
+            E[it][0] = cadd(x0, x1);
+            E[it][1] = csub(x0, x1);
+        }
+        __syncthreads();                                  // every E has been read
+        commit(cur, 1, tid);
+        const long vnext = vt + gridDim.x;
+        const tile_t nxt = tile_of(remap(min(vnext, ntiles - 1)));
+        prefetch(nxt, 0, tid);                            // (unconditional: the last iteration re-reads a tile)
+        __syncthreads();
+        ct_pass<PK, NH, NCH, BS, NH, R0, SIGN, false, T>(sm, wA, tid);
+        __syncthreads();
+        ct_pass<PK, NH, NCH, BS, Q0, R1, SIGN, false, T>(sm, wB, tid);
+        __syncthreads();
+        {
+            double2 w = wK;
+            asm volatile("" : "+v"(w.x), "+v"(w.y));
+#pragma unroll
+            for (int it = 0; it < IT; it++) {
+                const int idx = tid + it * T;
+                const int ch = idx & (NCH - 1), t = idx / NCH;
+                const int k = (t >> 4) + 16 * (t & 15);
+                const double2 *p = sm + ch * BS + fpad(t * R2);
+                const double2 x0 = p[0], x1 = p[fpc(1)];
+                const double2 o0 = cmul(w, cadd(x0, x1));                       // w^k O_k
+                const double2 o1s = cmul(w, csub(x0, x1));
+                const double2 o1 = SIGN > 0 ? make_double2(-o1s.y, o1s.x) : make_double2(o1s.y, -o1s.x);   // w^(k + N/4) O_(k + N/4)
+                if (ch < cur.teff) {
+                    double2 *o = out + cur.base + (long)k * inner + ch;
+                    const double2 a0 = cadd(E[it][0], o0), b0 = csub(E[it][0], o0), a1 = cadd(E[it][1], o1), b1 = csub(E[it][1], o1);
+                    o[0] = make_double2(a0.x * scale, a0.y * scale);
+                    o[(long)(N / 4) * inner] = make_double2(a1.x * scale, a1.y * scale);
+                    o[(long)(N / 2) * inner] = make_double2(b0.x * scale, b0.y * scale);
+                    o[(long)(3 * N / 4) * inner] = make_double2(b1.x * scale, b1.y * scale);
+                }
+                w = cmul(w, wK2);
+            }
+        }
+        if (vnext >= ntiles) break;
+        vt = vnext;
+        cur = nxt;
+    }
+}
+
 template <int N, int NCH, int T>
 static int launch_linec2c(corahip_ctx *ctx, const double *in, double *out, long nouter, long inner, int inverse, double scale, bool gen,
                           uint64_t seed) {
@@ -290,6 +443,25 @@ static int launch_linec2c(corahip_ctx *ctx, const double *in, double *out, long 
     LAUNCH_CHECK();
     return 0;
 }
+template <int N, int NCH, int T>
+static int launch_linec2c_h2(corahip_ctx *ctx, const double *in, double *out, long nouter, long inner, int inverse, double scale, bool gen,
+                             uint64_t seed) {
+    constexpr int PK = 1;
+    constexpr int BS = fpc(N / 2) + K5_CH_SKEW;
+    const size_t shm = sizeof(double2) * ((size_t)NCH * BS + (gen ? 513 : 0));
+    const long ntiles = nouter * ((inner + NCH - 1) / NCH);
+    dim3 grid((unsigned)std::min<long>(ntiles, (long)ctx->num_cu));
+    double2 *o2 = reinterpret_cast<double2 *>(out);
+#define C2C_LAUNCH(SG, GN)                                                                                                  \
+    HIP_TRY(hipFuncSetAttribute((const void *)linec2c_h2_ct<N, NCH, T, SG, GN>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+    linec2c_h2_ct<N, NCH, T, SG, GN><<<grid, T, shm, ctx->stream>>>(in, o2, nouter, inner, scale, seed)
+    if (gen) { C2C_LAUNCH(1, true); }
+    else if (inverse) { C2C_LAUNCH(1, false); }
+    else { C2C_LAUNCH(-1, false); }
+#undef C2C_LAUNCH
+    LAUNCH_CHECK();
+    return 0;
+}
 // a strided complex pass of the flat-sky transforms (inner > 1) for the lengths that have a compile-time schedule;
 // gen: inverse pass whose input is generated from the real k-weights `in` (corahip_randomfield_irfftn).  *took = false:
 // the generic line kernel takes it
@@ -301,6 +473,7 @@ int flat_c2c_ct(corahip_ctx *ctx, const double *in, double *out, long nouter, in
     int rc;
     if (n == 256 && inner >= 16) rc = launch_linec2c<256, 16, 256>(ctx, in, out, nouter, inner, inverse, scale, gen, seed);
     else if (n == 512 && inner >= 16) rc = launch_linec2c<512, 16, 512>(ctx, in, out, nouter, inner, inverse, scale, gen, seed);
+    else if (n == 1024 && inner >= 16 && !getenv("CORAHIP_FLAT_NOH2")) rc = launch_linec2c_h2<1024, 16, 512>(ctx, in, out, nouter, inner, inverse, scale, gen, seed);
     else if (n == 1024 && inner >= 8) rc = launch_linec2c<1024, 8, 512>(ctx, in, out, nouter, inner, inverse, scale, gen, seed);
     else if (n == 384 && inner >= 16) rc = launch_linec2c<384, 16, 512>(ctx, in, out, nouter, inner, inverse, scale, gen, seed);
     else if (n == 768 && inner >= 8) rc = launch_linec2c<768, 8, 512>(ctx, in, out, nouter, inner, inverse, scale, gen, seed);
