@@ -16,6 +16,9 @@
 #include <cstring>
 #include <type_traits>
 
+#ifndef CL_BUILD_BY_ROW
+#define CL_BUILD_BY_ROW 1   // profile build with the row loop outside the profile loop (0: the profile-major loops of rounds 1-4, A/B)
+#endif
 #ifndef CL_ABLATE
 #define CL_ABLATE 0  // diagnostic builds: 1 no table loads in the profile build, 2 interpolation for one multipole per thread only
 #endif
@@ -135,6 +138,43 @@ clarray21_kernel(const double *__restrict__ tt, int nkperp, int nkpar, double kp
     for (int a = 0; a < zint; a++) {
         __syncthreads();
         // ---- profiles of the zint sub-sample pairs (a, b = 0..zint-1)
+#if CL_ABLATE == 0 && CL_BUILD_BY_ROW
+        if constexpr (ZINT > 0) {
+            // Row-major build (round 5): a thread takes table row x for ALL ZINT profiles - over the union of their row
+            // ranges; a row outside a profile's own range is never read by the interpolation - so that its 6 ZINT table
+            // loads are independent straight-line code in flight together.  With the profile-major loops every (b, x)
+            // step waited out its own L2 latency: 18 exposed latencies per a, against 2 here.
+            int xlo = ipar[(a * ZINT) * 4 + 1], xhi = ipar[(a * ZINT) * 4 + 2];
+#pragma unroll
+            for (int b = 1; b < ZINT; b++) {
+                xlo = min(xlo, ipar[(a * ZINT + b) * 4 + 1]);
+                xhi = max(xhi, ipar[(a * ZINT + b) * 4 + 2]);
+            }
+            for (int x = xlo + tid; x < xhi; x += 256) {
+                double v[ZINT][6];
+#pragma unroll
+                for (int b = 0; b < ZINT; b++) {
+                    const double *r0 = tt + (size_t)ipar[(a * ZINT + b) * 4 + 0] * CL_XS + x, *r1 = r0 + CL_XS;
+                    v[b][0] = r0[0];
+                    v[b][1] = r1[0];
+                    v[b][2] = r0[tsz];
+                    v[b][3] = r1[tsz];
+                    v[b][4] = r0[2 * tsz];
+                    v[b][5] = r1[2 * tsz];
+                }
+#pragma unroll
+                for (int b = 0; b < ZINT; b++) {
+                    const double *pp = par + (a * ZINT + b) * 8;
+                    prof[b * PS + x] = pp[0] * v[b][0] + pp[1] * v[b][1] + pp[2] * v[b][2] + pp[3] * v[b][3] + pp[4] * v[b][4] +
+                                       pp[5] * v[b][5];
+                }
+            }
+            if (tid < ZINT) lxcs_s[tid] = par[(a * ZINT + tid) * 8 + 6];
+            __syncthreads();
+            // slot nkperp repeats the last row (see below)
+            if (xhi == nkperp && tid < ZINT) prof[tid * PS + nkperp] = prof[tid * PS + nkperp - 1];
+        } else
+#endif
         for (int b = 0; b < zint; b++) {
             const int t = a * zint + b;
             const double *pp = par + t * 8;
