@@ -134,45 +134,72 @@ clarray21_kernel(const double *__restrict__ tt, int nkperp, int nkpar, double kp
     // uniform over the workgroup: every sub-sample pair can skip the clamps (true for every configuration cora's
     // frequency ranges produce: 0 <= x <= ~390 of 500 rows for l >= 1)
     const bool all_fast = __syncthreads_and(noclamp) != 0;
+    // The first multipoles of a range that starts at low l are many table rows apart (x = log10 l * xscale: l = 1, 2, 3 sit
+    // 35 and 21 rows from each other; from l ~ 25 on consecutive l are less than two rows apart): entries 0 .. nsp - 1 get
+    // their two rows built individually, the dense row range starts at entry nsp - a third of the table reads of a
+    // cfg-3 profile were rows between those first multipoles that no interpolation ever looks at.
+    __shared__ int s_nsp;
+    if (tid < 64) {
+        bool wide = false;
+        if (l_base + tid + 1 < l_end) wide = (log10l[l_base + tid + 1] - log10l[l_base + tid]) * xscale >= 2.0;
+        const unsigned long long m = __ballot(wide);
+        if (tid == 0) s_nsp = m == ~0ull ? 32 : min(32, (int)__builtin_ctzll(~m));
+    }
 
     for (int a = 0; a < zint; a++) {
         __syncthreads();
         // ---- profiles of the zint sub-sample pairs (a, b = 0..zint-1)
 #if CL_ABLATE == 0 && CL_BUILD_BY_ROW
-        if constexpr (ZINT > 0) {
+        if (ZINT > 0 && all_fast) {
             // Row-major build (round 5): a thread takes table row x for ALL ZINT profiles - over the union of their row
             // ranges; a row outside a profile's own range is never read by the interpolation - so that its 6 ZINT table
             // loads are independent straight-line code in flight together.  With the profile-major loops every (b, x)
             // step waited out its own L2 latency: 18 exposed latencies per a, against 2 here.
-            int xlo = ipar[(a * ZINT) * 4 + 1], xhi = ipar[(a * ZINT) * 4 + 2];
+            constexpr int ZN = ZINT > 0 ? ZINT : 1;
+            const int nsp = min(s_nsp, l_end - l_base);
+            const double lxd = log10l[min(l_base + nsp, nl_total - 1)] * xscale;     // first entry of the dense part
+            int xlo = nkperp, xhi = 0;
 #pragma unroll
-            for (int b = 1; b < ZINT; b++) {
-                xlo = min(xlo, ipar[(a * ZINT + b) * 4 + 1]);
-                xhi = max(xhi, ipar[(a * ZINT + b) * 4 + 2]);
+            for (int b = 0; b < ZN; b++) {
+                const double xx = fmin(fmax(lxd - par[(a * ZN + b) * 8 + 6], 0.0), ux);
+                xlo = min(xlo, (int)xx);
+                xhi = max(xhi, ipar[(a * ZN + b) * 4 + 2]);
             }
+            if (nsp >= l_end - l_base) xlo = xhi;                                    // (every entry is built individually)
+            auto row_of = [&](int b, int x, double (&v)[6]) {
+                const double *r0 = tt + (size_t)ipar[(a * ZN + b) * 4 + 0] * CL_XS + x, *r1 = r0 + CL_XS;
+                v[0] = r0[0];
+                v[1] = r1[0];
+                v[2] = r0[tsz];
+                v[3] = r1[tsz];
+                v[4] = r0[2 * tsz];
+                v[5] = r1[2 * tsz];
+            };
+            auto combine = [&](int b, const double (&v)[6]) {
+                const double *pp = par + (a * ZN + b) * 8;
+                return pp[0] * v[0] + pp[1] * v[1] + pp[2] * v[2] + pp[3] * v[3] + pp[4] * v[4] + pp[5] * v[5];
+            };
             for (int x = xlo + tid; x < xhi; x += 256) {
-                double v[ZINT][6];
+                double v[ZN][6];
 #pragma unroll
-                for (int b = 0; b < ZINT; b++) {
-                    const double *r0 = tt + (size_t)ipar[(a * ZINT + b) * 4 + 0] * CL_XS + x, *r1 = r0 + CL_XS;
-                    v[b][0] = r0[0];
-                    v[b][1] = r1[0];
-                    v[b][2] = r0[tsz];
-                    v[b][3] = r1[tsz];
-                    v[b][4] = r0[2 * tsz];
-                    v[b][5] = r1[2 * tsz];
-                }
+                for (int b = 0; b < ZN; b++) row_of(b, x, v[b]);
 #pragma unroll
-                for (int b = 0; b < ZINT; b++) {
-                    const double *pp = par + (a * ZINT + b) * 8;
-                    prof[b * PS + x] = pp[0] * v[b][0] + pp[1] * v[b][1] + pp[2] * v[b][2] + pp[3] * v[b][3] + pp[4] * v[b][4] +
-                                       pp[5] * v[b][5];
-                }
+                for (int b = 0; b < ZN; b++) prof[b * PS + x] = combine(b, v[b]);
             }
-            if (tid < ZINT) lxcs_s[tid] = par[(a * ZINT + tid) * 8 + 6];
+            // the two rows of every early entry, per profile (slot nkperp, if an entry reaches it, repeats row nkperp - 1)
+            for (int e = tid; e < nsp * ZN * 2; e += 256) {
+                const int b = e % ZN, r = e / ZN;
+                const double lxk = log10l[l_base + (r >> 1)] * xscale;
+                const double xx = fmin(fmax(lxk - par[(a * ZN + b) * 8 + 6], 0.0), ux);
+                const int x = (int)xx + (r & 1);
+                double v[6];
+                row_of(b, min(x, nkperp - 1), v);
+                prof[b * PS + x] = combine(b, v);
+            }
+            if (tid < ZN) lxcs_s[tid] = par[(a * ZN + tid) * 8 + 6];
             __syncthreads();
             // slot nkperp repeats the last row (see below)
-            if (xhi == nkperp && tid < ZINT) prof[tid * PS + nkperp] = prof[tid * PS + nkperp - 1];
+            if (xhi == nkperp && tid < ZN) prof[tid * PS + nkperp] = prof[tid * PS + nkperp - 1];
         } else
 #endif
         for (int b = 0; b < zint; b++) {
