@@ -19,6 +19,9 @@
 #ifndef CL_BUILD_BY_ROW
 #define CL_BUILD_BY_ROW 1   // profile build with the row loop outside the profile loop (0: the profile-major loops of rounds 1-4, A/B)
 #endif
+#ifndef CL_BUILD_X4
+#define CL_BUILD_X4 1       // dense rows of the row-major build two at a time with 16-byte loads (0: one row per thread, A/B)
+#endif
 #ifndef CL_ABLATE
 #define CL_ABLATE 0  // diagnostic builds: 1 no table loads in the profile build, 2 interpolation for one multipole per thread only
 #endif
@@ -179,6 +182,43 @@ clarray21_kernel(const double *__restrict__ tt, int nkperp, int nkpar, double kp
                 const double *pp = par + (a * ZN + b) * 8;
                 return pp[0] * v[0] + pp[1] * v[1] + pp[2] * v[2] + pp[3] * v[3] + pp[4] * v[4] + pp[5] * v[5];
             };
+#if CL_BUILD_X4
+            {
+                // two rows per thread and 16-byte loads: threads 0 .. 127 build the first (ZN + 1) / 2 profiles, threads
+                // 128 .. 255 the others (the table columns past nkperp are zero padding, the profile has room for them)
+                constexpr int ZH = (ZN + 1) / 2;
+                const int hb = tid >> 7, b0 = hb ? ZH : 0, nb = hb ? ZN - ZH : ZH;
+                constexpr int QB = 3;                          // profiles whose loads are in flight together (18 x 16 bytes per thread)
+                for (int x = (xlo & ~1) + 2 * (tid & 127); x < xhi; x += 256) {
+#pragma unroll
+                    for (int q0 = 0; q0 < ZH; q0 += QB) {
+                        double2 v[QB][6];
+#pragma unroll
+                        for (int q = 0; q < QB; q++) {
+                            if (q0 + q < nb) {
+                                const double *r0 = tt + (size_t)ipar[(a * ZN + b0 + q0 + q) * 4 + 0] * CL_XS + x, *r1 = r0 + CL_XS;
+                                v[q][0] = *reinterpret_cast<const double2 *>(r0);
+                                v[q][1] = *reinterpret_cast<const double2 *>(r1);
+                                v[q][2] = *reinterpret_cast<const double2 *>(r0 + tsz);
+                                v[q][3] = *reinterpret_cast<const double2 *>(r1 + tsz);
+                                v[q][4] = *reinterpret_cast<const double2 *>(r0 + 2 * tsz);
+                                v[q][5] = *reinterpret_cast<const double2 *>(r1 + 2 * tsz);
+                            }
+                        }
+#pragma unroll
+                        for (int q = 0; q < QB; q++) {
+                            if (q0 + q < nb) {
+                                const double *pp = par + (a * ZN + b0 + q0 + q) * 8;
+                                double2 o;
+                                o.x = pp[0] * v[q][0].x + pp[1] * v[q][1].x + pp[2] * v[q][2].x + pp[3] * v[q][3].x + pp[4] * v[q][4].x + pp[5] * v[q][5].x;
+                                o.y = pp[0] * v[q][0].y + pp[1] * v[q][1].y + pp[2] * v[q][2].y + pp[3] * v[q][3].y + pp[4] * v[q][4].y + pp[5] * v[q][5].y;
+                                *reinterpret_cast<double2 *>(prof + (b0 + q0 + q) * PS + x) = o;
+                            }
+                        }
+                    }
+                }
+            }
+#else
             for (int x = xlo + tid; x < xhi; x += 256) {
                 double v[ZN][6];
 #pragma unroll
@@ -186,6 +226,7 @@ clarray21_kernel(const double *__restrict__ tt, int nkperp, int nkpar, double kp
 #pragma unroll
                 for (int b = 0; b < ZN; b++) prof[b * PS + x] = combine(b, v[b]);
             }
+#endif
             // the two rows of every early entry, per profile (slot nkperp, if an entry reaches it, repeats row nkperp - 1)
             for (int e = tid; e < nsp * ZN * 2; e += 256) {
                 const int b = e % ZN, r = e / ZN;
@@ -250,7 +291,9 @@ clarray21_kernel(const double *__restrict__ tt, int nkperp, int nkpar, double kp
 #if CL_ABLATE == 2   // diagnostic: no interpolation phase
                 if (k >= 1) continue;
 #endif
-                if (k < kmax) {  // uniform: l-sharded callers pass short l ranges
+                // (uniform: l-sharded callers pass short l ranges; the LAST slot of a range is usually almost empty - 2049 =
+                //  8 x 256 + 1: one lane of the workgroup has a ninth multipole - and the waves without one skip it)
+                if (k < kmax && (k < kmax - 1 || l_base + tid + 256 * k < nl_total)) {
                     // (FAST: only the first entry of the launch - thread 0, k = 0 - is clamped)
                     const bool clamp = !FAST || (k == 0 && tid == 0);
                     double s = 0.0;
