@@ -23,7 +23,7 @@
 #define CL_BUILD_X4 1       // dense rows of the row-major build two at a time with 16-byte loads (0: one row per thread, A/B)
 #endif
 #ifndef CL_ABLATE
-#define CL_ABLATE 0  // diagnostic builds: 1 no table loads in the profile build, 2 interpolation for one multipole per thread only
+#define CL_ABLATE 0  // diagnostic builds: 1 no table loads in the (profile-major) build, 2 interpolation for one multipole per thread only, 3 the row-major build without the loads of its dense part, 4 = 3 + 2
 #endif
 #define CL_MAXZ 17  // zint <= 17 (zromb <= 4)
 
@@ -142,6 +142,8 @@ clarray21_kernel(const double *__restrict__ tt, int nkperp, int nkpar, double kp
     // their two rows built individually, the dense row range starts at entry nsp - a third of the table reads of a
     // cfg-3 profile were rows between those first multipoles that no interpolation ever looks at.
     __shared__ int s_nsp;
+    __shared__ double s_lxk[32];
+    if (tid < 32) s_lxk[tid] = log10l[min(l_base + tid, nl_total - 1)] * xscale;
     if (tid < 64) {
         bool wide = false;
         if (l_base + tid + 1 < l_end) wide = (log10l[l_base + tid + 1] - log10l[l_base + tid]) * xscale >= 2.0;
@@ -152,7 +154,7 @@ clarray21_kernel(const double *__restrict__ tt, int nkperp, int nkpar, double kp
     for (int a = 0; a < zint; a++) {
         __syncthreads();
         // ---- profiles of the zint sub-sample pairs (a, b = 0..zint-1)
-#if CL_ABLATE == 0 && CL_BUILD_BY_ROW
+#if (CL_ABLATE == 0 || CL_ABLATE >= 3) && CL_BUILD_BY_ROW
         if (ZINT > 0 && all_fast) {
             // Row-major build (round 5): a thread takes table row x for ALL ZINT profiles - over the union of their row
             // ranges; a row outside a profile's own range is never read by the interpolation - so that its 6 ZINT table
@@ -195,6 +197,11 @@ clarray21_kernel(const double *__restrict__ tt, int nkperp, int nkpar, double kp
                         double2 v[QB][6];
 #pragma unroll
                         for (int q = 0; q < QB; q++) {
+#if CL_ABLATE >= 3   // diagnostic: the row-major build without its table loads
+                            if (q0 + q < nb) {
+                                for (int i6 = 0; i6 < 6; i6++) v[q][i6] = make_double2((double)x, 1.0 + i6);
+                            } else
+#endif
                             if (q0 + q < nb) {
                                 const double *r0 = tt + (size_t)ipar[(a * ZN + b0 + q0 + q) * 4 + 0] * CL_XS + x, *r1 = r0 + CL_XS;
                                 v[q][0] = *reinterpret_cast<const double2 *>(r0);
@@ -228,14 +235,16 @@ clarray21_kernel(const double *__restrict__ tt, int nkperp, int nkpar, double kp
             }
 #endif
             // the two rows of every early entry, per profile (slot nkperp, if an entry reaches it, repeats row nkperp - 1)
-            for (int e = tid; e < nsp * ZN * 2; e += 256) {
-                const int b = e % ZN, r = e / ZN;
-                const double lxk = log10l[l_base + (r >> 1)] * xscale;
-                const double xx = fmin(fmax(lxk - par[(a * ZN + b) * 8 + 6], 0.0), ux);
-                const int x = (int)xx + (r & 1);
-                double v[6];
-                row_of(b, min(x, nkperp - 1), v);
-                prof[b * PS + x] = combine(b, v);
+            // (one thread per (entry, profile): its twelve loads are in flight together; 25 x 9 = 225 of them at cfg 3)
+            for (int e = tid; e < nsp * ZN; e += 256) {
+                const int b = e % ZN, k = e / ZN;
+                const double xx = fmin(fmax(s_lxk[k] - par[(a * ZN + b) * 8 + 6], 0.0), ux);
+                const int x = (int)xx;
+                double v0[6], v1[6];
+                row_of(b, x, v0);
+                row_of(b, min(x + 1, nkperp - 1), v1);
+                prof[b * PS + x] = combine(b, v0);
+                prof[b * PS + x + 1] = combine(b, v1);
             }
             if (tid < ZN) lxcs_s[tid] = par[(a * ZN + tid) * 8 + 6];
             __syncthreads();
@@ -288,7 +297,7 @@ clarray21_kernel(const double *__restrict__ tt, int nkperp, int nkpar, double kp
             constexpr bool FAST = decltype(fast_c)::value;
 #pragma unroll
             for (int k = 0; k < CL_LPT; k++) {
-#if CL_ABLATE == 2   // diagnostic: no interpolation phase
+#if CL_ABLATE == 2 || CL_ABLATE == 4   // diagnostic: no interpolation phase
                 if (k >= 1) continue;
 #endif
                 // (uniform: l-sharded callers pass short l ranges; the LAST slot of a range is usually almost empty - 2049 =
