@@ -53,6 +53,8 @@ struct corahip_ctx {
     hipStream_t stream2 = nullptr;                 // second stream for kernels that run beside those of `stream` (K5 pair)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // the l-range pipeline of the numpy-stream draw (drawstream.hip): its generator stream and the ring's events
+    unsigned *draw_slot_tab = nullptr;             // K3: (l, m block) of every work slot of 0 .. draw_slot_lmax (draw.hip)
+    int draw_slot_lmax = -1;
     bool mt_plist_ready = false;                   // scratch slot 9 holds the position lists (mtlegacy.hip)
     hipStream_t gen_stream = nullptr;
     hipEvent_t ev_ring[8] = {};

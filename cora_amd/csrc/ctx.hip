@@ -85,6 +85,7 @@ int corahip_ctx_destroy(corahip_ctx *ctx) {
     }
     for (int i = 0; i < CORAHIP_NSCRATCH; i++)
         if (ctx->scratch[i]) (void)hipFree(ctx->scratch[i]);
+    if (ctx->draw_slot_tab) (void)hipFree(ctx->draw_slot_tab);
     for (auto &kv : ctx->linefft) {
         if (kv.second.tw) (void)hipFree(kv.second.tw);
         if (kv.second.chirp) (void)hipFree(kv.second.chirp);

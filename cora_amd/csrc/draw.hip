@@ -214,7 +214,7 @@ __global__ void __launch_bounds__(64 * DRAW_WAVES, 2)
 draw_rng_kernel(const double *__restrict__ T, size_t t_ldl, int rows, const int32_t *__restrict__ info,
                 const double *__restrict__ zeros, uint64_t seed, const double *__restrict__ gsrc, size_t g_off, int l_lo,
                 int l_hi, int lmax, int F, int nu0, int nu1, int cw, int nnu, int Gout, int nslots, int ncg0, int ncg,
-                double *__restrict__ alm, unsigned *__restrict__ queue) {
+                double *__restrict__ alm, unsigned *__restrict__ queue, const unsigned *__restrict__ slot_tab) {
     constexpr int NC = 16 * NCT;
     constexpr int ROWD = DRAW_KC;            // doubles per channel row in LDS: 256 B, unpadded (DMA is lane-linear)
     constexpr int BUF = NC * ROWD;           // doubles per stage
@@ -247,18 +247,13 @@ draw_rng_kernel(const double *__restrict__ T, size_t t_ldl, int rows, const int3
     auto decode = [&](int it) {
         item_t w;
         const int cg = ncg - 1 - it / nslots;          // the column groups with the longest nu' range first
-        int s = it - (it / nslots) * nslots;
-        int l = 0, mb = 0;
-        for (int j = l_hi / DRAW_MB; j >= l_lo / DRAW_MB; j--) {    // bands of l from the top of the launch's range [l_lo, l_hi]: j + 1 blocks of m per l
-            const int lhi = min(l_hi, DRAW_MB * j + DRAW_MB - 1), llo = max(l_lo, DRAW_MB * j);
-            const int cnt = (lhi - llo + 1) * (j + 1);
-            if (s < cnt) {
-                l = lhi - s / (j + 1);
-                mb = s - (s / (j + 1)) * (j + 1);
-                break;
-            }
-            s -= cnt;
-        }
+        // slot -> (l, m block): the multipoles of the launch from l_hi down, the blocks of an l in order - a table of the
+        // whole range 0 .. lmax (draw_slot_table: the same order; the launch's slots are the run that starts at its l_hi),
+        // read by one scalar load (round 5: the walk over the bands of l with its integer divisions was 4-6 % of the
+        // kernel's wave cycles, per item)
+        const int s = it - (it / nslots) * nslots;
+        const unsigned e = slot_tab[s];
+        const int l = (int)(e >> 8), mb = (int)(e & 255u);
         w.l = l;
         w.mb = mb;
         const bool second = cg >= ncg0;
@@ -538,6 +533,29 @@ draw_rng_kernel(const double *__restrict__ T, size_t t_ldl, int rows, const int3
 struct draw_chan {
     int nu0, nu1, cw, nnu;
 };
+// (l, m block) of every slot of the range 0 .. lmax in the order the kernel takes them: l from lmax down, the l / 128 + 1
+// blocks of an l in order; entry = l << 8 | block.  Built once per lmax, kept in the context.
+static int draw_slot_table(corahip_ctx *ctx, int lmax, const unsigned **tab) {
+    if (ctx->draw_slot_tab && ctx->draw_slot_lmax == lmax) {
+        *tab = ctx->draw_slot_tab;
+        return 0;
+    }
+    std::vector<unsigned> h;
+    h.reserve((size_t)draw_slots(0, lmax));
+    for (int l = lmax; l >= 0; l--)
+        for (int mb = 0; mb <= l / DRAW_MB; mb++) h.push_back(((unsigned)l << 8) | (unsigned)mb);
+    if (ctx->draw_slot_tab) (void)hipFree(ctx->draw_slot_tab);
+    ctx->draw_slot_tab = nullptr;
+    ctx->draw_slot_lmax = -1;
+    unsigned *d = nullptr;
+    HIP_TRY(hipMalloc((void **)&d, sizeof(unsigned) * h.size()));
+    HIP_TRY(hipMemcpy(d, h.data(), sizeof(unsigned) * h.size(), hipMemcpyHostToDevice));   // (synchronous: visible to every stream)
+    ctx->draw_slot_tab = d;
+    ctx->draw_slot_lmax = lmax;
+    *tab = d;
+    return 0;
+}
+
 template <int NCT, bool FROMG = false>
 static int launch_draw_rng(corahip_ctx *ctx, hipStream_t stream, const double *T, size_t t_ldl, int rows, const int32_t *info,
                            uint64_t seed, const double *gsrc, size_t g_off, int l_lo, int l_hi, int lmax, int F,
@@ -555,14 +573,17 @@ static int launch_draw_rng(corahip_ctx *ctx, hipStream_t stream, const double *T
     const int ncg0 = (((n0 + 3) & ~3) + NC - 1) / NC, ncg = ncg0 + (((n1 + 3) & ~3) + NC - 1) / NC;
     const long nslots = draw_slots(l_lo, l_hi);
     const long nitems = nslots * ncg;
-    ARG_CHECK(nitems < (1L << 30));
+    ARG_CHECK(nitems < (1L << 30) && lmax < (1 << 24) && lmax / DRAW_MB < 256);
+    const unsigned *slot_tab = nullptr;
+    if ((rc = draw_slot_table(ctx, lmax, &slot_tab))) return rc;
+    slot_tab += l_hi < lmax ? draw_slots(l_hi + 1, lmax) : 0;      // the launch's run of the table starts at its l_hi
     // persistent: one workgroup per CU for the 128-channel shape (106 KB of LDS), two for the narrower ones
     const int per_cu = (shm + 8300 > 80 * 1024) ? 1 : 2;
     dim3 grid((unsigned)std::min<long>(nitems, (long)ctx->num_cu * per_cu));
     draw_rng_kernel<NCT, FROMG><<<grid, 64 * DRAW_WAVES, shm, stream>>>(T, t_ldl, rows, info, (const double *)zq, seed, gsrc,
                                                                         g_off, l_lo, l_hi, lmax, F, ch.nu0, ch.nu1, ch.cw,
                                                                         ch.nnu, Gout, (int)nslots, ncg0, ncg, alm,
-                                                                        (unsigned *)(zq + 4096));
+                                                                        (unsigned *)(zq + 4096), slot_tab);
     LAUNCH_CHECK();
 #if DRAW_STAMPS
     {
