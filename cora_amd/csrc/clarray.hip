@@ -247,9 +247,12 @@ clarray21_kernel(const double *__restrict__ tt, int nkperp, int nkpar, double kp
                 prof[b * PS + x + 1] = combine(b, v1);
             }
             if (tid < ZN) lxcs_s[tid] = par[(a * ZN + tid) * 8 + 6];
-            __syncthreads();
-            // slot nkperp repeats the last row (see below)
-            if (xhi == nkperp && tid < ZN) prof[tid * PS + nkperp] = prof[tid * PS + nkperp - 1];
+            // slot nkperp repeats the last row (see below); xhi is uniform, and cora's frequency ranges never reach the
+            // last table row - no barrier for a write that does not happen
+            if (xhi == nkperp) {
+                __syncthreads();
+                if (tid < ZN) prof[tid * PS + nkperp] = prof[tid * PS + nkperp - 1];
+            }
         } else
 #endif
         for (int b = 0; b < zint; b++) {
