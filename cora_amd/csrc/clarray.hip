@@ -240,11 +240,17 @@ clarray21_kernel(const double *__restrict__ tt, int nkperp, int nkpar, double kp
                 const int b = e % ZN, k = e / ZN;
                 const double xx = fmin(fmax(s_lxk[k] - par[(a * ZN + b) * 8 + 6], 0.0), ux);
                 const int x = (int)xx;
-                double v0[6], v1[6];
-                row_of(b, x, v0);
-                row_of(b, min(x + 1, nkperp - 1), v1);
-                prof[b * PS + x] = combine(b, v0);
-                prof[b * PS + x + 1] = combine(b, v1);
+                // rows x and x + 1 by one 16-byte load per table row (8-byte aligned: x has either parity)
+                typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));
+                const double *r0 = tt + (size_t)ipar[(a * ZN + b) * 4 + 0] * CL_XS + x, *r1 = r0 + CL_XS;
+                const d2u t0 = *reinterpret_cast<const d2u *>(r0), t1 = *reinterpret_cast<const d2u *>(r1);
+                const d2u t2 = *reinterpret_cast<const d2u *>(r0 + tsz), t3 = *reinterpret_cast<const d2u *>(r1 + tsz);
+                const d2u t4 = *reinterpret_cast<const d2u *>(r0 + 2 * tsz), t5 = *reinterpret_cast<const d2u *>(r1 + 2 * tsz);
+                const double v0[6] = {t0.x, t1.x, t2.x, t3.x, t4.x, t5.x};
+                const double v1[6] = {t0.y, t1.y, t2.y, t3.y, t4.y, t5.y};
+                const double p0 = combine(b, v0);
+                prof[b * PS + x] = p0;
+                prof[b * PS + x + 1] = x + 1 < nkperp ? combine(b, v1) : p0;      // (slot nkperp repeats row nkperp - 1)
             }
             if (tid < ZN) lxcs_s[tid] = par[(a * ZN + tid) * 8 + 6];
             // slot nkperp repeats the last row (see below); xhi is uniform, and cora's frequency ranges never reach the
