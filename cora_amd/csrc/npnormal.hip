@@ -208,6 +208,14 @@ __device__ inline unsigned uni32(unsigned v) { return (unsigned)__builtin_amdgcn
 __device__ inline uint64_t uni64(uint64_t v) { return ((uint64_t)uni32((unsigned)(v >> 32)) << 32) | uni32((unsigned)v); }
 __device__ inline unsigned readlane32(unsigned v, int l) { return (unsigned)__builtin_amdgcn_readlane(v, l); }
 // number of set bits of m below this lane
+// lane i <- lane i + 1 (lane 63 keeps its own value): a DPP wave shift, two VALU moves - __shfl_down compiles to two
+// ds_bpermute round trips through the LDS crossbar, which the classifying loop took in more than half of its rows
+__device__ inline uint64_t wave_shl1(uint64_t v) {
+    const int lo = (int)(unsigned)v, hi = (int)(unsigned)(v >> 32);
+    const int slo = __builtin_amdgcn_update_dpp(lo, lo, 0x130, 0xF, 0xF, false);   // wave_shl:1
+    const int shi = __builtin_amdgcn_update_dpp(hi, hi, 0x130, 0xF, 0xF, false);
+    return ((uint64_t)(unsigned)shi << 32) | (unsigned)slo;
+}
 __device__ inline unsigned mbcnt64(uint64_t m) {
     return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
 }
@@ -502,7 +510,7 @@ __device__ inline uint64_t block_classify(cols_t &c, u128 s_blk, u128 inc, u128 
 #endif
         if (Wm) {
             // the wedge draw of position p is the draw of position p + 1: the next lane, or lane 0 of the next row
-            uint64_t r1 = __shfl_down(raw_cur, 1);
+            uint64_t r1 = wave_shl1(raw_cur);
             const uint64_t first_next = readlane64(raw_next, 0);
             if (lane == 63) r1 = first_next;
             const unsigned add = __builtin_popcountll(Wm);
