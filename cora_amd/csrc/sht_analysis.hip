@@ -5,6 +5,9 @@
 #ifndef ADJ_MU
 #define ADJ_MU 1         // 1: scaled two-instruction recurrence (mu form), scale applied per output row; 0: (A, B) form (A/B builds)
 #endif
+#ifndef ADJ_ROWS_REDUCE
+#define ADJ_ROWS_REDUCE 1   // 1: the tile reduction goes row by row (m) and skips what a ring tile cannot reach; 0: flat sum over zero-filled partial buffers (A/B)
+#endif
 #ifndef ADJ_CUNROLL
 #define ADJ_CUNROLL 8    // recurrence steps whose (scalar-loaded) coefficients are fetched together; measured 8 / 16 / 32: 25.1 / 26.9 / 25.5 ms
 #endif
@@ -68,8 +71,12 @@ legendre_adj_kernel(int lmax, int npair, int nring, int ncols, const double *__r
         const long base_m = alm_idx(0, m, lmax);
         const int lb0 = lmin <= lmax ? m + ((lmin - m) & ~(LB - 1)) : lmax + 1;
         double *pout = part + ((size_t)rtile * nalm + base_m) * ncols + (size_t)cg * TCOLS;
+#if !ADJ_ROWS_REDUCE
         // multipoles this tile cannot reach contribute zero
         for (int e = tid; e < (lb0 - m) * TCOLS; e += 512) pout[(size_t)(m + e / TCOLS) * ncols + e % TCOLS] = 0.0;
+#endif
+        // (ADJ_ROWS_REDUCE: the rows below lb0 are neither written here nor read by alm_reduce_rows_kernel, which forms the
+        //  same lb0 per (m, ring tile) - a fifth of the partial buffers' traffic was zeros)
 
         if (lb0 <= lmax) {
             // ---- this wave's G tile -> registers (B operand): k-step s covers rings 4s..4s+3 of the wave
@@ -250,6 +257,75 @@ __global__ void alm_reduce_kernel(const double *__restrict__ part, long n, int n
         alm[q] = s;
     }
 }
+// the same sum by rows: block (chunk of 64 multipoles, m).  Ring tile t reaches row m from lb0_t(m) on (the block of
+// 32 l that holds the first l any of its rings contributes to - legendre_adj_kernel's own expression); below that the
+// tile's partial buffer holds nothing and is not read.
+__global__ void __launch_bounds__(256)
+alm_reduce_rows_kernel(const double *__restrict__ part, long nalm, int ntile, int ncols, int lmax, int ntile128,
+                       const int32_t *__restrict__ lmin_tab, const double *__restrict__ zeros, double *__restrict__ alm) {
+    __shared__ int s_lb0[16];
+    const int m = blockIdx.y, l0 = m + 64 * (int)blockIdx.x;
+    if (l0 > lmax) return;
+    const int l1 = min(lmax + 1, l0 + 64), tid = threadIdx.x;
+    if (tid < ntile) {
+        int lmin = lmax + 1;
+        for (int q = 0; q < 4; q++) {
+            const int t128 = tid * 4 + q;
+            if (t128 < ntile128) lmin = min(lmin, lmin_tab[m * ntile128 + t128]);
+        }
+        s_lb0[tid] = lmin <= lmax ? m + ((lmin - m) & ~31) : lmax + 1;
+    }
+    __syncthreads();
+    const long base_m = alm_idx(0, m, lmax);
+    const size_t n = (size_t)nalm * ncols;
+    const double2 *p2 = reinterpret_cast<const double2 *>(part);
+    double2 *a2 = reinterpret_cast<double2 *>(alm);
+    const int half = ncols >> 1;                       // double2 per row (ncols is a multiple of 16)
+    const float rcp = 1.0f / (float)half;
+    const double2 *z2 = reinterpret_cast<const double2 *>(zeros);
+    constexpr int UN = 4;                              // elements per thread in flight (their loads are independent)
+    for (int e0 = tid; e0 < (l1 - l0) * half; e0 += 256 * UN) {
+        size_t q[UN];
+        int lu[UN];
+        const double2 *src[UN][4];
+#pragma unroll
+        for (int u = 0; u < UN; u++) {
+            const int e = min(e0 + 256 * u, (l1 - l0) * half - 1);
+            int lo = (int)((float)e * rcp);            // e / half (e < 2^23: one float multiply and a correction)
+            int rem = e - lo * half;
+            if (rem < 0) lo--, rem += half;
+            if (rem >= half) lo++, rem -= half;
+            const int l = l0 + lo;
+            lu[u] = l;
+            q[u] = ((size_t)(base_m + l) * ncols >> 1) + rem;
+            // a tile that does not reach the row is read from a line of zeros (no branch: the loads of all tiles and of
+            // the UN elements go out together)
+#pragma unroll
+            for (int t = 0; t < 4; t++) src[u][t] = (t < ntile && l >= s_lb0[t]) ? p2 + (size_t)t * (n >> 1) + q[u] : z2;
+        }
+        double2 v[UN][4];
+#pragma unroll
+        for (int u = 0; u < UN; u++)
+#pragma unroll
+            for (int t = 0; t < 4; t++) v[u][t] = *src[u][t];
+#pragma unroll
+        for (int u = 0; u < UN; u++) {
+            double2 s = make_double2(0.0, 0.0);
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                s.x += v[u][t].x;
+                s.y += v[u][t].y;
+            }
+            for (int t = 4; t < ntile; t++)            // (more than four ring tiles: nside > 1024)
+                if (lu[u] >= s_lb0[t]) {
+                    const double2 w = p2[(size_t)t * (n >> 1) + q[u]];
+                    s.x += w.x;
+                    s.y += w.y;
+                }
+            if (e0 + 256 * u < (l1 - l0) * half) a2[q[u]] = s;
+        }
+    }
+}
 template <int NCT>
 static int launch_legendre_adj(corahip_ctx *ctx, const corahip_sht_plan *p, int ncols, const double *inter,
                                double *part) {
@@ -277,7 +353,19 @@ int sht_legendre_adj(corahip_ctx *ctx, const corahip_sht_plan *p, int ncols, con
     if (rc) return rc;
     const int ntile = (p->npair + 64 * ADJ_WAVES - 1) / (64 * ADJ_WAVES);
     const long n = p->nalm * (long)ncols;
+    (void)n;
+#if ADJ_ROWS_REDUCE
+    if (ntile <= 16) {
+        const int ntile128 = (p->npair + LMIN_RINGS - 1) / LMIN_RINGS;
+        dim3 grid((unsigned)((p->L + 63) / 64), (unsigned)p->L);
+        alm_reduce_rows_kernel<<<grid, 256, 0, ctx->stream>>>(part, p->nalm, ntile, ncols, p->lmax, ntile128, p->d_lmin, p->d_zeros, alm_dev);
+        LAUNCH_CHECK();
+        return 0;
+    }
+    return CORAHIP_EINVAL;      // (more than 16 ring tiles: nside > 16384)
+#else
     alm_reduce_kernel<<<(int)std::min<long>((n + 255) / 256, 8192), 256, 0, ctx->stream>>>(part, n, ntile, alm_dev);
     LAUNCH_CHECK();
+#endif
     return 0;
 }
