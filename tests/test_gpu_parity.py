@@ -905,6 +905,31 @@ def test_map2alm_full_size_adjointness(ctx):
     torch.cuda.empty_cache()
 
 
+def test_map2alm_adjointness_nside2048(ctx):
+    """The same property at the cfg-5 geometry (nside 2048; lmax 383 keeps it light): eight ring tiles - the tile reduction's
+    path beyond four -, the belt rings through the length-4096 analysis kernel, the caps through the run-time kernel."""
+    import torch
+
+    nside, lmax, nnu = 2048, 383, 8
+    L = lmax + 1
+    nalm = L * (L + 1) // 2
+    npix = 12 * nside * nside
+    gen = torch.Generator(device=ctx.device).manual_seed(4)
+    a = torch.randn((nalm, 2, 2, 4), generator=gen, device=ctx.device, dtype=torch.float64)
+    a[:L, :, 1, :] = 0.0
+    x = torch.randn((nnu, npix), generator=gen, device=ctx.device, dtype=torch.float64)
+    Sa = ctx.alm2map(a, nside, lmax, nnu)
+    Ax = ctx.map2alm(x, nside, lmax, None)
+    wgt = torch.full((nalm, 1, 1, 1), 2.0, device=ctx.device, dtype=torch.float64)
+    wgt[:L] = 1.0
+    lhs = (Sa * x).sum(dim=1) * (4 * np.pi / npix)
+    rhs = (wgt * a * Ax).sum(dim=(0, 2)).reshape(-1)[:nnu]
+    scale = (Sa.abs() * x.abs()).sum(dim=1) * (4 * np.pi / npix)
+    assert ((lhs - rhs).abs() / scale).max().item() < 1e-12
+    del a, x, Sa, Ax
+    torch.cuda.empty_cache()
+
+
 def test_mkconstrained_vs_oracle(golden):
     """skysim.mkconstrained (cora/core/skysim.py:139-205): constrained channels reproduce their constraint
     maps (up to the l = 0 mode the reference zeroes) and the whole stack matches the CPU oracle."""
