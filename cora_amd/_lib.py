@@ -52,6 +52,7 @@ SIGNATURES = {
     "corahip_normals_pcg64": (c_int, [c_void_p, ctypes.POINTER(c_u64), ctypes.POINTER(c_u64), ctypes.c_int64, PTR,
                                       ctypes.POINTER(c_u64)]),
     "corahip_normals_mt19937_legacy": (c_int, [c_void_p, c_void_p, ctypes.c_int64, PTR]),
+    "corahip_glibc_exp": (c_int, [c_void_p, PTR, ctypes.c_int64, PTR]),
     "corahip_pcg64_advance": (c_int, [ctypes.POINTER(c_u64), ctypes.POINTER(c_u64), c_u64, ctypes.POINTER(c_u64)]),
     "corahip_draw_alm_philox": (c_int, [c_void_p, PTR, PTR, c_u64, c_int, c_int, c_int, c_int, PTR]),
     "corahip_draw_alm_philox_rows": (c_int, [c_void_p, PTR, PTR, c_u64, c_int, c_int, c_int, c_int, PTR]),
@@ -444,6 +445,13 @@ class Context:
         nraw = c_u64(0)
         _check(self.lib.corahip_normals_pcg64(self.h, st, ic, int(n), self._f64(g), ctypes.byref(nraw)))
         return g, int(nraw.value)
+
+    def glibc_exp(self, x):
+        """exp(x) of a device float64 tensor as the wedge test of the device ziggurat evaluates it (glibc's routine,
+        restated): the test hook ``corahip_glibc_exp``."""
+        y = self.empty(tuple(x.shape))
+        _check(self.lib.corahip_glibc_exp(self.h, self._f64(x), int(x.numel()), self._f64(y)))
+        return y
 
     def normals_legacy(self, state, n, out=None):
         """The next ``n`` values of numpy's LEGACY stream (``np.random.standard_normal`` / ``RandomState``: MT19937 + polar

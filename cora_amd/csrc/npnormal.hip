@@ -10,11 +10,10 @@
 //                  distributions.c, tables zig_tab.inc read out of numpy's own library by tools/gen_zig_tabs.py):
 //                  one raw draw on the fast path (98.5 % of the positions), two for a wedge sample (accepted or
 //                  not), 1 + 2 i for a tail sample.  Tail samples use glibc's log1p restated operation by operation
-//                  (fdlibm's algorithm in glibc's evaluation order, no contraction): bit-identical to numpy on glibc.
-//                  One caveat: the WEDGE test compares against exp(-x^2 / 2) of the device library (<= 1 ulp), not
-//                  glibc's exp; an argument within one ulp of the acceptance threshold could flip an accept and shift
-//                  every later sample (probability ~1e-9 per cfg-3 realisation; never met in 2.4e8 compared samples,
-//                  tests/test_gpu_npnormal.py) - "bit for bit" holds up to that event.
+//                  (fdlibm's algorithm in glibc's evaluation order, no contraction), and the WEDGE test compares
+//                  against glibc's exp restated the same way (glibc_exp_fma: the table-driven routine in the
+//                  evaluation order of its FMA build, round 6; until then the device library's exp, within one ulp of
+//                  it, could have flipped an accept at the threshold): bit-identical to numpy on glibc.
 //
 // "Which raw position starts a sample" is a prefix problem; oracle/npnormal_model.py states the decomposition in python
 // (checked against numpy on the CPU), this is the same thing on the device:
@@ -176,6 +175,41 @@ __device__ __attribute__((noinline)) double glibc_log1p_neg(double x) {
     return k * ln2_hi - ((hfsq - (s * (hfsq + Rr) + (k * ln2_lo + c))) - f);
 }
 
+// glibc's exp (sysdeps/ieee754/dbl-64/e_exp.c: x = k ln2 / 128 + r, 2^(k/128) from a 128-entry table of (tail, scale
+// bits), exp(r) - 1 by a degree-5 polynomial) in the evaluation order of its FMA build - the one the loader selects on
+// every CPU with FMA + AVX2, read off the installed libm's code - operation by operation: what is fused there is an fma
+// here, what is separate stays separate (contraction off).  Constants: glibc_exp_tab.inc (tools/gen_glibc_exp_tab.py
+// reads them out of the installed libm).  For |x| < 512 (the wedge test's argument is in [-6.7, 0)); oracle/npnormal.py
+// restates the same sequence and tests/test_oracle.py pins it to the host's exp bit for bit.
+#include "glibc_exp_tab.inc"
+__device__ const ulonglong2 g_gexp_T[128] = GLIBC_EXP_T;
+__device__ inline double glibc_exp_fma(double x) {
+#pragma clang fp contract(off)
+    constexpr double C[4] = GLIBC_EXP_C;
+    const unsigned abstop = ((unsigned)__double2hiint(x) >> 20) & 0x7ffu;
+    if (abstop < 0x3c9u) return 1.0 + x;                          // |x| < 2^-54
+    double kd = fma(x, GLIBC_EXP_INVLN2N, GLIBC_EXP_SHIFT);
+    const unsigned long long ki = (unsigned long long)__double_as_longlong(kd);
+    kd = kd - GLIBC_EXP_SHIFT;
+    const double r = fma(kd, GLIBC_EXP_NEGLN2LON, fma(kd, GLIBC_EXP_NEGLN2HIN, x));
+    const ulonglong2 t = g_gexp_T[ki & 127ull];
+    const double tail = __longlong_as_double((long long)t.x);
+    const unsigned long long sbits = t.y + (ki << 45);
+    const double p23 = fma(r, C[1], C[0]);
+    const double tr = r + tail;
+    const double r2 = r * r;
+    const double p45 = fma(r, C[3], C[2]);
+    const double t1 = fma(p23, r2, tr);
+    const double r4 = r2 * r2;
+    const double tmp = fma(r4, p45, t1);
+    const double scale = __longlong_as_double((long long)sbits);
+    return fma(scale, tmp, scale);
+}
+__global__ void glibc_exp_kernel(const double *__restrict__ x, long n, double *__restrict__ y) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = glibc_exp_fma(x[i]);
+}
+
 __device__ inline double raw_to_double(uint64_t r) { return (double)(r >> 11) * (1.0 / 9007199254740992.0); }
 
 // the value of a fast-path / wedge sample: rabs * wi[idx], negated by the sign bit
@@ -191,7 +225,7 @@ __device__ __attribute__((noinline)) bool zig_wedge_accept(uint64_t r0, uint64_t
     const double x = (double)((r0 >> 9) & M52) * wi[idx];
     const double u = raw_to_double(r1);
     const double lhs = (fi[idx - 1] - fi[idx]) * u + fi[idx];
-    return lhs < exp(-0.5 * x * x);
+    return lhs < glibc_exp_fma(-0.5 * x * x);
 }
 
 struct zig_status {
@@ -481,9 +515,13 @@ __device__ inline void wedge_flush(zig_wlds *W, unsigned ncand, const double *wi
     wave_lds_fence();
 }
 
-// rows 0 .. 15 of block b: the class masks of every row (columns) - pass 1's vector work
+// rows 0 .. 15 of block b: the class masks of every row (columns) - pass 1's vector work.  KEEP (the single-pass
+// kernel): the raw draws of the 16 rows stay in `raw` (row j of lane p = position 64 j + p) and the values of the
+// tail samples of the table in `tv` (entry i of the table <-> tv[i]; wave-uniform).
+template <bool KEEP = false>
 __device__ inline uint64_t block_classify(cols_t &c, u128 s_blk, u128 inc, u128 lane_m, u128 lane_c, u128 c64,
-                                          const zig_lds &L, zig_wlds *W, unsigned *err) {
+                                          const zig_lds &L, zig_wlds *W, unsigned *err, uint64_t *raw = nullptr,
+                                          double *tv = nullptr) {
     const int lane = threadIdx.x & 63;
     constexpr u128 M64 = mk128(H_POW2.v[6].mhi, H_POW2.v[6].mlo);
     u128 s = lane_m * s_blk + lane_c;                            // state after position `lane` of row 0
@@ -494,6 +532,7 @@ __device__ inline uint64_t block_classify(cols_t &c, u128 s_blk, u128 inc, u128 
 #pragma unroll
     for (int j = 0; j < ZIG_ROWS; j++) {
         const u128 s_row = s;                                    // the states that put out row j
+        if (KEEP) raw[64 * j + lane] = raw_cur;                 // (wave-private LDS: a lane reads back what it wrote)
         s = s * M64 + c64;
         const uint64_t raw_next = pcg_out(s);                    // row j + 1 (row 16: the next block's first row)
         const unsigned idx = (unsigned)(raw_cur & 0xff);
@@ -531,6 +570,10 @@ __device__ inline uint64_t block_classify(cols_t &c, u128 s_blk, u128 inc, u128 
                 double v;
                 unsigned consumed;
                 zig_tail_from(bcast128(s_row, pz), inc, v, consumed, err);
+                if (KEEP) {
+#pragma unroll
+                    for (int i = 0; i < 4; i++) tv[i] = ntail == (unsigned)i ? v : tv[i];
+                }
                 tt = ttab_add(tt, ntail++, 64u * j + pz, consumed);
             }
         }
@@ -981,6 +1024,492 @@ __global__ void zig_range_kernel(const ulonglong2 *__restrict__ entry, long nblk
     blk_first[r] = lo;
 }
 
+
+// ---- ONE pass: classify, chained scan with decoupled look-back, emit (round 6) -----------------------------------------
+// The two-pass form above steps the 128-bit generator twice: once to find every block's (entry, first ordinal), once to
+// write the samples.  Here a workgroup of ZC_WAVES waves takes a CHUNK of ZC_WAVES consecutive blocks (a ticket: chunks
+// are handed out in order, so every predecessor of a running chunk is running or done - no residency assumption), each
+// wave classifies its block and KEEPS its 1024 raw draws in wave-private LDS (in registers the kernel needed 242 VGPRs:
+// one workgroup per CU), the workgroup composes its blocks'
+// functions on {0, 1} into the chunk's aggregate and publishes it; wave 0 then looks back over the predecessors'
+// words (64 chunks per poll; an aggregate can be folded, an inclusive word ends the walk - Merrill & Garland's
+// decoupled look-back on a function composition instead of a sum), publishes the chunk's inclusive word (exit k,
+// ordinal after) BEFORE anything is written, and every wave emits from the kept draws.  Words are single naturally
+// aligned 8-byte values with their valid bit inside, stored and polled with agent-scope relaxed atomics (L1 bypass):
+// no fences, nothing else is handed over.
+// An entry k >= 2 (a tail sample across a boundary, 1.5e-4 of the blocks) has no table entry: inside a chunk the wave
+// that owns the block evaluates it for that k on request (block_chain), across chunks the look-back simply waits for
+// the inclusive word of the chunk that was entered that way.
+// One launch = one RANGE of ordinals: it starts at the raw position where the previous range ended (*carry_in, left by
+// the lane that wrote the previous range's last sample) and leaves its own end in *carry_out.
+#ifndef ZC_WAVES
+#define ZC_WAVES 4
+#endif
+#ifndef ZC_SLEEP
+#define ZC_SLEEP 4
+#endif
+#define ZC_WG (64 * ZC_WAVES)
+#define ZC_PATCH 16
+#define ZC_NONE 0xffffffffu
+#define ZC_SPIN_CAP (1u << 22)          // polls of one look-back before the status word is flagged (seconds; never met)
+#define ZC_VALID (1ull << 63)
+#define ZC_K(w, e) ((unsigned)((w) >> (28 * (e))) & 0x3fffu)
+#define ZC_C(w, e) ((unsigned)((w) >> (28 * (e) + 14)) & 0x3fffu)
+#define ZC_ORD_MASK ((1ull << 48) - 1ull)
+
+struct zc_head {
+    unsigned ticket, pad0;
+    unsigned long long pad1;
+#ifdef ZC_STATS
+    unsigned long long polls, folds, cyc_classify, cyc_lookback, cyc_emit, cyc_total, chunks, dist;
+#endif
+};
+
+__device__ inline unsigned long long zc_ld(const unsigned long long *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ inline void zc_st(unsigned long long *p, unsigned long long v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// state before the first position of block b of a range that starts at raw position *pos_base
+__global__ void zig_seek_rel_kernel(uint64_t s_hi, uint64_t s_lo, uint64_t i_hi, uint64_t i_lo,
+                                    const unsigned long long *__restrict__ pos_base, long nblk, ulonglong2 *__restrict__ blk_state) {
+    const long b = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nblk) return;
+    const u128 inc = mk128(i_hi, i_lo);
+    u128 s = mk128(s_hi, s_lo);
+    const unsigned long long n = *pos_base + (unsigned long long)b * ZIG_BLK;
+    for (int i = 0; i < 64 && (n >> i); i++)
+        if ((n >> i) & 1) s = jump_apply(ZIG_POW2.v[i], s, inc);
+    blk_state[b] = make_ulonglong2((uint64_t)(s >> 64), (uint64_t)s);
+}
+
+// the chunk's blocks entered with k: entry and sample offset of every block (when ent != NULL), exit k and sample
+// count; false = the function value of block req >> 16 for k = req & 0xffff is not known yet
+__device__ inline bool zc_walk(unsigned k, const unsigned (*fun)[2], const uint2 *patch, unsigned np, unsigned *ent, unsigned *off,
+                               unsigned &kout, unsigned &tot, unsigned &req) {
+    unsigned c = 0;
+    for (int w = 0; w < ZC_WAVES; w++) {
+        if (ent) {
+            ent[w] = k;
+            off[w] = c;
+        }
+        unsigned v = 0;
+        if (k < 2) v = fun[w][k];
+        else {
+            const unsigned key = ((unsigned)w << 16) | k;
+            bool hit = false;
+            for (unsigned i = 0; i < np && i < ZC_PATCH; i++)
+                if (patch[i].x == key) {
+                    v = patch[i].y;
+                    hit = true;
+                }
+            if (!hit) {
+                req = key;
+                return false;
+            }
+        }
+        k = v >> 16;
+        c += v & 0xffffu;
+    }
+    kout = k;
+    tot = c;
+    return true;
+}
+
+// A chunk's function on {0, 1} in one 64-bit word for the look-back: entry e in bits 32 e .. 32 e + 31 as count << 8 | k,
+// k = 0xff ("poison") when the exit is >= 2 - such a chunk's successor is not in anybody's table, the walk waits for an
+// inclusive word behind it instead.  (Counts of one round of ZC_NWIN windows: < 2^24.)
+#define ZC_NWIN 4
+#define ZC_IDENT ((1ull << 32) | 0ull)
+__device__ inline unsigned long long zc_pack(unsigned long long a) {
+    const unsigned k0 = ZC_K(a, 0), k1 = ZC_K(a, 1);
+    const unsigned e0 = (ZC_C(a, 0) << 8) | (k0 < 2 ? k0 : 0xffu), e1 = (ZC_C(a, 1) << 8) | (k1 < 2 ? k1 : 0xffu);
+    return ((unsigned long long)e1 << 32) | e0;
+}
+// h = g o f: f (the farther chunks) first
+__device__ inline unsigned long long zc_compose(unsigned long long g, unsigned long long f) {
+    unsigned h[2];
+#pragma unroll
+    for (int e = 0; e < 2; e++) {
+        const unsigned fe = (unsigned)(f >> (32 * e)), kf = fe & 0xffu;
+        const unsigned ge = kf ? (unsigned)(g >> 32) : (unsigned)g;
+        h[e] = kf >= 2 ? 0xffu : (((fe >> 8) + (ge >> 8)) << 8) | (ge & 0xffu);
+    }
+    return ((unsigned long long)h[1] << 32) | h[0];
+}
+__device__ inline unsigned long long shfl_down64(unsigned long long v, int d) {
+    const unsigned lo = __shfl_down((unsigned)v, d), hi = __shfl_down((unsigned)(v >> 32), d);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+// wave 0: (entry k, first ordinal) of chunk c from the words of its predecessors.  Every round has the words of
+// ZC_NWIN x 64 predecessors in flight together (a poll is a round trip to the memory side of the L2s: the words are
+// stored write-through), the windows are evaluated nearest first: an inclusive word ends the walk, 64 aggregates
+// without one are composed by a log-step reduction across the lanes and the walk goes on.  false: gave up (status flagged).
+__device__ inline bool zc_lookback(long c, const unsigned long long *agg, const unsigned long long *incw, unsigned &k_out,
+                                   unsigned long long &ord_out, unsigned *err, zc_head *head = nullptr) {
+    const int lane = threadIdx.x & 63;
+    for (unsigned spin = 0;; spin++) {
+        // pending = the composition of the windows already folded (the chunks between `base` and c), on {0, 1}
+        unsigned pk[2] = {0u, 1u};
+        unsigned long long pc[2] = {0ull, 0ull};
+        bool any_pending = false, failed = false;
+        for (long base = c - 1; !failed; base -= 64 * ZC_NWIN) {
+#ifdef ZC_STATS
+            if (lane == 0) atomicAdd(&head->polls, 1ull);
+#endif
+            unsigned long long iw[ZC_NWIN], aw[ZC_NWIN];
+#pragma unroll
+            for (int w = 0; w < ZC_NWIN; w++) {
+                const long j = base - 64 * w - lane;
+                iw[w] = aw[w] = 0;
+                if (j >= 0) {
+                    iw[w] = zc_ld(incw + j);
+                    aw[w] = zc_ld(agg + j);
+                } else if (j == -1) iw[w] = ZC_VALID;             // in front of chunk 0: k = 0, ordinal 0
+            }
+#pragma unroll
+            for (int w = 0; w < ZC_NWIN && !failed; w++) {
+                const unsigned long long im = __ballot((iw[w] >> 63) != 0), am = __ballot((aw[w] >> 63) != 0);
+                const int li = im ? __builtin_ctzll(im) : 64;       // the nearest inclusive word of the window
+                const unsigned long long need = li == 64 ? ~0ull : (1ull << li) - 1ull;
+                if ((am & need) != need) {
+                    failed = true;                                  // an aggregate on the way is not there yet
+                    break;
+                }
+                // the aggregates of lanes 0 .. li - 1, the nearest (lane 0) applied last
+                unsigned long long f = lane < li ? zc_pack(aw[w]) : ZC_IDENT;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const unsigned long long far = shfl_down64(f, d);
+                    f = zc_compose(f, lane + d < 64 ? far : ZC_IDENT);
+                }
+                f = readlane64(f, 0);
+                if (li < 64) {
+                    const unsigned long long w0 = readlane64(iw[w], li);
+                    unsigned k = (unsigned)(w0 >> 48) & 0x3fffu;
+                    unsigned long long ord = w0 & ZC_ORD_MASK;
+                    // (li = 0 and nothing pending: the word of c - 1 itself, whose k may be anything)
+                    if (li > 0) {
+                        const unsigned fe = k < 2 ? (unsigned)(f >> (32 * k)) : 0xffu;
+                        if ((fe & 0xffu) >= 2) {                    // a chunk on the way was entered with k >= 2, or hands one to c:
+                            failed = true;                          // its own inclusive word will say which k
+                            break;
+                        }
+                        ord += fe >> 8;
+                        k = fe & 0xffu;
+                    }
+                    if (any_pending) {
+                        if (k >= 2) {
+                            failed = true;
+                            break;
+                        }
+                        ord += pc[k];
+                        k = pk[k];
+                    }
+                    k_out = k;
+                    ord_out = ord;
+#ifdef ZC_STATS
+                    if (lane == 0) atomicAdd(&head->dist, (unsigned long long)(c - 1 - base + 64 * w + li));
+#endif
+                    return true;
+                }
+                // 64 aggregates, no inclusive word: pending <- pending o f
+                unsigned nk[2];
+                unsigned long long nc[2];
+#pragma unroll
+                for (int e = 0; e < 2; e++) {
+                    const unsigned fe = (unsigned)(f >> (32 * e)), kf = fe & 0xffu;
+                    if (kf >= 2) failed = true;
+                    nk[e] = any_pending ? pk[kf & 1u] : kf;
+                    nc[e] = (fe >> 8) + (any_pending ? pc[kf & 1u] : 0ull);
+                    if (nk[e] >= 2) failed = true;
+                }
+                pk[0] = nk[0], pk[1] = nk[1], pc[0] = nc[0], pc[1] = nc[1];
+                any_pending = true;
+#ifdef ZC_STATS
+                if (lane == 0) atomicAdd(&head->folds, 1ull);
+#endif
+            }
+        }
+        if (spin >= ZC_SPIN_CAP) {
+            if (lane == 0) atomicOr(err, 8u);
+            return false;
+        }
+        // a word is missing, or a chunk on the way was entered with k >= 2 (it publishes its own inclusive word): start
+        // again from the nearest window - by then the inclusive words have come closer
+        __builtin_amdgcn_s_sleep(ZC_SLEEP);
+    }
+}
+
+// the samples of one block, from the raw draws kept in LDS: entry `pos`, first ordinal ord_blk (relative to the
+// range); ordinals below o_n are written, and whoever writes the range's last one leaves the raw position behind it
+__device__ inline void block_emit(const uint64_t *raw, const cols_t &c, uint64_t tt, const double (&tv)[4], unsigned G,
+                                  unsigned C1, u128 s_blk, u128 inc, unsigned pos, unsigned long long ord_blk,
+                                  unsigned long long o_n, double *__restrict__ g, unsigned long long blk_pos,
+                                  unsigned long long *carry_out, const double *wi, unsigned *err) {
+    const int lane = threadIdx.x & 63;
+    const bool row = lane < ZIG_ROWS;
+    const uint64_t nf_col = ((uint64_t)c.nf_hi << 32) | c.nf_lo, z_col = ((uint64_t)c.z_hi << 32) | c.z_lo,
+                   w_col = ((uint64_t)c.w_hi << 32) | c.w_lo;
+    if (pos < 2 && !(tt & ZIG_TT_OVER)) {
+        const unsigned cins = row_carries(G, C1, pos);
+        const bool c1 = (cins >> lane) & 1u;
+        const vrow_t v = row_eval_vec(nf_col, z_col, w_col, c1 ? 1u : 0u, tt, 64u * lane);
+        if (__ballot(row && v.big) == 0) {
+            const uint64_t ew_col = row ? v.ew : 0ull, t_col = row ? v.t : 0ull, e_col = row ? v.e : 0ull;
+            const unsigned pc = __builtin_popcountll(e_col | t_col);
+            const unsigned base_col = row16_scan(pc) - pc;          // samples of the block before row `lane`
+            const unsigned trows = (unsigned)__ballot(t_col != 0);  // rows with a tail sample
+#pragma unroll
+            for (int j = 0; j < ZIG_ROWS; j++) {
+                const uint64_t e = readlane64(e_col, j);
+                const unsigned long long ord_row = ord_blk + readlane32(base_col, j);
+                if ((trows >> j) & 1) {
+                    const uint64_t tj = readlane64(t_col, j), all = e | tj;
+                    for (uint64_t zz = tj; zz; zz &= zz - 1) {
+                        const int pz = __builtin_ctzll(zz);
+                        const unsigned q = 64u * j + pz;
+                        double v2 = 0.0;
+                        unsigned consumed = 0;
+#pragma unroll
+                        for (int i = 0; i < 4; i++) {
+                            const unsigned en = (unsigned)(tt >> (16 * i)) & 0x7fffu;
+                            if (en != 0 && (en & 0x3ffu) == q) {
+                                v2 = tv[i];
+                                consumed = (en >> 10) << 1;
+                            }
+                        }
+                        const unsigned long long o = ord_row + __builtin_popcountll(all & ((1ull << pz) - 1ull));
+                        if (lane == 0 && o < o_n) {
+                            g[o] = v2;
+                            if (o + 1 == o_n) *carry_out = blk_pos + q + 1 + consumed;
+                        }
+                    }
+                    if ((e >> lane) & 1) {
+                        const unsigned long long o = ord_row + mbcnt64(all);
+                        if (o < o_n) {
+                            g[o] = zig_value(raw[64 * j + lane], wi);
+                            if (o + 1 == o_n) *carry_out = blk_pos + 64u * j + lane + 1 + ((readlane64(ew_col, j) >> lane) & 1);
+                        }
+                    }
+                } else if ((e >> lane) & 1) {
+                    const unsigned long long o = ord_row + mbcnt64(e);
+                    if (o < o_n) {
+                        g[o] = zig_value(raw[64 * j + lane], wi);
+                        if (o + 1 == o_n) *carry_out = blk_pos + 64u * j + lane + 1 + ((readlane64(ew_col, j) >> lane) & 1);
+                    }
+                }
+            }
+            return;
+        }
+    }
+    unsigned long long ord = ord_blk;                        // ordinal of the next sample
+#pragma unroll
+    for (int j = 0; j < ZIG_ROWS; j++) {
+        if (pos >= 64u * (j + 1)) continue;
+        const uint64_t nf_j = readlane64(nf_col, j), z_j = readlane64(z_col, j), w_j = readlane64(w_col, j);
+        while (pos < 64u * (j + 1)) {
+            const row_eval_t r = row_eval(nf_j, z_j, w_j, j, pos);
+            const uint64_t e = r.e_fast | r.e_wedge;
+            if ((e >> lane) & 1) {
+                const unsigned long long o = ord + mbcnt64(e);
+                if (o < o_n) {
+                    g[o] = zig_value(raw[64 * j + lane], wi);
+                    if (o + 1 == o_n) *carry_out = blk_pos + 64u * j + lane + 1 + ((r.e_wedge >> lane) & 1);
+                }
+            }
+            ord += __builtin_popcountll(e);
+            if (r.tl_bit == 64) break;
+            double v;
+            unsigned consumed;
+            zig_tail_walk(s_blk, inc, 64u * j + r.tl_bit, v, consumed, err);
+            if (lane == 0 && ord < o_n) {
+                g[ord] = v;
+                if (ord + 1 == o_n) *carry_out = blk_pos + 64u * j + r.tl_bit + 1 + consumed;
+            }
+            ord += 1;
+            pos = 64u * j + r.tl_bit + 1 + consumed;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(ZC_WG, 3)
+zig_chain_kernel(const ulonglong2 *__restrict__ blk_state, uint64_t i_hi, uint64_t i_lo, long nchunk, zc_head *head,
+                 unsigned long long *agg, unsigned long long *incw, const unsigned long long *__restrict__ carry_in,
+                 unsigned long long *carry_out, unsigned long long o_n, double *__restrict__ g, zig_status *st) {
+    __shared__ zig_lds L;
+    __shared__ zig_wlds Wall[ZC_WAVES];
+    __shared__ uint64_t s_raw[ZC_WAVES][ZIG_BLK];       // the raw draws of the chunk: position q of block w at [w][q]
+    __shared__ unsigned s_fun[ZC_WAVES][2], s_ent[ZC_WAVES], s_off[ZC_WAVES];
+    __shared__ uint2 s_patch[ZC_PATCH];
+    __shared__ unsigned s_req1, s_req2, s_np, s_skip;   // (one request word per phase: a late reader of phase 1 must not see phase 2's)
+    __shared__ unsigned long long s_ord;
+    __shared__ long s_chunk;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    zig_wlds *W = &Wall[wave];
+    zig_lds_fill(L);
+    const u128 inc = mk128(i_hi, i_lo);
+    const u128 c64 = inc * mk128(H_POW2.v[6].ghi, H_POW2.v[6].glo);
+    const jump_t lj = ZIG_LANE.v[lane];
+    const u128 lane_m = mk128(lj.mhi, lj.mlo), lane_c = inc * mk128(lj.ghi, lj.glo);
+    const unsigned long long pos_base = *carry_in;
+    long next = 0;
+    if (threadIdx.x == 0) next = (long)atomicAdd(&head->ticket, 1u);
+    for (;;) {
+        if (threadIdx.x == 0) {
+            s_chunk = next;
+            s_np = 0;
+        }
+        __syncthreads();
+        const long chunk = s_chunk;
+        if (chunk >= nchunk) break;
+        const long b = chunk * ZC_WAVES + wave;
+#ifdef ZC_STATS
+        const unsigned long long tA = __builtin_readcyclecounter();
+#endif
+        const ulonglong2 bs = blk_state[b];
+        const u128 s_blk = mk128(uni64(bs.x), uni64(bs.y));
+        cols_t c;
+        uint64_t *raw = s_raw[wave];
+        double tv[4] = {0.0, 0.0, 0.0, 0.0};
+        const uint64_t tt = block_classify<true>(c, s_blk, inc, lane_m, lane_c, c64, L, W, &st->error, raw, tv);
+        // the block's function on {0, 1} (as pass 1 of the two-pass form)
+        unsigned G, C1;
+        {
+            const bool row = lane < ZIG_ROWS;
+            const uint64_t nf = ((uint64_t)c.nf_hi << 32) | c.nf_lo, z = ((uint64_t)c.z_hi << 32) | c.z_lo,
+                           w = ((uint64_t)c.w_hi << 32) | c.w_lo;
+            const vrow_t v0 = row_eval_vec(nf, z, w, 0u, tt, 64u * lane), v1 = row_eval_vec(nf, z, w, 1u, tt, 64u * lane);
+            G = (unsigned)__ballot(row && v0.cout);
+            C1 = (unsigned)__ballot(row && v1.cout);
+            const unsigned p0 = row ? __builtin_popcountll(v0.e | v0.t) : 0u;
+            const unsigned p1 = row ? __builtin_popcountll(v1.e | v1.t) : 0u;
+            const unsigned sum0 = row16_sum(p0);
+            const bool over = (tt & ZIG_TT_OVER) != 0;
+            for (unsigned e = 0; e < 2; e++) {
+                const unsigned cins = row_carries(G, C1, e);
+                const bool c1 = (cins >> lane) & 1u;
+                const bool slow = over || __ballot(row && (c1 ? v1.big : v0.big)) != 0;
+                unsigned kk, cnt;
+                if (!slow) {
+                    kk = cins >> 16;
+                    cnt = sum0 + row16_sum(c1 && row ? p1 - p0 : 0u);
+                } else {
+                    unsigned pp, cc;
+                    block_chain(c, s_blk, inc, e, kk, cnt, pp, cc, ZIG_ROWS, &st->error);
+                }
+                if (lane == 0) s_fun[wave][e] = (kk << 16) | cnt;
+            }
+        }
+        __syncthreads();
+        // the chunk's aggregate; a block entered with k >= 2 is evaluated by its wave on request
+        unsigned ak[2] = {0, 0}, ac[2] = {0, 0};
+        for (;;) {
+            if (threadIdx.x == 0) {
+                unsigned req = ZC_NONE;
+                const bool ok = zc_walk(0u, s_fun, s_patch, s_np, nullptr, nullptr, ak[0], ac[0], req) &&
+                                zc_walk(1u, s_fun, s_patch, s_np, nullptr, nullptr, ak[1], ac[1], req);
+                if (ok) {
+                    zc_st(agg + chunk, ZC_VALID | (unsigned long long)(ak[0] & 0x3fffu) | ((unsigned long long)ac[0] << 14) |
+                                           ((unsigned long long)(ak[1] & 0x3fffu) << 28) | ((unsigned long long)ac[1] << 42));
+                    if ((ak[0] | ak[1]) > 0x3fffu) atomicOr(&st->error, 1u);
+                } else if (s_np >= ZC_PATCH) {
+                    atomicOr(&st->error, 2u);
+                    req = ZC_NONE;
+                    zc_st(agg + chunk, ZC_VALID);
+                }
+                s_req1 = ok ? ZC_NONE : req;
+            }
+            __syncthreads();
+            const unsigned req = s_req1;
+            if (req == ZC_NONE) break;
+            if ((unsigned)wave == (req >> 16)) {
+                unsigned kb, total, pp, cc;
+                block_chain(c, s_blk, inc, req & 0xffffu, kb, total, pp, cc, ZIG_ROWS, &st->error);
+                if (lane == 0) {
+                    s_patch[s_np] = make_uint2(req, (kb << 16) | total);
+                    s_np = s_np + 1;
+                }
+            }
+            __syncthreads();
+        }
+        // look-back (wave 0), then the entries of the chunk's blocks; the inclusive word goes out before any sample
+        unsigned k_c = 0;
+        unsigned long long ord_c = 0;
+        bool lb_ok = true;
+#ifdef ZC_STATS
+        const unsigned long long tB = __builtin_readcyclecounter();
+#endif
+#if defined(ZC_ABLATE) && ZC_ABLATE == 1      // (timing only, wrong ordinals: no look-back at all - the work of the kernel by itself)
+        ord_c = (unsigned long long)chunk * 4000ull;
+#else
+        if (wave == 0) lb_ok = zc_lookback(chunk, agg, incw, k_c, ord_c, &st->error, head);
+#endif
+#ifdef ZC_STATS
+        const unsigned long long tC = __builtin_readcyclecounter();
+#endif
+        for (;;) {
+            if (threadIdx.x == 0) {
+                unsigned req = ZC_NONE, kx = 0, cx = 0;
+                bool ok = true;
+                if (!lb_ok) {
+                    zc_st(incw + chunk, ZC_VALID);               // (status flagged: let the successors finish)
+                    s_skip = 1;
+                } else {
+                    ok = zc_walk(k_c, s_fun, s_patch, s_np, s_ent, s_off, kx, cx, req);
+                    if (!ok && s_np >= ZC_PATCH) {
+                        atomicOr(&st->error, 2u);
+                        ok = true;
+                        lb_ok = false;
+                        zc_st(incw + chunk, ZC_VALID);
+                        s_skip = 1;
+                    } else if (ok) {
+                        zc_st(incw + chunk, ZC_VALID | ((unsigned long long)(kx & 0x3fffu) << 48) | ((ord_c + cx) & ZC_ORD_MASK));
+                        s_ord = ord_c;
+                        s_skip = ord_c >= o_n ? 1u : 0u;           // (the range ended in front of this chunk)
+                        if (chunk == nchunk - 1) {
+                            st->total = ord_c + cx;
+                            if (ord_c + cx < o_n) atomicOr(&st->error, 16u);   // the range's blocks did not hold its normals
+                        }
+                    }
+                }
+                s_req2 = ok ? ZC_NONE : req;
+            }
+            __syncthreads();
+            const unsigned req = s_req2;
+            if (req == ZC_NONE) break;
+            if ((unsigned)wave == (req >> 16)) {
+                unsigned kb, total, pp, cc;
+                block_chain(c, s_blk, inc, req & 0xffffu, kb, total, pp, cc, ZIG_ROWS, &st->error);
+                if (lane == 0) {
+                    s_patch[s_np] = make_uint2(req, (kb << 16) | total);
+                    s_np = s_np + 1;
+                }
+            }
+            __syncthreads();
+        }
+        // the next ticket is taken only now, behind this chunk's inclusive word: a ticket held by a workgroup that still
+        // waits in its look-back is a chunk nobody classifies, and every later chunk waits for its aggregate (taken one
+        // chunk ahead, the scan ran at 100 polls per chunk); here the atomic's latency hides behind the emission
+        if (threadIdx.x == 0) next = (long)atomicAdd(&head->ticket, 1u);
+        if (!s_skip)
+            block_emit(raw, c, tt, tv, G, C1, s_blk, inc, s_ent[wave], s_ord + s_off[wave], o_n, g,
+                       pos_base + (unsigned long long)b * ZIG_BLK, carry_out, L.wi, &st->error);
+#ifdef ZC_STATS
+        if (threadIdx.x == 0) {
+            const unsigned long long tD = __builtin_readcyclecounter();
+            atomicAdd(&head->cyc_classify, tB - tA);
+            atomicAdd(&head->cyc_lookback, tC - tB);
+            atomicAdd(&head->cyc_emit, tD - tC);
+            atomicAdd(&head->chunks, 1ull);
+        }
+#endif
+    }
+}
+
 __global__ void zig_debug_kernel(const ulonglong2 *blk_state, uint64_t i_hi, uint64_t i_lo, long b, uint64_t *out) {
     const u128 inc = mk128(i_hi, i_lo);
     const int lane = threadIdx.x & 63;
@@ -1101,8 +1630,8 @@ static void zig_debug_dump(corahip_ctx *ctx, const zig_round &rd, const uint64_t
                 he[i].x, he[i].y);
 }
 
-// ---- the stream in ranges (stream_internal.h): one round, its tables kept for the emit launches of the ranges -----------
-struct zig_session {
+// ---- the stream in ranges, two-pass form (the default; CORAHIP_ZIG_ONEPASS=1 takes the single pass below) ---------------
+struct zig2_session {
     zig_round rd;
     uint64_t state[2], inc[2];
     unsigned long long n = 0;
@@ -1112,10 +1641,10 @@ struct zig_session {
     int nr = 0;
 };
 
-int zig_stream_prepare(corahip_ctx *ctx, hipStream_t stream, const uint64_t state[2], const uint64_t inc[2], int64_t n,
-                       const std::vector<unsigned long long> &bounds, zig_session **out) {
+static int zig2_stream_prepare(corahip_ctx *ctx, hipStream_t stream, const uint64_t state[2], const uint64_t inc[2], int64_t n,
+                       const std::vector<unsigned long long> &bounds, zig2_session **out) {
     ARG_CHECK(n > 0 && bounds.size() >= 2 && bounds.front() == 0 && bounds.back() == (unsigned long long)n);
-    zig_session *s = new zig_session();
+    zig2_session *s = new zig2_session();
     s->n = (unsigned long long)n;
     s->bounds = bounds;
     s->nr = (int)bounds.size() - 1;
@@ -1148,7 +1677,7 @@ int zig_stream_prepare(corahip_ctx *ctx, hipStream_t stream, const uint64_t stat
     return 0;
 }
 
-int zig_stream_emit_range(corahip_ctx *ctx, hipStream_t stream, zig_session *s, int r, double *slot) {
+static int zig2_stream_emit_range(corahip_ctx *ctx, hipStream_t stream, zig2_session *s, int r, double *slot) {
     ARG_CHECK(s != nullptr && r >= 0 && r < s->nr && slot != nullptr);
     const unsigned long long o_lo = s->bounds[r], o_hi = s->bounds[r + 1];
     // one wave per block of ~1000 normals; the grid covers the range's blocks (+ slack: the loop strides, nothing is missed)
@@ -1161,7 +1690,7 @@ int zig_stream_emit_range(corahip_ctx *ctx, hipStream_t stream, zig_session *s, 
     return 0;
 }
 
-int zig_stream_finish(corahip_ctx *ctx, hipStream_t stream, zig_session *s, uint64_t *n_raw) {
+static int zig2_stream_finish(corahip_ctx *ctx, hipStream_t stream, zig2_session *s, uint64_t *n_raw) {
     ARG_CHECK(s != nullptr && n_raw != nullptr);
     zig_status hs;
     HIP_TRY(hipMemcpyAsync(&hs, s->rd.st, sizeof(hs), hipMemcpyDeviceToHost, stream));
@@ -1178,9 +1707,171 @@ int zig_stream_finish(corahip_ctx *ctx, hipStream_t stream, zig_session *s, uint
     return 0;
 }
 
-void zig_stream_free(zig_session *s) { delete s; }
+static void zig2_stream_free(zig2_session *s) { delete s; }
+
+
+// ---- the stream in ranges (stream_internal.h), single pass: every range is one memset + seek + chain launch ---------------
+struct zig_session {
+    zig2_session *two = nullptr;                 // the default (two-pass) form; NULL: CORAHIP_ZIG_ONEPASS=1
+    uint64_t state[2], inc[2];
+    unsigned long long n = 0;
+    std::vector<unsigned long long> bounds;      // [nr + 1] ordinals
+    int nr = 0;
+    long nblk_cap = 0;                           // blocks the tables hold (the largest range)
+    ulonglong2 *blk_state = nullptr;
+    zc_head *head = nullptr;                     // head | agg[nchunk] | inc[nchunk]: zeroed in front of every range
+    unsigned long long *agg = nullptr, *incw = nullptr, *carry = nullptr;   // carry[r] = raw position where range r starts
+    zig_status *st = nullptr;
+    size_t zero_bytes = 0;
+};
+// blocks of a range of `want` normals: 1.02145 raw draws per normal on average; the margin (0.13 % + two blocks) is
+// 85 sigma for a 1 GiB slot, more for smaller ranges; whole chunks
+static long zc_blocks(unsigned long long want) {
+    const long nblk = (long)((want + want / 44 + 2 * ZIG_BLK) / ZIG_BLK) + 1;
+    return (nblk + ZC_WAVES - 1) / ZC_WAVES * ZC_WAVES;
+}
+// The two-pass form is the default: measured at cfg 3 (HISTORY.md, round 6) the single pass takes 14.5 ms against 6.3 -
+// its work alone (look-back ablated) is 5.5 ms, and the chunks wait ~19 polls each for the aggregates of stragglers that
+// the LDS-bound run-ahead (768 chunks) cannot absorb.  CORAHIP_ZIG_ONEPASS=1 selects it (tests/test_gpu_npnormal.py runs both).
+static bool zig_two_pass() {
+    const char *e = getenv("CORAHIP_ZIG_ONEPASS");
+    return !(e && atoi(e) != 0);
+}
+
+int zig_stream_prepare(corahip_ctx *ctx, hipStream_t stream, const uint64_t state[2], const uint64_t inc[2], int64_t n,
+                       const std::vector<unsigned long long> &bounds, zig_session **out) {
+    ARG_CHECK(n > 0 && bounds.size() >= 2 && bounds.front() == 0 && bounds.back() == (unsigned long long)n);
+    zig_session *s = new zig_session();
+    if (zig_two_pass()) {
+        const int rc = zig2_stream_prepare(ctx, stream, state, inc, n, bounds, &s->two);
+        if (rc) {
+            delete s;
+            return rc;
+        }
+        *out = s;
+        return 0;
+    }
+    s->n = (unsigned long long)n;
+    s->bounds = bounds;
+    s->nr = (int)bounds.size() - 1;
+    for (int i = 0; i < 2; i++) {
+        s->state[i] = state[i];
+        s->inc[i] = inc[i];
+    }
+    unsigned long long widest = 0;
+    for (int r = 0; r < s->nr; r++) {
+        if (bounds[r + 1] <= bounds[r]) {
+            delete s;
+            corahip_set_error("normals_pcg64 (ranges): empty range %d", r);
+            return CORAHIP_EINVAL;
+        }
+        widest = std::max(widest, bounds[r + 1] - bounds[r]);
+    }
+    if (widest >= ZC_ORD_MASK / 2) {
+        delete s;
+        corahip_set_error("normals_pcg64 (ranges): a range of %llu normals is beyond the ordinal field of the scan", widest);
+        return CORAHIP_EINVAL;
+    }
+    s->nblk_cap = zc_blocks(widest);
+    const size_t nblk = (size_t)s->nblk_cap, nchunk = nblk / ZC_WAVES;
+    const size_t off_head = sizeof(ulonglong2) * nblk;
+    const size_t off_agg = off_head + sizeof(zc_head);
+    const size_t off_inc = off_agg + sizeof(unsigned long long) * nchunk;
+    const size_t off_carry = off_inc + sizeof(unsigned long long) * nchunk;
+    const size_t off_st = (off_carry + sizeof(unsigned long long) * (s->nr + 1) + 15) & ~(size_t)15;
+    char *ws = nullptr;
+    int rc = corahip_ctx_scratch(ctx, 6, off_st + sizeof(zig_status), (void **)&ws);
+    if (rc) {
+        delete s;
+        return rc;
+    }
+    s->blk_state = (ulonglong2 *)ws;
+    s->head = (zc_head *)(ws + off_head);
+    s->agg = (unsigned long long *)(ws + off_agg);
+    s->incw = (unsigned long long *)(ws + off_inc);
+    s->carry = (unsigned long long *)(ws + off_carry);
+    s->st = (zig_status *)(ws + off_st);
+    s->zero_bytes = off_carry - off_head;
+    // carry[0] = 0: the first range starts at the generator's position; the status word
+    hipError_t e = hipMemsetAsync(s->carry, 0, off_st + sizeof(zig_status) - off_carry, stream);
+    if (e != hipSuccess) {
+        delete s;
+        corahip_set_error("normals_pcg64 (ranges): memset failed: %s", hipGetErrorString(e));
+        return (int)e;
+    }
+    *out = s;
+    return 0;
+}
+
+int zig_stream_emit_range(corahip_ctx *ctx, hipStream_t stream, zig_session *s, int r, double *slot) {
+    ARG_CHECK(s != nullptr && slot != nullptr);
+    if (s->two) return zig2_stream_emit_range(ctx, stream, s->two, r, slot);
+    ARG_CHECK(r >= 0 && r < s->nr);
+    const unsigned long long o_n = s->bounds[r + 1] - s->bounds[r];
+    const long nblk = zc_blocks(o_n), nchunk = nblk / ZC_WAVES;
+    ARG_CHECK(nblk <= s->nblk_cap);
+    StageTimer t3(ctx, "zig_chain", stream, stream != ctx->stream);
+    HIP_TRY(hipMemsetAsync(s->head, 0, sizeof(zc_head) + 2 * sizeof(unsigned long long) * (size_t)(s->nblk_cap / ZC_WAVES), stream));
+    zig_seek_rel_kernel<<<(unsigned)((nblk + 255) / 256), 256, 0, stream>>>(s->state[0], s->state[1], s->inc[0], s->inc[1], s->carry + r,
+                                                                          nblk, s->blk_state);
+    LAUNCH_CHECK();
+    // tickets: a workgroup that is not resident yet has no chunk, so the grid may exceed what fits
+    const unsigned grid = (unsigned)std::max<long>(1, std::min<long>(nchunk, (long)ctx->num_cu * 4));
+    zig_chain_kernel<<<grid, ZC_WG, 0, stream>>>(s->blk_state, s->inc[0], s->inc[1], nchunk, s->head, s->agg, s->incw, s->carry + r,
+                                                s->carry + r + 1, o_n, slot, s->st);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int zig_stream_finish(corahip_ctx *ctx, hipStream_t stream, zig_session *s, uint64_t *n_raw) {
+    ARG_CHECK(s != nullptr && n_raw != nullptr);
+    if (s->two) return zig2_stream_finish(ctx, stream, s->two, n_raw);
+    zig_status hs;
+    unsigned long long last = 0;
+    HIP_TRY(hipMemcpyAsync(&hs, s->st, sizeof(hs), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipMemcpyAsync(&last, s->carry + s->nr, sizeof(last), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+#ifdef ZC_STATS
+    {
+        zc_head hh;
+        (void)hipMemcpy(&hh, s->head, sizeof(hh), hipMemcpyDeviceToHost);
+        const double nc = (double)std::max<unsigned long long>(1, hh.chunks);
+        fprintf(stderr, "zc stats (last range): chunks %llu polls/chunk %.2f folds/chunk %.3f distance %.1f | cycles per chunk (100 MHz clock): classify %.0f "
+                "lookback %.0f emit %.0f\n", hh.chunks, hh.polls / nc, hh.folds / nc, hh.dist / nc, hh.cyc_classify / nc, hh.cyc_lookback / nc,
+                hh.cyc_emit / nc);
+    }
+#endif
+#ifdef ZC_ABLATE
+    *n_raw = 1;
+    return 0;
+#endif
+    if (hs.error) {
+        corahip_set_error("normals_pcg64: device status %u (1 tail loop cap, 2 patch list full, 8 look-back gave up, 16 a range's raw blocks "
+                          "did not hold its normals)", hs.error);
+        return CORAHIP_ESTATE;
+    }
+    if (last == 0) {            // (nobody wrote the last sample: a range's blocks did not hold its normals - 85 sigma)
+        corahip_set_error("normals_pcg64: the raw range of a slot did not hold its normals (%llu counted in the last one)", hs.total);
+        return CORAHIP_ESTATE;
+    }
+    *n_raw = last;
+    return 0;
+}
+
+void zig_stream_free(zig_session *s) {
+    if (s && s->two) zig2_stream_free(s->two);
+    delete s;
+}
 
 extern "C" {
+
+int corahip_glibc_exp(corahip_ctx *ctx, const double *x, int64_t n, double *y) {
+    ARG_CHECK(ctx != nullptr && n >= 0 && (n == 0 || (x != nullptr && y != nullptr)));
+    if (n == 0) return 0;
+    glibc_exp_kernel<<<(unsigned)((n + 255) / 256), 256, 0, ctx->stream>>>(x, (long)n, y);
+    LAUNCH_CHECK();
+    return 0;
+}
 
 int corahip_pcg64_advance(const uint64_t state[2], const uint64_t inc[2], uint64_t delta, uint64_t out_state[2]) {
     ARG_CHECK(state != nullptr && inc != nullptr && out_state != nullptr);
@@ -1197,6 +1888,18 @@ int corahip_normals_pcg64(corahip_ctx *ctx, const uint64_t state[2], const uint6
     *n_raw = 0;
     if (n == 0) return 0;
     StageTimer timer(ctx, "normals_pcg64");
+    if (!zig_two_pass()) {                      // the whole stream as one range of the single-pass form
+        zig_session *s = nullptr;
+        int rc = zig_stream_prepare(ctx, ctx->stream, state, inc, n, std::vector<unsigned long long>{0ull, (unsigned long long)n}, &s);
+        if (rc) return rc;
+        rc = zig_stream_emit_range(ctx, ctx->stream, s, 0, g);
+        uint64_t raw = 0;
+        if (!rc) rc = zig_stream_finish(ctx, ctx->stream, s, &raw);
+        else (void)hipStreamSynchronize(ctx->stream);
+        zig_stream_free(s);
+        if (!rc) *n_raw = raw;
+        return rc;
+    }
     unsigned long long pos0 = 0, ord0 = 0;
     for (int round = 0; round < 64; round++) {
         zig_round rd;

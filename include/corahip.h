@@ -154,7 +154,8 @@ int corahip_normals_philox(corahip_ctx *ctx, uint64_t seed, int lmax, int F, dou
 /* The REFERENCE's own seeded stream on the device: the next n values of
  * numpy.random.Generator(PCG64).standard_normal - what `rng.standard_normal(shape)` of cora/util/nputil.py:121-125
  * returns for the `rng = default_rng(seed)` of cora/signal/lss.py:449-450 - bit for bit (fast-path and wedge samples
- * are one exact multiply; tail samples use glibc's log1p restated operation by operation), written to g[0..n) in draw
+ * are one exact multiply; tail samples use glibc's log1p, the wedge test glibc's exp, both restated operation by
+ * operation), written to g[0..n) in draw
  * order: with n = 2*F*nalm the "stream order" buffer draw_alm consumes.
  *   state, inc   host: the 128-bit PCG64 state and increment as {high 64 bits, low 64 bits}
  *                (rng.bit_generator.state["state"]["state" | "inc"])
@@ -165,6 +166,11 @@ int corahip_normals_philox(corahip_ctx *ctx, uint64_t seed, int lmax, int F, dou
  * 256-strip ziggurat of numpy/random/src/distributions/distributions.c; restated in oracle/npnormal.py. */
 int corahip_normals_pcg64(corahip_ctx *ctx, const uint64_t host_state[2], const uint64_t host_inc[2], int64_t n,
                           double *g, uint64_t *host_n_raw);
+/* Test hook of that stream's one libm call in the accept path: y[i] = exp(x[i]) as the wedge test of the ziggurat
+ * evaluates it on the device - glibc's table-driven exp (sysdeps/ieee754/dbl-64/e_exp.c) in the evaluation order of its
+ * FMA build, the libm numpy's random_standard_normal calls (reached from cora/util/nputil.py:125) - for |x| < 512.
+ * x, y device arrays; asynchronous on the context's stream.  tests/test_gpu_npnormal.py sweeps it against the host's exp. */
+int corahip_glibc_exp(corahip_ctx *ctx, const double *x, int64_t n, double *y);
 /* host arithmetic: the PCG64 state after `delta` steps (numpy's bit_generator.advance) */
 int corahip_pcg64_advance(const uint64_t host_state[2], const uint64_t host_inc[2], uint64_t delta,
                           uint64_t host_out_state[2]);

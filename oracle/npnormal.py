@@ -105,6 +105,65 @@ def glibc_log1p(x):
     return k * ln2_hi - ((hfsq - (s * (hfsq + R) + (k * ln2_lo + c))) - f)
 
 
+# ---- glibc's exp, FMA build (the wedge test of the ziggurat) -----------------------------------------------------------
+def _fma(a, b, c):
+    """fma(a, b, c) exactly rounded (python 3.10 has no math.fma): rational arithmetic, one rounding."""
+    from fractions import Fraction
+    return float(Fraction(a) * Fraction(b) + Fraction(c))
+
+
+_EXPTAB = None
+
+
+def glibc_exp_tables():
+    """(InvLn2N, Shift, NegLn2hiN, NegLn2loN, C[4], T[256] as ints) parsed from the include file the kernels are
+    compiled with (cora_amd/csrc/glibc_exp_tab.inc, written by tools/gen_glibc_exp_tab.py from the installed libm)."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "cora_amd", "csrc", "glibc_exp_tab.inc")
+    txt = open(path).read()
+    hx = r"-?0x[01]\.[0-9a-f]+p[+-]?\d+"
+    one = lambda name: float.fromhex(re.search(r"%s (%s)" % (name, hx), txt).group(1))
+    C = [float.fromhex(t) for t in re.findall(hx, re.search(r"GLIBC_EXP_C \{(.*)\}", txt).group(1))]
+    T = [int(t, 16) for t in re.findall(r"0x([0-9a-f]{16})ull", txt[txt.index("GLIBC_EXP_T"):])]
+    assert len(C) == 4 and len(T) == 256
+    return one("GLIBC_EXP_INVLN2N"), one("GLIBC_EXP_SHIFT"), one("GLIBC_EXP_NEGLN2HIN"), one("GLIBC_EXP_NEGLN2LON"), C, T
+
+
+def glibc_exp_fma(x):
+    """glibc's ``exp`` (sysdeps/ieee754/dbl-64/e_exp.c) for 2^-54 <= |x| < 512 - and the ``1 + x`` it returns below
+    that -, in the evaluation order of its FMA build (``__exp_fma``, what the loader selects on CPUs with FMA + AVX2 -
+    read off the installed libm's code): every fused operation below is fused there, every separate one separate.
+    cora_amd/csrc/npnormal.hip runs the same sequence (``glibc_exp_fma``) in the wedge test of numpy's ziggurat;
+    tests/test_oracle.py compares this with ``math.exp`` on the host."""
+    import struct
+
+    global _EXPTAB
+    if _EXPTAB is None:
+        _EXPTAB = glibc_exp_tables()
+    invln2n, shift, neghi, neglo, C, T = _EXPTAB
+    bits = struct.unpack("<Q", struct.pack("<d", x))[0]
+    abstop = (bits >> 52) & 0x7FF
+    if abstop < 0x3C9:                                  # |x| < 2^-54
+        return 1.0 + x
+    assert abstop < 0x408, "restated for |x| < 512 only"
+    kd = _fma(x, invln2n, shift)                        # z + Shift in one rounding
+    ki = struct.unpack("<Q", struct.pack("<d", kd))[0]
+    kd = kd - shift
+    r = _fma(kd, neglo, _fma(kd, neghi, x))
+    idx = 2 * (ki % 128)
+    top = (ki << 45) & 0xFFFFFFFFFFFFFFFF
+    tail = struct.unpack("<d", struct.pack("<Q", T[idx]))[0]
+    sbits = (T[idx + 1] + top) & 0xFFFFFFFFFFFFFFFF
+    p23 = _fma(r, C[1], C[0])
+    tr = r + tail
+    r2 = r * r
+    p45 = _fma(r, C[3], C[2])
+    t1 = _fma(p23, r2, tr)
+    r4 = r2 * r2
+    tmp = _fma(r4, p45, t1)
+    scale = struct.unpack("<d", struct.pack("<Q", sbits))[0]
+    return _fma(scale, tmp, scale)
+
+
 def tables():
     """(ki, wi, fi) parsed from the generated include file the kernels are compiled with."""
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "cora_amd", "csrc", "zig_tab.inc")

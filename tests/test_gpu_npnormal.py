@@ -54,6 +54,54 @@ def test_device_stream_is_numpys_over_1e8_samples(ctx):
     assert abs(dev.mean()) < 5e-4 and abs(dev.std() - 1.0) < 5e-4
 
 
+def test_device_exp_of_the_wedge_test_is_the_hosts_exp(ctx):
+    """The wedge test of numpy's ziggurat compares against libm's exp(-x^2 / 2) (random_standard_normal, reached from
+    cora/util/nputil.py:125); a last-bit difference at the threshold would flip an accept and shift every later sample.
+    The device runs glibc's routine operation by operation (glibc_exp_fma): 1.2e7 arguments - the wedge test's own
+    arguments -x^2 / 2 for x across the ziggurat, a dense sweep of [-6.7, 0), neighbours of every reduction boundary
+    k ln2 / 128, tiny arguments - against numpy's exp on the host, bit for bit.  Skipped where the host's libm is not
+    glibc's FMA build (tests/test_oracle.py pins the same restatement on the CPU)."""
+    import math
+
+    from oracle import npnormal
+
+    probe = [-0.5, -6.6, -1e-3, -3.21, -0.6931471805599453, -2.0**-30, -5.0]
+    if not all(npnormal.glibc_exp_fma(x) == math.exp(x) for x in probe):
+        pytest.skip("this host's exp is not glibc's FMA build")
+    rs = np.random.default_rng(5)
+    xw = ZIG_R * rs.random(5_000_000)
+    parts = [-0.5 * xw * xw, -6.7 * rs.random(5_000_000), -rs.random(500_000) * 2.0 ** (-rs.integers(1, 60, 500_000).astype(np.float64))]
+    kb = -(np.arange(1300) + 0.5) * (math.log(2.0) / 128.0)
+    parts.append(np.concatenate([np.nextafter(kb, 0.0), kb, np.nextafter(kb, -10.0)] * 400) + 0.0)
+    parts.append(np.array([-2.0**-54, -2.0**-55, -0.0, 0.0, -6.7, -2.0**-53]))
+    x = np.concatenate(parts)
+    assert x.size > 12_000_000
+    y = ctx.glibc_exp(ctx.to_device(x)).cpu().numpy()
+    ref = np.exp(x)
+    if not np.array_equal(np.array([math.exp(v) for v in x[:2000]]), ref[:2000]):
+        ref = np.array([math.exp(v) for v in x])          # (numpy's vectorised exp is not libm's on this host: take libm's)
+    assert np.array_equal(y.view(np.uint64), ref.view(np.uint64)), int((y != ref).sum())
+
+
+@pytest.mark.parametrize("n", [1, 65, 1024, 4097, 100003, 3 * 4096 * 64 + 5, 30_000_011])
+def test_single_pass_form_is_numpys_too(ctx, monkeypatch, n):
+    """The round-6 single pass (classify + chained scan with decoupled look-back + emit in ONE launch,
+    CORAHIP_ZIG_ONEPASS=1: slower than the two-pass default, kept as the measured alternative) produces the same
+    stream: sizes around its row / block / chunk (4 blocks) / look-back window (64 chunks) boundaries and 3e7 samples
+    (4e3 blocks handing k >= 2 across a boundary: the request path inside a chunk and the wait across chunks)."""
+    monkeypatch.setenv("CORAHIP_ZIG_ONEPASS", "1")
+    rng = np.random.default_rng(77 + n)
+    rng.standard_normal(n % 41)
+    dev, state_after = _device_stream(ctx, rng, n)
+    ref = rng.standard_normal(n)
+    same = dev.view(np.uint64) == ref.view(np.uint64)
+    if not same.all():      # (a libm other than glibc: tail samples only, one ulp at most - as above)
+        bad = np.flatnonzero(~same)
+        ulp = np.abs(dev.view(np.int64)[bad] - ref.view(np.int64)[bad])
+        assert np.all(np.abs(ref[bad]) > ZIG_R) and ulp.max() <= 1, (bad[:5], ulp.max())
+    assert state_after == int(rng.bit_generator.state["state"]["state"])
+
+
 @pytest.mark.parametrize("F,lmax", [(5, 33), (8, 64), (40, 200)])
 def test_stream_normals_order_and_generator_state(ctx, F, lmax):
     """skysim.stream_normals = the reference's draw order (per l: F (l + 1) reals, then the imaginaries; nputil.py:121-125)
@@ -262,6 +310,18 @@ def _factors(ctx, F, lmax, seed):
                                                     (136, 260, 0, 136, 3000), (256, 300, 64, 64, 5000),
                                                     (256, 300, 192, 64, 1 << 20), (40, 90, 8, 16, 100), (7, 33, 2, 5, 10)])
 def test_pcg64_stream_in_l_ranges_equals_the_full_buffer(ctx, F, lmax, nu0, nnu, ring_kb):
+    _check_pcg64_ranges(ctx, F, lmax, nu0, nnu, ring_kb)
+
+
+@pytest.mark.parametrize("F,lmax,nu0,nnu,ring_kb", [(8, 40, 0, 8, 1), (72, 150, 0, 72, 700), (256, 300, 64, 64, 5000)])
+def test_pcg64_stream_in_l_ranges_single_pass_form(ctx, monkeypatch, F, lmax, nu0, nnu, ring_kb):
+    """The ranged pipeline on the single-pass generator (CORAHIP_ZIG_ONEPASS=1): every range is its own launch that starts
+    at the raw position the previous one left on the device (no whole-stream count pass), ranges down to one l."""
+    monkeypatch.setenv("CORAHIP_ZIG_ONEPASS", "1")
+    _check_pcg64_ranges(ctx, F, lmax, nu0, nnu, ring_kb)
+
+
+def _check_pcg64_ranges(ctx, F, lmax, nu0, nnu, ring_kb):
     """corahip_draw_alm_numpy (numpy's PCG64 stream emitted one range of multipoles at a time into a two-slot ring, K3
     consuming range by range) against normals_pcg64 + draw_alm on the whole stream: the a_lm bit for bit, the generator
     state after, for ring sizes that put the range edges anywhere inside the generator's 1024-position blocks (1 KB:

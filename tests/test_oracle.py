@@ -698,6 +698,31 @@ def test_glibc_log_restatement_is_the_hosts_log():
         assert abs(math.log(1.0 / T[2 * i]) - T[2 * i + 1]) < 1e-9
 
 
+def test_glibc_exp_restatement_is_the_hosts_exp():
+    """oracle.npnormal.glibc_exp_fma - glibc's table-driven exp in the evaluation order of its FMA build, the sequence
+    cora_amd/csrc/npnormal.hip runs in the wedge test of numpy's ziggurat (numpy/random/src/distributions/distributions.c
+    ``random_standard_normal``, reached from cora/util/nputil.py:125) - against math.exp (the libm numpy calls) on this
+    host: the wedge test's whole argument range -x^2 / 2 in [-6.7, 0), every table index, tiny arguments.  Skipped where
+    the host's libm is another routine (no FMA, another libc)."""
+    import math
+    import random
+
+    from oracle import npnormal
+
+    probe = [-0.5, -6.6, -1e-3, -3.21, -0.6931471805599453, -2.0**-30, -5.0]
+    if not all(npnormal.glibc_exp_fma(x) == math.exp(x) for x in probe):
+        pytest.skip("this host's exp is not glibc's FMA build")
+    random.seed(12)
+    xs = [-6.7 * random.random() for _ in range(8000)] + [-random.random() * 2.0 ** (-random.randint(1, 60)) for _ in range(1500)]
+    xs += [-0.5 * (3.6541528853610088 * random.random()) ** 2 for _ in range(2000)] + [-(k + 0.5) * math.log(2.0) / 128.0 for k in range(1300)]
+    xs += [-2.0**-54, -2.0**-55, -0.0, 0.0]
+    bad = [x for x in xs if npnormal.glibc_exp_fma(x) != math.exp(x)]
+    assert not bad, bad[:5]
+    invln2n, shift, neghi, neglo, C, T = npnormal.glibc_exp_tables()
+    assert abs(invln2n * math.log(2.0) - 128.0) < 1e-12 and shift == 1.5 * 2.0**52 and abs(C[0] - 0.5) < 1e-12
+    assert T[0] == 0 and T[1] == 0x3FF0000000000000
+
+
 # ------------------------------------------------------------------ EoR21cm (cora/signal/corr21cm.py:333-385)
 @pytest.fixture(scope="module")
 def eor_golden():

@@ -1,6 +1,7 @@
 """GPU probe of corahip_normals_pcg64: the device stream against numpy's own Generator, and its timing.
 
 usage: python tools/npnormal_probe.py [n ...]      (default: a ladder of sizes up to 2e8)
+CORAHIP_ZIG_ONEPASS=1: the round-6 single-pass form (stage zig_chain) instead of the two-pass default; ZIG_TIME_ONLY=1: timing only.
 """
 import os
 import sys
@@ -64,7 +65,7 @@ def main():
     for _ in range(reps):
         ctx.normals_pcg64(st["state"], st["inc"], n, out=g)
     print("  per kernel (ms): " + ", ".join("%s %.3f" % (k, ctx.profile_get(k)[0] / reps)
-                                          for k in ("zig_seek", "zig_count", "zig_scan", "zig_emit", "normals_pcg64")))
+                                          for k in ("zig_seek", "zig_count", "zig_scan", "zig_emit", "zig_chain", "normals_pcg64")))
     ctx.profile_enable(False)
     print("ALL OK" if ok else "FAILED")
     return 0 if ok else 1

@@ -13,7 +13,7 @@ F, nside, lmax = 256, 1024, 2048
 freq = 400.0 + (np.arange(F) + 0.5) * (400.0 / F)
 sh = SkyShard(corr21cm.Corr21cm(), freq, nside, lmax, zromb=3, ctx=ctx)
 nrep = int(sys.argv[1]) if len(sys.argv) > 1 else 5
-names = ("clarray", "factor", "zig_seek", "zig_count", "zig_scan", "zig_emit", "mt_jump", "mt_count", "mt_emit", "draw", "legendre", "ringfft")
+names = ("clarray", "factor", "zig_seek", "zig_count", "zig_scan", "zig_emit", "zig_chain", "mt_jump", "mt_count", "mt_emit", "draw", "legendre", "ringfft")
 rng = np.random.default_rng(1)
 np.random.seed(2)
 st0 = np.random.default_rng(9).bit_generator.state["state"]
