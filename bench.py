@@ -49,6 +49,7 @@ MIN_RANKS = {"cfg5": 8}        # workloads that do not fit fewer GPUs: emulate o
 
 FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X vendor spec; profiles/mfma_f64_probe_r01.txt measures 77.4
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md
+L2_PEAK_GBS = 34500.0          # MI355X_MICROARCH.md: L2 (per XCD, aggregate) ~34.5 TB/s
 
 
 def build_model(name):
@@ -137,13 +138,25 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29655")
+        if "MASTER_PORT" not in os.environ:       # (one rank forced through the group: any free port, runs may follow each other closely)
+            import socket
+
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        if args.dist_backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(args.dist_backend)
+        # a rendezvous or a collective that does not complete ends the job - non-zero exit, the stage named - instead of
+        # hanging it: torch's watchdog through `timeout`, and the stage guard of cora_amd.parallel (CORA_DIST_TIMEOUT_S)
+        from cora_amd import parallel as _par
+
+        _par.start_watchdog(rank, world)
+        with _par.exchange_stage("init_process_group (%s rendezvous at %s:%s)" % (args.dist_backend, os.environ["MASTER_ADDR"],
+                                                                                  os.environ["MASTER_PORT"])):
+            if args.dist_backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=_par.dist_timeout())
+            else:
+                dist.init_process_group(args.dist_backend, timeout=_par.dist_timeout())
 
     comps, F, nu_lo, nu_hi, nside, lmax = WORKLOADS[args.workload]
     model_name = "+".join(c[0] for c in comps)
@@ -154,6 +167,21 @@ def main():
     from cora_amd.parallel import SkyShard, SkySum
 
     ranks_seen = dist.get_world_size() if dist is not None else 1
+    # which GPU every rank really sits on: (rank, device index, name, uuid / PCI id) gathered to rank 0 - the line then shows
+    # N DISTINCT devices, or says that ranks share one (--same-device test hook)
+    def device_id_string():
+        pr = torch.cuda.get_device_properties(torch.cuda.current_device())
+        ident = getattr(pr, "uuid", None)
+        pci = "%04x:%02x:%02x" % (getattr(pr, "pci_domain_id", 0), getattr(pr, "pci_bus_id", 0), getattr(pr, "pci_device_id", 0))
+        return "rank %d: cuda:%d %s uuid=%s pci=%s" % (rank, torch.cuda.current_device(), pr.name, ident, pci)
+
+    rank_devices = [device_id_string()]
+    if dist is not None:
+        gathered = [None] * ranks_seen
+        with _par.exchange_stage("all_gather_object of the ranks' device ids"):
+            dist.all_gather_object(gathered, rank_devices[0])
+        rank_devices = gathered
+    distinct_devices = len({d.split(" ", 3)[3] for d in rank_devices})
     if world < MIN_RANKS.get(args.workload, 1) and args.emulate_shard <= 1:
         if world != 1:
             raise SystemExit("%s needs %d ranks (or 1 rank emulating one of them)" % (args.workload, MIN_RANKS[args.workload]))
@@ -165,8 +193,11 @@ def main():
 
     def barrier():
         if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
+            with _par.exchange_stage("barrier + device synchronisation (everything enqueued before it)", sync=False):
+                dist.barrier()
+                torch.cuda.synchronize()
+        else:
+            torch.cuda.synchronize()
 
     def measure(emulate_rank):
         """Build the rank's pipeline object (untimed: everything the timed region reads is put in HBM - tables, plan,
@@ -236,10 +267,20 @@ def main():
                           "fold": bool(args.fold),
                           "note": "one GPU doing the share of each of %d ranks in turn, exchanges excluded: unmeasured on "
                                   "multi-GPU hardware" % args.emulate_shard}
+        emulated_ranks["exchange_model"] = exchange_model(comps, F, L, args.emulate_shard, args.sum_mode, crit["ms_per_step"])
         if crit["rank"] != args.emulate_shard - 1:
-            del keep
+            # (both names dropped: two resident rank pipelines would be an OOM risk at cfg 5)
+            del m, keep
             torch.cuda.empty_cache()
             keep = measure(crit["rank"])
+            # one number per rank in the line: the critical rank's entry IS the run the headline is taken from
+            redo = {"rank": crit["rank"], "ms_per_step": keep["dt"] / args.steps * 1e3, "channels": [list(c) for c in keep["shard"].chunks],
+                    "stages_ms": {k: round(v["ms_per_step"], 3) for k, v in keep["stages"].items()}}
+            runs[crit["rank"]] = redo
+            emulated_ranks["per_rank_ms"] = [round(x["ms_per_step"], 3) for x in runs]
+            emulated_ranks["critical_path_ms"] = redo["ms_per_step"]
+            emulated_ranks["job_maps_per_s_no_exchange"] = F / (redo["ms_per_step"] * 1e-3)
+            emulated_ranks["exchange_model"] = exchange_model(comps, F, L, args.emulate_shard, args.sum_mode, redo["ms_per_step"])
         m = keep
     else:
         m = measure(args.emulate_rank)
@@ -284,6 +325,17 @@ def main():
             host_delivered = host_delivered_rate(ctx, shard, nside, F, npix)
         except Exception as e:      # (e.g. a box that cannot page-lock 80 GB): the leg is extra, the headline must not die with it
             host_delivered = {"skipped": "%s: %s" % (type(e).__name__, e)}
+            torch.cuda.synchronize()
+
+    # the literal drop-in call: what a cora user sees from ONE `skysim.mkfullsky(C_numpy, nside, rng=default_rng(s))`
+    # (cora/core/skysim.py:72-136; the second half of Sky3d.getsky(), cora/core/maps.py:227-237) - H2D of the 1.07 GB
+    # C_l, factor + seeded draw + synthesis, D2H of the 25.8 GB of maps into a fresh numpy array.  Outside the timed region.
+    drop_in = None
+    if rank == 0 and world == 1 and args.emulate_shard <= 1 and len(comps) == 1 and not (args.no_host_delivered or args.checksum or args.warm):
+        try:
+            drop_in = drop_in_call(build_model(comps[0][0]), freq, nside, lmax, zromb, F, npix)
+        except Exception as e:      # (extra leg: the headline must not die with it)
+            drop_in = {"skipped": "%s: %s" % (type(e).__name__, e)}
             torch.cuda.synchronize()
 
     # sanity: the maps of the last step are finite and have the expected variance scale
@@ -357,6 +409,8 @@ def main():
             "unit": "maps/s",
             "n_gpus": world,
             "ranks_seen": ranks_seen,
+            "rank_devices": rank_devices,
+            "distinct_devices": distinct_devices,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": ms_step,
@@ -386,6 +440,7 @@ def main():
                 "warm_path": None if warm_ms is None else {"ms_per_step": warm_ms, "maps_per_s": F / (warm_ms * 1e-3)},
                 "setup_s": t_setup,
                 "host_delivered": host_delivered,
+                "drop_in_call": drop_in,
                 "seeded_numpy_mode": seeded_numpy,
                 "legacy_rng_mode": legacy_rng,
             },
@@ -437,13 +492,46 @@ def main():
     return result
 
 
+def exchange_model(comps, F, L, N, sum_mode, critical_ms):
+    """A MODELLED cost of the two exchange steps of an N-rank step (cora_amd/parallel.py; the counterpart of the
+    reference's allgather / redistribute, cora/core/skysim.py:97-134), to stand next to the exchange-free emulated
+    critical path - nothing here is measured.  Bytes one rank SENDS:
+      all-to-all #1  its pair shard of every table component's C_l, cut by destination multipole shard:
+                     8 (F (F + 1) / 2 / N) L (N - 1) / N per component that is integrated per pair
+      all-to-all #2  the factor row blocks of the other ranks' channels: 8 (L / N) F^2 (N - 1) / N per factored component
+                     (joint mode: the one summed covariance)
+    xGMI is point to point, one link per peer (MI355X: 7 links of ~153 GB/s peak each way): the N - 1 messages of a rank go
+    out in parallel, each over its own link, so the time of an exchange is (bytes sent / (N - 1)) / link rate + a launch
+    latency.  Two link rates bracket it: 50 GB/s (small messages, protocol overhead) and 150 GB/s (peak); latency 50 us per
+    collective (RCCL launch + synchronisation), all stated in the record."""
+    kinds = ["table" if m == "21cm" else "separable" for m, _ in comps]
+    joint = len(comps) > 1 and sum_mode == "joint"
+    ntab = sum(1 for k in kinds if k == "table")
+    nfac = 1 if joint else ntab           # components factored per l (a separable one is factored once, on every rank)
+    a2a1 = ntab * 8.0 * (F * (F + 1) / 2.0 / N) * L * (N - 1) / N
+    a2a2 = nfac * 8.0 * (L / float(N)) * F * F * (N - 1) / N
+    lat_ms = 0.05
+    out = {"modelled": True, "bytes_sent_per_rank": {"all_to_all_pair_slabs": a2a1, "all_to_all_factor_rows": a2a2},
+           "links_per_rank": N - 1, "link_GBs_bracket": [50.0, 150.0], "latency_ms_per_collective": lat_ms,
+           "note": "modelled, not measured: (bytes sent / (N - 1) links) / link rate + latency per exchange; RCCL over xGMI has never "
+                   "run with more than one rank on this pool"}
+    ms = []
+    for rate in (50.0, 150.0):
+        t = sum((b / max(N - 1, 1)) / (rate * 1e9) * 1e3 + (lat_ms if b else 0.0) for b in (a2a1, a2a2))
+        ms.append(t)
+    out["exchange_ms_bracket"] = [ms[1], ms[0]]
+    out["critical_path_ms_with_exchange_bracket"] = [critical_ms + ms[1], critical_ms + ms[0]]
+    return out
+
+
 def stage_work(comps, F, nside, lmax, nnu, nu0, nranks, sum_mode, legendre_executed_flops, channels=None):
     """Algorithmic work of ONE RANK per step, per stage: {stage: (bound, flops, bytes, note)} (DESIGN
     section 3).  `comps` = [(model name, zromb)], `nranks` = ranks the work is cut over (the world size, or the N of
     --emulate-shard N), channels [nu0, nu0 + nnu) are this rank's.
-      clarray   pair-sharded: F (F + 1) / 2 / nranks channel pairs x zint^2 sub-sample pairs x L multipoles x a NOMINAL 60
-                flop per evaluation of the table model (interpolations + prefactors; not an executed-instruction count);
-                separable components cost an outer product (no flops counted), bytes = the C_l rows written
+      clarray   pair-sharded: F (F + 1) / 2 / nranks channel pairs x zint^2 sub-sample pairs; its roof is the L2 -> CU traffic
+                of the profile build (6 table values per k_perp row and sub-sample pair), priced against the L2 peak; the
+                NOMINAL 60 flop per evaluation of the table model stay in the record as TFLOPs but are no fraction of
+                anything; separable components cost an outer product: bytes = the C_l rows written, HBM bound
       factor    l-sharded: L / nranks blocks of F^3 / 3 for every component that is factored per l (the table model; the
                 summed covariance in joint mode); a separable component is ONE F^3 / 3 (its root serves every l)
       draw      triangular factors: channel nu takes nu + 1 columns, re and im: 4 nalm sum_{nu in the shard} (nu + 1) flop
@@ -453,11 +541,18 @@ def stage_work(comps, F, nside, lmax, nnu, nu0, nranks, sum_mode, legendre_execu
     nalm = L * (L + 1) // 2
     npix = 12 * nside * nside
     kinds = ["table" if m == "21cm" else "separable" for m, _ in comps]
-    k1_flops = k1_bytes = 0.0
+    k1_flops = k1_bytes = k1_l2 = 0.0
+    # table rows of the k_perp axis a profile spans: x = log10(l) 499 / log10(4e5) puts 89.07 rows in a decade of l; the
+    # first 25 multipoles are more than two rows apart and get their two rows each, the dense range runs from l = 25 on
+    rows = 2.0 * min(25, L) + 89.07 * np.log10(max(lmax, 25) / 25.0)
     for (m, z), kind in zip(comps, kinds):
         zint = 2**z + 1 if z else 1
         if kind == "table":
             k1_flops += 60.0 * L * (F * (F + 1) / 2.0 / nranks) * zint * zint
+            # L2 -> CU bytes of the profile build: every sub-sample pair reads its two k_par columns of three tables on
+            # every row (6 values of 8 bytes; cfg 3: 2.66e6 sub-sample pairs x 220 rows x 48 B = 28 GB, the figure the
+            # ablations and the TCP counters of round 5 gave)
+            k1_l2 += (F * (F + 1) / 2.0 / nranks) * zint * zint * rows * 48.0
         k1_bytes += 8.0 * L * F * F / nranks
     joint = len(comps) > 1 and sum_mode == "joint"
     per_l = 1 if joint else sum(1 for k in kinds if k == "table")
@@ -469,7 +564,9 @@ def stage_work(comps, F, nside, lmax, nnu, nu0, nranks, sum_mode, legendre_execu
     k3_flops = ndraw * 4.0 * nalm * (nnu * (nu0 + 0.5 * (nnu + 1)) if channels is None else float(sum(int(c) + 1 for c in channels)))
     k3_bytes = ndraw * (8.0 * L * F * nnu + 16.0 * nalm * nnu)
     return {
-        "clarray": ("valu", k1_flops, k1_bytes, "nominal 60 flop per table evaluation; pairs of this rank only"),
+        "clarray": ("l2" if k1_l2 else "hbm", k1_flops, k1_l2 if k1_l2 else k1_bytes,
+                    "bound by the table reads of the profile build (L2 -> CU bytes by the model of bench.stage_work, 28 GB at cfg 3); "
+                    "TFLOPs is a NOMINAL 60 flop per table evaluation, never a fraction; pairs of this rank only"),
         "factor": ("valu", k2_flops, k2_bytes, "multipoles of this rank only"),
         "draw": ("mfma", k3_flops, k3_bytes, "rows of this rank's channels; %d draw(s) per step" % ndraw),
         "legendre": ("mfma", legendre_executed_flops, 16.0 * nalm * nnu + 16.0 * (4 * nside - 1) * L * nnu, "executed MFMAs"),
@@ -488,11 +585,16 @@ def stage_rooflines(stages, comps, F, nside, lmax, nnu, nu0, nranks, sum_mode, l
             continue
         sec = stages[k]["ms_per_step"] * 1e-3
         e = {"ms": stages[k]["ms_per_step"], "bound": bound, "TFLOPs": flops / sec / 1e12, "GBs": nbytes / sec / 1e9}
-        e["frac"] = e["GBs"] / HBM_PEAK_GBS if bound == "hbm" else e["TFLOPs"] / FP64_MFMA_PEAK_TFLOPS
+        if bound == "hbm":
+            e["frac"] = e["GBs"] / HBM_PEAK_GBS
+        elif bound == "l2":                   # K1: table bytes through the L2s against their aggregate peak
+            e["peak_GBs"] = L2_PEAK_GBS
+            e["frac"] = e["GBs"] / L2_PEAK_GBS
+            e["nominal_TFLOPs"] = e.pop("TFLOPs")   # (60 flop per evaluation by convention: may exceed the FP64 peak, prices nothing)
+        else:
+            e["frac"] = e["TFLOPs"] / FP64_MFMA_PEAK_TFLOPS
         if note:
             e["work"] = note
-        if k == "clarray":
-            e["frac_is_nominal"] = True       # a nominal flop count over the FP64 peak, not a measured VALU utilisation
         out[k] = e
     return out
 
@@ -601,6 +703,44 @@ def host_delivered_rate(ctx, shard, nside, F, npix, nrep=4):
     return {"maps_per_s": F * n / dt, "GB_per_s": F * n * npix * 8 / dt / 1e9, "realisations": n,
             "warmup_s_incl_page_locking": t_first, "finite": bool(np.isfinite(chk)),
             "path": "skysim.mkfullsky_stream: device Philox draw + synthesis, pinned double-buffered D2H on a copy stream"}
+
+
+def drop_in_call(model, freq, nside, lmax, zromb, F, npix):
+    """Wall seconds of the reference's own call forms, numpy in / numpy out, as a cora user would type them
+    (cora/core/maps.py:227-237: ``cla = skysim.clarray(aps, lmax, freqs, zromb)``; ``skysim.mkfullsky(cla, nside, rng)``):
+    ``clarray`` (K1 + 1.07 GB to the host), then the FIRST and a LATER ``mkfullsky(C_numpy, nside, rng=default_rng(s))``
+    (1.07 GB up, K2 + numpy's PCG64 stream + K3 + K4 + K5 on the device, 25.8 GB down into a new ndarray; the first call
+    also grows the library's workspaces).  PCIe- and page-fault-bound, never `value`."""
+    import torch
+
+    from cora_amd.core import skysim
+
+    need = 1.15 * F * npix * 8
+    try:
+        avail = [int(l.split()[1]) * 1024 for l in open("/proc/meminfo") if l.startswith("MemAvailable")][0]
+    except Exception:
+        avail = 0
+    if avail < need + 16e9:
+        return {"skipped": "host has %.0f GB available, one returned realisation needs %.0f GB" % (avail / 1e9, need / 1e9)}
+    torch.cuda.synchronize()
+    t0 = time.time()
+    cla = skysim.clarray(model.angular_powerspectrum, lmax, freq.copy(), zromb=zromb)
+    t_cla = time.time() - t0
+    times = []
+    chk = 0.0
+    for s in (11, 12, 13):
+        rng = np.random.default_rng(s)
+        t0 = time.time()
+        sky = skysim.mkfullsky(cla, nside, rng=rng)
+        times.append(time.time() - t0)
+        chk += float(sky[0, 0]) + float(sky[-1, -1])
+        assert sky.shape == (F, npix) and isinstance(sky, np.ndarray)
+        del sky
+    return {"clarray_s": t_cla, "mkfullsky_first_s": times[0], "mkfullsky_later_s": min(times[1:]), "maps_per_s_later": F / min(times[1:]),
+            "GB_returned": F * npix * 8 / 1e9, "finite": bool(np.isfinite(chk)),
+            "call": "skysim.clarray(Corr21cm().angular_powerspectrum, lmax, freqs, zromb) -> ndarray; skysim.mkfullsky(ndarray[L,F,F], "
+                    "nside, rng=numpy.random.default_rng(s)) -> ndarray[F,npix]: H2D + factor + seeded draw + synthesis + D2H "
+                    "into a page-locked block the returned ndarray views"}
 
 
 def cpu_baseline(model_name, F, freq, nside, lmax, zromb):

@@ -109,7 +109,10 @@ SIGNATURES = {
 
 
 class CoraHipError(RuntimeError):
-    """An entry point of libcorahip.so returned a non-zero status."""
+    """An entry point of libcorahip.so returned a non-zero status (``status``: <0 a CORAHIP_E* code of include/corahip.h,
+    >0 a hipError_t)."""
+
+    status = 0
 
 
 _lib = None
@@ -156,7 +159,9 @@ def pcg64_advance(state, inc, delta):
 def _check(rc):
     if rc != 0:
         msg = load().corahip_last_error()
-        raise CoraHipError("libcorahip status %d: %s" % (rc, msg.decode() if msg else "?"))
+        err = CoraHipError("libcorahip status %d: %s" % (rc, msg.decode() if msg else "?"))
+        err.status = int(rc)
+        raise err
 
 
 def _torch():

@@ -249,8 +249,12 @@ def draw_numpy_stream(ctx, T, info, rng, maxl, numz, nu0=0, nnu=None, out=None, 
     defer : return ``(alm, finish)``: the draw is only ENQUEUED; ``finish()`` - to be called after the caller has
         enqueued what follows, e.g. the synthesis - waits for the queue and writes the generator's state back (the
         generator's lock is held until then).  Default: ``alm``, generator already updated.
-    A device-side failure of the generator (its margins are > 100 sigma) falls back to the host stream with the
-    caller's generator untouched."""
+    Errors: a call the generator's set-up refuses as a STATE error (``CORAHIP_ESTATE``: e.g. a draw still pending on the
+    context) is redone on the host stream with the caller's generator untouched; invalid shapes (``CORAHIP_EINVAL``), a
+    ring that cannot be allocated (``CORAHIP_ENOMEM``) and HIP errors are raised as they are - the host path would
+    materialise the whole 16 F nalm byte stream and hide them.  A status the device generator flags while it runs (a
+    margin of > 85 sigma exceeded) is read back at the end: ``finish()`` then raises, the a_lm of that call are not to
+    be used and the generator is left untouched."""
     if chunks is not None:
         rows, nu0, nnu = True, chunks[0][0], sum(c[1] for c in chunks)
     nnu = numz if nnu is None else nnu
@@ -296,8 +300,10 @@ def draw_numpy_stream(ctx, T, info, rng, maxl, numz, nu0=0, nnu=None, out=None, 
             st = bg.state
             spec = ("pcg64", int(st["state"]["state"]), int(st["state"]["inc"]))
         alm, fin = ctx.draw_alm_numpy(T, info, spec, maxl, numz, nu0=nu0, nnu=nnu, out=out, rows=rows, defer=True, chunks=chunks)
-    except _lib.CoraHipError:
+    except _lib.CoraHipError as e:
         lock.release()
+        if e.status != -3:                                 # only CORAHIP_ESTATE is a reason to take the host stream
+            raise
         return done(host_path())
     except BaseException:
         lock.release()

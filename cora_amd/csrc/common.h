@@ -58,6 +58,10 @@ struct corahip_ctx {
     bool mt_plist_ready = false;                   // scratch slot 9 holds the position lists (mtlegacy.hip)
     hipStream_t gen_stream = nullptr;
     hipEvent_t ev_ring[8] = {};
+    // the session of corahip_draw_alm_numpy_begin that has not seen its _end yet: its generator tables (scratch slot 6)
+    // and ring (slot 7) are in use by queued launches, so a second _begin and the whole-stream generators
+    // (corahip_normals_pcg64 / _mt19937_legacy, which share slot 6) return CORAHIP_ESTATE until _end has run
+    const void *draw_pending = nullptr;
     hipEvent_t t0 = nullptr, t1 = nullptr;
     bool profile = false;
     std::map<std::string, corahip_prof_entry> prof;

@@ -54,6 +54,11 @@ static int draw_numpy_begin(corahip_ctx *ctx, const double *T, int rows, const i
     ARG_CHECK(rng->kind == CORAHIP_RNG_PCG64 || rng->kind == CORAHIP_RNG_MT19937);
     ARG_CHECK(rng->kind != CORAHIP_RNG_MT19937 || rng->legacy != nullptr);
     *pending = nullptr;
+    if (ctx->draw_pending) {
+        corahip_set_error("draw_alm_numpy_begin: the previous session has not been ended (corahip_draw_alm_numpy_end): its "
+                          "generator tables and ring are still in use");
+        return CORAHIP_ESTATE;
+    }
     int rc = ring_setup(ctx);
     if (rc) return rc;
     const unsigned long long total = (unsigned long long)F * (lmax + 1) * (lmax + 2);
@@ -147,6 +152,7 @@ static int draw_numpy_begin(corahip_ctx *ctx, const double *T, int rows, const i
     }
     // (the last draw waited for the last emit: everything of the generator stream is behind the context stream's tail)
     *pending = pd;
+    ctx->draw_pending = pd;
     return 0;
 }
 
@@ -168,6 +174,7 @@ int corahip_draw_alm_numpy_begin_set(corahip_ctx *ctx, const double *T_rows, con
 
 int corahip_draw_alm_numpy_end(corahip_ctx *ctx, corahip_draw_pending *pd, corahip_rng *rng) {
     ARG_CHECK(ctx != nullptr && pd != nullptr && rng != nullptr);
+    ARG_CHECK(ctx->draw_pending == pd);
     int rc;
     if (pd->zs) {
         uint64_t n_raw = 0, after[2];
@@ -181,6 +188,7 @@ int corahip_draw_alm_numpy_end(corahip_ctx *ctx, corahip_draw_pending *pd, corah
         rc = rng->legacy ? mt_stream_finish(ctx, ctx->stream, pd->ms, rng->legacy) : CORAHIP_EINVAL;
     }
     if (rc) (void)hipStreamSynchronize(ctx->gen_stream);
+    ctx->draw_pending = nullptr;
     pending_free(pd);
     return rc;
 }

@@ -659,6 +659,10 @@ int corahip_normals_mt19937_legacy(corahip_ctx *ctx, corahip_mt_state *state, in
     ARG_CHECK(ctx != nullptr && state != nullptr && n >= 0 && (n == 0 || g != nullptr));
     ARG_CHECK(state->pos >= 0 && state->pos <= MTN);
     if (n == 0) return 0;
+    if (ctx->draw_pending) {
+        corahip_set_error("normals_mt19937_legacy: a corahip_draw_alm_numpy_begin session is pending (its tables share this call's scratch)");
+        return CORAHIP_ESTATE;
+    }
     StageTimer timer(ctx, "normals_legacy");
     mt_session *s = nullptr;
     int rc = mt_stream_prepare(ctx, ctx->stream, state, n, std::vector<unsigned long long>{0ull, (unsigned long long)n}, &s);

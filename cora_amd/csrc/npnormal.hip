@@ -1887,6 +1887,10 @@ int corahip_normals_pcg64(corahip_ctx *ctx, const uint64_t state[2], const uint6
     ARG_CHECK(n == 0 || g != nullptr);
     *n_raw = 0;
     if (n == 0) return 0;
+    if (ctx->draw_pending) {
+        corahip_set_error("normals_pcg64: a corahip_draw_alm_numpy_begin session is pending (its tables share this call's scratch)");
+        return CORAHIP_ESTATE;
+    }
     StageTimer timer(ctx, "normals_pcg64");
     if (!zig_two_pass()) {                      // the whole stream as one range of the single-pass form
         zig_session *s = nullptr;

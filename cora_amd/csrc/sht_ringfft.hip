@@ -510,16 +510,22 @@ int sht_ringfft(corahip_ctx *ctx, const corahip_sht_plan *p, const double *inter
         static const bool one_stream = getenv("CORAHIP_K5_ONE_STREAM") != nullptr;
         const bool two = !one_stream && !class_times && !K5_STAMPS && p->classes.size() > 1;
         hipStream_t const main_stream = ctx->stream;
-        struct Restore {          // ctx->stream is switched per launch below: back to the caller's on every exit path
-            corahip_ctx *c;
-            hipStream_t s;
-            ~Restore() { c->stream = s; }
+        struct Restore {          // ctx->stream is switched per launch below: back to the caller's on every exit path -
+            corahip_ctx *c;       // and the caller's stream waits for whatever was put on the second one (an error return
+            hipStream_t s;        // in the middle of the loop must not leave class kernels running on stream2 unordered
+            bool forked = false;  // against the caller's next launches, or against its freeing of `inter` / `maps`)
+            ~Restore() {
+                c->stream = s;
+                if (forked && (hipEventRecord(c->ev_join, c->stream2) != hipSuccess || hipStreamWaitEvent(s, c->ev_join, 0) != hipSuccess))
+                    (void)hipStreamSynchronize(c->stream2);
+            }
         } restore{ctx, main_stream};
         if (two) {
             int rc2 = sht_second_stream(ctx);
             if (rc2) return rc2;
             HIP_TRY(hipEventRecord(ctx->ev_fork, main_stream));
             HIP_TRY(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
+            restore.forked = true;
         }
         int launch_no = 0;
         for (const auto &c : p->classes) {
@@ -584,6 +590,7 @@ int sht_ringfft(corahip_ctx *ctx, const corahip_sht_plan *p, const double *inter
         if (two) {
             HIP_TRY(hipEventRecord(ctx->ev_join, ctx->stream2));
             HIP_TRY(hipStreamWaitEvent(main_stream, ctx->ev_join, 0));
+            restore.forked = false;                 // (joined here: nothing left for the guard)
         }
     }
     return 0;
@@ -601,16 +608,22 @@ int sht_ringana(corahip_ctx *ctx, const corahip_sht_plan *p, const double *maps,
     static const bool class_times = getenv("CORAHIP_K5_TIMES") != nullptr;   // diagnostics: per-class ms on stderr
     const bool two = !one_stream && !class_times && p->classes.size() > 1;
     hipStream_t const main_stream = ctx->stream;
-    struct Restore {
+    struct Restore {          // (as in sht_ringfft: the caller's stream back, and joined with the second one, on every exit path)
         corahip_ctx *c;
         hipStream_t s;
-        ~Restore() { c->stream = s; }
+        bool forked = false;
+        ~Restore() {
+            c->stream = s;
+            if (forked && (hipEventRecord(c->ev_join, c->stream2) != hipSuccess || hipStreamWaitEvent(s, c->ev_join, 0) != hipSuccess))
+                (void)hipStreamSynchronize(c->stream2);
+        }
     } restore{ctx, main_stream};
     if (two) {
         int rc2 = sht_second_stream(ctx);
         if (rc2) return rc2;
         HIP_TRY(hipEventRecord(ctx->ev_fork, main_stream));
         HIP_TRY(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
+        restore.forked = true;
     }
     int launch_no = 0;
     for (const auto &c : p->classes) {
@@ -654,6 +667,7 @@ int sht_ringana(corahip_ctx *ctx, const corahip_sht_plan *p, const double *maps,
     if (two) {
         HIP_TRY(hipEventRecord(ctx->ev_join, ctx->stream2));
         HIP_TRY(hipStreamWaitEvent(main_stream, ctx->ev_join, 0));
+        restore.forked = false;
     }
     return 0;
 }

@@ -1163,11 +1163,11 @@ int sht_ringfft_ct_pair(corahip_ctx *ctx, const corahip_sht_plan *p, const corah
     HIP_TRY(hipEventRecord(ctx->ev_fork, ctx->stream));
     HIP_TRY(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
     int rc = launch_blu<4096, 1, 8, 256>(ctx, ctx->stream2, 1, p, cap, inter, G, nnu, maps);
+    if (!rc) rc = launch_direct<2048, 2, 8, 256>(ctx, ctx->stream, 1, p, belt, inter, G, nnu, maps);
+    // joined on the error path as well: nothing may stay on stream2 unordered against the caller's stream
+    if (hipEventRecord(ctx->ev_join, ctx->stream2) != hipSuccess || hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0) != hipSuccess)
+        HIP_TRY(hipStreamSynchronize(ctx->stream2));
     if (rc) return rc;
-    rc = launch_direct<2048, 2, 8, 256>(ctx, ctx->stream, 1, p, belt, inter, G, nnu, maps);
-    if (rc) return rc;
-    HIP_TRY(hipEventRecord(ctx->ev_join, ctx->stream2));
-    HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
     *took = true;
     return 0;
 }

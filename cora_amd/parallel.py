@@ -75,6 +75,80 @@ def shard_plan(L, F, rank, world, fold=False):
     return ShardPlan(rank, world, l_lo, l_hi, l_shard, l_shard * world, nu0, nnu, L, ((nu0, nnu),))
 
 
+# ---- exchange guard: a hung collective must end the job with the stage's name, not hang it --------------------------------
+# RCCL collectives are enqueued asynchronously: a peer that never arrives shows up as a host that blocks in a LATER
+# synchronisation.  Two defences: (i) `init_process_group(timeout=...)` (:func:`dist_timeout`) makes torch's own
+# watchdog abort a collective that does not complete; (ii) every exchange of this module runs inside :func:`exchange_stage`,
+# which records its name, and a daemon thread (:func:`start_watchdog`) ends the process with exit code 3 and the name of
+# the stage it is in - or was last in - when nothing has moved for the timeout.  CORA_DIST_TIMEOUT_S (default 300);
+# CORA_DIST_SYNC_EXCHANGES=1 synchronises behind every exchange so that the stage named is the one that hangs.
+import contextlib as _contextlib
+import threading as _threading
+
+_STAGE = {"name": None, "since": None, "last": None, "beat": None, "thread": None}
+
+
+def dist_timeout():
+    """The timeout (datetime.timedelta) for ``init_process_group`` and the watchdog: CORA_DIST_TIMEOUT_S, default 300 s."""
+    import datetime
+    import os
+
+    return datetime.timedelta(seconds=float(os.environ.get("CORA_DIST_TIMEOUT_S", "300")))
+
+
+def start_watchdog(rank=0, world=1, exit_fn=None):
+    """Starts (once) the thread that ends the process when a stage entered through :func:`exchange_stage` has been
+    active for longer than :func:`dist_timeout`: prints the stage, rank and world to stderr and leaves with code 3
+    (``os._exit``: the main thread is blocked inside a collective and will not unwind)."""
+    import os
+    import sys
+    import time
+
+    if _STAGE["thread"] is not None:
+        return _STAGE["thread"]
+    limit = dist_timeout().total_seconds()
+    leave = exit_fn or (lambda code: os._exit(code))
+
+    def run():
+        while True:
+            time.sleep(min(1.0, limit / 4.0))
+            name, since = _STAGE["name"], _STAGE["since"]
+            if name is not None and since is not None and time.time() - since > limit:
+                sys.stderr.write("cora_amd.parallel: stage '%s' has not completed after %.0f s on rank %d of %d (last completed "
+                                 "stage: %s): a peer is missing or a collective hangs - aborting\n"
+                                 % (name, limit, rank, world, _STAGE["last"]))
+                sys.stderr.flush()
+                leave(3)
+                return
+
+    t = _threading.Thread(target=run, name="cora-dist-watchdog", daemon=True)
+    _STAGE["thread"] = t
+    t.start()
+    return t
+
+
+@_contextlib.contextmanager
+def exchange_stage(name, sync=None):
+    """Marks the calling thread as being inside exchange ``name`` (seen by the watchdog); with ``sync`` (default: the
+    environment's CORA_DIST_SYNC_EXCHANGES) the device is synchronised before the stage is left, so that a hang is
+    attributed to this stage and not to a later synchronisation point."""
+    import os
+    import time
+
+    prev = (_STAGE["name"], _STAGE["since"])
+    _STAGE["name"], _STAGE["since"] = name, time.time()
+    try:
+        yield
+        if os.environ.get("CORA_DIST_SYNC_EXCHANGES") if sync is None else sync:
+            import torch
+
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()
+        _STAGE["last"] = name
+    finally:
+        _STAGE["name"], _STAGE["since"] = prev
+
+
 def allgather_factors(T_local, info_local, plan):
     """All-gather the per-rank factor shards into the full [L, F, F] / [L] stacks."""
     import torch
@@ -88,8 +162,9 @@ def allgather_factors(T_local, info_local, plan):
     pad_i[:n].copy_(info_local)
     T_all = torch.empty((plan.l_pad, F, F), dtype=T_local.dtype, device=T_local.device)
     i_all = torch.empty((plan.l_pad,), dtype=info_local.dtype, device=info_local.device)
-    dist.all_gather_into_tensor(T_all, pad_T)
-    dist.all_gather_into_tensor(i_all, pad_i)
+    with exchange_stage("all-gather of the factor shards"):
+        dist.all_gather_into_tensor(T_all, pad_T)
+        dist.all_gather_into_tensor(i_all, pad_i)
     return T_all[: plan.L], i_all[: plan.L]
 
 
@@ -106,7 +181,8 @@ def allgather_channels(shard, F):
     pad = torch.zeros((nmax,) + tuple(shard.shape[1:]), dtype=shard.dtype, device=shard.device)
     pad[: shard.shape[0]].copy_(shard)
     full = torch.empty((world * nmax,) + tuple(shard.shape[1:]), dtype=shard.dtype, device=shard.device)
-    dist.all_gather_into_tensor(full, pad)
+    with exchange_stage("all-gather of the channel shards"):
+        dist.all_gather_into_tensor(full, pad)
     parts = []
     for r in range(world):
         sp = shard_plan(1, F, r, world)
@@ -137,7 +213,8 @@ def exchange_pair_slabs(slabs, plan):
     """K1 pair shards [world, npl, l_shard] (slab q = this rank's pairs at rank q's multipoles) ->
     [world, npl, l_shard] (slab r = rank r's pairs at THIS rank's multipoles)."""
     assert slabs.shape[0] == plan.world and slabs.shape[2] == plan.l_shard
-    return _all_to_all(slabs, plan.world)
+    with exchange_stage("all-to-all #1 (C_l pair slabs -> multipole shards)"):
+        return _all_to_all(slabs, plan.world)
 
 
 def _rows_pack(T_local, l_stride, world):
@@ -184,26 +261,49 @@ def exchange_factor_rows(T_local, info_local, plan):
     pad_i = torch.zeros((plan.l_shard,), dtype=info_local.dtype, device=info_local.device)
     pad_i[:n].copy_(info_local)
     send = _rows_pack(T_local, plan.l_shard, W)     # [dst, l, row, k]
-    recv = _all_to_all(send, W)                     # [src, l_shard, nnu, F]
-    i_all = torch.empty((plan.l_pad,), dtype=info_local.dtype, device=info_local.device)
-    dist.all_gather_into_tensor(i_all, pad_i)
+    with exchange_stage("all-to-all #2 (factor row blocks -> channel shards)"):
+        recv = _all_to_all(send, W)                     # [src, l_shard, nnu, F]
+        i_all = torch.empty((plan.l_pad,), dtype=info_local.dtype, device=info_local.device)
+        dist.all_gather_into_tensor(i_all, pad_i)
     counts = [max(0, min(plan.L, (r + 1) * plan.l_shard) - min(plan.L, r * plan.l_shard)) for r in range(W)]
     return _rows_unpack(recv, counts), i_all[: plan.L]
 
 
-def numpy_ring_bytes(F, lmax, device_bytes=288e9):
+def device_memory_bytes(default=288e9):
+    """The device memory the C side sizes the ring against (``prop.totalGlobalMem``, ~3.09e11 on a 288 GiB part) when a
+    GPU is visible, else ``default`` (the planning figure of the no-GPU memory model)."""
+    try:
+        import torch
+
+        if torch.cuda.is_available():
+            return float(torch.cuda.get_device_properties(torch.cuda.current_device()).total_memory)
+    except Exception:
+        pass
+    return float(default)
+
+
+def numpy_ring_bytes(F, lmax, device_bytes=None):
     """Bytes of the normal-stream ring ``corahip_draw_alm_numpy`` allocates by default (csrc/drawstream.hip): two slots
     in 2 GiB while the whole stream of a realisation (16 F nalm bytes) is at most 1/8 of the device memory (the measured
     optimum of the cfg-3 step: more ranges cost launches, fewer cost the kernel behind the draw its cache / TLB state),
-    else in 1/16 of the memory - a slot never smaller than the normals of l = lmax, the ring never larger than the stream."""
+    else in 1/16 of the memory - a slot never smaller than the normals of l = lmax, the ring never larger than the stream.
+    ``device_bytes``: what the C side reads from the device (:func:`device_memory_bytes`; 288e9 without a GPU).  The
+    environment's ``CORAHIP_RING_MB`` overrides the default on the C side and is honoured here as well."""
+    import os
+
+    if device_bytes is None:
+        device_bytes = device_memory_bytes()
     L = lmax + 1
+    if os.environ.get("CORAHIP_RING_MB"):
+        ring = float(max(1, int(os.environ["CORAHIP_RING_MB"])) << 20)
+        return int(min(8 * F * L * (L + 1), 2 * max(ring / 2, 16.0 * F * L)))
     stream = 8 * F * L * (L + 1)
     ring = 2.0**31 if stream <= device_bytes / 8 else max(device_bytes / 16, 2.0**31)
     slot = max(ring / 2, 16.0 * F * L)
     return int(min(stream, 2 * slot))
 
 
-def rank_memory_bytes(kinds, F, nside, lmax, world, sum_mode="joint", rng="philox"):
+def rank_memory_bytes(kinds, F, nside, lmax, world, sum_mode="joint", rng="philox", fold=False, device_bytes=288e9):
     """Device bytes ONE rank of a ``world``-rank job holds at the peak of a cold step: the buffers of
     :class:`SkyShard` / :class:`SkySum` counted from their shapes (no GPU needed; ``tests/test_host.py`` sums them for
     BASELINE configs[3] and [4] at 8 ranks against the 288 GB of an MI355X, ``tests/test_gpu_parity.py`` compares the
@@ -211,7 +311,9 @@ def rank_memory_bytes(kinds, F, nside, lmax, world, sum_mode="joint", rng="philo
 
     kinds : per component "table21cm" | "separable";  rng : "philox" (no normal buffer) | "numpy" (numpy's own stream,
     PCG64 + ziggurat or the legacy MT19937 + polar method, generated range of multipoles by range on EVERY rank: the
-    ring of :func:`numpy_ring_bytes` plus the generator's count / scan tables, ~0.38 bytes per normal)."""
+    ring of :func:`numpy_ring_bytes` plus the generator's count / scan tables, ~0.38 bytes per normal);
+    fold : the folded channel assignment (one more copy of the local factor block while its rows are permuted);
+    device_bytes : the memory the ring is sized against (the 288e9 planning figure by default)."""
     L = lmax + 1
     nalm = L * (L + 1) // 2
     npix = 12 * nside * nside
@@ -237,12 +339,14 @@ def rank_memory_bytes(kinds, F, nside, lmax, world, sum_mode="joint", rng="philo
     ndraw = 1 if joint else len(kinds)
     if world > 1:
         # factor row blocks of this rank's channels + the slabs of all-to-all #2 while it runs
-        out["factor rows [L, nnu, F] (+ exchange slabs)"] = ndraw * 8 * L * nnu * F + 2 * 8 * world * lsh * nnu * F
+        # (+ a folded shard's row permutation in front of the exchange copies the local [lsh, F, F] factor block once)
+        out["factor rows [L, nnu, F] (+ exchange slabs)"] = (ndraw * 8 * L * nnu * F + 2 * 8 * world * lsh * nnu * F
+                                                             + (8 * lsh * F * F if fold else 0))
     elif not ntab:
         out["factor rows [L, nnu, F] (+ exchange slabs)"] = ndraw * 8 * L * nnu * F
     if rng == "numpy":
         nn = 2 * F * nalm
-        out["numpy normal stream: ring of l ranges + generator tables"] = numpy_ring_bytes(F, lmax) + int(0.38 * nn)
+        out["numpy normal stream: ring of l ranges + generator tables"] = numpy_ring_bytes(F, lmax, device_bytes) + int(0.38 * nn)
     out["total"] = sum(out.values())
     return out
 
@@ -674,16 +778,19 @@ def mkfullsky_sharded(corr_local, global_shape, nside, rng=None, alms=False, ctx
     pad_i = torch.zeros((lc,), dtype=torch.int32, device=ctx.device)
     pad_i[:n_local].copy_(i_loc)
     i_all = torch.empty((world * lc,), dtype=torch.int32, device=ctx.device)
-    dist.all_gather_into_tensor(i_all, pad_i)
     rows = F % world == 0
+    with exchange_stage("mkfullsky_sharded: factor exchange (l-distributed input -> channel shards)"):
+        dist.all_gather_into_tensor(i_all, pad_i)
+        if rows:
+            recv = _all_to_all(_rows_pack(T_loc, lc, world), world)       # [src, lc, nnu, F]
+        else:
+            pad_T = torch.zeros((lc, F, F), dtype=torch.float64, device=ctx.device)
+            pad_T[:n_local].copy_(T_loc)
+            recv = torch.empty((world * lc, F, F), dtype=torch.float64, device=ctx.device)
+            dist.all_gather_into_tensor(recv, pad_T)
     if rows:
-        recv = _all_to_all(_rows_pack(T_loc, lc, world), world)           # [src, lc, nnu, F]
         T = _rows_unpack(recv, counts)
     else:
-        pad_T = torch.zeros((lc, F, F), dtype=torch.float64, device=ctx.device)
-        pad_T[:n_local].copy_(T_loc)
-        recv = torch.empty((world * lc, F, F), dtype=torch.float64, device=ctx.device)
-        dist.all_gather_into_tensor(recv, pad_T)
         recv = recv.view(world, lc, F, F)
         T = torch.cat([recv[r, : counts[r]] for r in range(world)], dim=0).contiguous()
     info = torch.cat([i_all[r * lc : r * lc + counts[r]] for r in range(world)]).contiguous()

@@ -279,7 +279,8 @@ int corahip_mkfullsky(corahip_ctx *ctx, const corahip_sht_plan *plan, const doub
  * _begin / _end: the same in two halves.  _begin enqueues everything and returns without waiting; the caller goes on
  * enqueueing (the synthesis of the a_lm) and calls _end when it wants the generator state: _end waits for the context's
  * stream, updates host_rng and frees `pending`.  Between the two, no other numpy-stream draw may be started on the
- * context and host_rng->legacy (MT19937 kind) must stay valid. */
+ * context (enforced: a second _begin, corahip_normals_pcg64 and corahip_normals_mt19937_legacy return CORAHIP_ESTATE
+ * while a session is pending - they share its device tables) and host_rng->legacy (MT19937 kind) must stay valid. */
 typedef struct corahip_draw_pending corahip_draw_pending;
 int corahip_draw_alm_numpy(corahip_ctx *ctx, const double *T, int rows, const int32_t *info, corahip_rng *host_rng,
                            int lmax, int F, int nu0, int nnu, double *alm_dev, size_t ring_bytes);

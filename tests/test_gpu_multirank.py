@@ -64,6 +64,25 @@ def test_folded_channel_assignment_reproduces_the_single_rank_realisation(worklo
     assert len(s1) == 2 and s1 == s2, (s1, s2)
 
 
+@pytest.mark.parametrize("workload,extra", [("cfg2", []), ("tiny32s", ["--fold"]), ("tiny", [])])
+def test_rccl_code_path_with_one_rank(workload, extra):
+    """Everything of the N-rank path that can run on one GPU, on the REAL backend: `bench.py --gpus 1 --force-dist` makes
+    a one-rank nccl (= RCCL) process group (init_process_group with device_id and the timeout of cora_amd.parallel), runs
+    all-to-all #1 / #2 through `all_to_all_single`, the `all_gather_into_tensor` of the info vectors and the barrier +
+    max-over-ranks timing, for the separable model (cfg2: l-sharded factor + all-gather), the three-component sum with the
+    folded channel assignment (tiny32s --fold) and the pair-sharded 21cm model (tiny).  Same per-channel checksums and
+    same pixels (seeded / legacy streams) as the plain single-process run; the line names the rank's device."""
+    common = ["--workload", workload, "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--checksum"]
+    one, c1 = _bench(common + extra)
+    s1 = _bench.seeded
+    nc, c2 = _bench(["--gpus", "1", "--force-dist", "--dist-backend", "nccl"] + common + extra)
+    s2 = _bench.seeded
+    assert nc["ranks_seen"] == 1 and nc["distinct_devices"] == 1 and len(nc["rank_devices"]) == 1
+    assert nc["rank_devices"][0].startswith("rank 0: cuda:0 ") and "uuid=" in nc["rank_devices"][0]
+    assert c1 is not None and c1 == c2, (c1, c2)
+    assert len(s1) == 2 and s1 == s2, (s1, s2)
+
+
 def test_mkfullsky_l_distributed_mpiarray():
     """skysim.mkfullsky(MPIArray-like l-distributed corr): 2 and 3 ranks (uneven l blocks, F = 8 and 7) return the
     frequency shards of the single-process realisation (DeviceRNG and identically seeded numpy Generators)."""

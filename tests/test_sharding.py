@@ -215,3 +215,76 @@ def test_folded_factor_row_exchange_gloo(world):
     for p in procs:
         p.join(timeout=60)
     assert sorted(res) == [(r, True) for r in range(world)]
+
+
+# ------------------------------------------------------------------ a hung exchange ends the job with the stage's name
+def _worker_hang(rank, world, port):
+    """Rank 0 enters an exchange; rank 1 joins the group and then never calls the collective."""
+    import time
+
+    import torch
+    import torch.distributed as dist
+
+    sys.path.insert(0, ROOT)
+    from cora_amd import parallel
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["CORA_DIST_TIMEOUT_S"] = "3"
+    parallel.start_watchdog(rank, world)
+    with parallel.exchange_stage("init_process_group (test)"):
+        dist.init_process_group("gloo", rank=rank, world_size=world, timeout=parallel.dist_timeout())
+    if rank == 1:
+        time.sleep(30)               # the missing peer (killed by the test once rank 0 has given up)
+        return
+    p = parallel.shard_plan(11, 4, rank, world)
+    T = torch.zeros((p.l_hi - p.l_lo, 4, 4), dtype=torch.float64)
+    info = torch.zeros((p.l_hi - p.l_lo,), dtype=torch.int32)
+    parallel.exchange_factor_rows(T, info, p)        # blocks: the peer never arrives
+    os._exit(0)                      # (not reached)
+
+
+def test_a_hung_exchange_exits_nonzero_and_names_its_stage(capfd):
+    """The first real multi-GPU run must not be able to hang the driver: a collective whose peer never arrives ends the
+    rank that waits - non-zero exit code, the exchange's name on stderr - through the stage guard of cora_amd.parallel
+    (`exchange_stage` + watchdog, CORA_DIST_TIMEOUT_S) or through the backend's own timeout, whichever fires first."""
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker_hang, args=(r, 2, port)) for r in range(2)]
+    for p in procs:
+        p.start()
+    procs[0].join(timeout=90)
+    code = procs[0].exitcode
+    procs[1].terminate()
+    procs[1].join(timeout=30)
+    assert code is not None and code != 0, code
+    err = capfd.readouterr().err
+    assert "all-to-all #2 (factor row blocks -> channel shards)" in err or "Timed out" in err or "timeout" in err.lower(), err[-2000:]
+
+
+def test_exchange_stage_bookkeeping_and_watchdog_trigger(monkeypatch):
+    """exchange_stage nests and restores, records the last completed stage; the watchdog calls its exit function with
+    code 3 once a stage has been active for longer than CORA_DIST_TIMEOUT_S (injected exit function: same process)."""
+    import time
+
+    from cora_amd import parallel
+
+    monkeypatch.setenv("CORA_DIST_TIMEOUT_S", "0.4")
+    monkeypatch.setitem(parallel._STAGE, "thread", None)
+    assert abs(parallel.dist_timeout().total_seconds() - 0.4) < 1e-9
+    with parallel.exchange_stage("outer", sync=False):
+        assert parallel._STAGE["name"] == "outer"
+        with parallel.exchange_stage("inner", sync=False):
+            assert parallel._STAGE["name"] == "inner"
+        assert parallel._STAGE["name"] == "outer" and parallel._STAGE["last"] == "inner"
+    assert parallel._STAGE["name"] is None and parallel._STAGE["last"] == "outer"
+    fired = []
+    parallel.start_watchdog(0, 1, exit_fn=fired.append)
+    with parallel.exchange_stage("stuck exchange", sync=False):
+        t0 = time.time()
+        while not fired and time.time() - t0 < 10:
+            time.sleep(0.05)
+    assert fired == [3]
+    monkeypatch.setitem(parallel._STAGE, "thread", None)
