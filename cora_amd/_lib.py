@@ -58,6 +58,8 @@ SIGNATURES = {
     "corahip_draw_alm_philox_rows": (c_int, [c_void_p, PTR, PTR, c_u64, c_int, c_int, c_int, c_int, PTR]),
     "corahip_draw_alm": (c_int, [c_void_p, PTR, PTR, PTR, c_int, c_int, c_int, c_int, PTR]),
     "corahip_draw_alm_rows": (c_int, [c_void_p, PTR, PTR, PTR, c_int, c_int, c_int, c_int, PTR]),
+    "corahip_draw_alm_numpy_prepare": (c_int, [c_void_p, c_void_p, c_int, c_int, c_size_t, ctypes.POINTER(c_void_p)]),
+    "corahip_draw_alm_numpy_run": (c_int, [c_void_p, c_void_p, PTR, c_int, PTR, c_void_p, PTR]),
     "corahip_draw_alm_numpy": (c_int, [c_void_p, PTR, c_int, PTR, c_void_p, c_int, c_int, c_int, c_int, PTR, c_size_t]),
     "corahip_draw_alm_numpy_begin": (c_int, [c_void_p, PTR, c_int, PTR, c_void_p, c_int, c_int, c_int, c_int, PTR, c_size_t,
                                              ctypes.POINTER(c_void_p)]),
@@ -500,8 +502,28 @@ class Context:
                                               self._f64(g), lmax, F, nu0, nnu, self._f64(alm)))
         return alm
 
+    def draw_alm_numpy_prepare(self, rng, lmax, F, ring_bytes=0):
+        """``corahip_draw_alm_numpy_prepare``: the generator's part of :meth:`draw_alm_numpy` - its count / jump passes and
+        the first two ranges of normals - enqueued on the library's generator stream NOW, so that it runs beside
+        whatever the caller enqueues next (the kernels that make the factors).  Returns the handle ``draw_alm_numpy``
+        takes as ``prepared``; ``handle.abort()`` gives the session up (generator untouched)."""
+        r, ms = _rng_struct(rng)
+        pend = c_void_p()
+        _check(self.lib.corahip_draw_alm_numpy_prepare(self.h, ctypes.byref(r), int(lmax), int(F), int(ring_bytes), ctypes.byref(pend)))
+        ctx = self
+
+        class Prepared:
+            rng_struct, mt_state, pending, shape, live = r, ms, pend, (int(lmax), int(F)), True
+
+            def abort(self):
+                if self.live:
+                    self.live = False
+                    _check(ctx.lib.corahip_draw_alm_numpy_end(ctx.h, self.pending, ctypes.byref(self.rng_struct)))
+
+        return Prepared()
+
     def draw_alm_numpy(self, T, info, rng, lmax, F, nu0=0, nnu=None, out=None, rows=False, ring_bytes=0, defer=False,
-                       chunks=None):
+                       chunks=None, prepared=None):
         """``corahip_draw_alm_numpy``: K3 with numpy's own stream generated on the device range by range (no 16 F nalm
         byte buffer).  ``rng``: ("pcg64", state, inc) python ints of a PCG64 bit generator, or ("legacy",
         get_state(legacy=False) dict).  ``rows``: T is the row block [L, nnu, F].  Returns (alm, state after): the PCG64
@@ -509,7 +531,8 @@ class Context:
         everything is enqueued, nothing waited for; ``finish()`` (``corahip_draw_alm_numpy_end``: the one read-back)
         returns the state after and is called once the caller has enqueued what follows (the synthesis).
         ``chunks``: [(first, count), (first, count)] - the two chunks of a folded frequency shard (row-block T in local
-        channel order) instead of ``nu0`` / ``nnu``."""
+        channel order) instead of ``nu0`` / ``nnu``.  ``prepared``: the handle of :meth:`draw_alm_numpy_prepare` (``rng``
+        is then ignored: the session carries the generator)."""
         import numpy as np
 
         if chunks is not None:
@@ -518,9 +541,24 @@ class Context:
         assert tuple(T.shape) == ((lmax + 1, nnu, F) if rows else (lmax + 1, F, F)), T.shape
         nalm = (lmax + 1) * (lmax + 2) // 2
         alm = out if out is not None else self.empty((nalm, (nnu + 3) // 4, 2, 4))
-        r, ms = _rng_struct(rng)
-        pend = c_void_p()
-        if chunks is not None and len(chunks) > 1:
+        if prepared is not None:
+            # the generator's passes were enqueued earlier (draw_alm_numpy_prepare): K3 against the factors now
+            assert prepared.live and prepared.shape == (int(lmax), int(F)), "the prepared session is for another shape"
+            r, ms, pend = prepared.rng_struct, prepared.mt_state, prepared.pending
+            cs = _chanset(chunks if chunks is not None and len(chunks) > 1 else [(nu0, nnu)])
+            prepared.live = False
+            try:
+                _check(self.lib.corahip_draw_alm_numpy_run(self.h, pend, self._f64(T), 1 if rows else 0,
+                                                           self._p(info) if info is not None else None, ctypes.byref(cs), self._f64(alm)))
+            except CoraHipError:
+                self.lib.corahip_draw_alm_numpy_end(self.h, pend, ctypes.byref(r))       # (frees the session)
+                raise
+        else:
+            r, ms = _rng_struct(rng)
+            pend = c_void_p()
+        if prepared is not None:
+            pass
+        elif chunks is not None and len(chunks) > 1:
             cs = _chanset(chunks)
             _check(self.lib.corahip_draw_alm_numpy_begin_set(self.h, self._f64(T), self._p(info) if info is not None else None,
                                                              ctypes.byref(r), lmax, F, ctypes.byref(cs), self._f64(alm),

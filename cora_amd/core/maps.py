@@ -168,10 +168,20 @@ class Sky3d(Map3d):
         handed to :func:`skysim.mkfullsky_device`.
         """
         nu = self._channels()
-        cl = skysim.clarray_device(self.angular_powerspectrum, self._lmax(), nu,
-                                   zromb=self.oversample)
-        fluct = skysim.mkfullsky_device(cl, self.nside, rng=rng)
+        # the normals depend on the generator alone: its device passes (numpy's PCG64 / legacy MT19937 stream) start
+        # before the C_l integration and run beside it and the factorisation
         ctx = _lib.get_context()
+        prep = None
+        if not isinstance(rng, skysim.DeviceRNG):
+            prep = skysim.prepare_numpy_stream(ctx, rng, self._lmax(), len(nu))
+        try:
+            cl = skysim.clarray_device(self.angular_powerspectrum, self._lmax(), nu,
+                                       zromb=self.oversample)
+        except BaseException:
+            if prep is not None:
+                prep.abort()
+            raise
+        fluct = skysim.mkfullsky_device(cl, self.nside, rng=rng, prepared=prep)
         mean = np.asarray(self.mean_nu(nu), dtype=np.float64) * np.ones(nu.shape)
         if np.any(mean != 0.0):          # added on the device: a pass over 25.8 GB of host memory is seconds
             fluct += ctx.to_device(mean)[:, None]

@@ -233,7 +233,53 @@ def stream_normals(ctx, numz, maxl, rng):
     return g
 
 
-def draw_numpy_stream(ctx, T, info, rng, maxl, numz, nu0=0, nnu=None, out=None, rows=False, defer=False, chunks=None):
+class _PreparedStream:
+    """A numpy stream whose device generator has been started ahead of the factors (:func:`prepare_numpy_stream`): holds
+    the generator's lock until the draw's ``finish()`` - or :meth:`abort` - has run."""
+
+    def __init__(self, rng, legacy, lock, state, handle):
+        self.rng, self.legacy, self.lock, self.state, self.handle = rng, legacy, lock, state, handle
+
+    def abort(self):
+        """Give the session up (the factors could not be made): the generator is left as it was."""
+        try:
+            self.handle.abort()
+        finally:
+            if self.lock is not None:
+                self.lock.release()
+                self.lock = None
+
+
+def prepare_numpy_stream(ctx, rng, maxl, numz):
+    """Starts the device generator of :func:`draw_numpy_stream` NOW, on the library's generator stream: the passes that
+    do not depend on the factors (count + scan of numpy's PCG64 / ziggurat stream, or jump tree + count of the legacy
+    MT19937 stream, and the first two ranges of normals) then run BESIDE the kernels the caller enqueues next - the
+    C_l integration and the factorisation (the stream is a function of the generator alone: the reference draws it inside
+    ``mkfullsky``, cora/util/nputil.py:121-125, but nothing it draws depends on the covariance).  Returns the object
+    ``draw_numpy_stream(..., prepared=...)`` takes, or None for a generator that is consumed on the host.  The
+    generator's lock is held from here to the end of the draw."""
+    legacy = _legacy_state_of(rng)
+    pcg = legacy is None and _is_pcg64_generator(rng)
+    if legacy is None and not pcg:
+        return None
+    lock = legacy[2] if legacy is not None else rng.bit_generator.lock
+    lock.acquire()
+    try:
+        if legacy is not None:
+            st = None
+            spec = ("legacy", legacy[0](legacy=False))
+        else:
+            st = rng.bit_generator.state
+            spec = ("pcg64", int(st["state"]["state"]), int(st["state"]["inc"]))
+        handle = ctx.draw_alm_numpy_prepare(spec, maxl, numz)
+    except BaseException:
+        lock.release()
+        raise
+    return _PreparedStream(rng, legacy, lock, st, handle)
+
+
+def draw_numpy_stream(ctx, T, info, rng, maxl, numz, nu0=0, nnu=None, out=None, rows=False, defer=False, chunks=None,
+                      prepared=None):
     """K3 with the REFERENCE's normals: ``a_lm = T_l g_l`` for channels ``[nu0, nu0 + nnu)`` where ``g`` is what
     ``complex_std_normal((numz, l + 1), rng)`` returns inside the reference's l loop (cora/core/skysim.py:114-121,
     cora/util/nputil.py:104-125) - drawn the way the reference draws them: range of multipoles by range, never the
@@ -246,6 +292,7 @@ def draw_numpy_stream(ctx, T, info, rng, maxl, numz, nu0=0, nnu=None, out=None, 
         Any other generator is consumed on the host, l by l, and uploaded.
     T : full factors ``[L, F, F]`` or, with ``rows``, the row block ``[L, nnu, F]`` of a frequency shard
         (``chunks`` = [(first, count), (first, count)]: the two chunks of a FOLDED shard, rows in local order).
+    prepared : the object of :func:`prepare_numpy_stream` (the generator already runs; ``rng`` is then ignored).
     defer : return ``(alm, finish)``: the draw is only ENQUEUED; ``finish()`` - to be called after the caller has
         enqueued what follows, e.g. the synthesis - waits for the queue and writes the generator's state back (the
         generator's lock is held until then).  Default: ``alm``, generator already updated.
@@ -283,31 +330,46 @@ def draw_numpy_stream(ctx, T, info, rng, maxl, numz, nu0=0, nnu=None, out=None, 
         finish()
         return alm
 
-    legacy = _legacy_state_of(rng)
-    pcg = legacy is None and _is_pcg64_generator(rng)
-    if legacy is None and not pcg:
-        return done(host_path())
-    if legacy is not None:
-        get_state, set_state, lock = legacy
-    else:
-        bg = rng.bit_generator
-        lock = bg.lock                                     # the lock numpy's own draws hold
-    lock.acquire()
-    try:
+    if prepared is not None:
+        # the generator was started ahead of the factors (prepare_numpy_stream): its lock is held, K3 runs against T now
+        legacy, lock, st = prepared.legacy, prepared.lock, prepared.state
         if legacy is not None:
-            spec = ("legacy", get_state(legacy=False))
+            get_state, set_state, _ = legacy
         else:
-            st = bg.state
-            spec = ("pcg64", int(st["state"]["state"]), int(st["state"]["inc"]))
-        alm, fin = ctx.draw_alm_numpy(T, info, spec, maxl, numz, nu0=nu0, nnu=nnu, out=out, rows=rows, defer=True, chunks=chunks)
-    except _lib.CoraHipError as e:
-        lock.release()
-        if e.status != -3:                                 # only CORAHIP_ESTATE is a reason to take the host stream
+            bg = prepared.rng.bit_generator
+        prepared.lock = None                               # (released by finish() below, or here on failure)
+        try:
+            alm, fin = ctx.draw_alm_numpy(T, info, None, maxl, numz, nu0=nu0, nnu=nnu, out=out, rows=rows, defer=True,
+                                          chunks=chunks, prepared=prepared.handle)
+        except BaseException:
+            lock.release()
             raise
-        return done(host_path())
-    except BaseException:
-        lock.release()
-        raise
+    else:
+        legacy = _legacy_state_of(rng)
+        pcg = legacy is None and _is_pcg64_generator(rng)
+        if legacy is None and not pcg:
+            return done(host_path())
+        if legacy is not None:
+            get_state, set_state, lock = legacy
+        else:
+            bg = rng.bit_generator
+            lock = bg.lock                                     # the lock numpy's own draws hold
+        lock.acquire()
+        try:
+            if legacy is not None:
+                spec = ("legacy", get_state(legacy=False))
+            else:
+                st = bg.state
+                spec = ("pcg64", int(st["state"]["state"]), int(st["state"]["inc"]))
+            alm, fin = ctx.draw_alm_numpy(T, info, spec, maxl, numz, nu0=nu0, nnu=nnu, out=out, rows=rows, defer=True, chunks=chunks)
+        except _lib.CoraHipError as e:
+            lock.release()
+            if e.status != -3:                                 # only CORAHIP_ESTATE is a reason to take the host stream
+                raise
+            return done(host_path())
+        except BaseException:
+            lock.release()
+            raise
 
     def finish():
         try:
@@ -333,22 +395,33 @@ def factor_device(corr):
     return ctx.factor_batched(corr, jitter_rel=1e-14, eig_thresh=1e-16)
 
 
-def mkfullsky_device(corr, nside, alms=False, rng=None, factors=None, nu_range=None):
+def mkfullsky_device(corr, nside, alms=False, rng=None, factors=None, nu_range=None, prepared=None):
     """Device-resident :func:`mkfullsky`: returns torch tensors and accepts cached factors.
 
     corr : ndarray or device tensor [lmax+1, F, F] (ignored when ``factors`` is given)
     factors : optional (T, info) from :func:`factor_device`
     nu_range : optional (nu0, nnu): only these channels are synthesised (frequency shard);
         the normals are always the full global stream so shards are consistent.
+    prepared : optional object of :func:`prepare_numpy_stream` for ``rng`` (started by the caller ahead of its C_l
+        integration, as ``Sky3d.getsky`` does); without it the generator is started here, ahead of the factorisation.
     """
     import torch
 
     ctx = _lib.get_context()
+    prep = prepared
     if factors is None:
         numz = corr.shape[1]
         if corr.shape[2] != numz:
             raise Exception("Correlation matrix is incorrect shape.")
-        T, info = factor_device(corr)
+        if prep is None and not isinstance(rng, DeviceRNG):
+            # numpy's stream does not depend on the covariance: its generator passes start here, beside the factorisation
+            prep = prepare_numpy_stream(ctx, rng, corr.shape[0] - 1, numz)
+        try:
+            T, info = factor_device(corr)
+        except BaseException:
+            if prep is not None:
+                prep.abort()
+            raise
     else:
         T, info = factors
         numz = T.shape[1]
@@ -359,7 +432,7 @@ def mkfullsky_device(corr, nside, alms=False, rng=None, factors=None, nu_range=N
         alm = ctx.draw_alm_philox(T, info, rng.next_seed(), maxl, numz, nu0=nu0, nnu=nnu)
     else:
         # the draw is enqueued, the synthesis behind it; only then is the generator's state waited for
-        alm, finish = draw_numpy_stream(ctx, T, info, rng, maxl, numz, nu0=nu0, nnu=nnu, defer=True)
+        alm, finish = draw_numpy_stream(ctx, T, info, rng, maxl, numz, nu0=nu0, nnu=nnu, defer=True, prepared=prep)
         try:
             out = ctx.alm_dev_to_square(alm, maxl, nnu) if alms else ctx.alm2map(alm, int(nside), maxl, nnu)
         finally:

@@ -572,27 +572,45 @@ class SkyShard:
         self.draw(seed, factors)
         return self.ctx.alm2map(self.alm_buf, self.nside, self.lmax, self.nnu, out=self.maps_buf)
 
-    def realise_numpy(self, rng, factors=None):
+    def realise_numpy(self, rng, factors=None, prepared=None):
         """As :meth:`realise` with the REFERENCE's normal stream: ``rng`` is what cora's callers pass to
         ``mkfullsky`` - a ``numpy.random.Generator`` (on PCG64 it is continued on the device, bit for bit, and left where
         cora would leave it) or ``None`` (numpy's legacy global MT19937 state, continued on the device as well) - see
         ``skysim.draw_numpy_stream``.  Every rank consumes the whole stream (identically seeded generators) range of
         multipoles by range - no 16 F nalm byte buffer - against its own rows of the factors."""
-        _, finish = self.draw_numpy(rng, factors, defer=True)
+        _, finish = self.draw_numpy(rng, factors, defer=True, prepared=prepared)
         try:     # (the synthesis is enqueued behind the draw before the generator's state is waited for)
             return self.ctx.alm2map(self.alm_buf, self.nside, self.lmax, self.nnu, out=self.maps_buf)
         finally:
             finish()
 
-    def draw_numpy(self, rng, factors=None, out=None, defer=False):
+    def prepare_numpy(self, rng):
+        """Starts the device generator of ``rng``'s normal stream for one realisation NOW (``skysim.prepare_numpy_stream``):
+        called ahead of :meth:`factors`, the generator's own passes run beside the C_l integration and the factorisation.
+        Hand the result to :meth:`realise_numpy` / :meth:`draw_numpy` as ``prepared`` (None for generators that are
+        consumed on the host)."""
+        from .core import skysim
+
+        return skysim.prepare_numpy_stream(self.ctx, rng, self.lmax, self.F)
+
+    def draw_numpy(self, rng, factors=None, out=None, defer=False, prepared=None):
         """a_lm of this rank's channels from the reference's normal stream (see :meth:`realise_numpy`); ``defer``:
         ``(alm, finish)`` as ``skysim.draw_numpy_stream``."""
         from .core import skysim
 
-        T, info, rows = factors if factors is not None else self.factors()
+        if factors is None:
+            if prepared is None:
+                prepared = self.prepare_numpy(rng)          # (the generator beside K1 / K2)
+            try:
+                factors = self.factors()
+            except BaseException:
+                if prepared is not None:
+                    prepared.abort()
+                raise
+        T, info, rows = factors
         return skysim.draw_numpy_stream(self.ctx, T, info, rng, self.lmax, self.F, nu0=self.nu0, nnu=self.nnu,
                                         out=self.alm_buf if out is None else out, rows=rows, defer=defer,
-                                        chunks=self.chunks if (rows and self.folded) else None)
+                                        chunks=self.chunks if (rows and self.folded) else None, prepared=prepared)
 
 
 class SkySum:

@@ -32,7 +32,7 @@ extern "C" {
 #endif
 
 #define CORAHIP_ABI_VERSION 1
-#define CORAHIP_ABI_MINOR 3      /* additions since version 1: 1 = normals_pcg64, pcg64_advance, draw_alm_rows, mkfullsky, mkfullsky_workspace_bytes, abi_minor, normals_mt19937_legacy; 2 = sht_lambda_entry (test hook); 3 = draw_alm_numpy, draw_alm_numpy_begin / _end, corahip_chanset: draw_alm_philox_rows_set, draw_alm_numpy_begin_set, randomfield_irfftn */
+#define CORAHIP_ABI_MINOR 4      /* additions since version 1: 1 = normals_pcg64, pcg64_advance, draw_alm_rows, mkfullsky, mkfullsky_workspace_bytes, abi_minor, normals_mt19937_legacy; 2 = sht_lambda_entry (test hook); 3 = draw_alm_numpy, draw_alm_numpy_begin / _end, corahip_chanset: draw_alm_philox_rows_set, draw_alm_numpy_begin_set, randomfield_irfftn; 4 = glibc_exp (test hook), draw_alm_numpy_prepare / _run */
 
 #define CORAHIP_EINVAL (-1)   /* bad argument / shape */
 #define CORAHIP_ENOMEM (-2)   /* workspace too small / allocation refused */
@@ -288,6 +288,18 @@ int corahip_draw_alm_numpy_begin(corahip_ctx *ctx, const double *T, int rows, co
                                  int lmax, int F, int nu0, int nnu, double *alm_dev, size_t ring_bytes,
                                  corahip_draw_pending **pending);
 int corahip_draw_alm_numpy_end(corahip_ctx *ctx, corahip_draw_pending *pending, corahip_rng *host_rng);
+/* _begin in its two halves.  _prepare is the part of a draw that does NOT depend on the factors - ranges, ring, the
+ * generator's own passes (count + scan / jump tree + count) and the emit passes of the first two ranges, all on the
+ * library's generator stream: a caller that issues it BEFORE the launches that make the factors (C_l integration,
+ * factorisation) lets the generator run beside them (the stream is a function of the generator alone; the reference draws
+ * it inside mkfullsky, cora/util/nputil.py:121-125, but nothing it draws depends on the covariance).  _run enqueues K3 of
+ * every range against the factors (T full [L, F, F] with rows = 0 - `set` then names one block - or the row block of the
+ * set's channels with rows = 1) and the remaining emit passes; _end as above.  A prepared session that is given up
+ * (no _run) is freed by _end, which then leaves host_rng untouched.  _begin = _prepare + _run. */
+int corahip_draw_alm_numpy_prepare(corahip_ctx *ctx, const corahip_rng *host_rng, int lmax, int F, size_t ring_bytes,
+                                   corahip_draw_pending **pending);
+int corahip_draw_alm_numpy_run(corahip_ctx *ctx, corahip_draw_pending *pending, const double *T, int rows, const int32_t *info,
+                               const corahip_chanset *set, double *alm_dev);
 /* _begin for a channel set (the struct above; T_rows = the row block of its channels) */
 int corahip_draw_alm_numpy_begin_set(corahip_ctx *ctx, const double *T_rows, const int32_t *info, const corahip_rng *host_rng,
                                      int lmax, int F, const corahip_chanset *set, double *alm_dev, size_t ring_bytes,

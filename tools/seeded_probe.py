@@ -37,9 +37,19 @@ def pcg64_then_idle(i):
     ctx.alm2map(sh.alm_buf, sh.nside, sh.lmax, sh.nnu, out=sh.maps_buf)
 
 
+def early(g):
+    """the generator started AHEAD of K1 / K2 (corahip_draw_alm_numpy_prepare): its passes run beside them"""
+    def f(i):
+        prep = sh.prepare_numpy(g)
+        sh.realise_numpy(g, sh.factors(), prepared=prep)
+    return f
+
+
 modes = {"philox": lambda i: sh.realise(100 + i, sh.factors()), "pcg64": lambda i: sh.realise_numpy(rng, sh.factors()),
-         "legacy": lambda i: sh.realise_numpy(None, sh.factors()), "philox+dummy stream": philox_after_dummy_stream,
-         "pcg64, idle before K4": pcg64_then_idle}
+         "pcg64, generator ahead of K1": early(rng),
+         "legacy": lambda i: sh.realise_numpy(None, sh.factors()), "legacy, generator ahead of K1": early(None)}
+if os.environ.get("PROBE_MORE"):
+    modes.update({"philox+dummy stream": philox_after_dummy_stream, "pcg64, idle before K4": pcg64_then_idle})
 if os.environ.get("PROBE_RINGS"):       # the seeded step for several ring sizes (MB): does K4's first-run penalty follow the ring?
     def with_ring(mb):
         def f(i):
