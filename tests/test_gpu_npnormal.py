@@ -418,3 +418,80 @@ def test_folded_two_chunk_draw_equals_the_columns_of_the_full_draw(ctx, F, lmax,
     gotn, after = ctx.draw_alm_numpy(Trows, infod, ("pcg64", st["state"], st["inc"]), lmax, F, chunks=chunks, ring_bytes=1 << 22)
     assert after == after_full
     assert torch.equal(ctx.alm_dev_to_square(gotn, lmax, 2 * chunk), ctx.alm_dev_to_square(fulln, lmax, F).index_select(0, ch))
+
+
+# ------------------------------------------------------------------ the generator started ahead of the factors (round 6)
+@pytest.mark.parametrize("kind", ["pcg64", "legacy"])
+def test_generator_started_ahead_of_the_factors_gives_the_same_draw(ctx, kind):
+    """corahip_draw_alm_numpy_prepare / _run: the generator's passes (and the first two ranges of normals) are enqueued
+    BEFORE the kernels that make the factors and run beside them - the stream depends on the generator alone
+    (cora/util/nputil.py:121-125).  Same a_lm bit for bit and same generator state as the one-call form, for ring sizes
+    from one l per range to one range, full and row-block factors; a second session while one is pending is refused;
+    a prepared session that is given up leaves the generator untouched."""
+    import torch
+
+    from cora_amd import _lib
+    from cora_amd.core import skysim
+
+    F, lmax, nu0, nnu = 72, 150, 8, 32
+    Td, infod = _factors(ctx, F, lmax, 4711)
+
+    def fresh():
+        if kind == "pcg64":
+            g = np.random.default_rng(99)
+            g.standard_normal(5)
+            return g
+        rs = np.random.RandomState(98)
+        rs.standard_normal(3)                     # (an odd count: a cached value in front)
+        return rs
+
+    ref_rng = fresh()
+    ref = skysim.draw_numpy_stream(ctx, Td, infod, ref_rng, lmax, F, nu0=nu0, nnu=nnu).clone()
+    after_ref = ref_rng.standard_normal(4)
+    for rows in (False, True):
+        rng = fresh()
+        prep = skysim.prepare_numpy_stream(ctx, rng, lmax, F)
+        assert prep is not None
+        # "the kernels that make the factors": unrelated work on the context's stream while the generator runs
+        busy = ctx.to_device(np.ones((2048, 2048)))
+        for _ in range(3):
+            busy = busy @ busy * 1e-4
+        with pytest.raises(_lib.CoraHipError):   # one session per context: a second generator is refused, not interleaved
+            ctx.normals_pcg64(1, 3, 10)
+        Tin = Td[:, nu0:nu0 + nnu, :].contiguous() if rows else Td
+        alm = skysim.draw_numpy_stream(ctx, Tin, infod, rng, lmax, F, nu0=nu0, nnu=nnu, rows=rows, prepared=prep)
+        assert torch.equal(alm, ref), (kind, rows)
+        assert np.array_equal(rng.standard_normal(4), after_ref), (kind, rows)
+    # given up: nothing drawn, generator as it was, the context free for the next session
+    rng, twin = fresh(), fresh()
+    prep = skysim.prepare_numpy_stream(ctx, rng, lmax, F)
+    prep.abort()
+    assert np.array_equal(rng.standard_normal(6), twin.standard_normal(6))
+    again = skysim.draw_numpy_stream(ctx, Td, infod, fresh(), lmax, F, nu0=nu0, nnu=nnu)
+    assert torch.equal(again, ref)
+    # a generator that is consumed on the host has nothing to prepare
+    assert skysim.prepare_numpy_stream(ctx, np.random.Generator(np.random.MT19937(1)), lmax, F) is None
+
+
+def test_getsky_and_mkfullsky_start_the_generator_first(ctx, monkeypatch):
+    """Sky3d.getsky / skysim.mkfullsky_device order their launches generator first, C_l integration / factorisation second,
+    K3 third - and return the maps of the plain order."""
+    from cora_amd.core import skysim
+    from cora_amd.foreground import galaxy
+
+    order = []
+    real_prepare, real_factor, real_clarray = skysim.prepare_numpy_stream, skysim.factor_device, skysim.clarray_device
+    monkeypatch.setattr(skysim, "prepare_numpy_stream", lambda *a, **k: (order.append("prepare"), real_prepare(*a, **k))[1])
+    monkeypatch.setattr(skysim, "factor_device", lambda *a, **k: (order.append("factor"), real_factor(*a, **k))[1])
+    monkeypatch.setattr(skysim, "clarray_device", lambda *a, **k: (order.append("clarray"), real_clarray(*a, **k))[1])
+    sky = galaxy.FullSkySynchrotron()
+    sky.nside, sky.nu_lower, sky.nu_upper, sky.nu_num = 16, 400.0, 800.0, 8
+    sky.lmax = 40
+    m1 = sky.getsky(rng=np.random.default_rng(3))
+    assert order == ["prepare", "clarray", "factor"], order
+    monkeypatch.undo()
+    nu = np.asarray(sky._channels(), dtype=np.float64)
+    cl = skysim.clarray(sky.angular_powerspectrum, 40, nu.copy(), zromb=sky.oversample)
+    m2 = skysim.mkfullsky(cl, 16, rng=np.random.default_rng(3))
+    mean = np.asarray(sky.mean_nu(nu), dtype=np.float64) * np.ones(nu.shape)
+    assert np.abs(m1 - mean[:, None] - m2).max() <= 1e-9 * np.abs(m2).max()
