@@ -87,6 +87,29 @@ __device__ inline void mt_block_next(unsigned *mt, int lane) {
     }
 }
 
+// the next 624 words OUT OF PLACE: dst = the block behind src.  Same three phases (word k >= 227 needs the NEW word
+// k - 227, word 623 the new word 0), but nothing is overwritten, so a phase needs no separation of its reads from its
+// writes: one LDS round trip less per phase.  Used to keep TWO consecutive blocks resident (round 6): a block holds
+// 156 attempts = 2.44 rounds of 64 lanes, a pair 312 = 4.875 rounds - the third round of every block ran at 44 % lane
+// occupancy, the fifth round of a pair runs at 88 %.
+__device__ inline void mt_block_next_to(const unsigned *src, unsigned *dst, int lane) {
+#pragma unroll
+    for (int ph = 0; ph < 3; ph++) {
+        const int k0 = 227 * ph, k1 = ph == 2 ? MTN : 227 * (ph + 1);
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const int k = k0 + 64 * c + lane;
+            if (k < k1) {
+                const unsigned u = src[k], v = k + 1 < MTN ? src[k + 1] : dst[0];
+                const unsigned w = k + MTM < MTN ? src[k + MTM] : dst[k + MTM - MTN];
+                dst[k] = mt_next(u, v, w);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 struct mt_status {
     unsigned key[MTN];          // the block the generator is left in
     int pos, has_gauss;
@@ -326,11 +349,13 @@ constexpr int MT_NSUB = MT_SEG_BLOCKS / MT_SUB_BLOCKS;                          
 __global__ void __launch_bounds__(MT_WG)
 mt_count_kernel(const unsigned *__restrict__ seg_state, long nseg, unsigned *__restrict__ sub_state, unsigned *__restrict__ sub_cnt) {
 #pragma clang fp contract(off)
-    __shared__ __attribute__((aligned(16))) unsigned blk[MT_WG / 64][MTN + 8];
+    // two consecutive blocks per wave, [A | B] contiguous: attempt a < 156 of a pair reads words 4 a .. 4 a + 3 of A, attempt
+    // 156 + a' those of B - one index into one array
+    __shared__ __attribute__((aligned(16))) unsigned blk[MT_WG / 64][2 * MTN + 8];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const long j = (long)blockIdx.x * (MT_WG / 64) + wv;
     if (j >= nseg) return;
-    unsigned *mt = blk[wv];
+    unsigned *mt = blk[wv], *mtb = blk[wv] + MTN;
     for (int i = lane; i < MTN; i += 64) mt[i] = seg_state[j * MTN + i];
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     __builtin_amdgcn_wave_barrier();
@@ -341,8 +366,24 @@ mt_count_kernel(const unsigned *__restrict__ seg_state, long nseg, unsigned *__r
         for (int i = lane; i < MTN; i += 64) sub_state[sidx * MTN + i] = mt[i];
         const int b0 = k * MT_SUB_BLOCKS, b1 = k == MT_NSUB - 1 ? MT_SEG_BLOCKS : b0 + MT_SUB_BLOCKS;
         unsigned cnt = 0;
-        for (int bi = b0; bi < b1; bi++) {
-            const int nb = (int)std::min<long>(MT_ATT_BLOCK, MT_SEG_ATT - (long)bi * MT_ATT_BLOCK);   // attempts of this block that belong to the segment
+        int bi = b0;
+        for (; bi + 1 < b1; bi += 2) {
+            mt_block_next_to(mt, mtb, lane);
+            // attempts of the two blocks that belong to the segment (only a segment's LAST block is partial)
+            const int nbb = (int)std::min<long>(MT_ATT_BLOCK, MT_SEG_ATT - (long)(bi + 1) * MT_ATT_BLOCK);
+#pragma unroll
+            for (int r = 0; r < (2 * MT_ATT_BLOCK + 63) / 64; r++) {
+                const int a = 64 * r + lane;
+                const bool in = a < MT_ATT_BLOCK + nbb;
+                mt_attempt t;
+                t.ok = false;
+                if (in) t = mt_try(mt, a);
+                cnt += (unsigned)__builtin_popcountll(__ballot(in && t.ok));
+            }
+            mt_block_next_to(mtb, mt, lane);
+        }
+        if (bi < b1) {                                     // an odd block count: the sub-segment's last block by itself
+            const int nb = (int)std::min<long>(MT_ATT_BLOCK, MT_SEG_ATT - (long)bi * MT_ATT_BLOCK);
 #pragma unroll
             for (int r = 0; r < (MT_ATT_BLOCK + 63) / 64; r++) {
                 const int a = 64 * r + lane;
@@ -367,9 +408,9 @@ mt_emit_kernel(const unsigned *__restrict__ sub_state, long nsub, const unsigned
                const long *__restrict__ sub_first, unsigned long long w_lo, unsigned long long w_hi, unsigned off0,
                unsigned long long n, double *__restrict__ g, mt_status *st) {
 #pragma clang fp contract(off)
-    __shared__ __attribute__((aligned(16))) unsigned blk[MT_WG / 64][MTN + 8];
+    __shared__ __attribute__((aligned(16))) unsigned blk[MT_WG / 64][2 * MTN + 8];    // two consecutive blocks [A | B]: see mt_count_kernel
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    unsigned *mt = blk[wv];
+    unsigned *mt = blk[wv], *mtb = blk[wv] + MTN;
     const unsigned long long need = n - off0;
     const unsigned long long pairs = (need + 1) / 2;          // accepted attempts that are needed
     // accepted attempts o with an element below w_hi: off0 + 2 o < w_hi
@@ -385,49 +426,60 @@ mt_emit_kernel(const unsigned *__restrict__ sub_state, long nsub, const unsigned
         __builtin_amdgcn_wave_barrier();
         const int k = (int)(s % MT_NSUB);
         const int b0 = k * MT_SUB_BLOCKS, b1 = k == MT_NSUB - 1 ? MT_SEG_BLOCKS : b0 + MT_SUB_BLOCKS;
-        for (int bi = b0; bi < b1; bi++) {
-            const int nb = (int)std::min<long>(MT_ATT_BLOCK, MT_SEG_ATT - (long)bi * MT_ATT_BLOCK);
-#pragma unroll
-            for (int r = 0; r < (MT_ATT_BLOCK + 63) / 64; r++) {
-                const int a = 64 * r + lane;
-                const bool in = a < nb;
-                mt_attempt t;
-                t.ok = false;
-                if (in) t = mt_try(mt, a);
-                const unsigned long long acc = __ballot(in && t.ok);
-                if (in && t.ok) {
-                    const unsigned long long o = ord + __builtin_amdgcn_mbcnt_hi((unsigned)(acc >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)acc, 0u));
-                    if (o < pairs) {
-                        const unsigned long long e = (unsigned long long)off0 + 2 * o;
-                        const bool in0 = e - w_lo < w_n, in1 = e + 1 - w_lo < w_n && 2 * o + 1 < need;
-                        if (in0 || in1 || o + 1 == pairs) {
-                            const double f = sqrt(-2.0 * glibc_log_fma(t.r2) / t.r2);     // (sqrt and the division are correctly rounded on both sides)
-                            const double first = f * t.x2, second = f * t.x1;
-                            if (in0 && in1 && al16) *reinterpret_cast<double2 *>(g + (e - w_lo)) = make_double2(first, second);
-                            else {             // (a pair behind an odd offset, or one cut by the window's edge)
-                                if (in0) g[e - w_lo] = first;
-                                if (in1) g[e + 1 - w_lo] = second;
-                            }
-                            if (o + 1 == pairs) {
-                                // the generator after this attempt: inside this block, behind the attempt's four words; the
-                                // second value stays cached when an odd number of normals was asked for
-                                st->pos = 4 * (a + 1);
-                                st->has_gauss = (need & 1ull) ? 1 : 0;
-                                st->gauss = (need & 1ull) ? second : 0.0;
-                                st->done = 1;
-                            }
+        // one round of 64 attempts of the resident window [A | B]: attempt a (< 156: block A, else block B), `in` = it exists
+        auto round = [&](const int a, const bool in) {
+            mt_attempt t;
+            t.ok = false;
+            if (in) t = mt_try(mt, a);
+            const unsigned long long acc = __ballot(in && t.ok);
+            bool last = false;
+            if (in && t.ok) {
+                const unsigned long long o = ord + __builtin_amdgcn_mbcnt_hi((unsigned)(acc >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)acc, 0u));
+                if (o < pairs) {
+                    const unsigned long long e = (unsigned long long)off0 + 2 * o;
+                    const bool in0 = e - w_lo < w_n, in1 = e + 1 - w_lo < w_n && 2 * o + 1 < need;
+                    last = o + 1 == pairs;
+                    if (in0 || in1 || last) {
+                        const double f = sqrt(-2.0 * glibc_log_fma(t.r2) / t.r2);     // (sqrt and the division are correctly rounded on both sides)
+                        const double first = f * t.x2, second = f * t.x1;
+                        if (in0 && in1 && al16) *reinterpret_cast<double2 *>(g + (e - w_lo)) = make_double2(first, second);
+                        else {             // (a pair behind an odd offset, or one cut by the window's edge)
+                            if (in0) g[e - w_lo] = first;
+                            if (in1) g[e + 1 - w_lo] = second;
+                        }
+                        if (last) {
+                            // the generator after this attempt: inside its block, behind the attempt's four words; the
+                            // second value stays cached when an odd number of normals was asked for
+                            st->pos = 4 * ((a < MT_ATT_BLOCK ? a : a - MT_ATT_BLOCK) + 1);
+                            st->has_gauss = (need & 1ull) ? 1 : 0;
+                            st->gauss = (need & 1ull) ? second : 0.0;
+                            st->done = 1;
                         }
                     }
                 }
-                const unsigned long long nacc = __builtin_popcountll(acc);
-                if (ord < pairs && ord + nacc >= pairs) {
-                    // (wave-uniform) this block holds the last needed attempt: it is the key numpy is left with
-                    for (int i = lane; i < MTN; i += 64) st->key[i] = mt[i];
-                }
-                ord += nacc;
             }
+            const unsigned long long hit = __ballot(last);
+            if (hit) {
+                // (wave-uniform) the block that holds the last needed attempt is the key numpy is left with
+                const int a_hit = a - lane + (int)__builtin_ctzll(hit);
+                const unsigned *kb = a_hit < MT_ATT_BLOCK ? mt : mtb;
+                for (int i = lane; i < MTN; i += 64) st->key[i] = kb[i];
+            }
+            ord += __builtin_popcountll(acc);
+        };
+        int bi = b0;
+        for (; bi + 1 < b1; bi += 2) {
+            mt_block_next_to(mt, mtb, lane);
+            const int nbb = (int)std::min<long>(MT_ATT_BLOCK, MT_SEG_ATT - (long)(bi + 1) * MT_ATT_BLOCK);
+#pragma unroll
+            for (int r = 0; r < (2 * MT_ATT_BLOCK + 63) / 64; r++) round(64 * r + lane, 64 * r + lane < MT_ATT_BLOCK + nbb);
             if (ord >= p_end) break;
-            mt_block_next(mt, lane);
+            mt_block_next_to(mtb, mt, lane);
+        }
+        if (bi < b1 && bi + 1 >= b1 && ord < p_end) {          // an odd block count: the sub-segment's last block by itself
+            const int nb = (int)std::min<long>(MT_ATT_BLOCK, MT_SEG_ATT - (long)bi * MT_ATT_BLOCK);
+#pragma unroll
+            for (int r = 0; r < (MT_ATT_BLOCK + 63) / 64; r++) round(64 * r + lane, 64 * r + lane < nb);
         }
     }
 }
