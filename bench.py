@@ -392,7 +392,7 @@ def main():
         # HBM bytes of the dominant kernel from the PMC passes of the same command (collected separately
         # with rocprofv3 --pmc and committed under profiles/; bench.py cannot read counters itself)
         traffic = traffic_source = pmc_mfma = None
-        for pmc_name in ("r05_pmc.json", "r04_pmc.json", "r03_pmc.json", "r02_pmc.json"):
+        for pmc_name in ("r06_pmc.json", "r05_pmc.json", "r04_pmc.json", "r03_pmc.json", "r02_pmc.json"):
             pmc_file = os.path.join(ROOT, "profiles", pmc_name)
             if os.path.exists(pmc_file) and world == 1 and not emu and args.workload == "cfg3":
                 pmc = json.load(open(pmc_file)).get("kernels", {})

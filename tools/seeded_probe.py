@@ -56,9 +56,16 @@ if os.environ.get("PROBE_RINGS"):       # the seeded step for several ring sizes
             os.environ["CORAHIP_RING_MB"] = str(mb)
             sh.realise_numpy(rng, sh.factors())
         return f
+    def with_ring_ahead(mb, g):
+        def f(i):
+            os.environ["CORAHIP_RING_MB"] = str(mb)
+            early(g)(i)
+        return f
     modes = {"philox": modes["philox"]}
     for mb in os.environ["PROBE_RINGS"].split(","):
         modes["pcg64 ring %s MB" % mb] = with_ring(int(mb))
+        modes["pcg64 ring %s MB, generator ahead" % mb] = with_ring_ahead(int(mb), rng)
+        modes["legacy ring %s MB, generator ahead" % mb] = with_ring_ahead(int(mb), None)
 for tag, fn in modes.items():
     fn(0); fn(1)
     torch.cuda.synchronize()
