@@ -349,6 +349,9 @@ clarray21_kernel(const double *__restrict__ tt, int nkperp, int nkpar, double kp
 // this order, profiles/r02_pmc.json); and consecutive slots are consecutive j of one row i, so the transpose into
 // [l][i][j] writes contiguous segments (a plain diagonal-major order made every write an isolated 8 bytes).
 #define CL_BAND 32
+#ifndef CL_XCD_ORDER
+#define CL_XCD_ORDER 1   // 0: plain i-major order inside a band (A/B)
+#endif
 __host__ __device__ static inline long cl_band_count(int n) {   // pairs of a band that has n rows (n = F - CL_BAND B)
     return n >= CL_BAND ? (long)CL_BAND * (n - (CL_BAND - 1)) + (long)(CL_BAND - 1) * CL_BAND / 2 : (long)n * (n + 1) / 2;
 }
@@ -363,8 +366,21 @@ __host__ __device__ static inline int2 pair_of_index(long p, int F) {
     const int nfull = n >= CL_BAND ? n - (CL_BAND - 1) : 0;         // rows with all CL_BAND separations
     int i, dd;
     if (p < (long)nfull * CL_BAND) {
+#if CL_XCD_ORDER
+        // Round 6: inside a band's full rows index p = 8 s + x is pair (row s / 4, separation 4 x + s % 4).  Workgroups are
+        // dealt round-robin over the 8 XCDs, each with its own L2: with the plain i-major order (p = 32 i + d) XCD x got the
+        // separations x, x + 8, x + 16, x + 24 of every row - four groups of k_par columns 8 channels (430 columns) apart -
+        // now it gets the four ADJACENT separations 4 x .. 4 x + 3 (one group of columns).  Every band starts at a
+        // multiple of 8, so p mod 8 is the workgroup's XCD slot; 32 consecutive p still are the 32 separations of one row
+        // (cl_finish_kernel's contiguous segment), and rank r of an 8-rank pair shard (pairs r, r + 8, ...) integrates four
+        // adjacent separations of every band instead of four spread ones.
+        const int xq = (int)(p & 7), sq = (int)(p >> 3);
+        i = sq >> 2;
+        dd = 4 * xq + (sq & 3);
+#else
         i = (int)(p / CL_BAND);
         dd = (int)(p % CL_BAND);
+#endif
     } else {
         p -= (long)nfull * CL_BAND;
         int e = n >= CL_BAND ? CL_BAND - 1 : n;                     // entries of the first tail row

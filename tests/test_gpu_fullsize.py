@@ -382,7 +382,7 @@ def test_k4_mfma_count_matches_pmc_profile(ctx):
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     pmc = None
-    for name in ("r04_pmc.json", "r03_pmc.json", "r02_pmc.json"):
+    for name in ("r06_pmc.json", "r05_pmc.json", "r04_pmc.json", "r03_pmc.json", "r02_pmc.json"):
         f = os.path.join(root, "profiles", name)
         if os.path.exists(f):
             k = json.load(open(f))["kernels"]
