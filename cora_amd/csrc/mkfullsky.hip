@@ -73,10 +73,17 @@ int corahip_mkfullsky(corahip_ctx *ctx, const corahip_sht_plan *plan, const doub
     int32_t *info = (int32_t *)(ws + lo.off_info);
     double *alm = (double *)(ws + lo.off_alm);
     const int lmax = plan->lmax, L = plan->L;
-    // skysim.py:115-119: C_l + I max(diag) 1e-14 -> Cholesky, eigen root where that fails (nputil.py:51-101, threshold 1e-16)
-    if ((rc = corahip_factor_batched(ctx, C, L, F, 1e-14, 1e-16, T, info))) return rc;
-    // skysim.py:120-121
+    // numpy's own stream depends on the generator alone: its device passes (and the first two ranges of normals) are
+    // enqueued on the generator stream BEFORE the factorisation and run beside it (round 6)
     corahip_draw_pending *pending = nullptr;
+    const bool numpy_stream = rng->kind == CORAHIP_RNG_PCG64 || rng->kind == CORAHIP_RNG_MT19937;
+    if (numpy_stream && (rc = corahip_draw_alm_numpy_prepare(ctx, rng, lmax, F, 0, &pending))) return rc;
+    // skysim.py:115-119: C_l + I max(diag) 1e-14 -> Cholesky, eigen root where that fails (nputil.py:51-101, threshold 1e-16)
+    if ((rc = corahip_factor_batched(ctx, C, L, F, 1e-14, 1e-16, T, info))) {
+        if (pending) (void)corahip_draw_alm_numpy_end(ctx, pending, rng);     // (given up: the generator stays as it was)
+        return rc;
+    }
+    // skysim.py:120-121
     if (rng->kind == CORAHIP_RNG_PHILOX) {
         rc = corahip_draw_alm_philox(ctx, T, info, rng->seed, lmax, F, nu0, nnu, alm);
     } else if (rng->kind == CORAHIP_RNG_STREAM) {
@@ -85,9 +92,13 @@ int corahip_mkfullsky(corahip_ctx *ctx, const corahip_sht_plan *plan, const doub
         // numpy's own stream (PCG64 + ziggurat, or the legacy MT19937 + polar method), continued on the device range by
         // range: enqueued here, the generator state read back (rng->state / rng->legacy left where numpy would leave
         // them) once the synthesis has been enqueued behind it
-        rc = corahip_draw_alm_numpy_begin(ctx, T, 0, info, rng, lmax, F, nu0, nnu, alm, 0, &pending);
+        const corahip_chanset set = {1, nnu, {nu0, 0}};
+        rc = corahip_draw_alm_numpy_run(ctx, pending, T, 0, info, &set, alm);
     }
-    if (rc) return rc;
+    if (rc) {
+        if (pending) (void)corahip_draw_alm_numpy_end(ctx, pending, rng);     // (frees the session)
+        return rc;
+    }
     // skysim.py:123-130
     if (alms) rc = corahip_alm_dev_to_square(ctx, alm, lmax, nnu, out);
     else rc = corahip_alm2map(ctx, plan, alm, nnu, out, ws + lo.off_sht, workspace_bytes - lo.off_sht);
