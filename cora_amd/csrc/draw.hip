@@ -209,7 +209,7 @@ static inline long draw_slots(int l_lo, int l_hi) {
 // staging by HALF chunks: behind the barrier of chunk c a wave requests the second half of chunk c, THEN the DMA pieces
 // of stage c + 2 - the wait in front of the second half leaves those QPW pieces in flight and covers the loads; the
 // first half of chunk c + 1 is requested at that point and waited for, with everything else, at the next chunk begin.
-template <int NCT, bool FROMG = false>
+template <int NCT, bool FROMG = false, int NB = DRAW_NBUF>
 __global__ void __launch_bounds__(64 * DRAW_WAVES, 2)
 draw_rng_kernel(const double *__restrict__ T, size_t t_ldl, int rows, const int32_t *__restrict__ info,
                 const double *__restrict__ zeros, uint64_t seed, const double *__restrict__ gsrc, size_t g_off, int l_lo,
@@ -222,7 +222,8 @@ draw_rng_kernel(const double *__restrict__ T, size_t t_ldl, int rows, const int3
     static_assert(QPW * DRAW_WAVES == NC / 4 || NC / 4 < DRAW_WAVES, "every staging wave issues the same number of pieces");
     // Bs[n][slot' = slot ^ (n & 15)][2]: the 16-byte slots of a row are XOR-swizzled with the row number
     // (applied on the DMA source address), so that 16 rows read at the same k hit 16 distinct slots
-    extern __shared__ __attribute__((aligned(16))) double lds[];  // [DRAW_NBUF][NC][ROWD]
+    extern __shared__ __attribute__((aligned(16))) double lds[];  // [NB][NC][ROWD]
+    static_assert(NB == 3 || (NB == 2 && !FROMG), "two stages: the Philox instantiation only (no operand loads to count)");
     __shared__ double2 lg_s[257], sc_s[256];   // LDS copies of the Box-Muller tables (rng_dev.h): 8 KB
     __shared__ int s_next[2];                  // next work item, double-buffered (written one item ahead)
 
@@ -337,7 +338,7 @@ draw_rng_kernel(const double *__restrict__ T, size_t t_ldl, int rows, const int3
     item_t w = decode(item);
     int ring = 0, par = 0;
     stage(w, 0, 0);
-    if (w.nchunk > 1) stage(w, 1, 1);
+    if (NB > 2 && w.nchunk > 1) stage(w, 1, 1);
     if constexpr (FROMG) {
         if (w.mb * DRAW_MB + 16 * wave < w.l + 1) issue_a(w, 0, 0, a_x);
     }
@@ -360,16 +361,17 @@ draw_rng_kernel(const double *__restrict__ T, size_t t_ldl, int rows, const int3
         auto half_steps = [&](auto tmin_c, const double *sb, int k0, auto half_c) {
             constexpr int TMIN = decltype(tmin_c)::value;
             constexpr int half = decltype(half_c)::value;
-            constexpr int UNR = FROMG ? 4 : DRAW_KK_UNROLL;     // (FROMG indexes its operand registers by kk)
+            constexpr int UNR = FROMG ? 4 : (NCT > 8 ? 1 : DRAW_KK_UNROLL);     // (FROMG indexes its operand registers by kk; the 256-column shape has no registers for a second chain)
 #pragma unroll UNR
             for (int kk = 4 * half; kk < 4 * half + 4; kk++) {
                 const int kp = k0 + 4 * kk + kq;
                 const int kl = 4 * kk + kq;          // k within the chunk
-                // all B operands of the k-step are read up front (one address + immediate offsets)
-                double bv[NCT];
+                // all B operands of the k-step are read up front (one address + immediate offsets; the 256-column shape:
+                // the first eight tiles' - the others behind the first MFMAs)
+                double bv[NCT > 8 ? 8 : NCT];
                 const double *brow = sb + ri * ROWD + 2 * ((kl >> 1) ^ ri) + (kl & 1);
 #pragma unroll
-                for (int t = TMIN; t < NCT; t++) bv[t] = brow[16 * t * ROWD];
+                for (int t = TMIN; t < (NCT > 8 ? 8 : NCT); t++) bv[t] = brow[16 * t * ROWD];
 #if DRAW_ABLATE == 1   // diagnostic: no RNG
                 double2 a = make_double2(1.0 + kp, 0.5 * m_lane);
 #else
@@ -381,13 +383,23 @@ draw_rng_kernel(const double *__restrict__ T, size_t t_ldl, int rows, const int3
                 else a = philox_normal_pair(seed, l, F, kp, m_lane, lg_s, sc_s);
 #endif
 #pragma unroll
-                for (int t = TMIN; t < NCT; t++) {
+                for (int t = TMIN; t < (NCT > 8 ? 8 : NCT); t++) {
 #if DRAW_ABLATE == 2   // diagnostic: no MFMA
                     asm volatile("" ::"v"(a.x), "v"(a.y), "v"(bv[t]));
 #else
                     acc0[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, bv[t], acc0[t], 0, 0, 0);
                     acc1[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, bv[t], acc1[t], 0, 0, 0);
 #endif
+                }
+                if constexpr (NCT > 8) {
+#pragma unroll
+                    for (int t = (TMIN > 8 ? TMIN : 8); t < NCT; t++) bv[t - 8] = brow[16 * t * ROWD];
+#pragma unroll
+                    for (int t = (TMIN > 8 ? TMIN : 8); t < NCT; t++) {
+                        acc0[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, bv[t - 8], acc0[t], 0, 0, 0);
+                        acc1[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, bv[t - 8], acc1[t], 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);      // (the next k-step's generator chain must not be scheduled across: no registers for it)
                 }
             }
         };
@@ -413,7 +425,9 @@ draw_rng_kernel(const double *__restrict__ T, size_t t_ldl, int rows, const int3
             // FROMG: the first-half operands of this chunk were requested at the middle of the previous one, BEHIND the
             // DMA pieces of stage c + 1 - they are the youngest requests in flight, so everything is waited for (stage
             // c + 1 has then had one chunk, not two, to land; the counted wait is the one in front of the second half)
-            if (FROMG || c == 0 || c + 1 >= nchunk) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // (NB = 2 - the 256-column shape, whose three stages would not fit the LDS -: stage c was requested behind the
+            //  barrier of chunk c - 1 and nothing younger is in flight)
+            if (NB == 2 || FROMG || c == 0 || c + 1 >= nchunk) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(QPW) : "memory");
             if constexpr (FROMG) {
                 if (wave_has_rows) pin_a(a_x);
@@ -427,14 +441,14 @@ draw_rng_kernel(const double *__restrict__ T, size_t t_ldl, int rows, const int3
                 // second half of this chunk: ahead of the DMA pieces, so that the wait in front of the half leaves them
                 if (wave_has_rows && c * DRAW_KC + 16 < kmax) issue_a(w, c, 1, a_y);
             }
-            if (c + 2 < nchunk) stage(w, c + 2, (ring + c + 2) % DRAW_NBUF);
+            if (c + NB - 1 < nchunk) stage(w, c + NB - 1, (ring + c + NB - 1) % NB);
             DSTAMP(2);                       // issue of the stage after next
         };
         int c = 0;
         for (; c < w.c_full; c++) {
             chunk_begin(c);
             if (!wave_has_rows) continue;
-            const double *sb = lds + ((ring + c) % DRAW_NBUF) * BUF;
+            const double *sb = lds + ((ring + c) % NB) * BUF;
             half_steps(std::integral_constant<int, 0>{}, sb, c * DRAW_KC, std::integral_constant<int, 0>{});
             if (c * DRAW_KC + 16 < kmax) {
                 mid_chunk(c);
@@ -447,7 +461,7 @@ draw_rng_kernel(const double *__restrict__ T, size_t t_ldl, int rows, const int3
             if (c >= nchunk) return;         // (uniform; also the dense / unaligned case, where c == nchunk here)
             chunk_begin(c);
             if (wave_has_rows) {
-                const double *sb = lds + ((ring + c) % DRAW_NBUF) * BUF;
+                const double *sb = lds + ((ring + c) % NB) * BUF;
                 half_steps(std::integral_constant<int, (2 * J < NCT ? 2 * J : NCT)>{}, sb, c * DRAW_KC, std::integral_constant<int, 0>{});
                 if (c * DRAW_KC + 16 < kmax) {
                     mid_chunk(c);
@@ -462,7 +476,7 @@ draw_rng_kernel(const double *__restrict__ T, size_t t_ldl, int rows, const int3
 
         // ---- next item: its first two stages are requested now, ahead of this item's stores.  Only the slot of the
         //      last chunk can still be in use by a slower wave, and the ring moves on past it.
-        ring = (ring + nchunk) % DRAW_NBUF;
+        ring = (ring + nchunk) % NB;
         const int cur_lbase = w.lbase, cur_lend4 = (w.lend + 3) & ~3;
         item = __builtin_amdgcn_readfirstlane(s_next[par]);   // (written before this item's first barrier)
         par ^= 1;
@@ -470,7 +484,7 @@ draw_rng_kernel(const double *__restrict__ T, size_t t_ldl, int rows, const int3
         if (have_next) {
             w = decode(item);
             stage(w, 0, ring);
-            if (w.nchunk > 1) stage(w, 1, (ring + 1) % DRAW_NBUF);
+            if (NB > 2 && w.nchunk > 1) stage(w, 1, (ring + 1) % NB);      // (NB = 2: that slot is the last chunk's, maybe still read)
             if constexpr (FROMG) {
                 if (w.mb * DRAW_MB + 16 * wave < w.l + 1) issue_a(w, 0, 0, a_x);
             }
@@ -556,13 +570,13 @@ static int draw_slot_table(corahip_ctx *ctx, int lmax, const unsigned **tab) {
     return 0;
 }
 
-template <int NCT, bool FROMG = false>
+template <int NCT, bool FROMG = false, int NB = DRAW_NBUF>
 static int launch_draw_rng(corahip_ctx *ctx, hipStream_t stream, const double *T, size_t t_ldl, int rows, const int32_t *info,
                            uint64_t seed, const double *gsrc, size_t g_off, int l_lo, int l_hi, int lmax, int F,
                            draw_chan ch, int Gout, double *alm) {
     constexpr int NC = 16 * NCT;
-    const size_t shm = sizeof(double) * DRAW_NBUF * NC * DRAW_KC;
-    HIP_TRY(hipFuncSetAttribute((const void *)draw_rng_kernel<NCT, FROMG>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    const size_t shm = sizeof(double) * NB * NC * DRAW_KC;
+    HIP_TRY(hipFuncSetAttribute((const void *)draw_rng_kernel<NCT, FROMG, NB>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)shm));
     // scratch slot 3: 4096 bytes of zeros (DMA source of padded rows) + the work queue counter behind them
     char *zq = nullptr;
@@ -580,7 +594,7 @@ static int launch_draw_rng(corahip_ctx *ctx, hipStream_t stream, const double *T
     // persistent: one workgroup per CU for the 128-channel shape (106 KB of LDS), two for the narrower ones
     const int per_cu = (shm + 8300 > 80 * 1024) ? 1 : 2;
     dim3 grid((unsigned)std::min<long>(nitems, (long)ctx->num_cu * per_cu));
-    draw_rng_kernel<NCT, FROMG><<<grid, 64 * DRAW_WAVES, shm, stream>>>(T, t_ldl, rows, info, (const double *)zq, seed, gsrc,
+    draw_rng_kernel<NCT, FROMG, NB><<<grid, 64 * DRAW_WAVES, shm, stream>>>(T, t_ldl, rows, info, (const double *)zq, seed, gsrc,
                                                                         g_off, l_lo, l_hi, lmax, F, ch.nu0, ch.nu1, ch.cw,
                                                                         ch.nnu, Gout, (int)nslots, ncg0, ncg, alm,
                                                                         (unsigned *)(zq + 4096), slot_tab);
@@ -716,6 +730,14 @@ static int draw_philox(corahip_ctx *ctx, const double *T, int rows, const int32_
     if (ncol <= 16) return launch_draw_rng<1>(ctx, ctx->stream, T, t_ldl, rows, info, seed, nullptr, 0, 0, lmax, lmax, F, ch, Gout, alm_dev);
     if (ncol <= 32) return launch_draw_rng<2>(ctx, ctx->stream, T, t_ldl, rows, info, seed, nullptr, 0, 0, lmax, lmax, F, ch, Gout, alm_dev);
     if (ncol <= 64) return launch_draw_rng<4>(ctx, ctx->stream, T, t_ldl, rows, info, seed, nullptr, 0, 0, lmax, lmax, F, ch, Gout, alm_dev);
+    // Round-6 experiment, OFF by default (CORAHIP_K3_WIDE=1 selects it; tools/k3_wide_probe.py): ONE column group of 256 per
+    // (l, m block) where there are two of 128 - every normal pair generated once per 256 columns instead of once per 128
+    // (the generator is half of this kernel's issue time), two 64 KB stages instead of three.  Same a_lm - and 23.1 ms
+    // against 7.32: 128 accumulator registers + the generator chain do not fit the 256 of two waves per SIMD (1228 bytes
+    // of scratch per lane, ~25 scratch operations per k-step in the MFMA loop, each a vmcnt-ordered memory instruction).
+    static const bool wide = getenv("CORAHIP_K3_WIDE") && atoi(getenv("CORAHIP_K3_WIDE")) != 0;
+    if (wide && ncol >= 256 && ch.nu1 == 0 && ch.cw >= ch.nnu)
+        return launch_draw_rng<16, false, 2>(ctx, ctx->stream, T, t_ldl, rows, info, seed, nullptr, 0, 0, lmax, lmax, F, ch, Gout, alm_dev);
     return launch_draw_rng<8>(ctx, ctx->stream, T, t_ldl, rows, info, seed, nullptr, 0, 0, lmax, lmax, F, ch, Gout, alm_dev);
 }
 
