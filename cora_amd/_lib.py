@@ -556,17 +556,15 @@ class Context:
         else:
             r, ms = _rng_struct(rng)
             pend = c_void_p()
-        if prepared is not None:
-            pass
-        elif chunks is not None and len(chunks) > 1:
-            cs = _chanset(chunks)
-            _check(self.lib.corahip_draw_alm_numpy_begin_set(self.h, self._f64(T), self._p(info) if info is not None else None,
-                                                             ctypes.byref(r), lmax, F, ctypes.byref(cs), self._f64(alm),
-                                                             int(ring_bytes), ctypes.byref(pend)))
-        else:
-            _check(self.lib.corahip_draw_alm_numpy_begin(self.h, self._f64(T), 1 if rows else 0,
-                                                         self._p(info) if info is not None else None, ctypes.byref(r), lmax,
-                                                         F, nu0, nnu, self._f64(alm), int(ring_bytes), ctypes.byref(pend)))
+            if chunks is not None and len(chunks) > 1:
+                cs = _chanset(chunks)
+                _check(self.lib.corahip_draw_alm_numpy_begin_set(self.h, self._f64(T), self._p(info) if info is not None else None,
+                                                                 ctypes.byref(r), lmax, F, ctypes.byref(cs), self._f64(alm),
+                                                                 int(ring_bytes), ctypes.byref(pend)))
+            else:
+                _check(self.lib.corahip_draw_alm_numpy_begin(self.h, self._f64(T), 1 if rows else 0,
+                                                             self._p(info) if info is not None else None, ctypes.byref(r), lmax,
+                                                             F, nu0, nnu, self._f64(alm), int(ring_bytes), ctypes.byref(pend)))
         keep = [T, info, alm]           # (alive until the queue has been waited for)
 
         def finish():
