@@ -18,12 +18,12 @@
 // MT19937 itself is the sequential part: x[k + 624] = x[k + 397] ^ twist(x[k], x[k + 1]).  It is linear over GF(2), so
 // the window J words on is g(T) applied to the window, g = x^J mod phi (phi the minimal polynomial, degree 19937):
 // mt_jump.inc (tools/gen_mt_jump.py: Berlekamp-Massey on numpy's own output, square-and-multiply mod phi, checked
-// against plain stepping; restated in oracle/mtlegacy.py) holds x^(S 2^k - 1) for the segment length S = 2^20 words.
-// The stream is cut into segments of S words = 262144 attempts; the segment start windows come from a doubling tree
-// (level k: segments 2^k .. 2^(k+1) - 1 from segments 0 .. 2^k - 1 with polynomial k: 12 launches at cfg 3), each
-// application = extend the source window by 19938 words in LDS and XOR the windows at the polynomial's ~10^4 set bits
-// (6e6 word operations: with S = 2^18 the tree was 10.9 of 19.6 ms, with 2^20 it is 4.0 of 15.3 - fewer, longer
-// segments cost the two passes 2.6 ms of occupancy).
+// against plain stepping; restated in oracle/mtlegacy.py) holds x^(q 8^j S - 1), q = 1 .. 7, for the segment length S = 2^20 words.
+// The stream is cut into segments of S words = 262144 attempts; the segment start windows come from a radix-8 tree
+// (level j: the starts q 8^j + a, q = 1 .. 7, from the starts a < 8^j, one launch; round 6 - rounds 4-5 doubled: twelve
+// sequential launches at cfg 3 where there are four now), each application = extend the source window by 19938 words in
+// LDS and XOR the windows at the polynomial's ~10^4 set bits (6e6 word operations: with S = 2^18 the tree was 10.9 of
+// 19.6 ms, with 2^20 it is 4.0 of 15.3 - fewer, longer segments cost the two passes 2.6 ms of occupancy).
 // Then one wave per segment: pass 1 counts the accepted attempts, a one-workgroup scan gives every segment its first
 // output position, pass 2 regenerates and writes the normals (an accepted lane writes its pair: consecutive lanes,
 // consecutive addresses).  The wave that meets the last needed attempt writes out the state numpy would be left in:
@@ -165,18 +165,25 @@ mt_plist_kernel(unsigned *__restrict__ plist_all, unsigned *__restrict__ npos_al
 // the device-wide list (walking the list in global memory by scalar loads instead was measured SLOWER, tree 3.5 -> 4.7
 // ms: a load's latency per 16 positions is not hidden at one wave per SIMD).
 #define MT_JUMP_WG 1024                     // threads of a jump workgroup: MT_JUMP_WG / 256 position groups on the full window
+// One launch = one LEVEL of the radix-8 tree (round 6): from the segment starts 0 .. have - 1 the starts q have + a, q = 1 .. 7 -
+// application (q, a) applies polynomial kbase + q - 1 (x^(q have S - 1)) to start a.  (Rounds 4-5: a doubling tree, one
+// polynomial and `have` applications per level - twelve sequential launches at cfg 3, eight of them with fewer applications
+// than CUs, each bound by one application's latency; now four launches, two of them small.)
 __global__ void __launch_bounds__(MT_JUMP_WG)
-mt_jump_kernel(unsigned *__restrict__ seg_state, long src0, long dst0, long count, int k, int split,
+mt_jump_kernel(unsigned *__restrict__ seg_state, long have, long nseg, int kbase, int split,
                const unsigned *__restrict__ plist_all, const unsigned *__restrict__ npos_all) {
     extern __shared__ unsigned xs[];                          // [MT_JUMP_XS] words, then the position list (u16)
     constexpr int NQ = (MTN + MT_JUMP_T - 1) / MT_JUMP_T;     // words per thread on the full window: 3
     __shared__ unsigned red[NQ][MT_JUMP_WG];
     unsigned short *plist = (unsigned short *)(xs + MT_JUMP_XS);
-    const long a = blockIdx.x / split;
-    const int part = blockIdx.x - (int)a * split;
-    if (a >= count) return;
+    const long app = blockIdx.x / split;
+    const int part = blockIdx.x - (int)app * split;
+    const long q = app / have + 1, a = app - (q - 1) * have;
+    const long dst_seg = q * have + a;
+    if (q > 7 || dst_seg >= nseg) return;
+    const int k = kbase + (int)q - 1;
     const int tid = threadIdx.x, lane = tid & 63;
-    const unsigned *src = seg_state + (src0 + a) * MTN;
+    const unsigned *src = seg_state + a * MTN;
     const int npos = (int)npos_all[k];
     {
         const unsigned *__restrict__ pl = plist_all + (size_t)k * MT_PLIST_STRIDE;
@@ -244,7 +251,7 @@ mt_jump_kernel(unsigned *__restrict__ seg_state, long src0, long dst0, long coun
 #pragma unroll
     for (int q = 0; q < NQ; q++) red[q][tid] = gi < G ? acc[q] : 0u;
     __syncthreads();
-    unsigned *dst = seg_state + (dst0 + a) * MTN + w0;
+    unsigned *dst = seg_state + dst_seg * MTN + w0;
     if (gi == 0) {
 #pragma unroll
         for (int q = 0; q < NQ; q++) {
@@ -575,10 +582,10 @@ int mt_stream_prepare(corahip_ctx *ctx, hipStream_t stream, corahip_mt_state *st
     s->nseg = std::max<long>(1, (natt + MT_SEG_ATT - 1) / MT_SEG_ATT);
     s->nsub = s->nseg * MT_NSUB;
     int levels = 0;
-    while ((1L << levels) < s->nseg) levels++;
-    if (levels > MT_NPOLY) {
-        corahip_set_error("normals_mt19937_legacy: %lld normals need %ld segments, the jump table holds %d levels", (long long)n, s->nseg,
-                          MT_NPOLY);
+    for (long have = 1; have < s->nseg; have *= 8) levels++;
+    if (levels > MT_NLEV) {
+        corahip_set_error("normals_mt19937_legacy: %lld normals need %ld segments, the jump table holds %d radix-8 levels", (long long)n,
+                          s->nseg, MT_NLEV);
         delete s;
         return CORAHIP_EINVAL;
     }
@@ -639,8 +646,9 @@ int mt_stream_prepare(corahip_ctx *ctx, hipStream_t stream, corahip_mt_state *st
         const size_t shm = sizeof(unsigned) * MT_JUMP_XS + sizeof(unsigned short) * (MT_DEG + 8);
         if ((e = hipFuncSetAttribute((const void *)mt_jump_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm)) != hipSuccess)
             return fail(e, "hipFuncSetAttribute");
-        for (int k = 0; (1L << k) < s->nseg; k++) {
-            const long have = 1L << k, count = std::min<long>(have, s->nseg - have);
+        int lev = 0;
+        for (long have = 1; have < s->nseg; have *= 8, lev++) {
+            const long count = std::min<long>(7 * have, s->nseg - have);       // applications of this level
             // levels with fewer applications than CUs: several workgroups per application (divisors of 624).  (Splitting
             // the last partial round of the larger levels as well was measured: no gain, 2.32 vs 2.36 ms.)
             int split = 1;
@@ -649,8 +657,10 @@ int mt_stream_prepare(corahip_ctx *ctx, hipStream_t stream, corahip_mt_state *st
                     split = cand;
                     break;
                 }
-            mt_jump_kernel<<<(unsigned)(count * split), MT_JUMP_WG, shm, stream>>>(s->seg_state, 0, have, count, k, split, plist_all,
-                                                                                  npos_all);
+            // (the grid covers q = 1 .. 7 for every start a < have: applications past nseg return at once)
+            const long napp = std::min<long>(7 * have, ((s->nseg - 1) / have) * have);
+            mt_jump_kernel<<<(unsigned)(napp * split), MT_JUMP_WG, shm, stream>>>(s->seg_state, have, s->nseg, 7 * lev, split, plist_all,
+                                                                                 npos_all);
         }
     }
     {

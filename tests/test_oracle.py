@@ -666,11 +666,11 @@ def test_mt19937_jump_polynomials():
     words = [int(t, 16) for t in re.findall(r"0x([0-9a-f]{8})u,", txt)]
     npoly = int(re.search(r"#define MT_NPOLY (\d+)", txt).group(1))
     assert len(words) == npoly * 624
-    g = m.x_pow_mod((1 << seg) - 1, phi)
-    for k in range(3):
+    # radix-8 table (round 6): entry 7 j + q - 1 = x^(q 8^j S - 1); spot checks on both levels by square-and-multiply
+    assert npoly == 7 * int(re.search(r"#define MT_NLEV (\d+)", txt).group(1))
+    for k, e in ((0, 1), (1, 2), (2, 3), (6, 7), (7, 8), (11, 5 * 8)):
         got = sum(v << (32 * j) for j, v in enumerate(words[624 * k:624 * (k + 1)]))
-        assert got == g, k
-        g = m.polymod(m.polysqr_mod(g, phi) << 1, phi)
+        assert got == m.x_pow_mod(e * (1 << seg) - 1, phi), k
 
 
 def test_glibc_log_restatement_is_the_hosts_log():
