@@ -794,7 +794,7 @@ zig_tile_kernel(long nblk, long ntile, const unsigned *__restrict__ fun, const u
 __global__ void __launch_bounds__(ZIG_TOP_T)
 zig_top_kernel(long nblk, long ntile, const unsigned *__restrict__ fun, const ulonglong2 *__restrict__ patch,
                unsigned patch_cap, const uint4 *__restrict__ tile_fun, unsigned long long ord0,
-               ulonglong2 *__restrict__ tile_entry, zig_status *st) {
+               ulonglong2 *__restrict__ tile_entry, zig_status *st, int force_serial) {
     constexpr int T = ZIG_TOP_T;
     __shared__ unsigned g_k[T][2];
     __shared__ unsigned long long g_c[T][2];
@@ -825,7 +825,63 @@ zig_top_kernel(long nblk, long ntile, const unsigned *__restrict__ fun, const ul
         g_c[t][e] = o;
     }
     __syncthreads();
-    if (t == 0) {
+    // The T thread functions are composed by ONE wave in three short steps (round 6; a single thread walking all T entries -
+    // 1024 dependent LDS reads - was 0.25 ms of the 0.35 ms scan): lane L composes its T / 64 consecutive entries for both
+    // entries k, the 64 lane functions are chained through readlane, every lane walks its entries again with its true
+    // (k, ordinal).  An exit k >= 2 anywhere (a tail sample across a thread's boundary: ~15 % of the cfg-3 streams have
+    // one) has no table entry: the serial walk below, which evaluates such tiles block by block, takes over.
+    __shared__ int s_serial;
+    if (t == 0) s_serial = 0;
+    __syncthreads();
+    if (t < 64) {
+        constexpr int PER = T / 64;
+        unsigned fk[2];
+        unsigned long long fc[2];
+        bool bad = false;
+        for (int e = 0; e < 2; e++) {
+            unsigned k = e;
+            unsigned long long c = 0;
+            for (int i = t * PER; i < (t + 1) * PER; i++) {
+                if (k >= 2) {
+                    bad = true;
+                    break;
+                }
+                c += g_c[i][k];
+                k = g_k[i][k];
+            }
+            fk[e] = k;
+            fc[e] = c;
+            bad = bad || k >= 2;
+        }
+        if (__any(bad) || force_serial) {
+            if (t == 0) s_serial = 1;
+        } else {
+            unsigned k = 0, my_k = 0;
+            unsigned long long o = ord0, my_o = 0;
+            for (int L = 0; L < 64; L++) {
+                if (t == L) {
+                    my_k = k;
+                    my_o = o;
+                }
+                const unsigned k0 = readlane32(fk[0], L), k1 = readlane32(fk[1], L);
+                const unsigned long long c0 = readlane64(fc[0], L), c1 = readlane64(fc[1], L);
+                o += k ? c1 : c0;
+                k = k ? k1 : k0;
+            }
+            if (t == 0) {
+                st->total = o;
+                st->k_last = k;
+            }
+            for (int i = t * PER; i < (t + 1) * PER; i++) {
+                s_k[i] = my_k;
+                s_o[i] = my_o;
+                my_o += g_c[i][my_k];
+                my_k = g_k[i][my_k];
+            }
+        }
+    }
+    __syncthreads();
+    if (s_serial && t == 0) {
         unsigned k = 0;
         unsigned long long o = ord0;
         for (int i = 0; i < T; i++) {
@@ -1593,8 +1649,9 @@ static int zig_round_count_scan(corahip_ctx *ctx, hipStream_t stream, const uint
         const unsigned tgrid = (unsigned)((rd.ntile + 3) / 4);
         zig_tile_kernel<<<tgrid, 256, 0, stream>>>(rd.nblk, rd.ntile, rd.fun, rd.patch, rd.patch_cap, rd.tile_fun, rd.st);
         LAUNCH_CHECK();
+        const char *fs = getenv("CORAHIP_ZIG_TOP_SERIAL");       // (tests: the serial walk that takes over when a thread hands on k >= 2)
         zig_top_kernel<<<1, ZIG_TOP_T, 0, stream>>>(rd.nblk, rd.ntile, rd.fun, rd.patch, rd.patch_cap, rd.tile_fun, ord0, rd.tile_entry,
-                                                   rd.st);
+                                                   rd.st, fs && atoi(fs) ? 1 : 0);
         LAUNCH_CHECK();
         zig_entry_kernel<<<tgrid, 256, 0, stream>>>(rd.nblk, rd.ntile, rd.fun, rd.patch, rd.patch_cap, rd.tile_entry, rd.entry, rd.st);
         LAUNCH_CHECK();

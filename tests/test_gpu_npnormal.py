@@ -83,6 +83,23 @@ def test_device_exp_of_the_wedge_test_is_the_hosts_exp(ctx):
     assert np.array_equal(y.view(np.uint64), ref.view(np.uint64)), int((y != ref).sum())
 
 
+def test_serial_walk_of_the_top_scan_is_numpys_too(ctx, monkeypatch):
+    """The top level of the two-pass generator's scan composes its 1024 thread functions by one wave (round 6); a stream in
+    which a thread hands k >= 2 to its successor (a tail sample across the boundary: ~15 % of the cfg-3 streams) falls back to
+    the serial walk - forced here (CORAHIP_ZIG_TOP_SERIAL=1), so that the fall-back is exercised whatever the seeds do."""
+    monkeypatch.setenv("CORAHIP_ZIG_TOP_SERIAL", "1")
+    for n in (5, 100003, 20_000_003):
+        rng = np.random.default_rng(900 + n)
+        dev, state_after = _device_stream(ctx, rng, n)
+        ref = rng.standard_normal(n)
+        same = dev.view(np.uint64) == ref.view(np.uint64)
+        if not same.all():
+            bad = np.flatnonzero(~same)
+            ulp = np.abs(dev.view(np.int64)[bad] - ref.view(np.int64)[bad])
+            assert np.all(np.abs(ref[bad]) > ZIG_R) and ulp.max() <= 1, (bad[:5], ulp.max())
+        assert state_after == int(rng.bit_generator.state["state"]["state"])
+
+
 @pytest.mark.parametrize("n", [1, 65, 1024, 4097, 100003, 3 * 4096 * 64 + 5, 30_000_011])
 def test_single_pass_form_is_numpys_too(ctx, monkeypatch, n):
     """The round-6 single pass (classify + chained scan with decoupled look-back + emit in ONE launch,
