@@ -361,7 +361,16 @@ def main():
         import hashlib
 
         for tag, mk in (("CHECKSUM_SEEDED", lambda: np.random.default_rng(77)), ("CHECKSUM_LEGACY", lambda: np.random.seed(78))):
-            m = shard.realise_numpy(mk(), cold_factors()).cpu().numpy()
+            g = mk()
+            # (the generator started ahead of the factors, as the timed seeded legs run it - where the shard offers it)
+            prep = shard.prepare_numpy(g) if hasattr(shard, "prepare_numpy") else None
+            try:
+                fac = cold_factors()
+            except BaseException:
+                if prep is not None:
+                    prep.abort()
+                raise
+            m = (shard.realise_numpy(g, fac, prepared=prep) if prep is not None else shard.realise_numpy(g, fac)).cpu().numpy()
             hs = [hashlib.sha1(m[i].tobytes()).hexdigest() for i in range(m.shape[0])]
             if dist is not None:
                 parts = [None] * world
